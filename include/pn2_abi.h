@@ -1,0 +1,155 @@
+/*
+ * pn2_abi.h -- C ABI of libpn2_hip.so: the MI355X (gfx950) drop-in for the
+ * PointNet++ SA/FP custom ops of isl-org/Open3D-PointNet2-Semantic3D.
+ *
+ * Every entry point replaces one reference launcher / CPU op; dimension and
+ * pointer order are kept identical to the reference launcher it replaces so the
+ * mapping is auditable (reference file:line cited per function).  Differences
+ * from the reference launchers, all deliberate:
+ *   - extern "C", returns int (0 = ok, <0 = PN2_E* argument error, >0 = hipError_t
+ *     from the launch) instead of void-with-no-error-check;
+ *   - explicit stream (a hipStream_t passed as void*; NULL = the HIP null stream)
+ *     instead of the legacy default stream (tf_grouping.cu:141 etc.);
+ *   - gradient outputs are zero-filled by the callee with a stream-ordered
+ *     memset (the reference does it in the TF op glue: tf_sampling.cpp:236,
+ *     tf_grouping.cpp:271, tf_interpolate.cpp:477).
+ *
+ * Conventions: all tensors dense row-major contiguous DEVICE memory; float =
+ * IEEE fp32; indices int32.  The caller owns every buffer (outputs and scratch);
+ * the library never allocates, never synchronises and keeps no pointers.
+ * Re-entrant; safe from several host threads on different streams.
+ */
+#ifndef PN2_ABI_H_
+#define PN2_ABI_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PN2_ABI_VERSION 1
+
+/* error codes (negative); positive return values are hipError_t */
+#define PN2_OK 0
+#define PN2_EINVAL (-1)  /* non-positive dimension / bad attribute            */
+#define PN2_ENULL (-2)   /* required pointer is NULL                          */
+#define PN2_ERANGE (-3)  /* dimension exceeds what the kernel supports        */
+#define PN2_EUNSUP (-4)  /* unsupported configuration (e.g. channel widths)   */
+
+/* squared-distance arithmetic, see DESIGN.md "Arithmetic modes".  The reference
+ * CUDA build leaves nvcc's --fmad=true default on (tf_ops/CMakeLists.txt:5,13). */
+#define PN2_ARITH_STRICT 0  /* (dx*dx + dy*dy) + dz*dz, each op rounded        */
+#define PN2_ARITH_FMA 1     /* fma(dz,dz, fma(dx,dx, dy*dy))  (default)        */
+#define PN2_ARITH_FMA_ALT 2 /* fma(dz,dz, fma(dy,dy, dx*dx))                   */
+
+int pn2_abi_version(void);
+const char *pn2_build_info(void);     /* "gfx950 ..." static string */
+const char *pn2_strerror(int code);   /* static string for PN2_E* / hipError_t */
+
+/* ---- sampling (replaces tf_ops/tf_sampling.cu) --------------------------- */
+
+/* farthestpointsamplingLauncher(b,n,m,inp,temp,out)  tf_sampling.cu:218-221,
+ * declared tf_sampling.cpp:114.  inp (b,n,3) -> out (b,m) int32; first pick is
+ * index 0; tie-break (max dist, k mod 512, k) exactly as the 512-thread
+ * reference block produces.  `temp` is the reference's (32,n) float scratch: it
+ * is only used when n > PN2_FPS_MAX_REG_POINTS (then it must hold
+ * min(b,32)*n floats); may be NULL otherwise.  Requires m >= 1. */
+#define PN2_FPS_MAX_REG_POINTS 16384
+int pn2_farthest_point_sample(int b, int n, int m, const float *inp, float *temp,
+                              int *out, int arith_mode, void *stream);
+
+/* gatherpointLauncher(b,n,m,inp,idx,out)  tf_sampling.cu:222-225, tf_sampling.cpp:158 */
+int pn2_gather_point(int b, int n, int m, const float *inp, const int *idx,
+                     float *out, void *stream);
+
+/* scatteraddpointLauncher(b,n,m,out_g,idx,inp_g)  tf_sampling.cu:226-229,
+ * tf_sampling.cpp:195.  inp_g (b,n,3) is zeroed by the callee first. */
+int pn2_gather_point_grad(int b, int n, int m, const float *out_g, const int *idx,
+                          float *inp_g, void *stream);
+
+/* ---- grouping (replaces tf_ops/tf_grouping.cu) --------------------------- */
+
+/* queryBallPointLauncher(b,n,m,radius,nsample,xyz1,xyz2,idx,pts_cnt)
+ * tf_grouping.cu:138-144, tf_grouping.cpp:72.  xyz1 (b,n,3) dataset, xyz2
+ * (b,m,3) queries -> idx (b,m,nsample), pts_cnt (b,m).  First nsample hits in
+ * index order with max(sqrtf(d2),1e-20f) < radius; short rows padded with the
+ * first hit.  Rows with no hit: idx row = 0, pts_cnt = 0 (the reference leaves
+ * the row uninitialised; unreachable when queries are dataset points). */
+int pn2_query_ball_point(int b, int n, int m, float radius, int nsample,
+                         const float *xyz1, const float *xyz2, int *idx,
+                         int *pts_cnt, int arith_mode, void *stream);
+
+/* groupPointLauncher(b,n,c,m,nsample,points,idx,out)  tf_grouping.cu:150-154,
+ * tf_grouping.cpp:178.  out (b,m,nsample,c). */
+int pn2_group_point(int b, int n, int c, int m, int nsample, const float *points,
+                    const int *idx, float *out, void *stream);
+
+/* groupPointGradLauncher(b,n,c,m,nsample,grad_out,idx,grad_points)
+ * tf_grouping.cu:155-162, tf_grouping.cpp:220.  grad_points (b,n,c) zeroed first. */
+int pn2_group_point_grad(int b, int n, int c, int m, int nsample,
+                         const float *grad_out, const int *idx, float *grad_points,
+                         void *stream);
+
+/* ---- interpolation (replaces the CPU ops of tf_ops/tf_interpolate.cpp) --- */
+
+/* threenn_cpu(b,n,m,xyz1,xyz2,dists,indices)  tf_interpolate.cpp:213-243.
+ * xyz1 (b,n,3) unknown, xyz2 (b,m,3) known, m >= 3 -> dist (b,n,3) squared L2
+ * ascending (computed in float64 like the reference's KD-tree), idx (b,n,3);
+ * ties -> lowest index. */
+int pn2_three_nn(int b, int n, int m, const float *xyz1, const float *xyz2,
+                 float *dist, int *idx, void *stream);
+
+/* threeinterpolate_cpu(b,m,c,n,points,idx,weight,out)  tf_interpolate.cpp:307-330 */
+int pn2_three_interpolate(int b, int m, int c, int n, const float *points,
+                          const int *idx, const float *weight, float *out,
+                          void *stream);
+
+/* threeinterpolate_grad_cpu(b,n,c,m,grad_out,idx,weight,grad_points)
+ * tf_interpolate.cpp:397-421.  grad_points (b,m,c) zeroed first. */
+int pn2_three_interpolate_grad(int b, int n, int c, int m, const float *grad_out,
+                               const int *idx, const float *weight,
+                               float *grad_points, void *stream);
+
+/* ---- fused layer kernels (new: no reference kernel; they replace the TF
+ *      sub-graphs of util/pointnet_util.py:44-54,150-170 and :300-325) ------- */
+
+/* One dense layer of the shared MLP with the BatchNorm folded in (inference):
+ *   y = relu?( x @ W + bias )           x (rows,cin)  W (cin,cout)  y (rows,cout)
+ * optionally followed by a max over each consecutive group of `pool` rows
+ * (pool = nsample reproduces tf.reduce_max over K, pointnet_util.py:167-170;
+ * pool <= 1 = no pooling; otherwise pool must be 32 or a multiple of 32 ... see
+ * DESIGN.md).  y is (rows/pool, cout) when pooling.  fp32 MFMA, exact-f32
+ * products, fp32 accumulation. */
+int pn2_linear(int rows, int cin, int cout, const float *x, const float *w,
+               const float *bias, int relu, int pool, float *y, void *stream);
+
+/* Fused set-abstraction MLP (pointnet_util.py:43-54 + :150-170, inference BN
+ * folded): for every (b, j) group gathers nsample neighbours by idx, builds
+ * [xyz[idx]-new_xyz | points[idx]] (xyz first, pointnet_util.py:52-54), runs up
+ * to 3 dense layers (+bias, ReLU) and max-pools over the neighbours without the
+ * grouped tensor ever reaching HBM.
+ *   xyz (b,n,3)  new_xyz (b,m,3)  points (b,n,c) or NULL (c = 0)  idx (b,m,nsample)
+ *   w[l] (cin_l, widths[l]) row-major with cin_0 = 3 + c;  bias[l] (widths[l])
+ *   out (b,m,widths[nlayers-1])
+ * Constraints: nsample == 32, 1 <= nlayers <= 3, widths multiples of 32, <= 128
+ * (returns PN2_EUNSUP otherwise: callers fall back to pn2_group_point + pn2_linear). */
+int pn2_sa_mlp_max_fused(int b, int n, int m, int nsample, int c, const float *xyz,
+                         const float *new_xyz, const float *points, const int *idx,
+                         int nlayers, const int *widths, const float *const *w,
+                         const float *const *bias, float *out, void *stream);
+
+/* Fused feature-propagation front end (pointnet_util.py:300-311):
+ *   weight = (1/max(dist,1e-10)) / sum(1/max(dist,1e-10));
+ *   out[b,j,:] = [ sum_i weight_i * points2[b,idx_i,:]  |  points1[b,j,:] ]
+ * i.e. three_interpolate + concat (interpolated FIRST) in one pass.
+ *   dist,idx (b,n,3)  points2 (b,m,c2)  points1 (b,n,c1) or NULL -> out (b,n,c2+c1) */
+int pn2_fp_interp_concat(int b, int n, int m, int c1, int c2, const float *dist,
+                         const int *idx, const float *points1, const float *points2,
+                         float *out, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PN2_ABI_H_ */

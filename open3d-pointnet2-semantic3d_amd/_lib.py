@@ -1,0 +1,132 @@
+"""ctypes binding of libpn2_hip.so (the C ABI declared in include/pn2_abi.h).
+
+There is deliberately NO fallback: if the HIP library cannot be loaded the
+import fails loudly.  The library must be loaded after `import torch` so that it
+binds to the HIP runtime torch already mapped (same soname libamdhip64.so.7);
+tensors and streams are then shared with torch without copies.
+"""
+import ctypes
+import os
+
+import torch  # noqa: F401  (must precede CDLL: maps torch's libamdhip64.so.7)
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libpn2_hip.so")
+
+c_int, c_float, c_void_p = ctypes.c_int, ctypes.c_float, ctypes.c_void_p
+
+# name -> argtypes, in the order of include/pn2_abi.h
+SIGNATURES = {
+    "pn2_farthest_point_sample": [c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_int, c_void_p],
+    "pn2_gather_point": [c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p],
+    "pn2_gather_point_grad": [c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p],
+    "pn2_query_ball_point": [c_int, c_int, c_int, c_float, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p],
+    "pn2_group_point": [c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p],
+    "pn2_group_point_grad": [c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p],
+    "pn2_three_nn": [c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p],
+    "pn2_three_interpolate": [c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p],
+    "pn2_three_interpolate_grad": [c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p],
+    "pn2_linear": [c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p],
+    "pn2_sa_mlp_max_fused": [c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p,
+                             c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p],
+    "pn2_fp_interp_concat": [c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p,
+                             c_void_p, c_void_p],
+    "pn2_sa_group_concat": [c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p,
+                            c_void_p, c_void_p],
+}
+PN2_EUNSUP = -4
+
+
+class Pn2Error(RuntimeError):
+    pass
+
+
+def _load():
+    if not os.path.exists(LIB_PATH):
+        # build in-tree with hipcc (cross-compiles without a GPU); never fall back to CPU code
+        from . import build as _build
+        _build.build()
+    try:
+        lib = ctypes.CDLL(LIB_PATH)
+    except OSError as e:  # pragma: no cover
+        raise ImportError("cannot load the HIP extension %s: %s -- there is no CPU fallback; "
+                          "build it with `python open3d-pointnet2-semantic3d_amd/build.py`" % (LIB_PATH, e))
+    for name, argtypes in SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError if the ABI and the library disagree
+        fn.argtypes = argtypes
+        fn.restype = c_int
+    lib.pn2_abi_version.restype = c_int
+    lib.pn2_build_info.restype = ctypes.c_char_p
+    lib.pn2_strerror.restype = ctypes.c_char_p
+    lib.pn2_strerror.argtypes = [c_int]
+    if lib.pn2_abi_version() != 1:
+        raise ImportError("libpn2_hip.so ABI version mismatch")
+    return lib
+
+
+_raw = _load()
+
+
+class _LibProxy:
+    """Attribute proxy over the ctypes library.  When `trace` is a list, every pn2_* launch is
+    bracketed by two events on torch's current stream (the stream the kernel is launched on) and
+    (name, numeric_args, start_event, end_event) is appended -- bench.py derives per-kernel durations
+    and roofline numbers from it.  With trace=None (default) calls go straight through."""
+
+    def __init__(self, raw):
+        self._raw = raw
+        self.trace = None
+
+    def __getattr__(self, name):
+        fn = getattr(self._raw, name)
+        if name not in SIGNATURES:
+            return fn
+
+        def call(*args):
+            if self.trace is None:
+                return fn(*args)
+            s = torch.cuda.Event(enable_timing=True)
+            e = torch.cuda.Event(enable_timing=True)
+            s.record()
+            rc = fn(*args)
+            e.record()
+            ints = [a for a in args if isinstance(a, (int, float))]
+            if name == "pn2_sa_mlp_max_fused":  # decode the host-side widths[] array for flop accounting
+                wp = ctypes.cast(args[10], ctypes.POINTER(c_int))
+                ints += [wp[i] for i in range(args[9])]
+            self.trace.append((name, tuple(ints), s, e))
+            return rc
+
+        call.__name__ = name
+        setattr(self, name, call)  # cache
+        return call
+
+
+lib = _LibProxy(_raw)
+
+
+def strerror(code):
+    return lib.pn2_strerror(int(code)).decode()
+
+
+def check(code, what):
+    if code != 0:
+        raise Pn2Error("%s failed: %s (code %d)" % (what, strerror(code), code))
+
+
+def ptr(t):
+    """device pointer of a tensor (None -> NULL)."""
+    return None if t is None else c_void_p(t.data_ptr())
+
+
+def stream_ptr():
+    return c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def require_cuda(*tensors):
+    for t in tensors:
+        if t is None:
+            continue
+        if not t.is_cuda:
+            raise ValueError("pn2 ops run on the MI355X only: got a %s tensor (there is no CPU path in the "
+                             "product; the CPU oracle lives under oracle/ for tests)" % t.device)

@@ -1,0 +1,72 @@
+// pn2_common.h -- shared device helpers for the gfx950 (CDNA4, wave64) kernels.
+// The library is compiled with -ffp-contract=off: every fused multiply-add in
+// these kernels is an explicit __builtin_fmaf / MFMA, never a compiler choice.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/pn2_abi.h"
+
+#define PN2_WAVE 64
+
+#define PN2_RETURN_IF_LAUNCH_FAILED()                 \
+    do {                                              \
+        hipError_t e__ = hipGetLastError();           \
+        if (e__ != hipSuccess) return (int)e__;       \
+    } while (0)
+
+// Squared distance exactly as the reference expression
+//   (x2-x1)*(x2-x1) + (y2-y1)*(y2-y1) + (z2-z1)*(z2-z1)
+// (tf_sampling.cu:149-150, tf_grouping.cu:28-30) under the three contraction
+// hypotheses of pn2_abi.h.  dx/dy/dz are already-rounded differences.
+template <int MODE>
+__device__ __forceinline__ float pn2_sqdist(float dx, float dy, float dz) {
+    if constexpr (MODE == PN2_ARITH_FMA) {
+        return __builtin_fmaf(dz, dz, __builtin_fmaf(dx, dx, dy * dy));
+    } else if constexpr (MODE == PN2_ARITH_FMA_ALT) {
+        return __builtin_fmaf(dz, dz, __builtin_fmaf(dy, dy, dx * dx));
+    } else {
+        return (dx * dx + dy * dy) + dz * dz;  // -ffp-contract=off keeps these separate
+    }
+}
+
+// ---- wave64 DPP reductions (result broadcast through an SGPR) -------------
+// row_shr:n = 0x110+n, row_bcast:15 = 0x142, row_bcast:31 = 0x143 (gfx9 DPP).
+// old == src and bound_ctrl=false: lanes without a valid source keep their value.
+#define PN2_DPP_U32(v, ctrl, rmask) \
+    ((unsigned)__builtin_amdgcn_update_dpp((int)(v), (int)(v), (ctrl), (rmask), 0xF, false))
+
+__device__ __forceinline__ unsigned pn2_wave_umax(unsigned v) {
+    unsigned t;
+    t = PN2_DPP_U32(v, 0x111, 0xF); v = v > t ? v : t;
+    t = PN2_DPP_U32(v, 0x112, 0xF); v = v > t ? v : t;
+    t = PN2_DPP_U32(v, 0x114, 0xF); v = v > t ? v : t;
+    t = PN2_DPP_U32(v, 0x118, 0xF); v = v > t ? v : t;
+    t = PN2_DPP_U32(v, 0x142, 0xA); v = v > t ? v : t;
+    t = PN2_DPP_U32(v, 0x143, 0xC); v = v > t ? v : t;
+    return (unsigned)__builtin_amdgcn_readlane((int)v, 63);
+}
+
+// max of a 64-bit key over the 16 lanes of row 0; result (uniform) from lane 15.
+#define PN2_U64MAX_STEP(v, ctrl)                                        \
+    do {                                                                \
+        unsigned lo__ = (unsigned)(v), hi__ = (unsigned)((v) >> 32);    \
+        unsigned tlo__ = PN2_DPP_U32(lo__, (ctrl), 0xF);                \
+        unsigned thi__ = PN2_DPP_U32(hi__, (ctrl), 0xF);                \
+        unsigned long long t__ = ((unsigned long long)thi__ << 32) | tlo__; \
+        (v) = t__ > (v) ? t__ : (v);                                    \
+    } while (0)
+
+__device__ __forceinline__ unsigned long long pn2_row0_u64max(unsigned long long v) {
+    PN2_U64MAX_STEP(v, 0x111);
+    PN2_U64MAX_STEP(v, 0x112);
+    PN2_U64MAX_STEP(v, 0x114);
+    PN2_U64MAX_STEP(v, 0x118);
+    unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)v, 15);
+    unsigned hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(v >> 32), 15);
+    return ((unsigned long long)hi << 32) | lo;
+}
+
+__device__ __forceinline__ int pn2_lane_id() {
+    return (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+}

@@ -1,0 +1,238 @@
+// pn2_grouping.hip -- ball query, group_point and its gradient for gfx950.
+// MI355X-native replacements for tf_ops/tf_grouping.cu:3-90 (reference).
+//
+// Ball query: the reference runs ONE 256-thread block per batch element with a
+// serial per-thread scan (tf_grouping.cu:138-144).  Here one wave64 owns QPW
+// queries: it streams the dataset 64 candidates at a time (one per lane, reused
+// for all QPW queries), tests them with a wave ballot, and appends hits in lane
+// order == index order with an mbcnt prefix count, so "the FIRST nsample points
+// in the ball" (tf_grouping.cu:20-21) is preserved exactly.  The per-candidate
+// sqrtf of the reference is replaced by an exactly equivalent threshold on the
+// squared distance, computed on the host (see ball_threshold()).
+//
+// group_point: a row copy out[b,j,k,:] = points[b,idx[b,j,k],:]; HBM-bound, the
+// (b,m,nsample,c) write dominates.  16-byte lanes along c, rows contiguous per
+// wave, non-temporal stores so the gathered `points` stay L2-resident.
+#include <math.h>
+
+#include "pn2_common.h"
+
+namespace {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+// Largest float T with  max(sqrtf(T), 1e-20f) < radius  (sqrtf correctly rounded,
+// hence monotone): for every s >= 0, (s <= T) <=> the reference predicate
+// tf_grouping.cu:28-31.  Returns -1 when nothing can match.
+float ball_threshold(float radius) {
+    if (!(radius > 1e-20f)) return -1.0f;
+    auto pred = [radius](float s) { return sqrtf(s) < radius; };
+    float t = radius * radius;
+    if (!(t <= 3.402823466e38f)) t = 3.402823466e38f;
+    while (!pred(t)) t = nextafterf(t, -INFINITY);
+    for (;;) {
+        const float u = nextafterf(t, INFINITY);
+        if (!(u <= 3.402823466e38f) || !pred(u)) break;
+        t = u;
+    }
+    return t;
+}
+
+constexpr int kBqThreads = 256;
+constexpr int kBqWaves = kBqThreads / 64;
+
+template <int MODE, int QPW>
+__global__ void __launch_bounds__(kBqThreads)
+ball_query_kernel(int n, int m, float thr, int nsample, const float* __restrict__ xyz1_all,
+                  const float* __restrict__ xyz2_all, int* __restrict__ idx_all,
+                  int* __restrict__ cnt_all) {
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int bi = blockIdx.y;
+    const int q0 = (blockIdx.x * kBqWaves + wave) * QPW;
+    if (q0 >= m) return;  // wave-uniform; the kernel has no barriers
+    const float* __restrict__ xyz1 = xyz1_all + (size_t)bi * n * 3;
+    const float* __restrict__ xyz2 = xyz2_all + (size_t)bi * m * 3;
+    int* __restrict__ idx = idx_all + ((size_t)bi * m + q0) * nsample;
+    int* __restrict__ cnt_out = cnt_all + (size_t)bi * m + q0;
+
+    float qx[QPW], qy[QPW], qz[QPW];
+    int cnt[QPW], first[QPW];
+#pragma unroll
+    for (int q = 0; q < QPW; ++q) {
+        const int jq = q0 + q < m ? q0 + q : m - 1;
+        qx[q] = __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(xyz2[jq * 3 + 0])));
+        qy[q] = __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(xyz2[jq * 3 + 1])));
+        qz[q] = __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(xyz2[jq * 3 + 2])));
+        cnt[q] = q0 + q < m ? 0 : nsample;  // out-of-range queries are "already full"
+        first[q] = 0;
+    }
+
+    // software prefetch of the next 64 candidates
+    int k = lane;
+    float cx = 0.f, cy = 0.f, cz = 0.f;
+    if (k < n) { cx = xyz1[k * 3 + 0]; cy = xyz1[k * 3 + 1]; cz = xyz1[k * 3 + 2]; }
+    for (int c0 = 0; c0 < n; c0 += 64) {
+        const int kn = c0 + 64 + lane;
+        float nx = 0.f, ny = 0.f, nz = 0.f;
+        if (kn < n) { nx = xyz1[kn * 3 + 0]; ny = xyz1[kn * 3 + 1]; nz = xyz1[kn * 3 + 2]; }
+        const bool valid = k < n;
+        bool all_full = true;
+#pragma unroll
+        for (int q = 0; q < QPW; ++q) {
+            if (cnt[q] < nsample) {  // wave-uniform (tf_grouping.cu:20-21)
+                const float s = pn2_sqdist<MODE>(qx[q] - cx, qy[q] - cy, qz[q] - cz);
+                const bool hit = valid && (s <= thr);
+                const unsigned long long mask = __ballot(hit);
+                if (mask != 0ull) {
+                    const int pos = cnt[q] + (int)__builtin_amdgcn_mbcnt_hi(
+                                                 (unsigned)(mask >> 32),
+                                                 __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0u));
+                    if (hit && pos < nsample) idx[q * nsample + pos] = k;
+                    if (cnt[q] == 0) first[q] = c0 + __ffsll((long long)mask) - 1;
+                    cnt[q] += __popcll(mask);
+                }
+                all_full = all_full && (cnt[q] >= nsample);
+            }
+        }
+        if (all_full) break;
+        k = kn; cx = nx; cy = ny; cz = nz;
+    }
+#pragma unroll
+    for (int q = 0; q < QPW; ++q) {
+        if (q0 + q < m) {
+            const int c = cnt[q] < nsample ? cnt[q] : nsample;
+            // short rows: remaining slots repeat the first hit (tf_grouping.cu:32-36);
+            // empty rows are zero-filled (documented divergence: reference leaves them uninitialised)
+            const int fill = c > 0 ? first[q] : 0;
+            for (int l = c + lane; l < nsample; l += 64) idx[q * nsample + l] = fill;
+            if (lane == 0) cnt_out[q] = c;  // tf_grouping.cu:41
+        }
+    }
+}
+
+template <int MODE>
+int launch_ball_query(int b, int n, int m, float thr, int nsample, const float* xyz1,
+                      const float* xyz2, int* idx, int* cnt, hipStream_t st) {
+    constexpr int QPW = 8;
+    dim3 grid((m + kBqWaves * QPW - 1) / (kBqWaves * QPW), b);
+    ball_query_kernel<MODE, QPW><<<grid, kBqThreads, 0, st>>>(n, m, thr, nsample, xyz1, xyz2, idx, cnt);
+    PN2_RETURN_IF_LAUNCH_FAILED();
+    return PN2_OK;
+}
+
+// ---- group_point -----------------------------------------------------------
+// grid.y = batch; e indexes the (m*nsample*c/VEC) vector elements of one batch.
+template <typename VT, int VEC>
+__global__ void __launch_bounds__(256)
+group_point_kernel(int n, int c, unsigned per_batch_rows, const float* __restrict__ points_all,
+                   const int* __restrict__ idx_all, float* __restrict__ out_all) {
+    const unsigned cv = (unsigned)c / VEC;
+    const unsigned total = per_batch_rows * cv;
+    const int bi = blockIdx.y;
+    const VT* __restrict__ points = reinterpret_cast<const VT*>(points_all + (size_t)bi * n * c);
+    const int* __restrict__ idx = idx_all + (size_t)bi * per_batch_rows;
+    VT* __restrict__ out = reinterpret_cast<VT*>(out_all + (size_t)bi * per_batch_rows * c);
+    const bool pow2 = (cv & (cv - 1)) == 0;
+    const unsigned sh = 31 - __builtin_clz(cv | 1u);
+    for (unsigned e = blockIdx.x * blockDim.x + threadIdx.x; e < total; e += gridDim.x * blockDim.x) {
+        unsigned row, col;
+        if (pow2) { row = e >> sh; col = e & (cv - 1); }
+        else { row = e / cv; col = e - row * cv; }
+        const int ii = idx[row];
+        const VT v = points[(size_t)ii * cv + col];
+        __builtin_nontemporal_store(v, &out[e]);
+    }
+}
+
+template <typename VT, int VEC>
+__global__ void __launch_bounds__(256)
+group_point_grad_kernel(int n, int c, unsigned per_batch_rows, const float* __restrict__ grad_out_all,
+                        const int* __restrict__ idx_all, float* __restrict__ grad_points_all) {
+    const unsigned cv = (unsigned)c / VEC;
+    const unsigned total = per_batch_rows * cv;
+    const int bi = blockIdx.y;
+    const VT* __restrict__ go = reinterpret_cast<const VT*>(grad_out_all + (size_t)bi * per_batch_rows * c);
+    const int* __restrict__ idx = idx_all + (size_t)bi * per_batch_rows;
+    float* __restrict__ gp = grad_points_all + (size_t)bi * n * c;
+    for (unsigned e = blockIdx.x * blockDim.x + threadIdx.x; e < total; e += gridDim.x * blockDim.x) {
+        const unsigned row = e / cv, col = e - row * cv;
+        const int ii = idx[row];
+        const VT v = go[e];
+        float* dst = gp + (size_t)ii * c + col * VEC;
+        if constexpr (VEC == 4) {
+            atomicAdd(dst + 0, v.x); atomicAdd(dst + 1, v.y);
+            atomicAdd(dst + 2, v.z); atomicAdd(dst + 3, v.w);
+        } else {
+            atomicAdd(dst, v);  // tf_grouping.cu:85-86
+        }
+    }
+}
+
+inline int grid_x_for(unsigned long long total, int block, int batches) {
+    unsigned long long g = (total + block - 1) / block;
+    unsigned long long cap = (256ull * 8 + batches - 1) / batches;  // ~8 blocks per CU overall
+    if (cap < 1) cap = 1;
+    if (g > cap) g = cap;
+    if (g < 1) g = 1;
+    return (int)g;
+}
+
+}  // namespace
+
+extern "C" int pn2_query_ball_point(int b, int n, int m, float radius, int nsample,
+                                    const float* xyz1, const float* xyz2, int* idx, int* pts_cnt,
+                                    int arith_mode, void* stream) {
+    if (b <= 0 || n <= 0 || m <= 0 || nsample <= 0) return PN2_EINVAL;
+    if (!(radius > 0.0f)) return PN2_EINVAL;  // tf_grouping.cpp:80-83 "expects positive radius"
+    if (!xyz1 || !xyz2 || !idx || !pts_cnt) return PN2_ENULL;
+    if ((long long)n * 3 > 0x7fffffffLL || (long long)m * 3 > 0x7fffffffLL || b > 65535) return PN2_ERANGE;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    const float thr = ball_threshold(radius);
+    switch (arith_mode) {
+        case PN2_ARITH_STRICT: return launch_ball_query<PN2_ARITH_STRICT>(b, n, m, thr, nsample, xyz1, xyz2, idx, pts_cnt, st);
+        case PN2_ARITH_FMA: return launch_ball_query<PN2_ARITH_FMA>(b, n, m, thr, nsample, xyz1, xyz2, idx, pts_cnt, st);
+        case PN2_ARITH_FMA_ALT: return launch_ball_query<PN2_ARITH_FMA_ALT>(b, n, m, thr, nsample, xyz1, xyz2, idx, pts_cnt, st);
+        default: return PN2_EINVAL;
+    }
+}
+
+extern "C" int pn2_group_point(int b, int n, int c, int m, int nsample, const float* points,
+                               const int* idx, float* out, void* stream) {
+    if (b <= 0 || n <= 0 || c <= 0 || m <= 0 || nsample <= 0) return PN2_EINVAL;
+    if (!points || !idx || !out) return PN2_ENULL;
+    const unsigned long long rows = (unsigned long long)m * nsample;
+    if (rows * (unsigned long long)c > 0xffffffffull || b > 65535) return PN2_ERANGE;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    const bool vec4 = (c % 4 == 0) && (((uintptr_t)points | (uintptr_t)out) % 16 == 0);
+    if (vec4) {
+        dim3 grid(grid_x_for(rows * (c / 4), 256, b), b);
+        group_point_kernel<f32x4, 4><<<grid, 256, 0, st>>>(n, c, (unsigned)rows, points, idx, out);
+    } else {
+        dim3 grid(grid_x_for(rows * c, 256, b), b);
+        group_point_kernel<float, 1><<<grid, 256, 0, st>>>(n, c, (unsigned)rows, points, idx, out);
+    }
+    PN2_RETURN_IF_LAUNCH_FAILED();
+    return PN2_OK;
+}
+
+extern "C" int pn2_group_point_grad(int b, int n, int c, int m, int nsample, const float* grad_out,
+                                    const int* idx, float* grad_points, void* stream) {
+    if (b <= 0 || n <= 0 || c <= 0 || m <= 0 || nsample <= 0) return PN2_EINVAL;
+    if (!grad_out || !idx || !grad_points) return PN2_ENULL;
+    const unsigned long long rows = (unsigned long long)m * nsample;
+    if (rows * (unsigned long long)c > 0xffffffffull || b > 65535) return PN2_ERANGE;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    hipError_t e = hipMemsetAsync(grad_points, 0, sizeof(float) * (size_t)b * n * c, st);
+    if (e != hipSuccess) return (int)e;
+    const bool vec4 = (c % 4 == 0) && ((uintptr_t)grad_out % 16 == 0);
+    if (vec4) {
+        dim3 grid(grid_x_for(rows * (c / 4), 256, b), b);
+        group_point_grad_kernel<f32x4, 4><<<grid, 256, 0, st>>>(n, c, (unsigned)rows, grad_out, idx, grad_points);
+    } else {
+        dim3 grid(grid_x_for(rows * c, 256, b), b);
+        group_point_grad_kernel<float, 1><<<grid, 256, 0, st>>>(n, c, (unsigned)rows, grad_out, idx, grad_points);
+    }
+    PN2_RETURN_IF_LAUNCH_FAILED();
+    return PN2_OK;
+}

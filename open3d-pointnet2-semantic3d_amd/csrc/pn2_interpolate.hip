@@ -1,0 +1,223 @@
+// pn2_interpolate.hip -- three_nn, three_interpolate (+grad) and the fused FP
+// front end for gfx950.  MI355X-native replacements for the CPU-only ops of
+// tf_ops/tf_interpolate.cpp:213-243,307-330,397-421 (which bounce every FP layer
+// GPU->host->GPU in the reference) and of util/pointnet_util.py:300-311.
+//
+// three_nn computes in float64 exactly like the reference's KD-tree
+// (tf_interpolate.cpp:20-28: points widened to Eigen::Vector3d; FLANN L2<double>
+// accumulates ((0+dx*dx)+dy*dy)+dz*dz), brute force: the known points of a batch
+// element are staged in LDS as doubles and broadcast-read by a thread-per-query
+// scan.  Bound: fp64 VALU, not HBM.
+#include <math.h>
+
+#include "pn2_common.h"
+
+namespace {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int kNnThreads = 256;
+constexpr int kNnTile = 2048;  // known points per LDS tile: 2048*3*8 = 48 KiB
+
+__global__ void __launch_bounds__(kNnThreads)
+three_nn_kernel(int n, int m, const float* __restrict__ xyz1_all,
+                const float* __restrict__ xyz2_all, float* __restrict__ dist_all,
+                int* __restrict__ idx_all) {
+    __shared__ double sref[kNnTile * 3];
+    const int bi = blockIdx.y;
+    const int j = blockIdx.x * kNnThreads + threadIdx.x;
+    const float* __restrict__ xyz1 = xyz1_all + (size_t)bi * n * 3;
+    const float* __restrict__ xyz2 = xyz2_all + (size_t)bi * m * 3;
+    const bool active = j < n;
+    double qx = 0, qy = 0, qz = 0;
+    if (active) { qx = xyz1[j * 3 + 0]; qy = xyz1[j * 3 + 1]; qz = xyz1[j * 3 + 2]; }
+    double b1 = INFINITY, b2 = INFINITY, b3 = INFINITY;
+    int i1 = 0, i2 = 0, i3 = 0;
+    for (int t0 = 0; t0 < m; t0 += kNnTile) {
+        const int tn = m - t0 < kNnTile ? m - t0 : kNnTile;
+        __syncthreads();
+        for (int e = threadIdx.x; e < tn * 3; e += kNnThreads) sref[e] = (double)xyz2[t0 * 3 + e];
+        __syncthreads();
+        if (active) {
+            for (int k = 0; k < tn; ++k) {
+                const double dx = qx - sref[k * 3 + 0];
+                const double dy = qy - sref[k * 3 + 1];
+                const double dz = qz - sref[k * 3 + 2];
+                const double d = (dx * dx + dy * dy) + dz * dz;  // contraction is off
+                if (d < b3) {  // strict: ties keep the lower index (ascending k)
+                    const int kk = t0 + k;
+                    if (d < b1) { b3 = b2; i3 = i2; b2 = b1; i2 = i1; b1 = d; i1 = kk; }
+                    else if (d < b2) { b3 = b2; i3 = i2; b2 = d; i2 = kk; }
+                    else { b3 = d; i3 = kk; }
+                }
+            }
+        }
+    }
+    if (active) {
+        const size_t o = ((size_t)bi * n + j) * 3;
+        dist_all[o + 0] = (float)b1; dist_all[o + 1] = (float)b2; dist_all[o + 2] = (float)b3;
+        idx_all[o + 0] = i1; idx_all[o + 1] = i2; idx_all[o + 2] = i3;
+    }
+}
+
+// out[row, :] = (p1*w1 + p2*w2) + p3*w3, unfused fp32 (tf_interpolate.cpp:322-324).
+// grid.y = batch, e indexes the n*c/VEC vector elements of one batch element.
+template <typename VT, int VEC>
+__global__ void __launch_bounds__(256)
+three_interpolate_kernel(int m, int c, int n, const float* __restrict__ points_all,
+                         const int* __restrict__ idx_all, const float* __restrict__ weight_all,
+                         float* __restrict__ out_all) {
+    const unsigned cv = (unsigned)c / VEC;
+    const unsigned total = (unsigned)n * cv;
+    const int bi = blockIdx.y;
+    const VT* __restrict__ pts = reinterpret_cast<const VT*>(points_all + (size_t)bi * m * c);
+    const int* __restrict__ idx = idx_all + (size_t)bi * n * 3;
+    const float* __restrict__ w = weight_all + (size_t)bi * n * 3;
+    VT* __restrict__ out = reinterpret_cast<VT*>(out_all + (size_t)bi * n * c);
+    for (unsigned e = blockIdx.x * blockDim.x + threadIdx.x; e < total; e += gridDim.x * blockDim.x) {
+        const unsigned row = e / cv, col = e - row * cv;
+        const int i1 = idx[row * 3 + 0], i2 = idx[row * 3 + 1], i3 = idx[row * 3 + 2];
+        const float w1 = w[row * 3 + 0], w2 = w[row * 3 + 1], w3 = w[row * 3 + 2];
+        const VT p1 = pts[(size_t)i1 * cv + col], p2 = pts[(size_t)i2 * cv + col], p3 = pts[(size_t)i3 * cv + col];
+        out[e] = (p1 * w1 + p2 * w2) + p3 * w3;
+    }
+}
+
+template <typename VT, int VEC>
+__global__ void __launch_bounds__(256)
+three_interpolate_grad_kernel(int n, int c, int m, const float* __restrict__ grad_out_all,
+                              const int* __restrict__ idx_all, const float* __restrict__ weight_all,
+                              float* __restrict__ grad_points_all) {
+    const unsigned cv = (unsigned)c / VEC;
+    const unsigned total = (unsigned)n * cv;
+    const int bi = blockIdx.y;
+    const VT* __restrict__ go = reinterpret_cast<const VT*>(grad_out_all + (size_t)bi * n * c);
+    const int* __restrict__ idx = idx_all + (size_t)bi * n * 3;
+    const float* __restrict__ w = weight_all + (size_t)bi * n * 3;
+    float* __restrict__ gp = grad_points_all + (size_t)bi * m * c;
+    for (unsigned e = blockIdx.x * blockDim.x + threadIdx.x; e < total; e += gridDim.x * blockDim.x) {
+        const unsigned row = e / cv, col = e - row * cv;
+        const VT g = go[e];
+#pragma unroll
+        for (int t = 0; t < 3; ++t) {
+            const int ii = idx[row * 3 + t];
+            const float wt = w[row * 3 + t];
+            float* dst = gp + (size_t)ii * c + col * VEC;
+            if constexpr (VEC == 4) {
+                atomicAdd(dst + 0, g.x * wt); atomicAdd(dst + 1, g.y * wt);
+                atomicAdd(dst + 2, g.z * wt); atomicAdd(dst + 3, g.w * wt);
+            } else {
+                atomicAdd(dst, g * wt);  // tf_interpolate.cpp:411-415
+            }
+        }
+    }
+}
+
+// Fused FP front end: inverse-distance weights (pointnet_util.py:300-303) +
+// three_interpolate + concat([interp, points1]) (pointnet_util.py:304-311).
+// One thread per output float (channel widths like 131 are not vectorisable).
+__global__ void __launch_bounds__(256)
+fp_interp_concat_kernel(int n, int m, int c1, int c2, const float* __restrict__ dist_all,
+                        const int* __restrict__ idx_all, const float* __restrict__ points1_all,
+                        const float* __restrict__ points2_all, float* __restrict__ out_all) {
+    const unsigned cw = (unsigned)(c1 + c2);
+    const unsigned total = (unsigned)n * cw;
+    const int bi = blockIdx.y;
+    const float* __restrict__ dist = dist_all + (size_t)bi * n * 3;
+    const int* __restrict__ idx = idx_all + (size_t)bi * n * 3;
+    const float* __restrict__ p2 = points2_all + (size_t)bi * m * c2;
+    const float* __restrict__ p1 = points1_all ? points1_all + (size_t)bi * n * c1 : nullptr;
+    float* __restrict__ out = out_all + (size_t)bi * n * cw;
+    for (unsigned e = blockIdx.x * blockDim.x + threadIdx.x; e < total; e += gridDim.x * blockDim.x) {
+        const unsigned row = e / cw, col = e - row * cw;
+        float v;
+        if (col < (unsigned)c2) {
+            const float d1 = fmaxf(dist[row * 3 + 0], 1e-10f);
+            const float d2 = fmaxf(dist[row * 3 + 1], 1e-10f);
+            const float d3 = fmaxf(dist[row * 3 + 2], 1e-10f);
+            const float r1 = 1.0f / d1, r2 = 1.0f / d2, r3 = 1.0f / d3;  // IEEE division
+            const float norm = (r1 + r2) + r3;
+            const float w1 = r1 / norm, w2 = r2 / norm, w3 = r3 / norm;
+            const int i1 = idx[row * 3 + 0], i2 = idx[row * 3 + 1], i3 = idx[row * 3 + 2];
+            v = (p2[(size_t)i1 * c2 + col] * w1 + p2[(size_t)i2 * c2 + col] * w2) +
+                p2[(size_t)i3 * c2 + col] * w3;
+        } else {
+            v = p1[(size_t)row * c1 + (col - c2)];
+        }
+        out[e] = v;
+    }
+}
+
+inline int grid_x_for(unsigned long long total, int block, int batches) {
+    unsigned long long g = (total + block - 1) / block;
+    unsigned long long cap = (256ull * 8 + batches - 1) / batches;
+    if (cap < 1) cap = 1;
+    if (g > cap) g = cap;
+    if (g < 1) g = 1;
+    return (int)g;
+}
+
+}  // namespace
+
+extern "C" int pn2_three_nn(int b, int n, int m, const float* xyz1, const float* xyz2, float* dist,
+                            int* idx, void* stream) {
+    if (b <= 0 || n <= 0 || m < 3) return PN2_EINVAL;
+    if (!xyz1 || !xyz2 || !dist || !idx) return PN2_ENULL;
+    if ((long long)n * 3 > 0x7fffffffLL || (long long)m * 3 > 0x7fffffffLL || b > 65535) return PN2_ERANGE;
+    dim3 grid((n + kNnThreads - 1) / kNnThreads, b);
+    three_nn_kernel<<<grid, kNnThreads, 0, static_cast<hipStream_t>(stream)>>>(n, m, xyz1, xyz2, dist, idx);
+    PN2_RETURN_IF_LAUNCH_FAILED();
+    return PN2_OK;
+}
+
+extern "C" int pn2_three_interpolate(int b, int m, int c, int n, const float* points, const int* idx,
+                                     const float* weight, float* out, void* stream) {
+    if (b <= 0 || m <= 0 || c <= 0 || n <= 0) return PN2_EINVAL;
+    if (!points || !idx || !weight || !out) return PN2_ENULL;
+    if ((unsigned long long)n * c > 0xffffffffull || b > 65535) return PN2_ERANGE;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    const bool vec4 = (c % 4 == 0) && (((uintptr_t)points | (uintptr_t)out) % 16 == 0);
+    if (vec4) {
+        dim3 grid(grid_x_for((unsigned long long)n * (c / 4), 256, b), b);
+        three_interpolate_kernel<f32x4, 4><<<grid, 256, 0, st>>>(m, c, n, points, idx, weight, out);
+    } else {
+        dim3 grid(grid_x_for((unsigned long long)n * c, 256, b), b);
+        three_interpolate_kernel<float, 1><<<grid, 256, 0, st>>>(m, c, n, points, idx, weight, out);
+    }
+    PN2_RETURN_IF_LAUNCH_FAILED();
+    return PN2_OK;
+}
+
+extern "C" int pn2_three_interpolate_grad(int b, int n, int c, int m, const float* grad_out,
+                                          const int* idx, const float* weight, float* grad_points,
+                                          void* stream) {
+    if (b <= 0 || m <= 0 || c <= 0 || n <= 0) return PN2_EINVAL;
+    if (!grad_out || !idx || !weight || !grad_points) return PN2_ENULL;
+    if ((unsigned long long)n * c > 0xffffffffull || b > 65535) return PN2_ERANGE;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    hipError_t e = hipMemsetAsync(grad_points, 0, sizeof(float) * (size_t)b * m * c, st);
+    if (e != hipSuccess) return (int)e;
+    const bool vec4 = (c % 4 == 0) && ((uintptr_t)grad_out % 16 == 0);
+    if (vec4) {
+        dim3 grid(grid_x_for((unsigned long long)n * (c / 4), 256, b), b);
+        three_interpolate_grad_kernel<f32x4, 4><<<grid, 256, 0, st>>>(n, c, m, grad_out, idx, weight, grad_points);
+    } else {
+        dim3 grid(grid_x_for((unsigned long long)n * c, 256, b), b);
+        three_interpolate_grad_kernel<float, 1><<<grid, 256, 0, st>>>(n, c, m, grad_out, idx, weight, grad_points);
+    }
+    PN2_RETURN_IF_LAUNCH_FAILED();
+    return PN2_OK;
+}
+
+extern "C" int pn2_fp_interp_concat(int b, int n, int m, int c1, int c2, const float* dist,
+                                    const int* idx, const float* points1, const float* points2,
+                                    float* out, void* stream) {
+    if (b <= 0 || n <= 0 || m <= 0 || c2 <= 0 || c1 < 0) return PN2_EINVAL;
+    if (!dist || !idx || !points2 || !out || (c1 > 0 && !points1)) return PN2_ENULL;
+    if ((unsigned long long)n * (c1 + c2) > 0xffffffffull || b > 65535) return PN2_ERANGE;
+    dim3 grid(grid_x_for((unsigned long long)n * (c1 + c2), 256, b), b);
+    fp_interp_concat_kernel<<<grid, 256, 0, static_cast<hipStream_t>(stream)>>>(
+        n, m, c1, c2, dist, idx, c1 > 0 ? points1 : nullptr, points2, out);
+    PN2_RETURN_IF_LAUNCH_FAILED();
+    return PN2_OK;
+}

@@ -1,0 +1,317 @@
+// pn2_sa_fused.hip -- fused set-abstraction MLP for gfx950:
+//   gather(idx) -> [xyz - centre | features] -> up to 3 x (1x1 conv + bias + ReLU)
+//   -> max over the K=32 neighbours, with the grouped (B,M,K,C) tensor and all
+//   intermediate activations living only in VGPRs.
+// Replaces the TF sub-graph util/pointnet_util.py:43-54 (group/centre/concat) +
+// :150-162 (conv2d stack, util/tf_util.py:181-203 with inference BN folded by the
+// host) + :167-170 (reduce_max over K).  No reference kernel exists for it.
+//
+// Mapping onto v_mfma_f32_32x32x2_f32 (exact fp32):
+//   * one wave64 owns one (b, j) neighbourhood = 32 rows; lane l carries
+//     neighbour (l & 31); the two half-waves carry two different input channels,
+//     which are the k = 0 / k = 1 slices of one 32x32x2 MFMA.
+//   * hidden layers are computed TRANSPOSED, D^T[channel][neighbour] =
+//     W^T x X^T (A operand = weights, B operand = activations).  The accumulator
+//     layout (lane = neighbour, register r -> channel (r&3)+8*(r>>2)+4*half) is
+//     then directly the B-operand layout of the next layer: no LDS round trip, no
+//     cross-lane traffic between layers.  The contraction index is visited in
+//     that (permuted) channel order; the weights are stored in LDS pre-permuted
+//     to match ([k-step][half][cout], conflict-free ds_read_b32).
+//   * the last layer is computed un-transposed (A = activations, B = weights) so
+//     the K-max is an in-lane max over the 16 accumulator registers plus one
+//     half-wave exchange, and the pooled row is written as 128-byte segments.
+// Weights (<= 3 layers, widths <= 128) stay resident in LDS for the whole
+// persistent workgroup.
+#include "pn2_common.h"
+
+namespace {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+struct SaFusedParams {
+    int n, m, c, groups;  // groups = b*m
+    int w[3];             // layer widths
+    const float* xyz;
+    const float* new_xyz;
+    const float* points;
+    const int* idx;
+    const float* W[3];
+    const float* bias[3];
+    float* out;
+};
+
+__device__ __forceinline__ int acc_chan(int r, int half) { return (r & 3) + 8 * (r >> 2) + 4 * half; }
+
+// number of k-steps of layer 1 for c feature channels
+__host__ __device__ inline int l1_steps(int c, bool vec8) { return 2 + (vec8 ? (c / 8) * 4 : (c + 1) / 2); }
+
+// input channel (row of W1) fed by half-wave `h` at k-step `s` of layer 1; -1 = zero pad
+__device__ __forceinline__ int l1_chan(int s, int h, int c, bool vec8) {
+    if (s == 0) return h;              // x | y
+    if (s == 1) return h ? -1 : 2;     // z | 0
+    const int sp = s - 2;
+    if (vec8) return 3 + 8 * (sp >> 2) + 4 * h + (sp & 3);
+    const int ch = 2 * sp + h;
+    return ch < c ? 3 + ch : -1;
+}
+
+template <int NT, bool LAST>
+__device__ __forceinline__ void mfma_step(f32x16 (&acc)[NT], const float* __restrict__ wrow, float act) {
+    // wrow points at Wp[(s*2+half)*w + l31]
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+        const float wv = wrow[nt * 32];
+        if constexpr (LAST) acc[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(act, wv, acc[nt], 0, 0, 0);
+        else acc[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(wv, act, acc[nt], 0, 0, 0);
+    }
+}
+
+template <int NT>
+__device__ __forceinline__ void zero_acc(f32x16 (&acc)[NT]) {
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[nt][r] = 0.f;
+}
+
+// hidden-layer epilogue: relu(acc + bias[channel]) in the transposed layout
+template <int NT>
+__device__ __forceinline__ void bias_relu_T(f32x16 (&acc)[NT], const float* __restrict__ sbias, int half) {
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+            acc[nt][r] = fmaxf(acc[nt][r] + sbias[nt * 32 + acc_chan(r, half)], 0.f);
+}
+
+// dense layer fed from the previous layer's accumulators.  The weight reads of
+// step s+1 are issued ahead of the MFMAs of step s and a sched_barrier pins that
+// order: without it the scheduler hoists all NTP*16*NT ds_reads of the unrolled
+// body to the top and the kernel spills.
+template <int NT>
+__device__ __forceinline__ void load_w(float (&wv)[NT], const float* __restrict__ wrow) {
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) wv[nt] = wrow[nt * 32];
+}
+
+template <int NT, bool LAST>
+__device__ __forceinline__ void mfma_regs(f32x16 (&acc)[NT], const float (&wv)[NT], float act) {
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+        if constexpr (LAST) acc[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(act, wv[nt], acc[nt], 0, 0, 0);
+        else acc[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(wv[nt], act, acc[nt], 0, 0, 0);
+    }
+}
+
+template <int NTP, int NT, bool LAST>
+__device__ __forceinline__ void layer_from_regs(const f32x16 (&in)[NTP], f32x16 (&acc)[NT],
+                                                const float* __restrict__ wp, int w, int half, int l31) {
+    const float* __restrict__ wl = wp + half * w + l31;
+    float wc[NT];
+    load_w<NT>(wc, wl);
+#pragma unroll
+    for (int ntp = 0; ntp < NTP; ++ntp)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int s = ntp * 16 + r;
+            float wn[NT];
+            if (s + 1 < NTP * 16) load_w<NT>(wn, wl + (s + 1) * 2 * w);
+            mfma_regs<NT, LAST>(acc, wc, in[ntp][r]);
+            __builtin_amdgcn_sched_barrier(0);
+            if (s + 1 < NTP * 16) {
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) wc[nt] = wn[nt];
+            }
+        }
+}
+
+// last-layer epilogue: max over the 32 rows, + bias, relu, store 32 floats per tile
+template <int NT>
+__device__ __forceinline__ void pool_store(const f32x16 (&acc)[NT], const float* __restrict__ sbias,
+                                           float* __restrict__ orow, int half, int l31) {
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+        float v = acc[nt][0];
+#pragma unroll
+        for (int r = 1; r < 16; ++r) v = fmaxf(v, acc[nt][r]);
+        v = fmaxf(v, __shfl_xor(v, 32));
+        v = fmaxf(v + sbias[nt * 32 + l31], 0.f);
+        if (half == 0) orow[nt * 32 + l31] = v;
+    }
+}
+
+template <int L, int NT1, int NT2, int NT3, bool VEC8>
+__global__ void __launch_bounds__(256, 2)  // 2 waves/SIMD: <= 256 VGPR+AGPR per lane
+sa_fused_kernel(SaFusedParams p) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int half = lane >> 5;
+    const int l31 = lane & 31;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    constexpr int W1 = NT1 * 32, W2 = NT2 * 32, W3 = NT3 * 32;
+    const int c = p.c;
+    const int steps1 = l1_steps(c, VEC8);
+
+    // ---- LDS carve + weight staging (once per persistent workgroup) -----------
+    float* wp1 = smem;
+    float* wp2 = wp1 + steps1 * 2 * W1;
+    float* wp3 = wp2 + (L >= 2 ? W1 * W2 : 0);            // (W1/2 steps) * 2 * W2
+    float* sb1 = wp3 + (L >= 3 ? W2 * W3 : 0);
+    float* sb2 = sb1 + W1;
+    float* sb3 = sb2 + (L >= 2 ? W2 : 0);
+    for (int e = tid; e < steps1 * 2 * W1; e += 256) {
+        const int col = e % W1, sh = e / W1;
+        const int ch = l1_chan(sh >> 1, sh & 1, c, VEC8);
+        wp1[e] = ch >= 0 ? p.W[0][(size_t)ch * W1 + col] : 0.f;
+    }
+    for (int e = tid; e < W1; e += 256) sb1[e] = p.bias[0][e];
+    if constexpr (L >= 2) {
+        for (int e = tid; e < W1 * W2; e += 256) {
+            const int col = e % W2, sh = e / W2;
+            const int s = sh >> 1, h = sh & 1;
+            const int ch = (s >> 4) * 32 + acc_chan(s & 15, h);
+            wp2[e] = p.W[1][(size_t)ch * W2 + col];
+        }
+        for (int e = tid; e < W2; e += 256) sb2[e] = p.bias[1][e];
+    }
+    if constexpr (L >= 3) {
+        for (int e = tid; e < W2 * W3; e += 256) {
+            const int col = e % W3, sh = e / W3;
+            const int s = sh >> 1, h = sh & 1;
+            const int ch = (s >> 4) * 32 + acc_chan(s & 15, h);
+            wp3[e] = p.W[2][(size_t)ch * W3 + col];
+        }
+        for (int e = tid; e < W3; e += 256) sb3[e] = p.bias[2][e];
+    }
+    __syncthreads();
+
+    constexpr int WOUT = L == 1 ? W1 : (L == 2 ? W2 : W3);
+    for (int g = blockIdx.x * 4 + wave; g < p.groups; g += gridDim.x * 4) {
+        const int bi = g / p.m;
+        const int ii = p.idx[(size_t)g * 32 + l31];
+        const size_t prow = (size_t)bi * p.n + ii;
+        const float cxv = p.new_xyz[(size_t)g * 3 + 0];
+        const float cyv = p.new_xyz[(size_t)g * 3 + 1];
+        const float czv = p.new_xyz[(size_t)g * 3 + 2];
+        const float rx = p.xyz[prow * 3 + 0] - cxv;  // grouped_xyz -= tile(new_xyz) :44-46
+        const float ry = p.xyz[prow * 3 + 1] - cyv;
+        const float rz = p.xyz[prow * 3 + 2] - czv;
+
+        f32x16 a1[NT1];
+        zero_acc<NT1>(a1);
+        constexpr bool LAST1 = (L == 1);
+        const float* w1l = wp1 + half * W1 + l31;
+        mfma_step<NT1, LAST1>(a1, w1l + 0 * 2 * W1, half ? ry : rx);
+        mfma_step<NT1, LAST1>(a1, w1l + 1 * 2 * W1, half ? 0.f : rz);
+        if constexpr (VEC8) {
+            const f32x4* __restrict__ fp =
+                reinterpret_cast<const f32x4*>(p.points + prow * c) + half;
+            const int nt8 = c >> 3;
+            f32x4 cur = fp[0];
+            for (int t = 0; t < nt8; ++t) {
+                f32x4 nxt = cur;
+                if (t + 1 < nt8) nxt = fp[(t + 1) * 2];
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+                    mfma_step<NT1, LAST1>(a1, w1l + (2 + 4 * t + q) * 2 * W1, cur[q]);
+                cur = nxt;
+            }
+        } else {
+            const float* __restrict__ fp = p.points + prow * c;
+            const int ns = (c + 1) >> 1;
+            for (int sp = 0; sp < ns; ++sp) {
+                const int ch = 2 * sp + half;
+                const float v = ch < c ? fp[ch] : 0.f;
+                mfma_step<NT1, LAST1>(a1, w1l + (2 + sp) * 2 * W1, v);
+            }
+        }
+        float* __restrict__ orow = p.out + (size_t)g * WOUT;
+        if constexpr (L == 1) {
+            pool_store<NT1>(a1, sb1, orow, half, l31);
+        } else {
+            bias_relu_T<NT1>(a1, sb1, half);
+            f32x16 a2[NT2];
+            zero_acc<NT2>(a2);
+            layer_from_regs<NT1, NT2, L == 2>(a1, a2, wp2, W2, half, l31);
+            if constexpr (L == 2) {
+                pool_store<NT2>(a2, sb2, orow, half, l31);
+            } else {
+                bias_relu_T<NT2>(a2, sb2, half);
+                f32x16 a3[NT3];
+                zero_acc<NT3>(a3);
+                layer_from_regs<NT2, NT3, true>(a2, a3, wp3, W3, half, l31);
+                pool_store<NT3>(a3, sb3, orow, half, l31);
+            }
+        }
+    }
+}
+
+template <int L, int NT1, int NT2, int NT3, bool VEC8>
+int launch_sa_fused(const SaFusedParams& p, hipStream_t st) {
+    constexpr int W1 = NT1 * 32, W2 = NT2 * 32, W3 = NT3 * 32;
+    const int steps1 = l1_steps(p.c, VEC8);
+    size_t floats = (size_t)steps1 * 2 * W1 + W1;
+    if (L >= 2) floats += (size_t)W1 * W2 + W2;
+    if (L >= 3) floats += (size_t)W2 * W3 + W3;
+    const size_t bytes = floats * sizeof(float);
+    if (bytes > 150 * 1024) return PN2_EUNSUP;
+    auto kern = sa_fused_kernel<L, NT1, NT2, NT3, VEC8>;
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+    if (e != hipSuccess) return (int)e;
+    // persistent grid: as many 4-wave workgroups as LDS lets be co-resident (<= 2 per CU)
+    int per_cu = (int)((160 * 1024) / (bytes + 1024));
+    if (per_cu < 1) per_cu = 1;
+    if (per_cu > 2) per_cu = 2;
+    int grid = 256 * per_cu;
+    const int need = (p.groups + 3) / 4;
+    if (grid > need) grid = need;
+    kern<<<grid, 256, bytes, st>>>(p);
+    PN2_RETURN_IF_LAUNCH_FAILED();
+    return PN2_OK;
+}
+
+}  // namespace
+
+extern "C" int pn2_sa_mlp_max_fused(int b, int n, int m, int nsample, int c, const float* xyz,
+                                    const float* new_xyz, const float* points, const int* idx,
+                                    int nlayers, const int* widths, const float* const* w,
+                                    const float* const* bias, float* out, void* stream) {
+    if (b <= 0 || n <= 0 || m <= 0 || nsample <= 0 || c < 0 || nlayers <= 0) return PN2_EINVAL;
+    if (!xyz || !new_xyz || !idx || !widths || !w || !bias || !out || (c > 0 && !points)) return PN2_ENULL;
+    if (nsample != 32 || nlayers > 3) return PN2_EUNSUP;
+    if ((long long)b * m > 0x7fffffffLL / 32) return PN2_ERANGE;
+    SaFusedParams p{};
+    p.n = n; p.m = m; p.c = c; p.groups = b * m;
+    p.xyz = xyz; p.new_xyz = new_xyz; p.points = points; p.idx = idx; p.out = out;
+    int nt[3] = {0, 0, 0};
+    for (int l = 0; l < nlayers; ++l) {
+        if (widths[l] <= 0 || widths[l] % 32 != 0 || widths[l] > 128) return PN2_EUNSUP;
+        if (!w[l] || !bias[l]) return PN2_ENULL;
+        p.w[l] = widths[l]; p.W[l] = w[l]; p.bias[l] = bias[l];
+        nt[l] = widths[l] / 32;
+    }
+    const bool vec8 = c > 0 && (c % 8 == 0) && ((uintptr_t)points % 16 == 0);
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    const int key = nlayers * 1000 + nt[0] * 100 + nt[1] * 10 + nt[2];
+#define PN2_SA_CASE(L_, A_, B_, C_)                                                     \
+    case (L_ * 1000 + A_ * 100 + B_ * 10 + C_):                                         \
+        return vec8 ? launch_sa_fused<L_, A_, (B_ ? B_ : 1), (C_ ? C_ : 1), true>(p, st) \
+                    : launch_sa_fused<L_, A_, (B_ ? B_ : 1), (C_ ? C_ : 1), false>(p, st);
+    switch (key) {
+        PN2_SA_CASE(3, 1, 1, 2)  // SA1 of semantic.json: [32,32,64]
+        PN2_SA_CASE(3, 2, 2, 4)  // SA2: [64,64,128]
+        PN2_SA_CASE(3, 2, 3, 4)  // MSG scale [64,96,128]
+        PN2_SA_CASE(3, 1, 1, 1)
+        PN2_SA_CASE(3, 2, 2, 2)
+        PN2_SA_CASE(2, 2, 4, 0)
+        PN2_SA_CASE(2, 4, 4, 0)
+        PN2_SA_CASE(1, 1, 0, 0)
+        PN2_SA_CASE(1, 2, 0, 0)
+        PN2_SA_CASE(1, 4, 0, 0)  // north-star shape: one 128 -> 128 layer + max
+        default: return PN2_EUNSUP;
+    }
+#undef PN2_SA_CASE
+}

@@ -1,0 +1,85 @@
+"""SSG PointNet++ semantic-segmentation network of the reference (model.py:22-148)
+on the MI355X layer API: 4 x pointnet_sa_module -> 4 x pointnet_fp_module ->
+conv1d(128)+BN+ReLU -> dropout(0.5) -> conv1d(num_class).
+
+`get_sa_fp_features` is the SA+FP stack alone -- the path BASELINE.json's metric
+("points/sec through SA+FP stack") is quoted on; `get_model` adds the head.
+Hyper-parameter keys are the reference's semantic.json keys verbatim.
+"""
+import json
+import os
+
+from .util import tf_util
+from .util.pointnet_util import pointnet_fp_module, pointnet_sa_module
+
+# semantic.json:8-9,23-37 of the reference
+SEMANTIC_HYPERPARAMS = {
+    "num_point": 8192, "batch_size": 16, "use_color": 1,
+    "l1_radius": 0.5, "l1_nsample": 32, "l1_npoint": 1024,
+    "l2_radius": 1.0, "l2_nsample": 32, "l2_npoint": 256,
+    "l3_radius": 2.0, "l3_nsample": 32, "l3_npoint": 64,
+    "l4_radius": 4.0, "l4_nsample": 32, "l4_npoint": 16,
+}
+
+SA_MLPS = ([32, 32, 64], [64, 64, 128], [128, 128, 256], [256, 256, 512])  # model.py:36-87
+FP_MLPS = ([256, 256], [256, 256], [256, 128], [128, 128, 128])            # model.py:90-129
+
+
+def load_hyperparams(path):
+    with open(path) as f:
+        return json.load(f)
+
+
+def get_sa_fp_features(point_cloud, is_training, hyperparams, bn_decay=None):
+    """point_cloud (B,N,3 or 6) -> l0_points (B,N,128) and end_points."""
+    end_points = {}
+    if hyperparams["use_color"]:
+        feature_size = 3 * int(hyperparams["use_color"])
+        l0_xyz = point_cloud[:, :, 0:3].contiguous()
+        l0_points = point_cloud[:, :, 3:3 + feature_size].contiguous()
+    else:
+        l0_xyz = point_cloud.contiguous()
+        l0_points = None
+    end_points["l0_xyz"] = l0_xyz
+
+    xyzs, feats = [l0_xyz], [l0_points]
+    for li in range(4):
+        k = "l%d_" % (li + 1)
+        new_xyz, new_points, _ = pointnet_sa_module(
+            xyzs[-1], feats[-1], npoint=hyperparams[k + "npoint"], radius=hyperparams[k + "radius"],
+            nsample=hyperparams[k + "nsample"], mlp=list(SA_MLPS[li]), mlp2=None, group_all=False,
+            is_training=is_training, bn_decay=bn_decay, scope="layer%d" % (li + 1))
+        xyzs.append(new_xyz)
+        feats.append(new_points)
+
+    # feature propagation, coarse to fine (model.py:90-129)
+    up = feats[4]
+    for fi in range(4):
+        lvl = 3 - fi  # target level: 3,2,1,0
+        up = pointnet_fp_module(xyzs[lvl], xyzs[lvl + 1], feats[lvl], up, list(FP_MLPS[fi]), is_training, bn_decay,
+                                scope="fa_layer%d" % (fi + 1))
+    end_points["xyzs"] = xyzs
+    return up, end_points
+
+
+def get_model(point_cloud, is_training, num_class, hyperparams, bn_decay=None):
+    """-> logits (B,N,num_class), end_points (model.py:22-148)."""
+    l0_points, end_points = get_sa_fp_features(point_cloud, is_training, hyperparams, bn_decay)
+    net = tf_util.conv1d(l0_points, 128, 1, padding="VALID", bn=True, is_training=is_training, scope="fc1",
+                         bn_decay=bn_decay)
+    end_points["feats"] = net
+    net = tf_util.dropout(net, keep_prob=0.5, is_training=is_training, scope="dp1")
+    net = tf_util.conv1d(net, num_class, 1, padding="VALID", activation_fn=None, scope="fc2",
+                         is_training=is_training)
+    return net, end_points
+
+
+def get_loss(pred, label, smpw):
+    """Weighted sparse softmax cross-entropy, tf.losses reduction SUM_BY_NONZERO_WEIGHTS
+    (model.py:152-161): sum(w * ce) / count(w != 0)."""
+    import torch
+    import torch.nn.functional as F
+    ce = F.cross_entropy(pred.reshape(-1, pred.shape[-1]), label.reshape(-1).long(), reduction="none")
+    w = smpw.reshape(-1)
+    nz = (w != 0).sum().clamp(min=1)
+    return (ce * w).sum() / nz

@@ -1,0 +1,84 @@
+"""query_ball_point / group_point on the MI355X.
+
+Same names, argument order and shapes as the reference wrappers
+(tf_ops/tf_grouping.py:13-25 query_ball_point, :46-54 group_point, gradient :57-61).
+knn_point / select_top_k (tf_grouping.py:31-43,64-89) are not on the model's path
+(model always passes knn=False) and are listed as "next" in DESIGN.md.
+"""
+import torch
+
+from .. import config
+from .._lib import check, lib, ptr, require_cuda, stream_ptr
+
+
+def query_ball_point(radius, nsample, xyz1, xyz2):
+    """radius float, nsample int, xyz1 (b,n,3) dataset, xyz2 (b,m,3) queries
+    -> idx (b,m,nsample) int32, pts_cnt (b,m) int32.  Not differentiable."""
+    if not radius > 0:
+        raise ValueError("QueryBallPoint expects positive radius")  # tf_grouping.cpp:80-83
+    if nsample <= 0:
+        raise ValueError("QueryBallPoint expects positive nsample")  # tf_grouping.cpp:84-87
+    require_cuda(xyz1, xyz2)
+    for t, nm in ((xyz1, "xyz1"), (xyz2, "xyz2")):
+        if t.dim() != 3 or t.shape[2] != 3:
+            raise ValueError("QueryBallPoint expects (batch_size, ndataset, 3) %s shape." % nm)  # :92-106
+        if t.dtype != torch.float32:
+            raise TypeError("QueryBallPoint expects float32 %s" % nm)
+    if xyz1.shape[0] != xyz2.shape[0]:
+        raise ValueError("QueryBallPoint expects xyz1 and xyz2 with the same batch size")
+    xyz1 = xyz1.detach().contiguous()
+    xyz2 = xyz2.detach().contiguous()
+    b, n, _ = xyz1.shape
+    m = xyz2.shape[1]
+    idx = torch.empty((b, m, nsample), dtype=torch.int32, device=xyz1.device)
+    cnt = torch.empty((b, m), dtype=torch.int32, device=xyz1.device)
+    with torch.cuda.device(xyz1.device):
+        check(lib.pn2_query_ball_point(b, n, m, float(radius), int(nsample), ptr(xyz1), ptr(xyz2), ptr(idx),
+                                       ptr(cnt), int(config.arith_mode), stream_ptr()), "pn2_query_ball_point")
+    return idx, cnt
+
+
+class _GroupPoint(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, points, idx):
+        b, n, c = points.shape
+        _, m, ns = idx.shape
+        out = torch.empty((b, m, ns, c), dtype=torch.float32, device=points.device)
+        with torch.cuda.device(points.device):
+            check(lib.pn2_group_point(b, n, c, m, ns, ptr(points), ptr(idx), ptr(out), stream_ptr()),
+                  "pn2_group_point")
+        ctx.save_for_backward(idx)
+        ctx.n = n
+        return out
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        (idx,) = ctx.saved_tensors
+        grad_out = grad_out.contiguous()
+        b, m, ns, c = grad_out.shape
+        gp = torch.empty((b, ctx.n, c), dtype=torch.float32, device=grad_out.device)
+        with torch.cuda.device(grad_out.device):
+            check(lib.pn2_group_point_grad(b, ctx.n, c, m, ns, ptr(grad_out), ptr(idx), ptr(gp), stream_ptr()),
+                  "pn2_group_point_grad")
+        return gp, None
+
+
+def group_point(points, idx):
+    """points (b,n,c) float32, idx (b,m,nsample) int32 -> (b,m,nsample,c); gradient w.r.t. points."""
+    require_cuda(points, idx)
+    if points.dim() != 3:
+        raise ValueError("GroupPoint expects (batch_size, num_points, channel) points shape")  # tf_grouping.cpp:189-192
+    if idx.dim() != 3 or idx.shape[0] != points.shape[0]:
+        raise ValueError("GroupPoint expects (batch_size, npoints, nsample) idx shape")  # :199-203
+    if points.dtype != torch.float32 or idx.dtype != torch.int32:
+        raise TypeError("GroupPoint expects float32 points and int32 idx")
+    return _GroupPoint.apply(points.contiguous(), idx.contiguous())
+
+
+def knn_point(k, xyz1, xyz2):
+    raise NotImplementedError("knn_point (tf_grouping.py:64-89) is outside the SA/FP hot path built so far; "
+                              "see DESIGN.md 'Next'")
+
+
+def select_top_k(k, dist):
+    raise NotImplementedError("select_top_k (tf_grouping.py:31-40) is outside the SA/FP hot path built so far")

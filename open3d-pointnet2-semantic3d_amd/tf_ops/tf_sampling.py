@@ -1,0 +1,71 @@
+"""farthest_point_sample / gather_point on the MI355X.
+
+Same names, argument order and shapes as the reference wrappers
+(tf_ops/tf_sampling.py:38-46 gather_point, :61-69 farthest_point_sample, gradient
+registration :54-58, NoGradient :72), but on torch CUDA(ROCm) tensors through the
+C ABI of libpn2_hip.so instead of tf.load_op_library.
+"""
+import torch
+
+from .. import _lib, config
+from .._lib import check, lib, ptr, require_cuda, stream_ptr
+
+
+def _chk_xyz(t, name, op):
+    if t.dim() != 3 or t.shape[2] != 3:
+        raise ValueError("%s expects (batch_size,num_points,3) %s shape" % (op, name))  # tf_sampling.cpp:131-134
+    if t.dtype != torch.float32:
+        raise TypeError("%s expects float32 %s" % (op, name))
+
+
+def farthest_point_sample(npoint, inp):
+    """npoint: int; inp (b,n,3) float32 -> (b,npoint) int32.  Not differentiable."""
+    if npoint <= 0:
+        raise ValueError("FarthestPointSample expects positive npoint")  # tf_sampling.cpp:121-123
+    require_cuda(inp)
+    _chk_xyz(inp, "inp", "FarthestPointSample")
+    inp = inp.detach().contiguous()
+    b, n, _ = inp.shape
+    out = torch.empty((b, npoint), dtype=torch.int32, device=inp.device)
+    temp = None
+    if n > 16384:  # PN2_FPS_MAX_REG_POINTS: the streaming kernel needs the reference's (32,n) scratch
+        temp = torch.empty((min(b, 32), n), dtype=torch.float32, device=inp.device)
+    with torch.cuda.device(inp.device):
+        check(lib.pn2_farthest_point_sample(b, n, int(npoint), ptr(inp), ptr(temp), ptr(out),
+                                            int(config.arith_mode), stream_ptr()), "pn2_farthest_point_sample")
+    return out
+
+
+class _GatherPoint(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, inp, idx):
+        b, n, _ = inp.shape
+        m = idx.shape[1]
+        out = torch.empty((b, m, 3), dtype=torch.float32, device=inp.device)
+        with torch.cuda.device(inp.device):
+            check(lib.pn2_gather_point(b, n, m, ptr(inp), ptr(idx), ptr(out), stream_ptr()), "pn2_gather_point")
+        ctx.save_for_backward(idx)
+        ctx.n = n
+        return out
+
+    @staticmethod
+    def backward(ctx, out_g):
+        (idx,) = ctx.saved_tensors
+        out_g = out_g.contiguous()
+        b, m, _ = out_g.shape
+        inp_g = torch.empty((b, ctx.n, 3), dtype=torch.float32, device=out_g.device)
+        with torch.cuda.device(out_g.device):
+            check(lib.pn2_gather_point_grad(b, ctx.n, m, ptr(out_g), ptr(idx), ptr(inp_g), stream_ptr()),
+                  "pn2_gather_point_grad")
+        return inp_g, None
+
+
+def gather_point(inp, idx):
+    """inp (b,n,3) float32, idx (b,m) int32 -> (b,m,3) float32; gradient w.r.t. inp."""
+    require_cuda(inp, idx)
+    _chk_xyz(inp, "inp", "GatherPoint")
+    if idx.dim() != 2 or idx.shape[0] != inp.shape[0]:
+        raise ValueError("GatherPoint expects (batch_size,num_result) idx shape")  # tf_sampling.cpp:175-178
+    if idx.dtype != torch.int32:
+        raise TypeError("GatherPoint expects int32 idx")
+    return _GatherPoint.apply(inp.contiguous(), idx.contiguous())

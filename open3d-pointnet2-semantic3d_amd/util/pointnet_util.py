@@ -1,0 +1,229 @@
+"""PointNet++ layers with the reference's API on the MI355X kernels.
+
+Keeps the names, argument orders and return values of util/pointnet_util.py:
+sample_and_group (:18-60), sample_and_group_all (:63-95), pointnet_sa_module
+(:98-216), pointnet_sa_module_msg (:219-282), pointnet_fp_module (:285-326).
+Tensors are torch float32/int32 CUDA(ROCm) tensors; variables live in the
+VariableStore of util/tf_util.py under the same scope names the reference uses
+("layer1/conv0/weights", "fa_layer4/conv_2/bn/gamma", ...).
+
+Inference (is_training=False) never materialises the grouped (B,M,K,C) tensor
+when the fused kernel applies; training uses the HIP index/gather ops with
+autograd plus differentiable torch layers.
+"""
+import ctypes
+
+import torch
+
+from . import tf_util
+from .._lib import PN2_EUNSUP, Pn2Error, check, lib, ptr, require_cuda, stream_ptr
+from ..tf_ops.tf_grouping import group_point, knn_point, query_ball_point
+from ..tf_ops.tf_interpolate import three_interpolate, three_nn
+from ..tf_ops.tf_sampling import farthest_point_sample, gather_point
+
+
+def sample_and_group(npoint, radius, nsample, xyz, points, knn=False, use_xyz=True):
+    """-> new_xyz (B,npoint,3), new_points (B,npoint,nsample,3+C), idx, grouped_xyz."""
+    new_xyz = gather_point(xyz, farthest_point_sample(npoint, xyz))
+    if knn:
+        _, idx = knn_point(nsample, xyz, new_xyz)
+    else:
+        idx, pts_cnt = query_ball_point(radius, nsample, xyz, new_xyz)
+    grouped_xyz = group_point(xyz, idx)
+    grouped_xyz = grouped_xyz - new_xyz.unsqueeze(2)  # translation normalisation (:44-46)
+    if points is not None:
+        grouped_points = group_point(points, idx)
+        if use_xyz:
+            new_points = torch.cat([grouped_xyz, grouped_points], dim=-1)  # xyz FIRST (:52-54)
+        else:
+            new_points = grouped_points
+    else:
+        new_points = grouped_xyz
+    return new_xyz, new_points, idx, grouped_xyz
+
+
+def sample_and_group_all(xyz, points, use_xyz=True):
+    """npoint=1, radius=inf, centroid (0,0,0) (:63-95)."""
+    b, n, _ = xyz.shape
+    new_xyz = torch.zeros((b, 1, 3), dtype=torch.float32, device=xyz.device)
+    idx = torch.arange(n, dtype=torch.int32, device=xyz.device).reshape(1, 1, n).repeat(b, 1, 1)
+    grouped_xyz = xyz.reshape(b, 1, n, 3)
+    if points is not None:
+        new_points = torch.cat([xyz, points], dim=2) if use_xyz else points
+        new_points = new_points.unsqueeze(1)
+    else:
+        new_points = grouped_xyz
+    return new_xyz, new_points, idx, grouped_xyz
+
+
+def _sa_fused_inference(xyz, new_xyz, points, idx, mlp, bn, conv_scope_fmt):
+    """Try the fully fused gather+MLP+max kernel; returns None if the configuration
+    is outside what pn2_sa_mlp_max_fused supports."""
+    b, n, _ = xyz.shape
+    m, nsample = idx.shape[1], idx.shape[2]
+    c = 0 if points is None else points.shape[2]
+    if nsample != 32 or len(mlp) > 3 or any(w % 32 != 0 or w > 128 for w in mlp):
+        return None
+    ws, bs = [], []
+    cin = 3 + c
+    for i, cout in enumerate(mlp):
+        with tf_util.variable_scope(conv_scope_fmt % i):
+            w2, b2 = tf_util.folded_dense(cin, cout, bn, (1, 1, cin, cout))
+        ws.append(w2)
+        bs.append(b2)
+        cin = cout
+    L = len(mlp)
+    widths = (ctypes.c_int * L)(*mlp)
+    wptrs = (ctypes.c_void_p * L)(*[t.data_ptr() for t in ws])
+    bptrs = (ctypes.c_void_p * L)(*[t.data_ptr() for t in bs])
+    out = torch.empty((b, m, mlp[-1]), dtype=torch.float32, device=xyz.device)
+    pts = None if points is None else points.contiguous()
+    with torch.cuda.device(xyz.device):
+        rc = lib.pn2_sa_mlp_max_fused(b, n, m, nsample, c, ptr(xyz), ptr(new_xyz), ptr(pts), ptr(idx), L,
+                                      ctypes.cast(widths, ctypes.c_void_p), ctypes.cast(wptrs, ctypes.c_void_p),
+                                      ctypes.cast(bptrs, ctypes.c_void_p), ptr(out), stream_ptr())
+    if rc == PN2_EUNSUP:
+        return None
+    check(rc, "pn2_sa_mlp_max_fused")
+    return out
+
+
+def _sa_group_concat(xyz, new_xyz, points, idx):
+    b, n, _ = xyz.shape
+    m, nsample = idx.shape[1], idx.shape[2]
+    c = 0 if points is None else points.shape[2]
+    out = torch.empty((b, m, nsample, 3 + c), dtype=torch.float32, device=xyz.device)
+    pts = None if points is None else points.contiguous()
+    with torch.cuda.device(xyz.device):
+        check(lib.pn2_sa_group_concat(b, n, m, nsample, c, ptr(xyz), ptr(new_xyz), ptr(pts), ptr(idx), ptr(out),
+                                      stream_ptr()), "pn2_sa_group_concat")
+    return out
+
+
+# set False to force the unfused HIP path (group_concat + pn2_linear); used by tests/bench
+USE_FUSED_SA = True
+
+
+def pointnet_sa_module(xyz, points, npoint, radius, nsample, mlp, mlp2, group_all, is_training, bn_decay, scope,
+                       bn=True, pooling="max", knn=False, use_xyz=True, use_nchw=False):
+    """PointNet Set Abstraction module -> new_xyz (B,npoint,3), new_points (B,npoint,mlp[-1] or mlp2[-1]), idx."""
+    require_cuda(xyz, points)
+    if use_nchw:
+        raise NotImplementedError("use_nchw is a TF layout hint; the MI355X kernels are channels-last only")
+    with tf_util.variable_scope(scope):
+        if not is_training and not group_all and not knn and use_xyz and pooling == "max":
+            # ---- inference fast path: HIP index ops + fused / MFMA MLP -------------
+            xyz = xyz.contiguous()
+            new_xyz = gather_point(xyz, farthest_point_sample(npoint, xyz))
+            idx, _ = query_ball_point(radius, nsample, xyz, new_xyz)
+            new_points = None
+            if USE_FUSED_SA:
+                new_points = _sa_fused_inference(xyz, new_xyz, points, idx, mlp, bn, "conv%d")
+            if new_points is None:
+                h = _sa_group_concat(xyz, new_xyz, points, idx)  # (B,M,K,3+C)
+                pool_ok = nsample == 16 or nsample % 32 == 0
+                for i, cout in enumerate(mlp):
+                    last = i == len(mlp) - 1
+                    h = tf_util.conv2d(h, cout, [1, 1], padding="VALID", stride=[1, 1], bn=bn, is_training=False,
+                                       scope="conv%d" % i, bn_decay=bn_decay,
+                                       pool=nsample if (last and pool_ok) else 0)
+                if not pool_ok:
+                    h = h.amax(dim=2, keepdim=True)
+                new_points = h.squeeze(2)
+            new_points = new_points.unsqueeze(2)
+        else:
+            if group_all:
+                nsample = xyz.shape[1]
+                new_xyz, new_points, idx, grouped_xyz = sample_and_group_all(xyz, points, use_xyz)
+            else:
+                new_xyz, new_points, idx, grouped_xyz = sample_and_group(npoint, radius, nsample, xyz, points, knn,
+                                                                         use_xyz)
+            for i, cout in enumerate(mlp):
+                new_points = tf_util.conv2d(new_points, cout, [1, 1], padding="VALID", stride=[1, 1], bn=bn,
+                                            is_training=is_training, scope="conv%d" % i, bn_decay=bn_decay)
+            if pooling == "max":
+                new_points = new_points.amax(dim=2, keepdim=True)
+            elif pooling == "avg":
+                new_points = new_points.mean(dim=2, keepdim=True)
+            elif pooling == "weighted_avg":
+                dists = torch.linalg.vector_norm(grouped_xyz, ord=2, dim=-1, keepdim=True)
+                exp_dists = torch.exp(-dists * 5)
+                weights = exp_dists / exp_dists.sum(dim=2, keepdim=True)
+                new_points = (new_points * weights).sum(dim=2, keepdim=True)
+            elif pooling == "max_and_avg":
+                new_points = torch.cat([new_points.mean(dim=2, keepdim=True), new_points.amax(dim=2, keepdim=True)],
+                                       dim=-1)
+            else:
+                raise ValueError("unknown pooling %r" % pooling)
+        if mlp2 is not None:
+            for i, cout in enumerate(mlp2):
+                new_points = tf_util.conv2d(new_points, cout, [1, 1], padding="VALID", stride=[1, 1], bn=bn,
+                                            is_training=is_training, scope="conv_post_%d" % i, bn_decay=bn_decay)
+        new_points = new_points.squeeze(2)
+        return new_xyz, new_points, idx
+
+
+def pointnet_sa_module_msg(xyz, points, npoint, radius_list, nsample_list, mlp_list, is_training, bn_decay, scope,
+                           bn=True, use_xyz=True, use_nchw=False):
+    """Multi-scale grouping SA module (:219-282): one FPS, per scale ball query +
+    group + MLP + max; NOTE the concat order here is [features, xyz] (:259), unlike
+    sample_and_group.  -> new_xyz, new_points (B,npoint,sum mlp[k][-1])."""
+    require_cuda(xyz, points)
+    with tf_util.variable_scope(scope):
+        xyz = xyz.contiguous()
+        new_xyz = gather_point(xyz, farthest_point_sample(npoint, xyz))
+        outs = []
+        for i, (radius, nsample) in enumerate(zip(radius_list, nsample_list)):
+            idx, _ = query_ball_point(radius, nsample, xyz, new_xyz)
+            grouped_xyz = group_point(xyz, idx) - new_xyz.unsqueeze(2)
+            if points is not None:
+                grouped_points = group_point(points, idx)
+                if use_xyz:
+                    grouped_points = torch.cat([grouped_points, grouped_xyz], dim=-1)
+            else:
+                grouped_points = grouped_xyz
+            pool_ok = (not is_training) and (nsample == 16 or nsample % 32 == 0)
+            for j, cout in enumerate(mlp_list[i]):
+                last = j == len(mlp_list[i]) - 1
+                grouped_points = tf_util.conv2d(grouped_points, cout, [1, 1], padding="VALID", stride=[1, 1], bn=bn,
+                                                is_training=is_training, scope="conv%d_%d" % (i, j),
+                                                bn_decay=bn_decay, pool=nsample if (last and pool_ok) else 0)
+            if pool_ok:
+                outs.append(grouped_points.squeeze(2))
+            else:
+                outs.append(grouped_points.amax(dim=2))
+        return new_xyz, torch.cat(outs, dim=-1)
+
+
+def _fp_interp_concat(dist, idx, points1, points2):
+    b, n, _ = dist.shape
+    m, c2 = points2.shape[1], points2.shape[2]
+    c1 = 0 if points1 is None else points1.shape[2]
+    out = torch.empty((b, n, c1 + c2), dtype=torch.float32, device=dist.device)
+    p1 = None if points1 is None else points1.contiguous()
+    p2 = points2.contiguous()
+    with torch.cuda.device(dist.device):
+        check(lib.pn2_fp_interp_concat(b, n, m, c1, c2, ptr(dist), ptr(idx), ptr(p1), ptr(p2), ptr(out),
+                                       stream_ptr()), "pn2_fp_interp_concat")
+    return out
+
+
+def pointnet_fp_module(xyz1, xyz2, points1, points2, mlp, is_training, bn_decay, scope, bn=True):
+    """Feature propagation: xyz1 (B,n1,3) dense, xyz2 (B,n2,3) sparse, points1 (B,n1,c1) or None,
+    points2 (B,n2,c2) -> (B,n1,mlp[-1])."""
+    require_cuda(xyz1, xyz2, points1, points2)
+    with tf_util.variable_scope(scope):
+        dist, idx = three_nn(xyz1, xyz2)
+        if not is_training:
+            new_points1 = _fp_interp_concat(dist, idx, points1, points2)  # weights + interpolate + concat fused
+        else:
+            dist = torch.clamp(dist, min=1e-10)
+            norm = (1.0 / dist).sum(dim=2, keepdim=True)
+            weight = (1.0 / dist) / norm
+            interpolated = three_interpolate(points2, idx, weight)
+            new_points1 = torch.cat([interpolated, points1], dim=2) if points1 is not None else interpolated
+        new_points1 = new_points1.unsqueeze(2)
+        for i, cout in enumerate(mlp):
+            new_points1 = tf_util.conv2d(new_points1, cout, [1, 1], padding="VALID", stride=[1, 1], bn=bn,
+                                         is_training=is_training, scope="conv_%d" % i, bn_decay=bn_decay)
+        return new_points1.squeeze(2)

@@ -1,0 +1,248 @@
+"""Layer helpers with the reference's names and maths, torch/HIP underneath.
+
+Mirrors the subset of util/tf_util.py the SA/FP stack uses: conv2d (1x1 only,
+:128-204), conv1d (kernel 1 only, :54-125), batch norm (:555-581, epsilon 1e-3,
+center+scale, moving averages updated in place), dropout (:646-665), xavier
+weights / zero biases (:30-51,109-111).  TF's implicit variable scopes become an
+explicit VariableStore (name -> tensor) so the reference's functional layer API
+(`scope=` strings) can be kept.
+
+Two execution paths per layer:
+  * is_training=False -> the BatchNorm is folded into (W, b) and the layer runs on
+    the hand-written fp32-MFMA kernels of libpn2_hip.so (pn2_linear / fused SA);
+  * is_training=True  -> differentiable torch ops (batch statistics cannot be
+    fused through; the index/gather ops around it are still the HIP kernels).
+"""
+import contextlib
+import math
+from collections import OrderedDict
+
+import torch
+import torch.nn.functional as F
+
+from .._lib import check, lib, ptr, require_cuda, stream_ptr
+
+BN_EPSILON = 1e-3  # tf.contrib.layers.batch_norm default (tf_util.py:571-581)
+
+
+class VariableStore:
+    """name -> tensor registry standing in for TF's variable scopes."""
+
+    def __init__(self, device="cuda", seed=0):
+        self.device = torch.device(device)
+        self.params = OrderedDict()   # trainable
+        self.buffers = OrderedDict()  # moving averages
+        self._gen = torch.Generator(device="cpu")
+        self._gen.manual_seed(seed)
+        self._folded = {}
+
+    def get_variable(self, name, shape, init):
+        if name not in self.params:
+            self.params[name] = torch.nn.Parameter(init(shape).to(self.device))
+        p = self.params[name]
+        if tuple(p.shape) != tuple(shape):
+            raise ValueError("variable %s exists with shape %s, requested %s" % (name, tuple(p.shape), tuple(shape)))
+        return p
+
+    def get_buffer(self, name, shape, value):
+        if name not in self.buffers:
+            self.buffers[name] = torch.full(shape, float(value), dtype=torch.float32, device=self.device)
+        return self.buffers[name]
+
+    def xavier(self, shape):
+        # tf.contrib.layers.xavier_initializer(uniform=True): limit = sqrt(6 / (fan_in + fan_out))
+        receptive = 1
+        for d in shape[:-2]:
+            receptive *= d
+        fan_in, fan_out = shape[-2] * receptive, shape[-1] * receptive
+        limit = math.sqrt(6.0 / (fan_in + fan_out))
+        return (torch.rand(shape, generator=self._gen, dtype=torch.float32) * 2 - 1) * limit
+
+    def parameters(self):
+        return list(self.params.values())
+
+    def num_parameters(self):
+        return sum(p.numel() for p in self.params.values())
+
+    def state_dict(self):
+        d = OrderedDict((k, v.detach().clone()) for k, v in self.params.items())
+        d.update((k, v.clone()) for k, v in self.buffers.items())
+        return d
+
+    def load_state_dict(self, state):
+        with torch.no_grad():
+            for k, v in state.items():
+                tgt = self.params.get(k, self.buffers.get(k))
+                if tgt is None:
+                    raise KeyError(k)
+                tgt.copy_(v.to(self.device))
+
+    # folded inference weights, cached on the version counters of their sources
+    def folded(self, key, sources, make):
+        stamp = tuple((id(t), t._version) for t in sources)
+        hit = self._folded.get(key)
+        if hit is None or hit[0] != stamp:
+            with torch.no_grad():
+                hit = (stamp, make())
+            self._folded[key] = hit
+        return hit[1]
+
+
+_default_store = None
+_scope_stack = []
+
+
+def get_default_store():
+    global _default_store
+    if _default_store is None:
+        _default_store = VariableStore()
+    return _default_store
+
+
+def set_default_store(store):
+    global _default_store
+    _default_store = store
+    return store
+
+
+@contextlib.contextmanager
+def variable_scope(name):
+    _scope_stack.append(name)
+    try:
+        yield "/".join(_scope_stack)
+    finally:
+        _scope_stack.pop()
+
+
+def _full_name(leaf):
+    return "/".join(_scope_stack + [leaf])
+
+
+def _dense_variables(cin, cout, bn, kernel_shape):
+    st = get_default_store()
+    w = st.get_variable(_full_name("weights"), kernel_shape, st.xavier)
+    b = st.get_variable(_full_name("biases"), (cout,), lambda s: torch.zeros(s))
+    if not bn:
+        return st, w, b, None
+    with variable_scope("bn"):
+        beta = st.get_variable(_full_name("beta"), (cout,), lambda s: torch.zeros(s))
+        gamma = st.get_variable(_full_name("gamma"), (cout,), lambda s: torch.ones(s))
+        mean = st.get_buffer(_full_name("moving_mean"), (cout,), 0.0)
+        var = st.get_buffer(_full_name("moving_variance"), (cout,), 1.0)
+    return st, w, b, (beta, gamma, mean, var)
+
+
+def folded_dense(cin, cout, bn, kernel_shape, pad_to=None):
+    """(W', b') with the inference BatchNorm folded in:
+    y = (x@W + b - mean)/sqrt(var+eps)*gamma + beta = x@(W*s) + ((b-mean)*s + beta)."""
+    st, w, b, bnv = _dense_variables(cin, cout, bn, kernel_shape)
+    key = (_full_name("folded"), pad_to)
+
+    def make():
+        w2 = w.detach().reshape(cin, cout)
+        b2 = b.detach()
+        if bnv is not None:
+            beta, gamma, mean, var = bnv
+            s = gamma.detach() / torch.sqrt(var + BN_EPSILON)
+            w2 = w2 * s
+            b2 = (b2 - mean) * s + beta.detach()
+        if pad_to is not None and cout % pad_to != 0:
+            padc = pad_to - cout % pad_to
+            w2 = F.pad(w2, (0, padc))
+            b2 = F.pad(b2, (0, padc))
+        return w2.contiguous(), b2.contiguous()
+
+    srcs = [w, b] + (list(bnv) if bnv is not None else [])
+    return st.folded(key, srcs, make)
+
+
+def hip_linear(x2d, w, b, relu=True, pool=0):
+    """y = relu?(x2d @ w + b), optional max over groups of `pool` consecutive rows.
+    Thin wrapper over pn2_linear (fp32 MFMA)."""
+    require_cuda(x2d, w, b)
+    rows, cin = x2d.shape
+    cout = w.shape[1]
+    x2d = x2d.contiguous()
+    orows = rows // pool if pool and pool > 1 else rows
+    y = torch.empty((orows, cout), dtype=torch.float32, device=x2d.device)
+    with torch.cuda.device(x2d.device):
+        check(lib.pn2_linear(rows, cin, cout, ptr(x2d), ptr(w), ptr(b), int(bool(relu)), int(pool or 0), ptr(y),
+                             stream_ptr()), "pn2_linear")
+    return y
+
+
+def _batch_norm_train(x, bnv, bn_decay):
+    beta, gamma, mean, var = bnv
+    decay = 0.9 if bn_decay is None else float(bn_decay)  # tf_util.py:571
+    c = x.shape[-1]
+    y = F.batch_norm(x.reshape(-1, c), mean, var, gamma, beta, training=True, momentum=1.0 - decay, eps=BN_EPSILON)
+    return y.reshape(x.shape)
+
+
+def _batch_norm_eval(x, bnv):
+    beta, gamma, mean, var = bnv
+    return (x - mean) / torch.sqrt(var + BN_EPSILON) * gamma + beta
+
+
+def conv2d(inputs, num_output_channels, kernel_size, scope, stride=(1, 1), padding="SAME", data_format="NHWC",
+           use_xavier=True, stddev=1e-3, weight_decay=None, activation_fn=torch.relu, bn=False, bn_decay=None,
+           is_training=None, pool=0):
+    """1x1 conv over an NHWC tensor (B,H,W,C) = matmul over C (tf_util.py:128-204).
+    Only the configuration the SA/FP stack uses is implemented: kernel [1,1],
+    stride [1,1], NHWC.  `pool` (extension): max over groups of `pool` rows of W,
+    fused in the HIP epilogue on the inference path."""
+    if list(kernel_size) != [1, 1] or list(stride) != [1, 1] or data_format != "NHWC":
+        raise NotImplementedError("only 1x1 / stride 1 / NHWC conv2d is on the SA/FP path")
+    if activation_fn not in (torch.relu, None):
+        raise NotImplementedError("activation_fn must be relu or None")
+    cin = inputs.shape[-1]
+    cout = int(num_output_channels)
+    with variable_scope(scope):
+        if not is_training:
+            w2, b2 = folded_dense(cin, cout, bn, (1, 1, cin, cout), pad_to=32)
+            y = hip_linear(inputs.reshape(-1, cin), w2, b2, relu=activation_fn is not None, pool=pool)
+            if y.shape[1] != cout:
+                y = y[:, :cout]
+            lead = list(inputs.shape[:-1])
+            if pool and pool > 1:
+                lead[-1] //= pool
+            return y.reshape(lead + [cout])
+        st, w, b, bnv = _dense_variables(cin, cout, bn, (1, 1, cin, cout))
+        y = inputs @ w.reshape(cin, cout) + b
+        if bnv is not None:
+            y = _batch_norm_train(y, bnv, bn_decay)
+        if activation_fn is not None:
+            y = activation_fn(y)
+        if pool and pool > 1:
+            y = y.reshape(list(y.shape[:-2]) + [y.shape[-2] // pool, pool, cout]).amax(dim=-2)
+        return y
+
+
+def conv1d(inputs, num_output_channels, kernel_size, scope, stride=1, padding="SAME", use_xavier=True,
+           stddev=1e-3, weight_decay=None, activation_fn=torch.relu, bn=False, bn_decay=None, is_training=None):
+    """kernel-1 conv over (B,N,C) (tf_util.py:54-125): same maths as conv2d on (B,N,1,C)."""
+    if kernel_size != 1 or stride != 1:
+        raise NotImplementedError("only kernel 1 / stride 1 conv1d is on the SA/FP path")
+    cin = inputs.shape[-1]
+    cout = int(num_output_channels)
+    with variable_scope(scope):
+        if not is_training:
+            w2, b2 = folded_dense(cin, cout, bn, (1, cin, cout), pad_to=32)
+            y = hip_linear(inputs.reshape(-1, cin), w2, b2, relu=activation_fn is not None)
+            if y.shape[1] != cout:
+                y = y[:, :cout].contiguous()
+            return y.reshape(list(inputs.shape[:-1]) + [cout])
+        st, w, b, bnv = _dense_variables(cin, cout, bn, (1, cin, cout))
+        y = inputs @ w.reshape(cin, cout) + b
+        if bnv is not None:
+            y = _batch_norm_train(y, bnv, bn_decay)
+        if activation_fn is not None:
+            y = activation_fn(y)
+        return y
+
+
+def dropout(inputs, is_training, scope, keep_prob=0.5, noise_shape=None):
+    """tf_util.py:646-665: active only while training."""
+    if is_training:
+        return F.dropout(inputs, p=1.0 - keep_prob, training=True)
+    return inputs

@@ -1,0 +1,213 @@
+"""numpy front-end of the CPU oracle (oracle/pn2_oracle.c) + numpy restatement of
+the grouped shared-MLP maths.
+
+TEST INFRASTRUCTURE ONLY: importable from tests/, __graft_entry__.smoke() and
+bench.py's cpu_baseline leg.  The product package never imports this module.
+
+Function names and argument orders follow the reference's Python op wrappers
+(tf_ops/tf_sampling.py:38,61; tf_ops/tf_grouping.py:13,46; tf_ops/tf_interpolate.py:13,50).
+"""
+import ctypes
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB_PATH = os.path.join(_HERE, "libpn2_oracle.so")
+
+ARITH_STRICT, ARITH_FMA, ARITH_FMA_ALT = 0, 1, 2
+DEFAULT_MODE = ARITH_FMA
+
+
+def build(force=False):
+    src = os.path.join(_HERE, "pn2_oracle.c")
+    if force or not os.path.exists(_LIB_PATH) or os.path.getmtime(_LIB_PATH) < os.path.getmtime(src):
+        subprocess.check_call(["make", "-C", _HERE, "-B", "libpn2_oracle.so"], stdout=subprocess.DEVNULL)
+    return _LIB_PATH
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        build()
+        _lib = ctypes.CDLL(_LIB_PATH)
+    return _lib
+
+
+def _f32(a):
+    return np.ascontiguousarray(a, dtype=np.float32)
+
+
+def _i32(a):
+    return np.ascontiguousarray(a, dtype=np.int32)
+
+
+def _p(a):
+    return a.ctypes.data_as(ctypes.c_void_p)
+
+
+def num_threads():
+    return int(lib().oracle_num_threads())
+
+
+def set_num_threads(t):
+    lib().oracle_set_num_threads(int(t))
+
+
+def farthest_point_sample(npoint, inp, mode=DEFAULT_MODE):
+    inp = _f32(inp)
+    b, n, _ = inp.shape
+    out = np.empty((b, npoint), dtype=np.int32)
+    rc = lib().oracle_fps(b, n, int(npoint), _p(inp), _p(out), int(mode))
+    assert rc == 0, rc
+    return out
+
+
+def gather_point(inp, idx):
+    inp, idx = _f32(inp), _i32(idx)
+    b, n, _ = inp.shape
+    m = idx.shape[1]
+    out = np.empty((b, m, 3), dtype=np.float32)
+    lib().oracle_gather_point(b, n, m, _p(inp), _p(idx), _p(out))
+    return out
+
+
+def gather_point_grad(inp, idx, out_g):
+    inp, idx, out_g = _f32(inp), _i32(idx), _f32(out_g)
+    b, n, _ = inp.shape
+    m = idx.shape[1]
+    inp_g = np.empty((b, n, 3), dtype=np.float32)
+    lib().oracle_gather_point_grad(b, n, m, _p(out_g), _p(idx), _p(inp_g))
+    return inp_g
+
+
+def query_ball_point(radius, nsample, xyz1, xyz2, mode=DEFAULT_MODE):
+    xyz1, xyz2 = _f32(xyz1), _f32(xyz2)
+    b, n, _ = xyz1.shape
+    m = xyz2.shape[1]
+    idx = np.zeros((b, m, nsample), dtype=np.int32)  # zero-fill: documented divergence for empty balls
+    cnt = np.empty((b, m), dtype=np.int32)
+    rc = lib().oracle_query_ball_point(b, n, m, ctypes.c_float(radius), int(nsample), _p(xyz1), _p(xyz2),
+                                       _p(idx), _p(cnt), int(mode))
+    assert rc == 0, rc
+    return idx, cnt
+
+
+def group_point(points, idx):
+    points, idx = _f32(points), _i32(idx)
+    b, n, c = points.shape
+    _, m, ns = idx.shape
+    out = np.empty((b, m, ns, c), dtype=np.float32)
+    lib().oracle_group_point(b, n, c, m, ns, _p(points), _p(idx), _p(out))
+    return out
+
+
+def group_point_grad(points, idx, grad_out):
+    points, idx, grad_out = _f32(points), _i32(idx), _f32(grad_out)
+    b, n, c = points.shape
+    _, m, ns = idx.shape
+    gp = np.empty((b, n, c), dtype=np.float32)
+    lib().oracle_group_point_grad(b, n, c, m, ns, _p(grad_out), _p(idx), _p(gp))
+    return gp
+
+
+def three_nn(xyz1, xyz2):
+    xyz1, xyz2 = _f32(xyz1), _f32(xyz2)
+    b, n, _ = xyz1.shape
+    m = xyz2.shape[1]
+    dist = np.empty((b, n, 3), dtype=np.float32)
+    idx = np.empty((b, n, 3), dtype=np.int32)
+    rc = lib().oracle_three_nn(b, n, m, _p(xyz1), _p(xyz2), _p(dist), _p(idx))
+    assert rc == 0, rc
+    return dist, idx
+
+
+def three_interpolate(points, idx, weight):
+    points, idx, weight = _f32(points), _i32(idx), _f32(weight)
+    b, m, c = points.shape
+    n = idx.shape[1]
+    out = np.empty((b, n, c), dtype=np.float32)
+    lib().oracle_three_interpolate(b, m, c, n, _p(points), _p(idx), _p(weight), _p(out))
+    return out
+
+
+def three_interpolate_grad(points, idx, weight, grad_out):
+    points, idx, weight, grad_out = _f32(points), _i32(idx), _f32(weight), _f32(grad_out)
+    b, m, c = points.shape
+    n = idx.shape[1]
+    gp = np.empty((b, m, c), dtype=np.float32)
+    lib().oracle_three_interpolate_grad(b, n, c, m, _p(grad_out), _p(idx), _p(weight), _p(gp))
+    return gp
+
+
+# ---------------------------------------------------------------------------
+# Layer maths (numpy).  These restate util/pointnet_util.py + util/tf_util.py.
+# `dtype` float64 gives the high-precision oracle the 1e-5 feature tolerance is
+# measured against; float32 gives a same-precision CPU baseline.
+# ---------------------------------------------------------------------------
+BN_EPS = 1e-3  # tf.contrib.layers.batch_norm default epsilon (util/tf_util.py:571-581)
+
+
+def fp_weights(dist):
+    """util/pointnet_util.py:300-303 -- fp32 elementwise, as TF would run it."""
+    dist = np.maximum(_f32(dist), np.float32(1e-10))
+    inv = np.float32(1.0) / dist
+    norm = np.sum(inv, axis=2, keepdims=True, dtype=np.float32)
+    return (inv / norm).astype(np.float32)
+
+
+def conv_bn_relu(x, layer, dtype=np.float64, relu=True):
+    """1x1 conv (= matmul over the last dim) + bias + inference BN + ReLU.
+    util/tf_util.py:181-203 (conv2d), :571-581 (batch_norm, is_training=False):
+    y = (x@W + b - mean) / sqrt(var + 1e-3) * gamma + beta.
+    layer: dict(W (Cin,Cout), b, gamma, beta, mean, var) or with bn=False only W,b."""
+    W = np.asarray(layer["W"], dtype=dtype)
+    y = x.astype(dtype) @ W + np.asarray(layer["b"], dtype=dtype)
+    if layer.get("gamma") is not None:
+        g = np.asarray(layer["gamma"], dtype=dtype)
+        be = np.asarray(layer["beta"], dtype=dtype)
+        mu = np.asarray(layer["mean"], dtype=dtype)
+        var = np.asarray(layer["var"], dtype=dtype)
+        y = (y - mu) / np.sqrt(var + dtype(BN_EPS)) * g + be
+    if relu:
+        y = np.maximum(y, 0)
+    return y
+
+
+def sample_and_group(npoint, radius, nsample, xyz, points, use_xyz=True, mode=DEFAULT_MODE):
+    """util/pointnet_util.py:18-60 (knn=False)."""
+    fidx = farthest_point_sample(npoint, xyz, mode)
+    new_xyz = gather_point(xyz, fidx)
+    idx, _ = query_ball_point(radius, nsample, xyz, new_xyz, mode)
+    grouped_xyz = group_point(xyz, idx) - new_xyz[:, :, None, :]
+    if points is not None:
+        gp = group_point(points, idx)
+        new_points = np.concatenate([grouped_xyz, gp], axis=-1) if use_xyz else gp
+    else:
+        new_points = grouped_xyz
+    return new_xyz, new_points, idx, grouped_xyz
+
+
+def sa_module(xyz, points, npoint, radius, nsample, layers, dtype=np.float64, mode=DEFAULT_MODE):
+    """pointnet_sa_module, pooling='max', mlp2=None, group_all=False, is_training=False
+    (util/pointnet_util.py:98-216)."""
+    new_xyz, new_points, idx, _ = sample_and_group(npoint, radius, nsample, xyz, points, True, mode)
+    h = new_points
+    for layer in layers:
+        h = conv_bn_relu(h, layer, dtype)
+    return new_xyz, h.max(axis=2), idx
+
+
+def fp_module(xyz1, xyz2, points1, points2, layers, dtype=np.float64):
+    """pointnet_fp_module, is_training=False (util/pointnet_util.py:285-326)."""
+    dist, idx = three_nn(xyz1, xyz2)
+    w = fp_weights(dist)
+    interp = three_interpolate(points2, idx, w)
+    h = np.concatenate([interp, points1], axis=2) if points1 is not None else interp
+    for layer in layers:
+        h = conv_bn_relu(h, layer, dtype)
+    return h

@@ -1,0 +1,337 @@
+/*
+ * pn2_oracle.c -- CPU restatement of the reference PointNet++ SA/FP custom ops.
+ *
+ * THIS IS TEST INFRASTRUCTURE, NOT PRODUCT CODE.  Only tests/, the smoke check
+ * in __graft_entry__.py and bench.py's `cpu_baseline` leg may load this library.
+ * The shipped path (open3d-pointnet2-semantic3d_amd/) never links, imports or
+ * falls back to it.
+ *
+ * Every function restates one reference kernel; citations are relative to the
+ * reference checkout (isl-org/Open3D-PointNet2-Semantic3D):
+ *
+ *   oracle_fps                   tf_ops/tf_sampling.cu:111-176  (farthestpointsamplingKernel)
+ *   oracle_gather_point          tf_ops/tf_sampling.cu:178-191  (gatherpointKernel)
+ *   oracle_gather_point_grad     tf_ops/tf_sampling.cu:193-206  (scatteraddpointKernel) + memset tf_sampling.cpp:236
+ *   oracle_query_ball_point      tf_ops/tf_grouping.cu:3-43     (query_ball_point_gpu)
+ *   oracle_group_point           tf_ops/tf_grouping.cu:47-66    (group_point_gpu)
+ *   oracle_group_point_grad      tf_ops/tf_grouping.cu:70-90    (group_point_grad_gpu) + memset tf_grouping.cpp:271
+ *   oracle_three_nn              tf_ops/tf_interpolate.cpp:20-28,213-243 (threenn_cpu -> Open3D KDTreeFlann, fp64)
+ *   oracle_three_interpolate     tf_ops/tf_interpolate.cpp:307-330 (threeinterpolate_cpu)
+ *   oracle_three_interpolate_grad tf_ops/tf_interpolate.cpp:397-421 (threeinterpolate_grad_cpu) + memset :477
+ *
+ * Parity pinning (see DESIGN.md "Oracle"):
+ *   - three_nn is pinned by the reference's own golden vector
+ *     (tf_ops/test_interpolate.py:30-35), reproduced in tests/test_oracle_golden.py.
+ *   - FPS / ball-query / gather / group forward values are NOT pinned by any
+ *     reference test and the reference (CUDA-only kernels, TensorFlow 1.x) cannot
+ *     be built or run in this environment: for those ops parity is "unpinned"
+ *     beyond this restatement.  The one arithmetic degree of freedom the source
+ *     text leaves open -- whether nvcc contracts the squared distance into FMAs
+ *     (the reference sets no -fmad flag, tf_ops/CMakeLists.txt:5,13, so nvcc's
+ *     default --fmad=true applies) -- is exposed as `mode`:
+ *         0 = PN2_ARITH_STRICT : every mul/add rounded separately
+ *         1 = PN2_ARITH_FMA    : fma(dz,dz, fma(dx,dx, dy*dy))   (LLVM/NVPTX
+ *                                DAG-combine order: the first fmul operand of an
+ *                                fadd is the one that is fused) -- default
+ *         2 = PN2_ARITH_FMA_ALT: fma(dz,dz, fma(dy,dy, dx*dx))
+ *     On inputs whose differences/squares/sums are exact in fp32 (the grid
+ *     fixtures) all three modes agree bit-for-bit.
+ *
+ * Third-party arithmetic: three_nn runs inside Open3D (IntelVCL/Open3D @33e46f7,
+ * tf_ops/open3d_builder.cmake:8-9, not vendored) -> KDTreeFlann::SearchKNN ->
+ * FLANN KDTreeSingleIndex with L2<double>.  The KD-tree search is exact (eps=0),
+ * so the published semantics are: exact 3 nearest neighbours of the float64-cast
+ * query among the float64-cast reference points, squared L2 accumulated as
+ * ((0 + dx*dx) + dy*dy) + dz*dz in double (FLANN L2 functor tail loop for
+ * dim=3), ascending, cast to float32.  Tie order among equal distances is
+ * FLANN-internal and unspecified; this oracle resolves ties to the lowest index.
+ *
+ * Build: see oracle/Makefile (gcc -O2 -ffp-contract=off -fopenmp).
+ */
+#include <math.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+
+#define FPS_BLOCK 512 /* tf_sampling.cu:116, launch <<<32,512>>> :220 */
+
+static inline float sqdist_mode(float x1, float y1, float z1, float x2, float y2,
+                                float z2, int mode) {
+    /* tf_sampling.cu:149-150 and tf_grouping.cu:28-30 share this expression:
+     * (x2-x1)*(x2-x1) + (y2-y1)*(y2-y1) + (z2-z1)*(z2-z1) */
+    volatile float dx = x2 - x1; /* volatile: forbid any re-association */
+    volatile float dy = y2 - y1;
+    volatile float dz = z2 - z1;
+    if (mode == 1) {
+        float t = dy * dy;
+        float u = fmaf(dx, dx, t);
+        return fmaf(dz, dz, u);
+    } else if (mode == 2) {
+        float t = dx * dx;
+        float u = fmaf(dy, dy, t);
+        return fmaf(dz, dz, u);
+    } else {
+        volatile float a = dx * dx;
+        volatile float b = dy * dy;
+        volatile float c = dz * dz;
+        volatile float ab = a + b;
+        return ab + c;
+    }
+}
+
+/* ------------------------------------------------------------------------- */
+/* Farthest point sampling: emulates the 512-thread block faithfully, i.e.
+ * per-thread strided scan with strict '>' (tf_sampling.cu:132-157) followed by
+ * the 9-level left-biased shared-memory tree (:160-170).  `temp` is the
+ * (n)-float running-min scratch of one block (tf_sampling.cu:124-126). */
+static void fps_one(int n, int m, const float *xyz, int *idxs, float *temp,
+                    int mode) {
+    float dists[FPS_BLOCK];
+    int dists_i[FPS_BLOCK];
+    if (m <= 0) return; /* :115 */
+    int old = 0;        /* :122 */
+    idxs[0] = old;      /* :123 */
+    for (int j = 0; j < n; ++j) temp[j] = 1e38f; /* :124-126 */
+    for (int j = 1; j < m; ++j) {
+        float x1 = xyz[old * 3 + 0], y1 = xyz[old * 3 + 1], z1 = xyz[old * 3 + 2];
+        for (int t = 0; t < FPS_BLOCK; ++t) {
+            int besti = 0;    /* :132 */
+            float best = -1;  /* :133 */
+            for (int k = t; k < n; k += FPS_BLOCK) {
+                float td = temp[k];
+                float d = sqdist_mode(x1, y1, z1, xyz[k * 3 + 0], xyz[k * 3 + 1],
+                                      xyz[k * 3 + 2], mode);
+                float d2 = d < td ? d : td; /* min(d, td) :151 */
+                if (d2 != td) temp[k] = d2; /* :152 */
+                if (d2 > best) {            /* :153 strict */
+                    best = d2;
+                    besti = k;
+                }
+            }
+            dists[t] = best;
+            dists_i[t] = besti;
+        }
+        for (int u = 0; (1 << u) < FPS_BLOCK; ++u) { /* :160 */
+            int half = FPS_BLOCK >> (u + 1);
+            for (int t = 0; t < half; ++t) {
+                int i1 = (t * 2) << u;
+                int i2 = (t * 2 + 1) << u;
+                if (dists[i1] < dists[i2]) { /* :165 strict */
+                    dists[i1] = dists[i2];
+                    dists_i[i1] = dists_i[i2];
+                }
+            }
+        }
+        old = dists_i[0]; /* :172 */
+        idxs[j] = old;    /* :173 */
+    }
+}
+
+int oracle_fps(int b, int n, int m, const float *inp, int *out, int mode) {
+    if (b <= 0 || n <= 0 || m <= 0 || !inp || !out) return -1;
+    int err = 0;
+#pragma omp parallel for schedule(dynamic, 1)
+    for (int i = 0; i < b; ++i) {
+        float *temp = (float *)malloc(sizeof(float) * (size_t)n);
+        if (!temp) {
+            err = 1;
+            continue;
+        }
+        fps_one(n, m, inp + (size_t)i * n * 3, out + (size_t)i * m, temp, mode);
+        free(temp);
+    }
+    return err ? -2 : 0;
+}
+
+/* ------------------------------------------------------------------------- */
+int oracle_gather_point(int b, int n, int m, const float *inp, const int *idx,
+                        float *out) {
+    for (int i = 0; i < b; ++i)
+        for (int j = 0; j < m; ++j) {
+            int a = idx[(size_t)i * m + j];
+            for (int c = 0; c < 3; ++c)
+                out[((size_t)i * m + j) * 3 + c] = inp[((size_t)i * n + a) * 3 + c];
+        }
+    return 0;
+}
+
+/* grad: zero then scatter-add (CUDA atomics => order unspecified; the oracle
+ * adds in (i, j) order -- tests compare with a tolerance where idx repeats). */
+int oracle_gather_point_grad(int b, int n, int m, const float *out_g,
+                             const int *idx, float *inp_g) {
+    memset(inp_g, 0, sizeof(float) * (size_t)b * n * 3);
+    for (int i = 0; i < b; ++i)
+        for (int j = 0; j < m; ++j) {
+            int a = idx[(size_t)i * m + j];
+            for (int c = 0; c < 3; ++c)
+                inp_g[((size_t)i * n + a) * 3 + c] += out_g[((size_t)i * m + j) * 3 + c];
+        }
+    return 0;
+}
+
+/* ------------------------------------------------------------------------- */
+/* Ball query (tf_grouping.cu:3-43).  Rows with no hit are left untouched by the
+ * reference (uninitialised TF output); the oracle leaves them untouched too, so
+ * callers should pre-fill idx (the HIP path documents zero-fill). */
+int oracle_query_ball_point(int b, int n, int m, float radius, int nsample,
+                            const float *xyz1, const float *xyz2, int *idx,
+                            int *pts_cnt, int mode) {
+    if (b <= 0 || n <= 0 || m <= 0 || nsample <= 0) return -1;
+#pragma omp parallel for collapse(2) schedule(static)
+    for (int bi = 0; bi < b; ++bi) {
+        for (int j = 0; j < m; ++j) {
+            const float *p1 = xyz1 + (size_t)bi * n * 3;
+            const float *p2 = xyz2 + (size_t)bi * m * 3;
+            int *row = idx + ((size_t)bi * m + j) * nsample;
+            int cnt = 0;
+            float x2 = p2[j * 3 + 0], y2 = p2[j * 3 + 1], z2 = p2[j * 3 + 2];
+            for (int k = 0; k < n; ++k) {
+                if (cnt == nsample) break; /* :20-21 */
+                /* note operand order in the reference: (x2 - x1) with x2 the
+                 * query; squares are sign-symmetric so this equals sqdist */
+                float s = sqdist_mode(p1[k * 3 + 0], p1[k * 3 + 1], p1[k * 3 + 2],
+                                      x2, y2, z2, mode);
+                float d = sqrtf(s); /* correctly rounded */
+                if (d < 1e-20f) d = 1e-20f; /* max(.,1e-20f) :28-30 */
+                if (d < radius) {           /* :31 strict, on the sqrt */
+                    if (cnt == 0)
+                        for (int l = 0; l < nsample; ++l) row[l] = k; /* :32-36 */
+                    row[cnt] = k;
+                    cnt += 1;
+                }
+            }
+            pts_cnt[(size_t)bi * m + j] = cnt; /* :41 */
+        }
+    }
+    return 0;
+}
+
+/* ------------------------------------------------------------------------- */
+int oracle_group_point(int b, int n, int c, int m, int nsample,
+                       const float *points, const int *idx, float *out) {
+#pragma omp parallel for collapse(2) schedule(static)
+    for (int bi = 0; bi < b; ++bi)
+        for (int j = 0; j < m; ++j)
+            for (int k = 0; k < nsample; ++k) {
+                int ii = idx[((size_t)bi * m + j) * nsample + k];
+                memcpy(out + (((size_t)bi * m + j) * nsample + k) * c,
+                       points + ((size_t)bi * n + ii) * c, sizeof(float) * (size_t)c);
+            }
+    return 0;
+}
+
+int oracle_group_point_grad(int b, int n, int c, int m, int nsample,
+                            const float *grad_out, const int *idx,
+                            float *grad_points) {
+    memset(grad_points, 0, sizeof(float) * (size_t)b * n * c);
+    for (int bi = 0; bi < b; ++bi)
+        for (int j = 0; j < m; ++j)
+            for (int k = 0; k < nsample; ++k) {
+                int ii = idx[((size_t)bi * m + j) * nsample + k];
+                const float *g = grad_out + (((size_t)bi * m + j) * nsample + k) * c;
+                float *dst = grad_points + ((size_t)bi * n + ii) * c;
+                for (int l = 0; l < c; ++l) dst[l] += g[l];
+            }
+    return 0;
+}
+
+/* ------------------------------------------------------------------------- */
+/* three_nn: exact 3-NN in float64 (see header).  xyz1 (b,n,3) unknown points,
+ * xyz2 (b,m,3) known points; dist (b,n,3) squared L2 ascending, idx (b,n,3).
+ * Requires m >= 3 (the reference would read garbage from a short FLANN result). */
+int oracle_three_nn(int b, int n, int m, const float *xyz1, const float *xyz2,
+                    float *dist, int *idx) {
+    if (b <= 0 || n <= 0 || m < 3) return -1;
+#pragma omp parallel for collapse(2) schedule(static)
+    for (int bi = 0; bi < b; ++bi) {
+        for (int j = 0; j < n; ++j) {
+            const float *q = xyz1 + ((size_t)bi * n + j) * 3;
+            const float *r = xyz2 + (size_t)bi * m * 3;
+            double qx = q[0], qy = q[1], qz = q[2]; /* tf_interpolate.cpp:20-28 */
+            double b1 = INFINITY, b2 = INFINITY, b3 = INFINITY;
+            int i1 = 0, i2 = 0, i3 = 0;
+            for (int k = 0; k < m; ++k) {
+                volatile double dx = qx - (double)r[k * 3 + 0];
+                volatile double dy = qy - (double)r[k * 3 + 1];
+                volatile double dz = qz - (double)r[k * 3 + 2];
+                volatile double xx = dx * dx;
+                volatile double yy = dy * dy;
+                volatile double zz = dz * dz;
+                volatile double s0 = xx + yy;
+                double d = s0 + zz; /* ((0+dx^2)+dy^2)+dz^2 */
+                if (d < b1) {
+                    b3 = b2; i3 = i2;
+                    b2 = b1; i2 = i1;
+                    b1 = d;  i1 = k;
+                } else if (d < b2) {
+                    b3 = b2; i3 = i2;
+                    b2 = d;  i2 = k;
+                } else if (d < b3) {
+                    b3 = d;  i3 = k;
+                }
+            }
+            size_t o = ((size_t)bi * n + j) * 3;
+            dist[o + 0] = (float)b1; dist[o + 1] = (float)b2; dist[o + 2] = (float)b3;
+            idx[o + 0] = i1; idx[o + 1] = i2; idx[o + 2] = i3;
+        }
+    }
+    return 0;
+}
+
+/* three_interpolate: out = (p1*w1 + p2*w2) + p3*w3 in fp32, unfused (host build
+ * has -O3 without -mfma: tf_ops/CMakeLists.txt:13). */
+int oracle_three_interpolate(int b, int m, int c, int n, const float *points,
+                             const int *idx, const float *weight, float *out) {
+#pragma omp parallel for collapse(2) schedule(static)
+    for (int i = 0; i < b; ++i)
+        for (int j = 0; j < n; ++j) {
+            const float *pts = points + (size_t)i * m * c;
+            size_t o = ((size_t)i * n + j) * 3;
+            float w1 = weight[o], w2 = weight[o + 1], w3 = weight[o + 2];
+            int i1 = idx[o], i2 = idx[o + 1], i3 = idx[o + 2];
+            float *dst = out + ((size_t)i * n + j) * c;
+            for (int l = 0; l < c; ++l) {
+                volatile float a = pts[(size_t)i1 * c + l] * w1;
+                volatile float bb = pts[(size_t)i2 * c + l] * w2;
+                volatile float cc = pts[(size_t)i3 * c + l] * w3;
+                volatile float ab = a + bb;
+                dst[l] = ab + cc;
+            }
+        }
+    return 0;
+}
+
+/* grad wrt points: zero, then serial scatter-add in (i, j, l) order, three adds
+ * per element in neighbour order 1,2,3 (tf_interpolate.cpp:411-415). */
+int oracle_three_interpolate_grad(int b, int n, int c, int m,
+                                  const float *grad_out, const int *idx,
+                                  const float *weight, float *grad_points) {
+    memset(grad_points, 0, sizeof(float) * (size_t)b * m * c);
+    for (int i = 0; i < b; ++i)
+        for (int j = 0; j < n; ++j) {
+            size_t o = ((size_t)i * n + j) * 3;
+            float w1 = weight[o], w2 = weight[o + 1], w3 = weight[o + 2];
+            int i1 = idx[o], i2 = idx[o + 1], i3 = idx[o + 2];
+            const float *g = grad_out + ((size_t)i * n + j) * c;
+            float *gp = grad_points + (size_t)i * m * c;
+            for (int l = 0; l < c; ++l) {
+                volatile float t1 = g[l] * w1;
+                volatile float t2 = g[l] * w2;
+                volatile float t3 = g[l] * w3;
+                gp[(size_t)i1 * c + l] += t1;
+                gp[(size_t)i2 * c + l] += t2;
+                gp[(size_t)i3 * c + l] += t3;
+            }
+        }
+    return 0;
+}
+
+/* Number of OpenMP threads the library will use (for cpu_baseline.cores). */
+#ifdef _OPENMP
+#include <omp.h>
+int oracle_num_threads(void) { return omp_get_max_threads(); }
+void oracle_set_num_threads(int t) { omp_set_num_threads(t); }
+#else
+int oracle_num_threads(void) { return 1; }
+void oracle_set_num_threads(int t) { (void)t; }
+#endif

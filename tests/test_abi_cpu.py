@@ -1,0 +1,70 @@
+"""CPU tests of the drop-in boundary: the C-ABI library loads without a GPU, exports every
+symbol include/pn2_abi.h declares, and validates arguments before touching the device."""
+import ctypes
+import os
+import re
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared():
+    src = open(os.path.join(ROOT, "include", "pn2_abi.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(pn2_[a-z0-9_]+)\s*\(", src)))
+
+
+def test_header_declares_the_nine_reference_ops():
+    names = _declared()
+    for n in ["pn2_farthest_point_sample", "pn2_gather_point", "pn2_gather_point_grad", "pn2_query_ball_point",
+              "pn2_group_point", "pn2_group_point_grad", "pn2_three_nn", "pn2_three_interpolate",
+              "pn2_three_interpolate_grad", "pn2_sa_mlp_max_fused", "pn2_linear", "pn2_fp_interp_concat"]:
+        assert n in names
+
+
+def test_library_exports_every_declared_symbol(pn2):
+    lib = ctypes.CDLL(pn2._lib.LIB_PATH)
+    for n in _declared():
+        assert hasattr(lib, n), n
+    assert pn2._lib.lib.pn2_abi_version() == 1
+    assert b"gfx950" in pn2._lib.lib.pn2_build_info()
+
+
+def test_python_signatures_cover_the_header(pn2):
+    decl = set(_declared()) - {"pn2_abi_version", "pn2_build_info", "pn2_strerror"}
+    assert decl <= set(pn2._lib.SIGNATURES) | {"pn2_sa_group_concat"}
+
+
+def test_argument_validation_needs_no_gpu(pn2):
+    L = pn2._lib.lib
+    nul = None
+    assert L.pn2_farthest_point_sample(0, 8, 4, nul, nul, nul, 1, nul) == -1      # PN2_EINVAL
+    assert L.pn2_farthest_point_sample(1, 8, 4, nul, nul, nul, 1, nul) == -2      # PN2_ENULL
+    assert L.pn2_query_ball_point(1, 8, 4, 0.0, 4, nul, nul, nul, nul, 1, nul) == -1  # radius must be > 0
+    assert L.pn2_query_ball_point(1, 8, 4, 0.5, 0, nul, nul, nul, nul, 1, nul) == -1  # nsample must be > 0
+    assert L.pn2_three_nn(1, 8, 2, nul, nul, nul, nul, nul) == -1                  # needs >= 3 known points
+    assert L.pn2_group_point(1, 8, 0, 4, 4, nul, nul, nul, nul) == -1
+    assert b"PN2_ENULL" in L.pn2_strerror(-2)
+
+
+def test_ops_refuse_cpu_tensors_loudly(pn2):
+    import torch
+    x = torch.zeros(1, 16, 3)
+    with pytest.raises(ValueError, match="MI355X only"):
+        pn2.farthest_point_sample(4, x)
+    with pytest.raises(ValueError, match="MI355X only"):
+        pn2.three_nn(x, x)
+    with pytest.raises(ValueError, match="positive npoint"):
+        pn2.farthest_point_sample(0, x)
+    with pytest.raises(ValueError, match="positive radius"):
+        pn2.query_ball_point(-1.0, 4, x, x)
+
+
+def test_product_package_never_imports_the_oracle():
+    pkg = os.path.join(ROOT, "open3d-pointnet2-semantic3d_amd")
+    for dp, _, fs in os.walk(pkg):
+        for f in fs:
+            if f.endswith((".py", ".hip", ".h")):
+                txt = open(os.path.join(dp, f)).read()
+                assert "import oracle" not in txt and "from oracle" not in txt and "pn2_oracle" not in txt, f

@@ -1,0 +1,303 @@
+"""GPU parity tests: every HIP op, called through the C ABI (ctypes), against the CPU oracle on
+the same seeded inputs.  Index outputs must be bit-exact; float copies bit-exact; scatter-add
+gradients within fp32 summation-order tolerance."""
+import os
+
+import numpy as np
+import pytest
+
+from conftest import s_grid, s_randn, s_scene
+
+pytestmark = pytest.mark.gpu
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def T(a, dev):
+    import torch
+    return torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+
+
+@pytest.fixture(autouse=True)
+def _reset_mode(pn2):
+    pn2.config.arith_mode = pn2.config.ARITH_FMA
+    yield
+    pn2.config.arith_mode = pn2.config.ARITH_FMA
+
+
+# ------------------------------------------------------------------ FPS -------------------
+@pytest.mark.parametrize("n,m", [(64, 16), (256, 64), (500, 100), (1024, 256), (1500, 200), (3000, 300),
+                                 (4096, 512), (8192, 1024), (10000, 64)])
+def test_fps_grid_bit_exact_all_modes(pn2, oracle, cuda, n, m):
+    x = s_grid(n, 3, n, 64 if n < 5000 else 1024)  # coarse grid: exact arithmetic + many ties
+    ref = oracle.farthest_point_sample(m, x, 0)
+    for mode in (0, 1, 2):
+        pn2.config.arith_mode = mode
+        got = pn2.farthest_point_sample(m, T(x, cuda)).cpu().numpy()
+        assert got.dtype == np.int32 and got.shape == (3, m)
+        assert np.array_equal(got, ref), "mode %d first diff at %s" % (mode, np.argwhere(got != ref)[:3])
+
+
+@pytest.mark.parametrize("mode", [0, 1, 2])
+@pytest.mark.parametrize("gen", ["randn", "scene"])
+def test_fps_float_inputs_bit_exact_per_mode(pn2, oracle, cuda, mode, gen):
+    x = s_randn(11, 4, 2048) if gen == "randn" else s_scene(12, 4, 2048)
+    pn2.config.arith_mode = mode
+    got = pn2.farthest_point_sample(512, T(x, cuda)).cpu().numpy()
+    assert np.array_equal(got, oracle.farthest_point_sample(512, x, mode))
+
+
+def test_fps_duplicates_and_degenerate(pn2, oracle, cuda):
+    x = np.ones((2, 700, 3), np.float32)  # all identical: every round is an all-way tie
+    assert pn2.farthest_point_sample(6, T(x, cuda)).cpu().numpy().tolist() == [[0] * 6] * 2
+    x = s_grid(5, 2, 1300, 16)  # duplicated points (dataset up-sampling duplicates short clouds)
+    assert np.array_equal(pn2.farthest_point_sample(300, T(x, cuda)).cpu().numpy(),
+                          oracle.farthest_point_sample(300, x))
+    x = s_randn(6, 1, 3)  # n < one wave, m == n
+    assert np.array_equal(pn2.farthest_point_sample(3, T(x, cuda)).cpu().numpy(),
+                          oracle.farthest_point_sample(3, x))
+    assert pn2.farthest_point_sample(1, T(x, cuda)).cpu().numpy().tolist() == [[0]]
+
+
+def test_fps_streaming_kernel_large_n(pn2, oracle, cuda):
+    x = s_scene(8, 2, 20000)  # n > 16384 -> global-scratch kernel
+    assert np.array_equal(pn2.farthest_point_sample(40, T(x, cuda)).cpu().numpy(),
+                          oracle.farthest_point_sample(40, x))
+    x = s_grid(9, 34, 17000, 32)[:, :, :]  # b > 32: blocks stride over the batch with the (32,n) scratch
+    assert np.array_equal(pn2.farthest_point_sample(6, T(x, cuda)).cpu().numpy(),
+                          oracle.farthest_point_sample(6, x))
+
+
+def test_fps_full_size_sa1(pn2, oracle, cuda):
+    """BASELINE config[1] SA1 shape B=16,N=8192,M=1024: oracle on 2 batch elements + properties on all."""
+    import torch
+    x = s_scene(0, 16, 8192)
+    got = pn2.farthest_point_sample(1024, T(x, cuda)).cpu().numpy()
+    ref = oracle.farthest_point_sample(1024, x[:2])
+    assert np.array_equal(got[:2], ref)
+    assert (got[:, 0] == 0).all()
+    for b in range(16):
+        assert len(np.unique(got[b])) == 1024  # continuous data: no duplicates
+    # farthest-point property: the distance of each pick to the already-picked set is non-increasing
+    p = x[3][got[3]].astype(np.float64)
+    d = np.full(1024, np.inf)
+    seq = []
+    for j in range(1, 200):
+        d = np.minimum(d, ((p - p[j - 1]) ** 2).sum(1))
+        seq.append(d[j])
+    assert all(seq[i] >= seq[i + 1] - 1e-9 for i in range(len(seq) - 1))
+
+
+def test_golden_fixtures_on_gpu(pn2, cuda):
+    g = np.load(os.path.join(GOLD, "oracle_small.npz"))
+    rs = np.random.RandomState(7)
+    xyz = rs.random_sample((2, 1024, 3)).astype(np.float32)
+    for mode in (0, 1, 2):
+        pn2.config.arith_mode = mode
+        f = pn2.farthest_point_sample(256, T(xyz, cuda))
+        assert np.array_equal(f.cpu().numpy(), g["cfg0_fps_m%d" % mode])
+        idx, cnt = pn2.query_ball_point(0.2, 16, T(xyz, cuda), pn2.gather_point(T(xyz, cuda), f))
+        assert np.array_equal(idx.cpu().numpy(), g["cfg0_bq_idx_m%d" % mode])
+        assert np.array_equal(cnt.cpu().numpy(), g["cfg0_bq_cnt_m%d" % mode])
+
+
+def test_three_nn_reference_golden_vector_on_gpu(pn2, cuda):
+    """The reference's own KAT (tf_ops/test_interpolate.py:30-35) through the HIP kernel."""
+    g = np.load(os.path.join(GOLD, "reference_three_nn.npz"))
+    np.random.seed(int(g["seed"]))
+    target = np.random.random(tuple(g["target_shape"])).astype("float32")
+    reference = np.random.random(tuple(g["reference_shape"])).astype("float32")
+    dist, idx = pn2.three_nn(T(target[:4], cuda), T(reference[:4], cuda))
+    dist, idx = dist.cpu().numpy(), idx.cpu().numpy()
+    assert (idx[:3, :3, :1].flatten() == g["idx"]).all()
+    assert np.array2string(dist[:3, :3, :1].flatten()) == str(g["printed"])
+
+
+# ------------------------------------------------------------------ gather ----------------
+def test_gather_point_and_grad(pn2, oracle, cuda):
+    import torch
+    rs = np.random.RandomState(1)
+    x = s_randn(1, 3, 777)
+    idx = rs.randint(0, 777, (3, 130)).astype(np.int32)
+    xt = T(x, cuda).requires_grad_(True)
+    out = pn2.gather_point(xt, T(idx, cuda))
+    assert np.array_equal(out.detach().cpu().numpy(), oracle.gather_point(x, idx))
+    go = rs.randn(3, 130, 3).astype(np.float32)
+    out.backward(T(go, cuda))
+    assert np.allclose(xt.grad.cpu().numpy(), oracle.gather_point_grad(x, idx, go), rtol=1e-5, atol=1e-6)
+
+
+# ------------------------------------------------------------------ ball query ------------
+@pytest.mark.parametrize("n,m,ns,r", [(64, 8, 4, 0.3), (300, 37, 16, 0.2), (1000, 130, 32, 0.15), (1500, 200, 32, 0.25),
+                                      (2048, 256, 64, 0.3), (130, 130, 8, 2.0)])
+def test_ball_query_grid_bit_exact_all_modes(pn2, oracle, cuda, n, m, ns, r):
+    x = s_grid(n + 1, 2, n, 64)
+    q = x[:, :m].copy()
+    q[:, ::3] += np.float32(1.0 / 128)  # off-grid-by-half queries too (still exact arithmetic)
+    ri, rc = oracle.query_ball_point(r, ns, x, q, 0)
+    for mode in (0, 1, 2):
+        pn2.config.arith_mode = mode
+        gi, gc = pn2.query_ball_point(r, ns, T(x, cuda), T(q, cuda))
+        assert np.array_equal(gc.cpu().numpy(), rc)
+        assert np.array_equal(gi.cpu().numpy(), ri)
+
+
+@pytest.mark.parametrize("mode", [0, 1, 2])
+def test_ball_query_float_inputs(pn2, oracle, cuda, mode):
+    pn2.config.arith_mode = mode
+    for x, r in ((s_randn(21, 3, 3000), 0.5), (s_scene(22, 3, 3000), 0.5), (s_scene(23, 3, 3000), 2.0)):
+        f = oracle.farthest_point_sample(200, x, mode)
+        q = oracle.gather_point(x, f)
+        gi, gc = pn2.query_ball_point(r, 32, T(x, cuda), T(q, cuda))
+        ri, rc = oracle.query_ball_point(r, 32, x, q, mode)
+        assert np.array_equal(gc.cpu().numpy(), rc) and np.array_equal(gi.cpu().numpy(), ri)
+        assert rc.min() >= 1  # queries are dataset points
+
+
+def test_ball_query_radius_boundary_is_exact(pn2, oracle, cuda):
+    """Distances exactly equal to / one ulp around the radius: the sqrt-free threshold must agree
+    with `sqrtf(d2) < r` (strict) for every candidate."""
+    rs = np.random.RandomState(5)
+    for r in (0.25, 0.3, 0.1, 1.0, 0.7071068, 3.0):
+        r32 = np.float32(r)
+        # points on the x axis at distances r-2ulp .. r+2ulp from the query at the origin
+        ds = [r32]
+        for _ in range(3):
+            ds.append(np.nextafter(ds[-1], np.float32(10)))
+        lo = r32
+        for _ in range(3):
+            lo = np.nextafter(lo, np.float32(0))
+            ds.append(lo)
+        pts = np.zeros((1, 64, 3), np.float32)
+        pts[0, :len(ds), 0] = np.array(ds, np.float32)
+        pts[0, len(ds):, :] = 50 + rs.rand(64 - len(ds), 3)
+        q = np.zeros((1, 1, 3), np.float32)
+        pts[0, 20] = 0  # the query itself
+        for mode in (0, 1, 2):
+            pn2.config.arith_mode = mode
+            gi, gc = pn2.query_ball_point(float(r32), 16, T(pts, cuda), T(q, cuda))
+            ri, rc = oracle.query_ball_point(float(r32), 16, pts, q, mode)
+            assert np.array_equal(gc.cpu().numpy(), rc) and np.array_equal(gi.cpu().numpy(), ri), (r, mode)
+
+
+def test_ball_query_empty_ball_and_full_ball(pn2, oracle, cuda):
+    x = s_grid(31, 1, 500, 64)
+    q = np.concatenate([np.full((1, 1, 3), 100.0, np.float32), x[:, :3]], axis=1)
+    gi, gc = pn2.query_ball_point(0.1, 8, T(x, cuda), T(q, cuda))
+    gi, gc = gi.cpu().numpy(), gc.cpu().numpy()
+    assert gc[0, 0] == 0 and (gi[0, 0] == 0).all()  # documented: empty rows are zero-filled
+    ri, rc = oracle.query_ball_point(0.1, 8, x, q)
+    assert np.array_equal(gi, ri) and np.array_equal(gc, rc)
+    gi, gc = pn2.query_ball_point(10.0, 8, T(x, cuda), T(q[:, 1:], cuda))  # everything is inside: first 8 indices
+    assert (gi.cpu().numpy() == np.arange(8)).all() and (gc.cpu().numpy() == 8).all()
+
+
+def test_ball_query_full_size_sa1(pn2, oracle, cuda):
+    x = s_scene(0, 16, 8192)
+    f = oracle.farthest_point_sample(1024, x[:2])
+    fx = pn2.farthest_point_sample(1024, T(x, cuda))
+    q = pn2.gather_point(T(x, cuda), fx)
+    gi, gc = pn2.query_ball_point(0.5, 32, T(x, cuda), q)
+    gi, gc = gi.cpu().numpy(), gc.cpu().numpy()
+    ri, rc = oracle.query_ball_point(0.5, 32, x[:2], oracle.gather_point(x[:2], f))
+    assert np.array_equal(gi[:2], ri) and np.array_equal(gc[:2], rc)
+    # size-independent properties on all 16 batch elements
+    qn = q.cpu().numpy()
+    assert gc.min() >= 1 and gc.max() <= 32
+    for b in (5, 11, 15):
+        for j in range(0, 1024, 97):
+            c = gc[b, j]
+            row = gi[b, j]
+            assert (np.diff(row[:c]) > 0).all()          # index order, no repeats among real hits
+            assert (row[c:] == row[0]).all()             # padding = first hit
+            d = np.sqrt(((x[b][row[:c]] - qn[b, j]) ** 2).sum(1))
+            assert (d < 0.5 + 1e-6).all()
+
+
+# ------------------------------------------------------------------ group ------------------
+@pytest.mark.parametrize("c", [1, 3, 4, 6, 64, 67, 128])
+def test_group_point_bit_exact_and_grad(pn2, oracle, cuda, c):
+    import torch
+    rs = np.random.RandomState(c)
+    pts = rs.randn(3, 500, c).astype(np.float32)
+    idx = rs.randint(0, 500, (3, 70, 16)).astype(np.int32)
+    pt = T(pts, cuda).requires_grad_(True)
+    out = pn2.group_point(pt, T(idx, cuda))
+    assert np.array_equal(out.detach().cpu().numpy(), oracle.group_point(pts, idx))
+    go = rs.randn(*out.shape).astype(np.float32)
+    out.backward(T(go, cuda))
+    ref = oracle.group_point_grad(pts, idx, go)
+    assert np.allclose(pt.grad.cpu().numpy(), ref, rtol=1e-5, atol=1e-5)
+
+
+def test_group_point_reference_gradient_check_shape(pn2, oracle, cuda):
+    """tf_ops/test_tf_ops.py:38-56: points (1,128,16), ball query r=0.3 K=32 on (1,128,3)/(1,8,3);
+    the Jacobian of group_point w.r.t. points must match finite differences (< 1e-4).  group_point is
+    linear in points, so J^T g == group_point_grad(g) exactly up to fp32 summation."""
+    import torch
+    rs = np.random.RandomState(0)
+    points = rs.random_sample((1, 128, 16)).astype(np.float32)
+    xyz1 = rs.random_sample((1, 128, 3)).astype(np.float32)
+    xyz2 = rs.random_sample((1, 8, 3)).astype(np.float32)
+    idx, cnt = pn2.query_ball_point(0.3, 32, T(xyz1, cuda), T(xyz2, cuda))
+    ri, rc = oracle.query_ball_point(0.3, 32, xyz1, xyz2)
+    assert np.array_equal(idx.cpu().numpy(), ri)
+    pt = T(points, cuda).requires_grad_(True)
+    out = pn2.group_point(pt, idx)
+    # finite-difference check along random directions (linear op: exact up to rounding)
+    for s in range(4):
+        v = np.random.RandomState(s).randn(*points.shape).astype(np.float32)
+        g = np.random.RandomState(10 + s).randn(*out.shape).astype(np.float32)
+        (gp,) = torch.autograd.grad(out, pt, T(g, cuda), retain_graph=True)
+        lhs = float((gp.cpu().numpy().astype(np.float64) * v).sum())
+        rhs = float((oracle.group_point(v, ri).astype(np.float64) * g).sum())
+        assert abs(lhs - rhs) < 1e-4 * max(1.0, abs(rhs))
+
+
+# ------------------------------------------------------------------ three_nn / interpolate --
+@pytest.mark.parametrize("n,m", [(64, 16), (100, 3), (1000, 250), (3000, 2100), (8192, 1024)])
+def test_three_nn_bit_exact(pn2, oracle, cuda, n, m):
+    a = s_randn(n, 2, n)
+    r = s_randn(m + 7, 2, m)
+    d, i = pn2.three_nn(T(a, cuda), T(r, cuda))
+    rd, ri = oracle.three_nn(a, r)
+    assert np.array_equal(i.cpu().numpy(), ri)
+    assert np.array_equal(d.cpu().numpy(), rd)
+
+
+def test_three_nn_ties_lowest_index(pn2, oracle, cuda):
+    a = s_grid(1, 2, 400, 8)
+    r = s_grid(2, 2, 90, 8)  # 512 positions, many equidistant neighbours
+    d, i = pn2.three_nn(T(a, cuda), T(r, cuda))
+    rd, ri = oracle.three_nn(a, r)
+    assert np.array_equal(i.cpu().numpy(), ri) and np.array_equal(d.cpu().numpy(), rd)
+
+
+@pytest.mark.parametrize("c", [1, 5, 16, 64, 128, 131])
+def test_three_interpolate_bit_exact_and_grad(pn2, oracle, cuda, c):
+    import torch
+    rs = np.random.RandomState(c)
+    pts = rs.randn(2, 60, c).astype(np.float32)
+    idx = rs.randint(0, 60, (2, 333, 3)).astype(np.int32)
+    w = rs.rand(2, 333, 3).astype(np.float32)
+    w /= w.sum(2, keepdims=True)
+    pt = T(pts, cuda).requires_grad_(True)
+    out = pn2.three_interpolate(pt, T(idx, cuda), T(w, cuda))
+    assert np.array_equal(out.detach().cpu().numpy(), oracle.three_interpolate(pts, idx, w))
+    go = rs.randn(*out.shape).astype(np.float32)
+    out.backward(T(go, cuda))
+    ref = oracle.three_interpolate_grad(pts, idx, w, go)
+    assert np.allclose(pt.grad.cpu().numpy(), ref, rtol=1e-4, atol=1e-5)
+
+
+def test_three_interpolate_reference_shapes(pn2, oracle, cuda):
+    """tf_ops/test_tf_ops.py:59-78: seed 100; three_nn((32,512,3),(32,128,3)), weights 1/3, pts (32,128,64)."""
+    np.random.seed(100)
+    pts = np.random.random((32, 128, 64)).astype("float32")
+    tmp1 = np.random.random((32, 512, 3)).astype("float32")
+    tmp2 = np.random.random((32, 128, 3)).astype("float32")
+    d, i = pn2.three_nn(T(tmp1, cuda), T(tmp2, cuda))
+    rd, ri = oracle.three_nn(tmp1, tmp2)
+    assert np.array_equal(i.cpu().numpy(), ri) and np.array_equal(d.cpu().numpy(), rd)
+    w = np.ones_like(rd) / np.float32(3.0)
+    out = pn2.three_interpolate(T(pts, cuda), i, T(w, cuda))
+    assert np.array_equal(out.cpu().numpy(), oracle.three_interpolate(pts, ri, w))

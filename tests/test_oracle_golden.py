@@ -1,0 +1,147 @@
+"""CPU tests: the oracle against the reference's known-answer vector and the frozen fixtures."""
+import os
+
+import numpy as np
+import pytest
+
+from conftest import s_grid, s_scene
+
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def test_three_nn_reference_golden_vector(oracle):
+    """tf_ops/test_interpolate.py:30-35 of the reference -- its only forward KAT for this path."""
+    g = np.load(os.path.join(GOLD, "reference_three_nn.npz"))
+    np.random.seed(int(g["seed"]))
+    target = np.random.random(tuple(g["target_shape"])).astype("float32")
+    reference = np.random.random(tuple(g["reference_shape"])).astype("float32")
+    dist, idx = oracle.three_nn(target[:3], reference[:3])  # the KAT only inspects [:3, :3, :1]
+    got_d = dist[:3, :3, :1].flatten()
+    got_i = idx[:3, :3, :1].flatten()
+    assert (got_i == g["idx"]).all()
+    # the reference prints with numpy's default 8 significant digits
+    assert np.abs(got_d.astype(np.float64) - g["dist"]).max() < 5.1e-9
+    assert np.array2string(got_d) == str(g["printed"])
+    assert dist.dtype == np.float32 and idx.dtype == np.int32
+
+
+def test_three_nn_matches_kdtree_float64(oracle):
+    """Independent check of the fp64 semantics with scipy's exact KD-tree."""
+    from scipy.spatial import cKDTree
+    rs = np.random.RandomState(1)
+    a = rs.random_sample((2, 500, 3)).astype(np.float32)
+    r = rs.random_sample((2, 64, 3)).astype(np.float32)
+    dist, idx = oracle.three_nn(a, r)
+    for b in range(2):
+        d, i = cKDTree(r[b].astype(np.float64)).query(a[b].astype(np.float64), k=3)
+        assert (i == idx[b]).all()
+        assert np.array_equal((d ** 2).astype(np.float32), dist[b]) or np.allclose((d ** 2), dist[b], rtol=3e-7, atol=0)
+
+
+def test_frozen_fixtures(oracle):
+    g = np.load(os.path.join(GOLD, "oracle_small.npz"))
+    rs = np.random.RandomState(7)
+    xyz = rs.random_sample((2, 1024, 3)).astype(np.float32)
+    feat = rs.random_sample((2, 1024, 3)).astype(np.float32)
+    for mode in (0, 1, 2):
+        f = oracle.farthest_point_sample(256, xyz, mode)
+        assert (f == g["cfg0_fps_m%d" % mode]).all()
+        idx, cnt = oracle.query_ball_point(0.2, 16, xyz, oracle.gather_point(xyz, f), mode)
+        assert (idx == g["cfg0_bq_idx_m%d" % mode]).all() and (cnt == g["cfg0_bq_cnt_m%d" % mode]).all()
+    gr = s_grid(3, 2, 1500, 64)
+    for mode in (0, 1, 2):  # exact arithmetic: all modes identical
+        fg = oracle.farthest_point_sample(200, gr, mode)
+        assert (fg == g["grid_fps"]).all()
+        gi, gc = oracle.query_ball_point(0.25, 32, gr, oracle.gather_point(gr, fg), mode)
+        assert (gi == g["grid_bq_idx"]).all() and (gc == g["grid_bq_cnt"]).all()
+    sc = s_scene(5, 1, 2048)
+    fs = oracle.farthest_point_sample(256, sc)
+    assert (fs == g["scene_fps"]).all()
+    f = g["cfg0_fps_m1"]
+    d, i3 = oracle.three_nn(xyz, oracle.gather_point(xyz, f))
+    assert np.array_equal(d, g["cfg0_nn_dist"]) and (i3 == g["cfg0_nn_idx"]).all()
+    out = oracle.three_interpolate(oracle.gather_point(feat, f), i3, oracle.fp_weights(d))
+    assert np.array_equal(out, g["cfg0_interp"])
+
+
+def _fps_by_key(x, m):
+    """FPS with the tie-break written as an explicit sort key (max dist, k mod 512, k): the
+    closed form of what the 512-thread block + tree of tf_sampling.cu:153-170 computes."""
+    n = len(x)
+    md = np.full(n, 1e38, np.float32)
+    k = np.arange(n)
+    key = (k % 512) * (1 << 22) + k // 512
+    out, old = [0], 0
+    for _ in range(1, m):
+        dd = (x - x[old]) ** 2
+        d = ((dd[:, 0] + dd[:, 1]) + dd[:, 2]).astype(np.float32)
+        md = np.minimum(md, d)
+        c = np.where(md == md.max())[0]
+        old = int(c[np.argmin(key[c])])
+        out.append(old)
+    return np.array(out)
+
+
+def test_fps_tie_break_closed_form(oracle):
+    """The block emulation equals the closed-form key on tie-heavy grid inputs (incl. duplicates)."""
+    x = s_grid(0, 3, 1300, 16)  # 4096 distinct positions for 1300 points -> many duplicates / ties
+    f = oracle.farthest_point_sample(150, x, 0)
+    for b in range(3):
+        assert (_fps_by_key(x[b], 150) == f[b]).all()
+    assert f[:, 0].tolist() == [0, 0, 0]
+
+
+def test_fps_all_points_identical(oracle):
+    x = np.ones((1, 700, 3), np.float32)
+    f = oracle.farthest_point_sample(5, x)
+    assert f.tolist() == [[0, 0, 0, 0, 0]]  # all distances 0: thread 0 / k=0 wins every round
+
+
+def test_ball_query_semantics(oracle):
+    rs = np.random.RandomState(2)
+    xyz = rs.random_sample((1, 300, 3)).astype(np.float32)
+    q = xyz[:, :10].copy()
+    idx, cnt = oracle.query_ball_point(0.15, 8, xyz, q, 0)
+    for j in range(10):
+        d = np.sqrt(((xyz[0] - q[0, j]) ** 2).sum(1, dtype=np.float32)).astype(np.float32)
+        hits = np.where(d < np.float32(0.15))[0]
+        c = min(len(hits), 8)
+        assert cnt[0, j] == c and c >= 1  # a query that is a dataset point always finds itself
+        assert (idx[0, j, :c] == hits[:c]).all()
+        assert (idx[0, j, c:] == hits[0]).all()  # padded with the FIRST hit
+    # a far-away query: empty ball -> count 0, row zero-filled (documented divergence)
+    far = np.full((1, 1, 3), 100.0, np.float32)
+    idx, cnt = oracle.query_ball_point(0.15, 8, xyz, far, 0)
+    assert cnt[0, 0] == 0 and (idx == 0).all()
+
+
+def test_group_and_grads_small(oracle):
+    rs = np.random.RandomState(3)
+    pts = rs.random_sample((2, 20, 5)).astype(np.float32)
+    idx = rs.randint(0, 20, (2, 4, 6)).astype(np.int32)
+    out = oracle.group_point(pts, idx)
+    for b in range(2):
+        assert np.array_equal(out[b], pts[b][idx[b]])
+    go = rs.random_sample(out.shape).astype(np.float32)
+    gp = oracle.group_point_grad(pts, idx, go)
+    ref = np.zeros_like(pts, dtype=np.float64)
+    for b in range(2):
+        np.add.at(ref[b], idx[b].reshape(-1), go[b].reshape(-1, 5))
+    assert np.allclose(gp, ref, rtol=1e-6, atol=1e-6)
+    w = rs.random_sample((2, 7, 3)).astype(np.float32)
+    i3 = rs.randint(0, 20, (2, 7, 3)).astype(np.int32)
+    o = oracle.three_interpolate(pts, i3, w)
+    ref = sum(pts[np.arange(2)[:, None], i3[:, :, t]] * w[:, :, t:t + 1] for t in range(3))
+    assert np.allclose(o, ref, rtol=1e-6, atol=1e-6)
+
+
+def test_mlp_oracle_bn_fold(oracle):
+    """conv_bn_relu == the folded (W', b') form the HIP path consumes."""
+    rs = np.random.RandomState(4)
+    x = rs.randn(50, 7)
+    layer = dict(W=rs.randn(7, 5), b=rs.randn(5), gamma=rs.rand(5) + 0.5, beta=rs.randn(5), mean=rs.randn(5),
+                 var=rs.rand(5) + 0.1)
+    y = oracle.conv_bn_relu(x, layer)
+    s = layer["gamma"] / np.sqrt(layer["var"] + 1e-3)
+    y2 = np.maximum(x @ (layer["W"] * s) + ((layer["b"] - layer["mean"]) * s + layer["beta"]), 0)
+    assert np.allclose(y, y2, rtol=1e-12, atol=1e-12)
