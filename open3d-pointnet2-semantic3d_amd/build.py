@@ -16,7 +16,7 @@ LIB = os.path.join(HERE, "libpn2_hip.so")
 SOURCES = ["pn2_abi.hip", "pn2_sampling.hip", "pn2_grouping.hip", "pn2_interpolate.hip",
            "pn2_linear.hip", "pn2_sa_fused.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off",
-         "-munsafe-fp-atomics", "-fno-gpu-rdc", "-Wall", "-Wno-unused-function"]
+         "-munsafe-fp-atomics", "-fno-gpu-rdc", "-fno-slp-vectorize", "-Wall", "-Wno-unused-function"]
 
 
 def _hipcc():
@@ -35,15 +35,18 @@ def _stale():
     return any(os.path.getmtime(d) > t for d in deps)
 
 
-def build(force=False, verbose=False):
-    if not force and not _stale():
+def build(force=False, verbose=False, extra_flags=(), out=None):
+    """extra_flags/out: build an experimental variant next to the default library (tools/ A/B runs)."""
+    if out is None and not force and not _stale():
         return LIB
     hipcc = _hipcc()
+    target = out or LIB
+    tag = "" if out is None else "." + os.path.basename(out).replace(".so", "")
     objs = []
     procs = []
     for src in SOURCES:
-        obj = os.path.join(CSRC, src.replace(".hip", ".o"))
-        cmd = [hipcc] + FLAGS + ["-c", os.path.join(CSRC, src), "-o", obj]
+        obj = os.path.join(CSRC, src.replace(".hip", tag + ".o"))
+        cmd = [hipcc] + FLAGS + list(extra_flags) + ["-c", os.path.join(CSRC, src), "-o", obj]
         if verbose:
             print(" ".join(cmd))
         procs.append((src, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)))
@@ -58,9 +61,9 @@ def build(force=False, verbose=False):
             print(out.decode(errors="replace"))
     if failed:
         raise RuntimeError("libpn2_hip.so build failed")
-    cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs
+    cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", target] + objs
     subprocess.check_call(cmd)
-    return LIB
+    return target
 
 
 if __name__ == "__main__":

@@ -26,44 +26,102 @@ constexpr int kFpsSlotsMax = 16;  // waves per workgroup <= 16
 __device__ __forceinline__ unsigned fps_tiekey(int k) {
     return (((unsigned)k & 511u) << 22) | ((unsigned)k >> 9);
 }
-
-// Merge per-wave candidates; returns the winning index (uniform).
-__device__ __forceinline__ int fps_merge_waves(unsigned long long* slots, int nwaves,
-                                               int lane) {
-    unsigned long long v = lane < nwaves ? slots[lane] : 0ull;
-    v = pn2_row0_u64max(v);
-    unsigned key = ~(unsigned)v;  // tiekey of the winner
+__device__ __forceinline__ int fps_untiekey(unsigned key) {
     return (int)(((key & 0x3FFFFFu) << 9) | (key >> 22));
 }
 
-// Per-wave candidate from per-thread (best, bestk): uniform 64-bit key.
-__device__ __forceinline__ unsigned long long fps_wave_candidate(float best, int bestk) {
-    const bool valid = best >= 0.0f;  // threads without points keep best = -1 (tf_sampling.cu:133)
-    const unsigned bits = valid ? __float_as_uint(best) : 0u;
-    const unsigned wmax = pn2_wave_umax(bits);
-    const unsigned long long mask = __ballot(valid && bits == wmax);
-    if (mask == 0ull) return 0ull;  // whole wave has no point
-    const int src = __ffsll((long long)mask) - 1;  // lowest lane = lowest residue
-    const int kw = __builtin_amdgcn_readlane(bestk, src);
-    return ((unsigned long long)wmax << 32) | (unsigned)(~fps_tiekey(kw));
+// Fused-DPP wave64 reductions on 32-bit keys (one VALU op per step; the s_nop 1
+// are the 2 wait states a DPP read needs after a VALU write of the same VGPR).
+// All distances are >= +0, so their bit patterns order like signed/unsigned ints;
+// the sentinel -1.0f (threads without points) is a negative int.
+__device__ __forceinline__ int wave_imax(int v) {
+    asm volatile(
+        "s_nop 1\n"
+        "v_max_i32_dpp %0, %0, %0 row_shr:1 row_mask:0xf bank_mask:0xf\n s_nop 1\n"
+        "v_max_i32_dpp %0, %0, %0 row_shr:2 row_mask:0xf bank_mask:0xf\n s_nop 1\n"
+        "v_max_i32_dpp %0, %0, %0 row_shr:4 row_mask:0xf bank_mask:0xf\n s_nop 1\n"
+        "v_max_i32_dpp %0, %0, %0 row_shr:8 row_mask:0xf bank_mask:0xf\n s_nop 1\n"
+        "v_max_i32_dpp %0, %0, %0 row_bcast:15 row_mask:0xa bank_mask:0xf\n s_nop 1\n"
+        "v_max_i32_dpp %0, %0, %0 row_bcast:31 row_mask:0xc bank_mask:0xf\n s_nop 1\n"
+        : "+v"(v));
+    return __builtin_amdgcn_readlane(v, 63);
+}
+// max over lanes 0..15 (row 0), result from lane 15
+__device__ __forceinline__ int row0_imax(int v) {
+    asm volatile(
+        "s_nop 1\n"
+        "v_max_i32_dpp %0, %0, %0 row_shr:1 row_mask:0xf bank_mask:0xf\n s_nop 1\n"
+        "v_max_i32_dpp %0, %0, %0 row_shr:2 row_mask:0xf bank_mask:0xf\n s_nop 1\n"
+        "v_max_i32_dpp %0, %0, %0 row_shr:4 row_mask:0xf bank_mask:0xf\n s_nop 1\n"
+        "v_max_i32_dpp %0, %0, %0 row_shr:8 row_mask:0xf bank_mask:0xf\n s_nop 1\n"
+        : "+v"(v));
+    return __builtin_amdgcn_readlane(v, 15);
+}
+__device__ __forceinline__ unsigned row0_umin(unsigned v) {
+    asm volatile(
+        "s_nop 1\n"
+        "v_min_u32_dpp %0, %0, %0 row_shr:1 row_mask:0xf bank_mask:0xf\n s_nop 1\n"
+        "v_min_u32_dpp %0, %0, %0 row_shr:2 row_mask:0xf bank_mask:0xf\n s_nop 1\n"
+        "v_min_u32_dpp %0, %0, %0 row_shr:4 row_mask:0xf bank_mask:0xf\n s_nop 1\n"
+        "v_min_u32_dpp %0, %0, %0 row_shr:8 row_mask:0xf bank_mask:0xf\n s_nop 1\n"
+        : "+v"(v));
+    return (unsigned)__builtin_amdgcn_readlane((int)v, 15);
 }
 
+// Merge the per-wave candidates {dist bits, tiekey}; returns the winning index (uniform).
+// Value-only max first; the 64-bit order (dist desc, tiekey asc) is only resolved on ties.
+__device__ __forceinline__ int fps_merge_waves(const uint2* slots, int nwaves, int lane) {
+    uint2 sv = make_uint2(0x80000000u, 0xFFFFFFFFu);  // "no candidate": negative as int
+    if (lane < nwaves) sv = slots[lane];
+    const int vmax = row0_imax((int)sv.x);
+    const unsigned long long tie = __ballot((int)sv.x == vmax) & 0xFFFFull;
+    unsigned key;
+    if (__popcll(tie) == 1) {
+        key = (unsigned)__builtin_amdgcn_readlane((int)sv.y, __ffsll((long long)tie) - 1);
+    } else {
+        key = row0_umin((int)sv.x == vmax ? sv.y : 0xFFFFFFFFu);
+    }
+    return fps_untiekey(key);
+}
+
+// Generic per-wave candidate from a per-thread (best, bestk) pair (used by the streaming kernel).
+__device__ __forceinline__ uint2 fps_wave_candidate(float best, int bestk) {
+    const int bits = __float_as_int(best);  // -1.0f sentinel is negative
+    const int wmax = wave_imax(bits);
+    if (wmax < 0) return make_uint2(0x80000000u, 0xFFFFFFFFu);
+    const unsigned long long mask = __ballot(bits == wmax);
+    const int src = __ffsll((long long)mask) - 1;  // lowest lane = lowest residue (NT % 512 == 0)
+    const int kw = __builtin_amdgcn_readlane(bestk, src);
+    return make_uint2((unsigned)wmax, fps_tiekey(kw));
+}
+
+// NT threads, thread t owns points k = t + NT*i (i < PPT) in VGPRs for the whole kernel.
+// Requires NT % 512 == 0 (all points of a thread share the residue t mod 512, scanned in ascending
+// k) or PPT == 1 (k == t).  A round:
+//   1. distance update (fp32 sub/mul/fma: 2-cycle VALU pipe) + integer min / max3 (4-cycle pipe);
+//   2. wave max of the VALUE by fused DPP; only the lanes holding that value (normally one) look
+//      up which of their points it was and publish the 64-bit key
+//          (dist bits << 32) | ~((k & 511) << 22 | k >> 9)
+//      with ONE LDS atomic max -- the LDS unit resolves the reference tie-break
+//      (max dist, then k mod 512, then k) across lanes and waves;
+//   3. one barrier, one broadcast read of the key, one broadcast read of the winner's xyz.
+// Three key slots rotate so the reset of a slot never races with its readers.
 template <int NT, int PPT, int MODE, bool LDS_XYZ>
 __global__ void __launch_bounds__(NT)
 fps_reg_kernel(int n, int m, const float* __restrict__ xyz_all, int* __restrict__ out_all) {
+    static_assert(NT % 512 == 0 || PPT == 1, "tie-break argument needs NT % 512 == 0 or one point per thread");
+    static_assert(NT != 64 || PPT == 1, "single-wave path keeps one point per lane");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    // layout: [2][16] u64 slots | float4 xyz[n] (if LDS_XYZ)
+    // layout: 4 x u64 key slots (3 used) | float4 xyz[n] (if LDS_XYZ)
     unsigned long long* slots = reinterpret_cast<unsigned long long*>(smem);
-    float4* sxyz = reinterpret_cast<float4*>(smem + 2 * kFpsSlotsMax * sizeof(unsigned long long));
+    float4* sxyz = reinterpret_cast<float4*>(smem + 4 * sizeof(unsigned long long));
 
     const int tid = threadIdx.x;
-    const int lane = tid & 63;
-    const int wave = tid >> 6;
-    constexpr int NW = NT / 64;
     const float* __restrict__ xyz = xyz_all + (size_t)blockIdx.x * n * 3;
     int* __restrict__ out = out_all + (size_t)blockIdx.x * m;
 
-    float px[PPT], py[PPT], pz[PPT], md[PPT];
+    float px[PPT], py[PPT], pz[PPT];
+    int md[PPT];  // running min distance as int bits (>= 0), or bits(-1.0f) for "no point"
 #pragma unroll
     for (int i = 0; i < PPT; ++i) {
         const int k = tid + NT * i;
@@ -71,43 +129,73 @@ fps_reg_kernel(int n, int m, const float* __restrict__ xyz_all, int* __restrict_
             px[i] = xyz[k * 3 + 0];
             py[i] = xyz[k * 3 + 1];
             pz[i] = xyz[k * 3 + 2];
-            md[i] = 1e38f;  // tf_sampling.cu:124-126
+            md[i] = __float_as_int(1e38f);  // tf_sampling.cu:124-126
             if constexpr (LDS_XYZ) sxyz[k] = make_float4(px[i], py[i], pz[i], 0.f);
         } else {
             px[i] = py[i] = pz[i] = 0.f;
-            md[i] = -1.0f;  // never beats best = -1 under strict '>'
+            md[i] = __float_as_int(-1.0f);  // never selected: stays below every real distance
         }
     }
+    if (tid < 4) slots[tid] = 0ull;
     if (tid == 0) out[0] = 0;  // first pick is index 0 (tf_sampling.cu:122-123)
     __syncthreads();
 
+    // tiekey(tid + NT*i) = keybase + i * (NT >> 9)   (NT % 512 == 0; PPT == 1 otherwise)
+    const unsigned keybase = fps_tiekey(tid);
     int old = 0;
+    int slot = 1;  // j % 3
+    float nx1 = xyz[0], ny1 = xyz[1], nz1 = xyz[2];  // NT == 64 path: coordinates of the current pick
     for (int j = 1; j < m; ++j) {
         float x1, y1, z1;
-        if constexpr (LDS_XYZ) {
+        if constexpr (NT == 64) {
+            x1 = nx1; y1 = ny1; z1 = nz1;
+        } else if constexpr (LDS_XYZ) {
             const float4 p = sxyz[old];
             x1 = p.x; y1 = p.y; z1 = p.z;
         } else {
             x1 = xyz[old * 3 + 0]; y1 = xyz[old * 3 + 1]; z1 = xyz[old * 3 + 2];
         }
-        float best = -1.0f;
-        int bestk = 0;
+        int best = __float_as_int(-1.0f);
 #pragma unroll
         for (int i = 0; i < PPT; ++i) {
             const float d = pn2_sqdist<MODE>(px[i] - x1, py[i] - y1, pz[i] - z1);
-            const float d2 = fminf(d, md[i]);  // min(d, td) :151
-            md[i] = d2;
-            if (d2 > best) {  // strict, ascending k :153
-                best = d2;
-                bestk = tid + NT * i;
-            }
+            const int di = __float_as_int(d);   // d >= +0: int order == float order
+            md[i] = di < md[i] ? di : md[i];    // min(d, td) :151
+            best = md[i] > best ? md[i] : best;
         }
-        const unsigned long long cand = fps_wave_candidate(best, bestk);
-        unsigned long long* s = slots + (j & 1) * kFpsSlotsMax;
-        if (lane == 0) s[wave] = cand;
+        const int wmax = wave_imax(best);
+        if constexpr (NT == 64) {
+            // one wave, one point per lane: winner = lowest lane holding the max; its coordinates are
+            // fetched with v_readlane -- no LDS, no barrier in the round
+            const int src = __ffsll((long long)__ballot(best == wmax)) - 1;
+            old = src;
+            nx1 = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(px[0]), src));
+            ny1 = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(py[0]), src));
+            nz1 = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(pz[0]), src));
+            if (tid == 0) out[j] = old;
+            continue;
+        }
+        if (best == wmax && wmax >= 0) {  // normally a single lane of the wave
+            int istar = 0;
+#pragma unroll
+            for (int i = PPT - 1; i >= 0; --i)
+                if (md[i] == best) istar = i;  // first (lowest-k) maximal point of this thread
+            const unsigned key = keybase + (unsigned)istar * (unsigned)(NT >> 9);
+            // one ds_max_u64 per winning lane (normally exactly one per wave); written as asm so the
+            // compiler's uniform-address atomic optimiser does not wrap it in a per-lane scalar loop
+            const unsigned long long comp = ((unsigned long long)(unsigned)wmax << 32) | (unsigned)(~key);
+            const unsigned saddr = (unsigned)(size_t)(&slots[slot]);  // LDS byte address (low 32 bits of the generic pointer)
+            asm volatile("ds_max_u64 %0, %1\n s_waitcnt lgkmcnt(0)" : : "v"(saddr), "v"(comp) : "memory");
+        }
         __syncthreads();
-        old = fps_merge_waves(s, NW, lane);
-        if (tid == 0) out[j] = old;
+        const unsigned long long win = slots[slot];
+        old = fps_untiekey(~(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)win));
+        const int nxt = slot == 2 ? 0 : slot + 1;          // (j+1) % 3
+        if (tid == 0) {
+            slots[nxt == 2 ? 0 : nxt + 1] = 0ull;          // (j+2) % 3: last read after barrier j-1, next used in round j+2
+            out[j] = old;
+        }
+        slot = nxt;
     }
 }
 
@@ -120,7 +208,7 @@ __global__ void __launch_bounds__(1024)
 fps_stream_kernel(int b, int n, int m, const float* __restrict__ xyz_all,
                   float* __restrict__ temp_all, int* __restrict__ out_all) {
     constexpr int NT = 1024;
-    __shared__ unsigned long long slots[2 * kFpsSlotsMax];
+    __shared__ uint2 slots[2 * kFpsSlotsMax];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     float* __restrict__ temp = temp_all + (size_t)blockIdx.x * n;
     for (int bi = blockIdx.x; bi < b; bi += gridDim.x) {
@@ -142,8 +230,8 @@ fps_stream_kernel(int b, int n, int m, const float* __restrict__ xyz_all,
                 if (d2 != td) temp[k] = d2;
                 if (d2 > best) { best = d2; bestk = k; }
             }
-            const unsigned long long cand = fps_wave_candidate(best, bestk);
-            unsigned long long* s = slots + (j & 1) * kFpsSlotsMax;
+            const uint2 cand = fps_wave_candidate(best, bestk);
+            uint2* s = slots + (j & 1) * kFpsSlotsMax;
             if (lane == 0) s[wave] = cand;
             __syncthreads();
             old = fps_merge_waves(s, NT / 64, lane);
@@ -155,7 +243,7 @@ fps_stream_kernel(int b, int n, int m, const float* __restrict__ xyz_all,
 
 template <int NT, int PPT, int MODE>
 int launch_fps_reg(int b, int n, int m, const float* inp, int* out, hipStream_t st) {
-    const size_t slots_bytes = 2 * kFpsSlotsMax * sizeof(unsigned long long);
+    const size_t slots_bytes = 4 * sizeof(unsigned long long);
     const size_t xyz_bytes = (size_t)n * sizeof(float4);
     // 160 KiB LDS per CU; keep the cloud in LDS when it fits (n <= 8192 -> 128 KiB)
     if (slots_bytes + xyz_bytes <= 144 * 1024) {
@@ -172,12 +260,22 @@ int launch_fps_reg(int b, int n, int m, const float* inp, int* out, hipStream_t 
     return PN2_OK;
 }
 
+int g_fps_variant = 0;  // tuning hook (pn2_debug_set(0, v)): 0 = default, 512 = 512-thread blocks for n in (1024, 8192]
+
 template <int MODE>
 int dispatch_fps(int b, int n, int m, const float* inp, float* temp, int* out, hipStream_t st) {
-    // NT must be a multiple of 512 (tie-break argument in the file header).
+    // NT % 512 == 0, or one point per thread (see fps_reg_kernel).
+    if (n <= 64) return launch_fps_reg<64, 1, MODE>(b, n, m, inp, out, st);
+    if (n <= 128) return launch_fps_reg<128, 1, MODE>(b, n, m, inp, out, st);
+    if (n <= 256) return launch_fps_reg<256, 1, MODE>(b, n, m, inp, out, st);
     if (n <= 512) return launch_fps_reg<512, 1, MODE>(b, n, m, inp, out, st);
-    if (n <= 1024) return launch_fps_reg<512, 2, MODE>(b, n, m, inp, out, st);
-    if (n <= 2048) return launch_fps_reg<512, 4, MODE>(b, n, m, inp, out, st);
+    if (n <= 1024) return launch_fps_reg<1024, 1, MODE>(b, n, m, inp, out, st);
+    if (g_fps_variant == 512) {
+        if (n <= 2048) return launch_fps_reg<512, 4, MODE>(b, n, m, inp, out, st);
+        if (n <= 4096) return launch_fps_reg<512, 8, MODE>(b, n, m, inp, out, st);
+        if (n <= 8192) return launch_fps_reg<512, 16, MODE>(b, n, m, inp, out, st);
+    }
+    if (n <= 2048) return launch_fps_reg<1024, 2, MODE>(b, n, m, inp, out, st);
     if (n <= 4096) return launch_fps_reg<1024, 4, MODE>(b, n, m, inp, out, st);
     if (n <= 8192) return launch_fps_reg<1024, 8, MODE>(b, n, m, inp, out, st);
     if (n <= 16384) return launch_fps_reg<1024, 16, MODE>(b, n, m, inp, out, st);
@@ -224,6 +322,12 @@ inline int grid_for(long long total, int block) {
 }
 
 }  // namespace
+
+// undocumented tuning/experiment hook (not part of the ABI header)
+extern "C" int pn2_debug_set(int what, int value) {
+    if (what == 0) { g_fps_variant = value; return 0; }
+    return PN2_EINVAL;
+}
 
 extern "C" int pn2_farthest_point_sample(int b, int n, int m, const float* inp, float* temp,
                                          int* out, int arith_mode, void* stream) {
