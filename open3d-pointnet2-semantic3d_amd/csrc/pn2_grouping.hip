@@ -41,20 +41,29 @@ float ball_threshold(float radius) {
 constexpr int kBqThreads = 256;
 constexpr int kBqWaves = kBqThreads / 64;
 
+struct BqChunk { float x, y, z; };
+
+// One wave64 owns QPW queries.  The dataset streams through registers 64 candidates at a time
+// (one global_load_dwordx3 per lane per chunk, shared by the QPW queries, prefetched chunks
+// ahead with unconditional clamped loads so the compiler can keep counted vmcnt waits); hits are
+// appended in lane order == index order into an LDS row buffer and the finished rows are written
+// to HBM once, coalesced.  No VMEM store inside the scan loop.
 template <int MODE, int QPW>
 __global__ void __launch_bounds__(kBqThreads)
 ball_query_kernel(int n, int m, float thr, int nsample, const float* __restrict__ xyz1_all,
                   const float* __restrict__ xyz2_all, int* __restrict__ idx_all,
                   int* __restrict__ cnt_all) {
+    extern __shared__ int srows[];  // [kBqWaves][QPW][nsample]
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int bi = blockIdx.y;
     const int q0 = (blockIdx.x * kBqWaves + wave) * QPW;
     if (q0 >= m) return;  // wave-uniform; the kernel has no barriers
-    const float* __restrict__ xyz1 = xyz1_all + (size_t)bi * n * 3;
+    const BqChunk* __restrict__ xyz1 = reinterpret_cast<const BqChunk*>(xyz1_all + (size_t)bi * n * 3);
     const float* __restrict__ xyz2 = xyz2_all + (size_t)bi * m * 3;
     int* __restrict__ idx = idx_all + ((size_t)bi * m + q0) * nsample;
     int* __restrict__ cnt_out = cnt_all + (size_t)bi * m + q0;
+    int* srow = srows + wave * QPW * nsample;
 
     float qx[QPW], qy[QPW], qz[QPW];
     int cnt[QPW], first[QPW];
@@ -68,35 +77,46 @@ ball_query_kernel(int n, int m, float thr, int nsample, const float* __restrict_
         first[q] = 0;
     }
 
-    // software prefetch of the next 64 candidates
-    int k = lane;
-    float cx = 0.f, cy = 0.f, cz = 0.f;
-    if (k < n) { cx = xyz1[k * 3 + 0]; cy = xyz1[k * 3 + 1]; cz = xyz1[k * 3 + 2]; }
-    for (int c0 = 0; c0 < n; c0 += 64) {
-        const int kn = c0 + 64 + lane;
-        float nx = 0.f, ny = 0.f, nz = 0.f;
-        if (kn < n) { nx = xyz1[kn * 3 + 0]; ny = xyz1[kn * 3 + 1]; nz = xyz1[kn * 3 + 2]; }
+    const int last = n - 1;
+    auto load = [&](int c0) {  // unconditional: out-of-range lanes re-read the last point (masked by `valid`)
+        const int kk = c0 + lane;
+        return xyz1[kk < last ? kk : last];
+    };
+    // scan one 64-candidate chunk held in `cur`; returns true when every query of the wave is full
+    auto scan = [&](const BqChunk& cur, int c0) -> bool {
+        const int k = c0 + lane;
         const bool valid = k < n;
         bool all_full = true;
 #pragma unroll
         for (int q = 0; q < QPW; ++q) {
             if (cnt[q] < nsample) {  // wave-uniform (tf_grouping.cu:20-21)
-                const float s = pn2_sqdist<MODE>(qx[q] - cx, qy[q] - cy, qz[q] - cz);
+                const float s = pn2_sqdist<MODE>(qx[q] - cur.x, qy[q] - cur.y, qz[q] - cur.z);
                 const bool hit = valid && (s <= thr);
                 const unsigned long long mask = __ballot(hit);
                 if (mask != 0ull) {
                     const int pos = cnt[q] + (int)__builtin_amdgcn_mbcnt_hi(
                                                  (unsigned)(mask >> 32),
                                                  __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0u));
-                    if (hit && pos < nsample) idx[q * nsample + pos] = k;
+                    if (hit && pos < nsample) srow[q * nsample + pos] = k;
                     if (cnt[q] == 0) first[q] = c0 + __ffsll((long long)mask) - 1;
                     cnt[q] += __popcll(mask);
                 }
                 all_full = all_full && (cnt[q] >= nsample);
             }
         }
-        if (all_full) break;
-        k = kn; cx = nx; cy = ny; cz = nz;
+        return all_full;
+    };
+    // 4 chunk registers rotate by name (loop unrolled x4): three loads stay in flight per wave
+    BqChunk r0 = load(0), r1 = load(64), r2 = load(128), r3 = load(192);
+    for (int c0 = 0; c0 < n; c0 += 256) {
+        if (scan(r0, c0)) break;
+        r0 = load(c0 + 256);
+        if (c0 + 64 >= n || scan(r1, c0 + 64)) break;
+        r1 = load(c0 + 320);
+        if (c0 + 128 >= n || scan(r2, c0 + 128)) break;
+        r2 = load(c0 + 384);
+        if (c0 + 192 >= n || scan(r3, c0 + 192)) break;
+        r3 = load(c0 + 448);
     }
 #pragma unroll
     for (int q = 0; q < QPW; ++q) {
@@ -105,20 +125,35 @@ ball_query_kernel(int n, int m, float thr, int nsample, const float* __restrict_
             // short rows: remaining slots repeat the first hit (tf_grouping.cu:32-36);
             // empty rows are zero-filled (documented divergence: reference leaves them uninitialised)
             const int fill = c > 0 ? first[q] : 0;
-            for (int l = c + lane; l < nsample; l += 64) idx[q * nsample + l] = fill;
+            for (int l = lane; l < nsample; l += 64)
+                idx[q * nsample + l] = l < c ? srow[q * nsample + l] : fill;
             if (lane == 0) cnt_out[q] = c;  // tf_grouping.cu:41
         }
     }
 }
 
+int g_bq_qpw = 8;  // tuning hook (pn2_debug_set(1, v))
+
+template <int MODE, int QPW>
+int launch_ball_query_q(int b, int n, int m, float thr, int nsample, const float* xyz1,
+                        const float* xyz2, int* idx, int* cnt, hipStream_t st) {
+    dim3 grid((m + kBqWaves * QPW - 1) / (kBqWaves * QPW), b);
+    const size_t lds = (size_t)kBqWaves * QPW * nsample * sizeof(int);
+    if (lds > 64 * 1024) return PN2_ERANGE;
+    ball_query_kernel<MODE, QPW><<<grid, kBqThreads, lds, st>>>(n, m, thr, nsample, xyz1, xyz2, idx, cnt);
+    PN2_RETURN_IF_LAUNCH_FAILED();
+    return PN2_OK;
+}
+
 template <int MODE>
 int launch_ball_query(int b, int n, int m, float thr, int nsample, const float* xyz1,
                       const float* xyz2, int* idx, int* cnt, hipStream_t st) {
-    constexpr int QPW = 8;
-    dim3 grid((m + kBqWaves * QPW - 1) / (kBqWaves * QPW), b);
-    ball_query_kernel<MODE, QPW><<<grid, kBqThreads, 0, st>>>(n, m, thr, nsample, xyz1, xyz2, idx, cnt);
-    PN2_RETURN_IF_LAUNCH_FAILED();
-    return PN2_OK;
+    // fewer queries per wave when there are too few queries to fill the chip (>= ~4 waves/SIMD wanted)
+    int qpw = g_bq_qpw;
+    while (qpw > 2 && (long long)b * ((m + qpw - 1) / qpw) < 4096) qpw >>= 1;
+    if (qpw >= 8) return launch_ball_query_q<MODE, 8>(b, n, m, thr, nsample, xyz1, xyz2, idx, cnt, st);
+    if (qpw >= 4) return launch_ball_query_q<MODE, 4>(b, n, m, thr, nsample, xyz1, xyz2, idx, cnt, st);
+    return launch_ball_query_q<MODE, 2>(b, n, m, thr, nsample, xyz1, xyz2, idx, cnt, st);
 }
 
 // ---- group_point -----------------------------------------------------------
@@ -179,6 +214,11 @@ inline int grid_x_for(unsigned long long total, int block, int batches) {
 }
 
 }  // namespace
+
+extern "C" int pn2_debug_set_grouping(int what, int value) {
+    if (what == 1) { g_bq_qpw = value; return 0; }
+    return PN2_EINVAL;
+}
 
 extern "C" int pn2_query_ball_point(int b, int n, int m, float radius, int nsample,
                                     const float* xyz1, const float* xyz2, int* idx, int* pts_cnt,

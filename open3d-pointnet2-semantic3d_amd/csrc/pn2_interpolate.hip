@@ -3,11 +3,11 @@
 // tf_ops/tf_interpolate.cpp:213-243,307-330,397-421 (which bounce every FP layer
 // GPU->host->GPU in the reference) and of util/pointnet_util.py:300-311.
 //
-// three_nn computes in float64 exactly like the reference's KD-tree
-// (tf_interpolate.cpp:20-28: points widened to Eigen::Vector3d; FLANN L2<double>
-// accumulates ((0+dx*dx)+dy*dy)+dz*dz), brute force: the known points of a batch
-// element are staged in LDS as doubles and broadcast-read by a thread-per-query
-// scan.  Bound: fp64 VALU, not HBM.
+// three_nn is exact float64 like the reference's KD-tree (tf_interpolate.cpp:20-28:
+// points widened to Eigen::Vector3d; FLANN L2<double> accumulates
+// ((0+dx*dx)+dy*dy)+dz*dz), brute force with an fp32 prefilter: the known points
+// of a batch element are staged in LDS and broadcast-read by a thread-per-query
+// scan.  Bound: VALU issue, not HBM.
 #include <math.h>
 
 #include "pn2_common.h"
@@ -17,38 +17,53 @@ namespace {
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 constexpr int kNnThreads = 256;
-constexpr int kNnTile = 2048;  // known points per LDS tile: 2048*3*8 = 48 KiB
+constexpr int kNnTile = 4096;  // known points per LDS tile as float4: 64 KiB
 
+// Exact float64 3-NN with an fp32 prefilter.  Every candidate is first measured in fp32 (6 fast
+// VALU ops); only candidates that could still enter the top-3 are re-measured in float64 exactly as
+// the reference does (tf_interpolate.cpp:20-28 -> FLANN L2<double>: ((0+dx*dx)+dy*dy)+dz*dz).
+// Safety of the filter: with exactly representable inputs the fp32 value d32 satisfies
+// |d32 - d| <= 5*2^-24 * d  (fl(a-b) and each mul/add contribute one 2^-24 relative error, all
+// terms are non-negative), so d < b3 implies d32 < b3*(1+3e-7) < thr := float(b3*(1+1e-6)).
+// Candidates are visited in ascending index with strict '<', so ties keep the lowest index.
 __global__ void __launch_bounds__(kNnThreads)
 three_nn_kernel(int n, int m, const float* __restrict__ xyz1_all,
                 const float* __restrict__ xyz2_all, float* __restrict__ dist_all,
                 int* __restrict__ idx_all) {
-    __shared__ double sref[kNnTile * 3];
+    __shared__ float4 sref[kNnTile];
     const int bi = blockIdx.y;
     const int j = blockIdx.x * kNnThreads + threadIdx.x;
     const float* __restrict__ xyz1 = xyz1_all + (size_t)bi * n * 3;
     const float* __restrict__ xyz2 = xyz2_all + (size_t)bi * m * 3;
     const bool active = j < n;
-    double qx = 0, qy = 0, qz = 0;
-    if (active) { qx = xyz1[j * 3 + 0]; qy = xyz1[j * 3 + 1]; qz = xyz1[j * 3 + 2]; }
+    float qxf = 0.f, qyf = 0.f, qzf = 0.f;
+    if (active) { qxf = xyz1[j * 3 + 0]; qyf = xyz1[j * 3 + 1]; qzf = xyz1[j * 3 + 2]; }
+    const double qx = qxf, qy = qyf, qz = qzf;
     double b1 = INFINITY, b2 = INFINITY, b3 = INFINITY;
     int i1 = 0, i2 = 0, i3 = 0;
+    float thr = INFINITY;
     for (int t0 = 0; t0 < m; t0 += kNnTile) {
         const int tn = m - t0 < kNnTile ? m - t0 : kNnTile;
         __syncthreads();
-        for (int e = threadIdx.x; e < tn * 3; e += kNnThreads) sref[e] = (double)xyz2[t0 * 3 + e];
+        for (int e = threadIdx.x; e < tn; e += kNnThreads)
+            sref[e] = make_float4(xyz2[(t0 + e) * 3 + 0], xyz2[(t0 + e) * 3 + 1], xyz2[(t0 + e) * 3 + 2], 0.f);
         __syncthreads();
         if (active) {
+#pragma unroll 4
             for (int k = 0; k < tn; ++k) {
-                const double dx = qx - sref[k * 3 + 0];
-                const double dy = qy - sref[k * 3 + 1];
-                const double dz = qz - sref[k * 3 + 2];
-                const double d = (dx * dx + dy * dy) + dz * dz;  // contraction is off
-                if (d < b3) {  // strict: ties keep the lower index (ascending k)
-                    const int kk = t0 + k;
-                    if (d < b1) { b3 = b2; i3 = i2; b2 = b1; i2 = i1; b1 = d; i1 = kk; }
-                    else if (d < b2) { b3 = b2; i3 = i2; b2 = d; i2 = kk; }
-                    else { b3 = d; i3 = kk; }
+                const float4 r = sref[k];  // broadcast read
+                const float fx = qxf - r.x, fy = qyf - r.y, fz = qzf - r.z;
+                const float d32 = (fx * fx + fy * fy) + fz * fz;
+                if (d32 <= thr) {  // rare once three neighbours are known
+                    const double dx = qx - (double)r.x, dy = qy - (double)r.y, dz = qz - (double)r.z;
+                    const double d = (dx * dx + dy * dy) + dz * dz;  // contraction is off
+                    if (d < b3) {
+                        const int kk = t0 + k;
+                        if (d < b1) { b3 = b2; i3 = i2; b2 = b1; i2 = i1; b1 = d; i1 = kk; }
+                        else if (d < b2) { b3 = b2; i3 = i2; b2 = d; i2 = kk; }
+                        else { b3 = d; i3 = kk; }
+                        thr = (float)(b3 * (1.0 + 1e-6));  // +inf while fewer than 3 neighbours are known
+                    }
                 }
             }
         }
@@ -115,36 +130,53 @@ three_interpolate_grad_kernel(int n, int c, int m, const float* __restrict__ gra
 
 // Fused FP front end: inverse-distance weights (pointnet_util.py:300-303) +
 // three_interpolate + concat([interp, points1]) (pointnet_util.py:304-311).
-// One thread per output float (channel widths like 131 are not vectorisable).
+// One wave owns 64 consecutive rows: lane l computes the three weights of row l once (IEEE
+// divisions), then the rows are produced one after another with that row's (idx, weight) broadcast
+// through SGPRs (v_readlane) and the lanes striding over the channels -- every global access is a
+// contiguous 256-byte segment even for odd row widths such as 131.
 __global__ void __launch_bounds__(256)
-fp_interp_concat_kernel(int n, int m, int c1, int c2, const float* __restrict__ dist_all,
+fp_interp_concat_kernel(int n, int m, int c1, int c2, int rpw, const float* __restrict__ dist_all,
                         const int* __restrict__ idx_all, const float* __restrict__ points1_all,
                         const float* __restrict__ points2_all, float* __restrict__ out_all) {
-    const unsigned cw = (unsigned)(c1 + c2);
-    const unsigned total = (unsigned)n * cw;
+    // rpw = rows per wave (1..64, chosen by the host so that small levels still fill the chip)
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int bi = blockIdx.y;
+    const int cw = c1 + c2;
     const float* __restrict__ dist = dist_all + (size_t)bi * n * 3;
     const int* __restrict__ idx = idx_all + (size_t)bi * n * 3;
     const float* __restrict__ p2 = points2_all + (size_t)bi * m * c2;
     const float* __restrict__ p1 = points1_all ? points1_all + (size_t)bi * n * c1 : nullptr;
     float* __restrict__ out = out_all + (size_t)bi * n * cw;
-    for (unsigned e = blockIdx.x * blockDim.x + threadIdx.x; e < total; e += gridDim.x * blockDim.x) {
-        const unsigned row = e / cw, col = e - row * cw;
-        float v;
-        if (col < (unsigned)c2) {
-            const float d1 = fmaxf(dist[row * 3 + 0], 1e-10f);
-            const float d2 = fmaxf(dist[row * 3 + 1], 1e-10f);
-            const float d3 = fmaxf(dist[row * 3 + 2], 1e-10f);
-            const float r1 = 1.0f / d1, r2 = 1.0f / d2, r3 = 1.0f / d3;  // IEEE division
-            const float norm = (r1 + r2) + r3;
-            const float w1 = r1 / norm, w2 = r2 / norm, w3 = r3 / norm;
-            const int i1 = idx[row * 3 + 0], i2 = idx[row * 3 + 1], i3 = idx[row * 3 + 2];
-            v = (p2[(size_t)i1 * c2 + col] * w1 + p2[(size_t)i2 * c2 + col] * w2) +
-                p2[(size_t)i3 * c2 + col] * w3;
-        } else {
-            v = p1[(size_t)row * c1 + (col - c2)];
-        }
-        out[e] = v;
+    for (int row0 = (blockIdx.x * 4 + wave) * rpw; row0 < n; row0 += gridDim.x * 4 * rpw) {
+        int r = row0 + (lane < rpw ? lane : rpw - 1);
+        r = r < n ? r : n - 1;
+        const float d1 = fmaxf(dist[r * 3 + 0], 1e-10f);
+        const float d2 = fmaxf(dist[r * 3 + 1], 1e-10f);
+        const float d3 = fmaxf(dist[r * 3 + 2], 1e-10f);
+        const float r1 = 1.0f / d1, r2 = 1.0f / d2, r3 = 1.0f / d3;  // IEEE division
+        const float norm = (r1 + r2) + r3;
+        const float w1 = r1 / norm, w2 = r2 / norm, w3 = r3 / norm;
+        const int i1 = idx[r * 3 + 0], i2 = idx[r * 3 + 1], i3 = idx[r * 3 + 2];
+        const int nrows = n - row0 < rpw ? n - row0 : rpw;
+        auto one_row = [&](int rr) {
+            const float a1 = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(w1), rr));
+            const float a2 = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(w2), rr));
+            const float a3 = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(w3), rr));
+            const float* __restrict__ s1 = p2 + (size_t)__builtin_amdgcn_readlane(i1, rr) * c2;
+            const float* __restrict__ s2 = p2 + (size_t)__builtin_amdgcn_readlane(i2, rr) * c2;
+            const float* __restrict__ s3 = p2 + (size_t)__builtin_amdgcn_readlane(i3, rr) * c2;
+            float* __restrict__ o = out + (size_t)(row0 + rr) * cw;
+#pragma unroll 4
+            for (int ch = lane; ch < c2; ch += 64) o[ch] = (s1[ch] * a1 + s2[ch] * a2) + s3[ch] * a3;
+            if (p1) {
+                const float* __restrict__ q = p1 + (size_t)(row0 + rr) * c1;
+                for (int ch = lane; ch < c1; ch += 64) o[c2 + ch] = q[ch];
+            }
+        };
+        int rr = 0;
+        for (; rr + 1 < nrows; rr += 2) { one_row(rr); one_row(rr + 1); }
+        if (rr < nrows) one_row(rr);
     }
 }
 
@@ -215,9 +247,18 @@ extern "C" int pn2_fp_interp_concat(int b, int n, int m, int c1, int c2, const f
     if (b <= 0 || n <= 0 || m <= 0 || c2 <= 0 || c1 < 0) return PN2_EINVAL;
     if (!dist || !idx || !points2 || !out || (c1 > 0 && !points1)) return PN2_ENULL;
     if ((unsigned long long)n * (c1 + c2) > 0xffffffffull || b > 65535) return PN2_ERANGE;
-    dim3 grid(grid_x_for((unsigned long long)n * (c1 + c2), 256, b), b);
+    // rows per wave: as many as possible (amortises the per-row weight maths) while keeping
+    // >= ~4096 waves in flight; 4 waves per block, grid-stride beyond ~8 blocks per CU
+    int rpw = (int)(((long long)b * n) / 4096);
+    if (rpw < 1) rpw = 1;
+    if (rpw > 64) rpw = 64;
+    int gx = (n + 4 * rpw - 1) / (4 * rpw);
+    const int cap = (256 * 8 + b - 1) / b;
+    if (gx > cap) gx = cap;
+    if (gx < 1) gx = 1;
+    dim3 grid(gx, b);
     fp_interp_concat_kernel<<<grid, 256, 0, static_cast<hipStream_t>(stream)>>>(
-        n, m, c1, c2, dist, idx, c1 > 0 ? points1 : nullptr, points2, out);
+        n, m, c1, c2, rpw, dist, idx, c1 > 0 ? points1 : nullptr, points2, out);
     PN2_RETURN_IF_LAUNCH_FAILED();
     return PN2_OK;
 }

@@ -7,15 +7,19 @@
 // Here: y = relu(x @ W + b) with the inference BatchNorm folded into (W, b) by the
 // host and the max over the K neighbours taken in the MFMA epilogue.
 //
-// Kernel shape: 256 threads = 4 waves; block tile 128 rows x BN cols (BN = 32*NT),
-// each wave owns 32 rows x BN cols = NT accumulators of v_mfma_f32_32x32x2_f32
-// (exact fp32 products, fp32 accumulate: bitwise an fmaf chain).  K is tiled by
-// 16 through double-buffered LDS (one barrier per tile), global->register
-// prefetch of tile t+1 overlaps the MFMAs of tile t.  LDS layouts are k-major with
-// row strides 130 / BN+4 floats so both operand reads (lane -> consecutive
-// floats) and the transposing A stores are bank-conflict free.
-// Because a wave's 32 rows are exactly one K=32 neighbourhood, the max-pool is an
-// in-register max over the 16 accumulator rows + one cross-half exchange.
+// Kernel shape: 256 threads = 4 waves arranged WM x WN; block tile (32*WM) rows x (32*NT*WN)
+// cols; each wave owns 32 rows x 32*NT cols = NT accumulators of v_mfma_f32_32x32x2_f32 (exact
+// fp32 products, fp32 accumulate: bitwise an fmaf chain).  K is tiled by 32 through LDS with a
+// global->register prefetch of tile t+1 under the MFMAs of tile t.
+//   * A tile: row-major [rows][32(+4 pad)] written with 16-byte stores straight from the 16-byte
+//     global loads (no transpose).  A lane (row = lane&31, half = lane>>5) reads FOUR k values
+//     with one ds_read_b128: k = 8t + 4*half + {0..3}.  The 32x32x2 MFMA only requires the A and
+//     B operands of a step to carry the SAME two k indices (half 0 / half 1), so visiting the
+//     contraction index in this permuted order is exact; row stride 36 floats makes the b128
+//     reads bank-conflict free.
+//   * B tile: k-major [32][BN(+4)], read one float per lane per step (lane -> consecutive cols).
+// Because a wave's 32 rows are exactly one K=32 neighbourhood, the max-pool is an in-register max
+// over the 16 accumulator rows + one cross-half exchange.
 #include "pn2_common.h"
 
 namespace {
@@ -23,33 +27,38 @@ namespace {
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
-constexpr int kBM = 128;
-constexpr int kBK = 16;
-constexpr int kAS = kBM + 2;  // A tile row stride (floats)
+constexpr int kBK = 32;
+constexpr int kAS = kBK + 4;  // A tile row stride (floats): 144 B, keeps b128 accesses 16-B aligned
 
 __device__ __forceinline__ void atomic_max_nonneg(float* addr, float v) {
     // v >= 0 (post-ReLU): integer order == float order
     atomicMax(reinterpret_cast<int*>(addr), __float_as_int(v));
 }
 
-template <int NT, bool VEC_A>
+template <int WM, int WN, int NT, bool VEC_A>
 __global__ void __launch_bounds__(256)
 linear_kernel(int rows, int cin, int cout, const float* __restrict__ x,
               const float* __restrict__ w, const float* __restrict__ bias, int relu, int pool,
               float* __restrict__ y) {
-    constexpr int BN = NT * 32;
-    constexpr int BS = BN + 4;  // B tile row stride (floats), keeps float4 stores 16-B aligned
-    constexpr int B_F4 = kBK * BN / 4;             // float4 per B tile
-    constexpr int B_PER_T = (B_F4 + 255) / 256;    // float4 per thread
-    __shared__ __attribute__((aligned(16))) float As[2][kBK * kAS];
-    __shared__ __attribute__((aligned(16))) float Bs[2][kBK * BS];
+    static_assert(WM * WN == 4, "4 waves per block");
+    constexpr int BM = 32 * WM;
+    constexpr int BN = 32 * NT * WN;
+    constexpr int BS = BN + 4;                   // B tile row stride (floats)
+    constexpr int A_F4 = BM * kBK / 4;           // float4 per A tile
+    constexpr int A_PER_T = (A_F4 + 255) / 256;
+    constexpr int A_SC = (BM * kBK + 255) / 256; // scalars per thread (non-vector path)
+    constexpr int B_F4 = kBK * BN / 4;
+    constexpr int B_PER_T = (B_F4 + 255) / 256;
+    __shared__ __attribute__((aligned(16))) float As[BM * kAS];
+    __shared__ __attribute__((aligned(16))) float Bs[kBK * BS];
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = tid >> 6;
+    const int wm = wave / WN, wn = wave % WN;
     const int half = lane >> 5;
     const int l31 = lane & 31;
-    const int row0 = blockIdx.x * kBM;
+    const int row0 = blockIdx.x * BM;
     const int col0 = blockIdx.y * BN;
 
     f32x16 acc[NT];
@@ -58,31 +67,30 @@ linear_kernel(int rows, int cin, int cout, const float* __restrict__ x,
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[nt][r] = 0.f;
 
-    // ---- staging registers -------------------------------------------------
-    f32x4 a_v[2];      // VEC_A: 2 float4 per thread
-    float a_s[8];      // scalar path: 8 floats per thread
+    f32x4 a_v[VEC_A ? A_PER_T : 1];
+    float a_s[VEC_A ? 1 : A_SC];
     f32x4 b_v[B_PER_T];
 
     auto load_tile = [&](int kt) {
         const int k0 = kt * kBK;
         if constexpr (VEC_A) {
 #pragma unroll
-            for (int i = 0; i < 2; ++i) {
+            for (int i = 0; i < A_PER_T; ++i) {
                 const int f = tid + 256 * i;
-                const int r = f >> 2, k4 = f & 3;
+                const int r = f >> 3, k4 = f & 7;
                 const int gr = row0 + r, gk = k0 + k4 * 4;
                 f32x4 v = {0.f, 0.f, 0.f, 0.f};
-                if (gr < rows && gk < cin)
+                if (f < A_F4 && gr < rows && gk < cin)
                     v = *reinterpret_cast<const f32x4*>(x + (size_t)gr * cin + gk);
                 a_v[i] = v;
             }
         } else {
 #pragma unroll
-            for (int i = 0; i < 8; ++i) {
+            for (int i = 0; i < A_SC; ++i) {
                 const int e = tid + 256 * i;
-                const int k = e & 15, r = e >> 4;
+                const int k = e & 31, r = e >> 5;
                 const int gr = row0 + r, gk = k0 + k;
-                a_s[i] = (gr < rows && gk < cin) ? x[(size_t)gr * cin + gk] : 0.f;
+                a_s[i] = (r < BM && gr < rows && gk < cin) ? x[(size_t)gr * cin + gk] : 0.f;
             }
         }
 #pragma unroll
@@ -95,62 +103,59 @@ linear_kernel(int rows, int cin, int cout, const float* __restrict__ x,
             b_v[i] = v;
         }
     };
-    auto store_tile = [&](int buf) {
-        float* as = As[buf];
-        float* bs = Bs[buf];
+    auto store_tile = [&]() {
         if constexpr (VEC_A) {
 #pragma unroll
-            for (int i = 0; i < 2; ++i) {
+            for (int i = 0; i < A_PER_T; ++i) {
                 const int f = tid + 256 * i;
-                const int r = f >> 2, k4 = f & 3;
-#pragma unroll
-                for (int jj = 0; jj < 4; ++jj) as[(k4 * 4 + jj) * kAS + r] = a_v[i][jj];
+                const int r = f >> 3, k4 = f & 7;
+                if (f < A_F4) *reinterpret_cast<f32x4*>(As + r * kAS + k4 * 4) = a_v[i];
             }
         } else {
 #pragma unroll
-            for (int i = 0; i < 8; ++i) {
+            for (int i = 0; i < A_SC; ++i) {
                 const int e = tid + 256 * i;
-                const int k = e & 15, r = e >> 4;
-                as[k * kAS + r] = a_s[i];
+                const int k = e & 31, r = e >> 5;
+                if (r < BM) As[r * kAS + k] = a_s[i];
             }
         }
 #pragma unroll
         for (int i = 0; i < B_PER_T; ++i) {
             const int f = tid + 256 * i;
             const int k = f / (BN / 4), n4 = f % (BN / 4);
-            if (f < B_F4) *reinterpret_cast<f32x4*>(bs + k * BS + n4 * 4) = b_v[i];
+            if (f < B_F4) *reinterpret_cast<f32x4*>(Bs + k * BS + n4 * 4) = b_v[i];
         }
     };
 
     const int nkt = (cin + kBK - 1) / kBK;
     load_tile(0);
-    store_tile(0);
-    __syncthreads();
     for (int kt = 0; kt < nkt; ++kt) {
-        const int buf = kt & 1;
-        if (kt + 1 < nkt) load_tile(kt + 1);
-        const float* as = As[buf] + wave * 32 + l31;
-        const float* bs = Bs[buf] + l31;
+        __syncthreads();  // previous tile fully consumed
+        store_tile();
+        __syncthreads();
+        if (kt + 1 < nkt) load_tile(kt + 1);  // in flight under the MFMAs below
+        const float* as = As + (wm * 32 + l31) * kAS + 4 * half;
+        const float* bs = Bs + (4 * half) * BS + wn * (NT * 32) + l31;
 #pragma unroll
-        for (int ks = 0; ks < kBK / 2; ++ks) {
-            const int k = ks * 2 + half;
-            const float a = as[k * kAS];
+        for (int t = 0; t < 4; ++t) {
+            const f32x4 av = *reinterpret_cast<const f32x4*>(as + 8 * t);
 #pragma unroll
-            for (int nt = 0; nt < NT; ++nt) {
-                const float bb = bs[k * BS + nt * 32];
-                acc[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, bb, acc[nt], 0, 0, 0);
+            for (int q = 0; q < 4; ++q) {
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) {
+                    const float bb = bs[(8 * t + q) * BS + nt * 32];
+                    acc[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[q], bb, acc[nt], 0, 0, 0);
+                }
             }
         }
-        if (kt + 1 < nkt) store_tile(buf ^ 1);
-        __syncthreads();
     }
 
     // ---- epilogue ------------------------------------------------------------
     // D[i][j]: j = l31, i = (r&3) + 8*(r>>2) + 4*half
-    const int wrow0 = row0 + wave * 32;
+    const int wrow0 = row0 + wm * 32;
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) {
-        const int col = col0 + nt * 32 + l31;
+        const int col = col0 + wn * (NT * 32) + nt * 32 + l31;
         const float bv = bias ? bias[col] : 0.f;
         if (pool <= 1) {
 #pragma unroll
@@ -188,13 +193,14 @@ linear_kernel(int rows, int cin, int cout, const float* __restrict__ x,
     }
 }
 
-template <int NT>
+template <int WM, int WN, int NT>
 int launch_linear(int rows, int cin, int cout, const float* x, const float* w, const float* bias,
                   int relu, int pool, float* y, hipStream_t st) {
-    dim3 grid((rows + kBM - 1) / kBM, cout / (NT * 32));
+    constexpr int BM = 32 * WM, BN = 32 * NT * WN;
+    dim3 grid((rows + BM - 1) / BM, cout / BN);
     const bool vec_a = (cin % 4 == 0) && ((uintptr_t)x % 16 == 0);
-    if (vec_a) linear_kernel<NT, true><<<grid, 256, 0, st>>>(rows, cin, cout, x, w, bias, relu, pool, y);
-    else linear_kernel<NT, false><<<grid, 256, 0, st>>>(rows, cin, cout, x, w, bias, relu, pool, y);
+    if (vec_a) linear_kernel<WM, WN, NT, true><<<grid, 256, 0, st>>>(rows, cin, cout, x, w, bias, relu, pool, y);
+    else linear_kernel<WM, WN, NT, false><<<grid, 256, 0, st>>>(rows, cin, cout, x, w, bias, relu, pool, y);
     PN2_RETURN_IF_LAUNCH_FAILED();
     return PN2_OK;
 }
@@ -231,7 +237,7 @@ extern "C" int pn2_linear(int rows, int cin, int cout, const float* x, const flo
     if (rows <= 0 || cin <= 0 || cout <= 0) return PN2_EINVAL;
     if (!x || !w || !y) return PN2_ENULL;
     if (cout % 32 != 0 || ((uintptr_t)w % 16) != 0) return PN2_EUNSUP;
-    if ((long long)rows + kBM > 0x7fffffffLL) return PN2_ERANGE;
+    if ((long long)rows + 128 > 0x7fffffffLL) return PN2_ERANGE;
     hipStream_t st = static_cast<hipStream_t>(stream);
     if (pool > 1) {
         if (pool != 16 && pool % 32 != 0) return PN2_EUNSUP;
@@ -242,9 +248,15 @@ extern "C" int pn2_linear(int rows, int cin, int cout, const float* x, const flo
             if (e != hipSuccess) return (int)e;
         }
     }
-    if (cout % 128 == 0) return launch_linear<4>(rows, cin, cout, x, w, bias, relu, pool, y, st);
-    if (cout % 64 == 0) return launch_linear<2>(rows, cin, cout, x, w, bias, relu, pool, y, st);
-    return launch_linear<1>(rows, cin, cout, x, w, bias, relu, pool, y, st);
+    if (cout % 128 == 0) {
+        // largest tile that still yields >= 2 blocks per CU; small problems get 32-row blocks
+        const long long cb = cout / 128;
+        if (((rows + 127) / 128) * cb >= 512) return launch_linear<4, 1, 4>(rows, cin, cout, x, w, bias, relu, pool, y, st);
+        if (((rows + 63) / 64) * cb >= 512) return launch_linear<2, 2, 2>(rows, cin, cout, x, w, bias, relu, pool, y, st);
+        return launch_linear<1, 4, 1>(rows, cin, cout, x, w, bias, relu, pool, y, st);
+    }
+    if (cout % 64 == 0) return launch_linear<4, 1, 2>(rows, cin, cout, x, w, bias, relu, pool, y, st);
+    return launch_linear<4, 1, 1>(rows, cin, cout, x, w, bias, relu, pool, y, st);
 }
 
 // internal helper (exported for the host package's unfused SA path and for tests)

@@ -258,9 +258,13 @@ int launch_sa_fused(const SaFusedParams& p, hipStream_t st) {
     const size_t bytes = floats * sizeof(float);
     if (bytes > 150 * 1024) return PN2_EUNSUP;
     auto kern = sa_fused_kernel<L, NT1, NT2, NT3, VEC8>;
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
-    if (e != hipSuccess) return (int)e;
+    static bool attr_set = false;  // per instantiation; benign race (idempotent call)
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (e != hipSuccess) return (int)e;
+        attr_set = true;
+    }
     // persistent grid: as many 4-wave workgroups as LDS lets be co-resident (<= 2 per CU)
     int per_cu = (int)((160 * 1024) / (bytes + 1024));
     if (per_cu < 1) per_cu = 1;

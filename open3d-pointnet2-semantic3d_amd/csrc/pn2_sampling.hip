@@ -248,10 +248,13 @@ int launch_fps_reg(int b, int n, int m, const float* inp, int* out, hipStream_t 
     // 160 KiB LDS per CU; keep the cloud in LDS when it fits (n <= 8192 -> 128 KiB)
     if (slots_bytes + xyz_bytes <= 144 * 1024) {
         auto kern = fps_reg_kernel<NT, PPT, MODE, true>;
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize,
-                                           (int)(slots_bytes + xyz_bytes));
-        if (e != hipSuccess) return (int)e;
+        static int attr_bytes = 0;  // per instantiation; benign race (idempotent call)
+        if (attr_bytes < (int)(slots_bytes + xyz_bytes)) {
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            if (e != hipSuccess) return (int)e;
+            attr_bytes = 160 * 1024;
+        }
         kern<<<b, NT, slots_bytes + xyz_bytes, st>>>(n, m, inp, out);
     } else {
         fps_reg_kernel<NT, PPT, MODE, false><<<b, NT, slots_bytes, st>>>(n, m, inp, out);
@@ -324,9 +327,10 @@ inline int grid_for(long long total, int block) {
 }  // namespace
 
 // undocumented tuning/experiment hook (not part of the ABI header)
+extern "C" int pn2_debug_set_grouping(int what, int value);
 extern "C" int pn2_debug_set(int what, int value) {
     if (what == 0) { g_fps_variant = value; return 0; }
-    return PN2_EINVAL;
+    return pn2_debug_set_grouping(what, value);
 }
 
 extern "C" int pn2_farthest_point_sample(int b, int n, int m, const float* inp, float* temp,

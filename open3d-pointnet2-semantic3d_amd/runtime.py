@@ -1,0 +1,37 @@
+"""HIP-graph capture of a forward pass.
+
+A PointNet++ forward is ~40 short launches; issued from Python the host becomes the bottleneck
+(measured: 2.7 ms wall for 2.0 ms of kernels).  `CapturedForward` records the whole pass -- the
+ctypes launches of libpn2_hip.so go to torch's current stream, which is the capture stream -- into
+one hipGraph and replays it per step.  Inputs are copied into static buffers; outputs are static
+tensors overwritten by each replay.
+"""
+import torch
+
+
+class CapturedForward:
+    def __init__(self, fn, *example_inputs, warmup=3):
+        """fn(*tensors) -> tensor | tuple of tensors; shapes/dtypes are frozen at capture time."""
+        self.static_inputs = [t.clone() for t in example_inputs]
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side), torch.no_grad():
+            for _ in range(warmup):  # creates variables, folded weights, sets kernel attributes
+                fn(*self.static_inputs)
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        self.graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.graph), torch.no_grad():
+            self.static_outputs = fn(*self.static_inputs)
+
+    def __call__(self, *inputs):
+        for dst, src in zip(self.static_inputs, inputs):
+            if dst.data_ptr() != src.data_ptr():
+                dst.copy_(src, non_blocking=True)
+        self.graph.replay()
+        return self.static_outputs
+
+    def replay(self):
+        """replay on the inputs already resident in the static buffers"""
+        self.graph.replay()
+        return self.static_outputs

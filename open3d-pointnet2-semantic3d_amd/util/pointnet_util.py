@@ -104,6 +104,37 @@ def _sa_group_concat(xyz, new_xyz, points, idx):
 USE_FUSED_SA = True
 
 
+def sa_geometry(xyz, npoint, radius, nsample):
+    """The feature-independent half of an SA layer: FPS -> gather -> ball query.
+    -> new_xyz (B,npoint,3), idx (B,npoint,nsample).  Depends only on coordinates, so a model can
+    run the geometry of all levels on a side stream (see model.get_sa_fp_features)."""
+    xyz = xyz.contiguous()
+    new_xyz = gather_point(xyz, farthest_point_sample(npoint, xyz))
+    idx, _ = query_ball_point(radius, nsample, xyz, new_xyz)
+    return new_xyz, idx
+
+
+def sa_features_inference(xyz, new_xyz, points, idx, mlp, bn=True, bn_decay=None):
+    """The feature half of an SA layer (inference, max pooling): gather + MLP + max over K,
+    fused when the widths allow it.  Must be called inside the layer's variable scope.
+    -> (B,npoint,mlp[-1])"""
+    nsample = idx.shape[2]
+    new_points = None
+    if USE_FUSED_SA:
+        new_points = _sa_fused_inference(xyz, new_xyz, points, idx, mlp, bn, "conv%d")
+    if new_points is None:
+        h = _sa_group_concat(xyz, new_xyz, points, idx)  # (B,M,K,3+C)
+        pool_ok = nsample == 16 or nsample % 32 == 0
+        for i, cout in enumerate(mlp):
+            last = i == len(mlp) - 1
+            h = tf_util.conv2d(h, cout, [1, 1], padding="VALID", stride=[1, 1], bn=bn, is_training=False,
+                               scope="conv%d" % i, bn_decay=bn_decay, pool=nsample if (last and pool_ok) else 0)
+        if not pool_ok:
+            h = h.amax(dim=2, keepdim=True)
+        new_points = h.squeeze(2)
+    return new_points
+
+
 def pointnet_sa_module(xyz, points, npoint, radius, nsample, mlp, mlp2, group_all, is_training, bn_decay, scope,
                        bn=True, pooling="max", knn=False, use_xyz=True, use_nchw=False):
     """PointNet Set Abstraction module -> new_xyz (B,npoint,3), new_points (B,npoint,mlp[-1] or mlp2[-1]), idx."""
@@ -114,22 +145,8 @@ def pointnet_sa_module(xyz, points, npoint, radius, nsample, mlp, mlp2, group_al
         if not is_training and not group_all and not knn and use_xyz and pooling == "max":
             # ---- inference fast path: HIP index ops + fused / MFMA MLP -------------
             xyz = xyz.contiguous()
-            new_xyz = gather_point(xyz, farthest_point_sample(npoint, xyz))
-            idx, _ = query_ball_point(radius, nsample, xyz, new_xyz)
-            new_points = None
-            if USE_FUSED_SA:
-                new_points = _sa_fused_inference(xyz, new_xyz, points, idx, mlp, bn, "conv%d")
-            if new_points is None:
-                h = _sa_group_concat(xyz, new_xyz, points, idx)  # (B,M,K,3+C)
-                pool_ok = nsample == 16 or nsample % 32 == 0
-                for i, cout in enumerate(mlp):
-                    last = i == len(mlp) - 1
-                    h = tf_util.conv2d(h, cout, [1, 1], padding="VALID", stride=[1, 1], bn=bn, is_training=False,
-                                       scope="conv%d" % i, bn_decay=bn_decay,
-                                       pool=nsample if (last and pool_ok) else 0)
-                if not pool_ok:
-                    h = h.amax(dim=2, keepdim=True)
-                new_points = h.squeeze(2)
+            new_xyz, idx = sa_geometry(xyz, npoint, radius, nsample)
+            new_points = sa_features_inference(xyz, new_xyz, points, idx, mlp, bn, bn_decay)
             new_points = new_points.unsqueeze(2)
         else:
             if group_all:
@@ -206,6 +223,16 @@ def _fp_interp_concat(dist, idx, points1, points2):
         check(lib.pn2_fp_interp_concat(b, n, m, c1, c2, ptr(dist), ptr(idx), ptr(p1), ptr(p2), ptr(out),
                                        stream_ptr()), "pn2_fp_interp_concat")
     return out
+
+
+def fp_features_inference(dist, idx, points1, points2, mlp, bn=True, bn_decay=None):
+    """The feature half of an FP layer (inference) given three_nn's (dist, idx).  Must be called
+    inside the layer's variable scope."""
+    h = _fp_interp_concat(dist, idx, points1, points2).unsqueeze(2)
+    for i, cout in enumerate(mlp):
+        h = tf_util.conv2d(h, cout, [1, 1], padding="VALID", stride=[1, 1], bn=bn, is_training=False,
+                           scope="conv_%d" % i, bn_decay=bn_decay)
+    return h.squeeze(2)
 
 
 def pointnet_fp_module(xyz1, xyz2, points1, points2, mlp, is_training, bn_decay, scope, bn=True):

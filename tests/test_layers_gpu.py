@@ -271,3 +271,34 @@ def test_get_model_head_shapes(pn2, cuda):
     assert logits.shape == (1, 1024, 9) and ep["feats"].shape == (1, 1024, 128)
     import torch
     assert torch.isfinite(logits).all()
+
+
+def test_two_stream_and_graph_forward_match_sequential(pn2, cuda):
+    """The geometry/feature two-stream schedule and its hipGraph replay are bit-identical to the
+    plain sequential forward (same kernels, same inputs)."""
+    import torch
+    tfu = pn2.util.tf_util
+    hp = dict(pn2.model.SEMANTIC_HYPERPARAMS)
+    hp.update(l1_npoint=256, l2_npoint=64, l3_npoint=32, l4_npoint=16)
+    rs = np.random.RandomState(3)
+    pc = np.concatenate([s_scene(4, 2, 2048), rs.random_sample((2, 2048, 3)).astype(np.float32)], axis=2)
+    store = tfu.set_default_store(tfu.VariableStore(device=cuda, seed=21))
+    x = T(pc, cuda)
+    with torch.no_grad():
+        ref, _ = pn2.model.get_sa_fp_features(x, False, hp)
+        randomize_bn(store, 22)
+        ref, _ = pn2.model.get_sa_fp_features(x, False, hp)
+        two, _ = pn2.model.get_sa_fp_features(x, False, hp, two_streams=True)
+    torch.cuda.synchronize()
+    assert torch.equal(ref, two)
+    cap = pn2.runtime.CapturedForward(lambda t: pn2.model.get_sa_fp_features(t, False, hp, two_streams=True)[0], x)
+    for _ in range(3):
+        out = cap.replay()
+    torch.cuda.synchronize()
+    assert torch.equal(ref, out)
+    x2 = T(np.ascontiguousarray(pc[::-1]), cuda)  # new input through the static buffer
+    out2 = cap(x2).clone()
+    with torch.no_grad():
+        ref2, _ = pn2.model.get_sa_fp_features(x2, False, hp)
+    torch.cuda.synchronize()
+    assert torch.equal(ref2, out2)
