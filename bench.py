@@ -224,6 +224,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--eager", action="store_true", help="launch from Python instead of replaying a hipGraph")
     ap.add_argument("--one-stream", action="store_true", help="do not overlap the geometry chain with the MLP chain")
+    ap.add_argument("--pipeline", type=int, default=2, help="independent batches in flight (graphs replayed round-robin)")
     ap.add_argument("--no-north-star", action="store_true")
     args = ap.parse_args()
 
@@ -268,10 +269,22 @@ def main():
 
     eager_step = step
     if not args.eager:
-        # one hipGraph per forward: replay removes the ~40 Python-side launches from the step
-        captured = pn2.runtime.CapturedForward(
-            lambda x: pn2.model.get_sa_fp_features(x, False, hp, two_streams=not args.one_stream)[0], pc)
-        step = captured.replay
+        # one hipGraph per forward: replay removes the ~40 Python-side launches from the step.
+        # --pipeline P: P independent batches in flight (P graphs with their own buffers, replayed
+        # round-robin on P streams), so one batch's latency-bound FPS (16 CUs) overlaps the MFMA
+        # layers of the previous batch.  Every step is still one full forward over one batch.
+        P = max(1, args.pipeline)
+        fwd = lambda x: pn2.model.get_sa_fp_features(x, False, hp, two_streams=not args.one_stream)[0]  # noqa: E731
+        batches = [pc] + [torch.from_numpy(s_scene(2000 + 10 * rank + i, B, N)).to(dev) for i in range(1, P)]
+        caps = [pn2.runtime.CapturedForward(fwd, b_) for b_ in batches]
+        streams = [torch.cuda.Stream() for _ in range(P)]
+        counter = [0]
+
+        def step():
+            i = counter[0] % P
+            counter[0] += 1
+            with torch.cuda.stream(streams[i]):
+                return caps[i].replay()
     for _ in range(args.warmup):
         step()
     torch.cuda.synchronize()
@@ -316,7 +329,8 @@ def main():
                        "batch_per_gpu": B, "num_point": N, "parallelism": "batch-sharded replicas x%d, no collective" % world,
                        "arith_mode": int(pn2.config.arith_mode),
                        "launch": "eager python launches" if args.eager else "one hipGraph replay per step",
-                       "streams": 1 if (args.eager or args.one_stream) else 2},
+                       "streams": 1 if (args.eager or args.one_stream) else 2,
+                       "batches_in_flight": 1 if args.eager else max(1, args.pipeline)},
             "roofline": {"kernel": dom["kernel"], "args": dom["args"], "bound": dom["bound"],
                          "achieved": dom["achieved"], "peak": dom["peak"], "unit": dom["unit"], "frac": dom["frac"],
                          "traffic": None, "avg_us": dom["avg_us"],
