@@ -75,6 +75,14 @@ def kernel_model(name, a):
     if name == "pn2_linear":
         rows, cin, cout = a[:3]
         return "mfma", 2 * rows * cin * cout
+    if name == "pn2_mlp_chain":
+        rows, cin, L = a[0], a[1], a[2]
+        widths = a[4:4 + L]
+        fl = 0
+        for w in widths:
+            fl += 2 * rows * cin * w
+            cin = w
+        return "mfma", fl
     if name == "pn2_sa_mlp_max_fused":
         b, n, m, ns, c, L = a[:6]
         widths = a[6:6 + L]

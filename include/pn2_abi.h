@@ -144,10 +144,22 @@ int pn2_sa_mlp_max_fused(int b, int n, int m, int nsample, int c, const float *x
  *   weight = (1/max(dist,1e-10)) / sum(1/max(dist,1e-10));
  *   out[b,j,:] = [ sum_i weight_i * points2[b,idx_i,:]  |  points1[b,j,:] ]
  * i.e. three_interpolate + concat (interpolated FIRST) in one pass.
- *   dist,idx (b,n,3)  points2 (b,m,c2)  points1 (b,n,c1) or NULL -> out (b,n,c2+c1) */
+ *   dist,idx (b,n,3)  points2 (b,m,c2)  points1 (b,n,c1) or NULL -> out (b,n,out_stride)
+ * out_stride >= c2+c1 (0 = c2+c1): row stride of `out`; pad columns are zero-filled so that the
+ * consumer can use 16-byte loads (e.g. 131 -> 136). */
 int pn2_fp_interp_concat(int b, int n, int m, int c1, int c2, const float *dist,
                          const int *idx, const float *points1, const float *points2,
-                         float *out, void *stream);
+                         float *out, int out_stride, void *stream);
+
+/* Dense-row MLP chain (pointnet_util.py:312-325, inference BN folded): up to 2 layers
+ *   y = relu(relu(x @ W0 + b0) @ W1 + b1)      x (rows,cin)  W_l (cin_l, widths[l])
+ * with all weights resident in LDS and the hidden activation kept in registers; pool = 32 adds a
+ * max over each consecutive group of 32 rows (y is (rows/32, w_last)), pool = 0 keeps all rows.
+ * widths multiples of 32, <= 128; PN2_EUNSUP when the configuration does not fit (callers fall
+ * back to pn2_linear). */
+int pn2_mlp_chain(int rows, int cin, const float *x, int nlayers, const int *widths,
+                  const float *const *w, const float *const *bias, int pool, float *y,
+                  void *stream);
 
 #ifdef __cplusplus
 }

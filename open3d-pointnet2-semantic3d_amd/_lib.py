@@ -30,7 +30,8 @@ SIGNATURES = {
     "pn2_sa_mlp_max_fused": [c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p,
                              c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p],
     "pn2_fp_interp_concat": [c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p,
-                             c_void_p, c_void_p],
+                             c_void_p, c_int, c_void_p],
+    "pn2_mlp_chain": [c_int, c_int, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p],
     "pn2_sa_group_concat": [c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p,
                             c_void_p, c_void_p],
 }
@@ -94,6 +95,9 @@ class _LibProxy:
             if name == "pn2_sa_mlp_max_fused":  # decode the host-side widths[] array for flop accounting
                 wp = ctypes.cast(args[10], ctypes.POINTER(c_int))
                 ints += [wp[i] for i in range(args[9])]
+            elif name == "pn2_mlp_chain":
+                wp = ctypes.cast(args[4], ctypes.POINTER(c_int))
+                ints += [wp[i] for i in range(args[3])]
             self.trace.append((name, tuple(ints), s, e))
             return rc
 

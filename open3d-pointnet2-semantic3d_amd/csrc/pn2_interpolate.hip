@@ -17,59 +17,166 @@ namespace {
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 constexpr int kNnThreads = 256;
-constexpr int kNnTile = 4096;  // known points per LDS tile as float4: 64 KiB
+constexpr int kNnWaves = kNnThreads / 64;
+constexpr int kNnQ = 8;        // queries per wave
+constexpr int kNnChunks = 16;  // candidate chunks (of 64) held in registers at a time: 1024 points
+constexpr int kNnList = 32;    // per-query candidate list (LDS)
 
-// Exact float64 3-NN with an fp32 prefilter.  Every candidate is first measured in fp32 (6 fast
-// VALU ops); only candidates that could still enter the top-3 are re-measured in float64 exactly as
-// the reference does (tf_interpolate.cpp:20-28 -> FLANN L2<double>: ((0+dx*dx)+dy*dy)+dz*dz).
-// Safety of the filter: with exactly representable inputs the fp32 value d32 satisfies
-// |d32 - d| <= 5*2^-24 * d  (fl(a-b) and each mul/add contribute one 2^-24 relative error, all
-// terms are non-negative), so d < b3 implies d32 < b3*(1+3e-7) < thr := float(b3*(1+1e-6)).
-// Candidates are visited in ascending index with strict '<', so ties keep the lowest index.
+struct NnPoint { float x, y, z; };
+
+__device__ __forceinline__ float nn_d32(float qx, float qy, float qz, const NnPoint& c) {
+    const float fx = qx - c.x, fy = qy - c.y, fz = qz - c.z;
+    return __builtin_fmaf(fz, fz, __builtin_fmaf(fy, fy, fx * fx));  // filter only: any rounding within the bound
+}
+
+// wave64 minimum of non-negative floats / +inf (as int bits), uniform result
+__device__ __forceinline__ int nn_wave_imin(int v) {
+    asm volatile(
+        "s_nop 1\n"
+        "v_min_i32_dpp %0, %0, %0 row_shr:1 row_mask:0xf bank_mask:0xf\n s_nop 1\n"
+        "v_min_i32_dpp %0, %0, %0 row_shr:2 row_mask:0xf bank_mask:0xf\n s_nop 1\n"
+        "v_min_i32_dpp %0, %0, %0 row_shr:4 row_mask:0xf bank_mask:0xf\n s_nop 1\n"
+        "v_min_i32_dpp %0, %0, %0 row_shr:8 row_mask:0xf bank_mask:0xf\n s_nop 1\n"
+        "v_min_i32_dpp %0, %0, %0 row_bcast:15 row_mask:0xa bank_mask:0xf\n s_nop 1\n"
+        "v_min_i32_dpp %0, %0, %0 row_bcast:31 row_mask:0xc bank_mask:0xf\n s_nop 1\n"
+        : "+v"(v));
+    return __builtin_amdgcn_readlane(v, 63);
+}
+
+// Exact float64 3-NN (reference semantics: tf_interpolate.cpp:20-28 -> FLANN L2<double>,
+// ((0+dx*dx)+dy*dy)+dz*dz), organised like the ball query: one wave owns kNnQ queries, the known
+// points sit one per lane in registers (16 chunks = 1024 points at a time) and are shared by the
+// wave's queries.
+//   pass 1  fp32, branch-free: per query, every lane keeps the minimum d32 over its own candidates;
+//           the 3rd smallest of the 64 lane minima (three distinct candidates) bounds the 3rd-NN
+//           distance from above:  thr = t3 * (1 + 2e-6);
+//   pass 2  fp32: candidates with d32 <= thr (a handful) are appended in index order (ballot +
+//           mbcnt) to the query's list in LDS;
+//   refine  lane q walks the list of query q in float64 with a strict '<' insertion, so ties keep
+//           the lowest index exactly like a full ascending scan.
+// Filter safety: inputs are exact and all terms non-negative, so |d32 - d| <= 5*2^-24 * d; the three
+// bounding candidates have exact distances <= t3*(1+4e-7), hence every true top-3 candidate has
+// d32 <= t3*(1+8e-7) < thr.  A list overflow (> 32 candidates inside thr: heavy duplication) falls
+// back to a full float64 scan of that query by one lane.
 __global__ void __launch_bounds__(kNnThreads)
 three_nn_kernel(int n, int m, const float* __restrict__ xyz1_all,
                 const float* __restrict__ xyz2_all, float* __restrict__ dist_all,
                 int* __restrict__ idx_all) {
-    __shared__ float4 sref[kNnTile];
+    __shared__ int slist[kNnWaves * kNnQ * kNnList];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int bi = blockIdx.y;
-    const int j = blockIdx.x * kNnThreads + threadIdx.x;
+    const int q0 = (blockIdx.x * kNnWaves + wave) * kNnQ;
+    if (q0 >= n) return;  // wave-uniform, no barriers in this kernel
     const float* __restrict__ xyz1 = xyz1_all + (size_t)bi * n * 3;
     const float* __restrict__ xyz2 = xyz2_all + (size_t)bi * m * 3;
-    const bool active = j < n;
-    float qxf = 0.f, qyf = 0.f, qzf = 0.f;
-    if (active) { qxf = xyz1[j * 3 + 0]; qyf = xyz1[j * 3 + 1]; qzf = xyz1[j * 3 + 2]; }
-    const double qx = qxf, qy = qyf, qz = qzf;
-    double b1 = INFINITY, b2 = INFINITY, b3 = INFINITY;
-    int i1 = 0, i2 = 0, i3 = 0;
-    float thr = INFINITY;
-    for (int t0 = 0; t0 < m; t0 += kNnTile) {
-        const int tn = m - t0 < kNnTile ? m - t0 : kNnTile;
-        __syncthreads();
-        for (int e = threadIdx.x; e < tn; e += kNnThreads)
-            sref[e] = make_float4(xyz2[(t0 + e) * 3 + 0], xyz2[(t0 + e) * 3 + 1], xyz2[(t0 + e) * 3 + 2], 0.f);
-        __syncthreads();
-        if (active) {
-#pragma unroll 4
-            for (int k = 0; k < tn; ++k) {
-                const float4 r = sref[k];  // broadcast read
-                const float fx = qxf - r.x, fy = qyf - r.y, fz = qzf - r.z;
-                const float d32 = (fx * fx + fy * fy) + fz * fz;
-                if (d32 <= thr) {  // rare once three neighbours are known
-                    const double dx = qx - (double)r.x, dy = qy - (double)r.y, dz = qz - (double)r.z;
-                    const double d = (dx * dx + dy * dy) + dz * dz;  // contraction is off
-                    if (d < b3) {
-                        const int kk = t0 + k;
-                        if (d < b1) { b3 = b2; i3 = i2; b2 = b1; i2 = i1; b1 = d; i1 = kk; }
-                        else if (d < b2) { b3 = b2; i3 = i2; b2 = d; i2 = kk; }
-                        else { b3 = d; i3 = kk; }
-                        thr = (float)(b3 * (1.0 + 1e-6));  // +inf while fewer than 3 neighbours are known
+    const NnPoint* __restrict__ cand = reinterpret_cast<const NnPoint*>(xyz2);
+    int* wl = slist + wave * kNnQ * kNnList;
+
+    float qx[kNnQ], qy[kNnQ], qz[kNnQ];
+#pragma unroll
+    for (int q = 0; q < kNnQ; ++q) {
+        const int jq = q0 + q < n ? q0 + q : n - 1;
+        qx[q] = __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(xyz1[jq * 3 + 0])));
+        qy[q] = __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(xyz1[jq * 3 + 1])));
+        qz[q] = __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(xyz1[jq * 3 + 2])));
+    }
+    const int last = m - 1;
+    const int nblk = (m + 64 * kNnChunks - 1) / (64 * kNnChunks);
+    NnPoint c[kNnChunks];
+    auto load_block = [&](int blk) {
+#pragma unroll
+        for (int t = 0; t < kNnChunks; ++t) {
+            const int k = (blk * kNnChunks + t) * 64 + lane;
+            c[t] = cand[k < last ? k : last];  // clamped; out-of-range lanes are masked by index below
+        }
+    };
+
+    // ---- pass 1 -------------------------------------------------------------------------------
+    float mn[kNnQ];
+#pragma unroll
+    for (int q = 0; q < kNnQ; ++q) mn[q] = INFINITY;
+    for (int blk = 0; blk < nblk; ++blk) {
+        load_block(blk);
+#pragma unroll
+        for (int t = 0; t < kNnChunks; ++t) {
+            const int k = (blk * kNnChunks + t) * 64 + lane;
+            if ((blk * kNnChunks + t) * 64 < m) {  // wave-uniform chunk guard
+                const bool valid = k < m;
+#pragma unroll
+                for (int q = 0; q < kNnQ; ++q) {
+                    const float d = nn_d32(qx[q], qy[q], qz[q], c[t]);
+                    mn[q] = fminf(mn[q], valid ? d : INFINITY);
+                }
+            }
+        }
+    }
+    float thr[kNnQ];
+#pragma unroll
+    for (int q = 0; q < kNnQ; ++q) {
+        int v = __float_as_int(mn[q]);  // >= 0 or +inf: int order == float order
+        int t3 = 0;
+#pragma unroll
+        for (int r = 0; r < 3; ++r) {
+            t3 = nn_wave_imin(v);
+            const unsigned long long eq = __ballot(v == t3);
+            const int first = __ffsll((long long)eq) - 1;
+            if (lane == first) v = 0x7F800000;  // drop exactly one holder of the current minimum
+        }
+        thr[q] = __int_as_float(t3) * (1.0f + 2e-6f);  // +inf stays +inf
+    }
+
+    // ---- pass 2: collect ----------------------------------------------------------------------
+    int cnt[kNnQ];
+#pragma unroll
+    for (int q = 0; q < kNnQ; ++q) cnt[q] = 0;
+    for (int blk = 0; blk < nblk; ++blk) {
+        if (nblk > 1) load_block(blk);  // single block: still resident from pass 1
+#pragma unroll
+        for (int t = 0; t < kNnChunks; ++t) {
+            const int k = (blk * kNnChunks + t) * 64 + lane;
+            if ((blk * kNnChunks + t) * 64 < m) {
+                const bool valid = k < m;
+#pragma unroll
+                for (int q = 0; q < kNnQ; ++q) {
+                    const bool hit = valid && nn_d32(qx[q], qy[q], qz[q], c[t]) <= thr[q];
+                    const unsigned long long mask = __ballot(hit);
+                    if (mask != 0ull) {
+                        const int pos = cnt[q] + (int)__builtin_amdgcn_mbcnt_hi(
+                                                     (unsigned)(mask >> 32),
+                                                     __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0u));
+                        if (hit && pos < kNnList) wl[q * kNnList + pos] = k;
+                        cnt[q] += __popcll(mask);  // may exceed kNnList: overflow marker
                     }
                 }
             }
         }
     }
-    if (active) {
-        const size_t o = ((size_t)bi * n + j) * 3;
+
+    // ---- refine: lane q owns query q ----------------------------------------------------------
+    int myc = 0;
+#pragma unroll
+    for (int q = 0; q < kNnQ; ++q) myc = lane == q ? cnt[q] : myc;
+    if (lane < kNnQ && q0 + lane < n) {
+        const int jq = q0 + lane;
+        const double dqx = xyz1[jq * 3 + 0], dqy = xyz1[jq * 3 + 1], dqz = xyz1[jq * 3 + 2];
+        double b1 = INFINITY, b2 = INFINITY, b3 = INFINITY;
+        int i1 = 0, i2 = 0, i3 = 0;
+        const bool overflow = myc > kNnList;
+        const int ne = overflow ? m : myc;
+        for (int e = 0; e < ne; ++e) {
+            const int kk = overflow ? e : wl[lane * kNnList + e];
+            const double dx = dqx - (double)xyz2[kk * 3 + 0];
+            const double dy = dqy - (double)xyz2[kk * 3 + 1];
+            const double dz = dqz - (double)xyz2[kk * 3 + 2];
+            const double d = (dx * dx + dy * dy) + dz * dz;  // contraction is off
+            if (d < b3) {  // strict: ascending index order keeps the lowest index on ties
+                if (d < b1) { b3 = b2; i3 = i2; b2 = b1; i2 = i1; b1 = d; i1 = kk; }
+                else if (d < b2) { b3 = b2; i3 = i2; b2 = d; i2 = kk; }
+                else { b3 = d; i3 = kk; }
+            }
+        }
+        const size_t o = ((size_t)bi * n + jq) * 3;
         dist_all[o + 0] = (float)b1; dist_all[o + 1] = (float)b2; dist_all[o + 2] = (float)b3;
         idx_all[o + 0] = i1; idx_all[o + 1] = i2; idx_all[o + 2] = i3;
     }
@@ -135,14 +242,14 @@ three_interpolate_grad_kernel(int n, int c, int m, const float* __restrict__ gra
 // through SGPRs (v_readlane) and the lanes striding over the channels -- every global access is a
 // contiguous 256-byte segment even for odd row widths such as 131.
 __global__ void __launch_bounds__(256)
-fp_interp_concat_kernel(int n, int m, int c1, int c2, int rpw, const float* __restrict__ dist_all,
+fp_interp_concat_kernel(int n, int m, int c1, int c2, int ostride, int rpw, const float* __restrict__ dist_all,
                         const int* __restrict__ idx_all, const float* __restrict__ points1_all,
                         const float* __restrict__ points2_all, float* __restrict__ out_all) {
     // rpw = rows per wave (1..64, chosen by the host so that small levels still fill the chip)
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int bi = blockIdx.y;
-    const int cw = c1 + c2;
+    const int cw = ostride;  // row stride of the output (>= c1 + c2; the pad columns are zero-filled)
     const float* __restrict__ dist = dist_all + (size_t)bi * n * 3;
     const int* __restrict__ idx = idx_all + (size_t)bi * n * 3;
     const float* __restrict__ p2 = points2_all + (size_t)bi * m * c2;
@@ -173,6 +280,7 @@ fp_interp_concat_kernel(int n, int m, int c1, int c2, int rpw, const float* __re
                 const float* __restrict__ q = p1 + (size_t)(row0 + rr) * c1;
                 for (int ch = lane; ch < c1; ch += 64) o[c2 + ch] = q[ch];
             }
+            if (lane < cw - c1 - c2) o[c1 + c2 + lane] = 0.f;  // zero the (< 8) pad columns
         };
         int rr = 0;
         for (; rr + 1 < nrows; rr += 2) { one_row(rr); one_row(rr + 1); }
@@ -196,7 +304,7 @@ extern "C" int pn2_three_nn(int b, int n, int m, const float* xyz1, const float*
     if (b <= 0 || n <= 0 || m < 3) return PN2_EINVAL;
     if (!xyz1 || !xyz2 || !dist || !idx) return PN2_ENULL;
     if ((long long)n * 3 > 0x7fffffffLL || (long long)m * 3 > 0x7fffffffLL || b > 65535) return PN2_ERANGE;
-    dim3 grid((n + kNnThreads - 1) / kNnThreads, b);
+    dim3 grid((n + kNnWaves * kNnQ - 1) / (kNnWaves * kNnQ), b);
     three_nn_kernel<<<grid, kNnThreads, 0, static_cast<hipStream_t>(stream)>>>(n, m, xyz1, xyz2, dist, idx);
     PN2_RETURN_IF_LAUNCH_FAILED();
     return PN2_OK;
@@ -243,10 +351,12 @@ extern "C" int pn2_three_interpolate_grad(int b, int n, int c, int m, const floa
 
 extern "C" int pn2_fp_interp_concat(int b, int n, int m, int c1, int c2, const float* dist,
                                     const int* idx, const float* points1, const float* points2,
-                                    float* out, void* stream) {
+                                    float* out, int out_stride, void* stream) {
     if (b <= 0 || n <= 0 || m <= 0 || c2 <= 0 || c1 < 0) return PN2_EINVAL;
+    if (out_stride == 0) out_stride = c1 + c2;
+    if (out_stride < c1 + c2 || out_stride > c1 + c2 + 64) return PN2_EINVAL;
     if (!dist || !idx || !points2 || !out || (c1 > 0 && !points1)) return PN2_ENULL;
-    if ((unsigned long long)n * (c1 + c2) > 0xffffffffull || b > 65535) return PN2_ERANGE;
+    if ((unsigned long long)n * out_stride > 0x7fffffffull || b > 65535) return PN2_ERANGE;
     // rows per wave: as many as possible (amortises the per-row weight maths) while keeping
     // >= ~4096 waves in flight; 4 waves per block, grid-stride beyond ~8 blocks per CU
     int rpw = (int)(((long long)b * n) / 4096);
@@ -258,7 +368,7 @@ extern "C" int pn2_fp_interp_concat(int b, int n, int m, int c1, int c2, const f
     if (gx < 1) gx = 1;
     dim3 grid(gx, b);
     fp_interp_concat_kernel<<<grid, 256, 0, static_cast<hipStream_t>(stream)>>>(
-        n, m, c1, c2, rpw, dist, idx, c1 > 0 ? points1 : nullptr, points2, out);
+        n, m, c1, c2, out_stride, rpw, dist, idx, c1 > 0 ? points1 : nullptr, points2, out);
     PN2_RETURN_IF_LAUNCH_FAILED();
     return PN2_OK;
 }

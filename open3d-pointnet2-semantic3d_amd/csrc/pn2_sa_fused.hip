@@ -30,7 +30,8 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 struct SaFusedParams {
-    int n, m, c, groups;  // groups = b*m
+    int n, m, c, groups;  // groups = b*m (gather mode) or ceil(rows/32) (dense mode)
+    int rows;             // dense mode: number of input rows
     int w[3];             // layer widths
     const float* xyz;
     const float* new_xyz;
@@ -44,16 +45,22 @@ struct SaFusedParams {
 __device__ __forceinline__ int acc_chan(int r, int half) { return (r & 3) + 8 * (r >> 2) + 4 * half; }
 
 // number of k-steps of layer 1 for c feature channels
-__host__ __device__ inline int l1_steps(int c, bool vec8) { return 2 + (vec8 ? (c / 8) * 4 : (c + 1) / 2); }
+__host__ __device__ inline int l1_steps(int c, bool vec8, bool dense = false) {
+    return (dense ? 0 : 2) + (vec8 ? (c / 8) * 4 : (c + 1) / 2);
+}
 
 // input channel (row of W1) fed by half-wave `h` at k-step `s` of layer 1; -1 = zero pad
-__device__ __forceinline__ int l1_chan(int s, int h, int c, bool vec8) {
-    if (s == 0) return h;              // x | y
-    if (s == 1) return h ? -1 : 2;     // z | 0
-    const int sp = s - 2;
-    if (vec8) return 3 + 8 * (sp >> 2) + 4 * h + (sp & 3);
-    const int ch = 2 * sp + h;
-    return ch < c ? 3 + ch : -1;
+__device__ __forceinline__ int l1_chan(int s, int h, int c, bool vec8, bool dense) {
+    int base = 0;
+    if (!dense) {
+        if (s == 0) return h;              // x | y
+        if (s == 1) return h ? -1 : 2;     // z | 0
+        s -= 2;
+        base = 3;
+    }
+    if (vec8) return base + 8 * (s >> 2) + 4 * h + (s & 3);
+    const int ch = 2 * s + h;
+    return ch < c ? base + ch : -1;
 }
 
 template <int NT, bool LAST>
@@ -141,8 +148,28 @@ __device__ __forceinline__ void pool_store(const f32x16 (&acc)[NT], const float*
     }
 }
 
-template <int L, int NT1, int NT2, int NT3, bool VEC8>
-__global__ void __launch_bounds__(256, 2)  // 2 waves/SIMD: <= 256 VGPR+AGPR per lane
+// last-layer epilogue without pooling: relu(acc + bias) for all 32 rows of the tile
+template <int NT>
+__device__ __forceinline__ void rows_store(const f32x16 (&acc)[NT], const float* __restrict__ sbias,
+                                           float* __restrict__ obase, int wout, int row0, int rows,
+                                           int half, int l31) {
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+        const float bv = sbias[nt * 32 + l31];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int row = row0 + acc_chan(r, half);
+            if (row < rows) obase[(size_t)row * wout + nt * 32 + l31] = fmaxf(acc[nt][r] + bv, 0.f);
+        }
+    }
+}
+
+// DENSE = false: set-abstraction mode (rows gathered by idx, [xyz - centre | features]).
+// DENSE = true : plain rows of a (rows, c) matrix (feature-propagation MLPs); POOL selects the
+//                max over each 32-row tile or the full (rows, wout) output.
+// NW waves per workgroup share one LDS copy of the weights.
+template <int L, int NT1, int NT2, int NT3, bool VEC8, bool DENSE, bool POOL, int NW>
+__global__ void __launch_bounds__(NW * 64, 2)  // 2 waves/SIMD: <= 256 VGPR+AGPR per lane
 sa_fused_kernel(SaFusedParams p) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int tid = threadIdx.x;
@@ -152,7 +179,8 @@ sa_fused_kernel(SaFusedParams p) {
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     constexpr int W1 = NT1 * 32, W2 = NT2 * 32, W3 = NT3 * 32;
     const int c = p.c;
-    const int steps1 = l1_steps(c, VEC8);
+    const int steps1 = l1_steps(c, VEC8, DENSE);
+    constexpr int NTH = NW * 64;
 
     // ---- LDS carve + weight staging (once per persistent workgroup) -----------
     float* wp1 = smem;
@@ -161,50 +189,56 @@ sa_fused_kernel(SaFusedParams p) {
     float* sb1 = wp3 + (L >= 3 ? W2 * W3 : 0);
     float* sb2 = sb1 + W1;
     float* sb3 = sb2 + (L >= 2 ? W2 : 0);
-    for (int e = tid; e < steps1 * 2 * W1; e += 256) {
+    for (int e = tid; e < steps1 * 2 * W1; e += NTH) {
         const int col = e % W1, sh = e / W1;
-        const int ch = l1_chan(sh >> 1, sh & 1, c, VEC8);
+        const int ch = l1_chan(sh >> 1, sh & 1, c, VEC8, DENSE);
         wp1[e] = ch >= 0 ? p.W[0][(size_t)ch * W1 + col] : 0.f;
     }
-    for (int e = tid; e < W1; e += 256) sb1[e] = p.bias[0][e];
+    for (int e = tid; e < W1; e += NTH) sb1[e] = p.bias[0][e];
     if constexpr (L >= 2) {
-        for (int e = tid; e < W1 * W2; e += 256) {
+        for (int e = tid; e < W1 * W2; e += NTH) {
             const int col = e % W2, sh = e / W2;
             const int s = sh >> 1, h = sh & 1;
             const int ch = (s >> 4) * 32 + acc_chan(s & 15, h);
             wp2[e] = p.W[1][(size_t)ch * W2 + col];
         }
-        for (int e = tid; e < W2; e += 256) sb2[e] = p.bias[1][e];
+        for (int e = tid; e < W2; e += NTH) sb2[e] = p.bias[1][e];
     }
     if constexpr (L >= 3) {
-        for (int e = tid; e < W2 * W3; e += 256) {
+        for (int e = tid; e < W2 * W3; e += NTH) {
             const int col = e % W3, sh = e / W3;
             const int s = sh >> 1, h = sh & 1;
             const int ch = (s >> 4) * 32 + acc_chan(s & 15, h);
             wp3[e] = p.W[2][(size_t)ch * W3 + col];
         }
-        for (int e = tid; e < W3; e += 256) sb3[e] = p.bias[2][e];
+        for (int e = tid; e < W3; e += NTH) sb3[e] = p.bias[2][e];
     }
     __syncthreads();
 
     constexpr int WOUT = L == 1 ? W1 : (L == 2 ? W2 : W3);
-    for (int g = blockIdx.x * 4 + wave; g < p.groups; g += gridDim.x * 4) {
-        const int bi = g / p.m;
-        const int ii = p.idx[(size_t)g * 32 + l31];
-        const size_t prow = (size_t)bi * p.n + ii;
-        const float cxv = p.new_xyz[(size_t)g * 3 + 0];
-        const float cyv = p.new_xyz[(size_t)g * 3 + 1];
-        const float czv = p.new_xyz[(size_t)g * 3 + 2];
-        const float rx = p.xyz[prow * 3 + 0] - cxv;  // grouped_xyz -= tile(new_xyz) :44-46
-        const float ry = p.xyz[prow * 3 + 1] - cyv;
-        const float rz = p.xyz[prow * 3 + 2] - czv;
-
+    for (int g = blockIdx.x * NW + wave; g < p.groups; g += gridDim.x * NW) {
+        size_t prow;  // row of the feature matrix feeding this lane
         f32x16 a1[NT1];
         zero_acc<NT1>(a1);
         constexpr bool LAST1 = (L == 1);
         const float* w1l = wp1 + half * W1 + l31;
-        mfma_step<NT1, LAST1>(a1, w1l + 0 * 2 * W1, half ? ry : rx);
-        mfma_step<NT1, LAST1>(a1, w1l + 1 * 2 * W1, half ? 0.f : rz);
+        constexpr int S0 = DENSE ? 0 : 2;  // first feature k-step
+        if constexpr (DENSE) {
+            const int row = g * 32 + l31;
+            prow = (size_t)(row < p.rows ? row : p.rows - 1);
+        } else {
+            const int bi = g / p.m;
+            const int ii = p.idx[(size_t)g * 32 + l31];
+            prow = (size_t)bi * p.n + ii;
+            const float cxv = p.new_xyz[(size_t)g * 3 + 0];
+            const float cyv = p.new_xyz[(size_t)g * 3 + 1];
+            const float czv = p.new_xyz[(size_t)g * 3 + 2];
+            const float rx = p.xyz[prow * 3 + 0] - cxv;  // grouped_xyz -= tile(new_xyz) :44-46
+            const float ry = p.xyz[prow * 3 + 1] - cyv;
+            const float rz = p.xyz[prow * 3 + 2] - czv;
+            mfma_step<NT1, LAST1>(a1, w1l + 0 * 2 * W1, half ? ry : rx);
+            mfma_step<NT1, LAST1>(a1, w1l + 1 * 2 * W1, half ? 0.f : rz);
+        }
         if constexpr (VEC8) {
             const f32x4* __restrict__ fp =
                 reinterpret_cast<const f32x4*>(p.points + prow * c) + half;
@@ -215,7 +249,7 @@ sa_fused_kernel(SaFusedParams p) {
                 if (t + 1 < nt8) nxt = fp[(t + 1) * 2];
 #pragma unroll
                 for (int q = 0; q < 4; ++q)
-                    mfma_step<NT1, LAST1>(a1, w1l + (2 + 4 * t + q) * 2 * W1, cur[q]);
+                    mfma_step<NT1, LAST1>(a1, w1l + (S0 + 4 * t + q) * 2 * W1, cur[q]);
                 cur = nxt;
             }
         } else {
@@ -224,55 +258,70 @@ sa_fused_kernel(SaFusedParams p) {
             for (int sp = 0; sp < ns; ++sp) {
                 const int ch = 2 * sp + half;
                 const float v = ch < c ? fp[ch] : 0.f;
-                mfma_step<NT1, LAST1>(a1, w1l + (2 + sp) * 2 * W1, v);
+                mfma_step<NT1, LAST1>(a1, w1l + (S0 + sp) * 2 * W1, v);
             }
         }
         float* __restrict__ orow = p.out + (size_t)g * WOUT;
         if constexpr (L == 1) {
-            pool_store<NT1>(a1, sb1, orow, half, l31);
+            if constexpr (POOL) pool_store<NT1>(a1, sb1, orow, half, l31);
+            else rows_store<NT1>(a1, sb1, p.out, WOUT, g * 32, p.rows, half, l31);
         } else {
             bias_relu_T<NT1>(a1, sb1, half);
             f32x16 a2[NT2];
             zero_acc<NT2>(a2);
             layer_from_regs<NT1, NT2, L == 2>(a1, a2, wp2, W2, half, l31);
             if constexpr (L == 2) {
-                pool_store<NT2>(a2, sb2, orow, half, l31);
+                if constexpr (POOL) pool_store<NT2>(a2, sb2, orow, half, l31);
+                else rows_store<NT2>(a2, sb2, p.out, WOUT, g * 32, p.rows, half, l31);
             } else {
                 bias_relu_T<NT2>(a2, sb2, half);
                 f32x16 a3[NT3];
                 zero_acc<NT3>(a3);
                 layer_from_regs<NT2, NT3, true>(a2, a3, wp3, W3, half, l31);
-                pool_store<NT3>(a3, sb3, orow, half, l31);
+                if constexpr (POOL) pool_store<NT3>(a3, sb3, orow, half, l31);
+                else rows_store<NT3>(a3, sb3, p.out, WOUT, g * 32, p.rows, half, l31);
             }
         }
     }
 }
 
-template <int L, int NT1, int NT2, int NT3, bool VEC8>
-int launch_sa_fused(const SaFusedParams& p, hipStream_t st) {
+template <int L, int NT1, int NT2, int NT3, bool VEC8, bool DENSE, bool POOL>
+int launch_chain(const SaFusedParams& p, hipStream_t st) {
     constexpr int W1 = NT1 * 32, W2 = NT2 * 32, W3 = NT3 * 32;
-    const int steps1 = l1_steps(p.c, VEC8);
+    const int steps1 = l1_steps(p.c, VEC8, DENSE);
     size_t floats = (size_t)steps1 * 2 * W1 + W1;
     if (L >= 2) floats += (size_t)W1 * W2 + W2;
     if (L >= 3) floats += (size_t)W2 * W3 + W3;
     const size_t bytes = floats * sizeof(float);
     if (bytes > 150 * 1024) return PN2_EUNSUP;
-    auto kern = sa_fused_kernel<L, NT1, NT2, NT3, VEC8>;
-    static bool attr_set = false;  // per instantiation; benign race (idempotent call)
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        if (e != hipSuccess) return (int)e;
-        attr_set = true;
+    const int need4 = (p.groups + 3) / 4;
+    if (bytes > 78 * 1024) {
+        // only one workgroup fits per CU: give it 8 waves (2 per SIMD) sharing the LDS weights
+        auto kern = sa_fused_kernel<L, NT1, NT2, NT3, VEC8, DENSE, POOL, 8>;
+        static bool attr_set = false;  // per instantiation; benign race (idempotent call)
+        if (!attr_set) {
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            if (e != hipSuccess) return (int)e;
+            attr_set = true;
+        }
+        int grid = 256;
+        const int need8 = (p.groups + 7) / 8;
+        if (grid > need8) grid = need8;
+        kern<<<grid, 512, bytes, st>>>(p);
+    } else {
+        auto kern = sa_fused_kernel<L, NT1, NT2, NT3, VEC8, DENSE, POOL, 4>;
+        static bool attr_set = false;
+        if (!attr_set) {
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            if (e != hipSuccess) return (int)e;
+            attr_set = true;
+        }
+        int grid = 256 * 2;  // two 4-wave workgroups per CU
+        if (grid > need4) grid = need4;
+        kern<<<grid, 256, bytes, st>>>(p);
     }
-    // persistent grid: as many 4-wave workgroups as LDS lets be co-resident (<= 2 per CU)
-    int per_cu = (int)((160 * 1024) / (bytes + 1024));
-    if (per_cu < 1) per_cu = 1;
-    if (per_cu > 2) per_cu = 2;
-    int grid = 256 * per_cu;
-    const int need = (p.groups + 3) / 4;
-    if (grid > need) grid = need;
-    kern<<<grid, 256, bytes, st>>>(p);
     PN2_RETURN_IF_LAUNCH_FAILED();
     return PN2_OK;
 }
@@ -302,8 +351,8 @@ extern "C" int pn2_sa_mlp_max_fused(int b, int n, int m, int nsample, int c, con
     const int key = nlayers * 1000 + nt[0] * 100 + nt[1] * 10 + nt[2];
 #define PN2_SA_CASE(L_, A_, B_, C_)                                                     \
     case (L_ * 1000 + A_ * 100 + B_ * 10 + C_):                                         \
-        return vec8 ? launch_sa_fused<L_, A_, (B_ ? B_ : 1), (C_ ? C_ : 1), true>(p, st) \
-                    : launch_sa_fused<L_, A_, (B_ ? B_ : 1), (C_ ? C_ : 1), false>(p, st);
+        return vec8 ? launch_chain<L_, A_, (B_ ? B_ : 1), (C_ ? C_ : 1), true, false, true>(p, st) \
+                    : launch_chain<L_, A_, (B_ ? B_ : 1), (C_ ? C_ : 1), false, false, true>(p, st);
     switch (key) {
         PN2_SA_CASE(3, 1, 1, 2)  // SA1 of semantic.json: [32,32,64]
         PN2_SA_CASE(3, 2, 2, 4)  // SA2: [64,64,128]
@@ -318,4 +367,47 @@ extern "C" int pn2_sa_mlp_max_fused(int b, int n, int m, int nsample, int c, con
         default: return PN2_EUNSUP;
     }
 #undef PN2_SA_CASE
+}
+
+// Dense-row MLP chain (feature-propagation layers, pointnet_util.py:312-325 with inference BN
+// folded): y = relu(...relu(x @ W0 + b0)... @ W_{L-1} + b_{L-1}), optionally max-pooled over each
+// consecutive group of 32 rows.  Same kernel as the fused SA MLP with the gather switched off: the
+// weights of all layers stay resident in LDS and activations never leave registers between layers.
+//   x (rows, cin) row-major;  y (rows, w_last) or (rows/32, w_last) when pool == 32.
+// Constraints: 1 <= nlayers <= 2 here (3 x 128-wide layers do not fit LDS), widths multiples of 32,
+// <= 128, all weights must fit ~150 KB of LDS; PN2_EUNSUP otherwise (callers fall back to pn2_linear).
+extern "C" int pn2_mlp_chain(int rows, int cin, const float* x, int nlayers, const int* widths,
+                             const float* const* w, const float* const* bias, int pool, float* y,
+                             void* stream) {
+    if (rows <= 0 || cin <= 0 || nlayers <= 0) return PN2_EINVAL;
+    if (!x || !widths || !w || !bias || !y) return PN2_ENULL;
+    if (nlayers > 2 || (pool != 0 && pool != 32)) return PN2_EUNSUP;
+    if (pool == 32 && rows % 32 != 0) return PN2_EINVAL;
+    SaFusedParams p{};
+    p.c = cin; p.rows = rows; p.groups = (rows + 31) / 32;
+    p.points = x; p.out = y;
+    int nt[2] = {0, 0};
+    for (int l = 0; l < nlayers; ++l) {
+        if (widths[l] <= 0 || widths[l] % 32 != 0 || widths[l] > 128) return PN2_EUNSUP;
+        if (!w[l] || !bias[l]) return PN2_ENULL;
+        p.w[l] = widths[l]; p.W[l] = w[l]; p.bias[l] = bias[l];
+        nt[l] = widths[l] / 32;
+    }
+    const bool vec8 = (cin % 8 == 0) && ((uintptr_t)x % 16 == 0);
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    const int key = nlayers * 100 + nt[0] * 10 + nt[1];
+#define PN2_CHAIN_CASE(L_, A_, B_)                                                                   \
+    case (L_ * 100 + A_ * 10 + B_):                                                                  \
+        if (pool) return vec8 ? launch_chain<L_, A_, (B_ ? B_ : 1), 1, true, true, true>(p, st)      \
+                              : launch_chain<L_, A_, (B_ ? B_ : 1), 1, false, true, true>(p, st);    \
+        return vec8 ? launch_chain<L_, A_, (B_ ? B_ : 1), 1, true, true, false>(p, st)               \
+                    : launch_chain<L_, A_, (B_ ? B_ : 1), 1, false, true, false>(p, st);
+    switch (key) {
+        PN2_CHAIN_CASE(1, 4, 0)
+        PN2_CHAIN_CASE(2, 4, 4)
+        PN2_CHAIN_CASE(1, 2, 0)
+        PN2_CHAIN_CASE(2, 2, 4)
+        default: return PN2_EUNSUP;
+    }
+#undef PN2_CHAIN_CASE
 }

@@ -212,27 +212,66 @@ def pointnet_sa_module_msg(xyz, points, npoint, radius_list, nsample_list, mlp_l
         return new_xyz, torch.cat(outs, dim=-1)
 
 
-def _fp_interp_concat(dist, idx, points1, points2):
+def _fp_interp_concat(dist, idx, points1, points2, pad_to=1):
+    """-> (B, n, roundup(c2+c1, pad_to)); pad columns are zero."""
     b, n, _ = dist.shape
     m, c2 = points2.shape[1], points2.shape[2]
     c1 = 0 if points1 is None else points1.shape[2]
-    out = torch.empty((b, n, c1 + c2), dtype=torch.float32, device=dist.device)
+    cw = -(-(c1 + c2) // pad_to) * pad_to
+    out = torch.empty((b, n, cw), dtype=torch.float32, device=dist.device)
     p1 = None if points1 is None else points1.contiguous()
     p2 = points2.contiguous()
     with torch.cuda.device(dist.device):
-        check(lib.pn2_fp_interp_concat(b, n, m, c1, c2, ptr(dist), ptr(idx), ptr(p1), ptr(p2), ptr(out),
+        check(lib.pn2_fp_interp_concat(b, n, m, c1, c2, ptr(dist), ptr(idx), ptr(p1), ptr(p2), ptr(out), cw,
                                        stream_ptr()), "pn2_fp_interp_concat")
     return out
+
+
+USE_MLP_CHAIN = True  # set False to force one pn2_linear launch per layer (tests/bench)
+
+
+def dense_mlp_inference(x2d, cin, mlp, scope_fmt, bn=True):
+    """Run a stack of 1x1-conv layers on (rows, cin_padded) rows.  Consecutive layers whose widths are
+    <= 128 run as LDS-resident chains (pn2_mlp_chain, up to 2 layers per launch); anything else runs
+    one pn2_linear per layer.  `cin` is the true input width (x2d may carry zero pad columns).
+    Must be called inside the module's variable scope."""
+    folded = []
+    c = cin
+    for i, cout in enumerate(mlp):
+        with tf_util.variable_scope(scope_fmt % i):
+            pad_in = x2d.shape[1] if i == 0 else None
+            folded.append(tf_util.folded_dense(c, cout, bn, (1, 1, c, cout), pad_to=32, pad_in=pad_in))
+        c = cout
+    i, h = 0, x2d
+    while i < len(mlp):
+        done = False
+        # the LDS-resident chain pays off when there are enough 32-row tiles to fill the chip
+        if USE_MLP_CHAIN and h.shape[0] >= 65536 and all(w <= 128 and w % 32 == 0 for w in mlp[i:i + 2]):
+            for take in (2, 1):
+                if i + take > len(mlp) or any(w > 128 or w % 32 for w in mlp[i:i + take]):
+                    continue
+                y = tf_util.hip_mlp_chain(h, [folded[k][0] for k in range(i, i + take)],
+                                          [folded[k][1] for k in range(i, i + take)])
+                if y is not None:
+                    h, i, done = y, i + take, True
+                    break
+        if not done:
+            w2, b2 = folded[i]
+            h = tf_util.hip_linear(h, w2, b2, relu=True)
+            if h.shape[1] != mlp[i]:
+                h = h[:, :mlp[i]].contiguous()
+            i += 1
+    return h
 
 
 def fp_features_inference(dist, idx, points1, points2, mlp, bn=True, bn_decay=None):
     """The feature half of an FP layer (inference) given three_nn's (dist, idx).  Must be called
     inside the layer's variable scope."""
-    h = _fp_interp_concat(dist, idx, points1, points2).unsqueeze(2)
-    for i, cout in enumerate(mlp):
-        h = tf_util.conv2d(h, cout, [1, 1], padding="VALID", stride=[1, 1], bn=bn, is_training=False,
-                           scope="conv_%d" % i, bn_decay=bn_decay)
-    return h.squeeze(2)
+    b, n = dist.shape[0], dist.shape[1]
+    cin = points2.shape[2] + (0 if points1 is None else points1.shape[2])
+    x = _fp_interp_concat(dist, idx, points1, points2, pad_to=8)  # e.g. 131 -> 136: 16-byte loads downstream
+    h = dense_mlp_inference(x.reshape(b * n, x.shape[2]), cin, mlp, "conv_%d", bn)
+    return h.reshape(b, n, mlp[-1])
 
 
 def pointnet_fp_module(xyz1, xyz2, points1, points2, mlp, is_training, bn_decay, scope, bn=True):
@@ -242,13 +281,13 @@ def pointnet_fp_module(xyz1, xyz2, points1, points2, mlp, is_training, bn_decay,
     with tf_util.variable_scope(scope):
         dist, idx = three_nn(xyz1, xyz2)
         if not is_training:
-            new_points1 = _fp_interp_concat(dist, idx, points1, points2)  # weights + interpolate + concat fused
-        else:
-            dist = torch.clamp(dist, min=1e-10)
-            norm = (1.0 / dist).sum(dim=2, keepdim=True)
-            weight = (1.0 / dist) / norm
-            interpolated = three_interpolate(points2, idx, weight)
-            new_points1 = torch.cat([interpolated, points1], dim=2) if points1 is not None else interpolated
+            # weights + interpolate + concat fused, then LDS-resident MLP chains / MFMA layers
+            return fp_features_inference(dist, idx, points1, points2, mlp, bn, bn_decay)
+        dist = torch.clamp(dist, min=1e-10)
+        norm = (1.0 / dist).sum(dim=2, keepdim=True)
+        weight = (1.0 / dist) / norm
+        interpolated = three_interpolate(points2, idx, weight)
+        new_points1 = torch.cat([interpolated, points1], dim=2) if points1 is not None else interpolated
         new_points1 = new_points1.unsqueeze(2)
         for i, cout in enumerate(mlp):
             new_points1 = tf_util.conv2d(new_points1, cout, [1, 1], padding="VALID", stride=[1, 1], bn=bn,

@@ -132,11 +132,11 @@ def _dense_variables(cin, cout, bn, kernel_shape):
     return st, w, b, (beta, gamma, mean, var)
 
 
-def folded_dense(cin, cout, bn, kernel_shape, pad_to=None):
+def folded_dense(cin, cout, bn, kernel_shape, pad_to=None, pad_in=None):
     """(W', b') with the inference BatchNorm folded in:
     y = (x@W + b - mean)/sqrt(var+eps)*gamma + beta = x@(W*s) + ((b-mean)*s + beta)."""
     st, w, b, bnv = _dense_variables(cin, cout, bn, kernel_shape)
-    key = (_full_name("folded"), pad_to)
+    key = (_full_name("folded"), pad_to, pad_in)
 
     def make():
         w2 = w.detach().reshape(cin, cout)
@@ -150,6 +150,8 @@ def folded_dense(cin, cout, bn, kernel_shape, pad_to=None):
             padc = pad_to - cout % pad_to
             w2 = F.pad(w2, (0, padc))
             b2 = F.pad(b2, (0, padc))
+        if pad_in is not None and pad_in > cin:  # zero rows for zero-padded input columns
+            w2 = F.pad(w2, (0, 0, 0, pad_in - cin))
         return w2.contiguous(), b2.contiguous()
 
     srcs = [w, b] + (list(bnv) if bnv is not None else [])
@@ -168,6 +170,30 @@ def hip_linear(x2d, w, b, relu=True, pool=0):
     with torch.cuda.device(x2d.device):
         check(lib.pn2_linear(rows, cin, cout, ptr(x2d), ptr(w), ptr(b), int(bool(relu)), int(pool or 0), ptr(y),
                              stream_ptr()), "pn2_linear")
+    return y
+
+
+def hip_mlp_chain(x2d, ws, bs, pool=0):
+    """relu(relu(x @ W0 + b0) @ W1 + b1) with LDS-resident weights (pn2_mlp_chain).  Returns None
+    when the library reports the configuration as unsupported (caller falls back to hip_linear)."""
+    import ctypes
+    from .._lib import PN2_EUNSUP
+    require_cuda(x2d)
+    rows, cin = x2d.shape
+    x2d = x2d.contiguous()
+    L = len(ws)
+    widths = (ctypes.c_int * L)(*[w.shape[1] for w in ws])
+    wptrs = (ctypes.c_void_p * L)(*[w.data_ptr() for w in ws])
+    bptrs = (ctypes.c_void_p * L)(*[b.data_ptr() for b in bs])
+    orows = rows // pool if pool else rows
+    y = torch.empty((orows, ws[-1].shape[1]), dtype=torch.float32, device=x2d.device)
+    with torch.cuda.device(x2d.device):
+        rc = lib.pn2_mlp_chain(rows, cin, ptr(x2d), L, ctypes.cast(widths, ctypes.c_void_p),
+                               ctypes.cast(wptrs, ctypes.c_void_p), ctypes.cast(bptrs, ctypes.c_void_p), int(pool),
+                               ptr(y), stream_ptr())
+    if rc == PN2_EUNSUP:
+        return None
+    check(rc, "pn2_mlp_chain")
     return y
 
 

@@ -302,3 +302,55 @@ def test_two_stream_and_graph_forward_match_sequential(pn2, cuda):
         ref2, _ = pn2.model.get_sa_fp_features(x2, False, hp)
     torch.cuda.synchronize()
     assert torch.equal(ref2, out2)
+
+
+# ------------------------------------------------------------------ pn2_mlp_chain -----------
+@pytest.mark.parametrize("rows,cin,widths,pool", [(4096, 136, [128, 128], 0), (1000, 128, [128], 0), (777, 131, [128, 128], 0),
+                                                  (2048, 64, [64, 128], 0), (3200, 128, [128, 128], 32), (96, 40, [64], 32)])
+def test_mlp_chain_vs_fp64(pn2, cuda, rows, cin, widths, pool):
+    rs = np.random.RandomState(rows + cin)
+    x = rs.randn(rows, cin).astype(np.float32)
+    ws, bs, ref = [], [], x.astype(np.float64)
+    c = cin
+    for w_ in widths:
+        W = (rs.randn(c, w_) / np.sqrt(c)).astype(np.float32)
+        b = (rs.randn(w_) * 0.1).astype(np.float32)
+        ws.append(T(W, cuda)); bs.append(T(b, cuda))
+        ref = np.maximum(ref @ W.astype(np.float64) + b, 0)
+        c = w_
+    if pool:
+        ref = ref.reshape(rows // pool, pool, widths[-1]).max(1)
+    y = pn2.util.tf_util.hip_mlp_chain(T(x, cuda), ws, bs, pool=pool)
+    assert y is not None
+    close(y.cpu().numpy(), ref)
+
+
+def test_mlp_chain_rejects_what_does_not_fit(pn2, cuda):
+    import torch
+    x = torch.zeros(64, 128, device=cuda)
+    w = torch.zeros(128, 256, device=cuda)
+    b = torch.zeros(256, device=cuda)
+    assert pn2.util.tf_util.hip_mlp_chain(x, [w], [b]) is None  # width 256 > 128 -> caller falls back
+
+
+def test_fp_module_chain_equals_per_layer_linear(pn2, oracle, cuda):
+    """FP4-shaped module: the chained path and the one-launch-per-layer path agree to fp32 rounding."""
+    tfu, pu = pn2.util.tf_util, pn2.util.pointnet_util
+    rs = np.random.RandomState(5)
+    xyz1 = rs.random_sample((2, 1024, 3)).astype(np.float32)
+    xyz2 = xyz1[:, :128].copy()
+    p1 = rs.randn(2, 1024, 3).astype(np.float32)
+    p2 = rs.randn(2, 128, 128).astype(np.float32)
+    store = tfu.set_default_store(tfu.VariableStore(device=cuda, seed=31))
+    args = (T(xyz1, cuda), T(xyz2, cuda), T(p1, cuda), T(p2, cuda), [128, 128, 128], False, None)
+    pu.pointnet_fp_module(*args, scope="fp4")
+    randomize_bn(store, 32)
+    a = pu.pointnet_fp_module(*args, scope="fp4").cpu().numpy()
+    pu.USE_MLP_CHAIN = False
+    try:
+        b = pu.pointnet_fp_module(*args, scope="fp4").cpu().numpy()
+    finally:
+        pu.USE_MLP_CHAIN = True
+    ref = oracle.fp_module(xyz1, xyz2, p1, p2, layer_dicts(store, "fp4", ["conv_0", "conv_1", "conv_2"]))
+    close(a, ref)
+    close(b, ref)
