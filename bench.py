@@ -244,12 +244,11 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     dist_on = world > 1
+    import pn2_amd as pn2
     if dist_on:
         import torch.distributed as dist
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        pn2.dist.init_from_env(backend="nccl", device=dev)  # RCCL; same helper the gloo CPU test drives
 
-    import pn2_amd as pn2
     tfu = pn2.util.tf_util
     hp = dict(pn2.model.SEMANTIC_HYPERPARAMS)
     hp["batch_size"], hp["num_point"] = args.batch, args.points
@@ -307,10 +306,7 @@ def main():
         dist.barrier()
         torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
-    if dist_on:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    elapsed = pn2.dist.max_over_ranks(elapsed, device=dev)  # the slowest rank defines the step time
     assert torch.isfinite(out).all()
 
     # ---- instrumented pass: same steps, every launch bracketed by HIP events on its stream ----

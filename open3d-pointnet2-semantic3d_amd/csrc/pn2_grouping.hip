@@ -43,6 +43,55 @@ constexpr int kBqWaves = kBqThreads / 64;
 
 struct BqChunk { float x, y, z; };
 
+// Scan one 64-candidate chunk for the wave's QPW queries.  TAIL: the chunk is the partial last
+// one (lanes past n are masked).  CHECK: some query may already be full, so each query is tested
+// against nsample first (tf_grouping.cu:20-21); while no query is full the test is skipped.
+// Returns true when every query of the wave is full.
+template <int MODE, int QPW, bool TAIL, bool CHECK>
+__device__ __forceinline__ bool bq_scan(const BqChunk& cur, int c0, int lane, int n, float thr, int nsample,
+                                        const float (&qx)[QPW], const float (&qy)[QPW], const float (&qz)[QPW],
+                                        int (&cnt)[QPW], int (&first)[QPW], int* __restrict__ srow,
+                                        bool& any_full) {
+    // All QPW hit masks are produced first (7 VALU each, the compare writes an SGPR pair directly),
+    // OR-ed, and ONE branch per chunk decides whether anything has to be appended: scalar
+    // instructions cost ~4 cycles each and serialise with VALU issue (PMC: profiles/), so the
+    // common no-hit chunk must not pay per-query branches.
+    const int k = c0 + lane;
+    unsigned long long mk[QPW];
+    unsigned long long any = 0ull;
+#pragma unroll
+    for (int q = 0; q < QPW; ++q) {
+        const float s = pn2_sqdist<MODE>(qx[q] - cur.x, qy[q] - cur.y, qz[q] - cur.z);
+        bool hit = s <= thr;
+        if constexpr (TAIL) hit = hit && (k < n);
+        mk[q] = __ballot(hit);
+        if constexpr (CHECK) mk[q] = cnt[q] < nsample ? mk[q] : 0ull;  // full queries stop collecting (:20-21)
+        any |= mk[q];
+    }
+    if (any != 0ull) {
+#pragma unroll
+        for (int q = 0; q < QPW; ++q) {
+            const unsigned long long mask = mk[q];
+            if (mask != 0ull) {
+                const int pos = cnt[q] + (int)__builtin_amdgcn_mbcnt_hi(
+                                             (unsigned)(mask >> 32),
+                                             __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0u));
+                if (((mask >> lane) & 1ull) && pos < nsample) srow[q * nsample + pos] = k;
+                if (cnt[q] == 0) first[q] = c0 + __ffsll((long long)mask) - 1;
+                cnt[q] += __popcll(mask);
+                any_full = any_full || (cnt[q] >= nsample);
+            }
+        }
+    }
+    if constexpr (CHECK) {
+        bool all_full = true;
+#pragma unroll
+        for (int q = 0; q < QPW; ++q) all_full = all_full && (cnt[q] >= nsample);
+        return all_full;
+    }
+    return false;
+}
+
 // One wave64 owns QPW queries.  The dataset streams through registers 64 candidates at a time
 // (one global_load_dwordx3 per lane per chunk, shared by the QPW queries, prefetched chunks
 // ahead with unconditional clamped loads so the compiler can keep counted vmcnt waits); hits are
@@ -82,29 +131,12 @@ ball_query_kernel(int n, int m, float thr, int nsample, const float* __restrict_
         const int kk = c0 + lane;
         return xyz1[kk < last ? kk : last];
     };
-    // scan one 64-candidate chunk held in `cur`; returns true when every query of the wave is full
+    // out-of-range queries start "full", which forces the checked path for this wave
+    bool any_full = q0 + QPW > m;
     auto scan = [&](const BqChunk& cur, int c0) -> bool {
-        const int k = c0 + lane;
-        const bool valid = k < n;
-        bool all_full = true;
-#pragma unroll
-        for (int q = 0; q < QPW; ++q) {
-            if (cnt[q] < nsample) {  // wave-uniform (tf_grouping.cu:20-21)
-                const float s = pn2_sqdist<MODE>(qx[q] - cur.x, qy[q] - cur.y, qz[q] - cur.z);
-                const bool hit = valid && (s <= thr);
-                const unsigned long long mask = __ballot(hit);
-                if (mask != 0ull) {
-                    const int pos = cnt[q] + (int)__builtin_amdgcn_mbcnt_hi(
-                                                 (unsigned)(mask >> 32),
-                                                 __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0u));
-                    if (hit && pos < nsample) srow[q * nsample + pos] = k;
-                    if (cnt[q] == 0) first[q] = c0 + __ffsll((long long)mask) - 1;
-                    cnt[q] += __popcll(mask);
-                }
-                all_full = all_full && (cnt[q] >= nsample);
-            }
-        }
-        return all_full;
+        if (c0 + 64 > n) return bq_scan<MODE, QPW, true, true>(cur, c0, lane, n, thr, nsample, qx, qy, qz, cnt, first, srow, any_full);
+        if (any_full) return bq_scan<MODE, QPW, false, true>(cur, c0, lane, n, thr, nsample, qx, qy, qz, cnt, first, srow, any_full);
+        return bq_scan<MODE, QPW, false, false>(cur, c0, lane, n, thr, nsample, qx, qy, qz, cnt, first, srow, any_full);
     };
     // 4 chunk registers rotate by name (loop unrolled x4): three loads stay in flight per wave
     BqChunk r0 = load(0), r1 = load(64), r2 = load(128), r3 = load(192);

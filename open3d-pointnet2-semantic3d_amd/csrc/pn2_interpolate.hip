@@ -93,20 +93,27 @@ three_nn_kernel(int n, int m, const float* __restrict__ xyz1_all,
     };
 
     // ---- pass 1 -------------------------------------------------------------------------------
-    float mn[kNnQ];
+    int mn[kNnQ];  // per-lane minimum d32 as int bits (distances are >= +0: int order == float order)
 #pragma unroll
-    for (int q = 0; q < kNnQ; ++q) mn[q] = INFINITY;
+    for (int q = 0; q < kNnQ; ++q) mn[q] = 0x7F800000;
     for (int blk = 0; blk < nblk; ++blk) {
         load_block(blk);
 #pragma unroll
         for (int t = 0; t < kNnChunks; ++t) {
             const int k = (blk * kNnChunks + t) * 64 + lane;
-            if ((blk * kNnChunks + t) * 64 < m) {  // wave-uniform chunk guard
+            const int cbase = (blk * kNnChunks + t) * 64;
+            if (cbase + 64 <= m) {  // full chunk (wave-uniform): no masking, integer min on the bits
+#pragma unroll
+                for (int q = 0; q < kNnQ; ++q) {
+                    const int di = __float_as_int(nn_d32(qx[q], qy[q], qz[q], c[t]));
+                    mn[q] = di < mn[q] ? di : mn[q];
+                }
+            } else if (cbase < m) {  // partial last chunk: lanes past m re-read point m-1 and must not count
                 const bool valid = k < m;
 #pragma unroll
                 for (int q = 0; q < kNnQ; ++q) {
-                    const float d = nn_d32(qx[q], qy[q], qz[q], c[t]);
-                    mn[q] = fminf(mn[q], valid ? d : INFINITY);
+                    const int di = valid ? __float_as_int(nn_d32(qx[q], qy[q], qz[q], c[t])) : 0x7F800000;
+                    mn[q] = di < mn[q] ? di : mn[q];
                 }
             }
         }
@@ -114,7 +121,7 @@ three_nn_kernel(int n, int m, const float* __restrict__ xyz1_all,
     float thr[kNnQ];
 #pragma unroll
     for (int q = 0; q < kNnQ; ++q) {
-        int v = __float_as_int(mn[q]);  // >= 0 or +inf: int order == float order
+        int v = mn[q];
         int t3 = 0;
 #pragma unroll
         for (int r = 0; r < 3; ++r) {
@@ -135,18 +142,29 @@ three_nn_kernel(int n, int m, const float* __restrict__ xyz1_all,
 #pragma unroll
         for (int t = 0; t < kNnChunks; ++t) {
             const int k = (blk * kNnChunks + t) * 64 + lane;
-            if ((blk * kNnChunks + t) * 64 < m) {
-                const bool valid = k < m;
+            const int cbase = (blk * kNnChunks + t) * 64;
+            if (cbase < m) {
+                const bool tail = cbase + 64 > m;  // wave-uniform
+                unsigned long long mk[kNnQ];
+                unsigned long long any = 0ull;
 #pragma unroll
                 for (int q = 0; q < kNnQ; ++q) {
-                    const bool hit = valid && nn_d32(qx[q], qy[q], qz[q], c[t]) <= thr[q];
-                    const unsigned long long mask = __ballot(hit);
-                    if (mask != 0ull) {
-                        const int pos = cnt[q] + (int)__builtin_amdgcn_mbcnt_hi(
-                                                     (unsigned)(mask >> 32),
-                                                     __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0u));
-                        if (hit && pos < kNnList) wl[q * kNnList + pos] = k;
-                        cnt[q] += __popcll(mask);  // may exceed kNnList: overflow marker
+                    bool hit = nn_d32(qx[q], qy[q], qz[q], c[t]) <= thr[q];
+                    if (tail) hit = hit && (k < m);
+                    mk[q] = __ballot(hit);
+                    any |= mk[q];
+                }
+                if (any != 0ull) {  // one branch per chunk (scalar ops are expensive, see pn2_grouping.hip)
+#pragma unroll
+                    for (int q = 0; q < kNnQ; ++q) {
+                        const unsigned long long mask = mk[q];
+                        if (mask != 0ull) {
+                            const int pos = cnt[q] + (int)__builtin_amdgcn_mbcnt_hi(
+                                                         (unsigned)(mask >> 32),
+                                                         __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0u));
+                            if (((mask >> lane) & 1ull) && pos < kNnList) wl[q * kNnList + pos] = k;
+                            cnt[q] += __popcll(mask);  // may exceed kNnList: overflow marker
+                        }
                     }
                 }
             }

@@ -1,0 +1,98 @@
+"""Multi-GPU plumbing: one process per GPU, torch.distributed over RCCL (backend "nccl" on ROCm).
+
+The SA/FP path shards over the batch dimension with NO data-path collective (every reference kernel
+indexes batch by block; scenes are independent): inference = independent replicas.  Data-parallel
+training (BASELINE config[3]: 16 scenes per GPU) adds ONE all-reduce per step of the flattened fp32
+gradient (967,945 parameters = 3.87 MB for the semantic.json model): latency-bound over xGMI, so a
+single bucket, no per-layer hooks.  BatchNorm statistics stay rank-local (the reference is a
+single-GPU B=16 model; no sync-BN).
+
+Everything here also runs on CPU with the gloo backend (tests/test_dist_cpu.py, world_size 2).
+"""
+import os
+
+import torch
+import torch.distributed as dist
+
+
+def init_from_env(backend=None, device=None):
+    """Initialise the default process group from RANK / WORLD_SIZE / MASTER_* (torch.distributed.run).
+    -> (rank, world_size).  A world of 1 needs no process group."""
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world > 1 and not dist.is_initialized():
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29500")
+        if backend is None:
+            backend = "nccl" if torch.cuda.is_available() else "gloo"
+        kw = {}
+        if backend == "nccl" and device is not None:
+            kw["device_id"] = device
+        dist.init_process_group(backend, rank=rank, world_size=world, **kw)
+    return rank, world
+
+
+def shard_range(n_items, rank, world):
+    """Contiguous [lo, hi) slice of n_items owned by `rank` (sizes differ by at most one)."""
+    base, rem = divmod(n_items, world)
+    lo = rank * base + min(rank, rem)
+    return lo, lo + base + (1 if rank < rem else 0)
+
+
+def max_over_ranks(value, device=None):
+    """max of a python float over all ranks (bench: the slowest rank defines the step time)."""
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        return float(value)
+    t = torch.tensor([float(value)], dtype=torch.float64, device=device)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return float(t.item())
+
+
+def barrier():
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+        dist.barrier()
+
+
+class FlatGradAllReduce:
+    """Averages gradients across ranks with ONE all-reduce of a persistent flat fp32 bucket.
+
+    usage:  bucket = FlatGradAllReduce(params);  loss.backward();  bucket.allreduce_();  opt.step()
+    Parameters without a gradient contribute zeros (keeps every rank's bucket layout identical)."""
+
+    def __init__(self, params):
+        self.params = [p for p in params if p.requires_grad]
+        self.numel = sum(p.numel() for p in self.params)
+        dev = self.params[0].device if self.params else torch.device("cpu")
+        self.flat = torch.zeros(self.numel, dtype=torch.float32, device=dev)
+        self.views, off = [], 0
+        for p in self.params:
+            self.views.append(self.flat[off:off + p.numel()].view_as(p))
+            off += p.numel()
+
+    def nbytes(self):
+        return self.numel * 4
+
+    @torch.no_grad()
+    def allreduce_(self):
+        world = dist.get_world_size() if (dist.is_available() and dist.is_initialized()) else 1
+        for p, v in zip(self.params, self.views):
+            if p.grad is None:
+                v.zero_()
+            else:
+                v.copy_(p.grad)
+        if world > 1:
+            dist.all_reduce(self.flat, op=dist.ReduceOp.SUM)
+            self.flat.div_(world)
+        for p, v in zip(self.params, self.views):
+            if p.grad is None:
+                p.grad = v.clone()
+            else:
+                p.grad.copy_(v)
+        return self.flat
+
+
+def broadcast_parameters(tensors, src=0):
+    """Make every rank start from rank `src`'s weights (replicated parameters)."""
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+        for t in tensors:
+            dist.broadcast(t.data if hasattr(t, "data") else t, src=src)

@@ -1,0 +1,92 @@
+"""CPU tests of the N>1 path: world_size-2 gloo process groups exercising the exact helpers bench.py
+and the data-parallel trainer use (batch sharding, max-over-ranks timing, flat gradient all-reduce)."""
+import os
+import socket
+
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, q):
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    import pn2_amd as pn2
+    d = pn2.dist
+    r, w = d.init_from_env(backend="gloo")
+    assert (r, w) == (rank, world)
+    out = {}
+    # 1. batch sharding: 128 scenes over 2 ranks = 64 each, 7 over 2 = 4 + 3, union is exact
+    out["shard128"] = d.shard_range(128, rank, world)
+    out["shard7"] = d.shard_range(7, rank, world)
+    # 2. slowest rank defines the time
+    out["tmax"] = d.max_over_ranks(1.0 + rank)
+    # 3. flat-bucket gradient averaging == manual average, single bucket covers every parameter
+    torch.manual_seed(0)
+    lin = torch.nn.Sequential(torch.nn.Linear(5, 7), torch.nn.ReLU(), torch.nn.Linear(7, 3))
+    d.broadcast_parameters(list(lin.parameters()))
+    x = torch.full((4, 5), float(rank + 1))
+    lin(x).sum().backward()
+    local = [p.grad.clone() for p in lin.parameters()]
+    bucket = d.FlatGradAllReduce(lin.parameters())
+    bucket.allreduce_()
+    out["numel"] = bucket.numel
+    out["local"] = [g.tolist() for g in local]
+    out["avg"] = [p.grad.tolist() for p in lin.parameters()]
+    out["w0"] = lin[0].weight.detach().flatten().tolist()
+    d.barrier()
+    torch.distributed.destroy_process_group()
+    q.put((rank, out))
+
+
+@pytest.mark.timeout(180)
+def test_world2_gloo_helpers():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = dict(q.get(timeout=150) for _ in range(2))
+    for p in procs:
+        p.join(30)
+        assert p.exitcode == 0
+    assert res[0]["shard128"] == (0, 64) and res[1]["shard128"] == (64, 128)
+    assert res[0]["shard7"] == (0, 4) and res[1]["shard7"] == (4, 7)
+    assert res[0]["tmax"] == res[1]["tmax"] == 2.0
+    assert res[0]["w0"] == res[1]["w0"]  # replicated parameters after broadcast
+    assert res[0]["numel"] == 5 * 7 + 7 + 7 * 3 + 3
+    for a, b_, g0, g1 in zip(res[0]["avg"], res[1]["avg"], res[0]["local"], res[1]["local"]):
+        ta, tb = torch.tensor(a), torch.tensor(b_)
+        assert torch.equal(ta, tb)  # both ranks hold the same averaged gradient
+        assert torch.allclose(ta, (torch.tensor(g0) + torch.tensor(g1)) / 2, rtol=1e-6, atol=1e-7)
+
+
+def test_shard_range_partitions_exactly():
+    import pn2_amd as pn2
+    for n in (0, 1, 7, 16, 128, 1000):
+        for w in (1, 2, 3, 8):
+            parts = [pn2.dist.shard_range(n, r, w) for r in range(w)]
+            assert parts[0][0] == 0 and parts[-1][1] == n
+            assert all(parts[i][1] == parts[i + 1][0] for i in range(w - 1))
+            sizes = [hi - lo for lo, hi in parts]
+            assert max(sizes) - min(sizes) <= 1
+
+
+def test_training_schedules_match_reference_constants():
+    """train.py:80-119: lr 1e-3 * 0.7^floor(step*16/200000) clipped at 1e-5; bn decay 0.5 -> 0.99."""
+    import pn2_amd as pn2
+    t = pn2.train
+    assert t.learning_rate(0, 16) == 1e-3
+    assert abs(t.learning_rate(12500, 16) - 7e-4) < 1e-12      # 12500*16 = 200000 -> one decay
+    assert t.learning_rate(10 ** 7, 16) == 1e-5
+    assert t.bn_decay(0, 16) == 0.5
+    assert abs(t.bn_decay(12500, 16) - 0.75) < 1e-12
+    assert t.bn_decay(10 ** 7, 16) == 0.99

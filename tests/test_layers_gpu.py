@@ -354,3 +354,22 @@ def test_fp_module_chain_equals_per_layer_linear(pn2, oracle, cuda):
     ref = oracle.fp_module(xyz1, xyz2, p1, p2, layer_dicts(store, "fp4", ["conv_0", "conv_1", "conv_2"]))
     close(a, ref)
     close(b, ref)
+
+
+def test_training_step_single_gpu(pn2, cuda):
+    """Trainer.train_step: forward (batch-stat BN) + weighted CE + backward through the HIP gradient
+    kernels + flat-bucket all-reduce (world 1) + Adam.  The loss must drop on a fixed batch."""
+    import torch
+    hp = dict(pn2.model.SEMANTIC_HYPERPARAMS)
+    hp.update(l1_npoint=128, l2_npoint=32, l3_npoint=16, l4_npoint=8)
+    rs = np.random.RandomState(0)
+    pc = T(np.concatenate([s_scene(1, 2, 1024), rs.random_sample((2, 1024, 3)).astype(np.float32)], 2), cuda)
+    labels = T(rs.randint(0, 9, (2, 1024)).astype(np.int64), cuda)
+    smpw = T((rs.random_sample((2, 1024)) + 0.5).astype(np.float32), cuda)
+    tr = pn2.train.Trainer(hp, 9, store=pn2.util.tf_util.VariableStore(device=cuda, seed=3))
+    losses = [tr.train_step(pc, labels, smpw) for _ in range(8)]
+    assert all(np.isfinite(losses))
+    assert losses[-1] < losses[0], losses
+    assert tr.bucket.numel == tr.store.num_parameters()
+    # the semantic.json model has 967,945 trainable parameters (SURVEY section 2.3)
+    assert tr.store.num_parameters() == 967945

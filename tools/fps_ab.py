@@ -15,25 +15,29 @@ def timeit(fn, iters=10):
     e.record(); torch.cuda.synchronize()
     return s.elapsed_time(e) / iters * 1e3
 
-libs = [a for a in sys.argv[1:] if not a.startswith("--")]
-variants = [int(a[2:]) for a in sys.argv[1:] if a.startswith("--")] or [0]
-dev = torch.device("cuda:0")
-st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
-P = lambda t: ctypes.c_void_p(t.data_ptr())
-ref = {}
-for path, var in [(p, v) for p in libs for v in variants]:
-    L = ctypes.CDLL(os.path.abspath(path))
-    L.pn2_debug_set(0, var)
-    row = [os.path.basename(path) + ":%d" % var]
-    for (b, n, m) in [(16, 8192, 1024), (16, 1024, 256), (16, 256, 64), (16, 64, 16), (16, 4096, 512), (16, 2048, 256)]:
-        x = torch.from_numpy(scene(n, b, n)).to(dev)
-        out = torch.empty((b, m), dtype=torch.int32, device=dev)
-        f = lambda: L.pn2_farthest_point_sample(b, n, m, P(x), None, P(out), 1, st)
-        assert f() == 0
-        t = timeit(f)
-        key = (b, n, m)
-        o = out.cpu().numpy()
-        if key in ref: assert (ref[key] == o).all(), "variant disagrees at %s" % (key,)
-        ref[key] = o
-        row.append("fps%s=%.1fus(%.3fus/round)" % (key, t, t / (m - 1)))
-    print("  ".join(row))
+def main():
+    libs = [a for a in sys.argv[1:] if not a.startswith("--")]
+    variants = [int(a[2:]) for a in sys.argv[1:] if a.startswith("--")] or [0]
+    dev = torch.device("cuda:0")
+    st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    P = lambda t: ctypes.c_void_p(t.data_ptr())
+    ref = {}
+    for path, var in [(p, v) for p in libs for v in variants]:
+        L = ctypes.CDLL(os.path.abspath(path))
+        L.pn2_debug_set(0, var)
+        row = [os.path.basename(path) + ":%d" % var]
+        for (b, n, m) in [(16, 8192, 1024), (16, 1024, 256), (16, 256, 64), (16, 64, 16), (16, 4096, 512), (16, 2048, 256)]:
+            x = torch.from_numpy(scene(n, b, n)).to(dev)
+            out = torch.empty((b, m), dtype=torch.int32, device=dev)
+            f = lambda: L.pn2_farthest_point_sample(b, n, m, P(x), None, P(out), 1, st)
+            assert f() == 0
+            t = timeit(f)
+            key = (b, n, m)
+            o = out.cpu().numpy()
+            if key in ref: assert (ref[key] == o).all(), "variant disagrees at %s" % (key,)
+            ref[key] = o
+            row.append("fps%s=%.1fus(%.3fus/round)" % (key, t, t / (m - 1)))
+        print("  ".join(row))
+
+if __name__ == "__main__":
+    main()
