@@ -164,6 +164,148 @@ ball_query_kernel(int n, int m, float thr, int nsample, const float* __restrict_
     }
 }
 
+// ---- ball query, lane = query ---------------------------------------------------------------
+// 512 threads = 8 waves serve 64 consecutive queries of one batch element: lane l of EVERY wave is
+// query q0 + l, and wave s scans candidate segment s (n/8 consecutive points).  Candidates are
+// wave-uniform, so their coordinates arrive through scalar loads (SGPR broadcast): the inner loop
+// is 3 sub + mul + 2 fma + compare per lane with no cross-lane traffic, no vector loads to wait
+// for and one branch per candidate (taken only when some lane hits).  Each wave appends its lane's
+// hits (ascending index inside the segment) to a private LDS list; after one barrier the segment
+// counts are prefix-summed per query, every wave drops its entries at their final positions of an
+// LDS row image, and the 64 finished rows (contiguous in HBM) are written coalesced with the
+// first-hit padding of tf_grouping.cu:32-36 applied on the fly.  Exactly the reference result:
+// segments are visited in index order and only the first nsample positions are kept.
+constexpr int kBq2Waves = 16;  // 16 segments: 1024 threads; 16-bit list entries keep the lists at 64 KB for nsample = 32
+constexpr int kBq2Threads = 64 * kBq2Waves;
+
+template <int MODE>
+__global__ void __launch_bounds__(kBq2Threads)
+ball_query_lane_kernel(int n, int m, float thr, int nsample, int seg,
+                       const float* __restrict__ xyz1_all, const float* __restrict__ xyz2_all,
+                       int* __restrict__ idx_all, int* __restrict__ cnt_all) {
+    extern __shared__ int smem_i[];
+    // layout: rows[64][nsample] | segcnt[W][64] | total[64] | first[64] | list[W][nsample][64] (16-bit, segment-relative)
+    int* rows = smem_i;
+    int* segcnt = rows + 64 * nsample;
+    int* total = segcnt + kBq2Waves * 64;
+    int* firsth = total + 64;
+    unsigned short* list = reinterpret_cast<unsigned short*>(firsth + 64);
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int bi = blockIdx.y;
+    const int q0 = blockIdx.x * 64;
+    const float* __restrict__ xyz1 = xyz1_all + (size_t)bi * n * 3;
+    const float* __restrict__ xyz2 = xyz2_all + (size_t)bi * m * 3;
+    const int q = q0 + lane < m ? q0 + lane : m - 1;  // surplus lanes shadow the last query, never stored
+    const float qx = xyz2[q * 3 + 0], qy = xyz2[q * 3 + 1], qz = xyz2[q * 3 + 2];
+
+    int lo = wave * seg;
+    int hi = lo + seg < n ? lo + seg : n;
+    if (lo > n) lo = n;
+    unsigned short* mylist = list + wave * nsample * 64 + lane;
+    int cnt = 0;
+    // Candidates are processed 8 at a time: their 24 coordinates are wave-uniform and arrive as wide
+    // scalar loads (two groups in flight: A/B name rotation, no register copies); the 8 compares write
+    // SGPR masks that are OR-ed so the common "nobody hit" case costs ONE branch per 8 candidates.
+    struct Grp { float c[24]; };
+    auto gload = [&](int k0) {
+        Grp g;
+        const float* __restrict__ p = xyz1 + (size_t)(k0 < n - 8 ? k0 : (n >= 8 ? n - 8 : 0)) * 3;  // clamped, never out of bounds
+#pragma unroll
+        for (int u = 0; u < 24; ++u) g.c[u] = p[u];
+        return g;
+    };
+    auto append = [&](int k) {
+        if (cnt < nsample) mylist[cnt * 64] = (unsigned short)(k - lo);
+        ++cnt;
+    };
+    auto gtest = [&](const Grp& g, int k0) {
+        unsigned long long mk[8];
+        unsigned long long any = 0ull;
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const float sd = pn2_sqdist<MODE>(qx - g.c[3 * u], qy - g.c[3 * u + 1], qz - g.c[3 * u + 2]);
+            mk[u] = __ballot(sd <= thr);
+            any |= mk[u];
+        }
+        if (any != 0ull) {
+#pragma unroll
+            for (int u = 0; u < 8; ++u)
+                if (mk[u] != 0ull && ((mk[u] >> lane) & 1ull)) append(k0 + u);
+        }
+    };
+    int k = lo;
+    if (n >= 8) {
+        Grp ga = gload(k), gb = gload(k + 8);
+        for (; k + 16 <= hi; k += 16) {
+            gtest(ga, k);
+            ga = gload(k + 16);
+            gtest(gb, k + 8);
+            gb = gload(k + 24);
+        }
+        if (k + 8 <= hi) { gtest(ga, k); k += 8; }
+    }
+    for (; k < hi; ++k) {  // tail (< 8 candidates)
+        const float sd = pn2_sqdist<MODE>(qx - xyz1[k * 3 + 0], qy - xyz1[k * 3 + 1], qz - xyz1[k * 3 + 2]);
+        if (sd <= thr) append(k);
+    }
+    segcnt[wave * 64 + lane] = cnt < nsample ? cnt : nsample;
+    __syncthreads();
+
+    // prefix over the segments (8 LDS reads per lane)
+    int before = 0, tot = 0, fseg = -1;
+#pragma unroll
+    for (int sgi = 0; sgi < kBq2Waves; ++sgi) {
+        const int c = segcnt[sgi * 64 + lane];
+        if (sgi < wave) before += c;
+        if (fseg < 0 && c > 0) fseg = sgi;
+        tot += c;
+    }
+    const int mine = cnt < nsample ? cnt : nsample;
+    for (int e = 0; e < mine; ++e) {
+        const int pos = before + e;
+        if (pos < nsample) rows[lane * nsample + pos] = lo + (int)mylist[e * 64];
+    }
+    if (wave == 0) {
+        total[lane] = tot < nsample ? tot : nsample;
+        firsth[lane] = fseg >= 0 ? fseg * seg + (int)list[fseg * nsample * 64 + lane] : 0;  // entry 0 of the first non-empty segment
+    }
+    __syncthreads();
+
+    // coalesced write-out of the 64 rows (contiguous in HBM)
+    const int nq = m - q0 < 64 ? m - q0 : 64;
+    int* __restrict__ out = idx_all + ((size_t)bi * m + q0) * nsample;
+    for (int e = tid; e < nq * nsample; e += kBq2Threads) {
+        const int r = e / nsample, pos = e - r * nsample;
+        out[e] = pos < total[r] ? rows[e] : firsth[r];  // padding with the first hit; empty rows -> 0
+    }
+    if (tid < nq) cnt_all[(size_t)bi * m + q0 + tid] = total[tid];
+}
+
+template <int MODE>
+int launch_ball_query_lane(int b, int n, int m, float thr, int nsample, const float* xyz1,
+                           const float* xyz2, int* idx, int* cnt, hipStream_t st) {
+    int seg = (n + kBq2Waves - 1) / kBq2Waves;
+    seg = (seg + 3) & ~3;
+    const size_t lds = ((size_t)64 * nsample + kBq2Waves * 64 + 128) * sizeof(int) + (size_t)kBq2Waves * nsample * 64 * sizeof(unsigned short);
+    if (seg > 65535) return PN2_ERANGE;
+    auto kern = ball_query_lane_kernel<MODE>;
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (e != hipSuccess) return (int)e;
+        attr_set = true;
+    }
+    dim3 grid((m + 63) / 64, b);
+    kern<<<grid, kBq2Threads, lds, st>>>(n, m, thr, nsample, seg, xyz1, xyz2, idx, cnt);
+    PN2_RETURN_IF_LAUNCH_FAILED();
+    return PN2_OK;
+}
+
+int g_bq_variant = 0;  // tuning hook (pn2_debug_set(2, v)): 0 = auto, 1 = wave-per-queries kernel, 2 = lane kernel
+
 int g_bq_qpw = 8;  // tuning hook (pn2_debug_set(1, v))
 
 template <int MODE, int QPW>
@@ -180,6 +322,10 @@ int launch_ball_query_q(int b, int n, int m, float thr, int nsample, const float
 template <int MODE>
 int launch_ball_query(int b, int n, int m, float thr, int nsample, const float* xyz1,
                       const float* xyz2, int* idx, int* cnt, hipStream_t st) {
+    // lane = query kernel whenever its LDS lists fit and there are enough queries to fill 64 lanes
+    const bool lane_ok = nsample <= 64 && m >= 32 && n <= 65535 * kBq2Waves;
+    if (g_bq_variant == 2 || (g_bq_variant == 0 && lane_ok))
+        return launch_ball_query_lane<MODE>(b, n, m, thr, nsample, xyz1, xyz2, idx, cnt, st);
     // fewer queries per wave when there are too few queries to fill the chip (>= ~4 waves/SIMD wanted)
     int qpw = g_bq_qpw;
     while (qpw > 2 && (long long)b * ((m + qpw - 1) / qpw) < 4096) qpw >>= 1;
@@ -249,6 +395,7 @@ inline int grid_x_for(unsigned long long total, int block, int batches) {
 
 extern "C" int pn2_debug_set_grouping(int what, int value) {
     if (what == 1) { g_bq_qpw = value; return 0; }
+    if (what == 2) { g_bq_variant = value; return 0; }
     return PN2_EINVAL;
 }
 
