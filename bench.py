@@ -121,6 +121,23 @@ def summarize_trace(trace, steps):
     return rows
 
 
+def pmc_traffic(kernel):
+    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes
+    (profiles/r01_pmc_hbm_traffic.json, produced by tools/pmc_mfma.sh on the same workload); None if absent."""
+    path = os.path.join(ROOT, "profiles", "r01_pmc_hbm_traffic.json")
+    names = {"farthest_point_sample": ("fps_reg_kernel<1024, 8,", "grid=16384")}
+    if kernel not in names or not os.path.exists(path):
+        return None
+    try:
+        data = json.load(open(path))["kernels"]
+        for k, v in data.items():
+            if all(t in k for t in names[kernel]):
+                return v["traffic_bytes"]
+    except Exception:
+        return None
+    return None
+
+
 def time_call(fn, iters, warmup=3):
     for _ in range(warmup):
         fn()
@@ -232,7 +249,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--eager", action="store_true", help="launch from Python instead of replaying a hipGraph")
     ap.add_argument("--one-stream", action="store_true", help="do not overlap the geometry chain with the MLP chain")
-    ap.add_argument("--pipeline", type=int, default=2, help="independent batches in flight (graphs replayed round-robin)")
+    ap.add_argument("--pipeline", type=int, default=4, help="independent batches in flight (graphs replayed round-robin)")
     ap.add_argument("--no-north-star", action="store_true")
     args = ap.parse_args()
 
@@ -337,7 +354,8 @@ def main():
                        "batches_in_flight": 1 if args.eager else max(1, args.pipeline)},
             "roofline": {"kernel": dom["kernel"], "args": dom["args"], "bound": dom["bound"],
                          "achieved": dom["achieved"], "peak": dom["peak"], "unit": dom["unit"], "frac": dom["frac"],
-                         "traffic": None, "avg_us": dom["avg_us"],
+                         "traffic": pmc_traffic(dom["kernel"]) if (B, N) == (16, 8192) else None,
+                         "algorithmic_bytes": dom["algorithmic_units"], "avg_us": dom["avg_us"],
                          "share_of_step": round(dom["ms_per_step"] / max(1e-9, sum(k["ms_per_step"] for k in kernels)), 3),
                          "note": ("farthest point sampling is a chain of M-1 dependent argmax rounds: bounded by "
                                   "LDS/barrier latency, not by HBM or MFMA; its HBM fraction is reported as measured"
