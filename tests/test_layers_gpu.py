@@ -373,3 +373,97 @@ def test_training_step_single_gpu(pn2, cuda):
     assert tr.bucket.numel == tr.store.num_parameters()
     # the semantic.json model has 967,945 trainable parameters
     assert tr.store.num_parameters() == 967945
+
+
+# ------------------------------------------------------------------ API coverage ------------
+def test_sample_and_group_api(pn2, oracle, cuda):
+    """sample_and_group returns (new_xyz, new_points [xyz first], idx, grouped_xyz) like pointnet_util.py:18-60."""
+    rs = np.random.RandomState(1)
+    xyz = rs.random_sample((2, 600, 3)).astype(np.float32)
+    pts = rs.randn(2, 600, 5).astype(np.float32)
+    nx, npts, idx, gx = pn2.sample_and_group(64, 0.3, 16, T(xyz, cuda), T(pts, cuda))
+    r_nx, r_np, r_idx, r_gx = oracle.sample_and_group(64, 0.3, 16, xyz, pts)
+    assert np.array_equal(idx.cpu().numpy(), r_idx) and np.array_equal(nx.cpu().numpy(), r_nx)
+    assert np.array_equal(gx.cpu().numpy(), r_gx) and np.array_equal(npts.cpu().numpy(), r_np)
+    nx, npts, idx, gx = pn2.sample_and_group(64, 0.3, 16, T(xyz, cuda), None)  # points=None -> xyz only
+    assert np.array_equal(npts.cpu().numpy(), r_gx)
+
+
+def test_sa_module_group_all_and_poolings(pn2, oracle, cuda):
+    """group_all=True (sample_and_group_all, :63-95) and the avg / max_and_avg poolings (:171-191)."""
+    tfu, pu = pn2.util.tf_util, pn2.util.pointnet_util
+    rs = np.random.RandomState(2)
+    xyz = rs.random_sample((2, 64, 3)).astype(np.float32)
+    pts = rs.randn(2, 64, 8).astype(np.float32)
+    store = tfu.set_default_store(tfu.VariableStore(device=cuda, seed=41))
+    kw = dict(npoint=None, radius=None, nsample=None, mlp=[32, 64], mlp2=None, group_all=True, is_training=False,
+              bn_decay=None, scope="ga")
+    pu.pointnet_sa_module(T(xyz, cuda), T(pts, cuda), **kw)
+    randomize_bn(store, 42)
+    new_xyz, new_points, idx = pu.pointnet_sa_module(T(xyz, cuda), T(pts, cuda), **kw)
+    layers = layer_dicts(store, "ga", ["conv0", "conv1"])
+    h = np.concatenate([xyz, pts], axis=2)[:, None].astype(np.float64)
+    for l in layers:
+        h = oracle.conv_bn_relu(h, l)
+    assert new_xyz.shape == (2, 1, 3) and float(new_xyz.abs().sum()) == 0.0
+    assert idx.shape == (2, 1, 64)
+    close(new_points.cpu().numpy(), h.max(2))
+    for pooling, fn in (("avg", lambda t: t.mean(2)), ("max_and_avg", lambda t: np.concatenate([t.mean(2), t.max(2)], -1))):
+        _, npool, _ = pu.pointnet_sa_module(T(xyz, cuda), T(pts, cuda), pooling=pooling, **kw)
+        close(npool.cpu().numpy(), fn(h))
+
+
+def test_sa_module_msg_vs_oracle(pn2, oracle, cuda):
+    """BASELINE config[2] shape family: MSG with 3 scales (radii/K/MLPs are builder-chosen: the reference
+    ships no MSG hyper-parameters).  NOTE the [features, xyz] concat order of pointnet_util.py:259."""
+    tfu, pu = pn2.util.tf_util, pn2.util.pointnet_util
+    rs = np.random.RandomState(3)
+    xyz = rs.random_sample((2, 1024, 3)).astype(np.float32)
+    pts = rs.randn(2, 1024, 6).astype(np.float32)
+    radii, ks, mlps = [0.1, 0.2, 0.4], [16, 32, 64], [[32, 32, 64], [64, 64, 128], [64, 96, 128]]
+    store = tfu.set_default_store(tfu.VariableStore(device=cuda, seed=43))
+    args = (T(xyz, cuda), T(pts, cuda), 128, radii, ks, mlps, False, None)
+    pu.pointnet_sa_module_msg(*args, scope="msg")
+    randomize_bn(store, 44)
+    new_xyz, new_points = pu.pointnet_sa_module_msg(*args, scope="msg")
+    f = oracle.farthest_point_sample(128, xyz)
+    nx = oracle.gather_point(xyz, f)
+    outs = []
+    for i, (r, k) in enumerate(zip(radii, ks)):
+        idx, _ = oracle.query_ball_point(r, k, xyz, nx)
+        gx = oracle.group_point(xyz, idx) - nx[:, :, None, :]
+        h = np.concatenate([oracle.group_point(pts, idx), gx], axis=-1).astype(np.float64)  # features FIRST here
+        for l in layer_dicts(store, "msg", ["conv%d_%d" % (i, j) for j in range(3)]):
+            h = oracle.conv_bn_relu(h, l)
+        outs.append(h.max(2))
+    assert np.array_equal(new_xyz.cpu().numpy(), nx)
+    assert new_points.shape == (2, 128, 64 + 128 + 128)
+    close(new_points.cpu().numpy(), np.concatenate(outs, -1))
+
+
+def test_large_scene_config4_shapes(pn2, oracle, cuda):
+    """BASELINE config[4] geometry at its own sizes (B=1, N=65536, npoint=4096, K=64, fp32): the
+    streaming FPS kernel (n > 16384) and the K=64 ball query, bit-exact against the oracle."""
+    xyz = s_scene(9, 1, 65536)
+    f = pn2.farthest_point_sample(4096, T(xyz, cuda)).cpu().numpy()
+    rf = oracle.farthest_point_sample(4096, xyz)
+    assert np.array_equal(f, rf)
+    q = oracle.gather_point(xyz, rf)
+    idx, cnt = pn2.query_ball_point(0.5, 64, T(xyz, cuda), T(q, cuda))
+    ri, rc = oracle.query_ball_point(0.5, 64, xyz, q)
+    assert np.array_equal(cnt.cpu().numpy(), rc) and np.array_equal(idx.cpu().numpy(), ri)
+    # K = 64 grouped MLP + max through the unfused MFMA path (pool = 64)
+    tfu, pu = pn2.util.tf_util, pn2.util.pointnet_util
+    store = tfu.set_default_store(tfu.VariableStore(device=cuda, seed=45))
+    feat = np.random.RandomState(1).randn(1, 65536, 16).astype(np.float32)
+    kw = dict(npoint=4096, radius=0.5, nsample=64, mlp=[64, 128], mlp2=None, group_all=False, is_training=False,
+              bn_decay=None, scope="big")
+    pu.pointnet_sa_module(T(xyz, cuda), T(feat, cuda), **kw)
+    randomize_bn(store, 46)
+    _, npts, i2 = pu.pointnet_sa_module(T(xyz, cuda), T(feat, cuda), **kw)
+    assert np.array_equal(i2.cpu().numpy(), ri)
+    gx = oracle.group_point(xyz, ri) - q[:, :, None, :]
+    h = np.concatenate([gx, oracle.group_point(feat, ri)], -1).astype(np.float64)
+    for l in layer_dicts(store, "big", ["conv0", "conv1"]):
+        h = oracle.conv_bn_relu(h, l)
+    close(npts.cpu().numpy(), h.max(2))
