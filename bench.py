@@ -83,7 +83,7 @@ def kernel_model(name, a):
             fl += 2 * rows * cin * w
             cin = w
         return "mfma", fl
-    if name == "pn2_sa_mlp_max_fused":
+    if name in ("pn2_sa_mlp_max_fused", "pn2_sa_mlp_rows_fused"):
         b, n, m, ns, c, L = a[:6]
         widths = a[6:6 + L]
         cin, fl = 3 + c, 0

@@ -140,6 +140,14 @@ int pn2_sa_mlp_max_fused(int b, int n, int m, int nsample, int c, const float *x
                          int nlayers, const int *widths, const float *const *w,
                          const float *const *bias, float *out, void *stream);
 
+/* Same gather + MLP chain without the max over the neighbours: out (b,m,nsample,widths[last]),
+ * ReLU applied.  Feeds a wider last layer that runs on pn2_linear with pool = nsample.
+ * Supported: nsample == 32, widths [128] or [128,128]; PN2_EUNSUP otherwise. */
+int pn2_sa_mlp_rows_fused(int b, int n, int m, int nsample, int c, const float *xyz,
+                          const float *new_xyz, const float *points, const int *idx,
+                          int nlayers, const int *widths, const float *const *w,
+                          const float *const *bias, float *out, void *stream);
+
 /* Fused feature-propagation front end (pointnet_util.py:300-311):
  *   weight = (1/max(dist,1e-10)) / sum(1/max(dist,1e-10));
  *   out[b,j,:] = [ sum_i weight_i * points2[b,idx_i,:]  |  points1[b,j,:] ]

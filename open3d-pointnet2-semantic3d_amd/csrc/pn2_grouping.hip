@@ -335,8 +335,12 @@ int launch_ball_query(int b, int n, int m, float thr, int nsample, const float* 
 }
 
 // ---- group_point -----------------------------------------------------------
-// grid.y = batch; e indexes the (m*nsample*c/VEC) vector elements of one batch.
-template <typename VT, int VEC>
+// grid.y = batch; e indexes the (m*nsample*c/VEC) vector elements of one batch.  UNR independent
+// 16-byte gathers are in flight per thread before the first store (memory-level parallelism);
+// NT selects non-temporal stores (the output is written once and never re-read by this kernel).
+int g_gp_variant = 0;  // tuning hook (pn2_debug_set(3, v)): bit0 = plain stores, bits 4.. = blocks-per-CU override
+
+template <typename VT, int VEC, int UNR, bool NT>
 __global__ void __launch_bounds__(256)
 group_point_kernel(int n, int c, unsigned per_batch_rows, const float* __restrict__ points_all,
                    const int* __restrict__ idx_all, float* __restrict__ out_all) {
@@ -348,13 +352,27 @@ group_point_kernel(int n, int c, unsigned per_batch_rows, const float* __restric
     VT* __restrict__ out = reinterpret_cast<VT*>(out_all + (size_t)bi * per_batch_rows * c);
     const bool pow2 = (cv & (cv - 1)) == 0;
     const unsigned sh = 31 - __builtin_clz(cv | 1u);
-    for (unsigned e = blockIdx.x * blockDim.x + threadIdx.x; e < total; e += gridDim.x * blockDim.x) {
-        unsigned row, col;
-        if (pow2) { row = e >> sh; col = e & (cv - 1); }
-        else { row = e / cv; col = e - row * cv; }
-        const int ii = idx[row];
-        const VT v = points[(size_t)ii * cv + col];
-        __builtin_nontemporal_store(v, &out[e]);
+    const unsigned stride = gridDim.x * blockDim.x;
+    for (unsigned e0 = blockIdx.x * blockDim.x + threadIdx.x; e0 < total; e0 += stride * UNR) {
+        VT v[UNR];
+#pragma unroll
+        for (int u = 0; u < UNR; ++u) {
+            const unsigned e = e0 + u * stride;
+            if (e < total) {
+                unsigned row, col;
+                if (pow2) { row = e >> sh; col = e & (cv - 1); }
+                else { row = e / cv; col = e - row * cv; }
+                v[u] = points[(size_t)idx[row] * cv + col];
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < UNR; ++u) {
+            const unsigned e = e0 + u * stride;
+            if (e < total) {
+                if constexpr (NT) __builtin_nontemporal_store(v[u], &out[e]);
+                else out[e] = v[u];
+            }
+        }
     }
 }
 
@@ -396,6 +414,7 @@ inline int grid_x_for(unsigned long long total, int block, int batches) {
 extern "C" int pn2_debug_set_grouping(int what, int value) {
     if (what == 1) { g_bq_qpw = value; return 0; }
     if (what == 2) { g_bq_variant = value; return 0; }
+    if (what == 3) { g_gp_variant = value; return 0; }
     return PN2_EINVAL;
 }
 
@@ -425,11 +444,20 @@ extern "C" int pn2_group_point(int b, int n, int c, int m, int nsample, const fl
     hipStream_t st = static_cast<hipStream_t>(stream);
     const bool vec4 = (c % 4 == 0) && (((uintptr_t)points | (uintptr_t)out) % 16 == 0);
     if (vec4) {
-        dim3 grid(grid_x_for(rows * (c / 4), 256, b), b);
-        group_point_kernel<f32x4, 4><<<grid, 256, 0, st>>>(n, c, (unsigned)rows, points, idx, out);
+        const unsigned long long tot = rows * (c / 4);
+        int gx = 1;
+        int bpc = g_gp_variant >> 4;  // blocks per CU overall; measured best at 64 (profiles/r01_group_point_sweep.txt)
+        if (bpc <= 0) bpc = 64;
+        {
+            unsigned long long cap = (256ull * bpc + b - 1) / b, g = (tot / 4 + 255) / 256;
+            gx = (int)(g < cap ? (g < 1 ? 1 : g) : cap);
+        }
+        dim3 grid(gx, b);
+        if (g_gp_variant & 1) group_point_kernel<f32x4, 4, 4, false><<<grid, 256, 0, st>>>(n, c, (unsigned)rows, points, idx, out);
+        else group_point_kernel<f32x4, 4, 4, true><<<grid, 256, 0, st>>>(n, c, (unsigned)rows, points, idx, out);
     } else {
         dim3 grid(grid_x_for(rows * c, 256, b), b);
-        group_point_kernel<float, 1><<<grid, 256, 0, st>>>(n, c, (unsigned)rows, points, idx, out);
+        group_point_kernel<float, 1, 4, true><<<grid, 256, 0, st>>>(n, c, (unsigned)rows, points, idx, out);
     }
     PN2_RETURN_IF_LAUNCH_FAILED();
     return PN2_OK;

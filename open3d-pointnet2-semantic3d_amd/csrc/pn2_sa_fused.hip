@@ -295,8 +295,9 @@ int launch_chain(const SaFusedParams& p, hipStream_t st) {
     const size_t bytes = floats * sizeof(float);
     if (bytes > 150 * 1024) return PN2_EUNSUP;
     const int need4 = (p.groups + 3) / 4;
-    if (bytes > 78 * 1024) {
-        // only one workgroup fits per CU: give it 8 waves (2 per SIMD) sharing the LDS weights
+    if (bytes > 78 * 1024 && p.groups >= 2048) {
+        // only one workgroup fits per CU: give it 8 waves (2 per SIMD) sharing the LDS weights.
+        // (With fewer than 2048 tiles, 4-wave workgroups spread the tiles over twice as many CUs.)
         auto kern = sa_fused_kernel<L, NT1, NT2, NT3, VEC8, DENSE, POOL, 8>;
         static bool attr_set = false;  // per instantiation; benign race (idempotent call)
         if (!attr_set) {
@@ -318,7 +319,7 @@ int launch_chain(const SaFusedParams& p, hipStream_t st) {
             if (e != hipSuccess) return (int)e;
             attr_set = true;
         }
-        int grid = 256 * 2;  // two 4-wave workgroups per CU
+        int grid = bytes > 78 * 1024 ? 256 : 256 * 2;  // 4-wave workgroups: as many as LDS lets co-reside per CU
         if (grid > need4) grid = need4;
         kern<<<grid, 256, bytes, st>>>(p);
     }
@@ -328,16 +329,38 @@ int launch_chain(const SaFusedParams& p, hipStream_t st) {
 
 }  // namespace
 
+static int sa_fused_impl(int b, int n, int m, int nsample, int c, const float* xyz,
+                         const float* new_xyz, const float* points, const int* idx,
+                         int nlayers, const int* widths, const float* const* w,
+                         const float* const* bias, float* out, bool pool, void* stream);
+
 extern "C" int pn2_sa_mlp_max_fused(int b, int n, int m, int nsample, int c, const float* xyz,
                                     const float* new_xyz, const float* points, const int* idx,
                                     int nlayers, const int* widths, const float* const* w,
                                     const float* const* bias, float* out, void* stream) {
+    return sa_fused_impl(b, n, m, nsample, c, xyz, new_xyz, points, idx, nlayers, widths, w, bias, out, true, stream);
+}
+
+// Same gather + MLP chain WITHOUT the max over the neighbours: out is (b, m, nsample, widths[last])
+// with ReLU applied -- the input of a wider following layer that runs on pn2_linear (+pool).  Used
+// when an SA stack starts with <= 128-wide layers and ends with a wider one ([128,128,256]).
+extern "C" int pn2_sa_mlp_rows_fused(int b, int n, int m, int nsample, int c, const float* xyz,
+                                     const float* new_xyz, const float* points, const int* idx,
+                                     int nlayers, const int* widths, const float* const* w,
+                                     const float* const* bias, float* out, void* stream) {
+    return sa_fused_impl(b, n, m, nsample, c, xyz, new_xyz, points, idx, nlayers, widths, w, bias, out, false, stream);
+}
+
+static int sa_fused_impl(int b, int n, int m, int nsample, int c, const float* xyz,
+                         const float* new_xyz, const float* points, const int* idx,
+                         int nlayers, const int* widths, const float* const* w,
+                         const float* const* bias, float* out, bool pool, void* stream) {
     if (b <= 0 || n <= 0 || m <= 0 || nsample <= 0 || c < 0 || nlayers <= 0) return PN2_EINVAL;
     if (!xyz || !new_xyz || !idx || !widths || !w || !bias || !out || (c > 0 && !points)) return PN2_ENULL;
     if (nsample != 32 || nlayers > 3) return PN2_EUNSUP;
     if ((long long)b * m > 0x7fffffffLL / 32) return PN2_ERANGE;
     SaFusedParams p{};
-    p.n = n; p.m = m; p.c = c; p.groups = b * m;
+    p.n = n; p.m = m; p.c = c; p.groups = b * m; p.rows = b * m * 32;
     p.xyz = xyz; p.new_xyz = new_xyz; p.points = points; p.idx = idx; p.out = out;
     int nt[3] = {0, 0, 0};
     for (int l = 0; l < nlayers; ++l) {
@@ -349,6 +372,14 @@ extern "C" int pn2_sa_mlp_max_fused(int b, int n, int m, int nsample, int c, con
     const bool vec8 = c > 0 && (c % 8 == 0) && ((uintptr_t)points % 16 == 0);
     hipStream_t st = static_cast<hipStream_t>(stream);
     const int key = nlayers * 1000 + nt[0] * 100 + nt[1] * 10 + nt[2];
+    if (!pool) {
+        // un-pooled variant: only the shapes the model needs ([*,128,128] prefixes)
+        if (key == 2440) return vec8 ? launch_chain<2, 4, 4, 1, true, false, false>(p, st)
+                                     : launch_chain<2, 4, 4, 1, false, false, false>(p, st);
+        if (key == 1400) return vec8 ? launch_chain<1, 4, 1, 1, true, false, false>(p, st)
+                                     : launch_chain<1, 4, 1, 1, false, false, false>(p, st);
+        return PN2_EUNSUP;
+    }
 #define PN2_SA_CASE(L_, A_, B_, C_)                                                     \
     case (L_ * 1000 + A_ * 100 + B_ * 10 + C_):                                         \
         return vec8 ? launch_chain<L_, A_, (B_ ? B_ : 1), (C_ ? C_ : 1), true, false, true>(p, st) \

@@ -56,9 +56,9 @@ def sample_and_group_all(xyz, points, use_xyz=True):
     return new_xyz, new_points, idx, grouped_xyz
 
 
-def _sa_fused_inference(xyz, new_xyz, points, idx, mlp, bn, conv_scope_fmt):
-    """Try the fully fused gather+MLP+max kernel; returns None if the configuration
-    is outside what pn2_sa_mlp_max_fused supports."""
+def _sa_fused_inference(xyz, new_xyz, points, idx, mlp, bn, conv_scope_fmt, pool=True):
+    """Try the fully fused gather+MLP(+max) kernel; returns None if the configuration is outside what
+    pn2_sa_mlp_max_fused / pn2_sa_mlp_rows_fused (pool=False: un-pooled (B,M,K,w) output) support."""
     b, n, _ = xyz.shape
     m, nsample = idx.shape[1], idx.shape[2]
     c = 0 if points is None else points.shape[2]
@@ -76,10 +76,12 @@ def _sa_fused_inference(xyz, new_xyz, points, idx, mlp, bn, conv_scope_fmt):
     widths = (ctypes.c_int * L)(*mlp)
     wptrs = (ctypes.c_void_p * L)(*[t.data_ptr() for t in ws])
     bptrs = (ctypes.c_void_p * L)(*[t.data_ptr() for t in bs])
-    out = torch.empty((b, m, mlp[-1]), dtype=torch.float32, device=xyz.device)
+    oshape = (b, m, mlp[-1]) if pool else (b, m, nsample, mlp[-1])
+    out = torch.empty(oshape, dtype=torch.float32, device=xyz.device)
     pts = None if points is None else points.contiguous()
+    fn = lib.pn2_sa_mlp_max_fused if pool else lib.pn2_sa_mlp_rows_fused
     with torch.cuda.device(xyz.device):
-        rc = lib.pn2_sa_mlp_max_fused(b, n, m, nsample, c, ptr(xyz), ptr(new_xyz), ptr(pts), ptr(idx), L,
+        rc = fn(b, n, m, nsample, c, ptr(xyz), ptr(new_xyz), ptr(pts), ptr(idx), L,
                                       ctypes.cast(widths, ctypes.c_void_p), ctypes.cast(wptrs, ctypes.c_void_p),
                                       ctypes.cast(bptrs, ctypes.c_void_p), ptr(out), stream_ptr())
     if rc == PN2_EUNSUP:
@@ -122,6 +124,14 @@ def sa_features_inference(xyz, new_xyz, points, idx, mlp, bn=True, bn_decay=None
     new_points = None
     if USE_FUSED_SA:
         new_points = _sa_fused_inference(xyz, new_xyz, points, idx, mlp, bn, "conv%d")
+    if new_points is None and USE_FUSED_SA and len(mlp) == 3 and mlp[0] == mlp[1] == 128 and mlp[2] % 32 == 0:
+        # [128,128,wide]: gather + first two layers fused (activations stay in registers), the wide
+        # last layer + max over K on pn2_linear
+        h = _sa_fused_inference(xyz, new_xyz, points, idx, mlp[:2], bn, "conv%d", pool=False)
+        if h is not None:
+            h = tf_util.conv2d(h, mlp[2], [1, 1], padding="VALID", stride=[1, 1], bn=bn, is_training=False,
+                               scope="conv2", bn_decay=bn_decay, pool=nsample)
+            new_points = h.squeeze(2)
     if new_points is None:
         h = _sa_group_concat(xyz, new_xyz, points, idx)  # (B,M,K,3+C)
         pool_ok = nsample == 16 or nsample % 32 == 0
