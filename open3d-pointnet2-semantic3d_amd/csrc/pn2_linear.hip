@@ -35,12 +35,15 @@ __device__ __forceinline__ void atomic_max_nonneg(float* addr, float v) {
     atomicMax(reinterpret_cast<int*>(addr), __float_as_int(v));
 }
 
-template <int WM, int WN, int NT, bool VEC_A>
+// WK = 2 splits every k-tile between two waves of the same output tile (intra-workgroup split-K,
+// reduced through LDS before the epilogue): small-row layers then launch twice as many workgroups.
+template <int WM, int WN, int NT, bool VEC_A, int WK = 1>
 __global__ void __launch_bounds__(256)
 linear_kernel(int rows, int cin, int cout, const float* __restrict__ x,
               const float* __restrict__ w, const float* __restrict__ bias, int relu, int pool,
               float* __restrict__ y) {
-    static_assert(WM * WN == 4, "4 waves per block");
+    static_assert(WM * WN * WK == 4, "4 waves per block");
+    static_assert(WK == 1 || (WK == 2 && NT * 16 * 64 * WM * WN <= kBK * (32 * NT * WN + 4)), "reduction buffer must fit the B tile");
     constexpr int BM = 32 * WM;
     constexpr int BN = 32 * NT * WN;
     constexpr int BS = BN + 4;                   // B tile row stride (floats)
@@ -55,7 +58,9 @@ linear_kernel(int rows, int cin, int cout, const float* __restrict__ x,
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = tid >> 6;
-    const int wm = wave / WN, wn = wave % WN;
+    const int wk = wave / (WM * WN);           // k-split index (0 when WK == 1)
+    const int wmn = wave % (WM * WN);
+    const int wm = wmn / WN, wn = wmn % WN;
     const int half = lane >> 5;
     const int l31 = lane & 31;
     const int row0 = blockIdx.x * BM;
@@ -137,7 +142,8 @@ linear_kernel(int rows, int cin, int cout, const float* __restrict__ x,
         const float* as = As + (wm * 32 + l31) * kAS + 4 * half;
         const float* bs = Bs + (4 * half) * BS + wn * (NT * 32) + l31;
 #pragma unroll
-        for (int t = 0; t < 4; ++t) {
+        for (int tt = 0; tt < 4 / WK; ++tt) {
+            const int t = tt + wk * (4 / WK);  // this wave's share of the k-tile
             const f32x4 av = *reinterpret_cast<const f32x4*>(as + 8 * t);
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
@@ -148,6 +154,23 @@ linear_kernel(int rows, int cin, int cout, const float* __restrict__ x,
                 }
             }
         }
+    }
+
+    if constexpr (WK == 2) {  // reduce the two k-halves through LDS (B tile memory is free now)
+        __syncthreads();
+        float* red = Bs + wmn * (NT * 16 * 64);
+        if (wk == 1) {
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) red[(nt * 16 + r) * 64 + lane] = acc[nt][r];
+        }
+        __syncthreads();
+        if (wk == 1) return;
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[nt][r] += red[(nt * 16 + r) * 64 + lane];
     }
 
     // ---- epilogue ------------------------------------------------------------
@@ -193,14 +216,14 @@ linear_kernel(int rows, int cin, int cout, const float* __restrict__ x,
     }
 }
 
-template <int WM, int WN, int NT>
+template <int WM, int WN, int NT, int WK = 1>
 int launch_linear(int rows, int cin, int cout, const float* x, const float* w, const float* bias,
                   int relu, int pool, float* y, hipStream_t st) {
     constexpr int BM = 32 * WM, BN = 32 * NT * WN;
     dim3 grid((rows + BM - 1) / BM, cout / BN);
     const bool vec_a = (cin % 4 == 0) && ((uintptr_t)x % 16 == 0);
-    if (vec_a) linear_kernel<WM, WN, NT, true><<<grid, 256, 0, st>>>(rows, cin, cout, x, w, bias, relu, pool, y);
-    else linear_kernel<WM, WN, NT, false><<<grid, 256, 0, st>>>(rows, cin, cout, x, w, bias, relu, pool, y);
+    if (vec_a) linear_kernel<WM, WN, NT, true, WK><<<grid, 256, 0, st>>>(rows, cin, cout, x, w, bias, relu, pool, y);
+    else linear_kernel<WM, WN, NT, false, WK><<<grid, 256, 0, st>>>(rows, cin, cout, x, w, bias, relu, pool, y);
     PN2_RETURN_IF_LAUNCH_FAILED();
     return PN2_OK;
 }
@@ -253,7 +276,9 @@ extern "C" int pn2_linear(int rows, int cin, int cout, const float* x, const flo
         const long long cb = cout / 128;
         if (((rows + 127) / 128) * cb >= 512) return launch_linear<4, 1, 4>(rows, cin, cout, x, w, bias, relu, pool, y, st);
         if (((rows + 63) / 64) * cb >= 512) return launch_linear<2, 2, 2>(rows, cin, cout, x, w, bias, relu, pool, y, st);
-        return launch_linear<1, 4, 1>(rows, cin, cout, x, w, bias, relu, pool, y, st);
+        if (((rows + 31) / 32) * cb >= 256 || cin < 128)
+            return launch_linear<1, 4, 1>(rows, cin, cout, x, w, bias, relu, pool, y, st);
+        return launch_linear<1, 2, 1, 2>(rows, cin, cout, x, w, bias, relu, pool, y, st);  // few rows: 32x64 tiles, split-K in the block
     }
     if (cout % 64 == 0) return launch_linear<4, 1, 2>(rows, cin, cout, x, w, bias, relu, pool, y, st);
     return launch_linear<4, 1, 1>(rows, cin, cout, x, w, bias, relu, pool, y, st);

@@ -189,29 +189,51 @@ sa_fused_kernel(SaFusedParams p) {
     float* sb1 = wp3 + (L >= 3 ? W2 * W3 : 0);
     float* sb2 = sb1 + W1;
     float* sb3 = sb2 + (L >= 2 ? W2 : 0);
-    for (int e = tid; e < steps1 * 2 * W1; e += NTH) {
-        const int col = e % W1, sh = e / W1;
-        const int ch = l1_chan(sh >> 1, sh & 1, c, VEC8, DENSE);
-        wp1[e] = ch >= 0 ? p.W[0][(size_t)ch * W1 + col] : 0.f;
-    }
-    for (int e = tid; e < W1; e += NTH) sb1[e] = p.bias[0][e];
-    if constexpr (L >= 2) {
-        for (int e = tid; e < W1 * W2; e += NTH) {
-            const int col = e % W2, sh = e / W2;
-            const int s = sh >> 1, h = sh & 1;
-            const int ch = (s >> 4) * 32 + acc_chan(s & 15, h);
-            wp2[e] = p.W[1][(size_t)ch * W2 + col];
+    // Weight staging, 8 independent global loads in flight per thread (the permutation index maths is
+    // cheap; what must be hidden is the L2 latency -- a workgroup may own only a handful of tiles).
+    // 16-byte version: index_of(e4) returns the global FLOAT index of 4 consecutive columns (or -1).
+    auto stage4 = [&](float* dst, int count4, const float* __restrict__ src, auto index_of) {
+        for (int base = 0; base < count4; base += NTH * 8) {
+            f32x4 v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int e = base + u * NTH + tid;
+                const int gi = e < count4 ? index_of(e) : -1;
+                const f32x4 t = *reinterpret_cast<const f32x4*>(src + (gi >= 0 ? gi : 0));
+                const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+                v[u] = gi >= 0 ? t : z;
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int e = base + u * NTH + tid;
+                if (e < count4) *reinterpret_cast<f32x4*>(dst + e * 4) = v[u];
+            }
         }
-        for (int e = tid; e < W2; e += NTH) sb2[e] = p.bias[1][e];
+    };
+    auto stage1 = [&](float* dst, int count, const float* __restrict__ src) {
+        for (int e = tid; e < count; e += NTH) dst[e] = src[e];
+    };
+    stage4(wp1, steps1 * 2 * W1 / 4, p.W[0], [&](int e4) {
+        const int col = (e4 % (W1 / 4)) * 4, sh = e4 / (W1 / 4);
+        const int ch = l1_chan(sh >> 1, sh & 1, c, VEC8, DENSE);
+        return ch >= 0 ? ch * W1 + col : -1;
+    });
+    stage1(sb1, W1, p.bias[0]);
+    if constexpr (L >= 2) {
+        stage4(wp2, W1 * W2 / 4, p.W[1], [&](int e4) {
+            const int col = (e4 % (W2 / 4)) * 4, sh = e4 / (W2 / 4);
+            const int s = sh >> 1, h = sh & 1;
+            return ((s >> 4) * 32 + acc_chan(s & 15, h)) * W2 + col;
+        });
+        stage1(sb2, W2, p.bias[1]);
     }
     if constexpr (L >= 3) {
-        for (int e = tid; e < W2 * W3; e += NTH) {
-            const int col = e % W3, sh = e / W3;
+        stage4(wp3, W2 * W3 / 4, p.W[2], [&](int e4) {
+            const int col = (e4 % (W3 / 4)) * 4, sh = e4 / (W3 / 4);
             const int s = sh >> 1, h = sh & 1;
-            const int ch = (s >> 4) * 32 + acc_chan(s & 15, h);
-            wp3[e] = p.W[2][(size_t)ch * W3 + col];
-        }
-        for (int e = tid; e < W3; e += NTH) sb3[e] = p.bias[2][e];
+            return ((s >> 4) * 32 + acc_chan(s & 15, h)) * W3 + col;
+        });
+        stage1(sb3, W3, p.bias[2]);
     }
     __syncthreads();
 
@@ -366,6 +388,7 @@ static int sa_fused_impl(int b, int n, int m, int nsample, int c, const float* x
     for (int l = 0; l < nlayers; ++l) {
         if (widths[l] <= 0 || widths[l] % 32 != 0 || widths[l] > 128) return PN2_EUNSUP;
         if (!w[l] || !bias[l]) return PN2_ENULL;
+        if ((uintptr_t)w[l] % 16 != 0) return PN2_EUNSUP;  // 16-byte weight staging
         p.w[l] = widths[l]; p.W[l] = w[l]; p.bias[l] = bias[l];
         nt[l] = widths[l] / 32;
     }
@@ -421,6 +444,7 @@ extern "C" int pn2_mlp_chain(int rows, int cin, const float* x, int nlayers, con
     for (int l = 0; l < nlayers; ++l) {
         if (widths[l] <= 0 || widths[l] % 32 != 0 || widths[l] > 128) return PN2_EUNSUP;
         if (!w[l] || !bias[l]) return PN2_ENULL;
+        if ((uintptr_t)w[l] % 16 != 0) return PN2_EUNSUP;  // 16-byte weight staging
         p.w[l] = widths[l]; p.W[l] = w[l]; p.bias[l] = bias[l];
         nt[l] = widths[l] / 32;
     }

@@ -467,3 +467,17 @@ def test_large_scene_config4_shapes(pn2, oracle, cuda):
     for l in layer_dicts(store, "big", ["conv0", "conv1"]):
         h = oracle.conv_bn_relu(h, l)
     close(npts.cpu().numpy(), h.max(2))
+
+
+@pytest.mark.parametrize("rows,cin,cout,pool", [(640, 256, 256, 32), (1024, 768, 256, 0), (96, 131, 128, 0), (2048, 384, 512, 32)])
+def test_linear_split_k_config(pn2, cuda, rows, cin, cout, pool):
+    """few rows + deep K -> 32x64 tiles with the k-tile split between two waves and reduced through LDS"""
+    rs = np.random.RandomState(rows + cout)
+    x = rs.randn(rows, cin).astype(np.float32)
+    w = (rs.randn(cin, cout) / np.sqrt(cin)).astype(np.float32)
+    b = rs.randn(cout).astype(np.float32)
+    y = pn2.util.tf_util.hip_linear(T(x, cuda), T(w, cuda), T(b, cuda), relu=1, pool=pool).cpu().numpy()
+    ref = np.maximum(x.astype(np.float64) @ w.astype(np.float64) + b, 0)
+    if pool:
+        ref = ref.reshape(rows // pool, pool, cout).max(1)
+    close(y, ref)
