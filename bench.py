@@ -48,9 +48,9 @@ def s_scene(seed, b, n):
 # ---- algorithmic work per launch (compulsory traffic) -----------------
 def kernel_model(name, a):
     """-> (bound, units) with units = algorithmic bytes (hbm) or flops (mfma) of ONE launch."""
-    if name == "pn2_farthest_point_sample":
+    if name in ("pn2_farthest_point_sample", "pn2_fps_gather"):
         b, n, m = a[0], a[1], a[2]
-        return "hbm", b * n * 12 + b * m * 4
+        return "hbm", b * n * 12 + b * m * 4 + (b * m * 12 if name == "pn2_fps_gather" else 0)
     if name == "pn2_gather_point":
         b, n, m = a[:3]
         return "hbm", b * m * 4 + b * m * 12 * 2
@@ -125,7 +125,8 @@ def pmc_traffic(kernel):
     """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes
     (profiles/r01_pmc_hbm_traffic.json, produced by tools/pmc_mfma.sh on the same workload); None if absent."""
     path = os.path.join(ROOT, "profiles", "r01_pmc_hbm_traffic.json")
-    names = {"farthest_point_sample": ("fps_reg_kernel<1024, 8,", "grid=16384")}
+    names = {"farthest_point_sample": ("fps_reg_kernel<1024, 8,", "grid=16384"),
+             "fps_gather": ("fps_reg_kernel<1024, 8,", "grid=16384")}
     if kernel not in names or not os.path.exists(path):
         return None
     try:
@@ -359,7 +360,7 @@ def main():
                          "share_of_step": round(dom["ms_per_step"] / max(1e-9, sum(k["ms_per_step"] for k in kernels)), 3),
                          "note": ("farthest point sampling is a chain of M-1 dependent argmax rounds: bounded by "
                                   "LDS/barrier latency, not by HBM or MFMA; its HBM fraction is reported as measured"
-                                  if dom["kernel"] == "farthest_point_sample" else "")},
+                                  if dom["kernel"] in ("farthest_point_sample", "fps_gather") else "")},
             "kernels": kernels,
             "gpu_ms_per_step_sum_of_kernels": round(sum(k["ms_per_step"] for k in kernels), 4),
         }

@@ -60,6 +60,12 @@ const char *pn2_strerror(int code);   /* static string for PN2_E* / hipError_t *
 int pn2_farthest_point_sample(int b, int n, int m, const float *inp, float *temp,
                               int *out, int arith_mode, void *stream);
 
+/* farthest_point_sample + gather_point fused (the layer API always chains them,
+ * util/pointnet_util.py:36-37): out (b,m) and new_xyz (b,m,3) = inp[out], bit-identical to the two
+ * separate calls. */
+int pn2_fps_gather(int b, int n, int m, const float *inp, float *temp, int *out,
+                   float *new_xyz, int arith_mode, void *stream);
+
 /* gatherpointLauncher(b,n,m,inp,idx,out)  tf_sampling.cu:222-225, tf_sampling.cpp:158 */
 int pn2_gather_point(int b, int n, int m, const float *inp, const int *idx,
                      float *out, void *stream);

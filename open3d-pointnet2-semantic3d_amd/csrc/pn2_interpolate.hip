@@ -19,7 +19,6 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 constexpr int kNnThreads = 256;
 constexpr int kNnWaves = kNnThreads / 64;
 constexpr int kNnQ = 8;        // queries per wave
-constexpr int kNnChunks = 16;  // candidate chunks (of 64) held in registers at a time: 1024 points
 constexpr int kNnList = 32;    // per-query candidate list (LDS)
 
 struct NnPoint { float x, y, z; };
@@ -58,6 +57,9 @@ __device__ __forceinline__ int nn_wave_imin(int v) {
 // bounding candidates have exact distances <= t3*(1+4e-7), hence every true top-3 candidate has
 // d32 <= t3*(1+8e-7) < thr.  A list overflow (> 32 candidates inside thr: heavy duplication) falls
 // back to a full float64 scan of that query by one lane.
+// kNnChunks = candidate chunks (of 64) held in registers at a time (16 -> 1024 points; small known
+// sets instantiate 4 or 1 so that the unrolled chunk loops do no dead work).
+template <int kNnChunks>
 __global__ void __launch_bounds__(kNnThreads)
 three_nn_kernel(int n, int m, const float* __restrict__ xyz1_all,
                 const float* __restrict__ xyz2_all, float* __restrict__ dist_all,
@@ -323,7 +325,10 @@ extern "C" int pn2_three_nn(int b, int n, int m, const float* xyz1, const float*
     if (!xyz1 || !xyz2 || !dist || !idx) return PN2_ENULL;
     if ((long long)n * 3 > 0x7fffffffLL || (long long)m * 3 > 0x7fffffffLL || b > 65535) return PN2_ERANGE;
     dim3 grid((n + kNnWaves * kNnQ - 1) / (kNnWaves * kNnQ), b);
-    three_nn_kernel<<<grid, kNnThreads, 0, static_cast<hipStream_t>(stream)>>>(n, m, xyz1, xyz2, dist, idx);
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    if (m <= 64) three_nn_kernel<1><<<grid, kNnThreads, 0, st>>>(n, m, xyz1, xyz2, dist, idx);
+    else if (m <= 256) three_nn_kernel<4><<<grid, kNnThreads, 0, st>>>(n, m, xyz1, xyz2, dist, idx);
+    else three_nn_kernel<16><<<grid, kNnThreads, 0, st>>>(n, m, xyz1, xyz2, dist, idx);
     PN2_RETURN_IF_LAUNCH_FAILED();
     return PN2_OK;
 }

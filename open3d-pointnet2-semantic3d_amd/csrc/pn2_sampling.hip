@@ -108,17 +108,25 @@ __device__ __forceinline__ uint2 fps_wave_candidate(float best, int bestk) {
 // Three key slots rotate so the reset of a slot never races with its readers.
 template <int NT, int PPT, int MODE, bool LDS_XYZ>
 __global__ void __launch_bounds__(NT)
-fps_reg_kernel(int n, int m, const float* __restrict__ xyz_all, int* __restrict__ out_all) {
+fps_reg_kernel(int n, int m, const float* __restrict__ xyz_all, int* __restrict__ out_all,
+               float* __restrict__ new_xyz_all) {
     static_assert(NT % 512 == 0 || PPT == 1, "tie-break argument needs NT % 512 == 0 or one point per thread");
     static_assert(NT != 64 || PPT == 1, "single-wave path keeps one point per lane");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    // layout: 4 x u64 key slots (3 used) | float4 xyz[n] (if LDS_XYZ)
+    // layout: 4 x u64 key slots (3 used) | float4 xyz[n] (if LDS_XYZ) | int picks[m] (if LDS_XYZ)
+    // The picks are kept in LDS and written to HBM once, coalesced, after the last round (together
+    // with their coordinates when the fused gather is requested): no global store sits on the
+    // round-to-round critical path of wave 0.
     unsigned long long* slots = reinterpret_cast<unsigned long long*>(smem);
     float4* sxyz = reinterpret_cast<float4*>(smem + 4 * sizeof(unsigned long long));
+    int* spick = reinterpret_cast<int*>(sxyz + (LDS_XYZ ? n : 0));
 
     const int tid = threadIdx.x;
     const float* __restrict__ xyz = xyz_all + (size_t)blockIdx.x * n * 3;
     int* __restrict__ out = out_all + (size_t)blockIdx.x * m;
+    // optional fused gather_point (tf_sampling.cu:178-191): the coordinates of every pick pass through
+    // this kernel anyway, so new_xyz[j] = xyz[out[j]] costs three extra stores per round
+    float* __restrict__ nxyz = new_xyz_all ? new_xyz_all + (size_t)blockIdx.x * m * 3 : nullptr;
 
     float px[PPT], py[PPT], pz[PPT];
     int md[PPT];  // running min distance as int bits (>= 0), or bits(-1.0f) for "no point"
@@ -137,7 +145,9 @@ fps_reg_kernel(int n, int m, const float* __restrict__ xyz_all, int* __restrict_
         }
     }
     if (tid < 4) slots[tid] = 0ull;
-    if (tid == 0) out[0] = 0;  // first pick is index 0 (tf_sampling.cu:122-123)
+    if (tid == 0) {  // first pick is index 0 (tf_sampling.cu:122-123)
+        if constexpr (LDS_XYZ) spick[0] = 0; else out[0] = 0;
+    }
     __syncthreads();
 
     // tiekey(tid + NT*i) = keybase + i * (NT >> 9)   (NT % 512 == 0; PPT == 1 otherwise)
@@ -154,6 +164,9 @@ fps_reg_kernel(int n, int m, const float* __restrict__ xyz_all, int* __restrict_
             x1 = p.x; y1 = p.y; z1 = p.z;
         } else {
             x1 = xyz[old * 3 + 0]; y1 = xyz[old * 3 + 1]; z1 = xyz[old * 3 + 2];
+        }
+        if constexpr (!LDS_XYZ) {
+            if (nxyz && tid == 0) { nxyz[(j - 1) * 3 + 0] = x1; nxyz[(j - 1) * 3 + 1] = y1; nxyz[(j - 1) * 3 + 2] = z1; }
         }
         int best = __float_as_int(-1.0f);
 #pragma unroll
@@ -172,7 +185,7 @@ fps_reg_kernel(int n, int m, const float* __restrict__ xyz_all, int* __restrict_
             nx1 = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(px[0]), src));
             ny1 = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(py[0]), src));
             nz1 = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(pz[0]), src));
-            if (tid == 0) out[j] = old;
+            if (tid == 0) { if constexpr (LDS_XYZ) spick[j] = old; else out[j] = old; }
             continue;
         }
         if (best == wmax && wmax >= 0) {  // normally a single lane of the wave
@@ -193,9 +206,22 @@ fps_reg_kernel(int n, int m, const float* __restrict__ xyz_all, int* __restrict_
         const int nxt = slot == 2 ? 0 : slot + 1;          // (j+1) % 3
         if (tid == 0) {
             slots[nxt == 2 ? 0 : nxt + 1] = 0ull;          // (j+2) % 3: last read after barrier j-1, next used in round j+2
-            out[j] = old;
+            if constexpr (LDS_XYZ) spick[j] = old; else out[j] = old;
         }
         slot = nxt;
+    }
+    if constexpr (LDS_XYZ) {
+        __syncthreads();
+        for (int jj = tid; jj < m; jj += NT) {
+            const int k = spick[jj];
+            out[jj] = k;
+            if (nxyz) {
+                const float4 p = sxyz[k];
+                nxyz[jj * 3 + 0] = p.x; nxyz[jj * 3 + 1] = p.y; nxyz[jj * 3 + 2] = p.z;
+            }
+        }
+    } else if (nxyz && tid == 0) {  // coordinates of the last pick
+        nxyz[(m - 1) * 3 + 0] = xyz[old * 3 + 0]; nxyz[(m - 1) * 3 + 1] = xyz[old * 3 + 1]; nxyz[(m - 1) * 3 + 2] = xyz[old * 3 + 2];
     }
 }
 
@@ -242,22 +268,23 @@ fps_stream_kernel(int b, int n, int m, const float* __restrict__ xyz_all,
 }
 
 template <int NT, int PPT, int MODE>
-int launch_fps_reg(int b, int n, int m, const float* inp, int* out, hipStream_t st) {
+int launch_fps_reg(int b, int n, int m, const float* inp, int* out, float* nxyz, hipStream_t st) {
     const size_t slots_bytes = 4 * sizeof(unsigned long long);
     const size_t xyz_bytes = (size_t)n * sizeof(float4);
-    // 160 KiB LDS per CU; keep the cloud in LDS when it fits (n <= 8192 -> 128 KiB)
-    if (slots_bytes + xyz_bytes <= 144 * 1024) {
+    // 160 KiB LDS per CU; keep the cloud (and the pick list) in LDS when they fit (n <= 8192 -> 128 KiB + 4m)
+    const size_t pick_bytes = (size_t)m * sizeof(int);
+    if (slots_bytes + xyz_bytes + pick_bytes <= 158 * 1024) {
         auto kern = fps_reg_kernel<NT, PPT, MODE, true>;
         static int attr_bytes = 0;  // per instantiation; benign race (idempotent call)
-        if (attr_bytes < (int)(slots_bytes + xyz_bytes)) {
+        if (attr_bytes < (int)(slots_bytes + xyz_bytes + pick_bytes)) {
             hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
             if (e != hipSuccess) return (int)e;
             attr_bytes = 160 * 1024;
         }
-        kern<<<b, NT, slots_bytes + xyz_bytes, st>>>(n, m, inp, out);
+        kern<<<b, NT, slots_bytes + xyz_bytes + pick_bytes, st>>>(n, m, inp, out, nxyz);
     } else {
-        fps_reg_kernel<NT, PPT, MODE, false><<<b, NT, slots_bytes, st>>>(n, m, inp, out);
+        fps_reg_kernel<NT, PPT, MODE, false><<<b, NT, slots_bytes, st>>>(n, m, inp, out, nxyz);
     }
     PN2_RETURN_IF_LAUNCH_FAILED();
     return PN2_OK;
@@ -266,27 +293,27 @@ int launch_fps_reg(int b, int n, int m, const float* inp, int* out, hipStream_t 
 int g_fps_variant = 0;  // tuning hook (pn2_debug_set(0, v)): 0 = default, 512 = 512-thread blocks for n in (1024, 8192]
 
 template <int MODE>
-int dispatch_fps(int b, int n, int m, const float* inp, float* temp, int* out, hipStream_t st) {
+int dispatch_fps(int b, int n, int m, const float* inp, float* temp, int* out, float* nxyz, hipStream_t st) {
     // NT % 512 == 0, or one point per thread (see fps_reg_kernel).
-    if (n <= 64) return launch_fps_reg<64, 1, MODE>(b, n, m, inp, out, st);
-    if (n <= 128) return launch_fps_reg<128, 1, MODE>(b, n, m, inp, out, st);
-    if (n <= 256) return launch_fps_reg<256, 1, MODE>(b, n, m, inp, out, st);
-    if (n <= 512) return launch_fps_reg<512, 1, MODE>(b, n, m, inp, out, st);
-    if (n <= 1024) return launch_fps_reg<1024, 1, MODE>(b, n, m, inp, out, st);
+    if (n <= 64) return launch_fps_reg<64, 1, MODE>(b, n, m, inp, out, nxyz, st);
+    if (n <= 128) return launch_fps_reg<128, 1, MODE>(b, n, m, inp, out, nxyz, st);
+    if (n <= 256) return launch_fps_reg<256, 1, MODE>(b, n, m, inp, out, nxyz, st);
+    if (n <= 512) return launch_fps_reg<512, 1, MODE>(b, n, m, inp, out, nxyz, st);
+    if (n <= 1024) return launch_fps_reg<1024, 1, MODE>(b, n, m, inp, out, nxyz, st);
     if (g_fps_variant == 512) {
-        if (n <= 2048) return launch_fps_reg<512, 4, MODE>(b, n, m, inp, out, st);
-        if (n <= 4096) return launch_fps_reg<512, 8, MODE>(b, n, m, inp, out, st);
-        if (n <= 8192) return launch_fps_reg<512, 16, MODE>(b, n, m, inp, out, st);
+        if (n <= 2048) return launch_fps_reg<512, 4, MODE>(b, n, m, inp, out, nxyz, st);
+        if (n <= 4096) return launch_fps_reg<512, 8, MODE>(b, n, m, inp, out, nxyz, st);
+        if (n <= 8192) return launch_fps_reg<512, 16, MODE>(b, n, m, inp, out, nxyz, st);
     }
-    if (n <= 2048) return launch_fps_reg<1024, 2, MODE>(b, n, m, inp, out, st);
-    if (n <= 4096) return launch_fps_reg<1024, 4, MODE>(b, n, m, inp, out, st);
-    if (n <= 8192) return launch_fps_reg<1024, 8, MODE>(b, n, m, inp, out, st);
-    if (n <= 16384) return launch_fps_reg<1024, 16, MODE>(b, n, m, inp, out, st);
+    if (n <= 2048) return launch_fps_reg<1024, 2, MODE>(b, n, m, inp, out, nxyz, st);
+    if (n <= 4096) return launch_fps_reg<1024, 4, MODE>(b, n, m, inp, out, nxyz, st);
+    if (n <= 8192) return launch_fps_reg<1024, 8, MODE>(b, n, m, inp, out, nxyz, st);
+    if (n <= 16384) return launch_fps_reg<1024, 16, MODE>(b, n, m, inp, out, nxyz, st);
     if (!temp) return PN2_ENULL;
     const int grid = b < 32 ? b : 32;
     fps_stream_kernel<MODE><<<grid, 1024, 0, st>>>(b, n, m, inp, temp, out);
     PN2_RETURN_IF_LAUNCH_FAILED();
-    return PN2_OK;
+    return nxyz ? 1000000 : PN2_OK;  // sentinel: caller still has to run the separate gather
 }
 
 // ---- gather_point / grad ---------------------------------------------------
@@ -333,18 +360,37 @@ extern "C" int pn2_debug_set(int what, int value) {
     return pn2_debug_set_grouping(what, value);
 }
 
-extern "C" int pn2_farthest_point_sample(int b, int n, int m, const float* inp, float* temp,
-                                         int* out, int arith_mode, void* stream) {
+static int fps_entry(int b, int n, int m, const float* inp, float* temp, int* out, float* nxyz,
+                     int arith_mode, void* stream) {
     if (b <= 0 || n <= 0 || m <= 0) return PN2_EINVAL;
     if (!inp || !out) return PN2_ENULL;
     if ((long long)n * 3 > 0x7fffffffLL) return PN2_ERANGE;
     hipStream_t st = static_cast<hipStream_t>(stream);
     switch (arith_mode) {
-        case PN2_ARITH_STRICT: return dispatch_fps<PN2_ARITH_STRICT>(b, n, m, inp, temp, out, st);
-        case PN2_ARITH_FMA: return dispatch_fps<PN2_ARITH_FMA>(b, n, m, inp, temp, out, st);
-        case PN2_ARITH_FMA_ALT: return dispatch_fps<PN2_ARITH_FMA_ALT>(b, n, m, inp, temp, out, st);
+        case PN2_ARITH_STRICT: return dispatch_fps<PN2_ARITH_STRICT>(b, n, m, inp, temp, out, nxyz, st);
+        case PN2_ARITH_FMA: return dispatch_fps<PN2_ARITH_FMA>(b, n, m, inp, temp, out, nxyz, st);
+        case PN2_ARITH_FMA_ALT: return dispatch_fps<PN2_ARITH_FMA_ALT>(b, n, m, inp, temp, out, nxyz, st);
         default: return PN2_EINVAL;
     }
+}
+
+extern "C" int pn2_farthest_point_sample(int b, int n, int m, const float* inp, float* temp,
+                                         int* out, int arith_mode, void* stream) {
+    return fps_entry(b, n, m, inp, temp, out, nullptr, arith_mode, stream);
+}
+
+extern "C" int pn2_gather_point(int b, int n, int m, const float* inp, const int* idx,
+                                float* out, void* stream);
+
+// farthest_point_sample + gather_point in one call (util/pointnet_util.py:36-37 always runs them
+// back to back): out (b,m) indices and new_xyz (b,m,3) = inp[out].  For n <= 16384 the FPS kernel
+// writes the coordinates itself; beyond that the streaming kernel is followed by the gather kernel.
+extern "C" int pn2_fps_gather(int b, int n, int m, const float* inp, float* temp, int* out,
+                              float* new_xyz, int arith_mode, void* stream) {
+    if (!new_xyz) return PN2_ENULL;
+    const int rc = fps_entry(b, n, m, inp, temp, out, new_xyz, arith_mode, stream);
+    if (rc == 1000000) return pn2_gather_point(b, n, m, inp, out, new_xyz, stream);
+    return rc;
 }
 
 extern "C" int pn2_gather_point(int b, int n, int m, const float* inp, const int* idx,

@@ -69,3 +69,23 @@ def gather_point(inp, idx):
     if idx.dtype != torch.int32:
         raise TypeError("GatherPoint expects int32 idx")
     return _GatherPoint.apply(inp.contiguous(), idx.contiguous())
+
+
+def farthest_point_sample_and_gather(npoint, inp):
+    """farthest_point_sample + gather_point in one launch (inference; no gradient):
+    -> idx (b,npoint) int32, new_xyz (b,npoint,3) == gather_point(inp, idx) bit for bit."""
+    if npoint <= 0:
+        raise ValueError("FarthestPointSample expects positive npoint")
+    require_cuda(inp)
+    _chk_xyz(inp, "inp", "FarthestPointSample")
+    inp = inp.detach().contiguous()
+    b, n, _ = inp.shape
+    out = torch.empty((b, npoint), dtype=torch.int32, device=inp.device)
+    new_xyz = torch.empty((b, npoint, 3), dtype=torch.float32, device=inp.device)
+    temp = None
+    if n > 16384:
+        temp = torch.empty((min(b, 32), n), dtype=torch.float32, device=inp.device)
+    with torch.cuda.device(inp.device):
+        check(lib.pn2_fps_gather(b, n, int(npoint), ptr(inp), ptr(temp), ptr(out), ptr(new_xyz),
+                                 int(config.arith_mode), stream_ptr()), "pn2_fps_gather")
+    return out, new_xyz

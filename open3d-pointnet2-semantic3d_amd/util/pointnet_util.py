@@ -19,7 +19,7 @@ from . import tf_util
 from .._lib import PN2_EUNSUP, Pn2Error, check, lib, ptr, require_cuda, stream_ptr
 from ..tf_ops.tf_grouping import group_point, knn_point, query_ball_point
 from ..tf_ops.tf_interpolate import three_interpolate, three_nn
-from ..tf_ops.tf_sampling import farthest_point_sample, gather_point
+from ..tf_ops.tf_sampling import farthest_point_sample, farthest_point_sample_and_gather, gather_point
 
 
 def sample_and_group(npoint, radius, nsample, xyz, points, knn=False, use_xyz=True):
@@ -111,7 +111,7 @@ def sa_geometry(xyz, npoint, radius, nsample):
     -> new_xyz (B,npoint,3), idx (B,npoint,nsample).  Depends only on coordinates, so a model can
     run the geometry of all levels on a side stream (see model.get_sa_fp_features)."""
     xyz = xyz.contiguous()
-    new_xyz = gather_point(xyz, farthest_point_sample(npoint, xyz))
+    _, new_xyz = farthest_point_sample_and_gather(npoint, xyz)  # one launch: the FPS kernel emits the coordinates
     idx, _ = query_ball_point(radius, nsample, xyz, new_xyz)
     return new_xyz, idx
 

@@ -301,3 +301,14 @@ def test_three_interpolate_reference_shapes(pn2, oracle, cuda):
     w = np.ones_like(rd) / np.float32(3.0)
     out = pn2.three_interpolate(T(pts, cuda), i, T(w, cuda))
     assert np.array_equal(out.cpu().numpy(), oracle.three_interpolate(pts, ri, w))
+
+
+@pytest.mark.parametrize("n,m", [(64, 16), (200, 50), (1024, 256), (8192, 1024), (20000, 33)])
+def test_fps_gather_fused_equals_separate(pn2, cuda, n, m):
+    """pn2_fps_gather == farthest_point_sample followed by gather_point, bit for bit."""
+    import torch
+    x = T(s_scene(n, 3, n), cuda)
+    idx, nx = pn2.tf_ops.tf_sampling.farthest_point_sample_and_gather(m, x)
+    ref_idx = pn2.farthest_point_sample(m, x)
+    assert torch.equal(idx, ref_idx)
+    assert torch.equal(nx, pn2.gather_point(x, ref_idx))
