@@ -87,6 +87,12 @@ int pn2_query_ball_point(int b, int n, int m, float radius, int nsample,
                          const float *xyz1, const float *xyz2, int *idx,
                          int *pts_cnt, int arith_mode, void *stream);
 
+/* selectionSortLauncher(b,n,m,k,dist,outi,out)  tf_grouping.cu:145-149, tf_grouping.cpp:135.
+ * dist (b,m,n) -> outi (b,m,n) int32, out (b,m,n): partial selection sort of the first k positions
+ * of every row including the reference's swaps (whole rows bit-identical).  n <= 19200. */
+int pn2_selection_sort(int b, int n, int m, int k, const float *dist, int *outi, float *out,
+                       void *stream);
+
 /* groupPointLauncher(b,n,c,m,nsample,points,idx,out)  tf_grouping.cu:150-154,
  * tf_grouping.cpp:178.  out (b,m,nsample,c). */
 int pn2_group_point(int b, int n, int c, int m, int nsample, const float *points,

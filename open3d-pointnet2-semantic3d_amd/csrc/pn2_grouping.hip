@@ -400,6 +400,46 @@ group_point_grad_kernel(int n, int c, unsigned per_batch_rows, const float* __re
     }
 }
 
+// ---- selection sort / top-k (tf_grouping.cu:95-136) ------------------------------------------------
+// One wave per (batch, query) row; the row (values + permutation) lives in LDS.  Round s finds the
+// minimum of positions [s, n) under the order (value, position) -- exactly what the reference's
+// ascending scan with a strict '<' selects -- with a strided lane scan + a 6-step wave reduction,
+// then swaps it into position s like the reference does, so the WHOLE output row (sorted head and
+// permuted tail) is bit-identical.
+__global__ void __launch_bounds__(64)
+selection_sort_kernel(int n, int m, int k, const float* __restrict__ dist_all,
+                      int* __restrict__ outi_all, float* __restrict__ out_all) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char ss_smem[];
+    float* v = reinterpret_cast<float*>(ss_smem);
+    int* id = reinterpret_cast<int*>(v + n);
+    const int lane = threadIdx.x;
+    const size_t rowoff = ((size_t)blockIdx.y * m + blockIdx.x) * n;
+    const float* __restrict__ src = dist_all + rowoff;
+    for (int t = lane; t < n; t += 64) { v[t] = src[t]; id[t] = t; }
+    __syncthreads();
+    const int kk = k < n ? k : n;
+    for (int s = 0; s < kk; ++s) {
+        float bv = v[s];
+        int bt = s;
+        for (int t = s + 1 + lane; t < n; t += 64) {
+            const float x = v[t];
+            if (x < bv) { bv = x; bt = t; }  // strict: a lane keeps its lowest position among equals
+        }
+#pragma unroll
+        for (int o = 32; o >= 1; o >>= 1) {
+            const float pv = __shfl_xor(bv, o);
+            const int pt = __shfl_xor(bt, o);
+            if (pv < bv || (pv == bv && pt < bt)) { bv = pv; bt = pt; }
+        }
+        if (lane == 0 && bt != s) {
+            const float tv = v[bt]; v[bt] = v[s]; v[s] = tv;
+            const int ti = id[bt]; id[bt] = id[s]; id[s] = ti;
+        }
+        __syncthreads();
+    }
+    for (int t = lane; t < n; t += 64) { out_all[rowoff + t] = v[t]; outi_all[rowoff + t] = id[t]; }
+}
+
 inline int grid_x_for(unsigned long long total, int block, int batches) {
     unsigned long long g = (total + block - 1) / block;
     unsigned long long cap = (256ull * 8 + batches - 1) / batches;  // ~8 blocks per CU overall
@@ -433,6 +473,26 @@ extern "C" int pn2_query_ball_point(int b, int n, int m, float radius, int nsamp
         case PN2_ARITH_FMA_ALT: return launch_ball_query<PN2_ARITH_FMA_ALT>(b, n, m, thr, nsample, xyz1, xyz2, idx, pts_cnt, st);
         default: return PN2_EINVAL;
     }
+}
+
+// selectionSortLauncher(b,n,m,k,dist,outi,out)  tf_grouping.cu:145-149, tf_grouping.cpp:135
+extern "C" int pn2_selection_sort(int b, int n, int m, int k, const float* dist, int* outi, float* out,
+                                  void* stream) {
+    if (b <= 0 || n <= 0 || m <= 0 || k <= 0) return PN2_EINVAL;  // "SelectionSort expects positive k" :142-144
+    if (!dist || !outi || !out) return PN2_ENULL;
+    const size_t lds = (size_t)n * 8;
+    if (lds > 150 * 1024 || m > 65535 * 32 || b > 65535) return PN2_ERANGE;  // row must fit LDS (n <= 19200)
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(selection_sort_kernel),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (e != hipSuccess) return (int)e;
+        attr_set = true;
+    }
+    dim3 grid(m, b);
+    selection_sort_kernel<<<grid, 64, lds, static_cast<hipStream_t>(stream)>>>(n, m, k, dist, outi, out);
+    PN2_RETURN_IF_LAUNCH_FAILED();
+    return PN2_OK;
 }
 
 extern "C" int pn2_group_point(int b, int n, int c, int m, int nsample, const float* points,

@@ -75,10 +75,34 @@ def group_point(points, idx):
     return _GroupPoint.apply(points.contiguous(), idx.contiguous())
 
 
-def knn_point(k, xyz1, xyz2):
-    raise NotImplementedError("knn_point (tf_grouping.py:64-89) is outside the SA/FP hot path built so far; "
-                              "see DESIGN.md 'Next'")
-
-
 def select_top_k(k, dist):
-    raise NotImplementedError("select_top_k (tf_grouping.py:31-40) is outside the SA/FP hot path built so far")
+    """k int, dist (b,m,n) float32 -> idx (b,m,n) int32, dist_out (b,m,n): the first k of every row are
+    the k smallest in ascending order (tf_grouping.py:31-40; SelectionSort, not differentiable)."""
+    if k <= 0:
+        raise ValueError("SelectionSort expects positive k")  # tf_grouping.cpp:142-144
+    require_cuda(dist)
+    if dist.dim() != 3:
+        raise ValueError("SelectionSort expects (b,m,n) dist shape.")  # tf_grouping.cpp:152-154
+    if dist.dtype != torch.float32:
+        raise TypeError("SelectionSort expects float32 dist")
+    dist = dist.detach().contiguous()
+    b, m, n = dist.shape
+    outi = torch.empty((b, m, n), dtype=torch.int32, device=dist.device)
+    out = torch.empty((b, m, n), dtype=torch.float32, device=dist.device)
+    with torch.cuda.device(dist.device):
+        check(lib.pn2_selection_sort(b, n, m, int(k), ptr(dist), ptr(outi), ptr(out), stream_ptr()),
+              "pn2_selection_sort")
+    return outi, out
+
+
+def knn_point(k, xyz1, xyz2):
+    """k int, xyz1 (b,n,c) dataset, xyz2 (b,m,c) queries -> val (b,m,k) squared L2, idx (b,m,k) int32
+    (tf_grouping.py:64-89: tile + subtract + square + reduce_sum, then select_top_k).  The distance
+    matrix is built with separate fp32 ops summed left to right, as the separate TF ops do."""
+    require_cuda(xyz1, xyz2)
+    d = (xyz1.detach().unsqueeze(1) - xyz2.detach().unsqueeze(2)) ** 2  # (b,m,n,c)
+    dist = d[..., 0]
+    for ch in range(1, d.shape[-1]):
+        dist = dist + d[..., ch]
+    outi, out = select_top_k(k, dist)
+    return out[:, :, :k].contiguous(), outi[:, :, :k].contiguous()

@@ -144,6 +144,27 @@ def three_interpolate_grad(points, idx, weight, grad_out):
     return gp
 
 
+def select_top_k(k, dist):
+    """tf_ops/tf_grouping.py:31-40 -> (idx (b,m,n) int32, dist_out (b,m,n)): first k sorted, rest swapped."""
+    dist = _f32(dist)
+    b, m, n = dist.shape
+    outi = np.empty((b, m, n), dtype=np.int32)
+    out = np.empty((b, m, n), dtype=np.float32)
+    rc = lib().oracle_selection_sort(b, n, m, int(k), _p(dist), _p(outi), _p(out))
+    assert rc == 0, rc
+    return outi, out
+
+
+def knn_point(k, xyz1, xyz2):
+    """tf_ops/tf_grouping.py:64-89: dist = reduce_sum((xyz1 - xyz2)^2, -1) in fp32 (separate TF ops:
+    no contraction; summed x^2 + y^2 + z^2 left to right), then select_top_k -> (val (b,m,k), idx (b,m,k))."""
+    xyz1, xyz2 = _f32(xyz1), _f32(xyz2)
+    d = (xyz1[:, None, :, :] - xyz2[:, :, None, :]) ** np.float32(2)
+    dist = ((d[..., 0] + d[..., 1]) + d[..., 2]).astype(np.float32)
+    outi, out = select_top_k(k, dist)
+    return out[:, :, :k], outi[:, :, :k]
+
+
 # ---------------------------------------------------------------------------
 # Layer maths (numpy).  These restate util/pointnet_util.py + util/tf_util.py.
 # `dtype` float64 gives the high-precision oracle the 1e-5 feature tolerance is

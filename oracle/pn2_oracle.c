@@ -18,6 +18,7 @@
  *   oracle_three_nn              tf_ops/tf_interpolate.cpp:20-28,213-243 (threenn_cpu -> Open3D KDTreeFlann, fp64)
  *   oracle_three_interpolate     tf_ops/tf_interpolate.cpp:307-330 (threeinterpolate_cpu)
  *   oracle_three_interpolate_grad tf_ops/tf_interpolate.cpp:397-421 (threeinterpolate_grad_cpu) + memset :477
+ *   oracle_selection_sort        tf_ops/tf_grouping.cu:95-136   (selection_sort_gpu)
  *
  * Parity pinning (see DESIGN.md "Oracle"):
  *   - three_nn is pinned by the reference's own golden vector
@@ -321,6 +322,32 @@ int oracle_three_interpolate_grad(int b, int n, int c, int m,
                 gp[(size_t)i1 * c + l] += t1;
                 gp[(size_t)i2 * c + l] += t2;
                 gp[(size_t)i3 * c + l] += t3;
+            }
+        }
+    return 0;
+}
+
+/* ------------------------------------------------------------------------- */
+/* SelectionSort (tf_grouping.cu:95-136): copy dist (b,m,n) to out, outi = 0..n-1, then a partial
+ * selection sort of the first k positions of every row WITH the swaps (the tail of the row keeps the
+ * swapped-out elements), strict '<' so the first minimum wins. */
+int oracle_selection_sort(int b, int n, int m, int k, const float *dist, int *outi, float *out) {
+    if (b <= 0 || n <= 0 || m <= 0 || k <= 0) return -1;
+#pragma omp parallel for collapse(2) schedule(static)
+    for (int bi = 0; bi < b; ++bi)
+        for (int j = 0; j < m; ++j) {
+            const float *src = dist + ((size_t)bi * m + j) * n;
+            float *p = out + ((size_t)bi * m + j) * n;
+            int *pi = outi + ((size_t)bi * m + j) * n;
+            for (int s = 0; s < n; ++s) { p[s] = src[s]; pi[s] = s; }
+            for (int s = 0; s < k && s < n; ++s) {
+                int mn = s;
+                for (int t = s + 1; t < n; ++t)
+                    if (p[t] < p[mn]) mn = t; /* :124 strict */
+                if (mn != s) {
+                    float tmp = p[mn]; p[mn] = p[s]; p[s] = tmp;
+                    int ti = pi[mn]; pi[mn] = pi[s]; pi[s] = ti;
+                }
             }
         }
     return 0;

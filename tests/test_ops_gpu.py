@@ -312,3 +312,43 @@ def test_fps_gather_fused_equals_separate(pn2, cuda, n, m):
     ref_idx = pn2.farthest_point_sample(m, x)
     assert torch.equal(idx, ref_idx)
     assert torch.equal(nx, pn2.gather_point(x, ref_idx))
+
+
+# ------------------------------------------------------------------ knn / selection sort
+def test_select_top_k_whole_rows_bit_exact(pn2, oracle, cuda):
+    """SelectionSort returns the whole (b,m,n) rows: sorted head AND the swap-permuted tail."""
+    rs = np.random.RandomState(0)
+    dist = rs.random_sample((3, 20, 300)).astype(np.float32)
+    dist[:, :, ::7] = dist[:, :, 3:4]  # ties: the strict '<' + swaps decide the order
+    for k in (1, 5, 64, 300, 400):
+        oi, od = pn2.select_top_k(k, T(dist, cuda))
+        ri, rd = oracle.select_top_k(k, dist)
+        assert np.array_equal(oi.cpu().numpy(), ri) and np.array_equal(od.cpu().numpy(), rd), k
+
+
+def test_knn_point_reference_test_shapes(pn2, oracle, cuda):
+    """tf_ops/test_tf_ops.py:9-36 (knn=True branch): seed 100, xyz1 (32,512,3), xyz2 (32,128,3), k=64,
+    then group_point on pts (32,512,64)."""
+    np.random.seed(100)
+    pts = np.random.random((32, 512, 64)).astype("float32")
+    tmp1 = np.random.random((32, 512, 3)).astype("float32")
+    tmp2 = np.random.random((32, 128, 3)).astype("float32")
+    val, idx = pn2.knn_point(64, T(tmp1, cuda), T(tmp2, cuda))
+    rv, ri = oracle.knn_point(64, tmp1, tmp2)
+    assert np.array_equal(idx.cpu().numpy(), ri) and np.array_equal(val.cpu().numpy(), rv)
+    assert (np.diff(rv, axis=2) >= 0).all()
+    g = pn2.group_point(T(pts, cuda), idx)
+    assert np.array_equal(g.cpu().numpy(), oracle.group_point(pts, ri))
+
+
+def test_sample_and_group_knn(pn2, oracle, cuda):
+    rs = np.random.RandomState(5)
+    xyz = rs.random_sample((2, 400, 3)).astype(np.float32)
+    pts = rs.randn(2, 400, 4).astype(np.float32)
+    nx, npts, idx, gx = pn2.sample_and_group(32, None, 8, T(xyz, cuda), T(pts, cuda), knn=True)
+    f = oracle.farthest_point_sample(32, xyz)
+    rnx = oracle.gather_point(xyz, f)
+    _, ri = oracle.knn_point(8, xyz, rnx)
+    assert np.array_equal(idx.cpu().numpy(), ri)
+    assert np.array_equal(npts.cpu().numpy(),
+                          np.concatenate([oracle.group_point(xyz, ri) - rnx[:, :, None], oracle.group_point(pts, ri)], -1))
