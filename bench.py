@@ -327,6 +327,16 @@ def main():
     elapsed = pn2.dist.max_over_ranks(elapsed, device=dev)  # the slowest rank defines the step time
     assert torch.isfinite(out).all()
 
+    # ---- latency of ONE batch (graph replay, nothing else in flight) -----------------------------
+    latency_ms = None
+    if not args.eager:
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for _ in range(10):
+            caps[0].replay()
+            torch.cuda.synchronize()
+        latency_ms = (time.perf_counter() - t1) / 10 * 1e3
+
     # ---- instrumented pass: same steps, every launch bracketed by HIP events on its stream ----
     trace_steps = min(args.steps, 10)
     pn2._lib.lib.trace = []
@@ -362,6 +372,7 @@ def main():
                                   "LDS/barrier latency, not by HBM or MFMA; its HBM fraction is reported as measured"
                                   if dom["kernel"] in ("farthest_point_sample", "fps_gather") else "")},
             "kernels": kernels,
+            "single_batch_latency_ms": None if latency_ms is None else round(latency_ms, 4),
             "gpu_ms_per_step_sum_of_kernels": round(sum(k["ms_per_step"] for k in kernels), 4),
         }
         if not args.no_north_star:
