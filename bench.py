@@ -83,6 +83,14 @@ def kernel_model(name, a):
             fl += 2 * rows * cin * w
             cin = w
         return "mfma", fl
+    if name == "pn2_fp_mlp_fused":
+        b, n, m, c1, c2, L = a[:6]
+        widths = a[6:6 + L]
+        cin, fl = c1 + c2, 0
+        for w in widths:
+            fl += 2 * b * n * cin * w
+            cin = w
+        return "mfma", fl
     if name in ("pn2_sa_mlp_max_fused", "pn2_sa_mlp_rows_fused"):
         b, n, m, ns, c, L = a[:6]
         widths = a[6:6 + L]
@@ -252,6 +260,10 @@ def main():
     ap.add_argument("--one-stream", action="store_true", help="do not overlap the geometry chain with the MLP chain")
     ap.add_argument("--pipeline", type=int, default=4, help="independent batches in flight (graphs replayed round-robin)")
     ap.add_argument("--no-north-star", action="store_true")
+    ap.add_argument("--fp-front", choices=("auto", "fused", "unfused"), default="auto",
+                    help="FP front end inside the first FP4 MLP kernel (pn2_fp_mlp_fused: lowest single-batch latency) "
+                         "or materialised by pn2_fp_interp_concat (measured 3%% better throughput with several batches "
+                         "in flight); auto = fused when --pipeline 1, else unfused")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -286,6 +298,9 @@ def main():
         for k, v in store.buffers.items():
             if k.endswith("moving_variance"):
                 v.copy_((torch.rand(v.shape, generator=g) + 0.5).to(dev))
+
+    fused_fp = args.fp_front == "fused" or (args.fp_front == "auto" and (args.eager or args.pipeline <= 1))
+    pn2.util.pointnet_util.USE_FUSED_FP = fused_fp
 
     def step():
         with torch.no_grad():
@@ -362,7 +377,8 @@ def main():
                        "arith_mode": int(pn2.config.arith_mode),
                        "launch": "eager python launches" if args.eager else "one hipGraph replay per step",
                        "streams": 1 if (args.eager or args.one_stream) else 2,
-                       "batches_in_flight": 1 if args.eager else max(1, args.pipeline)},
+                       "batches_in_flight": 1 if args.eager else max(1, args.pipeline),
+                       "fp_front": "fused" if fused_fp else "materialised"},
             "roofline": {"kernel": dom["kernel"], "args": dom["args"], "bound": dom["bound"],
                          "achieved": dom["achieved"], "peak": dom["peak"], "unit": dom["unit"], "frac": dom["frac"],
                          "traffic": pmc_traffic(dom["kernel"]) if (B, N) == (16, 8192) else None,

@@ -181,6 +181,17 @@ int pn2_mlp_chain(int rows, int cin, const float *x, int nlayers, const int *wid
                   const float *const *w, const float *const *bias, int pool, float *y,
                   void *stream);
 
+/* Fused feature-propagation block (pointnet_util.py:300-325, inference BN folded):
+ *   x[b,j,:] = [ three_interpolate(points2, idx, w(dist))[b,j,:] | points1[b,j,:] ]   (never stored)
+ *   y = relu(relu(x @ W0 + b0) @ W1 + b1)                                            (nlayers 1 or 2)
+ * i.e. pn2_fp_interp_concat + pn2_mlp_chain in one kernel: the interpolated rows go from L2 straight
+ * into the MFMA operands.  dist,idx (b,n,3)  points2 (b,m,c2)  points1 (b,n,c1) or NULL
+ * w[0] (>= c2+c1 rows, widths[0]), interpolated channels first  ->  y (b*n, widths[nlayers-1]).
+ * Constraints: c2 % 8 == 0, widths multiples of 32 and <= 128; PN2_EUNSUP otherwise. */
+int pn2_fp_mlp_fused(int b, int n, int m, int c1, int c2, const float *dist, const int *idx,
+                     const float *points1, const float *points2, int nlayers, const int *widths,
+                     const float *const *w, const float *const *bias, float *y, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -36,6 +36,8 @@ SIGNATURES = {
     "pn2_fp_interp_concat": [c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p,
                              c_void_p, c_int, c_void_p],
     "pn2_mlp_chain": [c_int, c_int, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p],
+    "pn2_fp_mlp_fused": [c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p,
+                         c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p],
     "pn2_sa_group_concat": [c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p,
                             c_void_p, c_void_p],
 }
@@ -97,6 +99,9 @@ class _LibProxy:
             e.record()
             ints = [a for a in args if isinstance(a, (int, float))]
             if name in ("pn2_sa_mlp_max_fused", "pn2_sa_mlp_rows_fused"):  # decode the host-side widths[] array for flop accounting
+                wp = ctypes.cast(args[10], ctypes.POINTER(c_int))
+                ints += [wp[i] for i in range(args[9])]
+            elif name == "pn2_fp_mlp_fused":
                 wp = ctypes.cast(args[10], ctypes.POINTER(c_int))
                 ints += [wp[i] for i in range(args[9])]
             elif name == "pn2_mlp_chain":

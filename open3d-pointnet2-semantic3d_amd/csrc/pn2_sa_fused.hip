@@ -37,6 +37,9 @@ struct SaFusedParams {
     const float* new_xyz;
     const float* points;
     const int* idx;
+    const float* dist;     // INTERP mode: three_nn distances (rows, 3); idx is then (rows, 3)
+    const float* points1;  // INTERP mode: skip-link features (rows, c1) or nullptr
+    int c1;
     const float* W[3];
     const float* bias[3];
     float* out;
@@ -45,18 +48,24 @@ struct SaFusedParams {
 __device__ __forceinline__ int acc_chan(int r, int half) { return (r & 3) + 8 * (r >> 2) + 4 * half; }
 
 // number of k-steps of layer 1 for c feature channels
-__host__ __device__ inline int l1_steps(int c, bool vec8, bool dense = false) {
-    return (dense ? 0 : 2) + (vec8 ? (c / 8) * 4 : (c + 1) / 2);
+// (c1 = extra un-vectorised channels appended after the c vectorised ones: FP skip link)
+__host__ __device__ inline int l1_steps(int c, bool vec8, bool dense = false, int c1 = 0) {
+    return (dense ? 0 : 2) + (vec8 ? (c / 8) * 4 : (c + 1) / 2) + (c1 + 1) / 2;
 }
 
 // input channel (row of W1) fed by half-wave `h` at k-step `s` of layer 1; -1 = zero pad
-__device__ __forceinline__ int l1_chan(int s, int h, int c, bool vec8, bool dense) {
+__device__ __forceinline__ int l1_chan(int s, int h, int c, bool vec8, bool dense, int c1 = 0) {
     int base = 0;
     if (!dense) {
         if (s == 0) return h;              // x | y
         if (s == 1) return h ? -1 : 2;     // z | 0
         s -= 2;
         base = 3;
+    }
+    const int nmain = vec8 ? (c / 8) * 4 : (c + 1) / 2;
+    if (s >= nmain) {  // appended skip-link channels
+        const int ch = 2 * (s - nmain) + h;
+        return ch < c1 ? base + c + ch : -1;
     }
     if (vec8) return base + 8 * (s >> 2) + 4 * h + (s & 3);
     const int ch = 2 * s + h;
@@ -167,8 +176,11 @@ __device__ __forceinline__ void rows_store(const f32x16 (&acc)[NT], const float*
 // DENSE = false: set-abstraction mode (rows gathered by idx, [xyz - centre | features]).
 // DENSE = true : plain rows of a (rows, c) matrix (feature-propagation MLPs); POOL selects the
 //                max over each 32-row tile or the full (rows, wout) output.
+// INTERP (with DENSE, VEC8): the rows are not read but produced on the fly as the feature-propagation
+//                front end [ three_interpolate(points2, idx, w(dist)) | points1 ] (pointnet_util.py:300-311),
+//                same fp32 operation order as fp_interp_concat_kernel / the reference ops.
 // NW waves per workgroup share one LDS copy of the weights.
-template <int L, int NT1, int NT2, int NT3, bool VEC8, bool DENSE, bool POOL, int NW>
+template <int L, int NT1, int NT2, int NT3, bool VEC8, bool DENSE, bool POOL, int NW, bool INTERP = false>
 __global__ void __launch_bounds__(NW * 64, 2)  // 2 waves/SIMD: <= 256 VGPR+AGPR per lane
 sa_fused_kernel(SaFusedParams p) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -179,7 +191,8 @@ sa_fused_kernel(SaFusedParams p) {
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     constexpr int W1 = NT1 * 32, W2 = NT2 * 32, W3 = NT3 * 32;
     const int c = p.c;
-    const int steps1 = l1_steps(c, VEC8, DENSE);
+    const int c1 = INTERP ? p.c1 : 0;
+    const int steps1 = l1_steps(c, VEC8, DENSE, c1);
     constexpr int NTH = NW * 64;
 
     // ---- LDS carve + weight staging (once per persistent workgroup) -----------
@@ -215,7 +228,7 @@ sa_fused_kernel(SaFusedParams p) {
     };
     stage4(wp1, steps1 * 2 * W1 / 4, p.W[0], [&](int e4) {
         const int col = (e4 % (W1 / 4)) * 4, sh = e4 / (W1 / 4);
-        const int ch = l1_chan(sh >> 1, sh & 1, c, VEC8, DENSE);
+        const int ch = l1_chan(sh >> 1, sh & 1, c, VEC8, DENSE, c1);
         return ch >= 0 ? ch * W1 + col : -1;
     });
     stage1(sb1, W1, p.bias[0]);
@@ -261,7 +274,39 @@ sa_fused_kernel(SaFusedParams p) {
             mfma_step<NT1, LAST1>(a1, w1l + 0 * 2 * W1, half ? ry : rx);
             mfma_step<NT1, LAST1>(a1, w1l + 1 * 2 * W1, half ? 0.f : rz);
         }
-        if constexpr (VEC8) {
+        if constexpr (INTERP) {
+            // inverse-distance weights exactly as fp_interp_concat_kernel (IEEE divisions)
+            const float* __restrict__ dr = p.dist + prow * 3;
+            const int* __restrict__ ir = p.idx + prow * 3;
+            const float d1 = fmaxf(dr[0], 1e-10f), d2 = fmaxf(dr[1], 1e-10f), d3 = fmaxf(dr[2], 1e-10f);
+            const float r1 = 1.0f / d1, r2 = 1.0f / d2, r3 = 1.0f / d3;
+            const float norm = (r1 + r2) + r3;
+            const float w1 = r1 / norm, w2 = r2 / norm, w3 = r3 / norm;
+            const size_t kb = (prow / (size_t)p.n) * (size_t)p.m;  // first known row of this batch element
+            const f32x4* __restrict__ f1 = reinterpret_cast<const f32x4*>(p.points + (kb + ir[0]) * c) + half;
+            const f32x4* __restrict__ f2 = reinterpret_cast<const f32x4*>(p.points + (kb + ir[1]) * c) + half;
+            const f32x4* __restrict__ f3 = reinterpret_cast<const f32x4*>(p.points + (kb + ir[2]) * c) + half;
+            const int nt8 = c >> 3;
+            f32x4 c1v = f1[0], c2v = f2[0], c3v = f3[0];
+            for (int t = 0; t < nt8; ++t) {
+                f32x4 n1 = c1v, n2 = c2v, n3 = c3v;
+                if (t + 1 < nt8) { n1 = f1[(t + 1) * 2]; n2 = f2[(t + 1) * 2]; n3 = f3[(t + 1) * 2]; }
+                const f32x4 cur = (c1v * w1 + c2v * w2) + c3v * w3;  // tf_interpolate.cpp:322-324 order, unfused
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+                    mfma_step<NT1, LAST1>(a1, w1l + (4 * t + q) * 2 * W1, cur[q]);
+                c1v = n1; c2v = n2; c3v = n3;
+            }
+            if (c1 > 0) {
+                const float* __restrict__ fp = p.points1 + prow * c1;
+                const int ns = (c1 + 1) >> 1;
+                for (int sp = 0; sp < ns; ++sp) {
+                    const int ch = 2 * sp + half;
+                    const float v = ch < c1 ? fp[ch] : 0.f;
+                    mfma_step<NT1, LAST1>(a1, w1l + (4 * nt8 + sp) * 2 * W1, v);
+                }
+            }
+        } else if constexpr (VEC8) {
             const f32x4* __restrict__ fp =
                 reinterpret_cast<const f32x4*>(p.points + prow * c) + half;
             const int nt8 = c >> 3;
@@ -307,10 +352,10 @@ sa_fused_kernel(SaFusedParams p) {
     }
 }
 
-template <int L, int NT1, int NT2, int NT3, bool VEC8, bool DENSE, bool POOL>
+template <int L, int NT1, int NT2, int NT3, bool VEC8, bool DENSE, bool POOL, bool INTERP = false>
 int launch_chain(const SaFusedParams& p, hipStream_t st) {
     constexpr int W1 = NT1 * 32, W2 = NT2 * 32, W3 = NT3 * 32;
-    const int steps1 = l1_steps(p.c, VEC8, DENSE);
+    const int steps1 = l1_steps(p.c, VEC8, DENSE, INTERP ? p.c1 : 0);
     size_t floats = (size_t)steps1 * 2 * W1 + W1;
     if (L >= 2) floats += (size_t)W1 * W2 + W2;
     if (L >= 3) floats += (size_t)W2 * W3 + W3;
@@ -320,7 +365,7 @@ int launch_chain(const SaFusedParams& p, hipStream_t st) {
     if (bytes > 78 * 1024 && p.groups >= 2048) {
         // only one workgroup fits per CU: give it 8 waves (2 per SIMD) sharing the LDS weights.
         // (With fewer than 2048 tiles, 4-wave workgroups spread the tiles over twice as many CUs.)
-        auto kern = sa_fused_kernel<L, NT1, NT2, NT3, VEC8, DENSE, POOL, 8>;
+        auto kern = sa_fused_kernel<L, NT1, NT2, NT3, VEC8, DENSE, POOL, 8, INTERP>;
         static bool attr_set = false;  // per instantiation; benign race (idempotent call)
         if (!attr_set) {
             hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
@@ -333,7 +378,7 @@ int launch_chain(const SaFusedParams& p, hipStream_t st) {
         if (grid > need8) grid = need8;
         kern<<<grid, 512, bytes, st>>>(p);
     } else {
-        auto kern = sa_fused_kernel<L, NT1, NT2, NT3, VEC8, DENSE, POOL, 4>;
+        auto kern = sa_fused_kernel<L, NT1, NT2, NT3, VEC8, DENSE, POOL, 4, INTERP>;
         static bool attr_set = false;
         if (!attr_set) {
             hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
@@ -465,4 +510,40 @@ extern "C" int pn2_mlp_chain(int rows, int cin, const float* x, int nlayers, con
         default: return PN2_EUNSUP;
     }
 #undef PN2_CHAIN_CASE
+}
+
+// Fused feature-propagation block (pointnet_util.py:300-325, inference BN folded): the FP front end
+// (inverse-distance weights + three_interpolate + concat [interp | points1]) feeds the first MFMA layer
+// directly from L2 -- the (b, n, c2+c1) concatenated tensor is never written to HBM -- followed by up to
+// two LDS-resident dense layers (+bias, ReLU).
+//   dist, idx (b,n,3) from pn2_three_nn;  points2 (b,m,c2) known features;  points1 (b,n,c1) or NULL
+//   w[0] ((c2+c1) rows or more, widths[0]) with the interpolated channels first;  y (b*n, widths[last])
+// Constraints: c2 % 8 == 0, points2 16-byte aligned, nlayers <= 2, widths multiples of 32 and <= 128;
+// PN2_EUNSUP otherwise (callers fall back to pn2_fp_interp_concat + pn2_mlp_chain / pn2_linear).
+extern "C" int pn2_fp_mlp_fused(int b, int n, int m, int c1, int c2, const float* dist, const int* idx,
+                                const float* points1, const float* points2, int nlayers, const int* widths,
+                                const float* const* w, const float* const* bias, float* y, void* stream) {
+    if (b <= 0 || n <= 0 || m <= 0 || c2 <= 0 || c1 < 0 || nlayers <= 0) return PN2_EINVAL;
+    if (!dist || !idx || !points2 || !widths || !w || !bias || !y || (c1 > 0 && !points1)) return PN2_ENULL;
+    if ((long long)b * n > 0x7fffffffLL - 32) return PN2_ERANGE;
+    if (nlayers > 2 || c2 % 8 != 0 || (uintptr_t)points2 % 16 != 0) return PN2_EUNSUP;
+    SaFusedParams p{};
+    p.n = n; p.m = m; p.c = c2; p.c1 = c1; p.rows = b * n; p.groups = (b * n + 31) / 32;
+    p.points = points2; p.points1 = points1; p.dist = dist; p.idx = idx; p.out = y;
+    int nt[2] = {0, 0};
+    for (int l = 0; l < nlayers; ++l) {
+        if (widths[l] <= 0 || widths[l] % 32 != 0 || widths[l] > 128) return PN2_EUNSUP;
+        if (!w[l] || !bias[l]) return PN2_ENULL;
+        if ((uintptr_t)w[l] % 16 != 0) return PN2_EUNSUP;
+        p.w[l] = widths[l]; p.W[l] = w[l]; p.bias[l] = bias[l];
+        nt[l] = widths[l] / 32;
+    }
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    switch (nlayers * 100 + nt[0] * 10 + nt[1]) {
+        case 244: return launch_chain<2, 4, 4, 1, true, true, false, true>(p, st);
+        case 140: return launch_chain<1, 4, 1, 1, true, true, false, true>(p, st);
+        case 224: return launch_chain<2, 2, 4, 1, true, true, false, true>(p, st);
+        case 120: return launch_chain<1, 2, 1, 1, true, true, false, true>(p, st);
+        default: return PN2_EUNSUP;
+    }
 }

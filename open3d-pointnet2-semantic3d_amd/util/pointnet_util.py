@@ -240,19 +240,45 @@ def _fp_interp_concat(dist, idx, points1, points2, pad_to=1):
 USE_MLP_CHAIN = True  # set False to force one pn2_linear launch per layer (tests/bench)
 
 
-def dense_mlp_inference(x2d, cin, mlp, scope_fmt, bn=True):
+USE_FUSED_FP = True    # set False to force pn2_fp_interp_concat + separate MLP launches (tests/bench)
+
+
+def dense_mlp_inference(x2d, cin, mlp, scope_fmt, bn=True, fp_front=None):
     """Run a stack of 1x1-conv layers on (rows, cin_padded) rows.  Consecutive layers whose widths are
     <= 128 run as LDS-resident chains (pn2_mlp_chain, up to 2 layers per launch); anything else runs
     one pn2_linear per layer.  `cin` is the true input width (x2d may carry zero pad columns).
+    fp_front = (dist, idx, points1, points2, pad_to): the rows are the FP front end; when the first layers
+    qualify they are produced inside the first chain kernel (pn2_fp_mlp_fused) and x2d may be None,
+    otherwise they are materialised with pn2_fp_interp_concat.
     Must be called inside the module's variable scope."""
+    if x2d is None:
+        dist, idx, points1, points2, pad_to = fp_front
+        rows = dist.shape[0] * dist.shape[1]
+        cw = -(-cin // pad_to) * pad_to
+    else:
+        rows, cw = x2d.shape
     folded = []
     c = cin
     for i, cout in enumerate(mlp):
         with tf_util.variable_scope(scope_fmt % i):
-            pad_in = x2d.shape[1] if i == 0 else None
+            pad_in = cw if i == 0 else None
             folded.append(tf_util.folded_dense(c, cout, bn, (1, 1, c, cout), pad_to=32, pad_in=pad_in))
         c = cout
     i, h = 0, x2d
+    if h is None:
+        if (USE_FUSED_FP and USE_MLP_CHAIN and rows >= 65536 and points2.shape[2] % 8 == 0
+                and mlp[0] <= 128 and mlp[0] % 32 == 0):
+            for take in (2, 1):
+                if take > len(mlp) or any(w > 128 or w % 32 for w in mlp[:take]):
+                    continue
+                y = tf_util.hip_fp_mlp_fused(dist, idx, points1, points2, [folded[k][0] for k in range(take)],
+                                             [folded[k][1] for k in range(take)])
+                if y is not None:
+                    h, i = y, take
+                    break
+        if h is None:
+            x = _fp_interp_concat(dist, idx, points1, points2, pad_to=pad_to)
+            h = x.reshape(rows, x.shape[2])
     while i < len(mlp):
         done = False
         # the LDS-resident chain pays off when there are enough 32-row tiles to fill the chip
@@ -279,8 +305,8 @@ def fp_features_inference(dist, idx, points1, points2, mlp, bn=True, bn_decay=No
     inside the layer's variable scope."""
     b, n = dist.shape[0], dist.shape[1]
     cin = points2.shape[2] + (0 if points1 is None else points1.shape[2])
-    x = _fp_interp_concat(dist, idx, points1, points2, pad_to=8)  # e.g. 131 -> 136: 16-byte loads downstream
-    h = dense_mlp_inference(x.reshape(b * n, x.shape[2]), cin, mlp, "conv_%d", bn)
+    # rows padded e.g. 131 -> 136 when materialised: 16-byte loads downstream
+    h = dense_mlp_inference(None, cin, mlp, "conv_%d", bn, fp_front=(dist, idx, points1, points2, 8))
     return h.reshape(b, n, mlp[-1])
 
 

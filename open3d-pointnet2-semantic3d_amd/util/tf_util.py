@@ -197,6 +197,32 @@ def hip_mlp_chain(x2d, ws, bs, pool=0):
     return y
 
 
+def hip_fp_mlp_fused(dist, idx, points1, points2, ws, bs):
+    """[three_interpolate(points2) | points1] -> up to two dense layers in ONE kernel (pn2_fp_mlp_fused);
+    returns (b*n, w_last) or None when the library reports the configuration as unsupported."""
+    import ctypes
+    from .._lib import PN2_EUNSUP
+    require_cuda(dist, idx, points1, points2)
+    b, n, _ = dist.shape
+    m, c2 = points2.shape[1], points2.shape[2]
+    c1 = 0 if points1 is None else points1.shape[2]
+    p1 = None if points1 is None else points1.contiguous()
+    p2 = points2.contiguous()
+    L = len(ws)
+    widths = (ctypes.c_int * L)(*[w.shape[1] for w in ws])
+    wptrs = (ctypes.c_void_p * L)(*[w.data_ptr() for w in ws])
+    bptrs = (ctypes.c_void_p * L)(*[bb.data_ptr() for bb in bs])
+    y = torch.empty((b * n, ws[-1].shape[1]), dtype=torch.float32, device=dist.device)
+    with torch.cuda.device(dist.device):
+        rc = lib.pn2_fp_mlp_fused(b, n, m, c1, c2, ptr(dist.contiguous()), ptr(idx.contiguous()), ptr(p1), ptr(p2), L,
+                                  ctypes.cast(widths, ctypes.c_void_p), ctypes.cast(wptrs, ctypes.c_void_p),
+                                  ctypes.cast(bptrs, ctypes.c_void_p), ptr(y), stream_ptr())
+    if rc == PN2_EUNSUP:
+        return None
+    check(rc, "pn2_fp_mlp_fused")
+    return y
+
+
 def _batch_norm_train(x, bnv, bn_decay):
     beta, gamma, mean, var = bnv
     decay = 0.9 if bn_decay is None else float(bn_decay)  # tf_util.py:571

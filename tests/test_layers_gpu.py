@@ -356,6 +356,78 @@ def test_fp_module_chain_equals_per_layer_linear(pn2, oracle, cuda):
     close(b, ref)
 
 
+@pytest.mark.parametrize("b,n,m,c1,c2,widths", [(2, 1000, 128, 3, 128, [128, 128]), (1, 333, 64, 0, 64, [128]),
+                                                 (3, 256, 32, 5, 64, [64, 128]), (2, 512, 100, 2, 32, [64]),
+                                                 (1, 31, 3, 3, 8, [128, 128])])
+def test_fp_mlp_fused_vs_oracle(pn2, oracle, cuda, b, n, m, c1, c2, widths):
+    """pn2_fp_mlp_fused = FP front end + LDS-resident chain in one kernel, vs the oracle's
+    three_nn -> fp_weights -> three_interpolate -> concat -> fp64 dense layers."""
+    tfu = pn2.util.tf_util
+    rs = np.random.RandomState(b * 1000 + n)
+    xyz1 = rs.random_sample((b, n, 3)).astype(np.float32)
+    xyz2 = rs.random_sample((b, m, 3)).astype(np.float32)
+    xyz2[:, :3] = xyz1[:, :3]  # a few zero distances: the 1e-10 clamp path
+    p1 = rs.randn(b, n, c1).astype(np.float32) if c1 else None
+    p2 = rs.randn(b, m, c2).astype(np.float32)
+    dist, idx = oracle.three_nn(xyz1, xyz2)
+    x = oracle.three_interpolate(p2, idx, oracle.fp_weights(dist))
+    if c1:
+        x = np.concatenate([x, p1], axis=2)
+    ref = x.reshape(b * n, c1 + c2).astype(np.float64)
+    ws, bs = [], []
+    c = c1 + c2
+    for w_ in widths:
+        W = (rs.randn(c, w_) / np.sqrt(c)).astype(np.float32)
+        bb = (rs.randn(w_) * 0.1).astype(np.float32)
+        ws.append(T(W, cuda)); bs.append(T(bb, cuda))
+        ref = np.maximum(ref @ W.astype(np.float64) + bb, 0)
+        c = w_
+    y = tfu.hip_fp_mlp_fused(T(dist, cuda), T(idx, cuda), None if p1 is None else T(p1, cuda), T(p2, cuda), ws, bs)
+    assert y is not None
+    close(y.cpu().numpy(), ref)
+
+
+def test_fp_mlp_fused_rejects_unsupported(pn2, cuda):
+    import torch
+    tfu = pn2.util.tf_util
+    dist = torch.ones(1, 64, 3, device=cuda)
+    idx = torch.zeros(1, 64, 3, dtype=torch.int32, device=cuda)
+    p2 = torch.zeros(1, 8, 12, device=cuda)  # c2 % 8 != 0
+    assert tfu.hip_fp_mlp_fused(dist, idx, None, p2, [torch.zeros(12, 128, device=cuda)], [torch.zeros(128, device=cuda)]) is None
+    p2 = torch.zeros(1, 8, 16, device=cuda)
+    assert tfu.hip_fp_mlp_fused(dist, idx, None, p2, [torch.zeros(16, 256, device=cuda)], [torch.zeros(256, device=cuda)]) is None
+
+
+def test_fp_module_fused_front_end_full_size(pn2, oracle, cuda):
+    """FP4-shaped module at a row count that takes the fused path (b*n >= 65536): fused == unfused to fp32
+    rounding, and both within tolerance of the oracle."""
+    tfu, pu = pn2.util.tf_util, pn2.util.pointnet_util
+    rs = np.random.RandomState(9)
+    xyz1 = rs.random_sample((8, 8192, 3)).astype(np.float32)
+    xyz2 = xyz1[:, :256].copy()
+    p1 = rs.randn(8, 8192, 3).astype(np.float32)
+    p2 = rs.randn(8, 256, 128).astype(np.float32)
+    store = tfu.set_default_store(tfu.VariableStore(device=cuda, seed=33))
+    args = (T(xyz1, cuda), T(xyz2, cuda), T(p1, cuda), T(p2, cuda), [128, 128, 128], False, None)
+    pu.pointnet_fp_module(*args, scope="fp4")
+    randomize_bn(store, 34)
+    calls = []
+    pn2._lib.lib.trace = calls
+    try:
+        a = pu.pointnet_fp_module(*args, scope="fp4").cpu().numpy()
+    finally:
+        pn2._lib.lib.trace = None
+    assert "pn2_fp_mlp_fused" in [c[0] for c in calls] and "pn2_fp_interp_concat" not in [c[0] for c in calls]
+    pu.USE_FUSED_FP = False
+    try:
+        b = pu.pointnet_fp_module(*args, scope="fp4").cpu().numpy()
+    finally:
+        pu.USE_FUSED_FP = True
+    np.testing.assert_allclose(a, b, rtol=1e-5, atol=1e-5)
+    ref = oracle.fp_module(xyz1, xyz2, p1, p2, layer_dicts(store, "fp4", ["conv_0", "conv_1", "conv_2"]))
+    close(a, ref)
+
+
 def test_training_step_single_gpu(pn2, cuda):
     """Trainer.train_step: forward (batch-stat BN) + weighted CE + backward through the HIP gradient
     kernels + flat-bucket all-reduce (world 1) + Adam.  The loss must drop on a fixed batch."""
