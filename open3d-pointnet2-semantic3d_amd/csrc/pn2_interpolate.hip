@@ -5,9 +5,9 @@
 //
 // three_nn is exact float64 like the reference's KD-tree (tf_interpolate.cpp:20-28:
 // points widened to Eigen::Vector3d; FLANN L2<double> accumulates
-// ((0+dx*dx)+dy*dy)+dz*dz), brute force with an fp32 prefilter: the known points
-// of a batch element are staged in LDS and broadcast-read by a thread-per-query
-// scan.  Bound: VALU issue, not HBM.
+// ((0+dx*dx)+dy*dy)+dz*dz), brute force with a rigorous fp32 ranking prefilter
+// (3 FMAs per pair) and float64 evaluation of the few survivors.  Bound: VALU
+// issue, not HBM.
 #include <math.h>
 
 #include "pn2_common.h"
@@ -23,40 +23,68 @@ constexpr int kNnList = 32;    // per-query candidate list (LDS)
 
 struct NnPoint { float x, y, z; };
 
-__device__ __forceinline__ float nn_d32(float qx, float qy, float qz, const NnPoint& c) {
-    const float fx = qx - c.x, fy = qy - c.y, fz = qz - c.z;
-    return __builtin_fmaf(fz, fz, __builtin_fmaf(fy, fy, fx * fx));  // filter only: any rounding within the bound
-}
-
-// wave64 minimum of non-negative floats / +inf (as int bits), uniform result
-__device__ __forceinline__ int nn_wave_imin(int v) {
+// wave64 maximum of non-negative floats (as int bits), uniform result
+__device__ __forceinline__ int nn_wave_imax(int v) {
     asm volatile(
         "s_nop 1\n"
-        "v_min_i32_dpp %0, %0, %0 row_shr:1 row_mask:0xf bank_mask:0xf\n s_nop 1\n"
-        "v_min_i32_dpp %0, %0, %0 row_shr:2 row_mask:0xf bank_mask:0xf\n s_nop 1\n"
-        "v_min_i32_dpp %0, %0, %0 row_shr:4 row_mask:0xf bank_mask:0xf\n s_nop 1\n"
-        "v_min_i32_dpp %0, %0, %0 row_shr:8 row_mask:0xf bank_mask:0xf\n s_nop 1\n"
-        "v_min_i32_dpp %0, %0, %0 row_bcast:15 row_mask:0xa bank_mask:0xf\n s_nop 1\n"
-        "v_min_i32_dpp %0, %0, %0 row_bcast:31 row_mask:0xc bank_mask:0xf\n s_nop 1\n"
+        "v_max_i32_dpp %0, %0, %0 row_shr:1 row_mask:0xf bank_mask:0xf\n s_nop 1\n"
+        "v_max_i32_dpp %0, %0, %0 row_shr:2 row_mask:0xf bank_mask:0xf\n s_nop 1\n"
+        "v_max_i32_dpp %0, %0, %0 row_shr:4 row_mask:0xf bank_mask:0xf\n s_nop 1\n"
+        "v_max_i32_dpp %0, %0, %0 row_shr:8 row_mask:0xf bank_mask:0xf\n s_nop 1\n"
+        "v_max_i32_dpp %0, %0, %0 row_bcast:15 row_mask:0xa bank_mask:0xf\n s_nop 1\n"
+        "v_max_i32_dpp %0, %0, %0 row_bcast:31 row_mask:0xc bank_mask:0xf\n s_nop 1\n"
         : "+v"(v));
     return __builtin_amdgcn_readlane(v, 63);
 }
 
+// v_min_f32 without the canonicalising v_max the compiler adds for llvm.minnum (operands are FMA results /
+// +inf, never signalling NaNs)
+__device__ __forceinline__ float nn_fmin(float a, float b) {
+    float r;
+    asm("v_min_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+
+#ifndef PN2_NN_STAGES
+#define PN2_NN_STAGES 9  // tools/nn_stage_ab.py builds truncated variants (timing breakdown only)
+#endif
+
+// value of lane perm(l) inside every group of 8 lanes; CTRL: 0xB1 = l^1, 0x4E = l^2, 0x141 = 7-l
+template <int CTRL>
+__device__ __forceinline__ float nn_dpp(float v) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xf, 0xf, true));
+}
+
+// (t0<=t1<=t2) <- three smallest of the multiset {t0,t1,t2} U {b0,b1,b2} (both sorted)
+__device__ __forceinline__ void nn_merge3(float& t0, float& t1, float& t2, float b0, float b1, float b2) {
+    const float r0 = fminf(t0, b0);
+    const float r1 = fminf(fminf(t1, b1), fmaxf(t0, b0));
+    const float r2 = fminf(fminf(fminf(t2, b2), fmaxf(t0, b1)), fmaxf(t1, b0));
+    t0 = r0; t1 = r1; t2 = r2;
+}
+
 // Exact float64 3-NN (reference semantics: tf_interpolate.cpp:20-28 -> FLANN L2<double>,
-// ((0+dx*dx)+dy*dy)+dz*dz), organised like the ball query: one wave owns kNnQ queries, the known
-// points sit one per lane in registers (16 chunks = 1024 points at a time) and are shared by the
-// wave's queries.
-//   pass 1  fp32, branch-free: per query, every lane keeps the minimum d32 over its own candidates;
-//           the 3rd smallest of the 64 lane minima (three distinct candidates) bounds the 3rd-NN
-//           distance from above:  thr = t3 * (1 + 2e-6);
-//   pass 2  fp32: candidates with d32 <= thr (a handful) are appended in index order (ballot +
-//           mbcnt) to the query's list in LDS;
-//   refine  lane q walks the list of query q in float64 with a strict '<' insertion, so ties keep
-//           the lowest index exactly like a full ascending scan.
-// Filter safety: inputs are exact and all terms non-negative, so |d32 - d| <= 5*2^-24 * d; the three
-// bounding candidates have exact distances <= t3*(1+4e-7), hence every true top-3 candidate has
-// d32 <= t3*(1+8e-7) < thr.  A list overflow (> 32 candidates inside thr: heavy duplication) falls
-// back to a full float64 scan of that query by one lane.
+// ((0+dx*dx)+dy*dy)+dz*dz, ties -> lowest index).  One wave owns kNnQ queries; the known points sit
+// one per lane in registers (16 chunks = 1024 points at a time) and are shared by the wave's queries.
+//
+// The fp32 passes only RANK candidates, so they use the expanded form around a per-cloud centre o
+// (= known point 0):  with Q = fl(q - o), C = fl(c - o),
+//     s(q, c) = fma(-2Qx, Cx, fma(-2Qy, Cy, fma(-2Qz, Cz, |C|^2)))  ~  |q - c|^2 - |Q|^2
+// -- 3 FMAs per pair instead of 3 sub + mul + 2 fma.  Error bound (u = 2^-24, R = largest |component| of
+// any Q or C): centring moves the true distance by <= 24 u R^2, |C|^2 carries <= 9 u R^2, the three
+// FMAs <= 27 u R^2, so  | s + |Q|^2 - |q - c|^2 | <= E := 64 u R^2  for every pair.
+//   pass 1  every lane keeps min s over its own candidates; v3 = 3rd smallest of the 64 lane minima
+//           (three distinct candidates), found for all 8 queries at once by a transposed top-3 merge
+//           (LDS transpose, 8 lanes per query, 3 DPP merge steps).  The true 3rd-NN distance is
+//           <= v3 + |Q|^2 + E, so every true top-3 candidate (ties included) has s <= v3 + 2E;
+//           thr = v3 + 3E absorbs the rounding of the addition.
+//   pass 2  the few lanes whose minimum is inside thr re-test their own candidates and append the hits
+//           (s <= thr, a handful per query) to the query's list in LDS, in arbitrary order;
+//           together with their exact float64 distance (raw coordinates re-read), in arbitrary order;
+//   refine  8 lanes per query rank the listed candidates by (distance, index); ranks 0..2 are written --
+//           exactly what a strict '<' insertion over a full ascending scan yields (ties -> lowest index).
+// A list overflow (> 32 candidates inside thr: heavy duplication, or a dynamic range (extent/spacing)^2
+// approaching 2^24 that makes E useless) falls back to a full float64 scan of that query by one lane.
 // kNnChunks = candidate chunks (of 64) held in registers at a time (16 -> 1024 points; small known
 // sets instantiate 4 or 1 so that the unrolled chunk loops do no dead work).
 template <int kNnChunks>
@@ -65,6 +93,11 @@ three_nn_kernel(int n, int m, const float* __restrict__ xyz1_all,
                 const float* __restrict__ xyz2_all, float* __restrict__ dist_all,
                 int* __restrict__ idx_all) {
     __shared__ int slist[kNnWaves * kNnQ * kNnList];
+    __shared__ double sdist[kNnWaves * kNnQ * kNnList];
+    __shared__ __attribute__((aligned(16))) float smin[kNnWaves * kNnQ * 64];
+    __shared__ __attribute__((aligned(16))) float sqp[kNnWaves * kNnQ * 4];  // (-2Qx, -2Qy, -2Qz, thr) per query
+    __shared__ __attribute__((aligned(16))) float sqr[kNnWaves * kNnQ * 4];  // raw query coordinates
+    __shared__ int scnt[kNnWaves * kNnQ];
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int bi = blockIdx.y;
@@ -74,131 +107,216 @@ three_nn_kernel(int n, int m, const float* __restrict__ xyz1_all,
     const float* __restrict__ xyz2 = xyz2_all + (size_t)bi * m * 3;
     const NnPoint* __restrict__ cand = reinterpret_cast<const NnPoint*>(xyz2);
     int* wl = slist + wave * kNnQ * kNnList;
+    double* wd = sdist + wave * kNnQ * kNnList;
+    float* wm = smin + wave * kNnQ * 64;
+    float* wq = sqp + wave * kNnQ * 4;
+    float* wr = sqr + wave * kNnQ * 4;
+    int* wc = scnt + wave * kNnQ;
 
-    float qx[kNnQ], qy[kNnQ], qz[kNnQ];
+    const float ox = xyz2[0], oy = xyz2[1], oz = xyz2[2];
+    float ax[kNnQ], ay[kNnQ], az[kNnQ];
+    float rq = 0.f;
 #pragma unroll
     for (int q = 0; q < kNnQ; ++q) {
         const int jq = q0 + q < n ? q0 + q : n - 1;
-        qx[q] = __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(xyz1[jq * 3 + 0])));
-        qy[q] = __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(xyz1[jq * 3 + 1])));
-        qz[q] = __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(xyz1[jq * 3 + 2])));
+        const float rx = __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(xyz1[jq * 3 + 0])));
+        const float ry = __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(xyz1[jq * 3 + 1])));
+        const float rz = __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(xyz1[jq * 3 + 2])));
+        if (lane == 0) *reinterpret_cast<f32x4*>(wr + q * 4) = f32x4{rx, ry, rz, 0.f};
+        const float x = rx - ox, y = ry - oy, z = rz - oz;
+        ax[q] = -2.0f * x; ay[q] = -2.0f * y; az[q] = -2.0f * z;  // exact scalings
+        rq = fmaxf(rq, fmaxf(fabsf(x), fmaxf(fabsf(y), fabsf(z))));
     }
     const int last = m - 1;
     const int nblk = (m + 64 * kNnChunks - 1) / (64 * kNnChunks);
-    NnPoint c[kNnChunks];
+    float cx[kNnChunks], cy[kNnChunks], cz[kNnChunks], cc[kNnChunks];
+    float rc = 0.f;  // largest |component| of this lane's centred candidates
     auto load_block = [&](int blk) {
 #pragma unroll
         for (int t = 0; t < kNnChunks; ++t) {
             const int k = (blk * kNnChunks + t) * 64 + lane;
-            c[t] = cand[k < last ? k : last];  // clamped; out-of-range lanes are masked by index below
+            const NnPoint p = cand[k < last ? k : last];  // clamped; out-of-range lanes are masked by index below
+            const float x = p.x - ox, y = p.y - oy, z = p.z - oz;
+            cx[t] = x; cy[t] = y; cz[t] = z;
+            cc[t] = __builtin_fmaf(z, z, __builtin_fmaf(y, y, x * x));
+            rc = fmaxf(rc, fmaxf(fabsf(x), fmaxf(fabsf(y), fabsf(z))));
         }
+    };
+    auto rank = [&](int q, int t) {
+        return __builtin_fmaf(ax[q], cx[t], __builtin_fmaf(ay[q], cy[t], __builtin_fmaf(az[q], cz[t], cc[t])));
     };
 
     // ---- pass 1 -------------------------------------------------------------------------------
-    int mn[kNnQ];  // per-lane minimum d32 as int bits (distances are >= +0: int order == float order)
+    float mn[kNnQ];
 #pragma unroll
-    for (int q = 0; q < kNnQ; ++q) mn[q] = 0x7F800000;
+    for (int q = 0; q < kNnQ; ++q) mn[q] = INFINITY;
     for (int blk = 0; blk < nblk; ++blk) {
         load_block(blk);
 #pragma unroll
         for (int t = 0; t < kNnChunks; ++t) {
             const int k = (blk * kNnChunks + t) * 64 + lane;
             const int cbase = (blk * kNnChunks + t) * 64;
-            if (cbase + 64 <= m) {  // full chunk (wave-uniform): no masking, integer min on the bits
+            if (cbase + 64 <= m) {  // full chunk (wave-uniform): no masking
 #pragma unroll
-                for (int q = 0; q < kNnQ; ++q) {
-                    const int di = __float_as_int(nn_d32(qx[q], qy[q], qz[q], c[t]));
-                    mn[q] = di < mn[q] ? di : mn[q];
-                }
+                for (int q = 0; q < kNnQ; ++q) mn[q] = nn_fmin(mn[q], rank(q, t));
             } else if (cbase < m) {  // partial last chunk: lanes past m re-read point m-1 and must not count
                 const bool valid = k < m;
 #pragma unroll
-                for (int q = 0; q < kNnQ; ++q) {
-                    const int di = valid ? __float_as_int(nn_d32(qx[q], qy[q], qz[q], c[t])) : 0x7F800000;
-                    mn[q] = di < mn[q] ? di : mn[q];
-                }
+                for (int q = 0; q < kNnQ; ++q) mn[q] = nn_fmin(mn[q], valid ? rank(q, t) : INFINITY);
             }
         }
+    }
+    if constexpr (PN2_NN_STAGES < 2) {
+        float acc = 0.f;
+#pragma unroll
+        for (int q = 0; q < kNnQ; ++q) acc += mn[q];
+        if (acc == 12345.f) dist_all[lane] = acc;
+        return;
+    }
+    // E = 64 u R^2 (rounded up)
+    const float R = fmaxf(__int_as_float(nn_wave_imax(__float_as_int(rc))), rq);
+    const float E3 = R * R * (3.0f * 64.0f * 5.9604645e-8f * 1.001f);
+    // transposed selection: lane (g = lane>>3, part = lane&7) takes 8 of query g's 64 lane minima
+#pragma unroll
+    for (int q = 0; q < kNnQ; ++q) wm[q * 64 + lane] = mn[q];
+    float t0, t1, t2;
+    {
+        const int g = lane >> 3, part = lane & 7;
+        const f32x4 v0 = *reinterpret_cast<const f32x4*>(wm + g * 64 + part * 8);
+        const f32x4 v1 = *reinterpret_cast<const f32x4*>(wm + g * 64 + part * 8 + 4);
+        t0 = fminf(fminf(v0[0], v0[1]), v0[2]);
+        t2 = fmaxf(fmaxf(v0[0], v0[1]), v0[2]);
+        t1 = __builtin_amdgcn_fmed3f(v0[0], v0[1], v0[2]);
+        const float rest[5] = {v0[3], v1[0], v1[1], v1[2], v1[3]};
+#pragma unroll
+        for (int i = 0; i < 5; ++i) {
+            const float d = rest[i];
+            const float n0 = fminf(t0, d);
+            const float n1 = __builtin_amdgcn_fmed3f(t0, t1, d);
+            const float n2 = __builtin_amdgcn_fmed3f(t1, t2, d);
+            t0 = n0; t1 = n1; t2 = n2;
+        }
+        nn_merge3(t0, t1, t2, nn_dpp<0xB1>(t0), nn_dpp<0xB1>(t1), nn_dpp<0xB1>(t2));
+        nn_merge3(t0, t1, t2, nn_dpp<0x4E>(t0), nn_dpp<0x4E>(t1), nn_dpp<0x4E>(t2));
+        nn_merge3(t0, t1, t2, nn_dpp<0x141>(t0), nn_dpp<0x141>(t1), nn_dpp<0x141>(t2));
     }
     float thr[kNnQ];
 #pragma unroll
-    for (int q = 0; q < kNnQ; ++q) {
-        int v = mn[q];
-        int t3 = 0;
-#pragma unroll
-        for (int r = 0; r < 3; ++r) {
-            t3 = nn_wave_imin(v);
-            const unsigned long long eq = __ballot(v == t3);
-            const int first = __ffsll((long long)eq) - 1;
-            if (lane == first) v = 0x7F800000;  // drop exactly one holder of the current minimum
-        }
-        thr[q] = __int_as_float(t3) * (1.0f + 2e-6f);  // +inf stays +inf
-    }
+    for (int q = 0; q < kNnQ; ++q)
+        thr[q] = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(t2), q * 8)) + E3;  // +inf stays +inf
 
-    // ---- pass 2: collect ----------------------------------------------------------------------
-    int cnt[kNnQ];
+    if constexpr (PN2_NN_STAGES < 3) {
+        float acc = 0.f;
 #pragma unroll
-    for (int q = 0; q < kNnQ; ++q) cnt[q] = 0;
+        for (int q = 0; q < kNnQ; ++q) acc += thr[q];
+        if (acc == 12345.f) dist_all[lane] = acc;
+        return;
+    }
+    // ---- pass 2: collect ----------------------------------------------------------------------
+    // Only lanes whose pass-1 minimum is inside thr hold a candidate of that query (typically 3-5 of
+    // the 64 lanes), so instead of re-testing every (query, chunk) pair wave-wide, every lane walks its
+    // own short work list of queries (bit q of `todo`), re-evaluates s for its <= kNnChunks candidates
+    // with the query's parameters fetched from LDS, and appends the hits through an LDS counter.  The
+    // list order is arbitrary; the refine step orders by (distance, index).
+#pragma unroll
+    for (int q = 0; q < kNnQ; ++q) {
+        if (lane == 0) {
+            *reinterpret_cast<f32x4*>(wq + q * 4) = f32x4{ax[q], ay[q], az[q], thr[q]};
+            wc[q] = 0;
+        }
+    }
+    unsigned todo = 0u;
+#pragma unroll
+    for (int q = 0; q < kNnQ; ++q) todo |= (mn[q] <= thr[q] ? 1u : 0u) << q;
     for (int blk = 0; blk < nblk; ++blk) {
         if (nblk > 1) load_block(blk);  // single block: still resident from pass 1
+        // chunks t < nvalid of this block hold a real candidate for this lane (k < m)
+        int nvalid = (m - lane - blk * kNnChunks * 64 + 63) >> 6;
+        nvalid = nvalid < 0 ? 0 : (nvalid > kNnChunks ? kNnChunks : nvalid);
+        const unsigned vmask = (1u << nvalid) - 1u;
+        unsigned td = todo;
+        while (td != 0u) {
+            const int q = __ffs(td) - 1;
+            td &= td - 1u;
+            const f32x4 qp = *reinterpret_cast<const f32x4*>(wq + q * 4);
+            unsigned hm = 0u;
 #pragma unroll
-        for (int t = 0; t < kNnChunks; ++t) {
-            const int k = (blk * kNnChunks + t) * 64 + lane;
-            const int cbase = (blk * kNnChunks + t) * 64;
-            if (cbase < m) {
-                const bool tail = cbase + 64 > m;  // wave-uniform
-                unsigned long long mk[kNnQ];
-                unsigned long long any = 0ull;
-#pragma unroll
-                for (int q = 0; q < kNnQ; ++q) {
-                    bool hit = nn_d32(qx[q], qy[q], qz[q], c[t]) <= thr[q];
-                    if (tail) hit = hit && (k < m);
-                    mk[q] = __ballot(hit);
-                    any |= mk[q];
-                }
-                if (any != 0ull) {  // one branch per chunk (scalar ops are expensive, see pn2_grouping.hip)
-#pragma unroll
-                    for (int q = 0; q < kNnQ; ++q) {
-                        const unsigned long long mask = mk[q];
-                        if (mask != 0ull) {
-                            const int pos = cnt[q] + (int)__builtin_amdgcn_mbcnt_hi(
-                                                         (unsigned)(mask >> 32),
-                                                         __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0u));
-                            if (((mask >> lane) & 1ull) && pos < kNnList) wl[q * kNnList + pos] = k;
-                            cnt[q] += __popcll(mask);  // may exceed kNnList: overflow marker
-                        }
-                    }
+            for (int t = 0; t < kNnChunks; ++t) {
+                const float sv = __builtin_fmaf(qp[0], cx[t], __builtin_fmaf(qp[1], cy[t], __builtin_fmaf(qp[2], cz[t], cc[t])));
+                hm |= (sv <= qp[3] ? 1u : 0u) << t;
+            }
+            hm &= vmask;
+            while (hm != 0u) {
+                const int t = __ffs(hm) - 1;
+                hm &= hm - 1u;
+                const int kk = (blk * kNnChunks + t) * 64 + lane;
+                const int pos = atomicAdd(&wc[q], 1);  // may exceed kNnList: overflow marker
+                if (pos < kNnList) {
+                    // exact float64 distance from the RAW coordinates (the centred ones are rounded)
+                    const f32x4 qr = *reinterpret_cast<const f32x4*>(wr + q * 4);
+                    const double dx = (double)qr[0] - (double)xyz2[kk * 3 + 0];
+                    const double dy = (double)qr[1] - (double)xyz2[kk * 3 + 1];
+                    const double dz = (double)qr[2] - (double)xyz2[kk * 3 + 2];
+                    wl[q * kNnList + pos] = kk;
+                    wd[q * kNnList + pos] = (dx * dx + dy * dy) + dz * dz;  // contraction is off
                 }
             }
         }
     }
-
-    // ---- refine: lane q owns query q ----------------------------------------------------------
-    int myc = 0;
+    int cnt[kNnQ];
 #pragma unroll
-    for (int q = 0; q < kNnQ; ++q) myc = lane == q ? cnt[q] : myc;
-    if (lane < kNnQ && q0 + lane < n) {
-        const int jq = q0 + lane;
-        const double dqx = xyz1[jq * 3 + 0], dqy = xyz1[jq * 3 + 1], dqz = xyz1[jq * 3 + 2];
-        double b1 = INFINITY, b2 = INFINITY, b3 = INFINITY;
-        int i1 = 0, i2 = 0, i3 = 0;
-        const bool overflow = myc > kNnList;
-        const int ne = overflow ? m : myc;
-        for (int e = 0; e < ne; ++e) {
-            const int kk = overflow ? e : wl[lane * kNnList + e];
-            const double dx = dqx - (double)xyz2[kk * 3 + 0];
-            const double dy = dqy - (double)xyz2[kk * 3 + 1];
-            const double dz = dqz - (double)xyz2[kk * 3 + 2];
-            const double d = (dx * dx + dy * dy) + dz * dz;  // contraction is off
-            if (d < b3) {  // strict: ascending index order keeps the lowest index on ties
-                if (d < b1) { b3 = b2; i3 = i2; b2 = b1; i2 = i1; b1 = d; i1 = kk; }
-                else if (d < b2) { b3 = b2; i3 = i2; b2 = d; i2 = kk; }
-                else { b3 = d; i3 = kk; }
+    for (int q = 0; q < kNnQ; ++q) cnt[q] = __builtin_amdgcn_readfirstlane(wc[q]);
+
+    if constexpr (PN2_NN_STAGES < 4) {
+        int acc = 0;
+#pragma unroll
+        for (int q = 0; q < kNnQ; ++q) acc += cnt[q];
+        if (acc == 12345) idx_all[lane] = acc + wl[lane];
+        return;
+    }
+    // ---- refine: 8 lanes per query; every listed candidate is ranked by (distance, index) ---------
+    // rank = number of listed candidates that precede it; ranks 0..2 are the answer -- exactly what a
+    // strict '<' insertion over a full ascending scan yields (ties keep the lowest index).  Indices are
+    // distinct, so ranks are distinct; the three candidates that defined v3 are always listed.
+    {
+        const int g = lane >> 3, part = lane & 7;
+        int cg = 0;
+#pragma unroll
+        for (int q = 0; q < kNnQ; ++q) cg = g == q ? cnt[q] : cg;
+        if (q0 + g < n) {
+            const size_t o = ((size_t)bi * n + q0 + g) * 3;
+            if (cg <= kNnList) {
+                for (int e = part; e < cg; e += 8) {
+                    const double d = wd[g * kNnList + e];
+                    const int kk = wl[g * kNnList + e];
+                    int rank = 0;
+                    for (int j = 0; j < cg; ++j) {
+                        const double dj = wd[g * kNnList + j];
+                        const int kj = wl[g * kNnList + j];
+                        rank += (dj < d || (dj == d && kj < kk)) ? 1 : 0;
+                    }
+                    if (rank < 3) { dist_all[o + rank] = (float)d; idx_all[o + rank] = kk; }
+                }
+            } else if (part == 0) {  // overflow: full float64 scan in ascending index order
+                const int jq = q0 + g;
+                const double dqx = xyz1[jq * 3 + 0], dqy = xyz1[jq * 3 + 1], dqz = xyz1[jq * 3 + 2];
+                double b1 = INFINITY, b2 = INFINITY, b3 = INFINITY;
+                int i1 = 0, i2 = 0, i3 = 0;
+                for (int kk = 0; kk < m; ++kk) {
+                    const double dx = dqx - (double)xyz2[kk * 3 + 0];
+                    const double dy = dqy - (double)xyz2[kk * 3 + 1];
+                    const double dz = dqz - (double)xyz2[kk * 3 + 2];
+                    const double d = (dx * dx + dy * dy) + dz * dz;  // contraction is off
+                    if (d < b3) {  // strict: ties keep the lowest index
+                        if (d < b1) { b3 = b2; i3 = i2; b2 = b1; i2 = i1; b1 = d; i1 = kk; }
+                        else if (d < b2) { b3 = b2; i3 = i2; b2 = d; i2 = kk; }
+                        else { b3 = d; i3 = kk; }
+                    }
+                }
+                dist_all[o + 0] = (float)b1; dist_all[o + 1] = (float)b2; dist_all[o + 2] = (float)b3;
+                idx_all[o + 0] = i1; idx_all[o + 1] = i2; idx_all[o + 2] = i3;
             }
         }
-        const size_t o = ((size_t)bi * n + jq) * 3;
-        dist_all[o + 0] = (float)b1; dist_all[o + 1] = (float)b2; dist_all[o + 2] = (float)b3;
-        idx_all[o + 0] = i1; idx_all[o + 1] = i2; idx_all[o + 2] = i3;
     }
 }
 

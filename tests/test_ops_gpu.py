@@ -272,6 +272,46 @@ def test_three_nn_ties_lowest_index(pn2, oracle, cuda):
     assert np.array_equal(i.cpu().numpy(), ri) and np.array_equal(d.cpu().numpy(), rd)
 
 
+@pytest.mark.parametrize("case", ["offset_1000", "offset_1e5", "range_1e4", "duplicates", "scene", "collinear", "tiny_spacing"])
+def test_three_nn_filter_adversarial(pn2, oracle, cuda, case):
+    """The fp32 ranking filter of three_nn (expanded form around a centre, margin 64 u R^2) must never drop
+    a true neighbour: far-from-origin clouds, huge extent/spacing ratios (margin useless -> the list
+    overflows -> float64 fallback scan), exact duplicates (ties -> lowest index), degenerate geometry."""
+    rs = np.random.RandomState(len(case))
+    n, m = 700, 300
+    if case == "offset_1000":
+        r = rs.rand(2, m, 3).astype(np.float32) + np.float32(1000.0)
+        a = rs.rand(2, n, 3).astype(np.float32) + np.float32(1000.0)
+    elif case == "offset_1e5":  # spacing close to the fp32 grid at 1e5: massive ties
+        r = (rs.rand(2, m, 3) * 4 + 1e5).astype(np.float32)
+        a = (rs.rand(2, n, 3) * 4 + 1e5).astype(np.float32)
+    elif case == "range_1e4":  # a tight cluster plus far outliers: R^2 u >> cluster distances
+        r = (rs.rand(2, m, 3) * 1e-3).astype(np.float32)
+        r[:, ::50] += np.float32(3000.0)
+        a = (rs.rand(2, n, 3) * 1e-3).astype(np.float32)
+        a[:, ::70] -= np.float32(2000.0)
+    elif case == "duplicates":
+        base = rs.rand(2, 10, 3).astype(np.float32)
+        r = base[:, rs.randint(0, 10, m)]  # every known point repeated ~30 times
+        a = base[:, rs.randint(0, 10, n)] + (rs.rand(2, n, 3) < 0.5).astype(np.float32) * np.float32(0.25)
+    elif case == "scene":
+        a = s_scene(3, 2, n)[..., :3]
+        r = a[:, :m].copy()
+    elif case == "collinear":
+        t = rs.rand(2, m, 1).astype(np.float32)
+        r = np.concatenate([t, t * np.float32(2), t * np.float32(-1)], 2)
+        t = rs.rand(2, n, 1).astype(np.float32)
+        a = np.concatenate([t, t * np.float32(2), t * np.float32(-1)], 2)
+    else:  # tiny_spacing: denormal-scale differences around a large value
+        r = (np.float32(8.0) + rs.randint(0, 64, (2, m, 3)).astype(np.float32) * np.float32(2.0 ** -20)).astype(np.float32)
+        a = (np.float32(8.0) + rs.randint(0, 64, (2, n, 3)).astype(np.float32) * np.float32(2.0 ** -20)).astype(np.float32)
+    a, r = np.ascontiguousarray(a, np.float32), np.ascontiguousarray(r, np.float32)
+    d, i = pn2.three_nn(T(a, cuda), T(r, cuda))
+    rd, ri = oracle.three_nn(a, r)
+    assert np.array_equal(i.cpu().numpy(), ri)
+    assert np.array_equal(d.cpu().numpy(), rd)
+
+
 @pytest.mark.parametrize("c", [1, 5, 16, 64, 128, 131])
 def test_three_interpolate_bit_exact_and_grad(pn2, oracle, cuda, c):
     import torch
