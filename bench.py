@@ -260,6 +260,8 @@ def main():
     ap.add_argument("--one-stream", action="store_true", help="do not overlap the geometry chain with the MLP chain")
     ap.add_argument("--pipeline", type=int, default=4, help="independent batches in flight (graphs replayed round-robin)")
     ap.add_argument("--no-north-star", action="store_true")
+    ap.add_argument("--debug-set", action="append", default=[], metavar="WHAT=VALUE",
+                    help="tuning hook: pn2_debug_set(what, value) before the run (A/B experiments)")
     ap.add_argument("--fp-front", choices=("auto", "fused", "unfused"), default="auto",
                     help="FP front end inside the first FP4 MLP kernel (pn2_fp_mlp_fused: lowest single-batch latency) "
                          "or materialised by pn2_fp_interp_concat (measured 3%% better throughput with several batches "
@@ -299,6 +301,9 @@ def main():
             if k.endswith("moving_variance"):
                 v.copy_((torch.rand(v.shape, generator=g) + 0.5).to(dev))
 
+    for kv in args.debug_set:
+        what, value = kv.split("=")
+        assert pn2._lib._raw.pn2_debug_set(int(what), int(value)) == 0
     fused_fp = args.fp_front == "fused" or (args.fp_front == "auto" and (args.eager or args.pipeline <= 1))
     pn2.util.pointnet_util.USE_FUSED_FP = fused_fp
 

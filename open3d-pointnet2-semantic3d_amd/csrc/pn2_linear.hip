@@ -20,9 +20,19 @@
 //   * B tile: k-major [32][BN(+4)], read one float per lane per step (lane -> consecutive cols).
 // Because a wave's 32 rows are exactly one K=32 neighbourhood, the max-pool is an in-register max
 // over the 16 accumulator rows + one cross-half exchange.
+#include <type_traits>
+
 #include "pn2_common.h"
 
 namespace {
+
+template <int U, int N, class F>
+__device__ __forceinline__ void static_for(F& f) {
+    if constexpr (U < N) {
+        f(std::integral_constant<int, U>{});
+        static_for<U + 1, N>(f);
+    }
+}
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -37,7 +47,9 @@ __device__ __forceinline__ void atomic_max_nonneg(float* addr, float v) {
 
 // WK = 2 splits every k-tile between two waves of the same output tile (intra-workgroup split-K,
 // reduced through LDS before the epilogue): small-row layers then launch twice as many workgroups.
-template <int WM, int WN, int NT, bool VEC_A, int WK = 1>
+// ST = register prefetch depth: the global loads of k-tile kt+ST-1 are issued under the MFMAs of tile
+// kt (ST = 2: one tile ahead; default 3, measured best: profiles/r01_linear_prefetch_depth.txt).
+template <int WM, int WN, int NT, bool VEC_A, int WK = 1, int ST = 2>
 __global__ void __launch_bounds__(256)
 linear_kernel(int rows, int cin, int cout, const float* __restrict__ x,
               const float* __restrict__ w, const float* __restrict__ bias, int relu, int pool,
@@ -72,22 +84,27 @@ linear_kernel(int rows, int cin, int cout, const float* __restrict__ x,
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[nt][r] = 0.f;
 
-    f32x4 a_v[VEC_A ? A_PER_T : 1];
-    float a_s[VEC_A ? 1 : A_SC];
-    f32x4 b_v[B_PER_T];
+    f32x4 a_vs[ST][VEC_A ? A_PER_T : 1];
+    float a_ss[ST][VEC_A ? 1 : A_SC];
+    f32x4 b_vs[ST][B_PER_T];
 
-    auto load_tile = [&](int kt) {
+    auto load_tile = [&](int kt, f32x4 (&a_v)[VEC_A ? A_PER_T : 1], float (&a_s)[VEC_A ? 1 : A_SC],
+                         f32x4 (&b_v)[B_PER_T]) {
+        // Every load is unconditional (addresses clamped into the buffers, out-of-range elements zeroed
+        // afterwards): straight-line loads let the compiler use counted s_waitcnt vmcnt(N), which is what
+        // keeps ST-1 tiles in flight; loads under a divergent branch force vmcnt(0).
         const int k0 = kt * kBK;
+        const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
         if constexpr (VEC_A) {
 #pragma unroll
             for (int i = 0; i < A_PER_T; ++i) {
                 const int f = tid + 256 * i;
                 const int r = f >> 3, k4 = f & 7;
                 const int gr = row0 + r, gk = k0 + k4 * 4;
-                f32x4 v = {0.f, 0.f, 0.f, 0.f};
-                if (f < A_F4 && gr < rows && gk < cin)
-                    v = *reinterpret_cast<const f32x4*>(x + (size_t)gr * cin + gk);
-                a_v[i] = v;
+                const int grc = gr < rows ? gr : rows - 1;
+                const int gkc = gk < cin ? gk : cin - 4;  // VEC_A: cin % 4 == 0
+                const f32x4 v = *reinterpret_cast<const f32x4*>(x + (size_t)grc * cin + gkc);
+                a_v[i] = (gr < rows && gk < cin) ? v : z4;
             }
         } else {
 #pragma unroll
@@ -95,20 +112,23 @@ linear_kernel(int rows, int cin, int cout, const float* __restrict__ x,
                 const int e = tid + 256 * i;
                 const int k = e & 31, r = e >> 5;
                 const int gr = row0 + r, gk = k0 + k;
-                a_s[i] = (r < BM && gr < rows && gk < cin) ? x[(size_t)gr * cin + gk] : 0.f;
+                const int grc = gr < rows ? gr : rows - 1;
+                const int gkc = gk < cin ? gk : cin - 1;
+                const float v = x[(size_t)grc * cin + gkc];
+                a_s[i] = (r < BM && gr < rows && gk < cin) ? v : 0.f;
             }
         }
 #pragma unroll
         for (int i = 0; i < B_PER_T; ++i) {
             const int f = tid + 256 * i;
             const int k = f / (BN / 4), n4 = f % (BN / 4);
-            f32x4 v = {0.f, 0.f, 0.f, 0.f};
-            if (f < B_F4 && k0 + k < cin)
-                v = *reinterpret_cast<const f32x4*>(w + (size_t)(k0 + k) * cout + col0 + n4 * 4);
-            b_v[i] = v;
+            const int kc = k0 + k < cin ? k0 + k : cin - 1;
+            const f32x4 v = *reinterpret_cast<const f32x4*>(w + (size_t)kc * cout + col0 + n4 * 4);
+            b_v[i] = (k0 + k < cin) ? v : z4;
         }
     };
-    auto store_tile = [&]() {
+    auto store_tile = [&](const f32x4 (&a_v)[VEC_A ? A_PER_T : 1], const float (&a_s)[VEC_A ? 1 : A_SC],
+                          const f32x4 (&b_v)[B_PER_T]) {
         if constexpr (VEC_A) {
 #pragma unroll
             for (int i = 0; i < A_PER_T; ++i) {
@@ -133,12 +153,17 @@ linear_kernel(int rows, int cin, int cout, const float* __restrict__ x,
     };
 
     const int nkt = (cin + kBK - 1) / kBK;
-    load_tile(0);
-    for (int kt = 0; kt < nkt; ++kt) {
+#pragma unroll
+    for (int u = 0; u < ST - 1; ++u) load_tile(u < nkt ? u : nkt - 1, a_vs[u], a_ss[u], b_vs[u]);
+    auto tile_step = [&](auto uc, int kt) {  // statically unrolled: the prefetch ring slots are compile-time
+        constexpr int u = decltype(uc)::value;
         __syncthreads();  // previous tile fully consumed
-        store_tile();
+        store_tile(a_vs[u], a_ss[u], b_vs[u]);
         __syncthreads();
-        if (kt + 1 < nkt) load_tile(kt + 1);  // in flight under the MFMAs below
+        constexpr int un = (u + ST - 1) % ST;
+        // always issued (tile index clamped: the last ST-1 prefetches re-read the last tile and are
+        // never stored) so that the loop body stays branch-free around the loads
+        load_tile(kt + ST - 1 < nkt ? kt + ST - 1 : nkt - 1, a_vs[un], a_ss[un], b_vs[un]);
         const float* as = As + (wm * 32 + l31) * kAS + 4 * half;
         const float* bs = Bs + (4 * half) * BS + wn * (NT * 32) + l31;
 #pragma unroll
@@ -154,6 +179,17 @@ linear_kernel(int rows, int cin, int cout, const float* __restrict__ x,
                 }
             }
         }
+    };
+    int kt0 = 0;
+    for (; kt0 + ST <= nkt; kt0 += ST) {  // full groups: no branches between the counted waits
+        auto step = [&](auto uc) { tile_step(uc, kt0 + decltype(uc)::value); };
+        static_for<0, ST>(step);
+    }
+    {
+        auto step = [&](auto uc) {
+            if (kt0 + decltype(uc)::value < nkt) tile_step(uc, kt0 + decltype(uc)::value);
+        };
+        static_for<0, ST - 1>(step);
     }
 
     if constexpr (WK == 2) {  // reduce the two k-halves through LDS (B tile memory is free now)
@@ -216,14 +252,14 @@ linear_kernel(int rows, int cin, int cout, const float* __restrict__ x,
     }
 }
 
-template <int WM, int WN, int NT, int WK = 1>
+template <int WM, int WN, int NT, int WK = 1, int ST = 2>
 int launch_linear(int rows, int cin, int cout, const float* x, const float* w, const float* bias,
                   int relu, int pool, float* y, hipStream_t st) {
     constexpr int BM = 32 * WM, BN = 32 * NT * WN;
     dim3 grid((rows + BM - 1) / BM, cout / BN);
     const bool vec_a = (cin % 4 == 0) && ((uintptr_t)x % 16 == 0);
-    if (vec_a) linear_kernel<WM, WN, NT, true, WK><<<grid, 256, 0, st>>>(rows, cin, cout, x, w, bias, relu, pool, y);
-    else linear_kernel<WM, WN, NT, false, WK><<<grid, 256, 0, st>>>(rows, cin, cout, x, w, bias, relu, pool, y);
+    if (vec_a) linear_kernel<WM, WN, NT, true, WK, ST><<<grid, 256, 0, st>>>(rows, cin, cout, x, w, bias, relu, pool, y);
+    else linear_kernel<WM, WN, NT, false, WK, ST><<<grid, 256, 0, st>>>(rows, cin, cout, x, w, bias, relu, pool, y);
     PN2_RETURN_IF_LAUNCH_FAILED();
     return PN2_OK;
 }
@@ -255,6 +291,8 @@ sa_group_concat_kernel(int n, int m, int nsample, int c, const float* __restrict
 
 }  // namespace
 
+int g_lin_stages = 3;  // tuning hook (pn2_debug_set(5, v)): register prefetch depth of linear_kernel
+
 extern "C" int pn2_linear(int rows, int cin, int cout, const float* x, const float* w,
                           const float* bias, int relu, int pool, float* y, void* stream) {
     if (rows <= 0 || cin <= 0 || cout <= 0) return PN2_EINVAL;
@@ -271,17 +309,27 @@ extern "C" int pn2_linear(int rows, int cin, int cout, const float* x, const flo
             if (e != hipSuccess) return (int)e;
         }
     }
+#define PN2_LIN(WM_, WN_, NT_, WK_)                                                                          \
+    (st_depth >= 4 ? launch_linear<WM_, WN_, NT_, WK_, 4>(rows, cin, cout, x, w, bias, relu, pool, y, st)      \
+     : st_depth == 3 ? launch_linear<WM_, WN_, NT_, WK_, 3>(rows, cin, cout, x, w, bias, relu, pool, y, st)    \
+                     : launch_linear<WM_, WN_, NT_, WK_, 2>(rows, cin, cout, x, w, bias, relu, pool, y, st))
+    const int st_depth = g_lin_stages;
     if (cout % 128 == 0) {
         // largest tile that still yields >= 2 blocks per CU; small problems get 32-row blocks
         const long long cb = cout / 128;
-        if (((rows + 127) / 128) * cb >= 512) return launch_linear<4, 1, 4>(rows, cin, cout, x, w, bias, relu, pool, y, st);
-        if (((rows + 63) / 64) * cb >= 512) return launch_linear<2, 2, 2>(rows, cin, cout, x, w, bias, relu, pool, y, st);
-        if (((rows + 31) / 32) * cb >= 256 || cin < 128)
-            return launch_linear<1, 4, 1>(rows, cin, cout, x, w, bias, relu, pool, y, st);
-        return launch_linear<1, 2, 1, 2>(rows, cin, cout, x, w, bias, relu, pool, y, st);  // few rows: 32x64 tiles, split-K in the block
+        if (((rows + 127) / 128) * cb >= 512) return PN2_LIN(4, 1, 4, 1);
+        if (((rows + 63) / 64) * cb >= 512) return PN2_LIN(2, 2, 2, 1);
+        if (((rows + 31) / 32) * cb >= 256 || cin < 128) return PN2_LIN(1, 4, 1, 1);
+        return PN2_LIN(1, 2, 1, 2);  // few rows: 32x64 tiles, split-K in the block
     }
-    if (cout % 64 == 0) return launch_linear<4, 1, 2>(rows, cin, cout, x, w, bias, relu, pool, y, st);
-    return launch_linear<4, 1, 1>(rows, cin, cout, x, w, bias, relu, pool, y, st);
+    if (cout % 64 == 0) return PN2_LIN(4, 1, 2, 1);
+    return PN2_LIN(4, 1, 1, 1);
+#undef PN2_LIN
+}
+
+extern "C" int pn2_debug_set_linear(int what, int value) {
+    if (what == 5) { g_lin_stages = value; return 0; }
+    return PN2_EINVAL;
 }
 
 // internal helper (exported for the host package's unfused SA path and for tests)

@@ -288,13 +288,22 @@ sa_fused_kernel(SaFusedParams p) {
             const f32x4* __restrict__ f3 = reinterpret_cast<const f32x4*>(p.points + (kb + ir[2]) * c) + half;
             const int nt8 = c >> 3;
             f32x4 c1v = f1[0], c2v = f2[0], c3v = f3[0];
+            float wc[NT1];
+            load_w<NT1>(wc, w1l);
             for (int t = 0; t < nt8; ++t) {
-                f32x4 n1 = c1v, n2 = c2v, n3 = c3v;
-                if (t + 1 < nt8) { n1 = f1[(t + 1) * 2]; n2 = f2[(t + 1) * 2]; n3 = f3[(t + 1) * 2]; }
+                const int tn = (t + 1 < nt8 ? t + 1 : t) * 2;  // unconditional (clamped): counted vmcnt
+                const f32x4 n1 = f1[tn], n2 = f2[tn], n3 = f3[tn];
                 const f32x4 cur = (c1v * w1 + c2v * w2) + c3v * w3;  // tf_interpolate.cpp:322-324 order, unfused
 #pragma unroll
-                for (int q = 0; q < 4; ++q)
-                    mfma_step<NT1, LAST1>(a1, w1l + (4 * t + q) * 2 * W1, cur[q]);
+                for (int q = 0; q < 4; ++q) {  // weights of the next k-step are fetched under this step's MFMAs
+                    const int sn = 4 * t + q + 1;
+                    float wn[NT1];
+                    load_w<NT1>(wn, w1l + (sn < steps1 ? sn : steps1 - 1) * 2 * W1);
+                    mfma_regs<NT1, LAST1>(a1, wc, cur[q]);
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int nt = 0; nt < NT1; ++nt) wc[nt] = wn[nt];
+                }
                 c1v = n1; c2v = n2; c3v = n3;
             }
             if (c1 > 0) {
@@ -311,12 +320,20 @@ sa_fused_kernel(SaFusedParams p) {
                 reinterpret_cast<const f32x4*>(p.points + prow * c) + half;
             const int nt8 = c >> 3;
             f32x4 cur = fp[0];
+            float wc[NT1];
+            load_w<NT1>(wc, w1l + S0 * 2 * W1);
             for (int t = 0; t < nt8; ++t) {
-                f32x4 nxt = cur;
-                if (t + 1 < nt8) nxt = fp[(t + 1) * 2];
+                const f32x4 nxt = fp[(t + 1 < nt8 ? t + 1 : t) * 2];  // unconditional (clamped): counted vmcnt
 #pragma unroll
-                for (int q = 0; q < 4; ++q)
-                    mfma_step<NT1, LAST1>(a1, w1l + (S0 + 4 * t + q) * 2 * W1, cur[q]);
+                for (int q = 0; q < 4; ++q) {  // weights of the next k-step are fetched under this step's MFMAs
+                    const int sn = S0 + 4 * t + q + 1;
+                    float wn[NT1];
+                    load_w<NT1>(wn, w1l + (sn < steps1 ? sn : steps1 - 1) * 2 * W1);
+                    mfma_regs<NT1, LAST1>(a1, wc, cur[q]);
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int nt = 0; nt < NT1; ++nt) wc[nt] = wn[nt];
+                }
                 cur = nxt;
             }
         } else {

@@ -355,8 +355,10 @@ inline int grid_for(long long total, int block) {
 
 // undocumented tuning/experiment hook (not part of the ABI header)
 extern "C" int pn2_debug_set_grouping(int what, int value);
+extern "C" int pn2_debug_set_linear(int what, int value);
 extern "C" int pn2_debug_set(int what, int value) {
     if (what == 0) { g_fps_variant = value; return 0; }
+    if (what == 5) return pn2_debug_set_linear(what, value);
     return pn2_debug_set_grouping(what, value);
 }
 
