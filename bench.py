@@ -257,15 +257,18 @@ def main():
     ap.add_argument("--points", type=int, default=8192)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--eager", action="store_true", help="launch from Python instead of replaying a hipGraph")
-    ap.add_argument("--one-stream", action="store_true", help="do not overlap the geometry chain with the MLP chain")
+    ap.add_argument("--one-stream", action="store_true", help="(default since r01q; kept for old scripts)")
+    ap.add_argument("--two-streams", action="store_true",
+                    help="capture the geometry chain and the MLP chain of a batch on two streams inside its graph "
+                         "(measured: no gain for one batch, -25%% throughput with several batches in flight: "
+                         "profiles/r01_stream_queue_sweep.txt)")
     ap.add_argument("--pipeline", type=int, default=4, help="independent batches in flight (graphs replayed round-robin)")
     ap.add_argument("--no-north-star", action="store_true")
     ap.add_argument("--debug-set", action="append", default=[], metavar="WHAT=VALUE",
                     help="tuning hook: pn2_debug_set(what, value) before the run (A/B experiments)")
     ap.add_argument("--fp-front", choices=("auto", "fused", "unfused"), default="auto",
-                    help="FP front end inside the first FP4 MLP kernel (pn2_fp_mlp_fused: lowest single-batch latency) "
-                         "or materialised by pn2_fp_interp_concat (measured 3%% better throughput with several batches "
-                         "in flight); auto = fused when --pipeline 1, else unfused")
+                    help="FP front end inside the first FP4 MLP kernel (pn2_fp_mlp_fused) or materialised by "
+                         "pn2_fp_interp_concat; auto = fused (faster at every pipeline depth with one stream per batch)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -304,7 +307,7 @@ def main():
     for kv in args.debug_set:
         what, value = kv.split("=")
         assert pn2._lib._raw.pn2_debug_set(int(what), int(value)) == 0
-    fused_fp = args.fp_front == "fused" or (args.fp_front == "auto" and (args.eager or args.pipeline <= 1))
+    fused_fp = args.fp_front != "unfused"
     pn2.util.pointnet_util.USE_FUSED_FP = fused_fp
 
     def step():
@@ -319,7 +322,7 @@ def main():
         # round-robin on P streams), so one batch's latency-bound FPS (16 CUs) overlaps the MFMA
         # layers of the previous batch.  Every step is still one full forward over one batch.
         P = max(1, args.pipeline)
-        fwd = lambda x: pn2.model.get_sa_fp_features(x, False, hp, two_streams=not args.one_stream)[0]  # noqa: E731
+        fwd = lambda x: pn2.model.get_sa_fp_features(x, False, hp, two_streams=args.two_streams)[0]  # noqa: E731
         batches = [pc] + [torch.from_numpy(s_scene(2000 + 10 * rank + i, B, N)).to(dev) for i in range(1, P)]
         caps = [pn2.runtime.CapturedForward(fwd, b_) for b_ in batches]
         streams = [torch.cuda.Stream() for _ in range(P)]
@@ -381,7 +384,7 @@ def main():
                        "batch_per_gpu": B, "num_point": N, "parallelism": "batch-sharded replicas x%d, no collective" % world,
                        "arith_mode": int(pn2.config.arith_mode),
                        "launch": "eager python launches" if args.eager else "one hipGraph replay per step",
-                       "streams": 1 if (args.eager or args.one_stream) else 2,
+                       "streams_per_batch": 2 if (args.two_streams and not args.eager) else 1,
                        "batches_in_flight": 1 if args.eager else max(1, args.pipeline),
                        "fp_front": "fused" if fused_fp else "materialised"},
             "roofline": {"kernel": dom["kernel"], "args": dom["args"], "bound": dom["bound"],

@@ -426,6 +426,176 @@ fp_interp_concat_kernel(int n, int m, int c1, int c2, int ostride, int rpw, cons
     }
 }
 
+// Same operation with R rows in flight per wave: all gathers of R rows are issued before the first
+// store (the row-at-a-time kernel above serialises load -> store -> load because the stores may alias
+// the loads), every load is unconditional (clamped column, result selected afterwards).  CHW =
+// ceil(ostride / 64) column chunks per row.
+template <int CHW, int R>
+__global__ void __launch_bounds__(256)
+fp_interp_concat_rows_kernel(int n, int m, int c1, int c2, int ostride, int rpw, const float* __restrict__ dist_all,
+                             const int* __restrict__ idx_all, const float* __restrict__ points1_all,
+                             const float* __restrict__ points2_all, float* __restrict__ out_all) {
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    // XCD-aware block remap (speed only): the dispatcher places workgroup L on XCD L % 8; giving every
+    // XCD a contiguous range of logical blocks = whole batch elements keeps each private 4 MiB L2
+    // gathering from its own 1/8 of points2 instead of from all of it.
+    int bx = blockIdx.x, bi = blockIdx.y;
+    {
+        const unsigned nwg = gridDim.x * gridDim.y;
+        if ((nwg & 7u) == 0u) {
+            const unsigned lin = blockIdx.x + gridDim.x * blockIdx.y;
+            const unsigned swz = (lin & 7u) * (nwg >> 3) + (lin >> 3);
+            bx = (int)(swz % gridDim.x);
+            bi = (int)(swz / gridDim.x);
+        }
+    }
+    const int cw = ostride;
+    const float* __restrict__ dist = dist_all + (size_t)bi * n * 3;
+    const int* __restrict__ idx = idx_all + (size_t)bi * n * 3;
+    const float* __restrict__ p2 = points2_all + (size_t)bi * m * c2;
+    const float* __restrict__ p1 = points1_all ? points1_all + (size_t)bi * n * c1 : p2;  // dummy when c1 == 0
+    float* __restrict__ out = out_all + (size_t)bi * n * cw;
+    const int c1m = c1 > 0 ? c1 - 1 : 0;
+    for (int row0 = (bx * 4 + wave) * rpw; row0 < n; row0 += gridDim.x * 4 * rpw) {
+        int r = row0 + (lane < rpw ? lane : rpw - 1);
+        r = r < n ? r : n - 1;
+        const float d1 = fmaxf(dist[r * 3 + 0], 1e-10f);
+        const float d2 = fmaxf(dist[r * 3 + 1], 1e-10f);
+        const float d3 = fmaxf(dist[r * 3 + 2], 1e-10f);
+        const float r1 = 1.0f / d1, r2 = 1.0f / d2, r3 = 1.0f / d3;  // IEEE division
+        const float norm = (r1 + r2) + r3;
+        const float w1 = r1 / norm, w2 = r2 / norm, w3 = r3 / norm;
+        const int i1 = idx[r * 3 + 0], i2 = idx[r * 3 + 1], i3 = idx[r * 3 + 2];
+        const int nrows = n - row0 < rpw ? n - row0 : rpw;
+        for (int rr = 0; rr < nrows; rr += R) {
+            float v[R][CHW];
+#pragma unroll
+            for (int q = 0; q < R; ++q) {
+                const int rx = rr + q < nrows ? rr + q : nrows - 1;
+                const float a1 = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(w1), rx));
+                const float a2 = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(w2), rx));
+                const float a3 = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(w3), rx));
+                const float* __restrict__ s1 = p2 + (size_t)__builtin_amdgcn_readlane(i1, rx) * c2;
+                const float* __restrict__ s2 = p2 + (size_t)__builtin_amdgcn_readlane(i2, rx) * c2;
+                const float* __restrict__ s3 = p2 + (size_t)__builtin_amdgcn_readlane(i3, rx) * c2;
+                const float* __restrict__ qp = p1 + (size_t)(row0 + rx) * c1;
+#pragma unroll
+                for (int j = 0; j < CHW; ++j) {
+                    const int col = lane + 64 * j;
+                    const int cc = col < c2 ? col : c2 - 1;
+                    int ci = col - c2;
+                    ci = ci < 0 ? 0 : (ci > c1m ? c1m : ci);
+                    const float x1 = s1[cc], x2 = s2[cc], x3 = s3[cc], xp = qp[ci];
+                    const float val = (x1 * a1 + x2 * a2) + x3 * a3;
+                    v[q][j] = col < c2 ? val : (col < c2 + c1 ? xp : 0.f);
+                }
+            }
+#pragma unroll
+            for (int q = 0; q < R; ++q) {
+                if (rr + q < nrows) {
+                    float* __restrict__ o = out + (size_t)(row0 + rr + q) * cw;
+#pragma unroll
+                    for (int j = 0; j < CHW; ++j) {
+                        const int col = lane + 64 * j;
+                        if (col < cw) o[col] = v[q][j];
+                    }
+                }
+            }
+        }
+    }
+}
+
+// 16-byte-lane version for the common power-of-two layouts (c2/4 and (ostride-c2)/4 powers of two):
+// a wave owns up to 64 consecutive rows; lane l computes the weights of row l once and parks
+// (w1,w2,w3,i1,i2,i3) in LDS; then the lanes sweep the (row, float4 column) elements of the interpolated
+// part -- three 16-byte gathers, the unfused (p1*w1 + p2*w2) + p3*w3 per component, one 16-byte store
+// -- four elements in flight per lane, followed by the [points1 | zero pad] tail columns.
+// P1V: points1 rows are 16-byte loadable (c1 % 4 == 0, aligned).
+template <bool P1V>
+__global__ void __launch_bounds__(256)
+fp_interp_concat_v4_kernel(int n, int m, int c1, int c2, int ostride, int rpw, int sh2, int sht,
+                           const float* __restrict__ dist_all, const int* __restrict__ idx_all,
+                           const float* __restrict__ points1_all, const float* __restrict__ points2_all,
+                           float* __restrict__ out_all) {
+    __shared__ __attribute__((aligned(16))) float swt[4 * 64 * 8];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    int bx = blockIdx.x, bi = blockIdx.y;
+    {   // XCD-aware block remap, see fp_interp_concat_rows_kernel
+        const unsigned nwg = gridDim.x * gridDim.y;
+        if ((nwg & 7u) == 0u) {
+            const unsigned lin = blockIdx.x + gridDim.x * blockIdx.y;
+            const unsigned swz = (lin & 7u) * (nwg >> 3) + (lin >> 3);
+            bx = (int)(swz % gridDim.x);
+            bi = (int)(swz / gridDim.x);
+        }
+    }
+    const int cv = ostride >> 2, c2v = c2 >> 2;
+    const float* __restrict__ dist = dist_all + (size_t)bi * n * 3;
+    const int* __restrict__ idx = idx_all + (size_t)bi * n * 3;
+    const f32x4* __restrict__ p2 = reinterpret_cast<const f32x4*>(points2_all + (size_t)bi * m * c2);
+    const float* __restrict__ p1 = points1_all ? points1_all + (size_t)bi * n * c1 : nullptr;
+    f32x4* __restrict__ out = reinterpret_cast<f32x4*>(out_all + (size_t)bi * n * ostride);
+    float* wv = swt + wave * 64 * 8;
+    const unsigned m2 = (1u << sh2) - 1u, mt = (1u << sht) - 1u;
+    for (int row0 = (bx * 4 + wave) * rpw; row0 < n; row0 += gridDim.x * 4 * rpw) {
+        {
+            int r = row0 + (lane < rpw ? lane : rpw - 1);
+            r = r < n ? r : n - 1;
+            const float d1 = fmaxf(dist[r * 3 + 0], 1e-10f);
+            const float d2 = fmaxf(dist[r * 3 + 1], 1e-10f);
+            const float d3 = fmaxf(dist[r * 3 + 2], 1e-10f);
+            const float r1 = 1.0f / d1, r2 = 1.0f / d2, r3 = 1.0f / d3;  // IEEE division
+            const float norm = (r1 + r2) + r3;
+            const f32x4 wq = {r1 / norm, r2 / norm, r3 / norm, 0.f};
+            const f32x4 iq = {__int_as_float(idx[r * 3 + 0]), __int_as_float(idx[r * 3 + 1]),
+                              __int_as_float(idx[r * 3 + 2]), 0.f};
+            *reinterpret_cast<f32x4*>(wv + lane * 8) = wq;
+            *reinterpret_cast<f32x4*>(wv + lane * 8 + 4) = iq;
+        }
+        const int nrows = n - row0 < rpw ? n - row0 : rpw;
+        // ---- interpolated columns ----
+        const unsigned E = (unsigned)nrows << sh2;
+        for (unsigned e0 = lane; e0 < E; e0 += 64 * 4) {
+            f32x4 v[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                unsigned e = e0 + 64 * u;
+                e = e < E ? e : E - 1;  // clamped: unconditional loads
+                const unsigned row = e >> sh2, col = e & m2;
+                const f32x4 wq = *reinterpret_cast<const f32x4*>(wv + row * 8);
+                const f32x4 iq = *reinterpret_cast<const f32x4*>(wv + row * 8 + 4);
+                const f32x4 x1 = p2[(size_t)__float_as_int(iq[0]) * c2v + col];
+                const f32x4 x2 = p2[(size_t)__float_as_int(iq[1]) * c2v + col];
+                const f32x4 x3 = p2[(size_t)__float_as_int(iq[2]) * c2v + col];
+                v[u] = (x1 * wq[0] + x2 * wq[1]) + x3 * wq[2];  // tf_interpolate.cpp:322-324, unfused
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const unsigned e = e0 + 64 * u;
+                if (e < E) out[(size_t)(row0 + (e >> sh2)) * cv + (e & m2)] = v[u];
+            }
+        }
+        // ---- [points1 | zero pad] columns ----
+        const unsigned ET = (unsigned)nrows << sht;
+        for (unsigned e = lane; e < ET; e += 64) {
+            const unsigned row = e >> sht, ct = e & mt;
+            f32x4 t = {0.f, 0.f, 0.f, 0.f};
+            if constexpr (P1V) {
+                if ((int)ct * 4 < c1) t = *reinterpret_cast<const f32x4*>(p1 + (size_t)(row0 + row) * c1 + ct * 4);
+            } else {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int ch = (int)ct * 4 + i;
+                    if (ch < c1) t[i] = p1[(size_t)(row0 + row) * c1 + ch];
+                }
+            }
+            out[(size_t)(row0 + row) * cv + c2v + ct] = t;
+        }
+    }
+}
+
 inline int grid_x_for(unsigned long long total, int block, int batches) {
     unsigned long long g = (total + block - 1) / block;
     unsigned long long cap = (256ull * 8 + batches - 1) / batches;
@@ -508,8 +678,37 @@ extern "C" int pn2_fp_interp_concat(int b, int n, int m, int c1, int c2, const f
     if (gx > cap) gx = cap;
     if (gx < 1) gx = 1;
     dim3 grid(gx, b);
-    fp_interp_concat_kernel<<<grid, 256, 0, static_cast<hipStream_t>(stream)>>>(
-        n, m, c1, c2, out_stride, rpw, dist, idx, c1 > 0 ? points1 : nullptr, points2, out);
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    const float* q1 = c1 > 0 ? points1 : nullptr;
+    {   // 16-byte-lane kernel when the layout allows it
+        const int tailv = (out_stride - c2) / 4, c2v = c2 / 4;
+        const bool pow2 = c2 % 4 == 0 && out_stride % 4 == 0 && (c2v & (c2v - 1)) == 0 && tailv > 0 &&
+                          (tailv & (tailv - 1)) == 0 && c2v <= 1024;
+        const bool al = (((uintptr_t)points2 | (uintptr_t)out) % 16) == 0;
+        if (pow2 && al) {
+            const int sh2 = 31 - __builtin_clz((unsigned)c2v), sht = 31 - __builtin_clz((unsigned)tailv);
+            const bool p1v = c1 > 0 && c1 % 4 == 0 && ((uintptr_t)points1 % 16) == 0;
+            if (p1v || c1 == 0)
+                fp_interp_concat_v4_kernel<true><<<grid, 256, 0, st>>>(n, m, c1, c2, out_stride, rpw, sh2, sht, dist, idx,
+                                                                     q1, points2, out);
+            else
+                fp_interp_concat_v4_kernel<false><<<grid, 256, 0, st>>>(n, m, c1, c2, out_stride, rpw, sh2, sht, dist,
+                                                                      idx, q1, points2, out);
+            PN2_RETURN_IF_LAUNCH_FAILED();
+            return PN2_OK;
+        }
+    }
+    const int chw = (out_stride + 63) / 64;
+#define PN2_FIC(CHW_, R_) fp_interp_concat_rows_kernel<CHW_, R_><<<grid, 256, 0, st>>>( \
+        n, m, c1, c2, out_stride, rpw, dist, idx, q1, points2, out)
+    if (chw <= 1) PN2_FIC(1, 8);
+    else if (chw == 2) PN2_FIC(2, 4);
+    else if (chw == 3) PN2_FIC(3, 4);
+    else if (chw == 4) PN2_FIC(4, 2);
+    else if (chw <= 6) PN2_FIC(6, 2);
+    else if (chw <= 12) PN2_FIC(12, 1);
+    else fp_interp_concat_kernel<<<grid, 256, 0, st>>>(n, m, c1, c2, out_stride, rpw, dist, idx, q1, points2, out);
+#undef PN2_FIC
     PN2_RETURN_IF_LAUNCH_FAILED();
     return PN2_OK;
 }
