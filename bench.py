@@ -266,6 +266,9 @@ def main():
     ap.add_argument("--no-north-star", action="store_true")
     ap.add_argument("--debug-set", action="append", default=[], metavar="WHAT=VALUE",
                     help="tuning hook: pn2_debug_set(what, value) before the run (A/B experiments)")
+    ap.add_argument("--dup", action="append", default=[], metavar="ENTRY",
+                    help="ablation: launch this entry point twice; the ms/step increase is its marginal cost in the "
+                         "pipelined regime")
     ap.add_argument("--fp-front", choices=("auto", "fused", "unfused"), default="auto",
                     help="FP front end inside the first FP4 MLP kernel (pn2_fp_mlp_fused) or materialised by "
                          "pn2_fp_interp_concat; auto = fused (faster at every pipeline depth with one stream per batch)")
@@ -307,6 +310,7 @@ def main():
     for kv in args.debug_set:
         what, value = kv.split("=")
         assert pn2._lib._raw.pn2_debug_set(int(what), int(value)) == 0
+    pn2._lib.lib.dup = tuple(args.dup)
     fused_fp = args.fp_front != "unfused"
     pn2.util.pointnet_util.USE_FUSED_FP = fused_fp
 

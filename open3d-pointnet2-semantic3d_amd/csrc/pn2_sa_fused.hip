@@ -120,24 +120,29 @@ __device__ __forceinline__ void mfma_regs(f32x16 (&acc)[NT], const float (&wv)[N
     }
 }
 
+// Weight prefetch distance in k-steps: the ds_reads of step s+kPF are issued right after the MFMAs of step s
+// (into the register slot that step just consumed).  tools/mfma_lds.hip: 136 / 142 / 149 TFLOP/s at distance
+// 1 / 2 / 4 for this loop shape at 2 waves/SIMD (and 100 without the sched_barrier pinning).
+constexpr int kPF = 4;
+
 template <int NTP, int NT, bool LAST>
 __device__ __forceinline__ void layer_from_regs(const f32x16 (&in)[NTP], f32x16 (&acc)[NT],
                                                 const float* __restrict__ wp, int w, int half, int l31) {
     const float* __restrict__ wl = wp + half * w + l31;
-    float wc[NT];
-    load_w<NT>(wc, wl);
+    constexpr int S = NTP * 16;
+    float wq[kPF][NT];
+#pragma unroll
+    for (int pf = 0; pf < kPF; ++pf) load_w<NT>(wq[pf], wl + pf * 2 * w);
 #pragma unroll
     for (int ntp = 0; ntp < NTP; ++ntp)
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int s = ntp * 16 + r;
-            float wn[NT];
-            if (s + 1 < NTP * 16) load_w<NT>(wn, wl + (s + 1) * 2 * w);
-            mfma_regs<NT, LAST>(acc, wc, in[ntp][r]);
+            mfma_regs<NT, LAST>(acc, wq[s % kPF], in[ntp][r]);
             __builtin_amdgcn_sched_barrier(0);
-            if (s + 1 < NTP * 16) {
-#pragma unroll
-                for (int nt = 0; nt < NT; ++nt) wc[nt] = wn[nt];
+            if (s + kPF < S) {
+                load_w<NT>(wq[s % kPF], wl + (s + kPF) * 2 * w);
+                __builtin_amdgcn_sched_barrier(0);
             }
         }
 }
@@ -162,6 +167,17 @@ template <int NT>
 __device__ __forceinline__ void rows_store(const f32x16 (&acc)[NT], const float* __restrict__ sbias,
                                            float* __restrict__ obase, int wout, int row0, int rows,
                                            int half, int l31) {
+    if (row0 + 32 <= rows) {  // whole tile in range (wave-uniform): no per-store exec masking, constant offsets
+        float* __restrict__ o = obase + (size_t)(row0 + 4 * half) * wout + l31;
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+            const float bv = sbias[nt * 32 + l31];
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+                o[((r & 3) + 8 * (r >> 2)) * wout + nt * 32] = fmaxf(acc[nt][r] + bv, 0.f);
+        }
+        return;
+    }
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) {
         const float bv = sbias[nt * 32 + l31];
@@ -181,7 +197,7 @@ __device__ __forceinline__ void rows_store(const f32x16 (&acc)[NT], const float*
 //                same fp32 operation order as fp_interp_concat_kernel / the reference ops.
 // NW waves per workgroup share one LDS copy of the weights.
 template <int L, int NT1, int NT2, int NT3, bool VEC8, bool DENSE, bool POOL, int NW, bool INTERP = false>
-__global__ void __launch_bounds__(NW * 64, 2)  // 2 waves/SIMD: <= 256 VGPR+AGPR per lane
+__global__ void __launch_bounds__(NW * 64, (NW >= 8 ? NW / 4 : 2))  // NW <= 8: 2 waves/SIMD (<= 256 VGPR+AGPR per lane)
 sa_fused_kernel(SaFusedParams p) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int tid = threadIdx.x;
@@ -251,7 +267,17 @@ sa_fused_kernel(SaFusedParams p) {
     __syncthreads();
 
     constexpr int WOUT = L == 1 ? W1 : (L == 2 ? W2 : W3);
-    for (int g = blockIdx.x * NW + wave; g < p.groups; g += gridDim.x * NW) {
+    // XCD-aware tile order (speed only): the dispatcher places workgroup w on XCD w % 8.  Giving XCD x the
+    // contiguous tile range [x*G/8, (x+1)*G/8) = whole batch elements makes each private 4 MiB L2 gather
+    // from 1/8 of the feature table instead of all of it.
+    int g_lo = blockIdx.x * NW + wave, g_hi = p.groups, g_step = gridDim.x * NW;
+    if ((gridDim.x & 7u) == 0u && (p.groups & 7) == 0) {
+        const int per = p.groups >> 3, xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+        g_lo = xcd * per + slot * NW + wave;
+        g_hi = (xcd + 1) * per;
+        g_step = (gridDim.x >> 3) * NW;
+    }
+    for (int g = g_lo; g < g_hi; g += g_step) {
         size_t prow;  // row of the feature matrix feeding this lane
         f32x16 a1[NT1];
         zero_acc<NT1>(a1);
@@ -288,21 +314,20 @@ sa_fused_kernel(SaFusedParams p) {
             const f32x4* __restrict__ f3 = reinterpret_cast<const f32x4*>(p.points + (kb + ir[2]) * c) + half;
             const int nt8 = c >> 3;
             f32x4 c1v = f1[0], c2v = f2[0], c3v = f3[0];
-            float wc[NT1];
-            load_w<NT1>(wc, w1l);
+            float wq[4][NT1];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) load_w<NT1>(wq[q], w1l + q * 2 * W1);
             for (int t = 0; t < nt8; ++t) {
                 const int tn = (t + 1 < nt8 ? t + 1 : t) * 2;  // unconditional (clamped): counted vmcnt
                 const f32x4 n1 = f1[tn], n2 = f2[tn], n3 = f3[tn];
                 const f32x4 cur = (c1v * w1 + c2v * w2) + c3v * w3;  // tf_interpolate.cpp:322-324 order, unfused
 #pragma unroll
-                for (int q = 0; q < 4; ++q) {  // weights of the next k-step are fetched under this step's MFMAs
-                    const int sn = 4 * t + q + 1;
-                    float wn[NT1];
-                    load_w<NT1>(wn, w1l + (sn < steps1 ? sn : steps1 - 1) * 2 * W1);
-                    mfma_regs<NT1, LAST1>(a1, wc, cur[q]);
+                for (int q = 0; q < 4; ++q) {  // slot q is refilled for the next t right after it is consumed
+                    mfma_regs<NT1, LAST1>(a1, wq[q], cur[q]);
                     __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                    for (int nt = 0; nt < NT1; ++nt) wc[nt] = wn[nt];
+                    const int sn = 4 * (t + 1) + q;
+                    load_w<NT1>(wq[q], w1l + (sn < steps1 ? sn : steps1 - 1) * 2 * W1);
+                    __builtin_amdgcn_sched_barrier(0);
                 }
                 c1v = n1; c2v = n2; c3v = n3;
             }
@@ -320,19 +345,18 @@ sa_fused_kernel(SaFusedParams p) {
                 reinterpret_cast<const f32x4*>(p.points + prow * c) + half;
             const int nt8 = c >> 3;
             f32x4 cur = fp[0];
-            float wc[NT1];
-            load_w<NT1>(wc, w1l + S0 * 2 * W1);
+            float wq[4][NT1];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) load_w<NT1>(wq[q], w1l + (S0 + q) * 2 * W1);
             for (int t = 0; t < nt8; ++t) {
                 const f32x4 nxt = fp[(t + 1 < nt8 ? t + 1 : t) * 2];  // unconditional (clamped): counted vmcnt
 #pragma unroll
-                for (int q = 0; q < 4; ++q) {  // weights of the next k-step are fetched under this step's MFMAs
-                    const int sn = S0 + 4 * t + q + 1;
-                    float wn[NT1];
-                    load_w<NT1>(wn, w1l + (sn < steps1 ? sn : steps1 - 1) * 2 * W1);
-                    mfma_regs<NT1, LAST1>(a1, wc, cur[q]);
+                for (int q = 0; q < 4; ++q) {  // slot q is refilled for the next t right after it is consumed
+                    mfma_regs<NT1, LAST1>(a1, wq[q], cur[q]);
                     __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                    for (int nt = 0; nt < NT1; ++nt) wc[nt] = wn[nt];
+                    const int sn = S0 + 4 * (t + 1) + q;
+                    load_w<NT1>(wq[q], w1l + (sn < steps1 ? sn : steps1 - 1) * 2 * W1);
+                    __builtin_amdgcn_sched_barrier(0);
                 }
                 cur = nxt;
             }
@@ -346,6 +370,16 @@ sa_fused_kernel(SaFusedParams p) {
             }
         }
         float* __restrict__ orow = p.out + (size_t)g * WOUT;
+            f32x16 a2[NT2];
+            zero_acc<NT2>(a2);
+            layer_from_regs<NT1, NT2, true>(a1, a2, wp2, W2, half, l31);
+            float sacc = 0.f;
+#pragma unroll
+            for (int nt = 0; nt < NT2; ++nt) sacc += a2[nt][0] + a2[nt][15];
+            if (sacc == 12345.f) orow[lane] = sacc;
+            continue;
+        }
+#endif
         if constexpr (L == 1) {
             if constexpr (POOL) pool_store<NT1>(a1, sb1, orow, half, l31);
             else rows_store<NT1>(a1, sb1, p.out, WOUT, g * 32, p.rows, half, l31);
@@ -369,6 +403,9 @@ sa_fused_kernel(SaFusedParams p) {
     }
 }
 
+int g_chain_nw = 0;      // tuning hook (pn2_debug_set(7, v)): 16 = 16-wave workgroups for the single-layer kernels
+int g_chain_grid = 256;  // tuning hook (pn2_debug_set(6, v)): persistent workgroups of the 1-per-CU configuration
+
 template <int L, int NT1, int NT2, int NT3, bool VEC8, bool DENSE, bool POOL, bool INTERP = false>
 int launch_chain(const SaFusedParams& p, hipStream_t st) {
     constexpr int W1 = NT1 * 32, W2 = NT2 * 32, W3 = NT3 * 32;
@@ -379,6 +416,21 @@ int launch_chain(const SaFusedParams& p, hipStream_t st) {
     const size_t bytes = floats * sizeof(float);
     if (bytes > 150 * 1024) return PN2_EUNSUP;
     const int need4 = (p.groups + 3) / 4;
+    if constexpr (L == 1) {
+        if (g_chain_nw == 16 && p.groups >= 4096) {  // one 16-wave workgroup per CU: 4 waves/SIMD share the MFMA pipe
+            auto kern = sa_fused_kernel<L, NT1, NT2, NT3, VEC8, DENSE, POOL, 16, INTERP>;
+            static bool attr_set = false;
+            if (!attr_set) {
+                hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                                   hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+                if (e != hipSuccess) return (int)e;
+                attr_set = true;
+            }
+            kern<<<g_chain_grid, 1024, bytes, st>>>(p);
+            PN2_RETURN_IF_LAUNCH_FAILED();
+            return PN2_OK;
+        }
+    }
     if (bytes > 78 * 1024 && p.groups >= 2048) {
         // only one workgroup fits per CU: give it 8 waves (2 per SIMD) sharing the LDS weights.
         // (With fewer than 2048 tiles, 4-wave workgroups spread the tiles over twice as many CUs.)
@@ -390,7 +442,7 @@ int launch_chain(const SaFusedParams& p, hipStream_t st) {
             if (e != hipSuccess) return (int)e;
             attr_set = true;
         }
-        int grid = 256;
+        int grid = g_chain_grid;
         const int need8 = (p.groups + 7) / 8;
         if (grid > need8) grid = need8;
         kern<<<grid, 512, bytes, st>>>(p);
@@ -403,7 +455,7 @@ int launch_chain(const SaFusedParams& p, hipStream_t st) {
             if (e != hipSuccess) return (int)e;
             attr_set = true;
         }
-        int grid = bytes > 78 * 1024 ? 256 : 256 * 2;  // 4-wave workgroups: as many as LDS lets co-reside per CU
+        int grid = bytes > 78 * 1024 ? g_chain_grid : g_chain_grid * 2;  // 4-wave workgroups: as many as LDS lets co-reside per CU
         if (grid > need4) grid = need4;
         kern<<<grid, 256, bytes, st>>>(p);
     }
@@ -412,6 +464,12 @@ int launch_chain(const SaFusedParams& p, hipStream_t st) {
 }
 
 }  // namespace
+
+extern "C" int pn2_debug_set_fused(int what, int value) {
+    if (what == 6) { g_chain_grid = value; return 0; }
+    if (what == 7) { g_chain_nw = value; return 0; }
+    return PN2_EINVAL;
+}
 
 static int sa_fused_impl(int b, int n, int m, int nsample, int c, const float* xyz,
                          const float* new_xyz, const float* points, const int* idx,
