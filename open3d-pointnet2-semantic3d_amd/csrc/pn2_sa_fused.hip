@@ -370,16 +370,6 @@ sa_fused_kernel(SaFusedParams p) {
             }
         }
         float* __restrict__ orow = p.out + (size_t)g * WOUT;
-            f32x16 a2[NT2];
-            zero_acc<NT2>(a2);
-            layer_from_regs<NT1, NT2, true>(a1, a2, wp2, W2, half, l31);
-            float sacc = 0.f;
-#pragma unroll
-            for (int nt = 0; nt < NT2; ++nt) sacc += a2[nt][0] + a2[nt][15];
-            if (sacc == 12345.f) orow[lane] = sacc;
-            continue;
-        }
-#endif
         if constexpr (L == 1) {
             if constexpr (POOL) pool_store<NT1>(a1, sb1, orow, half, l31);
             else rows_store<NT1>(a1, sb1, p.out, WOUT, g * 32, p.rows, half, l31);
