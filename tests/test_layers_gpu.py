@@ -221,6 +221,34 @@ def test_fp_interp_concat_matches_unfused_ops(pn2, oracle, cuda):
     assert np.allclose(got, ref, rtol=2e-7, atol=1e-7)  # 1/d and /norm are IEEE on both sides; sum order identical
 
 
+@pytest.mark.parametrize("n,m,c1,c2,pad_to", [(8192, 256, 3, 128, 8),     # v4 kernel, scalar points1 tail (FP4 layout)
+                                                 (1000, 100, 64, 256, 8),    # v4, 16-byte points1 tail (FP3 layout)
+                                                 (257, 40, 0, 64, 64),       # v4, no points1, pure zero-pad tail
+                                                 (300, 33, 0, 128, 1),       # no tail at all -> row kernel
+                                                 (500, 77, 5, 12, 1),        # odd widths -> row kernel
+                                                 (64, 16, 256, 512, 8),      # FP1 layout, 12 column chunks
+                                                 (100, 9, 7, 1000, 1)])      # > 12 chunks -> one-row kernel
+def test_fp_interp_concat_all_kernel_variants(pn2, oracle, cuda, n, m, c1, c2, pad_to):
+    """Every dispatch branch of pn2_fp_interp_concat reproduces oracle weights + three_interpolate + concat
+    bit for bit (same IEEE divisions, same unfused (p1*w1 + p2*w2) + p3*w3), pad columns are zero."""
+    rs = np.random.RandomState(n + c2)
+    xyz1 = rs.random_sample((3, n, 3)).astype(np.float32)
+    xyz2 = rs.random_sample((3, m, 3)).astype(np.float32)
+    xyz2[:, :3] = xyz1[:, :3]  # zero distances -> the 1e-10 clamp
+    p1 = rs.randn(3, n, c1).astype(np.float32) if c1 else None
+    p2 = rs.randn(3, m, c2).astype(np.float32)
+    rd, ri = oracle.three_nn(xyz1, xyz2)
+    got = pn2.util.pointnet_util._fp_interp_concat(T(rd, cuda), T(ri, cuda), None if p1 is None else T(p1, cuda),
+                                                   T(p2, cuda), pad_to=pad_to).cpu().numpy()
+    ref = oracle.three_interpolate(p2, ri, oracle.fp_weights(rd))
+    if c1:
+        ref = np.concatenate([ref, p1], axis=2)
+    cw = -(-(c1 + c2) // pad_to) * pad_to
+    assert got.shape == (3, n, cw)
+    assert np.array_equal(got[:, :, :c1 + c2], ref)
+    assert not got[:, :, c1 + c2:].any()
+
+
 # ------------------------------------------------------------------ whole stack -------------
 def _oracle_stack(oracle, store, pc, hp, pn2):
     xyz, feat = pc[:, :, :3], pc[:, :, 3:6]
