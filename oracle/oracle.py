@@ -232,3 +232,22 @@ def fp_module(xyz1, xyz2, points1, points2, layers, dtype=np.float64):
     for layer in layers:
         h = conv_bn_relu(h, layer, dtype)
     return h
+
+
+def model_head(feats, fc1, fc2, dtype=np.float64):
+    """model.py:131-146 at inference: conv1d(128)+BN+ReLU -> dropout (identity when not training,
+    util/tf_util.py:587-606) -> conv1d(num_class), no activation, no BN."""
+    h = conv_bn_relu(feats, fc1, dtype)
+    return conv_bn_relu(h, fc2, dtype, relu=False)
+
+
+def weighted_sparse_ce(pred, label, smpw):
+    """model.py:152-161: tf.losses.sparse_softmax_cross_entropy(labels, logits, weights) with the default
+    reduction SUM_BY_NONZERO_WEIGHTS = sum(w_i * ce_i) / #{i : w_i != 0} (0 when every weight is 0)."""
+    z = np.asarray(pred, np.float64).reshape(-1, pred.shape[-1])
+    y = np.asarray(label).reshape(-1).astype(np.int64)
+    w = np.asarray(smpw, np.float64).reshape(-1)
+    z = z - z.max(axis=1, keepdims=True)
+    ce = np.log(np.exp(z).sum(axis=1)) - z[np.arange(z.shape[0]), y]
+    nz = np.count_nonzero(w)
+    return float((ce * w).sum() / nz) if nz else 0.0

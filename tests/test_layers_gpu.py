@@ -42,7 +42,7 @@ def randomize_bn(store, seed):
 def layer_dicts(store, scope, names, bn=True):
     out = []
     for nm in names:
-        p = "%s/%s/" % (scope, nm)
+        p = ("%s/" % scope if scope else "") + nm + "/"
         W = store.params[p + "weights"].detach().cpu().numpy().astype(np.float64)
         W = W.reshape(W.shape[-2], W.shape[-1])
         d = dict(W=W, b=store.params[p + "biases"].detach().cpu().numpy())
@@ -299,6 +299,36 @@ def test_get_model_head_shapes(pn2, cuda):
     assert logits.shape == (1, 1024, 9) and ep["feats"].shape == (1, 1024, 128)
     import torch
     assert torch.isfinite(logits).all()
+
+
+def test_get_model_logits_and_loss_vs_oracle(pn2, oracle, cuda):
+    """the head (fc1 conv1d+BN+ReLU, dropout off, fc2) on top of the SA/FP stack and the weighted
+    sparse cross-entropy (SUM_BY_NONZERO_WEIGHTS) against their numpy restatements."""
+    import torch
+    tfu = pn2.util.tf_util
+    hp = dict(pn2.model.SEMANTIC_HYPERPARAMS)
+    hp.update(l1_npoint=128, l2_npoint=64, l3_npoint=32, l4_npoint=16)
+    store = tfu.set_default_store(tfu.VariableStore(device=cuda, seed=21))
+    rs = np.random.RandomState(4)
+    pc = np.concatenate([s_scene(5, 2, 1024), rs.random_sample((2, 1024, 3)).astype(np.float32)], 2)
+    pn2.model.get_model(T(pc, cuda), False, 9, hp)  # creates the variables
+    randomize_bn(store, 22)
+    logits, ep = pn2.model.get_model(T(pc, cuda), False, 9, hp)
+    feats = _oracle_stack(oracle, store, pc, hp, pn2)
+    (fc1,) = layer_dicts(store, None, ["fc1"])
+    (fc2,) = layer_dicts(store, None, ["fc2"], bn=False)
+    ref = oracle.model_head(feats, fc1, fc2)
+    got = logits.cpu().numpy().astype(np.float64)
+    err = np.abs(got - ref)
+    assert (err <= 5e-5 + 5e-5 * np.abs(ref)).all(), err.max()
+    labels = rs.randint(0, 9, (2, 1024))
+    smpw = (rs.random_sample((2, 1024)) * 2).astype(np.float32)
+    smpw[0, :100] = 0.0  # zero-weight points do not count in the denominator
+    loss = pn2.model.get_loss(logits, T(labels.astype(np.int64), cuda), T(smpw, cuda))
+    ref_loss = oracle.weighted_sparse_ce(got, labels, smpw)
+    assert abs(float(loss) - ref_loss) < 1e-5 * max(1.0, abs(ref_loss))
+    zero = pn2.model.get_loss(logits, T(labels.astype(np.int64), cuda), torch.zeros(2, 1024, device=cuda))
+    assert float(zero) == 0.0 == oracle.weighted_sparse_ce(got, labels, np.zeros((2, 1024)))
 
 
 def test_two_stream_and_graph_forward_match_sequential(pn2, cuda):

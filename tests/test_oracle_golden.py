@@ -145,3 +145,16 @@ def test_mlp_oracle_bn_fold(oracle):
     s = layer["gamma"] / np.sqrt(layer["var"] + 1e-3)
     y2 = np.maximum(x @ (layer["W"] * s) + ((layer["b"] - layer["mean"]) * s + layer["beta"]), 0)
     assert np.allclose(y, y2, rtol=1e-12, atol=1e-12)
+
+
+def test_weighted_sparse_ce_known_answers(oracle):
+    """model.py:152-161 restatement: uniform logits -> log(C); zero weights drop out of the denominator."""
+    pred = np.zeros((2, 5, 9), np.float32)
+    label = np.arange(10).reshape(2, 5) % 9
+    w = np.ones((2, 5), np.float32)
+    assert abs(oracle.weighted_sparse_ce(pred, label, w) - np.log(9.0)) < 1e-12
+    w[0, :3] = 0.0
+    w[1, :] = 2.0
+    # sum(w*ce)/count(w!=0) = (2 + 5*2) * log 9 / 7
+    assert abs(oracle.weighted_sparse_ce(pred, label, w) - 12.0 * np.log(9.0) / 7.0) < 1e-12
+    assert oracle.weighted_sparse_ce(pred, label, np.zeros((2, 5))) == 0.0
