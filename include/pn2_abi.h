@@ -192,6 +192,23 @@ int pn2_fp_mlp_fused(int b, int n, int m, int c1, int c2, const float *dist, con
                      const float *points1, const float *points2, int nlayers, const int *widths,
                      const float *const *w, const float *const *bias, float *y, void *stream);
 
+/* ---- post-processing next to the path ----------------------- */
+
+/* interpolate_label_with_color_cpu(num_sparse_points, num_dense_points, sparse_points, sparse_labels,
+ * dense_points, dense_labels, dense_colors, knn)  tf_interpolate.cpp:71-115 (CPU + Open3D KD-tree in the
+ * reference).  sparse_points (ns,3), sparse_labels (ns), dense_points (nd,3) -> dense_labels (nd) int32,
+ * dense_colors (nd,3) uint8: majority label among the min(knn, ns) nearest sparse points (exact, float64
+ * squared L2, ascending, ties -> lowest index; vote and colour table of :45-47,96-113).  ns == 0 gives
+ * label -1 / colour 0; labels outside [0,9) get colour 0 (both undefined behaviour in the reference).
+ * `workspace`: 256-byte aligned device scratch of at least pn2_interpolate_label_workspace_bytes(ns)
+ * bytes (uniform grid over the sparse points).  knn <= 16 (PN2_EUNSUP above). */
+size_t pn2_interpolate_label_workspace_bytes(int num_sparse_points);
+int pn2_interpolate_label_with_color(int num_sparse_points, int num_dense_points,
+                                     const float *sparse_points, const int *sparse_labels,
+                                     const float *dense_points, int *dense_labels,
+                                     uint8_t *dense_colors, int knn, void *workspace,
+                                     size_t workspace_bytes, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -7,10 +7,10 @@ from . import tf_ops, util  # noqa: F401
 from . import model, runtime, dist, train  # noqa: F401
 from .tf_ops.tf_sampling import farthest_point_sample, gather_point  # noqa: F401
 from .tf_ops.tf_grouping import query_ball_point, group_point, knn_point, select_top_k  # noqa: F401
-from .tf_ops.tf_interpolate import three_nn, three_interpolate  # noqa: F401
+from .tf_ops.tf_interpolate import three_nn, three_interpolate, interpolate_label_with_color  # noqa: F401
 from .util.pointnet_util import (sample_and_group, sample_and_group_all, pointnet_sa_module,  # noqa: F401
                                  pointnet_sa_module_msg, pointnet_fp_module)
 
 __all__ = ["farthest_point_sample", "gather_point", "query_ball_point", "group_point", "three_nn",
-           "three_interpolate", "sample_and_group", "sample_and_group_all", "pointnet_sa_module",
+           "three_interpolate", "interpolate_label_with_color", "sample_and_group", "sample_and_group_all", "pointnet_sa_module",
            "pointnet_sa_module_msg", "pointnet_fp_module", "model", "config", "tf_ops", "util"]

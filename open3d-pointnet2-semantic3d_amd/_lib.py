@@ -38,6 +38,8 @@ SIGNATURES = {
     "pn2_mlp_chain": [c_int, c_int, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p],
     "pn2_fp_mlp_fused": [c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p,
                          c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p],
+    "pn2_interpolate_label_with_color": [c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p,
+                                         ctypes.c_size_t, c_void_p],
     "pn2_sa_group_concat": [c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p,
                             c_void_p, c_void_p],
 }
@@ -62,6 +64,8 @@ def _load():
         fn = getattr(lib, name)  # AttributeError if the ABI and the library disagree
         fn.argtypes = argtypes
         fn.restype = c_int
+    lib.pn2_interpolate_label_workspace_bytes.argtypes = [c_int]
+    lib.pn2_interpolate_label_workspace_bytes.restype = ctypes.c_size_t
     lib.pn2_abi_version.restype = c_int
     lib.pn2_build_info.restype = ctypes.c_char_p
     lib.pn2_strerror.restype = ctypes.c_char_p

@@ -5,6 +5,8 @@ Same names, argument order and shapes as the reference wrappers
 :62-72).  The reference runs these on the CPU (tf_interpolate.cpp:184,283,378,482
 DEVICE_CPU); here they stay on the GPU.
 """
+import ctypes
+
 import torch
 
 from .._lib import check, lib, ptr, require_cuda, stream_ptr
@@ -72,5 +74,33 @@ def three_interpolate(points, idx, weight):
 
 
 def interpolate_label_with_color(sparse_points, sparse_labels, dense_points, knn):
-    raise NotImplementedError("interpolate_label_with_color (tf_interpolate.py:28-44) is post-processing outside "
-                              "the SA/FP hot path; see DESIGN.md 'Next'")
+    """tf_ops/tf_interpolate.py:28-44: sparse_points (ns,3) f32, sparse_labels (ns,) int32, dense_points (nd,3) f32,
+    knn int -> (dense_labels (nd,) int32, dense_colors (nd,3) uint8): majority label of the knn nearest
+    sparse points (exact float64 kNN on the device instead of the reference's CPU KD-tree)."""
+    require_cuda(sparse_points, sparse_labels, dense_points)
+    if sparse_points.dim() != 2 or sparse_points.shape[1] != 3:
+        raise ValueError("sparse_points must be: (num_sparse_points, 3)")  # tf_interpolate.cpp:127-131
+    ns = sparse_points.shape[0]
+    if sparse_labels.dim() != 1 or sparse_labels.shape[0] != ns:
+        raise ValueError("sparse_labels must be: (num_sparse_points, 3)")  # :138-143 (message as in the reference)
+    if dense_points.dim() != 2 or dense_points.shape[1] != 3:
+        raise ValueError("dense_points must be: (num_dense_points, 3)")  # :148-153
+    if not isinstance(knn, int) or isinstance(knn, bool):
+        raise ValueError("knn must be an int scalar")  # :159-160
+    if knn <= 0:
+        raise ValueError("knn must be positive")
+    if sparse_points.dtype != torch.float32 or dense_points.dtype != torch.float32 or sparse_labels.dtype != torch.int32:
+        raise TypeError("InterpolateLabelWithColor expects float32 points and int32 labels")
+    nd = dense_points.shape[0]
+    dev = dense_points.device
+    sp, sl, dp = sparse_points.contiguous(), sparse_labels.contiguous(), dense_points.contiguous()
+    labels = torch.empty((nd,), dtype=torch.int32, device=dev)
+    colors = torch.empty((nd, 3), dtype=torch.uint8, device=dev)
+    wbytes = int(lib.pn2_interpolate_label_workspace_bytes(ns))
+    ws = torch.empty((wbytes + 256,), dtype=torch.uint8, device=dev)
+    off = (-ws.data_ptr()) % 256
+    with torch.cuda.device(dev):
+        check(lib.pn2_interpolate_label_with_color(ns, nd, ptr(sp), ptr(sl), ptr(dp), ptr(labels), ptr(colors), knn,
+                                                   ctypes.c_void_p(ws.data_ptr() + off), wbytes, stream_ptr()),
+              "pn2_interpolate_label_with_color")
+    return labels, colors

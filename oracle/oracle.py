@@ -165,6 +165,18 @@ def knn_point(k, xyz1, xyz2):
     return out[:, :, :k], outi[:, :, :k]
 
 
+def interpolate_label_with_color(sparse_points, sparse_labels, dense_points, knn):
+    """tf_ops/tf_interpolate.py:28-44 -> (dense_labels (Nd,) int32, dense_colors (Nd,3) uint8)."""
+    sp, dp = _f32(sparse_points), _f32(dense_points)
+    sl = _i32(sparse_labels)
+    ns, nd = sp.shape[0], dp.shape[0]
+    labels = np.empty((nd,), dtype=np.int32)
+    colors = np.empty((nd, 3), dtype=np.uint8)
+    rc = lib().oracle_interpolate_label_with_color(ns, nd, _p(sp), _p(sl), _p(dp), _p(labels), _p(colors), int(knn))
+    assert rc == 0, rc
+    return labels, colors
+
+
 # ---------------------------------------------------------------------------
 # Layer maths (numpy).  These restate util/pointnet_util.py + util/tf_util.py.
 # `dtype` float64 gives the high-precision oracle the 1e-5 feature tolerance is

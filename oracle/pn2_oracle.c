@@ -19,6 +19,7 @@
  *   oracle_three_interpolate     tf_ops/tf_interpolate.cpp:307-330 (threeinterpolate_cpu)
  *   oracle_three_interpolate_grad tf_ops/tf_interpolate.cpp:397-421 (threeinterpolate_grad_cpu) + memset :477
  *   oracle_selection_sort        tf_ops/tf_grouping.cu:95-136   (selection_sort_gpu)
+ *   oracle_interpolate_label_with_color tf_ops/tf_interpolate.cpp:30-47,71-115 (interpolate_label_with_color_cpu)
  *
  * Parity pinning (see DESIGN.md "Oracle"):
  *   - three_nn is pinned by the reference's own golden vector
@@ -362,3 +363,63 @@ void oracle_set_num_threads(int t) { omp_set_num_threads(t); }
 int oracle_num_threads(void) { return 1; }
 void oracle_set_num_threads(int t) { (void)t; }
 #endif
+
+
+/* InterpolateLabelWithColor (tf_ops/tf_interpolate.cpp:71-115): for every dense point the knn nearest
+ * sparse points (Open3D KDTreeFlann::SearchKNN on float64-cast points: exact, squared L2 accumulated as
+ * ((0+dx*dx)+dy*dy)+dz*dz, ascending; tie order is FLANN-internal -> lowest index here), then the label
+ * vote of :96-107 in neighbour order -- a label becomes the answer when its running count EXCEEDS the
+ * running maximum -- and the colour look-up of :45-47,111-113.  knn_found = min(knn, num_sparse).
+ * Divergences (both are undefined behaviour in the reference): no neighbour (num_sparse == 0) -> label -1,
+ * colour (0,0,0); a label outside [0, 9) -> colour (0,0,0).  Brute force, O(num_sparse * num_dense). */
+static const uint8_t ORACLE_LABEL_COLOR[9][3] = {
+    {255, 255, 255}, {0, 0, 255}, {128, 0, 0}, {255, 0, 255}, {0, 128, 0},
+    {255, 0, 0}, {128, 0, 128}, {0, 0, 128}, {128, 128, 0}}; /* tf_interpolate.cpp:45-47 */
+#define ORACLE_KNN_MAX 64
+
+int oracle_interpolate_label_with_color(int num_sparse, int num_dense, const float *sparse_points,
+                                        const int *sparse_labels, const float *dense_points,
+                                        int *dense_labels, uint8_t *dense_colors, int knn) {
+    if (num_sparse < 0 || num_dense < 0 || knn <= 0 || knn > ORACLE_KNN_MAX) return -1;
+    const int kf = knn < num_sparse ? knn : num_sparse;
+#pragma omp parallel for schedule(static)
+    for (int j = 0; j < num_dense; ++j) {
+        double bd[ORACLE_KNN_MAX];
+        int bi[ORACLE_KNN_MAX];
+        int cnt = 0;
+        const double qx = dense_points[(size_t)j * 3 + 0], qy = dense_points[(size_t)j * 3 + 1],
+                     qz = dense_points[(size_t)j * 3 + 2];
+        for (int k = 0; k < num_sparse; ++k) {
+            volatile double dx = qx - (double)sparse_points[(size_t)k * 3 + 0];
+            volatile double dy = qy - (double)sparse_points[(size_t)k * 3 + 1];
+            volatile double dz = qz - (double)sparse_points[(size_t)k * 3 + 2];
+            volatile double xx = dx * dx, yy = dy * dy, zz = dz * dz;
+            volatile double s0 = xx + yy;
+            const double d = s0 + zz;
+            if (cnt == kf && !(d < bd[kf - 1])) continue; /* strict: ascending scan keeps the lowest index on ties */
+            int pos = cnt < kf ? cnt : kf - 1;
+            while (pos > 0 && d < bd[pos - 1]) {
+                bd[pos] = bd[pos - 1];
+                bi[pos] = bi[pos - 1];
+                --pos;
+            }
+            bd[pos] = d;
+            bi[pos] = k;
+            if (cnt < kf) ++cnt;
+        }
+        int max_count = 0, best = -1; /* tf_interpolate.cpp:96-107 */
+        for (int a = 0; a < cnt; ++a) {
+            const int label = sparse_labels[bi[a]];
+            int c = 0;
+            for (int e = 0; e <= a; ++e) c += sparse_labels[bi[e]] == label;
+            if (c > max_count) {
+                best = label;
+                max_count = c;
+            }
+        }
+        dense_labels[j] = best;
+        for (int c = 0; c < 3; ++c)
+            dense_colors[(size_t)j * 3 + c] = (best >= 0 && best < 9) ? ORACLE_LABEL_COLOR[best][c] : 0;
+    }
+    return 0;
+}

@@ -32,8 +32,10 @@ def test_library_exports_every_declared_symbol(pn2):
 
 
 def test_python_signatures_cover_the_header(pn2):
-    decl = set(_declared()) - {"pn2_abi_version", "pn2_build_info", "pn2_strerror"}
+    decl = set(_declared()) - {"pn2_abi_version", "pn2_build_info", "pn2_strerror",
+                               "pn2_interpolate_label_workspace_bytes"}  # bound separately: returns size_t
     assert decl <= set(pn2._lib.SIGNATURES) | {"pn2_sa_group_concat"}
+    assert pn2._lib.lib.pn2_interpolate_label_workspace_bytes(1000) > 2 * (1 << 21) * 4  # two cell tables + lists
 
 
 def test_argument_validation_needs_no_gpu(pn2):
@@ -46,6 +48,10 @@ def test_argument_validation_needs_no_gpu(pn2):
     assert L.pn2_three_nn(1, 8, 2, nul, nul, nul, nul, nul) == -1                  # needs >= 3 known points
     assert L.pn2_group_point(1, 8, 0, 4, 4, nul, nul, nul, nul) == -1
     assert b"PN2_ENULL" in L.pn2_strerror(-2)
+    assert L.pn2_interpolate_label_with_color(10, 10, nul, nul, nul, nul, nul, 0, nul, 0, nul) == -1   # knn > 0
+    assert L.pn2_interpolate_label_with_color(10, 10, nul, nul, nul, nul, nul, 3, nul, 0, nul) == -2
+    assert L.pn2_fp_mlp_fused(1, 8, 4, 0, 8, nul, nul, nul, nul, 1, nul, nul, nul, nul, nul) == -2
+    assert L.pn2_mlp_chain(0, 8, nul, 1, nul, nul, nul, 0, nul, nul) == -1
 
 
 def test_ops_refuse_cpu_tensors_loudly(pn2):

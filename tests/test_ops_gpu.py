@@ -392,3 +392,88 @@ def test_sample_and_group_knn(pn2, oracle, cuda):
     assert np.array_equal(idx.cpu().numpy(), ri)
     assert np.array_equal(npts.cpu().numpy(),
                           np.concatenate([oracle.group_point(xyz, ri) - rnx[:, :, None], oracle.group_point(pts, ri)], -1))
+
+
+# ------------------------------------------------------------------ InterpolateLabelWithColor --
+def _label_case(case):
+    rs = np.random.RandomState(abs(hash(case)) % 1000)
+    if case == "uniform":
+        sp, dp = rs.rand(5000, 3), rs.rand(20000, 3)
+    elif case == "scene_surface":  # 2.5-D: almost all cells empty, a few crowded
+        sp = np.concatenate([rs.uniform(-20, 20, (8000, 2)), np.abs(rs.normal(0, 0.05, (8000, 1)))], 1)
+        dp = np.concatenate([rs.uniform(-21, 21, (30000, 2)), np.abs(rs.normal(0, 0.3, (30000, 1)))], 1)
+    elif case == "grid_ties":  # lattice coordinates: equidistant neighbours everywhere -> lowest index wins
+        sp = rs.randint(0, 12, (3000, 3)) / 4.0
+        dp = rs.randint(0, 24, (10000, 3)) / 8.0
+    elif case == "far_outside":  # dense points far away from the sparse cloud's bounding box
+        sp = rs.rand(2000, 3) * 2
+        dp = rs.rand(4000, 3) * 2
+        dp[::3] += 500.0
+        dp[1::7] -= np.array([300.0, 0.0, 40.0])
+    elif case == "duplicates":
+        base = rs.rand(40, 3)
+        sp = base[rs.randint(0, 40, 4000)]
+        dp = base[rs.randint(0, 40, 6000)] + (rs.rand(6000, 3) < 0.3) * 0.01
+    elif case == "one_sparse":
+        sp, dp = rs.rand(1, 3), rs.rand(100, 3)
+    elif case == "line":  # zero extent on two axes
+        sp = np.concatenate([rs.rand(1000, 1), np.zeros((1000, 2))], 1)
+        dp = rs.rand(3000, 3) - 0.25
+    else:
+        raise KeyError(case)
+    sl = rs.randint(0, 9, sp.shape[0]).astype(np.int32)
+    return sp.astype(np.float32), sl, dp.astype(np.float32)
+
+
+@pytest.mark.parametrize("knn", [1, 3, 4, 8])
+@pytest.mark.parametrize("case", ["uniform", "scene_surface", "grid_ties", "far_outside", "duplicates", "one_sparse", "line"])
+def test_interpolate_label_with_color_bit_exact(pn2, oracle, cuda, case, knn):
+    """Dense-label kNN vote on the device grid == brute-force float64 oracle (labels and colours identical)."""
+    sp, sl, dp = _label_case(case)
+    lab, col = pn2.interpolate_label_with_color(T(sp, cuda), T(sl, cuda), T(dp, cuda), knn)
+    rl, rc = oracle.interpolate_label_with_color(sp, sl, dp, knn)
+    assert lab.dtype == __import__("torch").int32 and col.dtype == __import__("torch").uint8
+    assert np.array_equal(lab.cpu().numpy(), rl)
+    assert np.array_equal(col.cpu().numpy(), rc)
+
+
+def test_interpolate_label_edge_cases(pn2, oracle, cuda):
+    import torch
+    dp = np.random.RandomState(0).rand(50, 3).astype(np.float32)
+    # no sparse points: label -1, colour 0 (documented divergence; the reference indexes out of bounds)
+    lab, col = pn2.interpolate_label_with_color(torch.zeros((0, 3), device=cuda), torch.zeros((0,), dtype=torch.int32, device=cuda),
+                                                T(dp, cuda), 3)
+    assert (lab.cpu().numpy() == -1).all() and not col.cpu().numpy().any()
+    # labels outside the 9-entry colour table keep their label, colour 0
+    sp = np.random.RandomState(1).rand(20, 3).astype(np.float32)
+    sl = np.full((20,), 12, np.int32)
+    lab, col = pn2.interpolate_label_with_color(T(sp, cuda), T(sl, cuda), T(dp, cuda), 3)
+    rl, rc = oracle.interpolate_label_with_color(sp, sl, dp, 3)
+    assert np.array_equal(lab.cpu().numpy(), rl) and np.array_equal(col.cpu().numpy(), rc) and (rl == 12).all()
+    # argument errors mirror the op glue (tf_interpolate.cpp:127-160)
+    with pytest.raises(ValueError, match="sparse_points must be"):
+        pn2.interpolate_label_with_color(T(sp[:, :2], cuda), T(sl, cuda), T(dp, cuda), 3)
+    with pytest.raises(ValueError, match="sparse_labels must be"):
+        pn2.interpolate_label_with_color(T(sp, cuda), T(sl[:5], cuda), T(dp, cuda), 3)
+    with pytest.raises(ValueError, match="knn must be an int scalar"):
+        pn2.interpolate_label_with_color(T(sp, cuda), T(sl, cuda), T(dp, cuda), 3.0)
+
+
+def test_interpolate_label_large(pn2, oracle, cuda):
+    """200 k sparse / 2 M dense points (the reference runs this stage on 10^6-10^8 points): a random sample of the
+    dense points is checked against the brute-force oracle, and the whole result is invariant under a permutation of
+    the dense points (every query is independent)."""
+    import torch
+    rs = np.random.RandomState(7)
+    ns, nd = 200000, 2000000
+    sp = np.concatenate([rs.uniform(-50, 50, (ns, 2)), np.abs(rs.normal(0, 2.0, (ns, 1)))], 1).astype(np.float32)
+    sl = rs.randint(0, 9, ns).astype(np.int32)
+    dp = np.concatenate([rs.uniform(-50, 50, (nd, 2)), np.abs(rs.normal(0, 2.0, (nd, 1)))], 1).astype(np.float32)
+    lab, col = pn2.interpolate_label_with_color(T(sp, cuda), T(sl, cuda), T(dp, cuda), 3)
+    lab, col = lab.cpu().numpy(), col.cpu().numpy()
+    pick = rs.choice(nd, 3000, replace=False)
+    rl, rc = oracle.interpolate_label_with_color(sp, sl, dp[pick], 3)
+    assert np.array_equal(lab[pick], rl) and np.array_equal(col[pick], rc)
+    perm = rs.permutation(nd)
+    lab2, _ = pn2.interpolate_label_with_color(T(sp, cuda), T(sl, cuda), T(dp[perm], cuda), 3)
+    assert np.array_equal(lab2.cpu().numpy(), lab[perm])
