@@ -89,3 +89,10 @@ def farthest_point_sample_and_gather(npoint, inp):
         check(lib.pn2_fps_gather(b, n, int(npoint), ptr(inp), ptr(temp), ptr(out), ptr(new_xyz),
                                  int(config.arith_mode), stream_ptr()), "pn2_fps_gather")
     return out, new_xyz
+
+
+def prob_sample(inp, inpr):
+    """tf_ops/tf_sampling.py:18-26 (ProbSample: weighted sampling by cumulative sum + binary search,
+    tf_sampling.cu:7-110).  Registered by the reference but called by none of its models or scripts; not
+    part of the SA/FP path and not built here -- fails loudly instead of approximating."""
+    raise NotImplementedError("prob_sample (tf_sampling.cu:7-110) is not on the SA/FP path; see DESIGN.md section 8")
