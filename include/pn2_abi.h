@@ -152,6 +152,17 @@ int pn2_sa_mlp_max_fused(int b, int n, int m, int nsample, int c, const float *x
                          int nlayers, const int *widths, const float *const *w,
                          const float *const *bias, float *out, void *stream);
 
+/* bf16 variant of pn2_sa_mlp_max_fused (BASELINE configs[4]: large-scene inference, nsample 64): points is
+ * (b,n,c) bfloat16, weights/biases are fp32 and are rounded to bf16 (RNE) by the kernel, products exact,
+ * fp32 accumulation, hidden activations bf16(relu(acc+bias)), out (b,m,widths[last]) fp32 -- the precision
+ * contract is spelled out in csrc/pn2_sa_fused_bf16.hip and restated by oracle.mlp_max_bf16.
+ * Constraints: nsample 32 or 64, c % 16 == 0, points 16-byte aligned, widths multiples of 32 <= 128, a
+ * supported layer pattern ([128], [128,128], [64,128], [64,64,128], [128,128,128]); PN2_EUNSUP otherwise. */
+int pn2_sa_mlp_max_fused_bf16(int b, int n, int m, int nsample, int c, const float *xyz,
+                              const float *new_xyz, const void *points_bf16, const int *idx,
+                              int nlayers, const int *widths, const float *const *w,
+                              const float *const *bias, float *out, void *stream);
+
 /* Same gather + MLP chain without the max over the neighbours: out (b,m,nsample,widths[last]),
  * ReLU applied.  Feeds a wider last layer that runs on pn2_linear with pool = nsample.
  * Supported: nsample == 32, widths [128] or [128,128]; PN2_EUNSUP otherwise. */

@@ -31,6 +31,8 @@ SIGNATURES = {
     "pn2_linear": [c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p],
     "pn2_sa_mlp_max_fused": [c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p,
                              c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p],
+    "pn2_sa_mlp_max_fused_bf16": [c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p,
+                                  c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p],
     "pn2_sa_mlp_rows_fused": [c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p,
                               c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p],
     "pn2_fp_interp_concat": [c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p,
@@ -105,7 +107,7 @@ class _LibProxy:
             rc = fn(*args)
             e.record()
             ints = [a for a in args if isinstance(a, (int, float))]
-            if name in ("pn2_sa_mlp_max_fused", "pn2_sa_mlp_rows_fused"):  # decode the host-side widths[] array for flop accounting
+            if name in ("pn2_sa_mlp_max_fused", "pn2_sa_mlp_rows_fused", "pn2_sa_mlp_max_fused_bf16"):  # decode the host-side widths[] array for flop accounting
                 wp = ctypes.cast(args[10], ctypes.POINTER(c_int))
                 ints += [wp[i] for i in range(args[9])]
             elif name == "pn2_fp_mlp_fused":

@@ -62,7 +62,13 @@ def _sa_fused_inference(xyz, new_xyz, points, idx, mlp, bn, conv_scope_fmt, pool
     b, n, _ = xyz.shape
     m, nsample = idx.shape[1], idx.shape[2]
     c = 0 if points is None else points.shape[2]
-    if nsample != 32 or len(mlp) > 3 or any(w % 32 != 0 or w > 128 for w in mlp):
+    bf16 = points is not None and points.dtype == torch.bfloat16  # BASELINE configs[4]: bf16 features, K = 32 or 64
+    if bf16:
+        if not pool or nsample not in (32, 64) or c % 16 != 0:
+            return None
+    elif nsample != 32:
+        return None
+    if len(mlp) > 3 or any(w % 32 != 0 or w > 128 for w in mlp):
         return None
     ws, bs = [], []
     cin = 3 + c
@@ -79,7 +85,7 @@ def _sa_fused_inference(xyz, new_xyz, points, idx, mlp, bn, conv_scope_fmt, pool
     oshape = (b, m, mlp[-1]) if pool else (b, m, nsample, mlp[-1])
     out = torch.empty(oshape, dtype=torch.float32, device=xyz.device)
     pts = None if points is None else points.contiguous()
-    fn = lib.pn2_sa_mlp_max_fused if pool else lib.pn2_sa_mlp_rows_fused
+    fn = lib.pn2_sa_mlp_max_fused_bf16 if bf16 else (lib.pn2_sa_mlp_max_fused if pool else lib.pn2_sa_mlp_rows_fused)
     with torch.cuda.device(xyz.device):
         rc = fn(b, n, m, nsample, c, ptr(xyz), ptr(new_xyz), ptr(pts), ptr(idx), L,
                                       ctypes.cast(widths, ctypes.c_void_p), ctypes.cast(wptrs, ctypes.c_void_p),
@@ -124,6 +130,10 @@ def sa_features_inference(xyz, new_xyz, points, idx, mlp, bn=True, bn_decay=None
     new_points = None
     if USE_FUSED_SA:
         new_points = _sa_fused_inference(xyz, new_xyz, points, idx, mlp, bn, "conv%d")
+    if new_points is None and points is not None and points.dtype == torch.bfloat16:
+        points = points.float()  # configuration outside the bf16 kernel: run the fp32 kernels on the exact values
+        if USE_FUSED_SA:
+            new_points = _sa_fused_inference(xyz, new_xyz, points, idx, mlp, bn, "conv%d")
     if new_points is None and USE_FUSED_SA and len(mlp) == 3 and mlp[0] == mlp[1] == 128 and mlp[2] % 32 == 0:
         # [128,128,wide]: gather + first two layers fused (activations stay in registers), the wide
         # last layer + max over K on pn2_linear

@@ -246,6 +246,29 @@ def fp_module(xyz1, xyz2, points1, points2, layers, dtype=np.float64):
     return h
 
 
+def bf16_round(x):
+    """float32 -> nearest bfloat16 (ties to even), returned as float32 -- what v_cvt_pk_bf16_f32 does."""
+    u = np.ascontiguousarray(x, dtype=np.float32).view(np.uint32)
+    r = (u + np.uint32(0x7FFF) + ((u >> np.uint32(16)) & np.uint32(1))) & np.uint32(0xFFFF0000)
+    return r.view(np.float32)
+
+
+def mlp_max_bf16(grouped_xyz, grouped_points_bf16, ws, bs):
+    """The precision contract of pn2_sa_mlp_max_fused_bf16 (csrc/pn2_sa_fused_bf16.hip), restated:
+    input = [bf16(grouped_xyz) | features already bf16]; per layer W is rounded to bf16, products are exact,
+    the sum is taken here in float64 (the kernel: fp32 MFMA accumulation), + fp32 bias, ReLU; hidden
+    activations are rounded to bf16; the result is the max over the K neighbours of the last layer.
+    grouped_xyz (B,M,K,3) fp32 = xyz[idx] - new_xyz, grouped_points_bf16 (B,M,K,C) fp32 holding bf16 values,
+    ws[l] (cin_l, w_l) fp32 (BN already folded), bs[l] (w_l,) fp32."""
+    h = np.concatenate([bf16_round(grouped_xyz), _f32(grouped_points_bf16)], axis=-1).astype(np.float64)
+    for l, (w, b) in enumerate(zip(ws, bs)):
+        y = h @ bf16_round(w).astype(np.float64) + np.asarray(b, np.float64)
+        y = np.maximum(y, 0.0)
+        if l + 1 < len(ws):
+            h = bf16_round(y.astype(np.float32)).astype(np.float64)
+    return y.max(axis=2)
+
+
 def model_head(feats, fc1, fc2, dtype=np.float64):
     """model.py:131-146 at inference: conv1d(128)+BN+ReLU -> dropout (identity when not training,
     util/tf_util.py:587-606) -> conv1d(num_class), no activation, no BN."""

@@ -611,3 +611,66 @@ def test_linear_split_k_config(pn2, cuda, rows, cin, cout, pool):
     if pool:
         ref = ref.reshape(rows // pool, pool, cout).max(1)
     close(y, ref)
+
+
+# ------------------------------------------------------------------ bf16 fused SA (BASELINE configs[4]) ------
+def _bf16_case(pn2, oracle, cuda, b, n, m, K, c, mlp, radius, seed):
+    import torch
+    tfu, pu = pn2.util.tf_util, pn2.util.pointnet_util
+    rs = np.random.RandomState(seed)
+    xyz = s_scene(seed, b, n)
+    pts = oracle.bf16_round(rs.randn(b, n, c).astype(np.float32))
+    store = tfu.set_default_store(tfu.VariableStore(device=cuda, seed=seed + 1))
+    txyz = T(xyz, cuda)
+    tpts = T(pts, cuda).to(torch.bfloat16)
+    assert torch.equal(tpts.float().cpu(), torch.from_numpy(pts))  # the inputs are exactly representable
+    with tfu.variable_scope("sa"):
+        new_xyz, idx = pu.sa_geometry(txyz, m, radius, K)
+        pu.sa_features_inference(txyz, new_xyz, tpts, idx, mlp)  # creates the variables
+        randomize_bn(store, seed + 2)
+        calls = []
+        pn2._lib.lib.trace = calls
+        try:
+            out = pu.sa_features_inference(txyz, new_xyz, tpts, idx, mlp)
+        finally:
+            pn2._lib.lib.trace = None
+        ws, bs, cin = [], [], 3 + c
+        for i, cout in enumerate(mlp):
+            with tfu.variable_scope("conv%d" % i):
+                w2, b2 = tfu.folded_dense(cin, cout, True, (1, 1, cin, cout))  # the very tensors the kernel was given
+            ws.append(w2.cpu().numpy()); bs.append(b2.cpu().numpy())
+            cin = cout
+    ri = idx.cpu().numpy()
+    gx = oracle.group_point(xyz, ri) - new_xyz.cpu().numpy()[:, :, None, :]
+    ref = oracle.mlp_max_bf16(gx, oracle.group_point(pts, ri), ws, bs)
+    return out.cpu().numpy().astype(np.float64), ref, [c_[0] for c_ in calls]
+
+
+@pytest.mark.parametrize("K,c,mlp", [(64, 128, [128, 128]), (32, 128, [128]), (64, 64, [64, 64, 128]),
+                                     (32, 16, [64, 128]), (64, 128, [128, 128, 128])])
+def test_sa_fused_bf16_vs_contract(pn2, oracle, cuda, K, c, mlp):
+    """pn2_sa_mlp_max_fused_bf16 against the restated precision contract (bf16 inputs/weights/hidden activations,
+    exact products, wide accumulation).  The only freedom is the fp32 accumulation order, which can flip the bf16
+    rounding of an occasional hidden activation: tolerance 4e-3 of the output scale."""
+    got, ref, calls = _bf16_case(pn2, oracle, cuda, 2, 2048, 128, K, c, mlp, 0.9, 40 + K + c)
+    assert "pn2_sa_mlp_max_fused_bf16" in calls
+    scale = np.abs(ref).max()
+    err = np.abs(got - ref)
+    assert err.max() <= 4e-3 * scale, (err.max(), scale)
+    assert np.median(err) <= 2e-4 * scale
+
+
+def test_sa_bf16_unsupported_falls_back_to_fp32_kernels(pn2, oracle, cuda):
+    """bf16 features with a layer pattern outside the bf16 kernel run the fp32 kernels on the exact values."""
+    got, ref, calls = _bf16_case(pn2, oracle, cuda, 1, 1024, 64, 32, 16, [32, 32, 64], 0.9, 77)
+    assert calls[0] == "pn2_sa_mlp_max_fused_bf16" and calls[1:] == ["pn2_sa_mlp_max_fused"]  # refused, then fp32 fused
+    # fp32 kernels: no rounding of weights / hidden activations -> only close to the bf16 contract, not equal
+    assert np.abs(got - ref).max() <= 5e-2 * np.abs(ref).max()
+
+
+def test_large_scene_bf16_config4(pn2, oracle, cuda):
+    """BASELINE configs[4]: one scene, N=65536, npoint=4096, K=64, C=128 bf16 features, r=0.5, fused bf16 MLP."""
+    got, ref, calls = _bf16_case(pn2, oracle, cuda, 1, 65536, 4096, 64, 128, [128, 128], 0.5, 5)
+    assert "pn2_sa_mlp_max_fused_bf16" in calls and got.shape == (1, 4096, 128)
+    scale = np.abs(ref).max()
+    assert np.abs(got - ref).max() <= 4e-3 * scale
