@@ -87,6 +87,15 @@ int pn2_query_ball_point(int b, int n, int m, float radius, int nsample,
                          const float *xyz1, const float *xyz2, int *idx,
                          int *pts_cnt, int arith_mode, void *stream);
 
+/* Multi-radius ball query for MSG set abstraction (util/pointnet_util.py:245-250 calls query_ball_point once per
+ * radius on the same xyz / new_xyz): ONE scan of xyz1, every squared distance tested against all thresholds.
+ * radii, nsamples: host arrays of nradius (1..3) entries; idx[r] (b,m,nsamples[r]) and pts_cnt[r] (b,m): host
+ * arrays of device pointers.  Bit-identical to nradius separate pn2_query_ball_point calls.  PN2_EUNSUP when
+ * nradius > 3 or the hit lists do not fit LDS (sum of nsamples > ~130): call pn2_query_ball_point per radius. */
+int pn2_query_ball_point_multi(int b, int n, int m, int nradius, const float *radii, const int *nsamples,
+                               const float *xyz1, const float *xyz2, int *const *idx, int *const *pts_cnt,
+                               int arith_mode, void *stream);
+
 /* selectionSortLauncher(b,n,m,k,dist,outi,out)  tf_grouping.cu:145-149, tf_grouping.cpp:135.
  * dist (b,m,n) -> outi (b,m,n) int32, out (b,m,n): partial selection sort of the first k positions
  * of every row including the reference's swaps (whole rows bit-identical).  n <= 19200. */

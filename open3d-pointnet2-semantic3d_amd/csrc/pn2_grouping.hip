@@ -304,6 +304,169 @@ int launch_ball_query_lane(int b, int n, int m, float thr, int nsample, const fl
     return PN2_OK;
 }
 
+// ---- multi-radius ball query (MSG set abstraction, util/pointnet_util.py:219-282: one query set, several
+// (radius, nsample) pairs; the reference re-scans xyz once per radius, :245-250) ----------------------------
+// Same lane = query organisation with kBqmWaves candidate segments; every squared distance is computed ONCE and
+// compared with the R thresholds, each radius keeps its own LDS hit lists / row image.  Bit-identical to R
+// separate pn2_query_ball_point calls.
+constexpr int kBqmWaves = 8;  // 8 segments: the R lists of nsample_r 16-bit entries stay within LDS
+constexpr int kBqmThreads = 64 * kBqmWaves;
+constexpr int kBqmMaxR = 3;
+
+struct BqmParams {
+    int n, m, seg, nr;
+    float thr[kBqmMaxR];
+    int ns[kBqmMaxR];
+    const float* xyz1;
+    const float* xyz2;
+    int* idx[kBqmMaxR];
+    int* cnt[kBqmMaxR];
+};
+
+template <int MODE, int R>
+__global__ void __launch_bounds__(kBqmThreads)
+ball_query_multi_kernel(BqmParams p) {
+    extern __shared__ int smem_i[];
+    // per radius r: rows[64][ns_r] | segcnt[W][64] | total[64] | first[64];  then the 16-bit lists [W][ns_r][64]
+    int* rows[R]; int* segcnt[R]; int* total[R]; int* firsth[R];
+    unsigned short* list[R];
+    {
+        int* q = smem_i;
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            rows[r] = q; q += 64 * p.ns[r];
+            segcnt[r] = q; q += kBqmWaves * 64;
+            total[r] = q; q += 64;
+            firsth[r] = q; q += 64;
+        }
+        unsigned short* l = reinterpret_cast<unsigned short*>(q);
+#pragma unroll
+        for (int r = 0; r < R; ++r) { list[r] = l; l += kBqmWaves * p.ns[r] * 64; }
+    }
+    const int n = p.n, m = p.m, seg = p.seg;
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int bi = blockIdx.y;
+    const int q0 = blockIdx.x * 64;
+    const float* __restrict__ xyz1 = p.xyz1 + (size_t)bi * n * 3;
+    const float* __restrict__ xyz2 = p.xyz2 + (size_t)bi * m * 3;
+    const int q = q0 + lane < m ? q0 + lane : m - 1;  // surplus lanes shadow the last query, never stored
+    const float qx = xyz2[q * 3 + 0], qy = xyz2[q * 3 + 1], qz = xyz2[q * 3 + 2];
+    int lo = wave * seg;
+    int hi = lo + seg < n ? lo + seg : n;
+    if (lo > n) lo = n;
+    unsigned short* mylist[R];
+    int cnt[R];
+    float thr[R];
+    int ns[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        mylist[r] = list[r] + wave * p.ns[r] * 64 + lane;
+        cnt[r] = 0; thr[r] = p.thr[r]; ns[r] = p.ns[r];
+    }
+    struct Grp { float c[24]; };
+    auto gload = [&](int k0) {
+        Grp g;
+        const float* __restrict__ pp = xyz1 + (size_t)(k0 < n - 8 ? k0 : (n >= 8 ? n - 8 : 0)) * 3;  // clamped
+#pragma unroll
+        for (int u = 0; u < 24; ++u) g.c[u] = pp[u];
+        return g;
+    };
+    auto append = [&](int k, float sd) {
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            if (sd <= thr[r]) {
+                if (cnt[r] < ns[r]) mylist[r][cnt[r] * 64] = (unsigned short)(k - lo);
+                ++cnt[r];
+            }
+        }
+    };
+    auto gtest = [&](const Grp& g, int k0) {
+        float sd[8];
+        unsigned long long any = 0ull;
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            sd[u] = pn2_sqdist<MODE>(qx - g.c[3 * u], qy - g.c[3 * u + 1], qz - g.c[3 * u + 2]);
+            bool h = false;
+#pragma unroll
+            for (int r = 0; r < R; ++r) h = h || (sd[u] <= thr[r]);
+            any |= __ballot(h);
+        }
+        if (any != 0ull) {  // one branch per 8 candidates in the common "nobody hit" case
+#pragma unroll
+            for (int u = 0; u < 8; ++u) append(k0 + u, sd[u]);
+        }
+    };
+    int k = lo;
+    if (n >= 8) {
+        Grp ga = gload(k), gb = gload(k + 8);
+        for (; k + 16 <= hi; k += 16) {
+            gtest(ga, k);
+            ga = gload(k + 16);
+            gtest(gb, k + 8);
+            gb = gload(k + 24);
+        }
+        if (k + 8 <= hi) { gtest(ga, k); k += 8; }
+    }
+    for (; k < hi; ++k)  // tail (< 8 candidates)
+        append(k, pn2_sqdist<MODE>(qx - xyz1[k * 3 + 0], qy - xyz1[k * 3 + 1], qz - xyz1[k * 3 + 2]));
+#pragma unroll
+    for (int r = 0; r < R; ++r) segcnt[r][wave * 64 + lane] = cnt[r] < ns[r] ? cnt[r] : ns[r];
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        int before = 0, tot = 0, fseg = -1;
+#pragma unroll
+        for (int sgi = 0; sgi < kBqmWaves; ++sgi) {
+            const int c = segcnt[r][sgi * 64 + lane];
+            if (sgi < wave) before += c;
+            if (fseg < 0 && c > 0) fseg = sgi;
+            tot += c;
+        }
+        const int mine = cnt[r] < ns[r] ? cnt[r] : ns[r];
+        for (int e = 0; e < mine; ++e) {
+            const int pos = before + e;
+            if (pos < ns[r]) rows[r][lane * ns[r] + pos] = lo + (int)mylist[r][e * 64];
+        }
+        if (wave == 0) {
+            total[r][lane] = tot < ns[r] ? tot : ns[r];
+            firsth[r][lane] = fseg >= 0 ? fseg * seg + (int)list[r][fseg * ns[r] * 64 + lane] : 0;
+        }
+    }
+    __syncthreads();
+    const int nq = m - q0 < 64 ? m - q0 : 64;
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        int* __restrict__ out = p.idx[r] + ((size_t)bi * m + q0) * ns[r];
+        for (int e = tid; e < nq * ns[r]; e += kBqmThreads) {
+            const int row = e / ns[r], pos = e - row * ns[r];
+            out[e] = pos < total[r][row] ? rows[r][e] : firsth[r][row];  // first-hit padding; empty rows -> 0
+        }
+        if (tid < nq) p.cnt[r][(size_t)bi * m + q0 + tid] = total[r][tid];
+    }
+}
+
+template <int MODE, int R>
+int launch_ball_query_multi(int b, const BqmParams& p, hipStream_t st) {
+    size_t lds = 0;
+    for (int r = 0; r < R; ++r)
+        lds += ((size_t)64 * p.ns[r] + kBqmWaves * 64 + 128) * sizeof(int) + (size_t)kBqmWaves * p.ns[r] * 64 * sizeof(unsigned short);
+    if (lds > 150 * 1024) return PN2_EUNSUP;
+    auto kern = ball_query_multi_kernel<MODE, R>;
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (e != hipSuccess) return (int)e;
+        attr_set = true;
+    }
+    dim3 grid((p.m + 63) / 64, b);
+    kern<<<grid, kBqmThreads, lds, st>>>(p);
+    PN2_RETURN_IF_LAUNCH_FAILED();
+    return PN2_OK;
+}
+
 int g_bq_variant = 0;  // tuning hook (pn2_debug_set(2, v)): 0 = auto, 1 = wave-per-queries kernel, 2 = lane kernel
 
 int g_bq_qpw = 8;  // tuning hook (pn2_debug_set(1, v))
@@ -473,6 +636,35 @@ extern "C" int pn2_query_ball_point(int b, int n, int m, float radius, int nsamp
         case PN2_ARITH_FMA_ALT: return launch_ball_query<PN2_ARITH_FMA_ALT>(b, n, m, thr, nsample, xyz1, xyz2, idx, pts_cnt, st);
         default: return PN2_EINVAL;
     }
+}
+
+// One scan of xyz1 for several (radius, nsample) pairs -- see include/pn2_abi.h.
+extern "C" int pn2_query_ball_point_multi(int b, int n, int m, int nradius, const float* radii, const int* nsamples,
+                                          const float* xyz1, const float* xyz2, int* const* idx, int* const* pts_cnt,
+                                          int arith_mode, void* stream) {
+    if (b <= 0 || n <= 0 || m <= 0 || nradius <= 0) return PN2_EINVAL;
+    if (!radii || !nsamples || !xyz1 || !xyz2 || !idx || !pts_cnt) return PN2_ENULL;
+    if (nradius > kBqmMaxR) return PN2_EUNSUP;
+    if ((long long)n * 3 > 0x7fffffffLL || (long long)m * 3 > 0x7fffffffLL || b > 65535) return PN2_ERANGE;
+    BqmParams p{};
+    p.n = n; p.m = m; p.nr = nradius; p.xyz1 = xyz1; p.xyz2 = xyz2;
+    p.seg = (((n + kBqmWaves - 1) / kBqmWaves) + 3) & ~3;
+    if (p.seg > 65535) return PN2_ERANGE;
+    for (int r = 0; r < nradius; ++r) {
+        if (!(radii[r] > 0.0f) || nsamples[r] <= 0) return PN2_EINVAL;
+        if (!idx[r] || !pts_cnt[r]) return PN2_ENULL;
+        p.thr[r] = ball_threshold(radii[r]); p.ns[r] = nsamples[r]; p.idx[r] = idx[r]; p.cnt[r] = pts_cnt[r];
+    }
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    if (nradius == 1) return pn2_query_ball_point(b, n, m, radii[0], nsamples[0], xyz1, xyz2, idx[0], pts_cnt[0], arith_mode, stream);
+#define PN2_BQM(MODE_) (nradius == 2 ? launch_ball_query_multi<MODE_, 2>(b, p, st) : launch_ball_query_multi<MODE_, 3>(b, p, st))
+    switch (arith_mode) {
+        case PN2_ARITH_STRICT: return PN2_BQM(PN2_ARITH_STRICT);
+        case PN2_ARITH_FMA: return PN2_BQM(PN2_ARITH_FMA);
+        case PN2_ARITH_FMA_ALT: return PN2_BQM(PN2_ARITH_FMA_ALT);
+        default: return PN2_EINVAL;
+    }
+#undef PN2_BQM
 }
 
 // selectionSortLauncher(b,n,m,k,dist,outi,out)  tf_grouping.cu:145-149, tf_grouping.cpp:135

@@ -38,6 +38,41 @@ def query_ball_point(radius, nsample, xyz1, xyz2):
     return idx, cnt
 
 
+def query_ball_point_multi(radius_list, nsample_list, xyz1, xyz2):
+    """[(idx, pts_cnt) for each (radius, nsample)] from ONE scan of xyz1 (pn2_query_ball_point_multi): what
+    pointnet_sa_module_msg needs (util/pointnet_util.py:245-250 runs query_ball_point once per radius).
+    Bit-identical to separate query_ball_point calls; falls back to them when the configuration is unsupported."""
+    import ctypes
+    from .._lib import PN2_EUNSUP
+    if len(radius_list) != len(nsample_list) or len(radius_list) == 0:
+        raise ValueError("radius_list and nsample_list must have the same non-zero length")
+    for radius, nsample in zip(radius_list, nsample_list):
+        if not radius > 0:
+            raise ValueError("QueryBallPoint expects positive radius")
+        if nsample <= 0:
+            raise ValueError("QueryBallPoint expects positive nsample")
+    require_cuda(xyz1, xyz2)
+    R = len(radius_list)
+    if R > 1 and xyz1.dim() == 3 and xyz2.dim() == 3 and xyz1.dtype == torch.float32 and xyz2.dtype == torch.float32:
+        x1, x2 = xyz1.detach().contiguous(), xyz2.detach().contiguous()
+        b, n, _ = x1.shape
+        m = x2.shape[1]
+        idxs = [torch.empty((b, m, int(k)), dtype=torch.int32, device=x1.device) for k in nsample_list]
+        cnts = [torch.empty((b, m), dtype=torch.int32, device=x1.device) for _ in nsample_list]
+        radii = (ctypes.c_float * R)(*[float(r) for r in radius_list])
+        nss = (ctypes.c_int * R)(*[int(k) for k in nsample_list])
+        ip = (ctypes.c_void_p * R)(*[t.data_ptr() for t in idxs])
+        cp = (ctypes.c_void_p * R)(*[t.data_ptr() for t in cnts])
+        with torch.cuda.device(x1.device):
+            rc = lib.pn2_query_ball_point_multi(b, n, m, R, ctypes.cast(radii, ctypes.c_void_p), ctypes.cast(nss, ctypes.c_void_p),
+                                                ptr(x1), ptr(x2), ctypes.cast(ip, ctypes.c_void_p),
+                                                ctypes.cast(cp, ctypes.c_void_p), int(config.arith_mode), stream_ptr())
+        if rc != PN2_EUNSUP:
+            check(rc, "pn2_query_ball_point_multi")
+            return list(zip(idxs, cnts))
+    return [query_ball_point(r, k, xyz1, xyz2) for r, k in zip(radius_list, nsample_list)]
+
+
 class _GroupPoint(torch.autograd.Function):
     @staticmethod
     def forward(ctx, points, idx):

@@ -17,7 +17,7 @@ import torch
 
 from . import tf_util
 from .._lib import PN2_EUNSUP, Pn2Error, check, lib, ptr, require_cuda, stream_ptr
-from ..tf_ops.tf_grouping import group_point, knn_point, query_ball_point
+from ..tf_ops.tf_grouping import query_ball_point_multi, group_point, knn_point, query_ball_point
 from ..tf_ops.tf_interpolate import three_interpolate, three_nn
 from ..tf_ops.tf_sampling import farthest_point_sample, farthest_point_sample_and_gather, gather_point
 
@@ -56,9 +56,11 @@ def sample_and_group_all(xyz, points, use_xyz=True):
     return new_xyz, new_points, idx, grouped_xyz
 
 
-def _sa_fused_inference(xyz, new_xyz, points, idx, mlp, bn, conv_scope_fmt, pool=True):
+def _sa_fused_inference(xyz, new_xyz, points, idx, mlp, bn, conv_scope_fmt, pool=True, xyz_last=False):
     """Try the fully fused gather+MLP(+max) kernel; returns None if the configuration is outside what
-    pn2_sa_mlp_max_fused / pn2_sa_mlp_rows_fused (pool=False: un-pooled (B,M,K,w) output) support."""
+    pn2_sa_mlp_max_fused / pn2_sa_mlp_rows_fused (pool=False: un-pooled (B,M,K,w) output) support.
+    xyz_last: the layer's variables expect [features | xyz] (the MSG module's order); the kernel always feeds
+    [xyz | features], so the first layer's weight rows are rotated accordingly (same products, same sum)."""
     b, n, _ = xyz.shape
     m, nsample = idx.shape[1], idx.shape[2]
     c = 0 if points is None else points.shape[2]
@@ -74,7 +76,8 @@ def _sa_fused_inference(xyz, new_xyz, points, idx, mlp, bn, conv_scope_fmt, pool
     cin = 3 + c
     for i, cout in enumerate(mlp):
         with tf_util.variable_scope(conv_scope_fmt % i):
-            w2, b2 = tf_util.folded_dense(cin, cout, bn, (1, 1, cin, cout))
+            w2, b2 = tf_util.folded_dense(cin, cout, bn, (1, 1, cin, cout),
+                                          rotate_rows=3 if (xyz_last and i == 0 and c > 0) else 0)
         ws.append(w2)
         bs.append(b2)
         cin = cout
@@ -210,8 +213,17 @@ def pointnet_sa_module_msg(xyz, points, npoint, radius_list, nsample_list, mlp_l
         xyz = xyz.contiguous()
         new_xyz = gather_point(xyz, farthest_point_sample(npoint, xyz))
         outs = []
+        # one scan of xyz for all radii (the reference re-scans once per radius, :245-250)
+        queries = query_ball_point_multi(radius_list, nsample_list, xyz, new_xyz)
         for i, (radius, nsample) in enumerate(zip(radius_list, nsample_list)):
-            idx, _ = query_ball_point(radius, nsample, xyz, new_xyz)
+            idx = queries[i][0]
+            if (not is_training) and USE_FUSED_SA and (use_xyz or points is None):
+                # gather + MLP + max in one kernel; this module's [features | xyz] order is absorbed into the weights
+                fused = _sa_fused_inference(xyz, new_xyz, points, idx, mlp_list[i], bn, "conv%d_" % i + "%d",
+                                            xyz_last=True)
+                if fused is not None:
+                    outs.append(fused)
+                    continue
             grouped_xyz = group_point(xyz, idx) - new_xyz.unsqueeze(2)
             if points is not None:
                 grouped_points = group_point(points, idx)

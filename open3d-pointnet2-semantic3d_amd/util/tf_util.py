@@ -132,11 +132,13 @@ def _dense_variables(cin, cout, bn, kernel_shape):
     return st, w, b, (beta, gamma, mean, var)
 
 
-def folded_dense(cin, cout, bn, kernel_shape, pad_to=None, pad_in=None):
+def folded_dense(cin, cout, bn, kernel_shape, pad_to=None, pad_in=None, rotate_rows=0):
     """(W', b') with the inference BatchNorm folded in:
-    y = (x@W + b - mean)/sqrt(var+eps)*gamma + beta = x@(W*s) + ((b-mean)*s + beta)."""
+    y = (x@W + b - mean)/sqrt(var+eps)*gamma + beta = x@(W*s) + ((b-mean)*s + beta).
+    rotate_rows = r moves the LAST r input rows of W' to the front (a kernel that feeds [xyz | features] to a
+    layer whose variables were created for [features | xyz], pointnet_util.py:259)."""
     st, w, b, bnv = _dense_variables(cin, cout, bn, kernel_shape)
-    key = (_full_name("folded"), pad_to, pad_in)
+    key = (_full_name("folded"), pad_to, pad_in, rotate_rows)
 
     def make():
         w2 = w.detach().reshape(cin, cout)
@@ -150,6 +152,8 @@ def folded_dense(cin, cout, bn, kernel_shape, pad_to=None, pad_in=None):
             padc = pad_to - cout % pad_to
             w2 = F.pad(w2, (0, padc))
             b2 = F.pad(b2, (0, padc))
+        if rotate_rows:
+            w2 = torch.cat([w2[cin - rotate_rows:], w2[:cin - rotate_rows]], dim=0)
         if pad_in is not None and pad_in > cin:  # zero rows for zero-padded input columns
             w2 = F.pad(w2, (0, 0, 0, pad_in - cin))
         return w2.contiguous(), b2.contiguous()

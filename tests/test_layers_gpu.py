@@ -569,6 +569,23 @@ def test_sa_module_msg_vs_oracle(pn2, oracle, cuda):
     assert np.array_equal(new_xyz.cpu().numpy(), nx)
     assert new_points.shape == (2, 128, 64 + 128 + 128)
     close(new_points.cpu().numpy(), np.concatenate(outs, -1))
+    # the K=32 scale runs on the fused kernel (weights rotated to the kernel's [xyz | features] order), all three
+    # ball queries come from ONE multi-radius scan, and the unfused path gives the same numbers
+    calls = []
+    pn2._lib.lib.trace = calls
+    try:
+        pu.pointnet_sa_module_msg(*args, scope="msg")
+    finally:
+        pn2._lib.lib.trace = None
+    names = [c_[0] for c_ in calls]
+    assert names.count("pn2_query_ball_point_multi") == 1 and "pn2_query_ball_point" not in names
+    assert "pn2_sa_mlp_max_fused" in names
+    pu.USE_FUSED_SA = False
+    try:
+        _, unfused = pu.pointnet_sa_module_msg(*args, scope="msg")
+    finally:
+        pu.USE_FUSED_SA = True
+    np.testing.assert_allclose(new_points.cpu().numpy(), unfused.cpu().numpy(), rtol=1e-5, atol=1e-5)
 
 
 def test_large_scene_config4_shapes(pn2, oracle, cuda):

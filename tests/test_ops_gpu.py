@@ -477,3 +477,38 @@ def test_interpolate_label_large(pn2, oracle, cuda):
     perm = rs.permutation(nd)
     lab2, _ = pn2.interpolate_label_with_color(T(sp, cuda), T(sl, cuda), T(dp[perm], cuda), 3)
     assert np.array_equal(lab2.cpu().numpy(), lab[perm])
+
+
+# ------------------------------------------------------------------ multi-radius ball query (configs[2]) -----
+@pytest.mark.parametrize("case", ["scene", "grid", "tiny", "dense"])
+@pytest.mark.parametrize("mode", [0, 1, 2])
+def test_query_ball_point_multi_equals_separate_calls(pn2, oracle, cuda, case, mode):
+    """One scan for several (radius, nsample) pairs == separate query_ball_point calls == the oracle, bit for bit."""
+    pn2.config.arith_mode = mode
+    try:
+        if case == "scene":
+            xyz, m, radii, ks = s_scene(11, 3, 4096), 512, [0.25, 0.5, 1.0], [16, 32, 64]
+        elif case == "grid":  # exact arithmetic, many points exactly on a radius
+            xyz, m, radii, ks = s_grid(4, 2, 2000, 16), 200, [0.125, 0.25], [8, 32]
+        elif case == "tiny":  # fewer than 8 points per segment, m not a multiple of 64
+            xyz, m, radii, ks = s_randn(5, 2, 37), 13, [0.5, 1.0, 3.0], [4, 16, 48]
+        else:  # every point inside every radius: early-full lists, first-nsample-in-index-order semantics
+            xyz, m, radii, ks = (s_scene(12, 2, 3000) * np.float32(0.01)), 100, [1.0, 2.0, 5.0], [16, 32, 64]
+        new_xyz = xyz[:, :m].copy()
+        multi = pn2.tf_ops.tf_grouping.query_ball_point_multi(radii, ks, T(xyz, cuda), T(new_xyz, cuda))
+        for (idx, cnt), r, k in zip(multi, radii, ks):
+            si, sc = pn2.query_ball_point(r, k, T(xyz, cuda), T(new_xyz, cuda))
+            oi, oc = oracle.query_ball_point(r, k, xyz, new_xyz, mode)
+            assert np.array_equal(idx.cpu().numpy(), oi) and np.array_equal(cnt.cpu().numpy(), oc)
+            assert np.array_equal(si.cpu().numpy(), oi) and np.array_equal(sc.cpu().numpy(), oc)
+    finally:
+        pn2.config.arith_mode = 1
+
+
+def test_query_ball_point_multi_falls_back_when_lists_do_not_fit(pn2, oracle, cuda):
+    xyz = s_scene(13, 1, 2048)
+    new_xyz = xyz[:, :64].copy()
+    res = pn2.tf_ops.tf_grouping.query_ball_point_multi([0.3, 0.6, 1.2], [64, 128, 128], T(xyz, cuda), T(new_xyz, cuda))
+    for (idx, cnt), r, k in zip(res, [0.3, 0.6, 1.2], [64, 128, 128]):
+        oi, oc = oracle.query_ball_point(r, k, xyz, new_xyz)
+        assert np.array_equal(idx.cpu().numpy(), oi) and np.array_equal(cnt.cpu().numpy(), oc)
