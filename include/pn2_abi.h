@@ -154,8 +154,9 @@ int pn2_linear(int rows, int cin, int cout, const float *x, const float *w,
  *   xyz (b,n,3)  new_xyz (b,m,3)  points (b,n,c) or NULL (c = 0)  idx (b,m,nsample)
  *   w[l] (cin_l, widths[l]) row-major with cin_0 = 3 + c;  bias[l] (widths[l])
  *   out (b,m,widths[nlayers-1])
- * Constraints: nsample == 32, 1 <= nlayers <= 3, widths multiples of 32, <= 128
- * (returns PN2_EUNSUP otherwise: callers fall back to pn2_group_point + pn2_linear). */
+ * Constraints: nsample 16, 32, 64, 128 or 256 (32 is the native tile; 16 needs b*m even), 1 <= nlayers <= 3,
+ * widths multiples of 32, <= 128 and a supported layer pattern (returns PN2_EUNSUP otherwise: callers fall back
+ * to pn2_group_point + pn2_linear). */
 int pn2_sa_mlp_max_fused(int b, int n, int m, int nsample, int c, const float *xyz,
                          const float *new_xyz, const float *points, const int *idx,
                          int nlayers, const int *widths, const float *const *w,

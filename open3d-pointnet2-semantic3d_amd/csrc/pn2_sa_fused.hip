@@ -30,7 +30,8 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 struct SaFusedParams {
-    int n, m, c, groups;  // groups = b*m (gather mode) or ceil(rows/32) (dense mode)
+    int n, m, c, groups;  // groups = 32-row tiles: b*m*K/32 (gather mode) or ceil(rows/32) (dense mode)
+    int kshift;           // gather mode: log2(K), K = neighbours per centre (16, 32, 64, 128, ...)
     int rows;             // dense mode: number of input rows
     int w[3];             // layer widths
     const float* xyz;
@@ -162,6 +163,37 @@ __device__ __forceinline__ void pool_store(const f32x16 (&acc)[NT], const float*
     }
 }
 
+// pooled epilogue for K != 32 (kshift != 5): K = 16 -> the tile holds two centres (rows 0..15 = accumulator
+// registers 0..7 of both half-waves, rows 16..31 = registers 8..15); K = 32*t -> t tiles share a centre and merge
+// their maxima with an integer atomicMax on the zero-initialised output (values are post-ReLU, >= +0).
+template <int NT>
+__device__ __forceinline__ void pool_store_k(const f32x16 (&acc)[NT], const float* __restrict__ sbias,
+                                             float* __restrict__ out, int wout, int g, int kshift, int half, int l31) {
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+        const float bv = sbias[nt * 32 + l31];
+        if (kshift == 4) {
+            float v0 = acc[nt][0], v1 = acc[nt][8];
+#pragma unroll
+            for (int r = 1; r < 8; ++r) { v0 = fmaxf(v0, acc[nt][r]); v1 = fmaxf(v1, acc[nt][8 + r]); }
+            v0 = fmaxf(v0, __shfl_xor(v0, 32));
+            v1 = fmaxf(v1, __shfl_xor(v1, 32));
+            if (half == 0) {
+                out[(size_t)(2 * g) * wout + nt * 32 + l31] = fmaxf(v0 + bv, 0.f);
+                out[(size_t)(2 * g + 1) * wout + nt * 32 + l31] = fmaxf(v1 + bv, 0.f);
+            }
+        } else {
+            float v = acc[nt][0];
+#pragma unroll
+            for (int r = 1; r < 16; ++r) v = fmaxf(v, acc[nt][r]);
+            v = fmaxf(v, __shfl_xor(v, 32));
+            v = fmaxf(v + bv, 0.f);
+            if (half == 0)
+                atomicMax(reinterpret_cast<int*>(out + (size_t)(g >> (kshift - 5)) * wout + nt * 32 + l31), __float_as_int(v));
+        }
+    }
+}
+
 // last-layer epilogue without pooling: relu(acc + bias) for all 32 rows of the tile
 template <int NT>
 __device__ __forceinline__ void rows_store(const f32x16 (&acc)[NT], const float* __restrict__ sbias,
@@ -288,12 +320,15 @@ sa_fused_kernel(SaFusedParams p) {
             const int row = g * 32 + l31;
             prow = (size_t)(row < p.rows ? row : p.rows - 1);
         } else {
-            const int bi = g / p.m;
+            // tile g = rows [32g, 32g+32) of the flat (b*m*K) neighbour list; K = 32: one centre per tile,
+            // K = 16: two centres per tile, K = 64, 128, ...: a centre spans several tiles (max merged at the end)
+            const int grp = (g * 32 + l31) >> p.kshift;
+            const int bi = grp / p.m;
             const int ii = p.idx[(size_t)g * 32 + l31];
             prow = (size_t)bi * p.n + ii;
-            const float cxv = p.new_xyz[(size_t)g * 3 + 0];
-            const float cyv = p.new_xyz[(size_t)g * 3 + 1];
-            const float czv = p.new_xyz[(size_t)g * 3 + 2];
+            const float cxv = p.new_xyz[(size_t)grp * 3 + 0];
+            const float cyv = p.new_xyz[(size_t)grp * 3 + 1];
+            const float czv = p.new_xyz[(size_t)grp * 3 + 2];
             const float rx = p.xyz[prow * 3 + 0] - cxv;  // grouped_xyz -= tile(new_xyz) :44-46
             const float ry = p.xyz[prow * 3 + 1] - cyv;
             const float rz = p.xyz[prow * 3 + 2] - czv;
@@ -371,7 +406,10 @@ sa_fused_kernel(SaFusedParams p) {
         }
         float* __restrict__ orow = p.out + (size_t)g * WOUT;
         if constexpr (L == 1) {
-            if constexpr (POOL) pool_store<NT1>(a1, sb1, orow, half, l31);
+            if constexpr (POOL) {
+                if (DENSE || p.kshift == 5) pool_store<NT1>(a1, sb1, orow, half, l31);
+                else pool_store_k<NT1>(a1, sb1, p.out, WOUT, g, p.kshift, half, l31);
+            }
             else rows_store<NT1>(a1, sb1, p.out, WOUT, g * 32, p.rows, half, l31);
         } else {
             bias_relu_T<NT1>(a1, sb1, half);
@@ -379,14 +417,20 @@ sa_fused_kernel(SaFusedParams p) {
             zero_acc<NT2>(a2);
             layer_from_regs<NT1, NT2, L == 2>(a1, a2, wp2, W2, half, l31);
             if constexpr (L == 2) {
-                if constexpr (POOL) pool_store<NT2>(a2, sb2, orow, half, l31);
+                if constexpr (POOL) {
+                if (DENSE || p.kshift == 5) pool_store<NT2>(a2, sb2, orow, half, l31);
+                else pool_store_k<NT2>(a2, sb2, p.out, WOUT, g, p.kshift, half, l31);
+            }
                 else rows_store<NT2>(a2, sb2, p.out, WOUT, g * 32, p.rows, half, l31);
             } else {
                 bias_relu_T<NT2>(a2, sb2, half);
                 f32x16 a3[NT3];
                 zero_acc<NT3>(a3);
                 layer_from_regs<NT2, NT3, true>(a2, a3, wp3, W3, half, l31);
-                if constexpr (POOL) pool_store<NT3>(a3, sb3, orow, half, l31);
+                if constexpr (POOL) {
+                if (DENSE || p.kshift == 5) pool_store<NT3>(a3, sb3, orow, half, l31);
+                else pool_store_k<NT3>(a3, sb3, p.out, WOUT, g, p.kshift, half, l31);
+            }
                 else rows_store<NT3>(a3, sb3, p.out, WOUT, g * 32, p.rows, half, l31);
             }
         }
@@ -489,10 +533,17 @@ static int sa_fused_impl(int b, int n, int m, int nsample, int c, const float* x
                          const float* const* bias, float* out, bool pool, void* stream) {
     if (b <= 0 || n <= 0 || m <= 0 || nsample <= 0 || c < 0 || nlayers <= 0) return PN2_EINVAL;
     if (!xyz || !new_xyz || !idx || !widths || !w || !bias || !out || (c > 0 && !points)) return PN2_ENULL;
-    if (nsample != 32 || nlayers > 3) return PN2_EUNSUP;
-    if ((long long)b * m > 0x7fffffffLL / 32) return PN2_ERANGE;
+    if (nlayers > 3) return PN2_EUNSUP;
+    // K = 32 is the native tile; 16 (two centres per tile) and 64, 128, 256 (several tiles per centre) reuse it
+    int kshift = 0;
+    while ((1 << kshift) < nsample) ++kshift;
+    if ((1 << kshift) != nsample || kshift < 4 || kshift > 8) return PN2_EUNSUP;
+    if (kshift != 5 && !pool) return PN2_EUNSUP;
+    if (kshift == 4 && (((long long)b * m) & 1)) return PN2_EUNSUP;
+    if ((long long)b * m * nsample > 0x7fffffffLL - 64) return PN2_ERANGE;
     SaFusedParams p{};
-    p.n = n; p.m = m; p.c = c; p.groups = b * m; p.rows = b * m * 32;
+    p.n = n; p.m = m; p.c = c; p.kshift = kshift;
+    p.groups = (int)(((long long)b * m * nsample) / 32); p.rows = p.groups * 32;
     p.xyz = xyz; p.new_xyz = new_xyz; p.points = points; p.idx = idx; p.out = out;
     int nt[3] = {0, 0, 0};
     for (int l = 0; l < nlayers; ++l) {
@@ -504,6 +555,10 @@ static int sa_fused_impl(int b, int n, int m, int nsample, int c, const float* x
     }
     const bool vec8 = c > 0 && (c % 8 == 0) && ((uintptr_t)points % 16 == 0);
     hipStream_t st = static_cast<hipStream_t>(stream);
+    if (kshift > 5) {  // tiles of one centre merge through atomicMax: start from +0
+        hipError_t e = hipMemsetAsync(out, 0, sizeof(float) * (size_t)b * m * widths[nlayers - 1], st);
+        if (e != hipSuccess) return (int)e;
+    }
     const int key = nlayers * 1000 + nt[0] * 100 + nt[1] * 10 + nt[2];
     if (!pool) {
         // un-pooled variant: only the shapes the model needs ([*,128,128] prefixes)

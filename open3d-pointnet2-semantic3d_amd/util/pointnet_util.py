@@ -68,7 +68,7 @@ def _sa_fused_inference(xyz, new_xyz, points, idx, mlp, bn, conv_scope_fmt, pool
     if bf16:
         if not pool or nsample not in (32, 64) or c % 16 != 0:
             return None
-    elif nsample != 32:
+    elif nsample != 32 and (not pool or nsample not in (16, 64, 128, 256)):
         return None
     if len(mlp) > 3 or any(w % 32 != 0 or w > 128 for w in mlp):
         return None

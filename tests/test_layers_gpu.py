@@ -135,6 +135,32 @@ def test_sa_module_inference_vs_oracle(pn2, oracle, cuda, case, fused):
     close(new_points.cpu().numpy(), r_pts)
 
 
+@pytest.mark.parametrize("K,npoint,c,mlp", [(16, 64, 3, [32, 32, 64]), (64, 96, 64, [64, 64, 128]), (128, 50, 8, [128]),
+                                            (16, 33 * 2, 0, [32, 32, 64]), (64, 7, 3, [64, 128])])
+def test_sa_fused_other_neighbourhood_sizes(pn2, oracle, cuda, K, npoint, c, mlp):
+    """The fused gather+MLP+max kernel for K != 32: two centres per 32-row tile (K=16) or several tiles per centre
+    merged with atomicMax (K=64,128), against the oracle."""
+    tfu, pu = pn2.util.tf_util, pn2.util.pointnet_util
+    rs = np.random.RandomState(K + npoint)
+    xyz = s_scene(K, 2, 1500)
+    pts = rs.randn(2, 1500, c).astype(np.float32) if c else None
+    store = tfu.set_default_store(tfu.VariableStore(device=cuda, seed=K))
+    args = (T(xyz, cuda), None if pts is None else T(pts, cuda), npoint, 1.2, K, mlp, None, False, False, None)
+    pu.pointnet_sa_module(*args, scope="sa")
+    randomize_bn(store, K + 1)
+    calls = []
+    pn2._lib.lib.trace = calls
+    try:
+        new_xyz, new_points, idx = pu.pointnet_sa_module(*args, scope="sa")
+    finally:
+        pn2._lib.lib.trace = None
+    assert "pn2_sa_mlp_max_fused" in [c_[0] for c_ in calls] and "pn2_linear" not in [c_[0] for c_ in calls]
+    layers = layer_dicts(store, "sa", ["conv%d" % i for i in range(len(mlp))])
+    rx, rp, ri = oracle.sa_module(xyz, pts, npoint, 1.2, K, layers)
+    assert np.array_equal(idx.cpu().numpy(), ri)
+    close(new_points.cpu().numpy(), rp)
+
+
 def test_sa_module_k16_config0(pn2, oracle, cuda):
     """BASELINE config[0]: B=2, N=1024, npoint=256, K=16, C=3, r=0.2 (K=16 -> unfused path with pool=16)."""
     tfu, pu = pn2.util.tf_util, pn2.util.pointnet_util
