@@ -403,6 +403,11 @@ def main():
             "single_batch_latency_ms": None if latency_ms is None else round(latency_ms, 4),
             "gpu_ms_per_step_sum_of_kernels": round(sum(k["ms_per_step"] for k in kernels), 4),
         }
+        if dom["kernel"] in ("farthest_point_sample", "fps_gather"):
+            # FPS is reported by its own work unit as well -- dependent rounds and distance evaluations
+            fb, fn, fm = dom["args"][:3]
+            res["roofline"]["ns_per_round"] = round(dom["avg_us"] * 1e3 / max(1, fm - 1), 1)
+            res["roofline"]["distance_evals_per_s"] = round(fb * (fm - 1) * fn / (dom["avg_us"] * 1e-6), 1)
         if not args.no_north_star:
             try:
                 res["north_star"] = north_star_kernels(pn2, dev)
