@@ -248,6 +248,36 @@ def cpu_baseline(pn2, store, pc, hp):
                       % (passes, pc.shape[0], pc.shape[1])}
 
 
+def bench_train(pn2, args, hp, B, N, rank, world, dev):
+    """configs[3]: every rank trains on its own 16 scenes; the only collective is the flat gradient all-reduce."""
+    rs = np.random.RandomState(100 + rank)
+    pc = torch.from_numpy(np.concatenate([s_scene(3000 + rank, B, N), rs.random_sample((B, N, 3)).astype(np.float32)], 2)).to(dev)
+    labels = torch.from_numpy(rs.randint(0, 9, (B, N)).astype(np.int64)).to(dev)
+    smpw = torch.from_numpy((rs.random_sample((B, N)) + 0.5).astype(np.float32)).to(dev)
+    tr = pn2.train.Trainer(hp, 9, store=pn2.util.tf_util.VariableStore(device=dev, seed=0), device=dev)
+    for _ in range(max(1, args.warmup)):
+        tr.train_step(pc, labels, smpw)
+    pn2.dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss = tr.train_step(pc, labels, smpw)
+    torch.cuda.synchronize()
+    pn2.dist.barrier()
+    elapsed = pn2.dist.max_over_ranks(time.perf_counter() - t0, device=dev)
+    if rank == 0:
+        print(json.dumps({
+            "metric": "training points/sec through SA+FP stack + head (B=16/GPU, N=%d)" % N,
+            "value": round(world * B * N * args.steps / elapsed, 1), "unit": "points/s", "n_gpus": world,
+            "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 4),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "configs[3]: data-parallel training, %d scenes x %d points per GPU, semantic.json, "
+                                   "batch-stat BN, weighted CE, Adam, one flat gradient all-reduce (%d parameters)"
+                                   % (B, N, tr.store.num_parameters()),
+                       "global_batch": world * B, "parallelism": "dp%d" % world},
+            "last_loss": loss}))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -272,6 +302,9 @@ def main():
     ap.add_argument("--fp-front", choices=("auto", "fused", "unfused"), default="auto",
                     help="FP front end inside the first FP4 MLP kernel (pn2_fp_mlp_fused) or materialised by "
                          "pn2_fp_interp_concat; auto = fused (faster at every pipeline depth with one stream per batch)")
+    ap.add_argument("--train", action="store_true",
+                    help="BASELINE configs[3] instead of the headline: data-parallel TRAINING steps (forward with batch-stat "
+                         "BN + weighted CE + backward + one flat RCCL gradient all-reduce + Adam), 16 scenes per GPU")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -291,6 +324,8 @@ def main():
     hp = dict(pn2.model.SEMANTIC_HYPERPARAMS)
     hp["batch_size"], hp["num_point"] = args.batch, args.points
     B, N = args.batch, args.points
+    if args.train:
+        return bench_train(pn2, args, hp, B, N, rank, world, dev)
 
     pc_np = s_scene(1000 + rank, B, N)        # each rank its own scenes (weak scaling)
     pc = torch.from_numpy(pc_np).to(dev)      # resident in HBM before the timed region
