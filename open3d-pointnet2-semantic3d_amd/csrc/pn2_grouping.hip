@@ -506,17 +506,29 @@ int g_gp_variant = 0;  // tuning hook (pn2_debug_set(3, v)): bit0 = plain stores
 template <typename VT, int VEC, int UNR, bool NT>
 __global__ void __launch_bounds__(256)
 group_point_kernel(int n, int c, unsigned per_batch_rows, const float* __restrict__ points_all,
-                   const int* __restrict__ idx_all, float* __restrict__ out_all) {
+                   const int* __restrict__ idx_all, float* __restrict__ out_all, int g_remap) {
     const unsigned cv = (unsigned)c / VEC;
     const unsigned total = per_batch_rows * cv;
-    const int bi = blockIdx.y;
+    // XCD-aware block remap (speed only; workgroup L runs on XCD L % 8): every XCD gathers from whole batch
+    // elements of its own instead of from all of `points`
+    unsigned bx = blockIdx.x;
+    int bi = blockIdx.y;
+    if (g_remap) {
+        const unsigned nwg = gridDim.x * gridDim.y;
+        if ((nwg & 7u) == 0u) {
+            const unsigned lin = blockIdx.x + gridDim.x * blockIdx.y;
+            const unsigned swz = (lin & 7u) * (nwg >> 3) + (lin >> 3);
+            bx = swz % gridDim.x;
+            bi = (int)(swz / gridDim.x);
+        }
+    }
     const VT* __restrict__ points = reinterpret_cast<const VT*>(points_all + (size_t)bi * n * c);
     const int* __restrict__ idx = idx_all + (size_t)bi * per_batch_rows;
     VT* __restrict__ out = reinterpret_cast<VT*>(out_all + (size_t)bi * per_batch_rows * c);
     const bool pow2 = (cv & (cv - 1)) == 0;
     const unsigned sh = 31 - __builtin_clz(cv | 1u);
     const unsigned stride = gridDim.x * blockDim.x;
-    for (unsigned e0 = blockIdx.x * blockDim.x + threadIdx.x; e0 < total; e0 += stride * UNR) {
+    for (unsigned e0 = bx * blockDim.x + threadIdx.x; e0 < total; e0 += stride * UNR) {
         VT v[UNR];
 #pragma unroll
         for (int u = 0; u < UNR; ++u) {
@@ -705,11 +717,11 @@ extern "C" int pn2_group_point(int b, int n, int c, int m, int nsample, const fl
             gx = (int)(g < cap ? (g < 1 ? 1 : g) : cap);
         }
         dim3 grid(gx, b);
-        if (g_gp_variant & 1) group_point_kernel<f32x4, 4, 4, false><<<grid, 256, 0, st>>>(n, c, (unsigned)rows, points, idx, out);
-        else group_point_kernel<f32x4, 4, 4, true><<<grid, 256, 0, st>>>(n, c, (unsigned)rows, points, idx, out);
+        if (g_gp_variant & 1) group_point_kernel<f32x4, 4, 4, false><<<grid, 256, 0, st>>>(n, c, (unsigned)rows, points, idx, out, (g_gp_variant & 2) ? 0 : 1);
+        else group_point_kernel<f32x4, 4, 4, true><<<grid, 256, 0, st>>>(n, c, (unsigned)rows, points, idx, out, (g_gp_variant & 2) ? 0 : 1);
     } else {
         dim3 grid(grid_x_for(rows * c, 256, b), b);
-        group_point_kernel<float, 1, 4, true><<<grid, 256, 0, st>>>(n, c, (unsigned)rows, points, idx, out);
+        group_point_kernel<float, 1, 4, true><<<grid, 256, 0, st>>>(n, c, (unsigned)rows, points, idx, out, (g_gp_variant & 2) ? 0 : 1);
     }
     PN2_RETURN_IF_LAUNCH_FAILED();
     return PN2_OK;
