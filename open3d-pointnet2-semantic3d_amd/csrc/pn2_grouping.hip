@@ -467,7 +467,255 @@ int launch_ball_query_multi(int b, const BqmParams& p, hipStream_t st) {
     return PN2_OK;
 }
 
-int g_bq_variant = 0;  // tuning hook (pn2_debug_set(2, v)): 0 = auto, 1 = wave-per-queries kernel, 2 = lane kernel
+// ---- ball query on a per-block uniform grid -------------------------------------------------------------
+// For clouds that fit LDS (n <= kBqgMaxN) every workgroup (64 consecutive queries of one batch element, 16
+// waves) first bins the whole cloud into a uniform grid IN LDS -- bounding box, cell ids, histogram, prefix
+// sum, scatter of (x, y, z, index) in cell order -- and then each wave answers 4 queries by testing only the
+// 27 cells around the query with the reference's own fp32 expression.  Cells are at least radius*(1+1e-4)
+// wide, so every point with sqrtf(d2) < radius lies in those cells; the hits (typically < 32 of ~100
+// candidates instead of a scan over all n points) are ordered by index with a rank pass, which reproduces
+// "first nsample in index order" (tf_grouping.cu:18-37).  A query with more than kBqgCap hits (dense clouds)
+// is re-done by an ordered early-exit scan over the cloud.  Results are bit-identical to the scan kernels.
+constexpr int kBqgThreads = 1024;
+constexpr int kBqgWaves = kBqgThreads / 64;
+constexpr int kBqgMaxN = 8192;
+constexpr int kBqgPPT = kBqgMaxN / kBqgThreads;  // points per thread while building
+constexpr int kBqgDim = 16;                       // cells per axis (at most)
+constexpr int kBqgCells = kBqgDim * kBqgDim * kBqgDim;
+constexpr int kBqgCap = 64;                       // hits per query kept before falling back
+constexpr int kBqgQPW = 4;                        // queries per wave (64 per workgroup)
+
+struct BqgGrid {
+    float lo[3], inv_h[3];
+    int dim[3];
+};
+
+__device__ __forceinline__ int bqg_cell1(float x, float lo, float inv_h, int dim) {
+    int c = (int)floorf((x - lo) * inv_h);
+    return c < 0 ? 0 : (c >= dim ? dim - 1 : c);
+}
+
+template <int MODE>
+__global__ void __launch_bounds__(kBqgThreads)
+ball_query_grid_kernel(int n, int m, float radius, float thr, int nsample, const float* __restrict__ xyz1_all,
+                       const float* __restrict__ xyz2_all, int* __restrict__ idx_all, int* __restrict__ cnt_all) {
+    extern __shared__ int smem_i[];
+    // layout (np = n rounded up to 64): sx[np] sy[np] sz[np] | ccount[kBqgCells+1] | rowbuf[W][64] | red[W][6] |
+    //         grid | sidx[np] (u16) | cstart[kBqgCells+1] (u16) | hits[W][4][kBqgCap] (u16)
+    const int np = (n + 63) & ~63;
+    float* sx = reinterpret_cast<float*>(smem_i);
+    float* sy = sx + np;
+    float* sz = sy + np;
+    int* ccount = reinterpret_cast<int*>(sz + np);
+    int* rowbuf = ccount + kBqgCells + 1;
+    float* red = reinterpret_cast<float*>(rowbuf + kBqgWaves * 64);
+    BqgGrid* grid = reinterpret_cast<BqgGrid*>(red + kBqgWaves * 6);
+    unsigned short* sidx = reinterpret_cast<unsigned short*>(grid + 1);
+    unsigned short* cstart = sidx + np;
+    unsigned short* hits = cstart + kBqgCells + 2;
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int bi = blockIdx.y;
+    const float* __restrict__ xyz1 = xyz1_all + (size_t)bi * n * 3;
+    const float* __restrict__ xyz2 = xyz2_all + (size_t)bi * m * 3;
+
+    // ---- build: bounding box ------------------------------------------------------------------------
+    float px[kBqgPPT], py[kBqgPPT], pz[kBqgPPT];
+    float mn[3] = {INFINITY, INFINITY, INFINITY}, mx[3] = {-INFINITY, -INFINITY, -INFINITY};
+#pragma unroll
+    for (int j = 0; j < kBqgPPT; ++j) {
+        const int k = tid + kBqgThreads * j;
+        const int kc = k < n ? k : n - 1;
+        px[j] = xyz1[kc * 3 + 0]; py[j] = xyz1[kc * 3 + 1]; pz[j] = xyz1[kc * 3 + 2];
+        mn[0] = fminf(mn[0], px[j]); mx[0] = fmaxf(mx[0], px[j]);
+        mn[1] = fminf(mn[1], py[j]); mx[1] = fmaxf(mx[1], py[j]);
+        mn[2] = fminf(mn[2], pz[j]); mx[2] = fmaxf(mx[2], pz[j]);
+    }
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            mn[a] = fminf(mn[a], __shfl_xor(mn[a], o));
+            mx[a] = fmaxf(mx[a], __shfl_xor(mx[a], o));
+        }
+        if (lane == 0) { red[wave * 6 + a] = mn[a]; red[wave * 6 + 3 + a] = mx[a]; }
+    }
+    for (int e = tid; e < kBqgCells + 1; e += kBqgThreads) ccount[e] = 0;
+    __syncthreads();
+    if (tid == 0) {
+        const float h0 = radius * 1.0001f + 1e-30f;  // every hit is within radius*(1+1e-6) per axis: 27 cells suffice
+        for (int a = 0; a < 3; ++a) {
+            float lo = red[a], hi = red[3 + a];
+            for (int w = 1; w < kBqgWaves; ++w) { lo = fminf(lo, red[w * 6 + a]); hi = fmaxf(hi, red[w * 6 + 3 + a]); }
+            const float ext = hi - lo;
+            float h = fmaxf(h0, ext * (1.00001f / kBqgDim));
+            if (!(h > 0.f) || !(h < 3.0e38f)) h = 1.0f;
+            const float inv = 1.0f / h;
+            int d = (int)floorf(ext * inv) + 1;
+            d = d < 1 ? 1 : (d > kBqgDim ? kBqgDim : d);
+            grid->lo[a] = lo; grid->inv_h[a] = inv; grid->dim[a] = d;
+        }
+    }
+    __syncthreads();
+#ifndef PN2_BQG_STAGE
+#define PN2_BQG_STAGE 9  // tools/bq_stage_ab.py builds truncated variants (timing breakdown only)
+#endif
+    if (PN2_BQG_STAGE < 2) { if (grid->dim[0] == 12345) idx_all[tid] = 1; return; }
+    const BqgGrid G = *grid;
+    // ---- build: histogram -> prefix sum -> scatter -------------------------------------------------------
+    int cell[kBqgPPT];
+#pragma unroll
+    for (int j = 0; j < kBqgPPT; ++j) {
+        const int k = tid + kBqgThreads * j;
+        const int cx = bqg_cell1(px[j], G.lo[0], G.inv_h[0], G.dim[0]);
+        const int cy = bqg_cell1(py[j], G.lo[1], G.inv_h[1], G.dim[1]);
+        const int cz = bqg_cell1(pz[j], G.lo[2], G.inv_h[2], G.dim[2]);
+        cell[j] = (cz * G.dim[1] + cy) * G.dim[0] + cx;
+        if (k < n) atomicAdd(&ccount[cell[j]], 1);
+    }
+    __syncthreads();
+    if (PN2_BQG_STAGE < 3) { if (ccount[tid] == 12345) idx_all[tid] = 1; return; }
+    {   // exclusive scan of ccount[0..kBqgCells): 4 cells per thread, wave scan, wave totals through `red`
+        int v[4], s = 0;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { v[i] = ccount[tid * 4 + i]; s += v[i]; }
+        int inc = s;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const int t = __shfl_up(inc, o);
+            if (lane >= o) inc += t;
+        }
+        int* wtot = reinterpret_cast<int*>(red);
+        if (lane == 63) wtot[wave] = inc;
+        __syncthreads();
+        int base = 0;
+        for (int w = 0; w < wave; ++w) base += wtot[w];
+        int run = base + inc - s;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            cstart[tid * 4 + i] = (unsigned short)run;
+            ccount[tid * 4 + i] = run;  // becomes the scatter cursor
+            run += v[i];
+        }
+        if (tid == kBqgThreads - 1) cstart[kBqgCells] = (unsigned short)run;  // == n
+    }
+    __syncthreads();
+    if (PN2_BQG_STAGE < 4) { if (cstart[tid] == 12345) idx_all[tid] = 1; return; }
+#pragma unroll
+    for (int j = 0; j < kBqgPPT; ++j) {
+        const int k = tid + kBqgThreads * j;
+        if (k < n) {
+            const int pos = atomicAdd(&ccount[cell[j]], 1);
+            sx[pos] = px[j]; sy[pos] = py[j]; sz[pos] = pz[j];
+            sidx[pos] = (unsigned short)k;
+        }
+    }
+    __syncthreads();
+
+    if (PN2_BQG_STAGE < 5) { if (sidx[tid] == 12345) idx_all[tid] = 1; return; }
+    // ---- queries: a wave answers 4 at a time, one per 16-lane group ------------------------------------------
+    // (the 27 cells of a query hold ~100 candidates in 9 short runs: 64-lane steps would idle most lanes)
+    const int grp = lane >> 4, l16 = lane & 15;
+    unsigned short* myhits = hits + (wave * 4 + grp) * kBqgCap;
+    int* myfirst = rowbuf + wave * 4 + grp;
+    const int qbase = blockIdx.x * (kBqgWaves * kBqgQPW) + wave * kBqgQPW;
+    {
+        const int q = qbase + grp;
+        const bool qv = q < m;
+        const int qc = qv ? q : m - 1;
+        const float qx = xyz2[qc * 3 + 0], qy = xyz2[qc * 3 + 1], qz = xyz2[qc * 3 + 2];
+        const int cx = bqg_cell1(qx, G.lo[0], G.inv_h[0], G.dim[0]);
+        const int cy = bqg_cell1(qy, G.lo[1], G.inv_h[1], G.dim[1]);
+        const int cz = bqg_cell1(qz, G.lo[2], G.inv_h[2], G.dim[2]);
+        const int x0 = cx > 0 ? cx - 1 : 0, x1 = cx + 1 < G.dim[0] ? cx + 1 : G.dim[0] - 1;
+        int nh = 0;
+#pragma unroll 1
+        for (int r = 0; r < 9; ++r) {
+            const int z = cz + r / 3 - 1, y = cy + r % 3 - 1;
+            int s0 = 0, e0 = 0;
+            if (qv && z >= 0 && z < G.dim[2] && y >= 0 && y < G.dim[1]) {
+                const int rowc = (z * G.dim[1] + y) * G.dim[0];
+                s0 = cstart[rowc + x0];
+                e0 = cstart[rowc + x1 + 1];  // the 3 x-cells are contiguous in the sorted arrays
+            }
+            for (int p0 = s0; __any(p0 < e0); p0 += 16) {
+                const int p = p0 + l16;
+                const int pc = p < e0 ? p : (e0 > 0 ? e0 - 1 : 0);
+                const float sd = pn2_sqdist<MODE>(qx - sx[pc], qy - sy[pc], qz - sz[pc]);
+                const bool hit = p < e0 && sd <= thr;
+                const unsigned gm = (unsigned)(__ballot(hit) >> (16 * grp)) & 0xffffu;
+                if (hit) {
+                    const int pos = nh + __popc(gm & ((1u << l16) - 1u));
+                    if (pos < kBqgCap) myhits[pos] = sidx[pc];
+                }
+                nh += __popc(gm);
+            }
+        }
+        int cnt = nh < nsample ? nh : nsample;
+        int* __restrict__ out = idx_all + ((size_t)bi * m + qc) * nsample;
+        const bool sparse = nh <= kBqgCap;
+        if (qv && sparse) {
+            // order the hits by index: rank = number of hits with a smaller index (indices are distinct)
+            for (int h = l16; h < nh; h += 16) {
+                const int me = myhits[h];
+                int rank = 0;
+                for (int j = 0; j < nh; ++j) rank += (int)myhits[j] < me ? 1 : 0;
+                if (rank < nsample) out[rank] = me;
+                if (rank == 0) *myfirst = me;
+            }
+        }
+        // queries with more than kBqgCap hits (dense clouds): ordered scan with early exit, the whole wave per query
+        const unsigned long long dense = __ballot(qv && !sparse && l16 == 0);
+        for (int g2 = 0; g2 < 4; ++g2) {
+            if (!((dense >> (16 * g2)) & 1ull)) continue;  // wave-uniform
+            const int q2 = qbase + g2;
+            const float ax = xyz2[q2 * 3 + 0], ay = xyz2[q2 * 3 + 1], az = xyz2[q2 * 3 + 2];
+            int* __restrict__ o2 = idx_all + ((size_t)bi * m + q2) * nsample;
+            int c2 = 0;
+            for (int c0 = 0; c0 < n && c2 < nsample; c0 += 64) {
+                const int k = c0 + lane;
+                const int kc = k < n ? k : n - 1;
+                const float sd = pn2_sqdist<MODE>(ax - xyz1[kc * 3 + 0], ay - xyz1[kc * 3 + 1], az - xyz1[kc * 3 + 2]);
+                const bool hit = k < n && sd <= thr;
+                const unsigned long long mask = __ballot(hit);
+                const int pos = c2 + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32),
+                                                                    __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0u));
+                if (hit && pos < nsample) o2[pos] = k;
+                if (hit && pos == 0) rowbuf[wave * 4 + g2] = k;
+                c2 += __popcll(mask);
+            }
+        }
+        // short rows repeat the first hit (tf_grouping.cu:32-36); empty rows are zero (documented divergence)
+        if (qv) {
+            const int first = cnt > 0 ? *myfirst : 0;
+            for (int l = cnt + l16; l < nsample; l += 16) out[l] = first;
+            if (l16 == 0) cnt_all[(size_t)bi * m + q] = cnt;
+        }
+    }
+}
+
+template <int MODE>
+int launch_ball_query_grid(int b, int n, int m, float radius, float thr, int nsample, const float* xyz1,
+                           const float* xyz2, int* idx, int* cnt, hipStream_t st) {
+    const int np = (n + 63) & ~63;
+    const size_t lds = (size_t)np * 12 + (size_t)(kBqgCells + 1) * 4 + kBqgWaves * 64 * 4 + kBqgWaves * 6 * 4 + sizeof(BqgGrid) +
+                       (size_t)np * 2 + (size_t)(kBqgCells + 2) * 2 + (size_t)kBqgWaves * 4 * kBqgCap * 2 + 64;
+    auto kern = ball_query_grid_kernel<MODE>;
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (e != hipSuccess) return (int)e;
+        attr_set = true;
+    }
+    dim3 grid((m + kBqgWaves * kBqgQPW - 1) / (kBqgWaves * kBqgQPW), b);
+    kern<<<grid, kBqgThreads, lds, st>>>(n, m, radius, thr, nsample, xyz1, xyz2, idx, cnt);
+    PN2_RETURN_IF_LAUNCH_FAILED();
+    return PN2_OK;
+}
+
+int g_bq_variant = 0;  // tuning hook (pn2_debug_set(2, v)): 0 = auto, 1 = wave-per-queries kernel, 2 = lane kernel, 3 = LDS grid kernel
 
 int g_bq_qpw = 8;  // tuning hook (pn2_debug_set(1, v))
 
@@ -483,8 +731,14 @@ int launch_ball_query_q(int b, int n, int m, float thr, int nsample, const float
 }
 
 template <int MODE>
-int launch_ball_query(int b, int n, int m, float thr, int nsample, const float* xyz1,
+int launch_ball_query(int b, int n, int m, float radius, float thr, int nsample, const float* xyz1,
                       const float* xyz2, int* idx, int* cnt, hipStream_t st) {
+    // per-block LDS grid: the whole cloud fits LDS, enough points / queries to amortise building it in every
+    // workgroup, and a neighbourhood size (nsample <= 32 is the caller's own estimate of the hits per ball) for which
+    // the hit lists stay short; dense balls are cheaper on the ordered scan kernels (profiles/r01_ball_query_grid.txt)
+    const bool grid_ok = n <= kBqgMaxN && n >= 4096 && m >= 256 && nsample <= 32 && radius < 1e18f;
+    if ((g_bq_variant == 3 && n <= kBqgMaxN && nsample <= 64 && radius < 1e18f) || (g_bq_variant == 0 && grid_ok))
+        return launch_ball_query_grid<MODE>(b, n, m, radius, thr, nsample, xyz1, xyz2, idx, cnt, st);
     // lane = query kernel whenever its LDS lists fit and there are enough queries to fill 64 lanes
     const bool lane_ok = nsample <= 64 && m >= 32 && n <= 65535 * kBq2Waves;
     if (g_bq_variant == 2 || (g_bq_variant == 0 && lane_ok))
@@ -643,9 +897,9 @@ extern "C" int pn2_query_ball_point(int b, int n, int m, float radius, int nsamp
     hipStream_t st = static_cast<hipStream_t>(stream);
     const float thr = ball_threshold(radius);
     switch (arith_mode) {
-        case PN2_ARITH_STRICT: return launch_ball_query<PN2_ARITH_STRICT>(b, n, m, thr, nsample, xyz1, xyz2, idx, pts_cnt, st);
-        case PN2_ARITH_FMA: return launch_ball_query<PN2_ARITH_FMA>(b, n, m, thr, nsample, xyz1, xyz2, idx, pts_cnt, st);
-        case PN2_ARITH_FMA_ALT: return launch_ball_query<PN2_ARITH_FMA_ALT>(b, n, m, thr, nsample, xyz1, xyz2, idx, pts_cnt, st);
+        case PN2_ARITH_STRICT: return launch_ball_query<PN2_ARITH_STRICT>(b, n, m, radius, thr, nsample, xyz1, xyz2, idx, pts_cnt, st);
+        case PN2_ARITH_FMA: return launch_ball_query<PN2_ARITH_FMA>(b, n, m, radius, thr, nsample, xyz1, xyz2, idx, pts_cnt, st);
+        case PN2_ARITH_FMA_ALT: return launch_ball_query<PN2_ARITH_FMA_ALT>(b, n, m, radius, thr, nsample, xyz1, xyz2, idx, pts_cnt, st);
         default: return PN2_EINVAL;
     }
 }

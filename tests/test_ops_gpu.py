@@ -512,3 +512,47 @@ def test_query_ball_point_multi_falls_back_when_lists_do_not_fit(pn2, oracle, cu
     for (idx, cnt), r, k in zip(res, [0.3, 0.6, 1.2], [64, 128, 128]):
         oi, oc = oracle.query_ball_point(r, k, xyz, new_xyz)
         assert np.array_equal(idx.cpu().numpy(), oi) and np.array_equal(cnt.cpu().numpy(), oc)
+
+
+# ------------------------------------------------------------------ ball query: LDS grid kernel ---------------
+@pytest.mark.parametrize("mode", [0, 1, 2])
+@pytest.mark.parametrize("case", ["scene", "grid_ties", "dense", "tiny_radius", "huge_radius", "outside", "ragged", "flat", "k64"])
+def test_query_ball_point_grid_kernel_bit_exact(pn2, oracle, cuda, case, mode):
+    """The per-block LDS-grid ball query (forced with the tuning hook so that small shapes reach it too) against the
+    oracle and against the scan kernel: sparse and dense neighbourhoods (rank ordering vs ordered fallback),
+    lattice points exactly on the radius, radii far below / above the cloud extent, queries outside the cloud's
+    bounding box, sizes that are not multiples of the tile sizes, degenerate (flat) clouds."""
+    raw = pn2._lib._raw
+    rs = np.random.RandomState(len(case) + mode)
+    K, r = 32, 0.5
+    if case == "scene":
+        xyz = s_scene(21, 2, 8192); q = xyz[:, :1024].copy()
+    elif case == "grid_ties":
+        xyz = s_grid(22, 2, 4096, 16); q = xyz[:, :300].copy(); r = 0.25
+    elif case == "dense":  # every ball holds far more than kBqgCap points -> ordered fallback
+        xyz = s_scene(23, 2, 5000) * np.float32(0.05); q = xyz[:, :130].copy()
+    elif case == "tiny_radius":
+        xyz = s_scene(24, 1, 3000); q = xyz[:, :257].copy(); r = 1e-3
+    elif case == "huge_radius":
+        xyz = s_scene(25, 1, 2000); q = xyz[:, :64].copy(); r = 1e4
+    elif case == "outside":  # queries up to 2 radii outside the cloud's bounding box, and some far away
+        xyz = s_scene(26, 2, 4000); q = (xyz[:, :500] + rs.uniform(-1.0, 1.0, (2, 500, 3))).astype(np.float32)
+        q[:, ::17] += np.float32(100.0)
+    elif case == "ragged":
+        xyz = s_randn(27, 3, 1237); q = s_randn(28, 3, 71); r = 0.4
+    elif case == "flat":
+        xyz = s_scene(29, 2, 2048); xyz[..., 2] = 0; q = xyz[:, :128].copy()
+    else:  # k64
+        xyz = s_scene(30, 2, 8192); q = xyz[:, :512].copy(); K, r = 64, 1.0
+    pn2.config.arith_mode = mode
+    try:
+        oi, oc = oracle.query_ball_point(r, K, xyz, q, mode)
+        assert raw.pn2_debug_set(2, 3) == 0
+        gi, gc = pn2.query_ball_point(r, K, T(xyz, cuda), T(q, cuda))
+        assert raw.pn2_debug_set(2, 2) == 0
+        si, sc = pn2.query_ball_point(r, K, T(xyz, cuda), T(q, cuda))
+    finally:
+        raw.pn2_debug_set(2, 0)
+        pn2.config.arith_mode = 1
+    assert np.array_equal(gc.cpu().numpy(), oc) and np.array_equal(gi.cpu().numpy(), oi)
+    assert np.array_equal(sc.cpu().numpy(), oc) and np.array_equal(si.cpu().numpy(), oi)
