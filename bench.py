@@ -179,6 +179,14 @@ def north_star_kernels(pn2, dev):
         "group_point_us": round(t_gp * 1e3, 1), "bytes": bq_bytes + gp_bytes, "bound": "hbm",
         "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4),
         "group_point_alone_GBs": round(gp_bytes / (t_gp * 1e-3) / 1e9, 1)}}
+    # the achievable copy bandwidth next to the 8 TB/s peak (device-to-device copy of the same 268 MB)
+    grouped = pn2.group_point(feat, idx)
+    dst = torch.empty_like(grouped)
+    t_cp = time_call(lambda: dst.copy_(grouped), 20)
+    cp = 2 * grouped.numel() * 4 / (t_cp * 1e-3) / 1e9
+    out["ball_query_group_point"]["d2d_copy_probe_GBs"] = round(cp, 1)
+    out["ball_query_group_point"]["frac_of_copy_probe"] = round(ach / cp, 4)
+    del grouped, dst
     # fused grouped MLP: one 128 -> 128 layer (+3 xyz channels of the SA concat) + max over K
     tfu, pu = pn2.util.tf_util, pn2.util.pointnet_util
     keep = tfu.get_default_store()

@@ -291,6 +291,7 @@ sa_group_concat_kernel(int n, int m, int nsample, int c, const float* __restrict
 
 }  // namespace
 
+int g_lin_cfg = 0;     // tuning hook (pn2_debug_set(8, v)): 0 = auto, 1..4 = force <4,1,4> / <2,2,2> / <1,4,1> / <1,2,1,split-K>
 int g_lin_stages = 3;  // tuning hook (pn2_debug_set(5, v)): register prefetch depth of linear_kernel
 
 extern "C" int pn2_linear(int rows, int cin, int cout, const float* x, const float* w,
@@ -314,6 +315,12 @@ extern "C" int pn2_linear(int rows, int cin, int cout, const float* x, const flo
      : st_depth == 3 ? launch_linear<WM_, WN_, NT_, WK_, 3>(rows, cin, cout, x, w, bias, relu, pool, y, st)    \
                      : launch_linear<WM_, WN_, NT_, WK_, 2>(rows, cin, cout, x, w, bias, relu, pool, y, st))
     const int st_depth = g_lin_stages;
+    if (cout % 128 == 0 && g_lin_cfg != 0) {  // tuning hook: force a tile configuration
+        if (g_lin_cfg == 1) return PN2_LIN(4, 1, 4, 1);
+        if (g_lin_cfg == 2) return PN2_LIN(2, 2, 2, 1);
+        if (g_lin_cfg == 3) return PN2_LIN(1, 4, 1, 1);
+        return PN2_LIN(1, 2, 1, 2);
+    }
     if (cout % 128 == 0) {
         // largest tile that still yields >= 2 blocks per CU; small problems get 32-row blocks
         const long long cb = cout / 128;
@@ -329,6 +336,7 @@ extern "C" int pn2_linear(int rows, int cin, int cout, const float* x, const flo
 
 extern "C" int pn2_debug_set_linear(int what, int value) {
     if (what == 5) { g_lin_stages = value; return 0; }
+    if (what == 8) { g_lin_cfg = value; return 0; }
     return PN2_EINVAL;
 }
 
