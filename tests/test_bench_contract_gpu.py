@@ -1,0 +1,34 @@
+"""bench.py prints ONE JSON line that carries the driver's contract keys plus `roofline` and `cpu_baseline`."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.mark.gpu
+def test_bench_json_contract():
+    env = dict(os.environ)
+    env.pop("RANK", None); env.pop("WORLD_SIZE", None); env.pop("LOCAL_RANK", None)
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "4", "--warmup", "2",
+                          "--batch", "4", "--points", "2048", "--no-north-star"],
+                         cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1, lines  # exactly one line on stdout
+    r = json.loads(lines[0])
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+              "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert k in r, k
+    assert r["n_gpus"] == 1 and r["steps"] == 4 and r["warmup"] == 2 and r["higher_is_better"] is True
+    assert r["scaling"] == "weak" and r["vs_baseline"] is None and r["dtype"] == "f32" and r["data"] == "synthetic"
+    assert abs(r["value"] - 4 * 2048 * 4 / (r["ms_per_step"] * 4 * 1e-3)) < 1e-3 * r["value"]
+    assert "workload" in r["config"] and "model" not in r["config"]
+    for k in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
+        assert k in r["roofline"], k
+    for k in ("value", "unit", "cores", "kind", "sample"):
+        assert k in r["cpu_baseline"], k
+    assert r["cpu_baseline"]["kind"] == "port" and r["cpu_baseline"]["value"] > 0
