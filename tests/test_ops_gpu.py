@@ -556,3 +556,64 @@ def test_query_ball_point_grid_kernel_bit_exact(pn2, oracle, cuda, case, mode):
         pn2.config.arith_mode = 1
     assert np.array_equal(gc.cpu().numpy(), oc) and np.array_equal(gi.cpu().numpy(), oi)
     assert np.array_equal(sc.cpu().numpy(), oc) and np.array_equal(si.cpu().numpy(), oi)
+
+
+def test_query_ball_point_kernels_fuzz(pn2, oracle, cuda):
+    """Differential fuzz: 40 random (cloud, queries, radius, nsample) draws, every ball-query kernel (LDS grid, lane
+    scan, wave-per-queries scan) against the oracle.  Mixes float clouds, lattice clouds (hits exactly on the
+    radius and on cell boundaries), anisotropic extents and radii from 1/200 to 2x of the extent."""
+    raw = pn2._lib._raw
+    rs = np.random.RandomState(1234)
+    try:
+        for it in range(40):
+            b = int(rs.randint(1, 4))
+            n = int(rs.choice([64, 333, 1024, 2500, 4096, 8192]))
+            m = int(rs.choice([1, 17, 64, 300, 1024]))
+            K = int(rs.choice([1, 8, 16, 32, 64]))
+            ext = rs.choice([0.01, 1.0, 10.0, 1000.0], 3).astype(np.float32)
+            if it % 3 == 0:  # lattice: many exact ties
+                g = int(rs.choice([8, 16, 64]))
+                xyz = (rs.randint(0, g, (b, n, 3)) / np.float32(g)).astype(np.float32) * ext
+            else:
+                xyz = (rs.random_sample((b, n, 3)).astype(np.float32) - np.float32(0.5 * (it % 2))) * ext
+            if it % 4 == 1:
+                q = (rs.random_sample((b, m, 3)).astype(np.float32) * 1.2 - 0.1).astype(np.float32) * ext
+            else:
+                q = xyz[:, rs.randint(0, n, m)].copy()
+            r = float(ext.max() * rs.choice([0.005, 0.02, 0.08, 0.3, 2.0]))
+            if it % 3 == 0 and it % 2 == 0:
+                r = float(ext.max() * rs.choice([1, 2, 4]) / g)  # a lattice distance: sqrt(d2) == radius cases
+            oi, oc = oracle.query_ball_point(r, K, xyz, q)
+            for variant in (3, 2, 1):
+                raw.pn2_debug_set(2, variant)
+                gi, gc = pn2.query_ball_point(r, K, T(xyz, cuda), T(q, cuda))
+                assert np.array_equal(gc.cpu().numpy(), oc), (it, variant, n, m, K, r)
+                assert np.array_equal(gi.cpu().numpy(), oi), (it, variant, n, m, K, r)
+    finally:
+        raw.pn2_debug_set(2, 0)
+
+
+def test_three_nn_fuzz(pn2, oracle, cuda):
+    """Differential fuzz of three_nn's fp32 ranking filter: random sizes, extents from 1e-3 to 1e4, offsets up to 1e5
+    (where the fp32 grid becomes coarser than the point spacing), lattices and duplicated points."""
+    rs = np.random.RandomState(4321)
+    for it in range(30):
+        b = int(rs.randint(1, 3))
+        n = int(rs.choice([1, 63, 500, 2000]))
+        m = int(rs.choice([3, 4, 64, 65, 700, 1024, 1500]))
+        ext = (rs.choice([1e-3, 1.0, 30.0, 1e4], 3)).astype(np.float32)
+        off = (rs.choice([0.0, 0.0, 5.0, 1e3, 1e5], 3)).astype(np.float32)
+        if it % 3 == 0:
+            g = int(rs.choice([4, 16]))
+            r = (rs.randint(0, g, (b, m, 3)) / np.float32(g)).astype(np.float32) * ext + off
+            a = (rs.randint(0, 2 * g, (b, n, 3)) / np.float32(2 * g)).astype(np.float32) * ext + off
+        else:
+            r = rs.random_sample((b, m, 3)).astype(np.float32) * ext + off
+            a = rs.random_sample((b, n, 3)).astype(np.float32) * ext + off
+        if it % 5 == 2:
+            r[:, ::2] = r[:, 1::2][:, : r[:, ::2].shape[1]] if m % 2 == 0 else r[:, ::2]  # duplicated known points
+        a, r = np.ascontiguousarray(a, np.float32), np.ascontiguousarray(r, np.float32)
+        d, i = pn2.three_nn(T(a, cuda), T(r, cuda))
+        rd, ri = oracle.three_nn(a, r)
+        assert np.array_equal(i.cpu().numpy(), ri), (it, n, m)
+        assert np.array_equal(d.cpu().numpy(), rd), (it, n, m)
