@@ -66,6 +66,13 @@ int pn2_farthest_point_sample(int b, int n, int m, const float *inp, float *temp
 int pn2_fps_gather(int b, int n, int m, const float *inp, float *temp, int *out,
                    float *new_xyz, int arith_mode, void *stream);
 
+/* probsampleLauncher(b,n,m,inp_p,inp_r,temp,out)  tf_sampling.cu:212-216, tf_sampling.cpp:72.  inp_p (b,n)
+ * non-negative weights, inp_r (b,m) uniforms in [0,1) -> out (b,m) int32: the index at which the running sum of
+ * the weights reaches inp_r * total (the reference's exact fp32 summation order and branch-free binary search).
+ * temp (b,n) receives the running sums (the reference's scratch tensor). */
+int pn2_prob_sample(int b, int n, int m, const float *inp_p, const float *inp_r, float *temp, int *out,
+                    void *stream);
+
 /* gatherpointLauncher(b,n,m,inp,idx,out)  tf_sampling.cu:222-225, tf_sampling.cpp:158 */
 int pn2_gather_point(int b, int n, int m, const float *inp, const int *idx,
                      float *out, void *stream);

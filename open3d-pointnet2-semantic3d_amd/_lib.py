@@ -19,6 +19,7 @@ c_int, c_float, c_void_p = ctypes.c_int, ctypes.c_float, ctypes.c_void_p
 SIGNATURES = {
     "pn2_farthest_point_sample": [c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_int, c_void_p],
     "pn2_fps_gather": [c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p],
+    "pn2_prob_sample": [c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p],
     "pn2_gather_point": [c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p],
     "pn2_gather_point_grad": [c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p],
     "pn2_query_ball_point": [c_int, c_int, c_int, c_float, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p],

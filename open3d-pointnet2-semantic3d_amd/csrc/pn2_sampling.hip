@@ -351,7 +351,103 @@ inline int grid_for(long long total, int block) {
     return (int)(g < 1 ? 1 : (g > cap ? cap : g));
 }
 
+// ---- prob_sample (tf_sampling.cu:7-110): categorical sampling by inverting the running sum of the weights -------
+// The drawn index depends on the exact fp32 running sum, so the kernel keeps the reference's summation ORDER:
+// chunks of 8192 values; inside a chunk groups of four (v2 = a1+a0, t = a3+a2, v3 = a2+v2, v4 = t+v2; a ragged last
+// group is summed left to right), a strided up-sweep / down-sweep over the group totals (total[i] += total[i-s]), the
+// preceding inclusive total added to every later group, the chunk offset added last and carried with a compensated
+// two-term update.  One 1024-thread workgroup per row, the chunk in LDS.  (oracle_prob_sample restates the same.)
+constexpr int kPsChunk = 8192;
+constexpr int kPsThreads = 1024;
+
+__global__ void __launch_bounds__(kPsThreads)
+prob_cumsum_kernel(int n, const float* __restrict__ inp_all, float* __restrict__ out_all) {
+    __shared__ float b4[kPsChunk];
+    __shared__ float tot[kPsChunk / 4];
+    const int tid = threadIdx.x;
+    const float* __restrict__ a_row = inp_all + (size_t)blockIdx.x * n;
+    float* __restrict__ o_row = out_all + (size_t)blockIdx.x * n;
+    float running = 0.f, running2 = 0.f;  // identical in every thread
+    for (int j = 0; j < n; j += kPsChunk) {
+        const int ni = n - j < kPsChunk ? n - j : kPsChunk;
+        const int n4 = (ni + 3) & ~3, ng = n4 >> 2;
+        const float* __restrict__ a = a_row + j;
+        for (int g = tid; g < ng; g += kPsThreads) {
+            const int k = 4 * g;
+            if (k + 3 < ni) {
+                const float v1 = a[k];
+                const float v2 = a[k + 1] + v1;
+                const float v3 = a[k + 2];
+                const float v4 = (a[k + 3] + v3) + v2;
+                b4[k] = v1; b4[k + 1] = v2; b4[k + 2] = v3 + v2; b4[k + 3] = v4;
+                tot[g] = v4;
+            } else {
+                float v = 0.f;
+                for (int k2 = k; k2 < ni; ++k2) { v += a[k2]; b4[k2] = v; }
+                for (int k2 = ni; k2 < n4; ++k2) b4[k2] = v;
+                tot[g] = v;
+            }
+        }
+        __syncthreads();
+        int s = 1;
+        for (; 2 * s <= ng; s <<= 1) {  // up-sweep
+            for (int k = tid; k < ng / (2 * s); k += kPsThreads) {
+                const int i1 = 2 * s * (k + 1) - 1;
+                tot[i1] += tot[i1 - s];
+            }
+            __syncthreads();
+        }
+        for (s >>= 1; s >= 1; s >>= 1) {  // down-sweep, starting at the last up-sweep stride
+            for (int k = tid; k < (ng - s) / (2 * s); k += kPsThreads) {
+                const int i1 = s * (2 * k + 3) - 1;
+                tot[i1] += tot[i1 - s];
+            }
+            __syncthreads();
+        }
+        for (int g = 1 + tid; g < ng; g += kPsThreads) {
+            const float p = tot[g - 1];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) b4[4 * g + e] += p;
+        }
+        __syncthreads();
+        for (int k = tid; k < ni; k += kPsThreads) o_row[j + k] = b4[k] + running;
+        const float t = tot[ng - 1] + running2;
+        const float r2 = running + t;
+        running2 = t - (r2 - running);
+        running = r2;
+        __syncthreads();
+    }
+}
+
+__global__ void __launch_bounds__(256)
+prob_search_kernel(int n, int m, int base, const float* __restrict__ cs_all, const float* __restrict__ query_all,
+                   int* __restrict__ out_all) {
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= m) return;
+    const float* __restrict__ cs = cs_all + (size_t)blockIdx.y * n;
+    const float q = query_all[(size_t)blockIdx.y * m + j] * cs[n - 1];
+    int r = n - 1;
+    for (int k = base; k >= 1; k >>= 1)
+        if (r >= k && cs[r - k] >= q) r -= k;
+    out_all[(size_t)blockIdx.y * m + j] = r;
+}
+
 }  // namespace
+
+// probsampleLauncher(b,n,m,inp_p,inp_r,temp,out)  tf_sampling.cu:212-216, tf_sampling.cpp:72
+extern "C" int pn2_prob_sample(int b, int n, int m, const float* inp_p, const float* inp_r, float* temp, int* out,
+                               void* stream) {
+    if (b <= 0 || n <= 0 || m <= 0) return PN2_EINVAL;
+    if (!inp_p || !inp_r || !temp || !out) return PN2_ENULL;
+    if (b > 65535) return PN2_ERANGE;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    prob_cumsum_kernel<<<b, kPsThreads, 0, st>>>(n, inp_p, temp);
+    int base = 1;
+    while (base < n) base <<= 1;
+    prob_search_kernel<<<dim3((m + 255) / 256, b), 256, 0, st>>>(n, m, base, temp, inp_r, out);
+    PN2_RETURN_IF_LAUNCH_FAILED();
+    return PN2_OK;
+}
 
 // undocumented tuning/experiment hook (not part of the ABI header)
 extern "C" int pn2_debug_set_grouping(int what, int value);

@@ -92,7 +92,20 @@ def farthest_point_sample_and_gather(npoint, inp):
 
 
 def prob_sample(inp, inpr):
-    """tf_ops/tf_sampling.py:18-26 (ProbSample: weighted sampling by cumulative sum + binary search,
-    tf_sampling.cu:7-110).  Registered by the reference but called by none of its models or scripts; not
-    part of the SA/FP path and not built here -- fails loudly instead of approximating."""
-    raise NotImplementedError("prob_sample (tf_sampling.cu:7-110) is not on the SA/FP path; see DESIGN.md section 8")
+    """tf_ops/tf_sampling.py:18-26: inp (batch_size, ncategory) float32 weights, inpr (batch_size, npoints) float32
+    uniforms -> (batch_size, npoints) int32 categories (ProbSample: running sum + binary search, tf_sampling.cu:7-110)."""
+    require_cuda(inp, inpr)
+    if inp.dim() != 2:
+        raise ValueError("ProbSample expects (batch_size,num_choices) inp shape")  # tf_sampling.cpp:86-89
+    if inpr.dim() != 2 or inpr.shape[0] != inp.shape[0]:
+        raise ValueError("ProbSample expects (batch_size,num_points) inpr shape")  # :92-96
+    if inp.dtype != torch.float32 or inpr.dtype != torch.float32:
+        raise TypeError("ProbSample expects float32 inputs")
+    b, n = inp.shape
+    m = inpr.shape[1]
+    inp, inpr = inp.detach().contiguous(), inpr.detach().contiguous()
+    temp = torch.empty((b, n), dtype=torch.float32, device=inp.device)
+    out = torch.empty((b, m), dtype=torch.int32, device=inp.device)
+    with torch.cuda.device(inp.device):
+        check(lib.pn2_prob_sample(b, n, m, ptr(inp), ptr(inpr), ptr(temp), ptr(out), stream_ptr()), "pn2_prob_sample")
+    return out

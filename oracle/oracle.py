@@ -165,6 +165,18 @@ def knn_point(k, xyz1, xyz2):
     return out[:, :, :k], outi[:, :, :k]
 
 
+def prob_sample(inp, inpr):
+    """tf_ops/tf_sampling.py:18-26 -> (out (b,m) int32, cumsum (b,n) float32 as the reference's scratch holds it)."""
+    inp, inpr = _f32(inp), _f32(inpr)
+    b, n = inp.shape
+    m = inpr.shape[1]
+    temp = np.empty((b, n), dtype=np.float32)
+    out = np.empty((b, m), dtype=np.int32)
+    rc = lib().oracle_prob_sample(b, n, m, _p(inp), _p(inpr), _p(temp), _p(out))
+    assert rc == 0, rc
+    return out, temp
+
+
 def interpolate_label_with_color(sparse_points, sparse_labels, dense_points, knn):
     """tf_ops/tf_interpolate.py:28-44 -> (dense_labels (Nd,) int32, dense_colors (Nd,3) uint8)."""
     sp, dp = _f32(sparse_points), _f32(dense_points)

@@ -19,6 +19,7 @@
  *   oracle_three_interpolate     tf_ops/tf_interpolate.cpp:307-330 (threeinterpolate_cpu)
  *   oracle_three_interpolate_grad tf_ops/tf_interpolate.cpp:397-421 (threeinterpolate_grad_cpu) + memset :477
  *   oracle_selection_sort        tf_ops/tf_grouping.cu:95-136   (selection_sort_gpu)
+ *   oracle_prob_sample           tf_ops/tf_sampling.cu:7-110,212-216 (cumsumKernel + binarysearchKernel)
  *   oracle_interpolate_label_with_color tf_ops/tf_interpolate.cpp:30-47,71-115 (interpolate_label_with_color_cpu)
  *
  * Parity pinning (see DESIGN.md "Oracle"):
@@ -421,5 +422,83 @@ int oracle_interpolate_label_with_color(int num_sparse, int num_dense, const flo
         for (int c = 0; c < 3; ++c)
             dense_colors[(size_t)j * 3 + c] = (best >= 0 && best < 9) ? ORACLE_LABEL_COLOR[best][c] : 0;
     }
+    return 0;
+}
+
+
+/* ProbSample (tf_ops/tf_sampling.cu:7-110, launcher :212-216): out[i,j] = index drawn from the categorical weights
+ * inp[i,:] by inverting their running sum at inpr[i,j] * total.  The result depends on the EXACT fp32 running sum, so
+ * the summation order of cumsumKernel is restated operation by operation:
+ *   per chunk of 8192 elements: groups of four (v2 = a1+a0; t = a3+a2; v3 = a2+v2; v4 = t+v2; a ragged last group
+ *   is summed left to right), an up-sweep / down-sweep over the group totals (strides 1,2,4,.. then back; each
+ *   update is total[i] += total[i - stride]), every group but the first adds the preceding inclusive total, the
+ *   chunk offset is added last; the offset itself is carried with the two-term compensated update of :84-88.
+ * binarysearchKernel (:93-110): q = inpr * cumsum[n-1]; r = n-1; for k = 2^ceil(log2 n) .. 1: if (r >= k &&
+ * cumsum[r-k] >= q) r -= k.  `temp` (b,n) receives the running sums like the reference's scratch tensor. */
+int oracle_prob_sample(int b, int n, int m, const float *inp, const float *inpr, float *temp, int *out) {
+    if (b <= 0 || n <= 0 || m <= 0) return -1;
+    enum { CHUNK = 8192 };
+    float *b4 = (float *)malloc(sizeof(float) * CHUNK), *tot = (float *)malloc(sizeof(float) * (CHUNK / 4));
+    if (!b4 || !tot) { free(b4); free(tot); return -2; }
+    for (int i = 0; i < b; ++i) {
+        volatile float running = 0.f, running2 = 0.f;
+        for (int j = 0; j < n; j += CHUNK) {
+            const int ni = n - j < CHUNK ? n - j : CHUNK; /* n24_i */
+            const int n4 = (ni + 3) & ~3, ng = n4 >> 2;   /* n24, n2 */
+            const float *a = inp + (size_t)i * n + j;
+            for (int k = 0; k < ni; k += 4) {
+                if (k + 3 < ni) {
+                    volatile float v1 = a[k], v2 = a[k + 1], v3 = a[k + 2], v4 = a[k + 3];
+                    v2 = v2 + v1;
+                    v4 = v4 + v3;
+                    v3 = v3 + v2;
+                    v4 = v4 + v2;
+                    b4[k] = v1; b4[k + 1] = v2; b4[k + 2] = v3; b4[k + 3] = v4;
+                    tot[k >> 2] = v4;
+                } else {
+                    volatile float v = 0.f;
+                    for (int k2 = k; k2 < ni; ++k2) { v = v + a[k2]; b4[k2] = v; }
+                    for (int k2 = ni; k2 < n4; ++k2) b4[k2] = v;
+                    tot[k >> 2] = v;
+                }
+            }
+            int u = 0;
+            for (; (2 << u) <= ng; ++u) { /* up-sweep, stride s = 1 << u */
+                const int s = 1 << u;
+                for (int k = 0; k < (ng >> (u + 1)); ++k) {
+                    const int i1 = 2 * s * (k + 1) - 1;
+                    volatile float t = tot[i1] + tot[i1 - s];
+                    tot[i1] = t;
+                }
+            }
+            for (--u; u >= 0; --u) { /* down-sweep */
+                const int s = 1 << u;
+                for (int k = 0; k < ((ng - s) >> (u + 1)); ++k) {
+                    const int i1 = s * (2 * k + 3) - 1;
+                    volatile float t = tot[i1] + tot[i1 - s];
+                    tot[i1] = t;
+                }
+            }
+            for (int k = 4; k < n4; k += 4)
+                for (int e = 0; e < 4; ++e) { volatile float t = b4[k + e] + tot[(k >> 2) - 1]; b4[k + e] = t; }
+            for (int k = 0; k < ni; ++k) { volatile float t = b4[k] + running; temp[(size_t)i * n + j + k] = t; }
+            volatile float t = tot[ng - 1] + running2;
+            volatile float r2 = running + t;
+            volatile float d = r2 - running;
+            running2 = t - d;
+            running = r2;
+        }
+        int base = 1;
+        while (base < n) base <<= 1;
+        const float *cs = temp + (size_t)i * n;
+        for (int jq = 0; jq < m; ++jq) {
+            volatile float q = inpr[(size_t)i * m + jq] * cs[n - 1];
+            int r = n - 1;
+            for (int k = base; k >= 1; k >>= 1)
+                if (r >= k && cs[r - k] >= q) r -= k;
+            out[(size_t)i * m + jq] = r;
+        }
+    }
+    free(b4); free(tot);
     return 0;
 }

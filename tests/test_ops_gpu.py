@@ -617,3 +617,35 @@ def test_three_nn_fuzz(pn2, oracle, cuda):
         rd, ri = oracle.three_nn(a, r)
         assert np.array_equal(i.cpu().numpy(), ri), (it, n, m)
         assert np.array_equal(d.cpu().numpy(), rd), (it, n, m)
+
+
+# ------------------------------------------------------------------ prob_sample ----------------
+@pytest.mark.parametrize("n", [1, 2, 3, 4, 5, 7, 100, 4095, 8192, 8193, 16384, 20001, 70000])
+def test_prob_sample_bit_exact(pn2, oracle, cuda, n):
+    """ProbSample: the running sums (read back through the C ABI) and the drawn indices equal the oracle's restatement
+    of the reference's summation order bit for bit, across chunk boundaries (8192) and ragged tails."""
+    import ctypes
+    import torch
+    rs = np.random.RandomState(n)
+    b, m = 3, 777
+    inp = rs.rand(b, n).astype(np.float32)
+    inp[0, : n // 2] = 0.0  # runs of zero weight: equal running sums, the search must still agree
+    inpr = rs.rand(b, m).astype(np.float32)
+    inpr[:, 0] = 0.0
+    inpr[:, 1] = np.float32(1.0) - np.float32(2 ** -24)
+    out = pn2.prob_sample(T(inp, cuda), T(inpr, cuda))
+    ro, rcs = oracle.prob_sample(inp, inpr)
+    assert np.array_equal(out.cpu().numpy(), ro)
+    temp = torch.empty((b, n), dtype=torch.float32, device=cuda)
+    o2 = torch.empty((b, m), dtype=torch.int32, device=cuda)
+    L = pn2._lib.lib
+    assert L.pn2_prob_sample(b, n, m, ctypes.c_void_p(T(inp, cuda).data_ptr()), ctypes.c_void_p(T(inpr, cuda).data_ptr()),
+                             ctypes.c_void_p(temp.data_ptr()), ctypes.c_void_p(o2.data_ptr()), None) == 0
+    torch.cuda.synchronize()
+    assert np.array_equal(temp.cpu().numpy(), rcs)
+    # and it is a sampler: the empirical distribution follows the weights
+    if n == 100:
+        w = rs.rand(1, n).astype(np.float32)
+        draws = pn2.prob_sample(T(w, cuda), T(rs.rand(1, 200000).astype(np.float32), cuda)).cpu().numpy()[0]
+        freq = np.bincount(draws, minlength=n) / 200000.0
+        assert np.abs(freq - w[0] / w[0].sum()).max() < 4e-3
