@@ -922,6 +922,32 @@ extern "C" int pn2_query_ball_point_multi(int b, int n, int m, int nradius, cons
         p.thr[r] = ball_threshold(radii[r]); p.ns[r] = nsamples[r]; p.idx[r] = idx[r]; p.cnt[r] = pts_cnt[r];
     }
     hipStream_t st = static_cast<hipStream_t>(stream);
+    if (arith_mode < 0 || arith_mode > 2) return PN2_EINVAL;
+    // radii whose neighbourhoods are small and whose cloud fits LDS are answered by the per-workgroup grid kernel
+    // (a few us each, see launch_ball_query); the remaining ones share one scan
+    {
+        BqmParams rest = p;
+        int nrest = 0;
+        for (int r = 0; r < nradius; ++r) {
+            const bool grid_ok = g_bq_variant == 0 && n <= kBqgMaxN && n >= 4096 && m >= 256 && nsamples[r] <= 32 && radii[r] < 1e18f;
+            if (grid_ok) {
+                const int rc = pn2_query_ball_point(b, n, m, radii[r], nsamples[r], xyz1, xyz2, idx[r], pts_cnt[r], arith_mode, stream);
+                if (rc != PN2_OK) return rc;
+            } else {
+                rest.thr[nrest] = p.thr[r]; rest.ns[nrest] = p.ns[r]; rest.idx[nrest] = p.idx[r]; rest.cnt[nrest] = p.cnt[r];
+                ++nrest;
+            }
+        }
+        if (nrest == 0) return PN2_OK;
+        if (nrest < nradius) {
+            if (nrest == 1) {
+                for (int r = 0; r < nradius; ++r)
+                    if (idx[r] == rest.idx[0])
+                        return pn2_query_ball_point(b, n, m, radii[r], nsamples[r], xyz1, xyz2, idx[r], pts_cnt[r], arith_mode, stream);
+            }
+            p = rest; p.nr = nrest; nradius = nrest;
+        }
+    }
     if (nradius == 1) return pn2_query_ball_point(b, n, m, radii[0], nsamples[0], xyz1, xyz2, idx[0], pts_cnt[0], arith_mode, stream);
 #define PN2_BQM(MODE_) (nradius == 2 ? launch_ball_query_multi<MODE_, 2>(b, p, st) : launch_ball_query_multi<MODE_, 3>(b, p, st))
     switch (arith_mode) {
