@@ -665,25 +665,57 @@ ball_query_grid_kernel(int n, int m, float radius, float thr, int nsample, const
                 if (rank == 0) *myfirst = me;
             }
         }
-        // queries with more than kBqgCap hits (dense clouds): ordered scan with early exit, the whole wave per query
+        // queries with more than kBqgCap hits (dense balls), the whole wave per query: the hits of the 27 cells set
+        // bits of an 8192-bit map (the histogram memory is free by now), which is then read out in index order
         const unsigned long long dense = __ballot(qv && !sparse && l16 == 0);
         for (int g2 = 0; g2 < 4; ++g2) {
             if (!((dense >> (16 * g2)) & 1ull)) continue;  // wave-uniform
             const int q2 = qbase + g2;
             const float ax = xyz2[q2 * 3 + 0], ay = xyz2[q2 * 3 + 1], az = xyz2[q2 * 3 + 2];
+            const int dx = bqg_cell1(ax, G.lo[0], G.inv_h[0], G.dim[0]);
+            const int dy = bqg_cell1(ay, G.lo[1], G.inv_h[1], G.dim[1]);
+            const int dz = bqg_cell1(az, G.lo[2], G.inv_h[2], G.dim[2]);
+            const int u0 = dx > 0 ? dx - 1 : 0, u1 = dx + 1 < G.dim[0] ? dx + 1 : G.dim[0] - 1;
+            unsigned* bm = reinterpret_cast<unsigned*>(ccount) + wave * 256;
+#pragma unroll
+            for (int w = 0; w < 4; ++w) bm[lane * 4 + w] = 0u;
+            for (int r = 0; r < 9; ++r) {
+                const int z = dz + r / 3 - 1, y = dy + r % 3 - 1;
+                if (z < 0 || z >= G.dim[2] || y < 0 || y >= G.dim[1]) continue;
+                const int rowc = (z * G.dim[1] + y) * G.dim[0];
+                const int s0 = cstart[rowc + u0], e0 = cstart[rowc + u1 + 1];
+                for (int p = s0 + lane; p < e0; p += 64) {
+                    const float sd = pn2_sqdist<MODE>(ax - sx[p], ay - sy[p], az - sz[p]);
+                    if (sd <= thr) {
+                        const unsigned id = sidx[p];
+                        atomicOr(&bm[id >> 5], 1u << (id & 31u));
+                    }
+                }
+            }
+            // lane l owns words 4l..4l+3 (indices 128l .. 128l+127): exclusive prefix of the set-bit counts
+            unsigned wv[4];
+            int mine = 0;
+#pragma unroll
+            for (int w = 0; w < 4; ++w) { wv[w] = bm[lane * 4 + w]; mine += __popc(wv[w]); }
+            int inc = mine;
+#pragma unroll
+            for (int o = 1; o < 64; o <<= 1) {
+                const int t = __shfl_up(inc, o);
+                if (lane >= o) inc += t;
+            }
+            int pos = inc - mine;
             int* __restrict__ o2 = idx_all + ((size_t)bi * m + q2) * nsample;
-            int c2 = 0;
-            for (int c0 = 0; c0 < n && c2 < nsample; c0 += 64) {
-                const int k = c0 + lane;
-                const int kc = k < n ? k : n - 1;
-                const float sd = pn2_sqdist<MODE>(ax - xyz1[kc * 3 + 0], ay - xyz1[kc * 3 + 1], az - xyz1[kc * 3 + 2]);
-                const bool hit = k < n && sd <= thr;
-                const unsigned long long mask = __ballot(hit);
-                const int pos = c2 + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32),
-                                                                    __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0u));
-                if (hit && pos < nsample) o2[pos] = k;
-                if (hit && pos == 0) rowbuf[wave * 4 + g2] = k;
-                c2 += __popcll(mask);
+#pragma unroll
+            for (int w = 0; w < 4; ++w) {
+                unsigned bits = wv[w];
+                while (bits != 0u && pos < nsample) {
+                    const int bit = __ffs(bits) - 1;
+                    bits &= bits - 1u;
+                    const int id = (lane * 4 + w) * 32 + bit;
+                    o2[pos] = id;
+                    if (pos == 0) rowbuf[wave * 4 + g2] = id;
+                    ++pos;
+                }
             }
         }
         // short rows repeat the first hit (tf_grouping.cu:32-36); empty rows are zero (documented divergence)
@@ -736,7 +768,7 @@ int launch_ball_query(int b, int n, int m, float radius, float thr, int nsample,
     // per-block LDS grid: the whole cloud fits LDS, enough points / queries to amortise building it in every
     // workgroup, and a neighbourhood size (nsample <= 32 is the caller's own estimate of the hits per ball) for which
     // the hit lists stay short; dense balls are cheaper on the ordered scan kernels (profiles/r01_ball_query_grid.txt)
-    const bool grid_ok = n <= kBqgMaxN && n >= 4096 && m >= 256 && nsample <= 32 && radius < 1e18f;
+    const bool grid_ok = n <= kBqgMaxN && n >= 4096 && m >= 256 && nsample <= 64 && radius < 1e18f;
     if ((g_bq_variant == 3 && n <= kBqgMaxN && nsample <= 64 && radius < 1e18f) || (g_bq_variant == 0 && grid_ok))
         return launch_ball_query_grid<MODE>(b, n, m, radius, thr, nsample, xyz1, xyz2, idx, cnt, st);
     // lane = query kernel whenever its LDS lists fit and there are enough queries to fill 64 lanes
@@ -929,7 +961,7 @@ extern "C" int pn2_query_ball_point_multi(int b, int n, int m, int nradius, cons
         BqmParams rest = p;
         int nrest = 0;
         for (int r = 0; r < nradius; ++r) {
-            const bool grid_ok = g_bq_variant == 0 && n <= kBqgMaxN && n >= 4096 && m >= 256 && nsamples[r] <= 32 && radii[r] < 1e18f;
+            const bool grid_ok = g_bq_variant == 0 && n <= kBqgMaxN && n >= 4096 && m >= 256 && nsamples[r] <= 64 && radii[r] < 1e18f;
             if (grid_ok) {
                 const int rc = pn2_query_ball_point(b, n, m, radii[r], nsamples[r], xyz1, xyz2, idx[r], pts_cnt[r], arith_mode, stream);
                 if (rc != PN2_OK) return rc;
