@@ -57,9 +57,17 @@ class Pn2Error(RuntimeError):
 
 def _load():
     if not os.path.exists(LIB_PATH):
-        # build in-tree with hipcc (cross-compiles without a GPU); never fall back to CPU code
+        # build in-tree with hipcc (cross-compiles without a GPU); never fall back to CPU code.
+        # One process per GPU may import concurrently (torch.distributed.run): serialise the build with a file lock.
+        import fcntl
         from . import build as _build
-        _build.build()
+        with open(os.path.join(_HERE, ".build.lock"), "w") as lock:
+            fcntl.flock(lock, fcntl.LOCK_EX)
+            try:
+                if not os.path.exists(LIB_PATH):
+                    _build.build()
+            finally:
+                fcntl.flock(lock, fcntl.LOCK_UN)
     try:
         lib = ctypes.CDLL(LIB_PATH)
     except OSError as e:  # pragma: no cover
