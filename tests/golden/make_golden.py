@@ -64,6 +64,35 @@ def main():
     out["cfg0_interp"] = O.three_interpolate(O.gather_point(feat, f), i3, w)
     np.savez_compressed(os.path.join(HERE, "oracle_small.npz"), **out)
     print("wrote", sorted(out))
+    more = extra_fixtures()
+    np.savez_compressed(os.path.join(HERE, "oracle_extra.npz"), **more)
+    print("wrote", sorted(more))
+
+
+def extra_inputs():
+    """Seeded inputs of the fixtures for the ops added after the first freeze (shared with the tests)."""
+    rs = np.random.RandomState(11)
+    return dict(
+        dist=rs.random_sample((2, 5, 300)).astype(np.float32),                       # select_top_k
+        kx1=rs.random_sample((2, 400, 3)).astype(np.float32), kx2=rs.random_sample((2, 30, 3)).astype(np.float32),
+        sp=s_scene(8, 1, 3000)[0], sl=rs.randint(0, 9, 3000).astype(np.int32), dp=s_scene(9, 1, 9000)[0],
+        pw=rs.random_sample((2, 9000)).astype(np.float32), pr=rs.random_sample((2, 500)).astype(np.float32),
+        logits=rs.randn(2, 50, 9).astype(np.float32), labels=rs.randint(0, 9, (2, 50)),
+        smpw=(rs.random_sample((2, 50)) * (rs.random_sample((2, 50)) > 0.2)).astype(np.float32),
+        bf=rs.randn(1000).astype(np.float32) * np.float32(37.0))
+
+
+def extra_fixtures():
+    x = extra_inputs()
+    out = {}
+    out["topk_idx"], out["topk_val"] = O.select_top_k(7, x["dist"])
+    out["knn_val"], out["knn_idx"] = O.knn_point(5, x["kx1"], x["kx2"])
+    for k in (1, 3, 8):
+        out["label_k%d" % k], out["color_k%d" % k] = O.interpolate_label_with_color(x["sp"], x["sl"], x["dp"], k)
+    out["prob_idx"], out["prob_cumsum"] = O.prob_sample(x["pw"], x["pr"])
+    out["ce"] = np.float64(O.weighted_sparse_ce(x["logits"], x["labels"], x["smpw"]))
+    out["bf16"] = O.bf16_round(x["bf"])
+    return out
 
 
 if __name__ == "__main__":

@@ -649,3 +649,26 @@ def test_prob_sample_bit_exact(pn2, oracle, cuda, n):
         draws = pn2.prob_sample(T(w, cuda), T(rs.rand(1, 200000).astype(np.float32), cuda)).cpu().numpy()[0]
         freq = np.bincount(draws, minlength=n) / 200000.0
         assert np.abs(freq - w[0] / w[0].sum()).max() < 4e-3
+
+
+def test_kernels_against_frozen_extra_fixtures(pn2, cuda):
+    """The HIP kernels against tests/golden/oracle_extra.npz (frozen oracle outputs: the oracle library itself is not
+    called here): selection sort / kNN, label interpolation, prob_sample, bf16 rounding of the device."""
+    import importlib.util
+    import torch
+    spec = importlib.util.spec_from_file_location("make_golden", os.path.join(GOLD, "make_golden.py"))
+    mg = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mg)
+    x = mg.extra_inputs()
+    g = np.load(os.path.join(GOLD, "oracle_extra.npz"))
+    oi, ov = pn2.select_top_k(7, T(x["dist"], cuda))
+    assert np.array_equal(oi.cpu().numpy(), g["topk_idx"]) and np.array_equal(ov.cpu().numpy(), g["topk_val"])
+    kv, ki = pn2.knn_point(5, T(x["kx1"], cuda), T(x["kx2"], cuda))
+    assert np.array_equal(ki.cpu().numpy(), g["knn_idx"]) and np.array_equal(kv.cpu().numpy(), g["knn_val"])
+    for k in (1, 3, 8):
+        lab, col = pn2.interpolate_label_with_color(T(x["sp"], cuda), T(x["sl"], cuda), T(x["dp"], cuda), k)
+        assert np.array_equal(lab.cpu().numpy(), g["label_k%d" % k]) and np.array_equal(col.cpu().numpy(), g["color_k%d" % k])
+    assert np.array_equal(pn2.prob_sample(T(x["pw"], cuda), T(x["pr"], cuda)).cpu().numpy(), g["prob_idx"])
+    assert np.array_equal(T(x["bf"], cuda).to(torch.bfloat16).float().cpu().numpy(), g["bf16"])
+    loss = pn2.model.get_loss(T(x["logits"], cuda), T(x["labels"].astype(np.int64), cuda), T(x["smpw"], cuda))
+    assert abs(float(loss) - float(g["ce"])) < 1e-5

@@ -158,3 +158,17 @@ def test_weighted_sparse_ce_known_answers(oracle):
     # sum(w*ce)/count(w!=0) = (2 + 5*2) * log 9 / 7
     assert abs(oracle.weighted_sparse_ce(pred, label, w) - 12.0 * np.log(9.0) / 7.0) < 1e-12
     assert oracle.weighted_sparse_ce(pred, label, np.zeros((2, 5))) == 0.0
+
+
+def test_frozen_fixtures_extra(oracle):
+    """Regression pins of the oracle functions added later (selection sort / kNN, label interpolation, prob_sample,
+    loss, bf16 rounding): tests/golden/oracle_extra.npz, inputs from make_golden.extra_inputs()."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("make_golden", os.path.join(GOLD, "make_golden.py"))
+    mg = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mg)
+    g = np.load(os.path.join(GOLD, "oracle_extra.npz"))
+    fresh = mg.extra_fixtures()
+    assert sorted(fresh) == sorted(g.files)
+    for k in g.files:
+        assert np.array_equal(np.asarray(fresh[k]), g[k]), k
