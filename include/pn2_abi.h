@@ -73,6 +73,15 @@ int pn2_fps_gather(int b, int n, int m, const float *inp, float *temp, int *out,
 int pn2_prob_sample(int b, int n, int m, const float *inp_p, const float *inp_r, float *temp, int *out,
                     void *stream);
 
+/* Farthest point sampling for clouds beyond PN2_FPS_MAX_REG_POINTS (16384 < n <= 131072), same picks as
+ * pn2_farthest_point_sample (bit-identical), ~6x faster than its streaming path at n = 65536: the cloud is
+ * sorted along a Morton curve into 64-point buckets and a round only revisits the buckets whose bounding box the
+ * new pick can reach (exact: skipped buckets provably keep their running minima).  new_xyz (b,m,3) may be NULL.
+ * `workspace`: 256-byte aligned device scratch of pn2_fps_large_workspace_bytes(b, n) bytes (replaces `temp`). */
+size_t pn2_fps_large_workspace_bytes(int b, int n);
+int pn2_fps_large(int b, int n, int m, const float *inp, void *workspace, size_t workspace_bytes, int *out,
+                  float *new_xyz, int arith_mode, void *stream);
+
 /* gatherpointLauncher(b,n,m,inp,idx,out)  tf_sampling.cu:222-225, tf_sampling.cpp:158 */
 int pn2_gather_point(int b, int n, int m, const float *inp, const int *idx,
                      float *out, void *stream);

@@ -20,6 +20,7 @@ SIGNATURES = {
     "pn2_farthest_point_sample": [c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_int, c_void_p],
     "pn2_fps_gather": [c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p],
     "pn2_prob_sample": [c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p],
+    "pn2_fps_large": [c_int, c_int, c_int, c_void_p, c_void_p, ctypes.c_size_t, c_void_p, c_void_p, c_int, c_void_p],
     "pn2_gather_point": [c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p],
     "pn2_gather_point_grad": [c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p],
     "pn2_query_ball_point": [c_int, c_int, c_int, c_float, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p],
@@ -77,6 +78,8 @@ def _load():
         fn = getattr(lib, name)  # AttributeError if the ABI and the library disagree
         fn.argtypes = argtypes
         fn.restype = c_int
+    lib.pn2_fps_large_workspace_bytes.argtypes = [c_int, c_int]
+    lib.pn2_fps_large_workspace_bytes.restype = ctypes.c_size_t
     lib.pn2_interpolate_label_workspace_bytes.argtypes = [c_int]
     lib.pn2_interpolate_label_workspace_bytes.restype = ctypes.c_size_t
     lib.pn2_abi_version.restype = c_int

@@ -18,6 +18,24 @@ def _chk_xyz(t, name, op):
         raise TypeError("%s expects float32 %s" % (op, name))
 
 
+USE_BUCKET_FPS = True  # clouds beyond 16384 points: Morton buckets + bounding-box skipping (pn2_fps_large); False = streaming kernel
+FPS_REG_MAX, FPS_BUCKET_MAX = 16384, 131072
+
+
+def _fps_large(npoint, inp, want_xyz):
+    import ctypes
+    b, n, _ = inp.shape
+    out = torch.empty((b, npoint), dtype=torch.int32, device=inp.device)
+    new_xyz = torch.empty((b, npoint, 3), dtype=torch.float32, device=inp.device) if want_xyz else None
+    wbytes = int(lib.pn2_fps_large_workspace_bytes(b, n))
+    ws = torch.empty((wbytes + 256,), dtype=torch.uint8, device=inp.device)
+    off = (-ws.data_ptr()) % 256
+    with torch.cuda.device(inp.device):
+        check(lib.pn2_fps_large(b, n, int(npoint), ptr(inp), ctypes.c_void_p(ws.data_ptr() + off), wbytes, ptr(out),
+                                ptr(new_xyz), int(config.arith_mode), stream_ptr()), "pn2_fps_large")
+    return out, new_xyz
+
+
 def farthest_point_sample(npoint, inp):
     """npoint: int; inp (b,n,3) float32 -> (b,npoint) int32.  Not differentiable."""
     if npoint <= 0:
@@ -26,6 +44,8 @@ def farthest_point_sample(npoint, inp):
     _chk_xyz(inp, "inp", "FarthestPointSample")
     inp = inp.detach().contiguous()
     b, n, _ = inp.shape
+    if USE_BUCKET_FPS and FPS_REG_MAX < n <= FPS_BUCKET_MAX:
+        return _fps_large(npoint, inp, False)[0]
     out = torch.empty((b, npoint), dtype=torch.int32, device=inp.device)
     temp = None
     if n > 16384:  # PN2_FPS_MAX_REG_POINTS: the streaming kernel needs the reference's (32,n) scratch
@@ -80,6 +100,8 @@ def farthest_point_sample_and_gather(npoint, inp):
     _chk_xyz(inp, "inp", "FarthestPointSample")
     inp = inp.detach().contiguous()
     b, n, _ = inp.shape
+    if USE_BUCKET_FPS and FPS_REG_MAX < n <= FPS_BUCKET_MAX:
+        return _fps_large(npoint, inp, True)
     out = torch.empty((b, npoint), dtype=torch.int32, device=inp.device)
     new_xyz = torch.empty((b, npoint, 3), dtype=torch.float32, device=inp.device)
     temp = None

@@ -672,3 +672,47 @@ def test_kernels_against_frozen_extra_fixtures(pn2, cuda):
     assert np.array_equal(T(x["bf"], cuda).to(torch.bfloat16).float().cpu().numpy(), g["bf16"])
     loss = pn2.model.get_loss(T(x["logits"], cuda), T(x["labels"].astype(np.int64), cuda), T(x["smpw"], cuda))
     assert abs(float(loss) - float(g["ce"])) < 1e-5
+
+
+# ------------------------------------------------------------------ FPS for large clouds (Morton buckets) ----
+@pytest.mark.parametrize("mode", [0, 1, 2])
+@pytest.mark.parametrize("case", ["scene_20000", "scene_65536", "grid_ties", "clustered", "duplicates", "ragged_batch", "line"])
+def test_fps_large_bucket_kernel_bit_exact(pn2, oracle, cuda, case, mode):
+    """pn2_fps_large (Morton buckets + bounding-box skipping) picks exactly what the reference algorithm picks
+    (oracle) and what the streaming kernel picks -- including lattice clouds where almost every round is decided
+    by the (k mod 512, k) tie-break -- and returns the picked coordinates."""
+    sm = pn2.tf_ops.tf_sampling
+    rs = np.random.RandomState(len(case))
+    if case == "scene_20000":
+        xyz, m = s_scene(41, 1, 20000), 700
+    elif case == "scene_65536":
+        xyz, m = s_scene(42, 1, 65536), 1024
+    elif case == "grid_ties":
+        xyz, m = s_grid(43, 1, 40000, 32), 600
+    elif case == "clustered":  # tight clusters far apart: most buckets are skipped from the start
+        c = rs.uniform(-50, 50, (1, 40, 3))
+        xyz = (c[:, rs.randint(0, 40, 30000)] + rs.normal(0, 0.05, (1, 30000, 3))).astype(np.float32); m = 500
+    elif case == "duplicates":
+        base = rs.rand(1, 300, 3).astype(np.float32)
+        xyz = base[:, rs.randint(0, 300, 17000)]; m = 350  # more picks than distinct points: td reaches 0 everywhere
+    elif case == "ragged_batch":
+        xyz, m = s_scene(44, 3, 16385 + 37), 300
+    else:  # line: degenerate bounding box on two axes
+        xyz = np.zeros((1, 18000, 3), np.float32); xyz[..., 0] = rs.rand(1, 18000); m = 400
+    xyz = np.ascontiguousarray(xyz, np.float32)
+    pn2.config.arith_mode = mode
+    try:
+        ref = oracle.farthest_point_sample(m, xyz, mode)
+        idx, new_xyz = sm.farthest_point_sample_and_gather(m, T(xyz, cuda))
+        only_idx = pn2.farthest_point_sample(m, T(xyz, cuda))
+        sm.USE_BUCKET_FPS = False
+        try:
+            streamed = pn2.farthest_point_sample(m, T(xyz, cuda))
+        finally:
+            sm.USE_BUCKET_FPS = True
+    finally:
+        pn2.config.arith_mode = 1
+    assert np.array_equal(idx.cpu().numpy(), ref)
+    assert np.array_equal(only_idx.cpu().numpy(), ref)
+    assert np.array_equal(streamed.cpu().numpy(), ref)
+    assert np.array_equal(new_xyz.cpu().numpy(), oracle.gather_point(xyz, ref))
