@@ -153,7 +153,7 @@ fps_bucket_kernel(int n, int npad, int m, const float* __restrict__ xyz_all, con
     unsigned short* alist = reinterpret_cast<unsigned short*>(&bb[6][0]);                     // buckets the current pick can change
     __shared__ unsigned long long slots[4];
     __shared__ float4 spick;
-    __shared__ int acount, wbucket;
+    __shared__ int acount;
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -251,13 +251,15 @@ fps_bucket_kernel(int n, int npad, int m, const float* __restrict__ xyz_all, con
         __syncthreads();
         const unsigned long long win = slots[slot];
 #pragma unroll
-        for (int u = 0; u < kFbBPT; ++u)
-            if (tid + kFbThreads * u < nb && mykey[u] == win) wbucket = tid + kFbThreads * u;  // keys are unique per point
-        __syncthreads();
+        for (int u = 0; u < kFbBPT; ++u) {
+            const int bk = tid + kFbThreads * u;
+            if (bk < nb && mykey[u] == win) {  // exactly one thread: keys are unique per point (pads share a bucket)
+                const float4 w = bwin[bk];
+                spick = w;
+                out[j] = __float_as_int(w.w);
+            }
+        }
         if (tid == 0) {
-            const float4 w = bwin[wbucket];
-            spick = w;
-            out[j] = __float_as_int(w.w);
             const int nxt = slot == 2 ? 0 : slot + 1;
             slots[nxt == 2 ? 0 : nxt + 1] = 0ull;  // (j+2) % 3
         }
