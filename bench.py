@@ -333,7 +333,11 @@ def main():
     hp["batch_size"], hp["num_point"] = args.batch, args.points
     B, N = args.batch, args.points
     if args.train:
-        return bench_train(pn2, args, hp, B, N, rank, world, dev)
+        bench_train(pn2, args, hp, B, N, rank, world, dev)
+        if dist_on:
+            dist.barrier()
+            dist.destroy_process_group()
+        return
 
     pc_np = s_scene(1000 + rank, B, N)        # each rank its own scenes (weak scaling)
     pc = torch.from_numpy(pc_np).to(dev)      # resident in HBM before the timed region
