@@ -162,6 +162,11 @@ int pn2_three_interpolate_grad(int b, int n, int c, int m, const float *grad_out
 int pn2_linear(int rows, int cin, int cout, const float *x, const float *w,
                const float *bias, int relu, int pool, float *y, void *stream);
 
+/* Weight gradient of that layer for the training path: dw (cin,cout) = x^T (cin,rows) . dy (rows,cout), overwritten.
+ * (The reduction over all B*M*K rows that TF / hipBLASLt run as a tall-skinny GEMM.)  fp32 MFMA, partial tiles
+ * merged with fp32 atomics: the summation order varies from run to run like the reference's atomicAdd gradients. */
+int pn2_linear_wgrad(int rows, int cin, int cout, const float *x, const float *dy, float *dw, void *stream);
+
 /* Fused set-abstraction MLP (pointnet_util.py:43-54 + :150-170, inference BN
  * folded): for every (b, j) group gathers nsample neighbours by idx, builds
  * [xyz[idx]-new_xyz | points[idx]] (xyz first, pointnet_util.py:52-54), runs up

@@ -264,6 +264,70 @@ int launch_linear(int rows, int cin, int cout, const float* x, const float* w, c
     return PN2_OK;
 }
 
+// Weight gradient of a dense layer (training): dW (cin, cout) = x^T (cin, rows) . dy (rows, cout), the reduction over
+// ALL rows (524288 for SA1) that hipBLASLt runs at ~10 % of the memory roofline on these tall-skinny shapes.  One
+// wave owns a (32*TM x 32*TN) tile of dW for a chunk of rows and streams x and dy straight from HBM into the MFMA
+// operands -- a 32x32x2 step contracts two rows: lanes 0-31 carry row r, lanes 32-63 row r+1, each a contiguous
+// 128-byte segment of x (A operand, m = cin index) and of dy (B operand, n = cout index) -- then adds its partial
+// tile to dW with fp32 atomics (dW zeroed by the entry point).  Memory-bound: every row is read once per tile column.
+template <int TM, int TN>
+__global__ void __launch_bounds__(256)
+linear_wgrad_kernel(int rows, int cin, int cout, int chunk, const float* __restrict__ x,
+                    const float* __restrict__ dy, float* __restrict__ dw) {
+    const int lane = threadIdx.x & 63, half = lane >> 5, l31 = lane & 31;
+    const int wave = threadIdx.x >> 6;
+    const long long r0 = ((long long)blockIdx.x * 4 + wave) * chunk;
+    if (r0 >= rows) return;
+    const long long r1 = r0 + chunk < rows ? r0 + chunk : rows;
+    const int m0 = blockIdx.y * 32 * TM, n0 = blockIdx.z * 32 * TN;
+    int mc[TM], nc[TN];
+    bool mv[TM], nv[TN];
+#pragma unroll
+    for (int t = 0; t < TM; ++t) { const int m = m0 + t * 32 + l31; mv[t] = m < cin; mc[t] = mv[t] ? m : cin - 1; }
+#pragma unroll
+    for (int t = 0; t < TN; ++t) { const int n = n0 + t * 32 + l31; nv[t] = n < cout; nc[t] = nv[t] ? n : cout - 1; }
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int a = 0; a < TM; ++a)
+#pragma unroll
+        for (int b = 0; b < TN; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+    constexpr int U = 4;  // k-steps (pairs of rows) whose loads are issued before their MFMAs
+    for (long long r = r0; r < r1; r += 2 * U) {
+        float av[U][TM], bv[U][TN];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const long long row = r + 2 * u + half;
+            const bool rv = row < r1;
+            const long long rc = rv ? row : r1 - 1;  // clamped: unconditional loads, counted waits
+#pragma unroll
+            for (int t = 0; t < TM; ++t) { const float v = x[rc * cin + mc[t]]; av[u][t] = (rv && mv[t]) ? v : 0.f; }
+#pragma unroll
+            for (int t = 0; t < TN; ++t) { const float v = dy[rc * cout + nc[t]]; bv[u][t] = (rv && nv[t]) ? v : 0.f; }
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+#pragma unroll
+            for (int a = 0; a < TM; ++a)
+#pragma unroll
+                for (int b = 0; b < TN; ++b)
+                    acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[u][a], bv[u][b], acc[a][b], 0, 0, 0);
+    }
+    // D[i][j]: j = l31 (cout index), i = (r&3) + 8*(r>>2) + 4*half (cin index)
+#pragma unroll
+    for (int a = 0; a < TM; ++a)
+#pragma unroll
+        for (int b = 0; b < TN; ++b) {
+            const int n = n0 + b * 32 + l31;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = m0 + a * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+                if (m < cin && n < cout) atomicAdd(&dw[(size_t)m * cout + n], acc[a][b][r]);
+            }
+        }
+}
+
 // grouped input of an SA layer: out[b,j,k,:] = [xyz[b,idx]-new_xyz[b,j] | points[b,idx]]
 // (xyz FIRST: util/pointnet_util.py:43-54).  One thread per output float.
 __global__ void __launch_bounds__(256)
@@ -338,6 +402,35 @@ extern "C" int pn2_debug_set_linear(int what, int value) {
     if (what == 5) { g_lin_stages = value; return 0; }
     if (what == 8) { g_lin_cfg = value; return 0; }
     return PN2_EINVAL;
+}
+
+// dW = x^T . dy (see linear_wgrad_kernel): the training path's weight gradient.  dw (cin, cout) is overwritten.
+extern "C" int pn2_linear_wgrad(int rows, int cin, int cout, const float* x, const float* dy, float* dw, void* stream) {
+    if (rows <= 0 || cin <= 0 || cout <= 0) return PN2_EINVAL;
+    if (!x || !dy || !dw) return PN2_ENULL;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    hipError_t e = hipMemsetAsync(dw, 0, sizeof(float) * (size_t)cin * cout, st);
+    if (e != hipSuccess) return (int)e;
+    // tile: up to 64 x 128 of dW per wave; rows split so that ~8192 waves are in flight (>= 64 rows each)
+    const int tm = cin > 32 ? 2 : 1, tn = cout > 64 ? 4 : (cout > 32 ? 2 : 1);
+    const int gy = (cin + 32 * tm - 1) / (32 * tm), gz = (cout + 32 * tn - 1) / (32 * tn);
+    long long waves = 8192 / ((long long)gy * gz);
+    if (waves < 64) waves = 64;
+    int chunk = (int)((rows + waves - 1) / waves);
+    chunk = (chunk + 7) & ~7;
+    if (chunk < 64) chunk = 64;
+    const int nchunks = (rows + chunk - 1) / chunk;
+    dim3 grid((nchunks + 3) / 4, gy, gz);
+#define PN2_WG(TM_, TN_) linear_wgrad_kernel<TM_, TN_><<<grid, 256, 0, st>>>(rows, cin, cout, chunk, x, dy, dw)
+    if (tm == 1 && tn == 1) PN2_WG(1, 1);
+    else if (tm == 1 && tn == 2) PN2_WG(1, 2);
+    else if (tm == 1 && tn == 4) PN2_WG(1, 4);
+    else if (tm == 2 && tn == 1) PN2_WG(2, 1);
+    else if (tm == 2 && tn == 2) PN2_WG(2, 2);
+    else PN2_WG(2, 4);
+#undef PN2_WG
+    PN2_RETURN_IF_LAUNCH_FAILED();
+    return PN2_OK;
 }
 
 // internal helper (exported for the host package's unfused SA path and for tests)

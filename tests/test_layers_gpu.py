@@ -717,3 +717,54 @@ def test_large_scene_bf16_config4(pn2, oracle, cuda):
     assert "pn2_sa_mlp_max_fused_bf16" in calls and got.shape == (1, 4096, 128)
     scale = np.abs(ref).max()
     assert np.abs(got - ref).max() <= 4e-3 * scale
+
+
+# ------------------------------------------------------------------ training: weight gradient kernel ---------
+@pytest.mark.parametrize("rows,cin,cout", [(524288 // 8, 6, 32), (4096, 32, 64), (1000, 67, 64), (777, 259, 256), (64, 131, 128),
+                                           (5, 3, 9), (20000, 128, 512), (33, 768, 256)])
+def test_linear_wgrad_vs_fp64(pn2, cuda, rows, cin, cout):
+    """pn2_linear_wgrad: dW = x^T . dy against float64 (fp32 products are exact; only the summation order differs)."""
+    import ctypes
+    import torch
+    rs = np.random.RandomState(rows + cin)
+    x = rs.randn(rows, cin).astype(np.float32)
+    dy = rs.randn(rows, cout).astype(np.float32)
+    dw = torch.empty((cin, cout), dtype=torch.float32, device=cuda)
+    P = lambda t: ctypes.c_void_p(t.data_ptr())
+    tx, tdy = T(x, cuda), T(dy, cuda)
+    assert pn2._lib.lib.pn2_linear_wgrad(rows, cin, cout, P(tx), P(tdy), P(dw), None) == 0
+    torch.cuda.synchronize()
+    ref = x.astype(np.float64).T @ dy.astype(np.float64)
+    err = np.abs(dw.cpu().numpy() - ref)
+    assert err.max() <= 1e-5 * np.sqrt(rows) * 8, err.max()  # random-walk growth of the fp32 rounding
+    assert err.max() <= 2e-4 * np.abs(ref).max() + 1e-3
+
+
+def test_training_gradients_with_hip_wgrad_match_torch(pn2, cuda):
+    """One training forward/backward with the HIP weight-gradient kernel == the same step with torch's GEMM (to fp32
+    summation-order noise) for every parameter."""
+    import torch
+    tfu = pn2.util.tf_util
+    hp = dict(pn2.model.SEMANTIC_HYPERPARAMS)
+    hp.update(l1_npoint=128, l2_npoint=32, l3_npoint=16, l4_npoint=8)
+    rs = np.random.RandomState(0)
+    pc = T(np.concatenate([s_scene(1, 2, 1024), rs.random_sample((2, 1024, 3)).astype(np.float32)], 2), cuda)
+    labels = T(rs.randint(0, 9, (2, 1024)).astype(np.int64), cuda)
+    smpw = T((rs.random_sample((2, 1024)) + 0.5).astype(np.float32), cuda)
+    grads = []
+    for use in (True, False):
+        tfu.USE_HIP_WGRAD = use
+        try:
+            store = tfu.set_default_store(tfu.VariableStore(device=cuda, seed=5))
+            torch.manual_seed(123)  # same dropout mask in both runs
+            logits, _ = pn2.model.get_model(pc, True, 9, hp, bn_decay=0.5)
+            loss = pn2.model.get_loss(logits, labels, smpw)
+            loss.backward()
+            grads.append({k: v.grad.detach().clone() for k, v in store.params.items() if v.grad is not None})
+        finally:
+            tfu.USE_HIP_WGRAD = True
+    assert grads[0].keys() == grads[1].keys() and len(grads[0]) > 40
+    for k in grads[0]:
+        a, b = grads[0][k], grads[1][k]
+        scale = float(b.abs().max())
+        assert float((a - b).abs().max()) <= 2e-3 * scale + 1e-5, (k, float((a - b).abs().max()), scale)
