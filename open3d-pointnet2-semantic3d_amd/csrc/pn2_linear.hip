@@ -271,21 +271,25 @@ int launch_linear(int rows, int cin, int cout, const float* x, const float* w, c
 // 128-byte segment of x (A operand, m = cin index) and of dy (B operand, n = cout index) -- then adds its partial
 // tile to dW with fp32 atomics (dW zeroed by the entry point).  Memory-bound: every row is read once per tile column.
 template <int TM, int TN>
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(256, 2)
 linear_wgrad_kernel(int rows, int cin, int cout, int chunk, const float* __restrict__ x,
                     const float* __restrict__ dy, float* __restrict__ dw) {
     const int lane = threadIdx.x & 63, half = lane >> 5, l31 = lane & 31;
-    const int wave = threadIdx.x >> 6;
-    const long long r0 = ((long long)blockIdx.x * 4 + wave) * chunk;
-    if (r0 >= rows) return;
-    const long long r1 = r0 + chunk < rows ? r0 + chunk : rows;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // row bookkeeping stays in SGPRs
+    const long long c0 = ((long long)blockIdx.x * 4 + wave) * chunk;
+    // a wave past the end contributes zeros (it still takes part in the block reduction)
+    const int r0 = c0 < rows ? (int)c0 : rows;
+    const int r1 = c0 + chunk < rows ? (int)(c0 + chunk) : rows;
     const int m0 = blockIdx.y * 32 * TM, n0 = blockIdx.z * 32 * TN;
-    int mc[TM], nc[TN];
-    bool mv[TM], nv[TN];
+    // per-lane element offsets inside a pair of rows; the pair's base address is wave-uniform (SGPR base + VGPR offset
+    // loads: no per-load 64-bit address registers).  Columns past cin / cout read clamped data and are dropped at the
+    // store.
+    const int hoff = rows > 1 ? half : 0;
+    unsigned offa[TM], offb[TN];
 #pragma unroll
-    for (int t = 0; t < TM; ++t) { const int m = m0 + t * 32 + l31; mv[t] = m < cin; mc[t] = mv[t] ? m : cin - 1; }
+    for (int t = 0; t < TM; ++t) { const int m = m0 + t * 32 + l31; offa[t] = (unsigned)(hoff * cin + (m < cin ? m : cin - 1)); }
 #pragma unroll
-    for (int t = 0; t < TN; ++t) { const int n = n0 + t * 32 + l31; nv[t] = n < cout; nc[t] = nv[t] ? n : cout - 1; }
+    for (int t = 0; t < TN; ++t) { const int n = n0 + t * 32 + l31; offb[t] = (unsigned)(hoff * cout + (n < cout ? n : cout - 1)); }
     f32x16 acc[TM][TN];
 #pragma unroll
     for (int a = 0; a < TM; ++a)
@@ -293,27 +297,78 @@ linear_wgrad_kernel(int rows, int cin, int cout, int chunk, const float* __restr
         for (int b = 0; b < TN; ++b)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
-    constexpr int U = 4;  // k-steps (pairs of rows) whose loads are issued before their MFMAs
-    for (long long r = r0; r < r1; r += 2 * U) {
-        float av[U][TM], bv[U][TN];
+    // Register double buffer: the loads of the NEXT U k-steps (pairs of rows) are in flight while the MFMAs of the
+    // current U run.  Loads are unconditional (pair base clamped to the last pair of the matrix) so the compiler waits
+    // with counted vmcnt.  A lane contributes iff the row it loaded belongs to this k-step and to this chunk; otherwise
+    // A = 0 is enough (the dy values it pairs with are finite data of the matrix).
+    constexpr int U = 4;
+    const int last_pair = rows > 1 ? rows - 2 : 0;
+    float av0[U][TM], bv0[U][TN], av1[U][TM], bv1[U][TN];
+    auto fetch = [&](float (&av)[U][TM], float (&bv)[U][TN], int r) {
 #pragma unroll
         for (int u = 0; u < U; ++u) {
-            const long long row = r + 2 * u + half;
-            const bool rv = row < r1;
-            const long long rc = rv ? row : r1 - 1;  // clamped: unconditional loads, counted waits
+            const int rb = r + 2 * u < last_pair ? r + 2 * u : last_pair;
+            const float* __restrict__ px = x + (size_t)rb * cin;
+            const float* __restrict__ pd = dy + (size_t)rb * cout;
 #pragma unroll
-            for (int t = 0; t < TM; ++t) { const float v = x[rc * cin + mc[t]]; av[u][t] = (rv && mv[t]) ? v : 0.f; }
+            for (int t = 0; t < TM; ++t) av[u][t] = px[offa[t]];
 #pragma unroll
-            for (int t = 0; t < TN; ++t) { const float v = dy[rc * cout + nc[t]]; bv[u][t] = (rv && nv[t]) ? v : 0.f; }
+            for (int t = 0; t < TN; ++t) bv[u][t] = pd[offb[t]];
         }
+    };
+    auto contract = [&](const float (&av)[U][TM], const float (&bv)[U][TN], int r) {
 #pragma unroll
-        for (int u = 0; u < U; ++u)
+        for (int u = 0; u < U; ++u) {
+            const int rb = r + 2 * u < last_pair ? r + 2 * u : last_pair;
+            const int loaded = rb + half;
+            const bool rv = loaded >= r + 2 * u && loaded < r1;
 #pragma unroll
-            for (int a = 0; a < TM; ++a)
+            for (int a = 0; a < TM; ++a) {
+                const float av_m = rv ? av[u][a] : 0.f;
 #pragma unroll
                 for (int b = 0; b < TN; ++b)
-                    acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[u][a], bv[u][b], acc[a][b], 0, 0, 0);
+                    acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(av_m, bv[u][b], acc[a][b], 0, 0, 0);
+            }
+        }
+    };
+    fetch(av0, bv0, r0);
+    for (int r = r0; r < r1; r += 4 * U) {
+        fetch(av1, bv1, r + 2 * U);
+        __builtin_amdgcn_sched_barrier(0);
+        contract(av0, bv0, r);
+        __builtin_amdgcn_sched_barrier(0);
+        fetch(av0, bv0, r + 4 * U);
+        __builtin_amdgcn_sched_barrier(0);
+        contract(av1, bv1, r + 2 * U);
+        __builtin_amdgcn_sched_barrier(0);
     }
+    // the four waves of the block own consecutive row chunks of the SAME tile: add them up through LDS (two tree steps)
+    // so that only one wave per block issues the global atomics
+    __shared__ float red[2][TM * TN * 16 * 64];
+    auto spill = [&](float* dst) {
+#pragma unroll
+        for (int a = 0; a < TM; ++a)
+#pragma unroll
+            for (int b = 0; b < TN; ++b)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) dst[((a * TN + b) * 16 + r) * 64 + lane] = acc[a][b][r];
+    };
+    auto absorb = [&](const float* src) {
+#pragma unroll
+        for (int a = 0; a < TM; ++a)
+#pragma unroll
+            for (int b = 0; b < TN; ++b)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[a][b][r] += src[((a * TN + b) * 16 + r) * 64 + lane];
+    };
+    if (wave >= 2) spill(red[wave - 2]);
+    __syncthreads();
+    if (wave < 2) absorb(red[wave]);
+    __syncthreads();
+    if (wave == 1) spill(red[0]);
+    __syncthreads();
+    if (wave != 0) return;
+    absorb(red[0]);
     // D[i][j]: j = l31 (cout index), i = (r&3) + 8*(r>>2) + 4*half (cin index)
 #pragma unroll
     for (int a = 0; a < TM; ++a)
@@ -357,6 +412,7 @@ sa_group_concat_kernel(int n, int m, int nsample, int c, const float* __restrict
 
 int g_lin_cfg = 0;     // tuning hook (pn2_debug_set(8, v)): 0 = auto, 1..4 = force <4,1,4> / <2,2,2> / <1,4,1> / <1,2,1,split-K>
 int g_lin_stages = 3;  // tuning hook (pn2_debug_set(5, v)): register prefetch depth of linear_kernel
+int g_wgrad_waves = 0; // tuning hook (pn2_debug_set(9, v)): waves in flight targeted by pn2_linear_wgrad (0 = auto)
 
 extern "C" int pn2_linear(int rows, int cin, int cout, const float* x, const float* w,
                           const float* bias, int relu, int pool, float* y, void* stream) {
@@ -401,6 +457,7 @@ extern "C" int pn2_linear(int rows, int cin, int cout, const float* x, const flo
 extern "C" int pn2_debug_set_linear(int what, int value) {
     if (what == 5) { g_lin_stages = value; return 0; }
     if (what == 8) { g_lin_cfg = value; return 0; }
+    if (what == 9) { g_wgrad_waves = value; return 0; }
     return PN2_EINVAL;
 }
 
@@ -408,14 +465,17 @@ extern "C" int pn2_debug_set_linear(int what, int value) {
 extern "C" int pn2_linear_wgrad(int rows, int cin, int cout, const float* x, const float* dy, float* dw, void* stream) {
     if (rows <= 0 || cin <= 0 || cout <= 0) return PN2_EINVAL;
     if (!x || !dy || !dw) return PN2_ENULL;
+    if ((long long)rows + 128 > 0x7fffffffLL) return PN2_ERANGE;
     hipStream_t st = static_cast<hipStream_t>(stream);
     hipError_t e = hipMemsetAsync(dw, 0, sizeof(float) * (size_t)cin * cout, st);
     if (e != hipSuccess) return (int)e;
-    // tile: up to 64 x 128 of dW per wave; rows split so that ~8192 waves are in flight (>= 64 rows each)
+    // tile: up to 64 x 128 of dW per wave; rows split so that ~1024 waves (256 blocks) are in flight (>= 64 rows each;
+    // measured best of 256..8192 over the training layer shapes, tools/wgrad_sweep.py);
+    // each block adds its four partial tiles in LDS and issues one set of atomics
     const int tm = cin > 32 ? 2 : 1, tn = cout > 64 ? 4 : (cout > 32 ? 2 : 1);
     const int gy = (cin + 32 * tm - 1) / (32 * tm), gz = (cout + 32 * tn - 1) / (32 * tn);
-    long long waves = 8192 / ((long long)gy * gz);
-    if (waves < 64) waves = 64;
+    long long waves = (g_wgrad_waves > 0 ? g_wgrad_waves : 1024) / ((long long)gy * gz);
+    if (waves < 16) waves = 16;
     int chunk = (int)((rows + waves - 1) / waves);
     chunk = (chunk + 7) & ~7;
     if (chunk < 64) chunk = 64;
