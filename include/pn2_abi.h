@@ -149,6 +149,16 @@ int pn2_three_interpolate_grad(int b, int n, int c, int m, const float *grad_out
                                const int *idx, const float *weight,
                                float *grad_points, void *stream);
 
+/* The same gradient with caller-provided scratch: large levels build a per-source-point list of (query, weight)
+ * with 3*n integer atomics per cloud and then GATHER each grad_points row (no float atomics: 690 -> ~60 us on the
+ * b=16, n=8192, m=1024, c=128 level of the training step); small levels, c % 4 != 0 or workspace == NULL run
+ * pn2_three_interpolate_grad.  `workspace`: 4-byte aligned device scratch of at least
+ * pn2_three_interpolate_grad_workspace_bytes(b, n, m) bytes.  Summation order varies from run to run. */
+size_t pn2_three_interpolate_grad_workspace_bytes(int b, int n, int m);
+int pn2_three_interpolate_grad_ws(int b, int n, int c, int m, const float *grad_out, const int *idx,
+                                  const float *weight, float *grad_points, void *workspace,
+                                  size_t workspace_bytes, void *stream);
+
 /* ---- fused layer kernels (new: no reference kernel; they replace the TF
  *      sub-graphs of util/pointnet_util.py:44-54,150-170 and :300-325) ------- */
 
@@ -166,6 +176,30 @@ int pn2_linear(int rows, int cin, int cout, const float *x, const float *w,
  * (The reduction over all B*M*K rows that TF / hipBLASLt run as a tall-skinny GEMM.)  fp32 MFMA, partial tiles
  * merged with fp32 atomics: the summation order varies from run to run like the reference's atomicAdd gradients. */
 int pn2_linear_wgrad(int rows, int cin, int cout, const float *x, const float *dy, float *dw, void *stream);
+
+/* Training-mode batch normalisation + ReLU of a dense layer's output y (rows,c), channels last
+ * (util/tf_util.py:555-581 batch_norm_template -> tf.contrib.layers.batch_norm, applied by conv2d / conv1d /
+ * fully_connected at tf_util.py:186-204 and followed by tf.nn.relu):
+ *   mean, var = per-channel batch moments over all rows (biased var; fp64 accumulation)
+ *   z = relu?( gamma * (y - mean) / sqrt(var + eps) + beta )
+ *   running_mean = decay*running_mean + (1-decay)*(mean + bias),  running_var likewise with the UNBIASED batch variance
+ * `bias` (nullable, (c)) is the layer bias the caller folded away: a per-channel constant in front of BN only moves
+ * the mean, so it enters the moving average and nothing else.  running_mean / running_var may both be NULL.
+ * save_mean / save_invstd (c) are kept for pn2_bn_relu_backward.  `workspace`: 8-byte aligned device scratch of at
+ * least pn2_bn_workspace_bytes(c) bytes (fp64 per-channel accumulators, contents irrelevant on entry).  c <= 1024; c % 4 != 0 needs c <= 256. */
+size_t pn2_bn_workspace_bytes(int c);
+int pn2_bn_relu_forward(long long rows, int c, const float *y, const float *gamma, const float *beta,
+                        const float *bias, float eps, float decay, int relu, float *running_mean,
+                        float *running_var, void *workspace, size_t workspace_bytes, float *save_mean,
+                        float *save_invstd, float *z, void *stream);
+/* Its gradient (what tf.gradients derives for the two ops above): with g = dz * [z > 0] (relu) and
+ * xhat = (y - mean) * invstd,
+ *   dbeta = sum_r g,  dgamma = sum_r g*xhat,  dy = gamma*invstd * (g - dbeta/rows - xhat * dgamma/rows).
+ * dy may alias dz.  The ReLU mask is recomputed from y with the forward's own float expressions. */
+int pn2_bn_relu_backward(long long rows, int c, const float *dz, const float *y, const float *gamma,
+                         const float *beta, const float *save_mean, const float *save_invstd, int relu,
+                         void *workspace, size_t workspace_bytes, float *dy, float *dgamma, float *dbeta,
+                         void *stream);
 
 /* Fused set-abstraction MLP (pointnet_util.py:43-54 + :150-170, inference BN
  * folded): for every (b, j) group gathers nsample neighbours by idx, builds

@@ -32,8 +32,14 @@ SIGNATURES = {
     "pn2_three_nn": [c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p],
     "pn2_three_interpolate": [c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p],
     "pn2_three_interpolate_grad": [c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p],
+    "pn2_three_interpolate_grad_ws": [c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                                      ctypes.c_size_t, c_void_p],
     "pn2_linear": [c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p],
     "pn2_linear_wgrad": [c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p],
+    "pn2_bn_relu_forward": [ctypes.c_longlong, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_float, c_int,
+                            c_void_p, c_void_p, c_void_p, ctypes.c_size_t, c_void_p, c_void_p, c_void_p, c_void_p],
+    "pn2_bn_relu_backward": [ctypes.c_longlong, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int,
+                             c_void_p, ctypes.c_size_t, c_void_p, c_void_p, c_void_p, c_void_p],
     "pn2_sa_mlp_max_fused": [c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p,
                              c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p],
     "pn2_sa_mlp_max_fused_bf16": [c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p,
@@ -83,6 +89,10 @@ def _load():
     lib.pn2_fps_large_workspace_bytes.restype = ctypes.c_size_t
     lib.pn2_interpolate_label_workspace_bytes.argtypes = [c_int]
     lib.pn2_interpolate_label_workspace_bytes.restype = ctypes.c_size_t
+    lib.pn2_three_interpolate_grad_workspace_bytes.argtypes = [c_int, c_int, c_int]
+    lib.pn2_three_interpolate_grad_workspace_bytes.restype = ctypes.c_size_t
+    lib.pn2_bn_workspace_bytes.argtypes = [c_int]
+    lib.pn2_bn_workspace_bytes.restype = ctypes.c_size_t
     lib.pn2_abi_version.restype = c_int
     lib.pn2_build_info.restype = ctypes.c_char_p
     lib.pn2_strerror.restype = ctypes.c_char_p

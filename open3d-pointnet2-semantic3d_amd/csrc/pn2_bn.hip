@@ -1,0 +1,379 @@
+// pn2_bn.hip -- training-mode batch normalisation (+ ReLU) of a dense layer's output, forward and backward, for the
+// data-parallel training path (reference: util/tf_util.py:555-581 batch_norm_template -> tf.contrib.layers.batch_norm,
+// applied after every conv2d / conv1d of the SA / FP stack, tf_util.py:186-204, followed by tf.nn.relu).
+//
+// Layout: y (rows, c) row-major ("channels last"), the same buffer pn2_linear / the GEMM wrote.  All four kernels are
+// HBM streams: the forward reads y twice (statistics, then normalise) and writes z once; the backward reads (dz, y)
+// twice and writes dy once.  Per-channel sums are carried in fp64 (full-rate on CDNA4, the kernels are memory-bound
+// anyway) so that var = E[y^2] - E[y]^2 has no cancellation problem at fp32 accuracy.  Partial sums of a block meet in
+// LDS and leave with one fp64 atomic per channel -- but atomics on ONE address retire serially (~0.1 us each, measured:
+// 2048 blocks on 2*c addresses cost 190 us), so the blocks spread over kBnSlots copies of the accumulators (<= 32
+// atomics per address) and the last block to finish (ticket counter) folds the copies into the final 2*c sums.
+#include "pn2_common.h"
+
+namespace {
+
+constexpr int kBnMaxC = 1024;   // channels held in LDS by the apply kernels
+constexpr int kBnThreads = 256;
+constexpr int kBnSlots = 16;    // copies of the per-channel accumulators the reduction blocks spread their atomics over
+constexpr int kBnBlocks = 512;  // reduction blocks (2 per CU, 8 x 16-byte loads in flight per thread)
+
+// workspace: final[2][c] | slot[kBnSlots][2][c] (doubles) | ticket (unsigned, 8-byte slot)
+__host__ __device__ inline size_t bn_ws_doubles(int c) { return (size_t)(1 + kBnSlots) * 2 * (size_t)c; }
+
+// thread -> (row slot rr, float4 column cc): cv = c/VEC columns, rp = 256/cv rows per pass
+template <int VEC>
+struct BnMap {
+    int cv, rp, rr, cc;
+    bool active;
+    __device__ BnMap(int c) {
+        cv = c / VEC;
+        rp = kBnThreads / cv;
+        rr = (int)threadIdx.x / cv;
+        cc = (int)threadIdx.x - rr * cv;
+        active = rr < rp;
+    }
+};
+
+template <int VEC>
+__device__ __forceinline__ void bn_load(const float* __restrict__ p, float (&v)[VEC]) {
+    if constexpr (VEC == 4) {
+        const float4 t = *reinterpret_cast<const float4*>(p);
+        v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
+    } else {
+        v[0] = *p;
+    }
+}
+
+// add the per-thread partial sums (NS doubles per channel of the thread's VEC channels) over the rp row slots of
+// the block, push them to this block's slot copy of the accumulators, and let the last block fold the copies into
+// ws[0 .. NS*c) (the sums every consumer reads)
+template <int VEC, int NS>
+__device__ __forceinline__ void bn_block_sums(const BnMap<VEC>& mp, int c, double (&part)[NS][VEC], double* __restrict__ ws) {
+    __shared__ double red[kBnThreads * NS * VEC];
+    __shared__ unsigned ticket;
+    if (mp.active) {
+#pragma unroll
+        for (int s = 0; s < NS; ++s)
+#pragma unroll
+            for (int v = 0; v < VEC; ++v) red[((s * VEC + v) * mp.rp + mp.rr) * mp.cv + mp.cc] = part[s][v];
+    }
+    __syncthreads();
+    // tree over the row slots (sz need not be a power of two)
+    for (int sz = mp.rp; sz > 1;) {
+        const int h = (sz + 1) >> 1;
+        if (mp.active && mp.rr + h < sz) {
+#pragma unroll
+            for (int s = 0; s < NS; ++s)
+#pragma unroll
+                for (int v = 0; v < VEC; ++v)
+                    red[((s * VEC + v) * mp.rp + mp.rr) * mp.cv + mp.cc] += red[((s * VEC + v) * mp.rp + mp.rr + h) * mp.cv + mp.cc];
+        }
+        __syncthreads();
+        sz = h;
+    }
+    double* __restrict__ slot = ws + (size_t)NS * c * (1 + (blockIdx.x % kBnSlots));
+    if (mp.active && mp.rr == 0) {
+#pragma unroll
+        for (int s = 0; s < NS; ++s)
+#pragma unroll
+            for (int v = 0; v < VEC; ++v)
+                atomicAdd(&slot[(size_t)s * c + mp.cc * VEC + v], red[((s * VEC + v) * mp.rp) * mp.cv + mp.cc]);
+    }
+    __threadfence();  // this block's atomics are performed before its ticket
+    __syncthreads();
+    unsigned* counter = reinterpret_cast<unsigned*>(ws + bn_ws_doubles(c));
+    if (threadIdx.x == 0) ticket = atomicAdd(counter, 1u);
+    __syncthreads();
+    if (ticket != gridDim.x - 1) return;
+    __threadfence();
+    for (int col = threadIdx.x; col < NS * c; col += kBnThreads) {
+        double t = 0.0;
+#pragma unroll
+        for (int k = 0; k < kBnSlots; ++k)
+            t += __hip_atomic_load(&ws[(size_t)NS * c * (1 + k) + col], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        ws[col] = t;
+    }
+}
+
+// acc[0][ch] = sum_r y[r][ch], acc[1][ch] = sum_r y[r][ch]^2 over the block's slab of rows
+template <int VEC>
+__global__ void __launch_bounds__(kBnThreads)
+bn_stats_kernel(long long rows, int c, long long slab, const float* __restrict__ y, double* __restrict__ acc) {
+    const BnMap<VEC> mp(c);
+    const long long rb = (long long)blockIdx.x * slab;
+    const long long re = rb + slab < rows ? rb + slab : rows;
+    double part[2][VEC];
+#pragma unroll
+    for (int v = 0; v < VEC; ++v) part[0][v] = part[1][v] = 0.0;
+    if (mp.active) {
+        const float* __restrict__ p = y + (size_t)mp.cc * VEC;
+        long long r = rb + mp.rr;
+        const long long step = mp.rp;
+        for (; r + 7 * step < re; r += 8 * step) {  // eight independent loads in flight
+            float a[8][VEC];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) bn_load<VEC>(p + (size_t)(r + u * step) * c, a[u]);
+#pragma unroll
+            for (int u = 0; u < 8; ++u)
+#pragma unroll
+                for (int v = 0; v < VEC; ++v) {
+                    const double d = (double)a[u][v];
+                    part[0][v] += d;
+                    part[1][v] = __builtin_fma(d, d, part[1][v]);
+                }
+        }
+        for (; r < re; r += step) {
+            float a[VEC];
+            bn_load<VEC>(p + (size_t)r * c, a);
+#pragma unroll
+            for (int v = 0; v < VEC; ++v) {
+                const double d = (double)a[v];
+                part[0][v] += d;
+                part[1][v] = __builtin_fma(d, d, part[1][v]);
+            }
+        }
+    }
+    bn_block_sums<VEC, 2>(mp, c, part, acc);
+}
+
+// per-channel constants of the normalisation, identical float expressions in the forward and the backward kernels so
+// that the ReLU mask recomputed in the backward is the forward's: z = fma(y, sc, sh), sc = gamma*invstd,
+// sh = fma(-mean, sc, beta)
+__device__ __forceinline__ void bn_scale_shift(float gamma, float beta, float mean, float invstd, float& sc, float& sh) {
+    sc = gamma * invstd;
+    sh = __builtin_fmaf(-mean, sc, beta);
+}
+
+// z = relu?(fma(y, sc[ch], sh[ch])).  Every block derives (mean, invstd) of all channels from the fp64 sums (c rsqrt's:
+// noise next to its share of the stream); block 0 also publishes them for the backward and moves the running averages.
+template <int VEC>
+__global__ void __launch_bounds__(kBnThreads)
+bn_apply_kernel(long long rows, int c, const float* __restrict__ y, const double* __restrict__ acc,
+                const float* __restrict__ gamma, const float* __restrict__ beta, const float* __restrict__ bias,
+                float eps, float decay, int relu, float* __restrict__ running_mean, float* __restrict__ running_var,
+                float* __restrict__ save_mean, float* __restrict__ save_invstd, float* __restrict__ z) {
+    __shared__ float sc[kBnMaxC], sh[kBnMaxC];
+    const double inv_n = 1.0 / (double)rows;
+    for (int ch = threadIdx.x; ch < c; ch += kBnThreads) {
+        const double mean_d = acc[ch] * inv_n;
+        double var_d = acc[(size_t)c + ch] * inv_n - mean_d * mean_d;
+        var_d = var_d > 0.0 ? var_d : 0.0;
+        const float mean = (float)mean_d;
+        const float invstd = (float)(1.0 / __builtin_sqrt(var_d + (double)eps));
+        bn_scale_shift(gamma[ch], beta[ch], mean, invstd, sc[ch], sh[ch]);
+        if (blockIdx.x == 0) {
+            save_mean[ch] = mean;
+            save_invstd[ch] = invstd;
+            if (running_mean) {
+                // moving averages as tf's fused batch norm keeps them: the mean of the layer output INCLUDING the
+                // bias the caller folded away (a per-channel constant before BN only moves the mean), and the
+                // unbiased batch variance
+                const double m_out = mean_d + (bias ? (double)bias[ch] : 0.0);
+                const double var_unb = rows > 1 ? var_d * ((double)rows / (double)(rows - 1)) : var_d;
+                running_mean[ch] = (float)((double)decay * running_mean[ch] + (1.0 - (double)decay) * m_out);
+                running_var[ch] = (float)((double)decay * running_var[ch] + (1.0 - (double)decay) * var_unb);
+            }
+        }
+    }
+    __syncthreads();
+    const size_t total = (size_t)rows * c / VEC;
+    const size_t stride = (size_t)gridDim.x * kBnThreads;
+    const bool pow2 = (c & (c - 1)) == 0;
+    for (size_t e = (size_t)blockIdx.x * kBnThreads + threadIdx.x; e < total; e += stride) {
+        const size_t f = e * VEC;
+        const int ch = pow2 ? (int)(f & (size_t)(c - 1)) : (int)(f % (size_t)c);
+        float v[VEC];
+        bn_load<VEC>(y + f, v);
+#pragma unroll
+        for (int k = 0; k < VEC; ++k) {
+            float t = __builtin_fmaf(v[k], sc[ch + k], sh[ch + k]);
+            if (relu) t = t > 0.f ? t : 0.f;
+            v[k] = t;
+        }
+        if constexpr (VEC == 4) *reinterpret_cast<float4*>(z + f) = make_float4(v[0], v[1], v[2], v[3]);
+        else z[f] = v[0];
+    }
+}
+
+// backward pass 1: acc[0][ch] = sum_r g, acc[1][ch] = sum_r g * xhat, with g = dz * [z > 0] (relu) and
+// xhat = (y - mean) * invstd
+template <int VEC>
+__global__ void __launch_bounds__(kBnThreads)
+bn_grad_reduce_kernel(long long rows, int c, long long slab, const float* __restrict__ dz, const float* __restrict__ y,
+                      const float* __restrict__ gamma, const float* __restrict__ beta,
+                      const float* __restrict__ save_mean, const float* __restrict__ save_invstd, int relu,
+                      double* __restrict__ acc) {
+    const BnMap<VEC> mp(c);
+    const long long rb = (long long)blockIdx.x * slab;
+    const long long re = rb + slab < rows ? rb + slab : rows;
+    double part[2][VEC];
+#pragma unroll
+    for (int v = 0; v < VEC; ++v) part[0][v] = part[1][v] = 0.0;
+    if (mp.active) {
+        float sc[VEC], sh[VEC], mean[VEC], invstd[VEC];
+#pragma unroll
+        for (int v = 0; v < VEC; ++v) {
+            const int ch = mp.cc * VEC + v;
+            mean[v] = save_mean[ch];
+            invstd[v] = save_invstd[ch];
+            bn_scale_shift(gamma[ch], beta[ch], mean[v], invstd[v], sc[v], sh[v]);
+        }
+        const size_t col = (size_t)mp.cc * VEC;
+        auto take = [&](const float (&g)[VEC], const float (&a)[VEC]) {
+#pragma unroll
+            for (int v = 0; v < VEC; ++v) {
+                const bool on = !relu || __builtin_fmaf(a[v], sc[v], sh[v]) > 0.f;
+                const double gd = on ? (double)g[v] : 0.0;
+                const double xh = (double)((a[v] - mean[v]) * invstd[v]);
+                part[0][v] += gd;
+                part[1][v] = __builtin_fma(gd, xh, part[1][v]);
+            }
+        };
+        long long r = rb + mp.rr;
+        const long long step = mp.rp;
+        for (; r + 3 * step < re; r += 4 * step) {  // four rows x two streams in flight
+            float g[4][VEC], a[4][VEC];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                bn_load<VEC>(dz + (size_t)(r + u * step) * c + col, g[u]);
+                bn_load<VEC>(y + (size_t)(r + u * step) * c + col, a[u]);
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) take(g[u], a[u]);
+        }
+        for (; r < re; r += step) {
+            float g0[VEC], a0[VEC];
+            bn_load<VEC>(dz + (size_t)r * c + col, g0);
+            bn_load<VEC>(y + (size_t)r * c + col, a0);
+            take(g0, a0);
+        }
+    }
+    bn_block_sums<VEC, 2>(mp, c, part, acc);
+}
+
+// backward pass 2: dy = sc * (g - mean(g) - xhat * mean(g * xhat)); block 0 publishes dgamma = sum g*xhat, dbeta = sum g
+template <int VEC>
+__global__ void __launch_bounds__(kBnThreads)
+bn_grad_apply_kernel(long long rows, int c, const float* __restrict__ dz, const float* __restrict__ y,
+                     const double* __restrict__ acc, const float* __restrict__ gamma, const float* __restrict__ beta,
+                     const float* __restrict__ save_mean, const float* __restrict__ save_invstd, int relu,
+                     float* __restrict__ dy, float* __restrict__ dgamma, float* __restrict__ dbeta) {
+    __shared__ float sc[kBnMaxC], sh[kBnMaxC], mu[kBnMaxC], is[kBnMaxC], k1[kBnMaxC], k2[kBnMaxC];
+    const double inv_n = 1.0 / (double)rows;
+    for (int ch = threadIdx.x; ch < c; ch += kBnThreads) {
+        mu[ch] = save_mean[ch];
+        is[ch] = save_invstd[ch];
+        bn_scale_shift(gamma[ch], beta[ch], mu[ch], is[ch], sc[ch], sh[ch]);
+        k1[ch] = (float)(acc[ch] * inv_n);
+        k2[ch] = (float)(acc[(size_t)c + ch] * inv_n);
+        if (blockIdx.x == 0) {
+            dbeta[ch] = (float)acc[ch];
+            dgamma[ch] = (float)acc[(size_t)c + ch];
+        }
+    }
+    __syncthreads();
+    const size_t total = (size_t)rows * c / VEC;
+    const size_t stride = (size_t)gridDim.x * kBnThreads;
+    const bool pow2 = (c & (c - 1)) == 0;
+    for (size_t e = (size_t)blockIdx.x * kBnThreads + threadIdx.x; e < total; e += stride) {
+        const size_t f = e * VEC;
+        const int ch = pow2 ? (int)(f & (size_t)(c - 1)) : (int)(f % (size_t)c);
+        float g[VEC], a[VEC];
+        bn_load<VEC>(dz + f, g);
+        bn_load<VEC>(y + f, a);
+#pragma unroll
+        for (int k = 0; k < VEC; ++k) {
+            const int cc = ch + k;
+            const bool on = !relu || __builtin_fmaf(a[k], sc[cc], sh[cc]) > 0.f;
+            const float gk = on ? g[k] : 0.f;
+            const float xh = (a[k] - mu[cc]) * is[cc];
+            g[k] = sc[cc] * __builtin_fmaf(-xh, k2[cc], gk - k1[cc]);
+        }
+        if constexpr (VEC == 4) *reinterpret_cast<float4*>(dy + f) = make_float4(g[0], g[1], g[2], g[3]);
+        else dy[f] = g[0];
+    }
+}
+
+struct BnPlan {
+    int vec;
+    int stat_blocks, apply_blocks;
+    long long slab;
+};
+
+int bn_plan(long long rows, int c, const void* a, const void* b, const void* o, BnPlan& p) {
+    if (rows <= 0 || c <= 0) return PN2_EINVAL;
+    const bool al = (((uintptr_t)a | (uintptr_t)b | (uintptr_t)o) % 16) == 0;
+    p.vec = (c % 4 == 0 && al) ? 4 : 1;
+    if (c / p.vec > kBnThreads || c > kBnMaxC) return PN2_EUNSUP;
+    const int rp = kBnThreads / (c / p.vec);
+    // reductions: kBnBlocks blocks, each with at least 8 passes of rows
+    long long blocks = kBnBlocks;
+    long long slab = (rows + blocks - 1) / blocks;
+    const long long min_slab = (long long)rp * 8;
+    if (slab < min_slab) slab = min_slab;
+    slab = (slab + rp - 1) / rp * rp;
+    p.slab = slab;
+    p.stat_blocks = (int)((rows + slab - 1) / slab);
+    const long long total = rows * (long long)c / p.vec;
+    long long ab = (total + kBnThreads * 4 - 1) / (kBnThreads * 4);  // >= 4 elements per thread
+    if (ab > 4096) ab = 4096;
+    if (ab < 1) ab = 1;
+    p.apply_blocks = (int)ab;
+    return PN2_OK;
+}
+
+}  // namespace
+
+extern "C" size_t pn2_bn_workspace_bytes(int c) { return c > 0 ? sizeof(double) * (bn_ws_doubles(c) + 1) : 0; }
+
+extern "C" int pn2_bn_relu_forward(long long rows, int c, const float* y, const float* gamma, const float* beta,
+                                   const float* bias, float eps, float decay, int relu, float* running_mean,
+                                   float* running_var, void* workspace, size_t workspace_bytes, float* save_mean,
+                                   float* save_invstd, float* z, void* stream) {
+    if (!y || !gamma || !beta || !workspace || !save_mean || !save_invstd || !z) return PN2_ENULL;
+    if ((running_mean == nullptr) != (running_var == nullptr)) return PN2_ENULL;
+    BnPlan p;
+    const int rc = bn_plan(rows, c, y, z, nullptr, p);
+    if (rc != PN2_OK) return rc;
+    if (workspace_bytes < pn2_bn_workspace_bytes(c) || ((uintptr_t)workspace % 8) != 0) return PN2_EINVAL;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    double* acc = static_cast<double*>(workspace);
+    hipError_t e = hipMemsetAsync(acc, 0, pn2_bn_workspace_bytes(c), st);
+    if (e != hipSuccess) return (int)e;
+    if (p.vec == 4) {
+        bn_stats_kernel<4><<<p.stat_blocks, kBnThreads, 0, st>>>(rows, c, p.slab, y, acc);
+        bn_apply_kernel<4><<<p.apply_blocks, kBnThreads, 0, st>>>(rows, c, y, acc, gamma, beta, bias, eps, decay, relu,
+                                                                running_mean, running_var, save_mean, save_invstd, z);
+    } else {
+        bn_stats_kernel<1><<<p.stat_blocks, kBnThreads, 0, st>>>(rows, c, p.slab, y, acc);
+        bn_apply_kernel<1><<<p.apply_blocks, kBnThreads, 0, st>>>(rows, c, y, acc, gamma, beta, bias, eps, decay, relu,
+                                                                running_mean, running_var, save_mean, save_invstd, z);
+    }
+    PN2_RETURN_IF_LAUNCH_FAILED();
+    return PN2_OK;
+}
+
+extern "C" int pn2_bn_relu_backward(long long rows, int c, const float* dz, const float* y, const float* gamma,
+                                    const float* beta, const float* save_mean, const float* save_invstd, int relu,
+                                    void* workspace, size_t workspace_bytes, float* dy, float* dgamma, float* dbeta,
+                                    void* stream) {
+    if (!dz || !y || !gamma || !beta || !save_mean || !save_invstd || !workspace || !dy || !dgamma || !dbeta) return PN2_ENULL;
+    BnPlan p;
+    const int rc = bn_plan(rows, c, dz, y, dy, p);
+    if (rc != PN2_OK) return rc;
+    if (workspace_bytes < pn2_bn_workspace_bytes(c) || ((uintptr_t)workspace % 8) != 0) return PN2_EINVAL;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    double* acc = static_cast<double*>(workspace);
+    hipError_t e = hipMemsetAsync(acc, 0, pn2_bn_workspace_bytes(c), st);
+    if (e != hipSuccess) return (int)e;
+    if (p.vec == 4) {
+        bn_grad_reduce_kernel<4><<<p.stat_blocks, kBnThreads, 0, st>>>(rows, c, p.slab, dz, y, gamma, beta, save_mean, save_invstd, relu, acc);
+        bn_grad_apply_kernel<4><<<p.apply_blocks, kBnThreads, 0, st>>>(rows, c, dz, y, acc, gamma, beta, save_mean, save_invstd, relu, dy, dgamma, dbeta);
+    } else {
+        bn_grad_reduce_kernel<1><<<p.stat_blocks, kBnThreads, 0, st>>>(rows, c, p.slab, dz, y, gamma, beta, save_mean, save_invstd, relu, acc);
+        bn_grad_apply_kernel<1><<<p.apply_blocks, kBnThreads, 0, st>>>(rows, c, dz, y, acc, gamma, beta, save_mean, save_invstd, relu, dy, dgamma, dbeta);
+    }
+    PN2_RETURN_IF_LAUNCH_FAILED();
+    return PN2_OK;
+}

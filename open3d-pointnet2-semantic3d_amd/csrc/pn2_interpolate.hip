@@ -373,6 +373,106 @@ three_interpolate_grad_kernel(int n, int c, int m, const float* __restrict__ gra
     }
 }
 
+// ---- three_interpolate gradient without float atomics (training path) -------------------------------------
+// The scatter above issues 3*c float atomics per query row (50 M for the l1 -> l0 level of the training step: 690 us,
+// all of it atomic throughput).  Inverted: a CSR list of (query, weight) per SOURCE point is built with 3*n integer
+// atomics per cloud, then each source row is produced by one group of lanes that walks its list and reads the grad_out
+// rows with 16-byte loads -- 3x the grad_out bytes, mostly from L2, and one plain store per output element.
+__global__ void __launch_bounds__(256)
+ti_csr_count_kernel(int n3, int m, const int* __restrict__ idx_all, int* __restrict__ cnt_all) {
+    const int bi = blockIdx.y;
+    const int* __restrict__ idx = idx_all + (size_t)bi * n3;
+    int* __restrict__ cnt = cnt_all + (size_t)bi * m;
+    for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < n3; e += gridDim.x * blockDim.x) atomicAdd(&cnt[idx[e]], 1);
+}
+
+// one block per cloud: off = exclusive scan of cnt; cnt is cleared to serve as the fill cursor
+__global__ void __launch_bounds__(256)
+ti_csr_scan_kernel(int m, int* __restrict__ cnt_all, int* __restrict__ off_all) {
+    __shared__ int part[256];
+    const int bi = blockIdx.x, t = threadIdx.x;
+    int* __restrict__ cnt = cnt_all + (size_t)bi * m;
+    int* __restrict__ off = off_all + (size_t)bi * m;
+    const int per = (m + 255) / 256;
+    const int lo = t * per < m ? t * per : m, hi = lo + per < m ? lo + per : m;
+    int sum = 0;
+    for (int i = lo; i < hi; ++i) sum += cnt[i];
+    part[t] = sum;
+    __syncthreads();
+    for (int d = 1; d < 256; d <<= 1) {  // Hillis-Steele inclusive scan of the 256 partial sums
+        const int v = t >= d ? part[t - d] : 0;
+        __syncthreads();
+        part[t] += v;
+        __syncthreads();
+    }
+    int run = part[t] - sum;
+    for (int i = lo; i < hi; ++i) {
+        const int v = cnt[i];
+        off[i] = run;
+        cnt[i] = 0;
+        run += v;
+    }
+}
+
+__global__ void __launch_bounds__(256)
+ti_csr_fill_kernel(int n3, int m, const int* __restrict__ idx_all, const float* __restrict__ weight_all,
+                   const int* __restrict__ off_all, int* __restrict__ cur_all, int* __restrict__ ent_q_all,
+                   float* __restrict__ ent_w_all) {
+    const int bi = blockIdx.y;
+    const int* __restrict__ idx = idx_all + (size_t)bi * n3;
+    const float* __restrict__ w = weight_all + (size_t)bi * n3;
+    const int* __restrict__ off = off_all + (size_t)bi * m;
+    int* __restrict__ cur = cur_all + (size_t)bi * m;
+    int* __restrict__ eq = ent_q_all + (size_t)bi * n3;
+    float* __restrict__ ew = ent_w_all + (size_t)bi * n3;
+    for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < n3; e += gridDim.x * blockDim.x) {
+        const int s = idx[e];
+        const int p = off[s] + atomicAdd(&cur[s], 1);
+        eq[p] = e / 3;
+        ew[p] = w[e];
+    }
+}
+
+// thread -> (source slot, float4 column); each slot walks the list of its source point, four entries in flight
+__global__ void __launch_bounds__(256)
+ti_csr_gather_kernel(int n, int c, int m, const float* __restrict__ grad_out_all, const int* __restrict__ off_all,
+                     const int* __restrict__ ent_q_all, const float* __restrict__ ent_w_all,
+                     float* __restrict__ grad_points_all) {
+    const int cv = c >> 2;
+    const int spb = 256 / cv;  // sources per block (host guarantees cv <= 256)
+    const int slot = (int)threadIdx.x / cv, col = (int)threadIdx.x - slot * cv;
+    const int bi = blockIdx.y;
+    const int s = blockIdx.x * spb + slot;
+    if (slot >= spb || s >= m) return;
+    const int n3 = 3 * n;
+    const f32x4* __restrict__ go = reinterpret_cast<const f32x4*>(grad_out_all + (size_t)bi * n * c);
+    const int* __restrict__ off = off_all + (size_t)bi * m;
+    const int* __restrict__ eq = ent_q_all + (size_t)bi * n3;
+    const float* __restrict__ ew = ent_w_all + (size_t)bi * n3;
+    const int lo = off[s], hi = s + 1 < m ? off[s + 1] : n3;
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    int e = lo;
+    for (; e + 3 < hi; e += 4) {
+        int q[4]; float w[4]; f32x4 g[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) { q[u] = eq[e + u]; w[u] = ew[e + u]; }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) g[u] = go[(size_t)q[u] * cv + col];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            acc.x = __builtin_fmaf(g[u].x, w[u], acc.x); acc.y = __builtin_fmaf(g[u].y, w[u], acc.y);
+            acc.z = __builtin_fmaf(g[u].z, w[u], acc.z); acc.w = __builtin_fmaf(g[u].w, w[u], acc.w);
+        }
+    }
+    for (; e < hi; ++e) {
+        const f32x4 g = go[(size_t)eq[e] * cv + col];
+        const float w = ew[e];
+        acc.x = __builtin_fmaf(g.x, w, acc.x); acc.y = __builtin_fmaf(g.y, w, acc.y);
+        acc.z = __builtin_fmaf(g.z, w, acc.z); acc.w = __builtin_fmaf(g.w, w, acc.w);
+    }
+    reinterpret_cast<f32x4*>(grad_points_all + ((size_t)bi * m + s) * c)[col] = acc;
+}
+
 // Fused FP front end: inverse-distance weights (pointnet_util.py:300-303) +
 // three_interpolate + concat([interp, points1]) (pointnet_util.py:304-311).
 // One wave owns 64 consecutive rows: lane l computes the three weights of row l once (IEEE
@@ -656,6 +756,41 @@ extern "C" int pn2_three_interpolate_grad(int b, int n, int c, int m, const floa
         dim3 grid(grid_x_for((unsigned long long)n * c, 256, b), b);
         three_interpolate_grad_kernel<float, 1><<<grid, 256, 0, st>>>(n, c, m, grad_out, idx, weight, grad_points);
     }
+    PN2_RETURN_IF_LAUNCH_FAILED();
+    return PN2_OK;
+}
+
+extern "C" size_t pn2_three_interpolate_grad_workspace_bytes(int b, int n, int m) {
+    if (b <= 0 || n <= 0 || m <= 0) return 0;
+    return sizeof(int) * ((size_t)2 * b * m + (size_t)6 * b * n);  // cursor, offsets | entry query, entry weight
+}
+
+extern "C" int pn2_three_interpolate_grad_ws(int b, int n, int c, int m, const float* grad_out, const int* idx,
+                                             const float* weight, float* grad_points, void* workspace,
+                                             size_t workspace_bytes, void* stream) {
+    if (b <= 0 || m <= 0 || c <= 0 || n <= 0) return PN2_EINVAL;
+    if (!grad_out || !idx || !weight || !grad_points) return PN2_ENULL;
+    const bool gather_ok = workspace && c % 4 == 0 && c <= 1024 && (((uintptr_t)grad_out | (uintptr_t)grad_points) % 16) == 0 &&
+                           (unsigned long long)n * 3 <= 0x7fffffffull && b <= 65535;
+    // the list build costs ~4 small launches: worth it from ~1 M float atomics
+    if (!gather_ok || (unsigned long long)b * n * 3 * c < (1ull << 20))
+        return pn2_three_interpolate_grad(b, n, c, m, grad_out, idx, weight, grad_points, stream);
+    if (workspace_bytes < pn2_three_interpolate_grad_workspace_bytes(b, n, m) || ((uintptr_t)workspace % 4) != 0) return PN2_EINVAL;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    int* cnt = static_cast<int*>(workspace);
+    int* off = cnt + (size_t)b * m;
+    int* ent_q = off + (size_t)b * m;
+    float* ent_w = reinterpret_cast<float*>(ent_q + (size_t)3 * b * n);
+    hipError_t e = hipMemsetAsync(cnt, 0, sizeof(int) * (size_t)b * m, st);
+    if (e != hipSuccess) return (int)e;
+    const int n3 = 3 * n;
+    dim3 ge(grid_x_for((unsigned long long)n3, 256, b), b);
+    ti_csr_count_kernel<<<ge, 256, 0, st>>>(n3, m, idx, cnt);
+    ti_csr_scan_kernel<<<b, 256, 0, st>>>(m, cnt, off);
+    ti_csr_fill_kernel<<<ge, 256, 0, st>>>(n3, m, idx, weight, off, cnt, ent_q, ent_w);
+    const int spb = 256 / (c / 4);
+    dim3 gg((m + spb - 1) / spb, b);
+    ti_csr_gather_kernel<<<gg, 256, 0, st>>>(n, c, m, grad_out, off, ent_q, ent_w, grad_points);
     PN2_RETURN_IF_LAUNCH_FAILED();
     return PN2_OK;
 }

@@ -53,9 +53,11 @@ class _ThreeInterpolate(torch.autograd.Function):
         grad_out = grad_out.contiguous()
         b, n, c = grad_out.shape
         gp = torch.empty((b, ctx.m, c), dtype=torch.float32, device=grad_out.device)
+        nbytes = lib.pn2_three_interpolate_grad_workspace_bytes(b, n, ctx.m)
+        ws = torch.empty(nbytes // 4, dtype=torch.int32, device=grad_out.device)
         with torch.cuda.device(grad_out.device):
-            check(lib.pn2_three_interpolate_grad(b, n, c, ctx.m, ptr(grad_out), ptr(idx), ptr(weight), ptr(gp),
-                                                 stream_ptr()), "pn2_three_interpolate_grad")
+            check(lib.pn2_three_interpolate_grad_ws(b, n, c, ctx.m, ptr(grad_out), ptr(idx), ptr(weight), ptr(gp), ptr(ws),
+                                                    nbytes, stream_ptr()), "pn2_three_interpolate_grad_ws")
         return gp, None, None  # idx, weight get no gradient (tf_interpolate.py:66-72)
 
 

@@ -269,6 +269,71 @@ def _batch_norm_train(x, bnv, bn_decay):
     return y.reshape(x.shape)
 
 
+class _TrainDenseBnRelu(torch.autograd.Function):
+    """relu?(batch_norm(x2d @ w + b)) for the training path, with the normalisation on the HIP library:
+    forward = GEMM -> pn2_bn_relu_forward (fp64 batch moments, normalise + ReLU; the pre-BN bias only moves the mean,
+    so it is folded into the moving average instead of being added); backward = pn2_bn_relu_backward (ReLU mask, dgamma,
+    dbeta, dy) -> dX = dY @ w^T, dW on pn2_linear_wgrad.  Replaces nine elementwise / reduction kernels per layer."""
+
+    @staticmethod
+    def forward(ctx, x2d, w, b, gamma, beta, running_mean, running_var, decay, relu):
+        y = x2d @ w
+        rows, c = y.shape
+        z = torch.empty_like(y)
+        save_mean = torch.empty(c, dtype=torch.float32, device=y.device)
+        save_invstd = torch.empty_like(save_mean)
+        ws = torch.empty(lib.pn2_bn_workspace_bytes(c) // 8, dtype=torch.float64, device=y.device)
+        with torch.cuda.device(y.device):
+            check(lib.pn2_bn_relu_forward(rows, c, ptr(y), ptr(gamma), ptr(beta), ptr(b), BN_EPSILON, decay, int(relu),
+                                          ptr(running_mean), ptr(running_var), ptr(ws), ws.numel() * 8, ptr(save_mean),
+                                          ptr(save_invstd), ptr(z), stream_ptr()), "pn2_bn_relu_forward")
+        ctx.save_for_backward(x2d, w, y, gamma, beta, save_mean, save_invstd)
+        ctx.relu = bool(relu)
+        return z
+
+    @staticmethod
+    def backward(ctx, dz):
+        x2d, w, y, gamma, beta, save_mean, save_invstd = ctx.saved_tensors
+        rows, c = y.shape
+        dz = dz.contiguous()
+        dy = torch.empty_like(y)
+        dgamma = torch.empty_like(gamma)
+        dbeta = torch.empty_like(beta)
+        ws = torch.empty(lib.pn2_bn_workspace_bytes(c) // 8, dtype=torch.float64, device=y.device)
+        with torch.cuda.device(y.device):
+            check(lib.pn2_bn_relu_backward(rows, c, ptr(dz), ptr(y), ptr(gamma), ptr(beta), ptr(save_mean),
+                                           ptr(save_invstd), int(ctx.relu), ptr(ws), ws.numel() * 8, ptr(dy), ptr(dgamma),
+                                           ptr(dbeta), stream_ptr()), "pn2_bn_relu_backward")
+            dx = dy @ w.t() if ctx.needs_input_grad[0] else None
+            dw = None
+            if ctx.needs_input_grad[1]:
+                dw = torch.empty_like(w)
+                check(lib.pn2_linear_wgrad(rows, w.shape[0], w.shape[1], ptr(x2d), ptr(dy), ptr(dw), stream_ptr()),
+                      "pn2_linear_wgrad")
+        # a constant in front of batch norm has no effect on the output: its gradient is exactly zero
+        db = torch.zeros(c, dtype=dy.dtype, device=dy.device) if ctx.needs_input_grad[2] else None
+        return dx, dw, db, dgamma, dbeta, None, None, None, None
+
+
+USE_HIP_BN = True  # set False to run batch norm / ReLU of the training path on torch (tests / A-B)
+
+
+def _train_layer(inputs, w2d, b, bnv, bn_decay, relu):
+    """One dense layer of the training path: inputs (..., cin) -> (..., cout)."""
+    cin, cout = w2d.shape
+    if (bnv is not None and USE_HIP_BN and USE_HIP_WGRAD and inputs.is_cuda and inputs.dtype == torch.float32
+            and cout <= 1024 and (cout % 4 == 0 or cout <= 256)):
+        beta, gamma, mean, var = bnv
+        decay = 0.9 if bn_decay is None else float(bn_decay)  # tf_util.py:571
+        z = _TrainDenseBnRelu.apply(inputs.reshape(-1, cin).contiguous(), w2d.contiguous(), b, gamma, beta, mean, var,
+                                    decay, relu)
+        return z.reshape(list(inputs.shape[:-1]) + [cout])
+    y = _train_dense(inputs, w2d, b)
+    if bnv is not None:
+        y = _batch_norm_train(y, bnv, bn_decay)
+    return torch.relu(y) if relu else y
+
+
 def _batch_norm_eval(x, bnv):
     beta, gamma, mean, var = bnv
     return (x - mean) / torch.sqrt(var + BN_EPSILON) * gamma + beta
@@ -298,11 +363,7 @@ def conv2d(inputs, num_output_channels, kernel_size, scope, stride=(1, 1), paddi
                 lead[-1] //= pool
             return y.reshape(lead + [cout])
         st, w, b, bnv = _dense_variables(cin, cout, bn, (1, 1, cin, cout))
-        y = _train_dense(inputs, w.reshape(cin, cout), b)
-        if bnv is not None:
-            y = _batch_norm_train(y, bnv, bn_decay)
-        if activation_fn is not None:
-            y = activation_fn(y)
+        y = _train_layer(inputs, w.reshape(cin, cout), b, bnv, bn_decay, activation_fn is not None)
         if pool and pool > 1:
             y = y.reshape(list(y.shape[:-2]) + [y.shape[-2] // pool, pool, cout]).amax(dim=-2)
         return y
@@ -323,11 +384,7 @@ def conv1d(inputs, num_output_channels, kernel_size, scope, stride=1, padding="S
                 y = y[:, :cout].contiguous()
             return y.reshape(list(inputs.shape[:-1]) + [cout])
         st, w, b, bnv = _dense_variables(cin, cout, bn, (1, cin, cout))
-        y = _train_dense(inputs, w.reshape(cin, cout), b)
-        if bnv is not None:
-            y = _batch_norm_train(y, bnv, bn_decay)
-        if activation_fn is not None:
-            y = activation_fn(y)
+        y = _train_layer(inputs, w.reshape(cin, cout), b, bnv, bn_decay, activation_fn is not None)
         return y
 
 

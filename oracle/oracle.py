@@ -298,3 +298,48 @@ def weighted_sparse_ce(pred, label, smpw):
     ce = np.log(np.exp(z).sum(axis=1)) - z[np.arange(z.shape[0]), y]
     nz = np.count_nonzero(w)
     return float((ce * w).sum() / nz) if nz else 0.0
+
+
+BN_EPSILON = 1e-3  # tf.contrib.layers.batch_norm default epsilon (util/tf_util.py:571-581 passes none)
+
+
+def batch_norm_relu_train(y, gamma, beta, relu=True, eps=BN_EPSILON, bias=None, moving=None, decay=0.9):
+    """Training-mode tf.contrib.layers.batch_norm + tf.nn.relu on a (rows, c) layer output
+    (util/tf_util.py:555-581, called from conv2d / conv1d at :186-204): batch moments over the rows (biased
+    variance), z = relu(gamma*(y-mean)/sqrt(var+eps)+beta).  Returns (z, mean, var[, new_moving_mean,
+    new_moving_var]); the moving averages follow tf's fused kernel: mean of the layer output INCLUDING `bias`
+    (the per-channel constant added before BN) and the unbiased batch variance, blended with `decay`."""
+    y = np.asarray(y, np.float64)
+    mean = y.mean(axis=0)
+    var = y.var(axis=0)
+    z = (y - mean) / np.sqrt(var + eps) * np.asarray(gamma, np.float64) + np.asarray(beta, np.float64)
+    if relu:
+        z = np.maximum(z, 0.0)
+    if moving is None:
+        return z, mean, var
+    rows = y.shape[0]
+    mm, mv = (np.asarray(a, np.float64) for a in moving)
+    m_out = mean + (0.0 if bias is None else np.asarray(bias, np.float64))
+    var_unb = var * rows / (rows - 1) if rows > 1 else var
+    return z, mean, var, decay * mm + (1.0 - decay) * m_out, decay * mv + (1.0 - decay) * var_unb
+
+
+def batch_norm_relu_train_grad(y, gamma, beta, dz, relu=True, eps=BN_EPSILON, mask=None):
+    """Gradient of batch_norm_relu_train w.r.t. (y, gamma, beta), as tf.gradients derives it:
+    g = dz*[z>0], xhat = (y-mean)/sqrt(var+eps), dbeta = sum g, dgamma = sum g*xhat,
+    dy = gamma/sqrt(var+eps) * (g - mean(g) - xhat*mean(g*xhat)).  `mask` overrides [z>0] (to use the mask a
+    float32 implementation took for elements within rounding of zero)."""
+    y = np.asarray(y, np.float64)
+    gamma = np.asarray(gamma, np.float64)
+    mean = y.mean(axis=0)
+    invstd = 1.0 / np.sqrt(y.var(axis=0) + eps)
+    xhat = (y - mean) * invstd
+    g = np.asarray(dz, np.float64)
+    if relu:
+        if mask is None:
+            mask = (xhat * gamma + np.asarray(beta, np.float64)) > 0
+        g = g * mask
+    dbeta = g.sum(axis=0)
+    dgamma = (g * xhat).sum(axis=0)
+    dy = gamma * invstd * (g - g.mean(axis=0) - xhat * (g * xhat).mean(axis=0))
+    return dy, dgamma, dbeta

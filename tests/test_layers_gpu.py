@@ -517,11 +517,13 @@ def test_training_step_single_gpu(pn2, cuda):
     kernels + flat-bucket all-reduce (world 1) + Adam.  The loss must drop on a fixed batch."""
     import torch
     hp = dict(pn2.model.SEMANTIC_HYPERPARAMS)
-    hp.update(l1_npoint=128, l2_npoint=32, l3_npoint=16, l4_npoint=8)
+    # batch statistics over at least 128 rows in every layer: with a handful of rows the normalisation amplifies
+    # rounding differences between the two stacks by up to 1/sqrt(eps) per layer
+    hp.update(l1_npoint=256, l2_npoint=64, l3_npoint=32, l4_npoint=16)
     rs = np.random.RandomState(0)
-    pc = T(np.concatenate([s_scene(1, 2, 1024), rs.random_sample((2, 1024, 3)).astype(np.float32)], 2), cuda)
-    labels = T(rs.randint(0, 9, (2, 1024)).astype(np.int64), cuda)
-    smpw = T((rs.random_sample((2, 1024)) + 0.5).astype(np.float32), cuda)
+    pc = T(np.concatenate([s_scene(1, 8, 2048), rs.random_sample((8, 2048, 3)).astype(np.float32)], 2), cuda)
+    labels = T(rs.randint(0, 9, (8, 2048)).astype(np.int64), cuda)
+    smpw = T((rs.random_sample((8, 2048)) + 0.5).astype(np.float32), cuda)
     tr = pn2.train.Trainer(hp, 9, store=pn2.util.tf_util.VariableStore(device=cuda, seed=3))
     losses = [tr.train_step(pc, labels, smpw) for _ in range(8)]
     assert all(np.isfinite(losses))
@@ -741,16 +743,18 @@ def test_linear_wgrad_vs_fp64(pn2, cuda, rows, cin, cout):
 
 
 def test_training_gradients_with_hip_wgrad_match_torch(pn2, cuda):
-    """One training forward/backward with the HIP weight-gradient kernel == the same step with torch's GEMM (to fp32
-    summation-order noise) for every parameter."""
+    """One training forward/backward on the HIP training kernels (batch norm + ReLU forward/backward, weight
+    gradient) == the same step on torch's own kernels (to fp32 rounding noise) for every parameter."""
     import torch
     tfu = pn2.util.tf_util
     hp = dict(pn2.model.SEMANTIC_HYPERPARAMS)
-    hp.update(l1_npoint=128, l2_npoint=32, l3_npoint=16, l4_npoint=8)
+    # batch statistics over at least 128 rows in every layer: with a handful of rows the normalisation amplifies
+    # rounding differences between the two stacks by up to 1/sqrt(eps) per layer
+    hp.update(l1_npoint=256, l2_npoint=64, l3_npoint=32, l4_npoint=16)
     rs = np.random.RandomState(0)
-    pc = T(np.concatenate([s_scene(1, 2, 1024), rs.random_sample((2, 1024, 3)).astype(np.float32)], 2), cuda)
-    labels = T(rs.randint(0, 9, (2, 1024)).astype(np.int64), cuda)
-    smpw = T((rs.random_sample((2, 1024)) + 0.5).astype(np.float32), cuda)
+    pc = T(np.concatenate([s_scene(1, 8, 2048), rs.random_sample((8, 2048, 3)).astype(np.float32)], 2), cuda)
+    labels = T(rs.randint(0, 9, (8, 2048)).astype(np.int64), cuda)
+    smpw = T((rs.random_sample((8, 2048)) + 0.5).astype(np.float32), cuda)
     grads = []
     for use in (True, False):
         tfu.USE_HIP_WGRAD = use
@@ -764,7 +768,107 @@ def test_training_gradients_with_hip_wgrad_match_torch(pn2, cuda):
         finally:
             tfu.USE_HIP_WGRAD = True
     assert grads[0].keys() == grads[1].keys() and len(grads[0]) > 40
+    # fp32 rounding differs between the two stacks (fp64 vs Welford moments, fused vs separate normalise/ReLU, atomics):
+    # a ReLU / max-pool decision within rounding of a tie flips for a few elements, so the bound on single elements
+    # is looser than the bound on the gradient as a whole
     for k in grads[0]:
         a, b = grads[0][k], grads[1][k]
         scale = float(b.abs().max())
-        assert float((a - b).abs().max()) <= 2e-3 * scale + 1e-5, (k, float((a - b).abs().max()), scale)
+        assert float((a - b).abs().max()) <= 1e-2 * scale + 1e-5, (k, float((a - b).abs().max()), scale)
+        assert float((a - b).norm()) <= 3e-3 * float(b.norm()) + 1e-5 * a.numel() ** 0.5, (k, float((a - b).norm()), float(b.norm()))
+
+
+# ------------------------------------------------------------------ training: batch norm + relu kernels ------
+@pytest.mark.parametrize("rows,c,relu", [(4096, 32, 1), (1000, 64, 1), (333, 128, 0), (8192, 512, 1), (257, 9, 1), (64, 1024, 1),
+                                         (5000, 36, 1), (1, 32, 1)])
+def test_bn_relu_forward_backward_vs_oracle(pn2, oracle, cuda, rows, c, relu):
+    """pn2_bn_relu_forward / _backward against the float64 oracle (tf_util.py:555-581 restated): z, batch moments,
+    moving averages, dy, dgamma, dbeta.  Tolerance 1e-5 of the output scale (fp32 normalisation of fp64 moments)."""
+    import ctypes
+    import torch
+    lib = pn2._lib.lib
+    P = lambda t: ctypes.c_void_p(t.data_ptr())
+    rs = np.random.RandomState(rows * 7 + c)
+    y = (rs.randn(rows, c) * (1.0 + np.arange(c) % 5) + 3.0 * np.sin(np.arange(c))).astype(np.float32)
+    gamma = (0.5 + rs.rand(c)).astype(np.float32)
+    beta = (rs.randn(c) * 0.3).astype(np.float32)
+    bias = rs.randn(c).astype(np.float32)
+    dz = rs.randn(rows, c).astype(np.float32)
+    eps, decay = 1e-3, 0.9
+    ty, tg, tb, tbias, tdz = (T(a, cuda) for a in (y, gamma, beta, bias, dz))
+    rm, rv = torch.full((c,), 0.25, device=cuda), torch.full((c,), 2.0, device=cuda)
+    z = torch.empty_like(ty)
+    sm, si = torch.empty(c, device=cuda), torch.empty(c, device=cuda)
+    assert lib.pn2_bn_workspace_bytes(c) >= 2 * c * 8 and lib.pn2_bn_workspace_bytes(c) % 8 == 0
+    ws = torch.empty(lib.pn2_bn_workspace_bytes(c) // 8, dtype=torch.float64, device=cuda)
+    assert lib.pn2_bn_relu_forward(rows, c, P(ty), P(tg), P(tb), P(tbias), eps, decay, relu, P(rm), P(rv), P(ws), ws.numel() * 8,
+                                   P(sm), P(si), P(z), None) == 0
+    zr, mean, var, mm, mv = oracle.batch_norm_relu_train(y, gamma, beta, bool(relu), eps, bias, (np.full(c, 0.25), np.full(c, 2.0)), decay)
+    zg = z.cpu().numpy()
+    assert np.abs(zg - zr).max() <= 1e-5 * max(np.abs(zr).max(), 1.0)
+    assert np.allclose(sm.cpu().numpy(), mean, rtol=1e-6, atol=1e-6)
+    assert np.allclose(si.cpu().numpy(), 1.0 / np.sqrt(var + eps), rtol=1e-6, atol=1e-6)
+    assert np.allclose(rm.cpu().numpy(), mm, rtol=1e-6, atol=1e-6) and np.allclose(rv.cpu().numpy(), mv, rtol=1e-6, atol=1e-6)
+    # elements within fp32 rounding of zero: the oracle takes the kernel's own ReLU mask
+    dyr, dgr, dbr = oracle.batch_norm_relu_train_grad(y, gamma, beta, dz, bool(relu), eps, mask=zg > 0)
+    dy = torch.empty_like(ty)
+    dg, db = torch.empty(c, device=cuda), torch.empty(c, device=cuda)
+    assert lib.pn2_bn_relu_backward(rows, c, P(tdz), P(ty), P(tg), P(tb), P(sm), P(si), relu, P(ws), ws.numel() * 8, P(dy), P(dg),
+                                    P(db), None) == 0
+    for got, ref in ((dy, dyr), (dg, dgr), (db, dbr)):
+        assert np.abs(got.cpu().numpy() - ref).max() <= 2e-5 * max(np.abs(ref).max(), 1.0)
+    dz2 = tdz.clone()  # in place: dy may alias dz
+    assert lib.pn2_bn_relu_backward(rows, c, P(dz2), P(ty), P(tg), P(tb), P(sm), P(si), relu, P(ws), ws.numel() * 8, P(dz2), P(dg),
+                                    P(db), None) == 0
+    assert torch.equal(dz2, dy)
+
+
+def test_bn_relu_argument_checks(pn2, cuda):
+    import ctypes
+    import torch
+    raw = pn2._lib._raw
+    P = lambda t: ctypes.c_void_p(t.data_ptr())
+    y = torch.zeros(8, 2048, device=cuda)
+    v = torch.zeros(2048, device=cuda)
+    ws = torch.empty(pn2._lib.lib.pn2_bn_workspace_bytes(2048) // 8, dtype=torch.float64, device=cuda)
+    head = (P(y), P(v), P(v), None, 1e-3, 0.9, 1)
+    tail = (P(ws), ws.numel() * 8, P(v), P(v), P(y), None)
+    assert raw.pn2_bn_relu_forward(8, 2048, *head, None, None, *tail) == pn2._lib.PN2_EUNSUP   # c > 1024
+    assert raw.pn2_bn_relu_forward(8, 300, *head, None, None, *tail) == 0                      # c % 4 == 0, vector path
+    assert raw.pn2_bn_relu_forward(8, 301, *head, None, None, *tail) == pn2._lib.PN2_EUNSUP   # scalar path stops at 256
+    assert raw.pn2_bn_relu_forward(0, 64, *head, None, None, *tail) != 0                       # no rows
+    assert raw.pn2_bn_relu_forward(8, 64, *head, None, None, P(ws), 8, *tail[2:]) != 0         # workspace too small
+    assert raw.pn2_bn_relu_forward(8, 64, None, *head[1:], None, None, *tail) != 0             # null y
+    assert raw.pn2_bn_relu_forward(8, 64, *head, P(v), None, *tail) != 0                       # only one moving average
+    torch.cuda.synchronize()
+
+
+def test_train_layer_hip_bn_matches_torch_autograd(pn2, cuda):
+    """_train_layer with the HIP batch norm vs the torch composition (F.batch_norm + relu autograd): output,
+    moving averages and every gradient (bias gradient exactly zero on the HIP path, rounding noise on torch's)."""
+    import torch
+    tfu = pn2.util.tf_util
+    torch.manual_seed(5)
+    x = torch.randn(16, 64, 32, 67, device=cuda)
+    w0 = torch.randn(67, 128, device=cuda) * 0.1
+    probe = torch.sin(torch.arange(16 * 64 * 32 * 128, device=cuda).float()).reshape(16, 64, 32, 128)
+    outs = {}
+    for use in (True, False):
+        tfu.USE_HIP_BN = use
+        try:
+            xx = x.clone().requires_grad_(True)
+            w = w0.clone().requires_grad_(True)
+            b = (torch.arange(128, device=cuda).float() * 0.01).requires_grad_(True)
+            beta = torch.zeros(128, device=cuda, requires_grad=True)
+            gamma = torch.ones(128, device=cuda, requires_grad=True)
+            mean, var = torch.zeros(128, device=cuda), torch.ones(128, device=cuda)
+            z = tfu._train_layer(xx, w, b, (beta, gamma, mean, var), None, True)
+            (z * probe).sum().backward()
+            outs[use] = (z.detach(), mean, var, xx.grad, w.grad, gamma.grad, beta.grad, b.grad)
+        finally:
+            tfu.USE_HIP_BN = True
+    assert float(outs[True][-1].abs().max()) == 0.0       # bias in front of BN: exactly zero ...
+    assert float(outs[False][-1].abs().max()) <= 5e-3     # ... where torch sums 32768 rounding errors
+    for a, r in zip(outs[True][:-1], outs[False][:-1]):
+        s = max(float(r.abs().max()), 1.0)
+        assert float((a - r).abs().max()) <= 2e-4 * s

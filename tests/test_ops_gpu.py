@@ -329,6 +329,35 @@ def test_three_interpolate_bit_exact_and_grad(pn2, oracle, cuda, c):
     assert np.allclose(pt.grad.cpu().numpy(), ref, rtol=1e-4, atol=1e-5)
 
 
+@pytest.mark.parametrize("c,m", [(32, 300), (128, 1024), (36, 77), (512, 64), (1024, 5)])
+def test_three_interpolate_grad_gather_path(pn2, oracle, cuda, c, m):
+    """Levels large enough for the list-and-gather gradient (pn2_three_interpolate_grad_ws): sources nobody references
+    (zero rows), one hot source, repeated indices inside a row.  Same tolerance as the atomic path."""
+    import torch
+    b, n = 4, 4096
+    rs = np.random.RandomState(c + m)
+    idx = rs.randint(0, m, (b, n, 3)).astype(np.int32)
+    idx[idx == 3 % m] = 0                      # source 3 never referenced (when m > 3)
+    idx[:, ::7, :] = 1 % m                     # hot source, three times per row
+    w = rs.rand(b, n, 3).astype(np.float32)
+    w /= w.sum(2, keepdims=True)
+    pts = rs.randn(b, m, c).astype(np.float32)
+    go = rs.randn(b, n, c).astype(np.float32)
+    pt = T(pts, cuda).requires_grad_(True)
+    pn2._lib.lib.trace = calls = []
+    try:
+        out = pn2.three_interpolate(pt, T(idx, cuda), T(w, cuda))
+        out.backward(T(go, cuda))
+    finally:
+        pn2._lib.lib.trace = None
+    assert "pn2_three_interpolate_grad_ws" in [t[0] for t in calls]
+    ref = oracle.three_interpolate_grad(pts, idx, w, go)
+    got = pt.grad.cpu().numpy()
+    assert np.allclose(got, ref, rtol=1e-4, atol=1e-4 * max(1.0, np.abs(ref).max() * 1e-2))
+    if m > 3:
+        assert not got[:, 3].any()
+
+
 def test_three_interpolate_reference_shapes(pn2, oracle, cuda):
     """tf_ops/test_tf_ops.py:59-78: seed 100; three_nn((32,512,3),(32,128,3)), weights 1/3, pts (32,128,64)."""
     np.random.seed(100)

@@ -172,3 +172,30 @@ def test_frozen_fixtures_extra(oracle):
     assert sorted(fresh) == sorted(g.files)
     for k in g.files:
         assert np.array_equal(np.asarray(fresh[k]), g[k]), k
+
+
+@pytest.mark.parametrize("relu", [True, False])
+def test_batch_norm_train_oracle_matches_torch_autograd(oracle, relu):
+    """oracle.batch_norm_relu_train(_grad) (tf_util.py:555-581 restated) against torch float64: F.batch_norm in
+    training mode (same fused-BN conventions: biased variance to normalise, unbiased into the moving average) + relu,
+    and autograd for the three gradients."""
+    import torch
+    import torch.nn.functional as F
+    rs = np.random.RandomState(11)
+    y = rs.randn(200, 12) * 2 + rs.randn(12)
+    gamma, beta, bias, dz = rs.rand(12) + 0.5, rs.randn(12) * 0.3, rs.randn(12), rs.randn(200, 12)
+    z, mean, var, mm, mv = oracle.batch_norm_relu_train(y, gamma, beta, relu, bias=bias, moving=(np.full(12, 0.25), np.full(12, 2.0)),
+                                                        decay=0.9)
+    ty = torch.tensor(y + bias, requires_grad=True)  # torch sees the biased output; BN removes the constant again
+    tg, tb = torch.tensor(gamma, requires_grad=True), torch.tensor(beta, requires_grad=True)
+    rm, rv = torch.full((12,), 0.25, dtype=torch.float64), torch.full((12,), 2.0, dtype=torch.float64)
+    tz = F.batch_norm(ty, rm, rv, tg, tb, training=True, momentum=0.1, eps=1e-3)
+    if relu:
+        tz = torch.relu(tz)
+    assert np.allclose(z, tz.detach().numpy(), rtol=1e-10, atol=1e-10)
+    assert np.allclose(mm, rm.numpy(), rtol=1e-12) and np.allclose(mv, rv.numpy(), rtol=1e-12)
+    (tz * torch.tensor(dz)).sum().backward()
+    dy, dgamma, dbeta = oracle.batch_norm_relu_train_grad(y, gamma, beta, dz, relu)
+    assert np.allclose(dy, ty.grad.numpy(), rtol=1e-9, atol=1e-10)
+    assert np.allclose(dgamma, tg.grad.numpy(), rtol=1e-9, atol=1e-10)
+    assert np.allclose(dbeta, tb.grad.numpy(), rtol=1e-9, atol=1e-10)
