@@ -744,38 +744,58 @@ def test_linear_wgrad_vs_fp64(pn2, cuda, rows, cin, cout):
 
 def test_training_gradients_with_hip_wgrad_match_torch(pn2, cuda):
     """One training forward/backward on the HIP training kernels (batch norm + ReLU forward/backward, weight
-    gradient) == the same step on torch's own kernels (to fp32 rounding noise) for every parameter."""
+    gradient) against the same step with every dense layer evaluated in float64 (matmul, batch norm, ReLU and their
+    autograd), for every parameter.  fp32 rounding is amplified by the chain of batch norms, so the yardstick is the
+    error of the all-torch fp32 stack against the same float64 reference: the HIP stack must be as close (x3)."""
     import torch
+    import torch.nn.functional as F
     tfu = pn2.util.tf_util
     hp = dict(pn2.model.SEMANTIC_HYPERPARAMS)
-    # batch statistics over at least 128 rows in every layer: with a handful of rows the normalisation amplifies
-    # rounding differences between the two stacks by up to 1/sqrt(eps) per layer
     hp.update(l1_npoint=256, l2_npoint=64, l3_npoint=32, l4_npoint=16)
     rs = np.random.RandomState(0)
     pc = T(np.concatenate([s_scene(1, 8, 2048), rs.random_sample((8, 2048, 3)).astype(np.float32)], 2), cuda)
     labels = T(rs.randint(0, 9, (8, 2048)).astype(np.int64), cuda)
     smpw = T((rs.random_sample((8, 2048)) + 0.5).astype(np.float32), cuda)
-    grads = []
-    for use in (True, False):
-        tfu.USE_HIP_WGRAD = use
+
+    def layer_fp64(inputs, w2d, b, bnv, bn_decay, relu):
+        y = inputs.double() @ w2d.double() + b.double()
+        if bnv is not None:
+            beta, gamma, mean, var = bnv
+            c = y.shape[-1]
+            y = F.batch_norm(y.reshape(-1, c), None, None, gamma.double(), beta.double(), training=True,
+                             eps=tfu.BN_EPSILON).reshape(y.shape)
+        return (torch.relu(y) if relu else y).float()
+
+    def run(mode):
+        orig = tfu._train_layer
+        tfu.USE_HIP_WGRAD = tfu.USE_HIP_BN = mode == "hip"
+        if mode == "fp64":
+            tfu._train_layer = layer_fp64
         try:
             store = tfu.set_default_store(tfu.VariableStore(device=cuda, seed=5))
-            torch.manual_seed(123)  # same dropout mask in both runs
+            torch.manual_seed(123)  # same dropout mask in every run
             logits, _ = pn2.model.get_model(pc, True, 9, hp, bn_decay=0.5)
-            loss = pn2.model.get_loss(logits, labels, smpw)
-            loss.backward()
-            grads.append({k: v.grad.detach().clone() for k, v in store.params.items() if v.grad is not None})
+            pn2.model.get_loss(logits, labels, smpw).backward()
+            return {k: v.grad.detach().double().clone() for k, v in store.params.items() if v.grad is not None}
         finally:
-            tfu.USE_HIP_WGRAD = True
-    assert grads[0].keys() == grads[1].keys() and len(grads[0]) > 40
-    # fp32 rounding differs between the two stacks (fp64 vs Welford moments, fused vs separate normalise/ReLU, atomics):
-    # a ReLU / max-pool decision within rounding of a tie flips for a few elements, so the bound on single elements
-    # is looser than the bound on the gradient as a whole
-    for k in grads[0]:
-        a, b = grads[0][k], grads[1][k]
-        scale = float(b.abs().max())
-        assert float((a - b).abs().max()) <= 1e-2 * scale + 1e-5, (k, float((a - b).abs().max()), scale)
-        assert float((a - b).norm()) <= 3e-3 * float(b.norm()) + 1e-5 * a.numel() ** 0.5, (k, float((a - b).norm()), float(b.norm()))
+            tfu._train_layer = orig
+            tfu.USE_HIP_WGRAD = tfu.USE_HIP_BN = True
+
+    hip, t32, ref = run("hip"), run("torch"), run("fp64")
+    assert hip.keys() == t32.keys() == ref.keys() and len(hip) > 40
+    bad = []
+    for k in ref:
+        n = float(ref[k].norm())
+        e_hip, e_t32 = float((hip[k] - ref[k]).norm()), float((t32[k] - ref[k]).norm())
+        if e_hip > 3.0 * e_t32 + 2e-5 * n + 1e-7 * ref[k].numel() ** 0.5:
+            bad.append((k, e_hip, e_t32, n))
+    rel = {k: (float((hip[k] - ref[k]).norm()) / max(float(ref[k].norm()), 1e-30),
+               float((t32[k] - ref[k]).norm()) / max(float(ref[k].norm()), 1e-30)) for k in ref if float(ref[k].norm()) > 1e-6}
+    worst = max(rel, key=lambda k: rel[k][0])
+    print("relative gradient error vs float64 layers: worst HIP %.2e (torch fp32 %.2e) at %s; median HIP %.2e, torch %.2e"
+          % (rel[worst][0], rel[worst][1], worst, float(np.median([v[0] for v in rel.values()])),
+             float(np.median([v[1] for v in rel.values()]))))
+    assert not bad, bad
 
 
 # ------------------------------------------------------------------ training: batch norm + relu kernels ------
