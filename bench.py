@@ -332,6 +332,9 @@ def main():
     hp = dict(pn2.model.SEMANTIC_HYPERPARAMS)
     hp["batch_size"], hp["num_point"] = args.batch, args.points
     B, N = args.batch, args.points
+    for kv in args.debug_set:
+        what, value = kv.split("=")
+        assert pn2._lib._raw.pn2_debug_set(int(what), int(value)) == 0
     if args.train:
         bench_train(pn2, args, hp, B, N, rank, world, dev)
         if dist_on:
@@ -354,9 +357,6 @@ def main():
             if k.endswith("moving_variance"):
                 v.copy_((torch.rand(v.shape, generator=g) + 0.5).to(dev))
 
-    for kv in args.debug_set:
-        what, value = kv.split("=")
-        assert pn2._lib._raw.pn2_debug_set(int(what), int(value)) == 0
     pn2._lib.lib.dup = tuple(args.dup)
     fused_fp = args.fp_front != "unfused"
     pn2.util.pointnet_util.USE_FUSED_FP = fused_fp

@@ -7,19 +7,22 @@
 // twice and writes dy once.  Per-channel sums are carried in fp64 (full-rate on CDNA4, the kernels are memory-bound
 // anyway) so that var = E[y^2] - E[y]^2 has no cancellation problem at fp32 accuracy.  Partial sums of a block meet in
 // LDS and leave with one fp64 atomic per channel -- but atomics on ONE address retire serially (~0.1 us each, measured:
-// 2048 blocks on 2*c addresses cost 190 us), so the blocks spread over kBnSlots copies of the accumulators (<= 32
-// atomics per address) and the last block to finish (ticket counter) folds the copies into the final 2*c sums.
+// 2048 blocks on 2*c addresses cost 190 us), so the blocks spread over up to kBnSlots copies of the accumulators (<= 32
+// atomics per address) and a one-block launch folds the copies into the final 2*c sums.
 #include "pn2_common.h"
 
 namespace {
 
 constexpr int kBnMaxC = 1024;   // channels held in LDS by the apply kernels
 constexpr int kBnThreads = 256;
-constexpr int kBnSlots = 16;    // copies of the per-channel accumulators the reduction blocks spread their atomics over
-constexpr int kBnBlocks = 512;  // reduction blocks (2 per CU, 8 x 16-byte loads in flight per thread)
+constexpr int kBnSlots = 64;     // most copies of the per-channel accumulators the reduction blocks spread their atomics over
+constexpr int kBnBlocks = 512;   // most reduction blocks (2 per CU, 8 x 16-byte loads in flight per thread); the training step is
+                                 // flat from 256 to 1024 and slower at 2048 (pn2_debug_set(10, v) sweep: every block ends in 2*c atomics)
 
-// workspace: final[2][c] | slot[kBnSlots][2][c] (doubles) | ticket (unsigned, 8-byte slot)
-__host__ __device__ inline size_t bn_ws_doubles(int c) { return (size_t)(1 + kBnSlots) * 2 * (size_t)c; }
+constexpr int kBnHead = 8;       // doubles reserved in front (alignment of the sums to 64 bytes)
+
+// workspace (doubles): reserved[kBnHead] | final[2][c] | slot[nslots][2][c], nslots <= kBnSlots chosen per call
+__host__ __device__ inline size_t bn_ws_doubles(int c, int nslots) { return kBnHead + (size_t)(1 + nslots) * 2 * (size_t)c; }
 
 // thread -> (row slot rr, float4 column cc): cv = c/VEC columns, rp = 256/cv rows per pass
 template <int VEC>
@@ -46,12 +49,12 @@ __device__ __forceinline__ void bn_load(const float* __restrict__ p, float (&v)[
 }
 
 // add the per-thread partial sums (NS doubles per channel of the thread's VEC channels) over the rp row slots of
-// the block, push them to this block's slot copy of the accumulators, and let the last block fold the copies into
-// ws[0 .. NS*c) (the sums every consumer reads)
+// the block and push them to this block's slot copy of the accumulators (bn_fold_kernel adds the copies up into
+// ws[kBnHead .. kBnHead+NS*c), the sums every consumer reads)
 template <int VEC, int NS>
-__device__ __forceinline__ void bn_block_sums(const BnMap<VEC>& mp, int c, double (&part)[NS][VEC], double* __restrict__ ws) {
+__device__ __forceinline__ void bn_block_sums(const BnMap<VEC>& mp, int c, int nslots, double (&part)[NS][VEC],
+                                              double* __restrict__ ws) {
     __shared__ double red[kBnThreads * NS * VEC];
-    __shared__ unsigned ticket;
     if (mp.active) {
 #pragma unroll
         for (int s = 0; s < NS; ++s)
@@ -72,7 +75,8 @@ __device__ __forceinline__ void bn_block_sums(const BnMap<VEC>& mp, int c, doubl
         __syncthreads();
         sz = h;
     }
-    double* __restrict__ slot = ws + (size_t)NS * c * (1 + (blockIdx.x % kBnSlots));
+    const unsigned my = blockIdx.x % (unsigned)nslots;
+    double* __restrict__ slot = ws + kBnHead + (size_t)NS * c * (1 + my);
     if (mp.active && mp.rr == 0) {
 #pragma unroll
         for (int s = 0; s < NS; ++s)
@@ -80,26 +84,25 @@ __device__ __forceinline__ void bn_block_sums(const BnMap<VEC>& mp, int c, doubl
             for (int v = 0; v < VEC; ++v)
                 atomicAdd(&slot[(size_t)s * c + mp.cc * VEC + v], red[((s * VEC + v) * mp.rp) * mp.cv + mp.cc]);
     }
-    __threadfence();  // this block's atomics are performed before its ticket
-    __syncthreads();
-    unsigned* counter = reinterpret_cast<unsigned*>(ws + bn_ws_doubles(c));
-    if (threadIdx.x == 0) ticket = atomicAdd(counter, 1u);
-    __syncthreads();
-    if (ticket != gridDim.x - 1) return;
-    __threadfence();
-    for (int col = threadIdx.x; col < NS * c; col += kBnThreads) {
-        double t = 0.0;
-#pragma unroll
-        for (int k = 0; k < kBnSlots; ++k)
-            t += __hip_atomic_load(&ws[(size_t)NS * c * (1 + k) + col], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        ws[col] = t;
-    }
+}
+
+// final[col] = sum over the slot copies.  A launch of its own rather than a "last block folds" epilogue: that variant
+// needs a ticket counter and device-scope fences in every reduction block and measured the same step time (8.2-8.7 ms
+// for 128-512 blocks) -- the kernel boundary gives the ordering for free.
+__global__ void __launch_bounds__(kBnThreads)
+bn_fold_kernel(int cols, int nslots, double* __restrict__ ws) {
+    const int col = blockIdx.x * kBnThreads + threadIdx.x;
+    if (col >= cols) return;
+    double t = 0.0;
+#pragma unroll 8
+    for (int k = 0; k < nslots; ++k) t += ws[kBnHead + (size_t)cols * (1 + k) + col];
+    ws[kBnHead + col] = t;
 }
 
 // acc[0][ch] = sum_r y[r][ch], acc[1][ch] = sum_r y[r][ch]^2 over the block's slab of rows
 template <int VEC>
 __global__ void __launch_bounds__(kBnThreads)
-bn_stats_kernel(long long rows, int c, long long slab, const float* __restrict__ y, double* __restrict__ acc) {
+bn_stats_kernel(long long rows, int c, long long slab, int nslots, const float* __restrict__ y, double* __restrict__ ws) {
     const BnMap<VEC> mp(c);
     const long long rb = (long long)blockIdx.x * slab;
     const long long re = rb + slab < rows ? rb + slab : rows;
@@ -134,7 +137,7 @@ bn_stats_kernel(long long rows, int c, long long slab, const float* __restrict__
             }
         }
     }
-    bn_block_sums<VEC, 2>(mp, c, part, acc);
+    bn_block_sums<VEC, 2>(mp, c, nslots, part, ws);
 }
 
 // per-channel constants of the normalisation, identical float expressions in the forward and the backward kernels so
@@ -200,10 +203,10 @@ bn_apply_kernel(long long rows, int c, const float* __restrict__ y, const double
 // xhat = (y - mean) * invstd
 template <int VEC>
 __global__ void __launch_bounds__(kBnThreads)
-bn_grad_reduce_kernel(long long rows, int c, long long slab, const float* __restrict__ dz, const float* __restrict__ y,
+bn_grad_reduce_kernel(long long rows, int c, long long slab, int nslots, const float* __restrict__ dz, const float* __restrict__ y,
                       const float* __restrict__ gamma, const float* __restrict__ beta,
                       const float* __restrict__ save_mean, const float* __restrict__ save_invstd, int relu,
-                      double* __restrict__ acc) {
+                      double* __restrict__ ws) {
     const BnMap<VEC> mp(c);
     const long long rb = (long long)blockIdx.x * slab;
     const long long re = rb + slab < rows ? rb + slab : rows;
@@ -249,7 +252,7 @@ bn_grad_reduce_kernel(long long rows, int c, long long slab, const float* __rest
             take(g0, a0);
         }
     }
-    bn_block_sums<VEC, 2>(mp, c, part, acc);
+    bn_block_sums<VEC, 2>(mp, c, nslots, part, ws);
 }
 
 // backward pass 2: dy = sc * (g - mean(g) - xhat * mean(g * xhat)); block 0 publishes dgamma = sum g*xhat, dbeta = sum g
@@ -295,8 +298,10 @@ bn_grad_apply_kernel(long long rows, int c, const float* __restrict__ dz, const 
     }
 }
 
+int g_bn_blocks = 0;  // tuning hook (pn2_debug_set(10, v)): reduction blocks, 0 = kBnBlocks
+
 struct BnPlan {
-    int vec;
+    int vec, nslots;
     int stat_blocks, apply_blocks;
     long long slab;
 };
@@ -308,13 +313,15 @@ int bn_plan(long long rows, int c, const void* a, const void* b, const void* o, 
     if (c / p.vec > kBnThreads || c > kBnMaxC) return PN2_EUNSUP;
     const int rp = kBnThreads / (c / p.vec);
     // reductions: kBnBlocks blocks, each with at least 8 passes of rows
-    long long blocks = kBnBlocks;
+    long long blocks = g_bn_blocks > 0 ? g_bn_blocks : kBnBlocks;
     long long slab = (rows + blocks - 1) / blocks;
     const long long min_slab = (long long)rp * 8;
     if (slab < min_slab) slab = min_slab;
     slab = (slab + rp - 1) / rp * rp;
     p.slab = slab;
     p.stat_blocks = (int)((rows + slab - 1) / slab);
+    p.nslots = (p.stat_blocks + 31) / 32;  // <= 32 same-address atomics (they retire one after another)
+    if (p.nslots > kBnSlots) p.nslots = kBnSlots;
     const long long total = rows * (long long)c / p.vec;
     long long ab = (total + kBnThreads * 4 - 1) / (kBnThreads * 4);  // >= 4 elements per thread
     if (ab > 4096) ab = 4096;
@@ -325,7 +332,12 @@ int bn_plan(long long rows, int c, const void* a, const void* b, const void* o, 
 
 }  // namespace
 
-extern "C" size_t pn2_bn_workspace_bytes(int c) { return c > 0 ? sizeof(double) * (bn_ws_doubles(c) + 1) : 0; }
+extern "C" int pn2_debug_set_bn(int what, int value) {
+    if (what == 10) { g_bn_blocks = value; return 0; }
+    return PN2_EINVAL;
+}
+
+extern "C" size_t pn2_bn_workspace_bytes(int c) { return c > 0 ? sizeof(double) * bn_ws_doubles(c, kBnSlots) : 0; }
 
 extern "C" int pn2_bn_relu_forward(long long rows, int c, const float* y, const float* gamma, const float* beta,
                                    const float* bias, float eps, float decay, int relu, float* running_mean,
@@ -338,15 +350,18 @@ extern "C" int pn2_bn_relu_forward(long long rows, int c, const float* y, const 
     if (rc != PN2_OK) return rc;
     if (workspace_bytes < pn2_bn_workspace_bytes(c) || ((uintptr_t)workspace % 8) != 0) return PN2_EINVAL;
     hipStream_t st = static_cast<hipStream_t>(stream);
-    double* acc = static_cast<double*>(workspace);
-    hipError_t e = hipMemsetAsync(acc, 0, pn2_bn_workspace_bytes(c), st);
+    double* ws = static_cast<double*>(workspace);
+    const double* acc = ws + kBnHead;
+    hipError_t e = hipMemsetAsync(ws, 0, sizeof(double) * bn_ws_doubles(c, p.nslots), st);
     if (e != hipSuccess) return (int)e;
     if (p.vec == 4) {
-        bn_stats_kernel<4><<<p.stat_blocks, kBnThreads, 0, st>>>(rows, c, p.slab, y, acc);
+        bn_stats_kernel<4><<<p.stat_blocks, kBnThreads, 0, st>>>(rows, c, p.slab, p.nslots, y, ws);
+        bn_fold_kernel<<<(2 * c + kBnThreads - 1) / kBnThreads, kBnThreads, 0, st>>>(2 * c, p.nslots, ws);
         bn_apply_kernel<4><<<p.apply_blocks, kBnThreads, 0, st>>>(rows, c, y, acc, gamma, beta, bias, eps, decay, relu,
                                                                 running_mean, running_var, save_mean, save_invstd, z);
     } else {
-        bn_stats_kernel<1><<<p.stat_blocks, kBnThreads, 0, st>>>(rows, c, p.slab, y, acc);
+        bn_stats_kernel<1><<<p.stat_blocks, kBnThreads, 0, st>>>(rows, c, p.slab, p.nslots, y, ws);
+        bn_fold_kernel<<<(2 * c + kBnThreads - 1) / kBnThreads, kBnThreads, 0, st>>>(2 * c, p.nslots, ws);
         bn_apply_kernel<1><<<p.apply_blocks, kBnThreads, 0, st>>>(rows, c, y, acc, gamma, beta, bias, eps, decay, relu,
                                                                 running_mean, running_var, save_mean, save_invstd, z);
     }
@@ -364,14 +379,17 @@ extern "C" int pn2_bn_relu_backward(long long rows, int c, const float* dz, cons
     if (rc != PN2_OK) return rc;
     if (workspace_bytes < pn2_bn_workspace_bytes(c) || ((uintptr_t)workspace % 8) != 0) return PN2_EINVAL;
     hipStream_t st = static_cast<hipStream_t>(stream);
-    double* acc = static_cast<double*>(workspace);
-    hipError_t e = hipMemsetAsync(acc, 0, pn2_bn_workspace_bytes(c), st);
+    double* ws = static_cast<double*>(workspace);
+    const double* acc = ws + kBnHead;
+    hipError_t e = hipMemsetAsync(ws, 0, sizeof(double) * bn_ws_doubles(c, p.nslots), st);
     if (e != hipSuccess) return (int)e;
     if (p.vec == 4) {
-        bn_grad_reduce_kernel<4><<<p.stat_blocks, kBnThreads, 0, st>>>(rows, c, p.slab, dz, y, gamma, beta, save_mean, save_invstd, relu, acc);
+        bn_grad_reduce_kernel<4><<<p.stat_blocks, kBnThreads, 0, st>>>(rows, c, p.slab, p.nslots, dz, y, gamma, beta, save_mean, save_invstd, relu, ws);
+        bn_fold_kernel<<<(2 * c + kBnThreads - 1) / kBnThreads, kBnThreads, 0, st>>>(2 * c, p.nslots, ws);
         bn_grad_apply_kernel<4><<<p.apply_blocks, kBnThreads, 0, st>>>(rows, c, dz, y, acc, gamma, beta, save_mean, save_invstd, relu, dy, dgamma, dbeta);
     } else {
-        bn_grad_reduce_kernel<1><<<p.stat_blocks, kBnThreads, 0, st>>>(rows, c, p.slab, dz, y, gamma, beta, save_mean, save_invstd, relu, acc);
+        bn_grad_reduce_kernel<1><<<p.stat_blocks, kBnThreads, 0, st>>>(rows, c, p.slab, p.nslots, dz, y, gamma, beta, save_mean, save_invstd, relu, ws);
+        bn_fold_kernel<<<(2 * c + kBnThreads - 1) / kBnThreads, kBnThreads, 0, st>>>(2 * c, p.nslots, ws);
         bn_grad_apply_kernel<1><<<p.apply_blocks, kBnThreads, 0, st>>>(rows, c, dz, y, acc, gamma, beta, save_mean, save_invstd, relu, dy, dgamma, dbeta);
     }
     PN2_RETURN_IF_LAUNCH_FAILED();

@@ -452,10 +452,12 @@ extern "C" int pn2_prob_sample(int b, int n, int m, const float* inp_p, const fl
 // undocumented tuning/experiment hook (not part of the ABI header)
 extern "C" int pn2_debug_set_grouping(int what, int value);
 extern "C" int pn2_debug_set_linear(int what, int value);
+extern "C" int pn2_debug_set_bn(int what, int value);
 extern "C" int pn2_debug_set_fused(int what, int value);
 extern "C" int pn2_debug_set(int what, int value) {
     if (what == 0) { g_fps_variant = value; return 0; }
     if (what == 5 || what == 8 || what == 9) return pn2_debug_set_linear(what, value);
+    if (what == 10) return pn2_debug_set_bn(what, value);
     if (what == 6 || what == 7) return pn2_debug_set_fused(what, value);
     return pn2_debug_set_grouping(what, value);
 }
