@@ -185,21 +185,27 @@ int pn2_linear_wgrad(int rows, int cin, int cout, const float *x, const float *d
  *   running_mean = decay*running_mean + (1-decay)*(mean + bias),  running_var likewise with the UNBIASED batch variance
  * `bias` (nullable, (c)) is the layer bias the caller folded away: a per-channel constant in front of BN only moves
  * the mean, so it enters the moving average and nothing else.  running_mean / running_var may both be NULL.
+ * pool > 1 fuses the SA layer's max over each group of `pool` consecutive rows (tf.reduce_max over the K neighbours,
+ * pointnet_util.py:167-170): z is then (rows/pool, c) and `ties` (rows/pool, c) receives the number of rows that
+ * attain the maximum (the gradient is shared equally among them, as tf / torch do); the (rows,c) activation is never
+ * written.  pool <= 1: z is (rows,c), ties unused (NULL).
  * save_mean / save_invstd (c) are kept for pn2_bn_relu_backward.  `workspace`: 8-byte aligned device scratch of at
- * least pn2_bn_workspace_bytes(c) bytes (fp64 per-channel accumulators, contents irrelevant on entry).  c <= 1024; c % 4 != 0 needs c <= 256. */
+ * least pn2_bn_workspace_bytes(c) bytes (fp64 per-channel accumulators, contents irrelevant on entry).
+ * c <= 1024; c % 4 != 0 needs c <= 256. */
 size_t pn2_bn_workspace_bytes(int c);
 int pn2_bn_relu_forward(long long rows, int c, const float *y, const float *gamma, const float *beta,
-                        const float *bias, float eps, float decay, int relu, float *running_mean,
+                        const float *bias, float eps, float decay, int relu, int pool, float *running_mean,
                         float *running_var, void *workspace, size_t workspace_bytes, float *save_mean,
-                        float *save_invstd, float *z, void *stream);
-/* Its gradient (what tf.gradients derives for the two ops above): with g = dz * [z > 0] (relu) and
- * xhat = (y - mean) * invstd,
+                        float *save_invstd, float *z, float *ties, void *stream);
+/* Its gradient (what tf.gradients derives for the ops above): with g = dz * [z > 0] (relu; behind the fused max
+ * pool dz (rows/pool,c) first goes to the rows that attain zmax, divided by `ties`) and xhat = (y - mean) * invstd,
  *   dbeta = sum_r g,  dgamma = sum_r g*xhat,  dy = gamma*invstd * (g - dbeta/rows - xhat * dgamma/rows).
- * dy may alias dz.  The ReLU mask is recomputed from y with the forward's own float expressions. */
+ * zmax / ties: the forward's z / ties when pool > 1 (else NULL).  dy (rows,c) may alias dz when pool <= 1.  The ReLU
+ * mask and the pooled maxima are recomputed from y with the forward's own float expressions. */
 int pn2_bn_relu_backward(long long rows, int c, const float *dz, const float *y, const float *gamma,
                          const float *beta, const float *save_mean, const float *save_invstd, int relu,
-                         void *workspace, size_t workspace_bytes, float *dy, float *dgamma, float *dbeta,
-                         void *stream);
+                         int pool, const float *zmax, const float *ties, void *workspace,
+                         size_t workspace_bytes, float *dy, float *dgamma, float *dbeta, void *stream);
 
 /* Fused set-abstraction MLP (pointnet_util.py:43-54 + :150-170, inference BN
  * folded): for every (b, j) group gathers nsample neighbours by idx, builds

@@ -36,10 +36,10 @@ SIGNATURES = {
                                       ctypes.c_size_t, c_void_p],
     "pn2_linear": [c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p],
     "pn2_linear_wgrad": [c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p],
-    "pn2_bn_relu_forward": [ctypes.c_longlong, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_float, c_int,
-                            c_void_p, c_void_p, c_void_p, ctypes.c_size_t, c_void_p, c_void_p, c_void_p, c_void_p],
+    "pn2_bn_relu_forward": [ctypes.c_longlong, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_float, c_int, c_int,
+                            c_void_p, c_void_p, c_void_p, ctypes.c_size_t, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p],
     "pn2_bn_relu_backward": [ctypes.c_longlong, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int,
-                             c_void_p, ctypes.c_size_t, c_void_p, c_void_p, c_void_p, c_void_p],
+                             c_int, c_void_p, c_void_p, c_void_p, ctypes.c_size_t, c_void_p, c_void_p, c_void_p, c_void_p],
     "pn2_sa_mlp_max_fused": [c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p,
                              c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p],
     "pn2_sa_mlp_max_fused_bf16": [c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p,

@@ -148,15 +148,15 @@ __device__ __forceinline__ void bn_scale_shift(float gamma, float beta, float me
     sh = __builtin_fmaf(-mean, sc, beta);
 }
 
-// z = relu?(fma(y, sc[ch], sh[ch])).  Every block derives (mean, invstd) of all channels from the fp64 sums (c rsqrt's:
-// noise next to its share of the stream); block 0 also publishes them for the backward and moves the running averages.
-template <int VEC>
-__global__ void __launch_bounds__(kBnThreads)
-bn_apply_kernel(long long rows, int c, const float* __restrict__ y, const double* __restrict__ acc,
-                const float* __restrict__ gamma, const float* __restrict__ beta, const float* __restrict__ bias,
-                float eps, float decay, int relu, float* __restrict__ running_mean, float* __restrict__ running_var,
-                float* __restrict__ save_mean, float* __restrict__ save_invstd, float* __restrict__ z) {
-    __shared__ float sc[kBnMaxC], sh[kBnMaxC];
+// Per-channel (scale, shift) of the forward into LDS.  Every block derives (mean, invstd) of all channels from the fp64
+// sums (c rsqrt's: noise next to its share of the stream); block 0 also publishes them for the backward and moves
+// the running averages.
+__device__ __forceinline__ void bn_forward_constants(long long rows, int c, const double* __restrict__ acc,
+                                                     const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                     const float* __restrict__ bias, float eps, float decay,
+                                                     float* __restrict__ running_mean, float* __restrict__ running_var,
+                                                     float* __restrict__ save_mean, float* __restrict__ save_invstd,
+                                                     float* sc, float* sh) {
     const double inv_n = 1.0 / (double)rows;
     for (int ch = threadIdx.x; ch < c; ch += kBnThreads) {
         const double mean_d = acc[ch] * inv_n;
@@ -180,6 +180,17 @@ bn_apply_kernel(long long rows, int c, const float* __restrict__ y, const double
         }
     }
     __syncthreads();
+}
+
+// z = relu?(fma(y, sc[ch], sh[ch]))
+template <int VEC>
+__global__ void __launch_bounds__(kBnThreads)
+bn_apply_kernel(long long rows, int c, const float* __restrict__ y, const double* __restrict__ acc,
+                const float* __restrict__ gamma, const float* __restrict__ beta, const float* __restrict__ bias,
+                float eps, float decay, int relu, float* __restrict__ running_mean, float* __restrict__ running_var,
+                float* __restrict__ save_mean, float* __restrict__ save_invstd, float* __restrict__ z) {
+    __shared__ float sc[kBnMaxC], sh[kBnMaxC];
+    bn_forward_constants(rows, c, acc, gamma, beta, bias, eps, decay, running_mean, running_var, save_mean, save_invstd, sc, sh);
     const size_t total = (size_t)rows * c / VEC;
     const size_t stride = (size_t)gridDim.x * kBnThreads;
     const bool pow2 = (c & (c - 1)) == 0;
@@ -199,14 +210,90 @@ bn_apply_kernel(long long rows, int c, const float* __restrict__ y, const double
     }
 }
 
-// backward pass 1: acc[0][ch] = sum_r g, acc[1][ch] = sum_r g * xhat, with g = dz * [z > 0] (relu) and
-// xhat = (y - mean) * invstd
+// The same followed by the max over each group of `pool` consecutive rows (the SA layer's tf.reduce_max over the K
+// neighbours, pointnet_util.py:167-170): zmax (rows/pool, c) and the number of rows that attain it (tf / torch give
+// every tied row an equal share of the gradient; duplicated neighbours of a sparse ball tie exactly).  The (rows, c)
+// activation is never written.  thread -> (group slot, 16-byte column); 8 rows in flight.
+template <int VEC>
+__global__ void __launch_bounds__(kBnThreads)
+bn_apply_pool_kernel(long long rows, int c, int pool, const float* __restrict__ y, const double* __restrict__ acc,
+                     const float* __restrict__ gamma, const float* __restrict__ beta, const float* __restrict__ bias,
+                     float eps, float decay, int relu, float* __restrict__ running_mean, float* __restrict__ running_var,
+                     float* __restrict__ save_mean, float* __restrict__ save_invstd, float* __restrict__ zmax,
+                     float* __restrict__ ties) {
+    __shared__ float sc[kBnMaxC], sh[kBnMaxC];
+    bn_forward_constants(rows, c, acc, gamma, beta, bias, eps, decay, running_mean, running_var, save_mean, save_invstd, sc, sh);
+    const BnMap<VEC> mp(c);
+    if (!mp.active) return;
+    const long long groups = rows / pool;
+    float s4[VEC], h4[VEC];
+#pragma unroll
+    for (int v = 0; v < VEC; ++v) { s4[v] = sc[mp.cc * VEC + v]; h4[v] = sh[mp.cc * VEC + v]; }
+    for (long long g = (long long)blockIdx.x * mp.rp + mp.rr; g < groups; g += (long long)gridDim.x * mp.rp) {
+        const float* __restrict__ p = y + (size_t)g * pool * c + (size_t)mp.cc * VEC;
+        float best[VEC], cnt[VEC];
+#pragma unroll
+        for (int v = 0; v < VEC; ++v) { best[v] = -__builtin_inff(); cnt[v] = 0.f; }
+        auto take = [&](const float (&a)[VEC]) {
+#pragma unroll
+            for (int v = 0; v < VEC; ++v) {
+                float t = __builtin_fmaf(a[v], s4[v], h4[v]);
+                if (relu) t = t > 0.f ? t : 0.f;
+                cnt[v] = t > best[v] ? 1.f : (t == best[v] ? cnt[v] + 1.f : cnt[v]);
+                best[v] = t > best[v] ? t : best[v];
+            }
+        };
+        int r = 0;
+        for (; r + 7 < pool; r += 8) {
+            float a[8][VEC];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) bn_load<VEC>(p + (size_t)(r + u) * c, a[u]);
+#pragma unroll
+            for (int u = 0; u < 8; ++u) take(a[u]);
+        }
+        for (; r < pool; ++r) {
+            float a[VEC];
+            bn_load<VEC>(p + (size_t)r * c, a);
+            take(a);
+        }
+        const size_t o = (size_t)g * c + (size_t)mp.cc * VEC;
+        if constexpr (VEC == 4) {
+            *reinterpret_cast<float4*>(zmax + o) = make_float4(best[0], best[1], best[2], best[3]);
+            *reinterpret_cast<float4*>(ties + o) = make_float4(cnt[0], cnt[1], cnt[2], cnt[3]);
+        } else {
+            zmax[o] = best[0];
+            ties[o] = cnt[0];
+        }
+    }
+}
+
+// gradient reaching the (un-pooled) activation of row `row`: dz itself, or -- behind the fused max pool -- the pooled
+// gradient shared equally among the rows of the group that attain the maximum.  t = the forward value of the element.
+template <int VEC>
+__device__ __forceinline__ void bn_incoming_grad(const float* __restrict__ dz, int pool, const float* __restrict__ zmax,
+                                                 const float* __restrict__ ties, long long row, int c, size_t col,
+                                                 const float (&t)[VEC], float (&g)[VEC]) {
+    if (pool <= 1) {
+        bn_load<VEC>(dz + (size_t)row * c + col, g);
+        return;
+    }
+    const size_t o = (size_t)(row / pool) * c + col;
+    float d[VEC], m[VEC], n[VEC];
+    bn_load<VEC>(dz + o, d);
+    bn_load<VEC>(zmax + o, m);
+    bn_load<VEC>(ties + o, n);
+#pragma unroll
+    for (int v = 0; v < VEC; ++v) g[v] = t[v] == m[v] ? d[v] / n[v] : 0.f;
+}
+
+// backward pass 1: acc[0][ch] = sum_r g, acc[1][ch] = sum_r g * xhat, with g = dz * [z > 0] (relu; dz through the
+// fused max pool when pool > 1) and xhat = (y - mean) * invstd
 template <int VEC>
 __global__ void __launch_bounds__(kBnThreads)
 bn_grad_reduce_kernel(long long rows, int c, long long slab, int nslots, const float* __restrict__ dz, const float* __restrict__ y,
                       const float* __restrict__ gamma, const float* __restrict__ beta,
-                      const float* __restrict__ save_mean, const float* __restrict__ save_invstd, int relu,
-                      double* __restrict__ ws) {
+                      const float* __restrict__ save_mean, const float* __restrict__ save_invstd, int relu, int pool,
+                      const float* __restrict__ zmax, const float* __restrict__ ties, double* __restrict__ ws) {
     const BnMap<VEC> mp(c);
     const long long rb = (long long)blockIdx.x * slab;
     const long long re = rb + slab < rows ? rb + slab : rows;
@@ -223,11 +310,19 @@ bn_grad_reduce_kernel(long long rows, int c, long long slab, int nslots, const f
             bn_scale_shift(gamma[ch], beta[ch], mean[v], invstd[v], sc[v], sh[v]);
         }
         const size_t col = (size_t)mp.cc * VEC;
-        auto take = [&](const float (&g)[VEC], const float (&a)[VEC]) {
+        auto take = [&](long long row, const float (&a)[VEC]) {
+            float t[VEC], g[VEC];
+            bool on[VEC];
 #pragma unroll
             for (int v = 0; v < VEC; ++v) {
-                const bool on = !relu || __builtin_fmaf(a[v], sc[v], sh[v]) > 0.f;
-                const double gd = on ? (double)g[v] : 0.0;
+                const float lin = __builtin_fmaf(a[v], sc[v], sh[v]);
+                on[v] = !relu || lin > 0.f;
+                t[v] = on[v] ? lin : 0.f;
+            }
+            bn_incoming_grad<VEC>(dz, pool, zmax, ties, row, c, col, t, g);
+#pragma unroll
+            for (int v = 0; v < VEC; ++v) {
+                const double gd = on[v] ? (double)g[v] : 0.0;
                 const double xh = (double)((a[v] - mean[v]) * invstd[v]);
                 part[0][v] += gd;
                 part[1][v] = __builtin_fma(gd, xh, part[1][v]);
@@ -235,21 +330,17 @@ bn_grad_reduce_kernel(long long rows, int c, long long slab, int nslots, const f
         };
         long long r = rb + mp.rr;
         const long long step = mp.rp;
-        for (; r + 3 * step < re; r += 4 * step) {  // four rows x two streams in flight
-            float g[4][VEC], a[4][VEC];
+        for (; r + 3 * step < re; r += 4 * step) {  // four rows in flight
+            float a[4][VEC];
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                bn_load<VEC>(dz + (size_t)(r + u * step) * c + col, g[u]);
-                bn_load<VEC>(y + (size_t)(r + u * step) * c + col, a[u]);
-            }
+            for (int u = 0; u < 4; ++u) bn_load<VEC>(y + (size_t)(r + u * step) * c + col, a[u]);
 #pragma unroll
-            for (int u = 0; u < 4; ++u) take(g[u], a[u]);
+            for (int u = 0; u < 4; ++u) take(r + u * step, a[u]);
         }
         for (; r < re; r += step) {
-            float g0[VEC], a0[VEC];
-            bn_load<VEC>(dz + (size_t)r * c + col, g0);
+            float a0[VEC];
             bn_load<VEC>(y + (size_t)r * c + col, a0);
-            take(g0, a0);
+            take(r, a0);
         }
     }
     bn_block_sums<VEC, 2>(mp, c, nslots, part, ws);
@@ -260,7 +351,8 @@ template <int VEC>
 __global__ void __launch_bounds__(kBnThreads)
 bn_grad_apply_kernel(long long rows, int c, const float* __restrict__ dz, const float* __restrict__ y,
                      const double* __restrict__ acc, const float* __restrict__ gamma, const float* __restrict__ beta,
-                     const float* __restrict__ save_mean, const float* __restrict__ save_invstd, int relu,
+                     const float* __restrict__ save_mean, const float* __restrict__ save_invstd, int relu, int pool,
+                     const float* __restrict__ zmax, const float* __restrict__ ties,
                      float* __restrict__ dy, float* __restrict__ dgamma, float* __restrict__ dbeta) {
     __shared__ float sc[kBnMaxC], sh[kBnMaxC], mu[kBnMaxC], is[kBnMaxC], k1[kBnMaxC], k2[kBnMaxC];
     const double inv_n = 1.0 / (double)rows;
@@ -282,14 +374,21 @@ bn_grad_apply_kernel(long long rows, int c, const float* __restrict__ dz, const 
     for (size_t e = (size_t)blockIdx.x * kBnThreads + threadIdx.x; e < total; e += stride) {
         const size_t f = e * VEC;
         const int ch = pow2 ? (int)(f & (size_t)(c - 1)) : (int)(f % (size_t)c);
-        float g[VEC], a[VEC];
-        bn_load<VEC>(dz + f, g);
+        float g[VEC], a[VEC], t[VEC];
+        bool on[VEC];
         bn_load<VEC>(y + f, a);
 #pragma unroll
         for (int k = 0; k < VEC; ++k) {
+            const float lin = __builtin_fmaf(a[k], sc[ch + k], sh[ch + k]);
+            on[k] = !relu || lin > 0.f;
+            t[k] = on[k] ? lin : 0.f;
+        }
+        if (pool <= 1) bn_load<VEC>(dz + f, g);
+        else bn_incoming_grad<VEC>(dz, pool, zmax, ties, (long long)((f - (size_t)ch) / (size_t)c), c, (size_t)ch, t, g);
+#pragma unroll
+        for (int k = 0; k < VEC; ++k) {
             const int cc = ch + k;
-            const bool on = !relu || __builtin_fmaf(a[k], sc[cc], sh[cc]) > 0.f;
-            const float gk = on ? g[k] : 0.f;
+            const float gk = on[k] ? g[k] : 0.f;
             const float xh = (a[k] - mu[cc]) * is[cc];
             g[k] = sc[cc] * __builtin_fmaf(-xh, k2[cc], gk - k1[cc]);
         }
@@ -340,13 +439,15 @@ extern "C" int pn2_debug_set_bn(int what, int value) {
 extern "C" size_t pn2_bn_workspace_bytes(int c) { return c > 0 ? sizeof(double) * bn_ws_doubles(c, kBnSlots) : 0; }
 
 extern "C" int pn2_bn_relu_forward(long long rows, int c, const float* y, const float* gamma, const float* beta,
-                                   const float* bias, float eps, float decay, int relu, float* running_mean,
+                                   const float* bias, float eps, float decay, int relu, int pool, float* running_mean,
                                    float* running_var, void* workspace, size_t workspace_bytes, float* save_mean,
-                                   float* save_invstd, float* z, void* stream) {
+                                   float* save_invstd, float* z, float* ties, void* stream) {
     if (!y || !gamma || !beta || !workspace || !save_mean || !save_invstd || !z) return PN2_ENULL;
     if ((running_mean == nullptr) != (running_var == nullptr)) return PN2_ENULL;
+    if (pool > 1 && !ties) return PN2_ENULL;
+    if (pool > 1 && rows % pool != 0) return PN2_EINVAL;
     BnPlan p;
-    const int rc = bn_plan(rows, c, y, z, nullptr, p);
+    const int rc = bn_plan(rows, c, y, z, ties, p);
     if (rc != PN2_OK) return rc;
     if (workspace_bytes < pn2_bn_workspace_bytes(c) || ((uintptr_t)workspace % 8) != 0) return PN2_EINVAL;
     hipStream_t st = static_cast<hipStream_t>(stream);
@@ -354,44 +455,63 @@ extern "C" int pn2_bn_relu_forward(long long rows, int c, const float* y, const 
     const double* acc = ws + kBnHead;
     hipError_t e = hipMemsetAsync(ws, 0, sizeof(double) * bn_ws_doubles(c, p.nslots), st);
     if (e != hipSuccess) return (int)e;
-    if (p.vec == 4) {
-        bn_stats_kernel<4><<<p.stat_blocks, kBnThreads, 0, st>>>(rows, c, p.slab, p.nslots, y, ws);
-        bn_fold_kernel<<<(2 * c + kBnThreads - 1) / kBnThreads, kBnThreads, 0, st>>>(2 * c, p.nslots, ws);
-        bn_apply_kernel<4><<<p.apply_blocks, kBnThreads, 0, st>>>(rows, c, y, acc, gamma, beta, bias, eps, decay, relu,
-                                                                running_mean, running_var, save_mean, save_invstd, z);
-    } else {
-        bn_stats_kernel<1><<<p.stat_blocks, kBnThreads, 0, st>>>(rows, c, p.slab, p.nslots, y, ws);
-        bn_fold_kernel<<<(2 * c + kBnThreads - 1) / kBnThreads, kBnThreads, 0, st>>>(2 * c, p.nslots, ws);
-        bn_apply_kernel<1><<<p.apply_blocks, kBnThreads, 0, st>>>(rows, c, y, acc, gamma, beta, bias, eps, decay, relu,
-                                                                running_mean, running_var, save_mean, save_invstd, z);
+    const int fold_blocks = (2 * c + kBnThreads - 1) / kBnThreads;
+    long long pb = 1;  // pooled apply: one group per (thread row slot), grid-stride beyond 8 blocks per CU
+    if (pool > 1) {
+        const int rp = kBnThreads / (c / p.vec);
+        pb = (rows / pool + rp - 1) / rp;
+        if (pb > 2048) pb = 2048;
     }
+#define PN2_BN_FWD(V_)                                                                                                   \
+    do {                                                                                                                 \
+        bn_stats_kernel<V_><<<p.stat_blocks, kBnThreads, 0, st>>>(rows, c, p.slab, p.nslots, y, ws);                      \
+        bn_fold_kernel<<<fold_blocks, kBnThreads, 0, st>>>(2 * c, p.nslots, ws);                                          \
+        if (pool > 1)                                                                                                    \
+            bn_apply_pool_kernel<V_><<<(int)pb, kBnThreads, 0, st>>>(rows, c, pool, y, acc, gamma, beta, bias, eps, decay, \
+                                                                   relu, running_mean, running_var, save_mean,           \
+                                                                   save_invstd, z, ties);                                \
+        else                                                                                                             \
+            bn_apply_kernel<V_><<<p.apply_blocks, kBnThreads, 0, st>>>(rows, c, y, acc, gamma, beta, bias, eps, decay,    \
+                                                                     relu, running_mean, running_var, save_mean,         \
+                                                                     save_invstd, z);                                    \
+    } while (0)
+    if (p.vec == 4) PN2_BN_FWD(4);
+    else PN2_BN_FWD(1);
+#undef PN2_BN_FWD
     PN2_RETURN_IF_LAUNCH_FAILED();
     return PN2_OK;
 }
 
 extern "C" int pn2_bn_relu_backward(long long rows, int c, const float* dz, const float* y, const float* gamma,
                                     const float* beta, const float* save_mean, const float* save_invstd, int relu,
-                                    void* workspace, size_t workspace_bytes, float* dy, float* dgamma, float* dbeta,
-                                    void* stream) {
+                                    int pool, const float* zmax, const float* ties, void* workspace,
+                                    size_t workspace_bytes, float* dy, float* dgamma, float* dbeta, void* stream) {
     if (!dz || !y || !gamma || !beta || !save_mean || !save_invstd || !workspace || !dy || !dgamma || !dbeta) return PN2_ENULL;
+    if (pool > 1 && (!zmax || !ties)) return PN2_ENULL;
+    if (pool > 1 && (rows % pool != 0 || dy == dz)) return PN2_EINVAL;
     BnPlan p;
-    const int rc = bn_plan(rows, c, dz, y, dy, p);
+    int rc = bn_plan(rows, c, dz, y, dy, p);
     if (rc != PN2_OK) return rc;
+    if (pool > 1 && p.vec == 4 && (((uintptr_t)zmax | (uintptr_t)ties) % 16) != 0) return PN2_EINVAL;
     if (workspace_bytes < pn2_bn_workspace_bytes(c) || ((uintptr_t)workspace % 8) != 0) return PN2_EINVAL;
     hipStream_t st = static_cast<hipStream_t>(stream);
     double* ws = static_cast<double*>(workspace);
     const double* acc = ws + kBnHead;
     hipError_t e = hipMemsetAsync(ws, 0, sizeof(double) * bn_ws_doubles(c, p.nslots), st);
     if (e != hipSuccess) return (int)e;
-    if (p.vec == 4) {
-        bn_grad_reduce_kernel<4><<<p.stat_blocks, kBnThreads, 0, st>>>(rows, c, p.slab, p.nslots, dz, y, gamma, beta, save_mean, save_invstd, relu, ws);
-        bn_fold_kernel<<<(2 * c + kBnThreads - 1) / kBnThreads, kBnThreads, 0, st>>>(2 * c, p.nslots, ws);
-        bn_grad_apply_kernel<4><<<p.apply_blocks, kBnThreads, 0, st>>>(rows, c, dz, y, acc, gamma, beta, save_mean, save_invstd, relu, dy, dgamma, dbeta);
-    } else {
-        bn_grad_reduce_kernel<1><<<p.stat_blocks, kBnThreads, 0, st>>>(rows, c, p.slab, p.nslots, dz, y, gamma, beta, save_mean, save_invstd, relu, ws);
-        bn_fold_kernel<<<(2 * c + kBnThreads - 1) / kBnThreads, kBnThreads, 0, st>>>(2 * c, p.nslots, ws);
-        bn_grad_apply_kernel<1><<<p.apply_blocks, kBnThreads, 0, st>>>(rows, c, dz, y, acc, gamma, beta, save_mean, save_invstd, relu, dy, dgamma, dbeta);
-    }
+    const int fold_blocks = (2 * c + kBnThreads - 1) / kBnThreads;
+#define PN2_BN_BWD(V_)                                                                                                  \
+    do {                                                                                                                \
+        bn_grad_reduce_kernel<V_><<<p.stat_blocks, kBnThreads, 0, st>>>(rows, c, p.slab, p.nslots, dz, y, gamma, beta,   \
+                                                                      save_mean, save_invstd, relu, pool, zmax, ties, ws); \
+        bn_fold_kernel<<<fold_blocks, kBnThreads, 0, st>>>(2 * c, p.nslots, ws);                                         \
+        bn_grad_apply_kernel<V_><<<p.apply_blocks, kBnThreads, 0, st>>>(rows, c, dz, y, acc, gamma, beta, save_mean,     \
+                                                                      save_invstd, relu, pool, zmax, ties, dy, dgamma,  \
+                                                                      dbeta);                                           \
+    } while (0)
+    if (p.vec == 4) PN2_BN_BWD(4);
+    else PN2_BN_BWD(1);
+#undef PN2_BN_BWD
     PN2_RETURN_IF_LAUNCH_FAILED();
     return PN2_OK;
 }

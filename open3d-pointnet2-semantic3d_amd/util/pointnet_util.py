@@ -178,11 +178,15 @@ def pointnet_sa_module(xyz, points, npoint, radius, nsample, mlp, mlp2, group_al
             else:
                 new_xyz, new_points, idx, grouped_xyz = sample_and_group(npoint, radius, nsample, xyz, points, knn,
                                                                          use_xyz)
+            # training: the max over K rides in the last layer's batch-norm kernels (tf_util._TrainDenseBnRelu)
+            fuse_pool = bool(is_training) and pooling == "max" and len(mlp) > 0 and nsample <= 1024
             for i, cout in enumerate(mlp):
                 new_points = tf_util.conv2d(new_points, cout, [1, 1], padding="VALID", stride=[1, 1], bn=bn,
-                                            is_training=is_training, scope="conv%d" % i, bn_decay=bn_decay)
+                                            is_training=is_training, scope="conv%d" % i, bn_decay=bn_decay,
+                                            pool=nsample if (fuse_pool and i == len(mlp) - 1) else 0)
             if pooling == "max":
-                new_points = new_points.amax(dim=2, keepdim=True)
+                if not fuse_pool:
+                    new_points = new_points.amax(dim=2, keepdim=True)
             elif pooling == "avg":
                 new_points = new_points.mean(dim=2, keepdim=True)
             elif pooling == "weighted_avg":

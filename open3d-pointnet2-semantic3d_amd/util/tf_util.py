@@ -270,30 +270,38 @@ def _batch_norm_train(x, bnv, bn_decay):
 
 
 class _TrainDenseBnRelu(torch.autograd.Function):
-    """relu?(batch_norm(x2d @ w + b)) for the training path, with the normalisation on the HIP library:
-    forward = GEMM -> pn2_bn_relu_forward (fp64 batch moments, normalise + ReLU; the pre-BN bias only moves the mean,
-    so it is folded into the moving average instead of being added); backward = pn2_bn_relu_backward (ReLU mask, dgamma,
-    dbeta, dy) -> dX = dY @ w^T, dW on pn2_linear_wgrad.  Replaces nine elementwise / reduction kernels per layer."""
+    """relu?(batch_norm(x2d @ w + b)) [-> max over groups of `pool` rows] for the training path, with the
+    normalisation on the HIP library: forward = GEMM -> pn2_bn_relu_forward (fp64 batch moments, normalise + ReLU
+    [+ max pool: the un-pooled activation is never written]; the pre-BN bias only moves the mean, so it is folded into
+    the moving average instead of being added); backward = pn2_bn_relu_backward (pool / ReLU masks, dgamma, dbeta, dy)
+    -> dX = dY @ w^T, dW on pn2_linear_wgrad.  Replaces nine elementwise / reduction kernels per layer."""
 
     @staticmethod
-    def forward(ctx, x2d, w, b, gamma, beta, running_mean, running_var, decay, relu):
+    def forward(ctx, x2d, w, b, gamma, beta, running_mean, running_var, decay, relu, pool):
         y = x2d @ w
         rows, c = y.shape
-        z = torch.empty_like(y)
+        pooled = pool > 1
+        z = torch.empty((rows // pool, c) if pooled else (rows, c), dtype=y.dtype, device=y.device)
+        ties = torch.empty_like(z) if pooled else None
         save_mean = torch.empty(c, dtype=torch.float32, device=y.device)
         save_invstd = torch.empty_like(save_mean)
         ws = torch.empty(lib.pn2_bn_workspace_bytes(c) // 8, dtype=torch.float64, device=y.device)
         with torch.cuda.device(y.device):
             check(lib.pn2_bn_relu_forward(rows, c, ptr(y), ptr(gamma), ptr(beta), ptr(b), BN_EPSILON, decay, int(relu),
-                                          ptr(running_mean), ptr(running_var), ptr(ws), ws.numel() * 8, ptr(save_mean),
-                                          ptr(save_invstd), ptr(z), stream_ptr()), "pn2_bn_relu_forward")
-        ctx.save_for_backward(x2d, w, y, gamma, beta, save_mean, save_invstd)
-        ctx.relu = bool(relu)
+                                          int(pool), ptr(running_mean), ptr(running_var), ptr(ws), ws.numel() * 8,
+                                          ptr(save_mean), ptr(save_invstd), ptr(z), ptr(ties), stream_ptr()),
+                  "pn2_bn_relu_forward")
+        if pooled:
+            ctx.save_for_backward(x2d, w, y, gamma, beta, save_mean, save_invstd, z, ties)
+        else:
+            ctx.save_for_backward(x2d, w, y, gamma, beta, save_mean, save_invstd)
+        ctx.relu, ctx.pool = bool(relu), int(pool)
         return z
 
     @staticmethod
     def backward(ctx, dz):
-        x2d, w, y, gamma, beta, save_mean, save_invstd = ctx.saved_tensors
+        x2d, w, y, gamma, beta, save_mean, save_invstd = ctx.saved_tensors[:7]
+        zmax, ties = ctx.saved_tensors[7:] if ctx.pool > 1 else (None, None)
         rows, c = y.shape
         dz = dz.contiguous()
         dy = torch.empty_like(y)
@@ -302,8 +310,9 @@ class _TrainDenseBnRelu(torch.autograd.Function):
         ws = torch.empty(lib.pn2_bn_workspace_bytes(c) // 8, dtype=torch.float64, device=y.device)
         with torch.cuda.device(y.device):
             check(lib.pn2_bn_relu_backward(rows, c, ptr(dz), ptr(y), ptr(gamma), ptr(beta), ptr(save_mean),
-                                           ptr(save_invstd), int(ctx.relu), ptr(ws), ws.numel() * 8, ptr(dy), ptr(dgamma),
-                                           ptr(dbeta), stream_ptr()), "pn2_bn_relu_backward")
+                                           ptr(save_invstd), int(ctx.relu), ctx.pool, ptr(zmax), ptr(ties), ptr(ws),
+                                           ws.numel() * 8, ptr(dy), ptr(dgamma), ptr(dbeta), stream_ptr()),
+                  "pn2_bn_relu_backward")
             dx = dy @ w.t() if ctx.needs_input_grad[0] else None
             dw = None
             if ctx.needs_input_grad[1]:
@@ -312,26 +321,37 @@ class _TrainDenseBnRelu(torch.autograd.Function):
                       "pn2_linear_wgrad")
         # a constant in front of batch norm has no effect on the output: its gradient is exactly zero
         db = torch.zeros(c, dtype=dy.dtype, device=dy.device) if ctx.needs_input_grad[2] else None
-        return dx, dw, db, dgamma, dbeta, None, None, None, None
+        return dx, dw, db, dgamma, dbeta, None, None, None, None, None
 
 
 USE_HIP_BN = True  # set False to run batch norm / ReLU of the training path on torch (tests / A-B)
 
 
-def _train_layer(inputs, w2d, b, bnv, bn_decay, relu):
-    """One dense layer of the training path: inputs (..., cin) -> (..., cout)."""
+def _train_layer(inputs, w2d, b, bnv, bn_decay, relu, pool=0):
+    """One dense layer of the training path: inputs (..., cin) -> (..., cout); pool > 1 also takes the max over
+    groups of `pool` consecutive entries of the second-to-last axis (..., W, cin) -> (..., W/pool, cout)."""
     cin, cout = w2d.shape
+    pool = int(pool) if pool and pool > 1 else 0
+    lead = list(inputs.shape[:-1])
+    if pool:
+        if lead[-1] % pool:
+            raise ValueError("pool must divide the grouped axis")
+        lead[-1] //= pool
     if (bnv is not None and USE_HIP_BN and USE_HIP_WGRAD and inputs.is_cuda and inputs.dtype == torch.float32
             and cout <= 1024 and (cout % 4 == 0 or cout <= 256)):
         beta, gamma, mean, var = bnv
         decay = 0.9 if bn_decay is None else float(bn_decay)  # tf_util.py:571
         z = _TrainDenseBnRelu.apply(inputs.reshape(-1, cin).contiguous(), w2d.contiguous(), b, gamma, beta, mean, var,
-                                    decay, relu)
-        return z.reshape(list(inputs.shape[:-1]) + [cout])
+                                    decay, relu, pool)
+        return z.reshape(lead + [cout])
     y = _train_dense(inputs, w2d, b)
     if bnv is not None:
         y = _batch_norm_train(y, bnv, bn_decay)
-    return torch.relu(y) if relu else y
+    if relu:
+        y = torch.relu(y)
+    if pool:
+        y = y.reshape(lead + [pool, cout]).amax(dim=-2)
+    return y
 
 
 def _batch_norm_eval(x, bnv):
@@ -363,10 +383,7 @@ def conv2d(inputs, num_output_channels, kernel_size, scope, stride=(1, 1), paddi
                 lead[-1] //= pool
             return y.reshape(lead + [cout])
         st, w, b, bnv = _dense_variables(cin, cout, bn, (1, 1, cin, cout))
-        y = _train_layer(inputs, w.reshape(cin, cout), b, bnv, bn_decay, activation_fn is not None)
-        if pool and pool > 1:
-            y = y.reshape(list(y.shape[:-2]) + [y.shape[-2] // pool, pool, cout]).amax(dim=-2)
-        return y
+        return _train_layer(inputs, w.reshape(cin, cout), b, bnv, bn_decay, activation_fn is not None, pool)
 
 
 def conv1d(inputs, num_output_channels, kernel_size, scope, stride=1, padding="SAME", use_xavier=True,

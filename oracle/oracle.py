@@ -343,3 +343,22 @@ def batch_norm_relu_train_grad(y, gamma, beta, dz, relu=True, eps=BN_EPSILON, ma
     dgamma = (g * xhat).sum(axis=0)
     dy = gamma * invstd * (g - g.mean(axis=0) - xhat * (g * xhat).mean(axis=0))
     return dy, dgamma, dbeta
+
+
+def max_pool_rows(z, pool):
+    """tf.reduce_max over the K neighbours of an SA layer (util/pointnet_util.py:167-170) on a (rows, c) activation
+    whose rows come in consecutive groups of `pool`: -> (zmax (rows/pool, c), ties (rows/pool, c) = how many rows of
+    the group attain the maximum)."""
+    z = np.asarray(z, np.float64)
+    g = z.reshape(z.shape[0] // pool, pool, z.shape[1])
+    zmax = g.max(axis=1)
+    return zmax, (g == zmax[:, None, :]).sum(axis=1).astype(np.float64)
+
+
+def max_pool_rows_grad(z, pool, dzmax):
+    """Gradient of max_pool_rows w.r.t. z as tf.gradients / torch.amax define it: the incoming gradient is shared
+    equally among the rows that attain the maximum."""
+    z = np.asarray(z, np.float64)
+    g = z.reshape(z.shape[0] // pool, pool, z.shape[1])
+    sel = g == g.max(axis=1, keepdims=True)
+    return (sel * (np.asarray(dzmax, np.float64) / sel.sum(axis=1))[:, None, :]).reshape(z.shape)

@@ -757,14 +757,17 @@ def test_training_gradients_with_hip_wgrad_match_torch(pn2, cuda):
     labels = T(rs.randint(0, 9, (8, 2048)).astype(np.int64), cuda)
     smpw = T((rs.random_sample((8, 2048)) + 0.5).astype(np.float32), cuda)
 
-    def layer_fp64(inputs, w2d, b, bnv, bn_decay, relu):
+    def layer_fp64(inputs, w2d, b, bnv, bn_decay, relu, pool=0):
         y = inputs.double() @ w2d.double() + b.double()
         if bnv is not None:
             beta, gamma, mean, var = bnv
             c = y.shape[-1]
             y = F.batch_norm(y.reshape(-1, c), None, None, gamma.double(), beta.double(), training=True,
                              eps=tfu.BN_EPSILON).reshape(y.shape)
-        return (torch.relu(y) if relu else y).float()
+        y = torch.relu(y) if relu else y
+        if pool and pool > 1:
+            y = y.reshape(list(y.shape[:-2]) + [y.shape[-2] // pool, pool, y.shape[-1]]).amax(dim=-2)
+        return y.float()
 
     def run(mode):
         orig = tfu._train_layer
@@ -821,8 +824,8 @@ def test_bn_relu_forward_backward_vs_oracle(pn2, oracle, cuda, rows, c, relu):
     sm, si = torch.empty(c, device=cuda), torch.empty(c, device=cuda)
     assert lib.pn2_bn_workspace_bytes(c) >= 2 * c * 8 and lib.pn2_bn_workspace_bytes(c) % 8 == 0
     ws = torch.empty(lib.pn2_bn_workspace_bytes(c) // 8, dtype=torch.float64, device=cuda)
-    assert lib.pn2_bn_relu_forward(rows, c, P(ty), P(tg), P(tb), P(tbias), eps, decay, relu, P(rm), P(rv), P(ws), ws.numel() * 8,
-                                   P(sm), P(si), P(z), None) == 0
+    assert lib.pn2_bn_relu_forward(rows, c, P(ty), P(tg), P(tb), P(tbias), eps, decay, relu, 0, P(rm), P(rv), P(ws), ws.numel() * 8,
+                                   P(sm), P(si), P(z), None, None) == 0
     zr, mean, var, mm, mv = oracle.batch_norm_relu_train(y, gamma, beta, bool(relu), eps, bias, (np.full(c, 0.25), np.full(c, 2.0)), decay)
     zg = z.cpu().numpy()
     assert np.abs(zg - zr).max() <= 1e-5 * max(np.abs(zr).max(), 1.0)
@@ -833,14 +836,67 @@ def test_bn_relu_forward_backward_vs_oracle(pn2, oracle, cuda, rows, c, relu):
     dyr, dgr, dbr = oracle.batch_norm_relu_train_grad(y, gamma, beta, dz, bool(relu), eps, mask=zg > 0)
     dy = torch.empty_like(ty)
     dg, db = torch.empty(c, device=cuda), torch.empty(c, device=cuda)
-    assert lib.pn2_bn_relu_backward(rows, c, P(tdz), P(ty), P(tg), P(tb), P(sm), P(si), relu, P(ws), ws.numel() * 8, P(dy), P(dg),
-                                    P(db), None) == 0
+    assert lib.pn2_bn_relu_backward(rows, c, P(tdz), P(ty), P(tg), P(tb), P(sm), P(si), relu, 0, None, None, P(ws), ws.numel() * 8,
+                                    P(dy), P(dg), P(db), None) == 0
     for got, ref in ((dy, dyr), (dg, dgr), (db, dbr)):
         assert np.abs(got.cpu().numpy() - ref).max() <= 2e-5 * max(np.abs(ref).max(), 1.0)
     dz2 = tdz.clone()  # in place: dy may alias dz
-    assert lib.pn2_bn_relu_backward(rows, c, P(dz2), P(ty), P(tg), P(tb), P(sm), P(si), relu, P(ws), ws.numel() * 8, P(dz2), P(dg),
-                                    P(db), None) == 0
+    assert lib.pn2_bn_relu_backward(rows, c, P(dz2), P(ty), P(tg), P(tb), P(sm), P(si), relu, 0, None, None, P(ws), ws.numel() * 8,
+                                    P(dz2), P(dg), P(db), None) == 0
     assert torch.equal(dz2, dy)
+
+
+@pytest.mark.parametrize("groups,pool,c,relu", [(512, 32, 64, 1), (100, 16, 128, 1), (64, 32, 512, 1), (33, 8, 36, 0),
+                                                 (7, 64, 9, 1), (300, 32, 32, 1)])
+def test_bn_relu_fused_max_pool_vs_oracle(pn2, oracle, cuda, groups, pool, c, relu):
+    """pool > 1: batch norm + ReLU + max over each group of `pool` rows in the forward, its gradient (shared equally
+    among tied rows) in the backward.  Groups contain duplicated rows (ball-query padding) and all-negative channels
+    (every row ties at the ReLU floor)."""
+    import ctypes
+    import torch
+    lib = pn2._lib.lib
+    P = lambda t: ctypes.c_void_p(t.data_ptr())
+    rows = groups * pool
+    rs = np.random.RandomState(groups + pool + c)
+    y = rs.randn(groups, pool, c).astype(np.float32)
+    y[::3, pool // 2:, :] = y[::3, :1, :]            # second half of every third group repeats its first row
+    y = y.reshape(rows, c)
+    gamma = (0.5 + rs.rand(c)).astype(np.float32)
+    beta = (rs.randn(c) * 0.3).astype(np.float32)
+    beta[::5] = -6.0                                   # channels that never pass the ReLU
+    dzp = rs.randn(groups, c).astype(np.float32)
+    eps = 1e-3
+    ty, tg, tb, tdz = (T(a, cuda) for a in (y, gamma, beta, dzp))
+    zmax, ties = torch.empty(groups, c, device=cuda), torch.empty(groups, c, device=cuda)
+    sm, si = torch.empty(c, device=cuda), torch.empty(c, device=cuda)
+    ws = torch.empty(lib.pn2_bn_workspace_bytes(c) // 8, dtype=torch.float64, device=cuda)
+    assert lib.pn2_bn_relu_forward(rows, c, P(ty), P(tg), P(tb), None, eps, 0.9, relu, pool, None, None, P(ws), ws.numel() * 8,
+                                   P(sm), P(si), P(zmax), P(ties), None) == 0
+    z, mean, var = oracle.batch_norm_relu_train(y, gamma, beta, bool(relu), eps)
+    zr, _ = oracle.max_pool_rows(z, pool)
+    assert np.abs(zmax.cpu().numpy() - zr).max() <= 1e-5 * max(np.abs(zr).max(), 1.0)
+    # which rows tie is decided in fp32: restate the kernel's value z = fma(y, sc, sh) (sc = gamma*invstd,
+    # sh = fma(-mean, sc, beta), one rounding each) from its own saved moments and pool THAT
+    m32, i32 = sm.cpu().numpy(), si.cpu().numpy()
+    sc = (gamma * i32).astype(np.float32)
+    sh = (-m32.astype(np.float64) * sc.astype(np.float64) + beta.astype(np.float64)).astype(np.float32)
+    z32 = (y.astype(np.float64) * sc.astype(np.float64) + sh.astype(np.float64)).astype(np.float32)
+    if relu:
+        z32 = np.maximum(z32, np.float32(0))
+    z32r, tr = oracle.max_pool_rows(z32, pool)
+    assert np.array_equal(zmax.cpu().numpy(), z32r.astype(np.float32))
+    assert np.array_equal(ties.cpu().numpy(), tr)
+    assert tr.max() >= pool // 2 + 1                 # duplicated rows tie
+    assert not relu or (tr[:, ::5] == pool).any()     # dead channels: every row ties at the ReLU floor
+    # gradient: pooled gradient -> tied rows -> ReLU mask -> batch norm
+    dz_full = oracle.max_pool_rows_grad(z32, pool, dzp)
+    dyr, dgr, dbr = oracle.batch_norm_relu_train_grad(y, gamma, beta, dz_full, bool(relu), eps, mask=z32 > 0)
+    dy = torch.empty_like(ty)
+    dg, db = torch.empty(c, device=cuda), torch.empty(c, device=cuda)
+    assert lib.pn2_bn_relu_backward(rows, c, P(tdz), P(ty), P(tg), P(tb), P(sm), P(si), relu, pool, P(zmax), P(ties), P(ws),
+                                    ws.numel() * 8, P(dy), P(dg), P(db), None) == 0
+    for got, ref in ((dy, dyr), (dg, dgr), (db, dbr)):
+        assert np.abs(got.cpu().numpy() - ref).max() <= 2e-5 * max(np.abs(ref).max(), 1.0)
 
 
 def test_bn_relu_argument_checks(pn2, cuda):
@@ -851,8 +907,8 @@ def test_bn_relu_argument_checks(pn2, cuda):
     y = torch.zeros(8, 2048, device=cuda)
     v = torch.zeros(2048, device=cuda)
     ws = torch.empty(pn2._lib.lib.pn2_bn_workspace_bytes(2048) // 8, dtype=torch.float64, device=cuda)
-    head = (P(y), P(v), P(v), None, 1e-3, 0.9, 1)
-    tail = (P(ws), ws.numel() * 8, P(v), P(v), P(y), None)
+    head = (P(y), P(v), P(v), None, 1e-3, 0.9, 1, 0)
+    tail = (P(ws), ws.numel() * 8, P(v), P(v), P(y), None, None)
     assert raw.pn2_bn_relu_forward(8, 2048, *head, None, None, *tail) == pn2._lib.PN2_EUNSUP   # c > 1024
     assert raw.pn2_bn_relu_forward(8, 300, *head, None, None, *tail) == 0                      # c % 4 == 0, vector path
     assert raw.pn2_bn_relu_forward(8, 301, *head, None, None, *tail) == pn2._lib.PN2_EUNSUP   # scalar path stops at 256
@@ -860,10 +916,13 @@ def test_bn_relu_argument_checks(pn2, cuda):
     assert raw.pn2_bn_relu_forward(8, 64, *head, None, None, P(ws), 8, *tail[2:]) != 0         # workspace too small
     assert raw.pn2_bn_relu_forward(8, 64, None, *head[1:], None, None, *tail) != 0             # null y
     assert raw.pn2_bn_relu_forward(8, 64, *head, P(v), None, *tail) != 0                       # only one moving average
+    assert raw.pn2_bn_relu_forward(8, 64, *head[:7], 4, None, None, *tail) != 0                # pooled without a ties buffer
+    assert raw.pn2_bn_relu_forward(8, 64, *head[:7], 3, None, None, *tail[:5], P(y), None) != 0  # pool does not divide rows
     torch.cuda.synchronize()
 
 
-def test_train_layer_hip_bn_matches_torch_autograd(pn2, cuda):
+@pytest.mark.parametrize("pool", [0, 32])
+def test_train_layer_hip_bn_matches_torch_autograd(pn2, cuda, pool):
     """_train_layer with the HIP batch norm vs the torch composition (F.batch_norm + relu autograd): output,
     moving averages and every gradient (bias gradient exactly zero on the HIP path, rounding noise on torch's)."""
     import torch
@@ -871,7 +930,9 @@ def test_train_layer_hip_bn_matches_torch_autograd(pn2, cuda):
     torch.manual_seed(5)
     x = torch.randn(16, 64, 32, 67, device=cuda)
     w0 = torch.randn(67, 128, device=cuda) * 0.1
-    probe = torch.sin(torch.arange(16 * 64 * 32 * 128, device=cuda).float()).reshape(16, 64, 32, 128)
+    x[:, ::3, 16:, :] = x[:, ::3, :1, :]  # duplicated neighbours: exact ties in the max pool
+    oshape = (16, 64, 1 if pool else 32, 128)
+    probe = torch.sin(torch.arange(int(np.prod(oshape)), device=cuda).float()).reshape(oshape)
     outs = {}
     for use in (True, False):
         tfu.USE_HIP_BN = use
@@ -882,7 +943,8 @@ def test_train_layer_hip_bn_matches_torch_autograd(pn2, cuda):
             beta = torch.zeros(128, device=cuda, requires_grad=True)
             gamma = torch.ones(128, device=cuda, requires_grad=True)
             mean, var = torch.zeros(128, device=cuda), torch.ones(128, device=cuda)
-            z = tfu._train_layer(xx, w, b, (beta, gamma, mean, var), None, True)
+            z = tfu._train_layer(xx, w, b, (beta, gamma, mean, var), None, True, pool)
+            assert tuple(z.shape) == oshape
             (z * probe).sum().backward()
             outs[use] = (z.detach(), mean, var, xx.grad, w.grad, gamma.grad, beta.grad, b.grad)
         finally:
