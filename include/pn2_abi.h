@@ -129,6 +129,13 @@ int pn2_group_point_grad(int b, int n, int c, int m, int nsample,
                          const float *grad_out, const int *idx, float *grad_points,
                          void *stream);
 
+/* The same gradient with caller-provided scratch (see pn2_three_interpolate_grad_ws): a per-point list of the grouped
+ * rows that reference it, then a gather -- no float atomics on large levels.  `workspace`: 4-byte aligned, at least
+ * pn2_group_point_grad_workspace_bytes(b, n, m, nsample) bytes. */
+size_t pn2_group_point_grad_workspace_bytes(int b, int n, int m, int nsample);
+int pn2_group_point_grad_ws(int b, int n, int c, int m, int nsample, const float *grad_out, const int *idx,
+                            float *grad_points, void *workspace, size_t workspace_bytes, void *stream);
+
 /* ---- interpolation (replaces the CPU ops of tf_ops/tf_interpolate.cpp) --- */
 
 /* threenn_cpu(b,n,m,xyz1,xyz2,dists,indices)  tf_interpolate.cpp:213-243.

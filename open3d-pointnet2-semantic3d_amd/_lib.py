@@ -32,6 +32,8 @@ SIGNATURES = {
     "pn2_three_nn": [c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p],
     "pn2_three_interpolate": [c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p],
     "pn2_three_interpolate_grad": [c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p],
+    "pn2_group_point_grad_ws": [c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, ctypes.c_size_t,
+                                c_void_p],
     "pn2_three_interpolate_grad_ws": [c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                       ctypes.c_size_t, c_void_p],
     "pn2_linear": [c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p],
@@ -91,6 +93,8 @@ def _load():
     lib.pn2_interpolate_label_workspace_bytes.restype = ctypes.c_size_t
     lib.pn2_three_interpolate_grad_workspace_bytes.argtypes = [c_int, c_int, c_int]
     lib.pn2_three_interpolate_grad_workspace_bytes.restype = ctypes.c_size_t
+    lib.pn2_group_point_grad_workspace_bytes.argtypes = [c_int, c_int, c_int, c_int]
+    lib.pn2_group_point_grad_workspace_bytes.restype = ctypes.c_size_t
     lib.pn2_bn_workspace_bytes.argtypes = [c_int]
     lib.pn2_bn_workspace_bytes.restype = ctypes.c_size_t
     lib.pn2_abi_version.restype = c_int

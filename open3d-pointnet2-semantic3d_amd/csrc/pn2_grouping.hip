@@ -1059,3 +1059,28 @@ extern "C" int pn2_group_point_grad(int b, int n, int c, int m, int nsample, con
     PN2_RETURN_IF_LAUNCH_FAILED();
     return PN2_OK;
 }
+
+// internal helpers of pn2_interpolate.hip (list-and-gather row scatter)
+extern "C" size_t pn2_scatter_rows_workspace_bytes(int b, int nent, int nsrc);
+extern "C" int pn2_scatter_rows_gather(int b, int nent, int div, int c, int nsrc, const float* rows_in, const int* idx,
+                                       const float* weight, float* out, void* workspace, void* stream);
+
+extern "C" size_t pn2_group_point_grad_workspace_bytes(int b, int n, int m, int nsample) {
+    if (b <= 0 || n <= 0 || m <= 0 || nsample <= 0) return 0;
+    return pn2_scatter_rows_workspace_bytes(b, m * nsample, n);
+}
+
+// group_point gradient with caller-provided scratch: large levels build a per-point list of the grouped rows that
+// reference it and gather (no float atomics); small ones, c % 4 != 0 or workspace == NULL run pn2_group_point_grad.
+extern "C" int pn2_group_point_grad_ws(int b, int n, int c, int m, int nsample, const float* grad_out, const int* idx,
+                                       float* grad_points, void* workspace, size_t workspace_bytes, void* stream) {
+    if (b <= 0 || n <= 0 || c <= 0 || m <= 0 || nsample <= 0) return PN2_EINVAL;
+    if (!grad_out || !idx || !grad_points) return PN2_ENULL;
+    const unsigned long long rows = (unsigned long long)m * nsample;
+    const bool gather_ok = workspace && c % 4 == 0 && c <= 1024 && (((uintptr_t)grad_out | (uintptr_t)grad_points) % 16) == 0 &&
+                           rows <= 0x7fffffffull && b <= 65535;
+    if (!gather_ok || (unsigned long long)b * rows * c < (1ull << 20))
+        return pn2_group_point_grad(b, n, c, m, nsample, grad_out, idx, grad_points, stream);
+    if (workspace_bytes < pn2_group_point_grad_workspace_bytes(b, n, m, nsample) || ((uintptr_t)workspace % 4) != 0) return PN2_EINVAL;
+    return pn2_scatter_rows_gather(b, (int)rows, 1, c, n, grad_out, idx, nullptr, grad_points, workspace, stream);
+}

@@ -415,12 +415,12 @@ ti_csr_scan_kernel(int m, int* __restrict__ cnt_all, int* __restrict__ off_all) 
 }
 
 __global__ void __launch_bounds__(256)
-ti_csr_fill_kernel(int n3, int m, const int* __restrict__ idx_all, const float* __restrict__ weight_all,
+ti_csr_fill_kernel(int n3, int m, int div, const int* __restrict__ idx_all, const float* __restrict__ weight_all,
                    const int* __restrict__ off_all, int* __restrict__ cur_all, int* __restrict__ ent_q_all,
                    float* __restrict__ ent_w_all) {
     const int bi = blockIdx.y;
     const int* __restrict__ idx = idx_all + (size_t)bi * n3;
-    const float* __restrict__ w = weight_all + (size_t)bi * n3;
+    const float* __restrict__ w = weight_all ? weight_all + (size_t)bi * n3 : nullptr;
     const int* __restrict__ off = off_all + (size_t)bi * m;
     int* __restrict__ cur = cur_all + (size_t)bi * m;
     int* __restrict__ eq = ent_q_all + (size_t)bi * n3;
@@ -428,14 +428,14 @@ ti_csr_fill_kernel(int n3, int m, const int* __restrict__ idx_all, const float* 
     for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < n3; e += gridDim.x * blockDim.x) {
         const int s = idx[e];
         const int p = off[s] + atomicAdd(&cur[s], 1);
-        eq[p] = e / 3;
-        ew[p] = w[e];
+        eq[p] = e / div;   // div entries per input row (3 for three_interpolate, 1 for group_point)
+        ew[p] = w ? w[e] : 1.f;
     }
 }
 
 // thread -> (source slot, float4 column); each slot walks the list of its source point, four entries in flight
 __global__ void __launch_bounds__(256)
-ti_csr_gather_kernel(int n, int c, int m, const float* __restrict__ grad_out_all, const int* __restrict__ off_all,
+ti_csr_gather_kernel(int n, int n3, int c, int m, const float* __restrict__ grad_out_all, const int* __restrict__ off_all,
                      const int* __restrict__ ent_q_all, const float* __restrict__ ent_w_all,
                      float* __restrict__ grad_points_all) {
     const int cv = c >> 2;
@@ -444,7 +444,6 @@ ti_csr_gather_kernel(int n, int c, int m, const float* __restrict__ grad_out_all
     const int bi = blockIdx.y;
     const int s = blockIdx.x * spb + slot;
     if (slot >= spb || s >= m) return;
-    const int n3 = 3 * n;
     const f32x4* __restrict__ go = reinterpret_cast<const f32x4*>(grad_out_all + (size_t)bi * n * c);
     const int* __restrict__ off = off_all + (size_t)bi * m;
     const int* __restrict__ eq = ent_q_all + (size_t)bi * n3;
@@ -760,9 +759,35 @@ extern "C" int pn2_three_interpolate_grad(int b, int n, int c, int m, const floa
     return PN2_OK;
 }
 
+// out[b, idx[b,e], :] += weight[b,e] * rows_in[b, e/div, :] for e < nent, as a list build + gather (see ti_csr_*).
+// rows_in (b, nent/div, c), out (b, nsrc, c) overwritten.  Internal: shared by the two *_grad_ws entry points.
+extern "C" size_t pn2_scatter_rows_workspace_bytes(int b, int nent, int nsrc) {
+    return sizeof(int) * ((size_t)2 * b * nsrc + (size_t)2 * b * nent);  // cursor, offsets | entry row, entry weight
+}
+
+extern "C" int pn2_scatter_rows_gather(int b, int nent, int div, int c, int nsrc, const float* rows_in, const int* idx,
+                                       const float* weight, float* out, void* workspace, void* stream) {
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    int* cnt = static_cast<int*>(workspace);
+    int* off = cnt + (size_t)b * nsrc;
+    int* ent_q = off + (size_t)b * nsrc;
+    float* ent_w = reinterpret_cast<float*>(ent_q + (size_t)b * nent);
+    hipError_t e = hipMemsetAsync(cnt, 0, sizeof(int) * (size_t)b * nsrc, st);
+    if (e != hipSuccess) return (int)e;
+    dim3 ge(grid_x_for((unsigned long long)nent, 256, b), b);
+    ti_csr_count_kernel<<<ge, 256, 0, st>>>(nent, nsrc, idx, cnt);
+    ti_csr_scan_kernel<<<b, 256, 0, st>>>(nsrc, cnt, off);
+    ti_csr_fill_kernel<<<ge, 256, 0, st>>>(nent, nsrc, div, idx, weight, off, cnt, ent_q, ent_w);
+    const int spb = 256 / (c / 4);
+    dim3 gg((nsrc + spb - 1) / spb, b);
+    ti_csr_gather_kernel<<<gg, 256, 0, st>>>(nent / div, nent, c, nsrc, rows_in, off, ent_q, ent_w, out);
+    PN2_RETURN_IF_LAUNCH_FAILED();
+    return PN2_OK;
+}
+
 extern "C" size_t pn2_three_interpolate_grad_workspace_bytes(int b, int n, int m) {
     if (b <= 0 || n <= 0 || m <= 0) return 0;
-    return sizeof(int) * ((size_t)2 * b * m + (size_t)6 * b * n);  // cursor, offsets | entry query, entry weight
+    return pn2_scatter_rows_workspace_bytes(b, 3 * n, m);
 }
 
 extern "C" int pn2_three_interpolate_grad_ws(int b, int n, int c, int m, const float* grad_out, const int* idx,
@@ -776,23 +801,7 @@ extern "C" int pn2_three_interpolate_grad_ws(int b, int n, int c, int m, const f
     if (!gather_ok || (unsigned long long)b * n * 3 * c < (1ull << 20))
         return pn2_three_interpolate_grad(b, n, c, m, grad_out, idx, weight, grad_points, stream);
     if (workspace_bytes < pn2_three_interpolate_grad_workspace_bytes(b, n, m) || ((uintptr_t)workspace % 4) != 0) return PN2_EINVAL;
-    hipStream_t st = static_cast<hipStream_t>(stream);
-    int* cnt = static_cast<int*>(workspace);
-    int* off = cnt + (size_t)b * m;
-    int* ent_q = off + (size_t)b * m;
-    float* ent_w = reinterpret_cast<float*>(ent_q + (size_t)3 * b * n);
-    hipError_t e = hipMemsetAsync(cnt, 0, sizeof(int) * (size_t)b * m, st);
-    if (e != hipSuccess) return (int)e;
-    const int n3 = 3 * n;
-    dim3 ge(grid_x_for((unsigned long long)n3, 256, b), b);
-    ti_csr_count_kernel<<<ge, 256, 0, st>>>(n3, m, idx, cnt);
-    ti_csr_scan_kernel<<<b, 256, 0, st>>>(m, cnt, off);
-    ti_csr_fill_kernel<<<ge, 256, 0, st>>>(n3, m, idx, weight, off, cnt, ent_q, ent_w);
-    const int spb = 256 / (c / 4);
-    dim3 gg((m + spb - 1) / spb, b);
-    ti_csr_gather_kernel<<<gg, 256, 0, st>>>(n, c, m, grad_out, off, ent_q, ent_w, grad_points);
-    PN2_RETURN_IF_LAUNCH_FAILED();
-    return PN2_OK;
+    return pn2_scatter_rows_gather(b, 3 * n, 3, c, m, grad_out, idx, weight, grad_points, workspace, stream);
 }
 
 extern "C" int pn2_fp_interp_concat(int b, int n, int m, int c1, int c2, const float* dist,

@@ -92,9 +92,11 @@ class _GroupPoint(torch.autograd.Function):
         grad_out = grad_out.contiguous()
         b, m, ns, c = grad_out.shape
         gp = torch.empty((b, ctx.n, c), dtype=torch.float32, device=grad_out.device)
+        nbytes = lib.pn2_group_point_grad_workspace_bytes(b, ctx.n, m, ns)
+        ws = torch.empty(nbytes // 4, dtype=torch.int32, device=grad_out.device)
         with torch.cuda.device(grad_out.device):
-            check(lib.pn2_group_point_grad(b, ctx.n, c, m, ns, ptr(grad_out), ptr(idx), ptr(gp), stream_ptr()),
-                  "pn2_group_point_grad")
+            check(lib.pn2_group_point_grad_ws(b, ctx.n, c, m, ns, ptr(grad_out), ptr(idx), ptr(gp), ptr(ws), nbytes,
+                                              stream_ptr()), "pn2_group_point_grad_ws")
         return gp, None
 
 

@@ -34,7 +34,8 @@ def test_library_exports_every_declared_symbol(pn2):
 def test_python_signatures_cover_the_header(pn2):
     decl = set(_declared()) - {"pn2_abi_version", "pn2_build_info", "pn2_strerror",
                                "pn2_interpolate_label_workspace_bytes", "pn2_fps_large_workspace_bytes",
-                               "pn2_bn_workspace_bytes", "pn2_three_interpolate_grad_workspace_bytes"}  # bound separately: size_t
+                               "pn2_bn_workspace_bytes", "pn2_three_interpolate_grad_workspace_bytes",
+                               "pn2_group_point_grad_workspace_bytes"}  # bound separately: size_t
     assert decl <= set(pn2._lib.SIGNATURES) | {"pn2_sa_group_concat"}
     assert pn2._lib.lib.pn2_interpolate_label_workspace_bytes(1000) > 2 * (1 << 21) * 4  # two cell tables + lists
 

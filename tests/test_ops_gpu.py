@@ -329,6 +329,34 @@ def test_three_interpolate_bit_exact_and_grad(pn2, oracle, cuda, c):
     assert np.allclose(pt.grad.cpu().numpy(), ref, rtol=1e-4, atol=1e-5)
 
 
+@pytest.mark.parametrize("c,n", [(32, 2048), (128, 700), (64, 5), (260, 333)])
+def test_group_point_grad_gather_path(pn2, oracle, cuda, c, n):
+    """Levels large enough for the list-and-gather gradient (pn2_group_point_grad_ws): points nobody groups (zero
+    rows), a hot point that pads many balls, every neighbour of a ball the same point."""
+    import torch
+    b, m, ns = 4, 512, 16
+    rs = np.random.RandomState(c + n)
+    idx = rs.randint(0, n, (b, m, ns)).astype(np.int32)
+    idx[idx == 3 % n] = 0                      # point 3 never grouped (when n > 3)
+    idx[:, ::5, ns // 2:] = 1 % n              # hot point: pads the second half of every fifth ball
+    idx[:, 7, :] = 2 % n                       # a ball made of one point
+    pts = rs.randn(b, n, c).astype(np.float32)
+    go = rs.randn(b, m, ns, c).astype(np.float32)
+    pt = T(pts, cuda).requires_grad_(True)
+    pn2._lib.lib.trace = calls = []
+    try:
+        out = pn2.group_point(pt, T(idx, cuda))
+        out.backward(T(go, cuda))
+    finally:
+        pn2._lib.lib.trace = None
+    assert "pn2_group_point_grad_ws" in [t[0] for t in calls]
+    ref = oracle.group_point_grad(pts, idx, go)
+    got = pt.grad.cpu().numpy()
+    assert np.allclose(got, ref, rtol=1e-4, atol=1e-4 * max(1.0, np.abs(ref).max() * 1e-2))
+    if n > 3:
+        assert not got[:, 3].any()
+
+
 @pytest.mark.parametrize("c,m", [(32, 300), (128, 1024), (36, 77), (512, 64), (1024, 5)])
 def test_three_interpolate_grad_gather_path(pn2, oracle, cuda, c, m):
     """Levels large enough for the list-and-gather gradient (pn2_three_interpolate_grad_ws): sources nobody references
