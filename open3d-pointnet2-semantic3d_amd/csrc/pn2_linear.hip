@@ -258,8 +258,14 @@ int launch_linear(int rows, int cin, int cout, const float* x, const float* w, c
     constexpr int BM = 32 * WM, BN = 32 * NT * WN;
     dim3 grid((rows + BM - 1) / BM, cout / BN);
     const bool vec_a = (cin % 4 == 0) && ((uintptr_t)x % 16 == 0);
-    if (vec_a) linear_kernel<WM, WN, NT, true, WK, ST><<<grid, 256, 0, st>>>(rows, cin, cout, x, w, bias, relu, pool, y);
-    else linear_kernel<WM, WN, NT, false, WK, ST><<<grid, 256, 0, st>>>(rows, cin, cout, x, w, bias, relu, pool, y);
+    if constexpr (WM == 4 && NT == 4) {
+        // the 128x128 tile exists with 16-byte A loads only (the scalar-load variant spills its accumulators)
+        if (!vec_a) return launch_linear<2, 2, 2, 1, ST>(rows, cin, cout, x, w, bias, relu, pool, y, st);
+        linear_kernel<WM, WN, NT, true, WK, ST><<<grid, 256, 0, st>>>(rows, cin, cout, x, w, bias, relu, pool, y);
+    } else {
+        if (vec_a) linear_kernel<WM, WN, NT, true, WK, ST><<<grid, 256, 0, st>>>(rows, cin, cout, x, w, bias, relu, pool, y);
+        else linear_kernel<WM, WN, NT, false, WK, ST><<<grid, 256, 0, st>>>(rows, cin, cout, x, w, bias, relu, pool, y);
+    }
     PN2_RETURN_IF_LAUNCH_FAILED();
     return PN2_OK;
 }
@@ -442,9 +448,12 @@ extern "C" int pn2_linear(int rows, int cin, int cout, const float* x, const flo
         return PN2_LIN(1, 2, 1, 2);
     }
     if (cout % 128 == 0) {
-        // largest tile that still yields >= 2 blocks per CU; small problems get 32-row blocks
+        // largest tile that still yields >= 2 blocks per CU; small problems get 32-row blocks.  The 128-row tile is
+        // only built for 16-byte A loads: with scalar A loads (cin % 4 != 0 or unaligned x) its accumulators spill
+        // to scratch (1.7 ms instead of 55 us at 131072 x 134 -> 128), so those shapes take the 64-row tile.
         const long long cb = cout / 128;
-        if (((rows + 127) / 128) * cb >= 512) return PN2_LIN(4, 1, 4, 1);
+        const bool vec_a = (cin % 4 == 0) && ((uintptr_t)x % 16 == 0);
+        if (((rows + 127) / 128) * cb >= 512 && vec_a) return PN2_LIN(4, 1, 4, 1);
         if (((rows + 63) / 64) * cb >= 512) return PN2_LIN(2, 2, 2, 1);
         if (((rows + 31) / 32) * cb >= 256 || cin < 128) return PN2_LIN(1, 4, 1, 1);
         return PN2_LIN(1, 2, 1, 2);  // few rows: 32x64 tiles, split-K in the block

@@ -71,6 +71,29 @@ def test_linear_vs_fp64(pn2, cuda, rows, cin, cout, relu):
     close(y, ref)
 
 
+@pytest.mark.parametrize("rows,cin,cout", [(70000, 134, 128), (66000, 67, 256), (131072, 131, 128)])
+def test_linear_large_rows_scalar_a_loads(pn2, cuda, rows, cin, cout):
+    """Many rows with cin % 4 != 0 (the reference's [xyz | features] widths 67 / 131 / 134): the 128-row tile has no
+    scalar-load variant (its accumulators spilled to scratch: 1.7 ms instead of 55 us), so these shapes must take the
+    64-row tile -- numerics against float64 and a loose guard on the time."""
+    import torch
+    rs = np.random.RandomState(rows % 1000 + cin)
+    x = rs.randn(rows, cin).astype(np.float32)
+    w = (rs.randn(cin, cout) / np.sqrt(cin)).astype(np.float32)
+    b = rs.randn(cout).astype(np.float32)
+    tx, tw, tb = T(x, cuda), T(w, cuda), T(b, cuda)
+    y = pn2.util.tf_util.hip_linear(tx, tw, tb, relu=1)
+    close(y.cpu().numpy(), np.maximum(x.astype(np.float64) @ w.astype(np.float64) + b, 0))
+    torch.cuda.synchronize()
+    s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    s.record()
+    for _ in range(5):
+        pn2.util.tf_util.hip_linear(tx, tw, tb, relu=1)
+    e.record()
+    torch.cuda.synchronize()
+    assert s.elapsed_time(e) / 5 < 0.6, "pn2_linear %.3f ms per call: a spilling tile configuration?" % (s.elapsed_time(e) / 5)
+
+
 def test_linear_layout_is_transpose_detecting(pn2, cuda):
     """A = identity-like, asymmetric W: catches swapped row/col or k-slice mix-ups exactly."""
     cin = cout = 64
