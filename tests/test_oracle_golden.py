@@ -199,3 +199,23 @@ def test_batch_norm_train_oracle_matches_torch_autograd(oracle, relu):
     assert np.allclose(dy, ty.grad.numpy(), rtol=1e-9, atol=1e-10)
     assert np.allclose(dgamma, tg.grad.numpy(), rtol=1e-9, atol=1e-10)
     assert np.allclose(dbeta, tb.grad.numpy(), rtol=1e-9, atol=1e-10)
+
+
+def test_max_pool_rows_oracle_matches_torch_amax(oracle):
+    """oracle.max_pool_rows(_grad) (tf.reduce_max over K, pointnet_util.py:167-170, gradient shared among tied rows)
+    against torch.amax and its autograd, with exact ties (duplicated rows, the ReLU floor)."""
+    import torch
+    rs = np.random.RandomState(3)
+    z = np.maximum(rs.randn(6, 8, 5), 0.0)      # (groups, pool, c); ReLU floor ties
+    z[1, 4:, :] = z[1, :1, :]                   # duplicated neighbours
+    z[2] = 0.0                                   # a group that never passes the ReLU
+    dzp = rs.randn(6, 5)
+    zmax, ties = oracle.max_pool_rows(z.reshape(48, 5), 8)
+    tz = torch.tensor(z, requires_grad=True)
+    tm = tz.amax(dim=1)
+    assert np.array_equal(zmax, tm.detach().numpy())
+    assert np.array_equal(ties, (z == z.max(axis=1, keepdims=True)).sum(axis=1))
+    assert ties[2].min() == 8 and ties[1].max() >= 5
+    (tm * torch.tensor(dzp)).sum().backward()
+    g = oracle.max_pool_rows_grad(z.reshape(48, 5), 8, dzp)
+    assert np.allclose(g.reshape(6, 8, 5), tz.grad.numpy(), rtol=1e-12, atol=1e-12)
