@@ -207,7 +207,8 @@ def test_max_pool_rows_oracle_matches_torch_amax(oracle):
     import torch
     rs = np.random.RandomState(3)
     z = np.maximum(rs.randn(6, 8, 5), 0.0)      # (groups, pool, c); ReLU floor ties
-    z[1, 4:, :] = z[1, :1, :]                   # duplicated neighbours
+    z[1, 0, :] = 10.0
+    z[1, 4:, :] = z[1, :1, :]                   # duplicated neighbours: the maximum is attained five times
     z[2] = 0.0                                   # a group that never passes the ReLU
     dzp = rs.randn(6, 5)
     zmax, ties = oracle.max_pool_rows(z.reshape(48, 5), 8)
