@@ -2,9 +2,11 @@
 // data-parallel training path (reference: util/tf_util.py:555-581 batch_norm_template -> tf.contrib.layers.batch_norm,
 // applied after every conv2d / conv1d of the SA / FP stack, tf_util.py:186-204, followed by tf.nn.relu).
 //
-// Layout: y (rows, c) row-major ("channels last"), the same buffer pn2_linear / the GEMM wrote.  All four kernels are
+// Layout: y (rows, c) row-major ("channels last"), the same buffer pn2_linear / the GEMM wrote.  All kernels are
 // HBM streams: the forward reads y twice (statistics, then normalise) and writes z once; the backward reads (dz, y)
-// twice and writes dy once.  Per-channel sums are carried in fp64 (full-rate on CDNA4, the kernels are memory-bound
+// twice and writes dy once.  With pool > 1 the SA layer's max over the K rows of a neighbourhood
+// (pointnet_util.py:167-170) rides along: the forward writes only the pooled maxima + tie counts, the backward reads
+// the pooled gradient.  Per-channel sums are carried in fp64 (full-rate on CDNA4, the kernels are memory-bound
 // anyway) so that var = E[y^2] - E[y]^2 has no cancellation problem at fp32 accuracy.  Partial sums of a block meet in
 // LDS and leave with one fp64 atomic per channel -- but atomics on ONE address retire serially (~0.1 us each, measured:
 // 2048 blocks on 2*c addresses cost 190 us), so the blocks spread over up to kBnSlots copies of the accumulators (<= 32
