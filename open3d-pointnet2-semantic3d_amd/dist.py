@@ -74,20 +74,25 @@ class FlatGradAllReduce:
 
     @torch.no_grad()
     def allreduce_(self):
+        """Pack every .grad into the flat bucket (ONE multi-tensor copy, not a launch per parameter), all-reduce, and
+        leave each p.grad as a view of the bucket: the optimizer reads the averaged gradient in place, no copy back.
+        (The next backward allocates fresh .grad tensors after zero_grad(set_to_none=True), or accumulates straight
+        into the views after zero_grad(set_to_none=False).)"""
         world = dist.get_world_size() if (dist.is_available() and dist.is_initialized()) else 1
+        src, dst = [], []
         for p, v in zip(self.params, self.views):
             if p.grad is None:
                 v.zero_()
-            else:
-                v.copy_(p.grad)
+            elif p.grad.data_ptr() != v.data_ptr():
+                src.append(p.grad)
+                dst.append(v)
+        if dst:
+            torch._foreach_copy_(dst, src)
         if world > 1:
             dist.all_reduce(self.flat, op=dist.ReduceOp.SUM)
             self.flat.div_(world)
         for p, v in zip(self.params, self.views):
-            if p.grad is None:
-                p.grad = v.clone()
-            else:
-                p.grad.copy_(v)
+            p.grad = v
         return self.flat
 
 

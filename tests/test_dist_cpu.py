@@ -90,3 +90,29 @@ def test_training_schedules_match_reference_constants():
     assert t.bn_decay(0, 16) == 0.5
     assert abs(t.bn_decay(12500, 16) - 0.75) < 1e-12
     assert t.bn_decay(10 ** 7, 16) == 0.99
+
+
+def test_flat_bucket_aliases_grads_and_survives_both_zero_grad_modes():
+    """FlatGradAllReduce (single process): after allreduce_ every p.grad is a view of the bucket (no copy back); a
+    backward after zero_grad(set_to_none=True) packs fresh gradients, one after set_to_none=False accumulates straight
+    into the views; a parameter without a gradient contributes zeros."""
+    import pn2_amd as pn2
+    torch.manual_seed(0)
+    w1, w2, unused = (torch.nn.Parameter(torch.randn(*s)) for s in ((4, 3), (3,), (2, 2)))
+    params = [w1, w2, unused]
+    bucket = pn2.dist.FlatGradAllReduce(params)
+    opt = torch.optim.SGD(params, lr=0.1)
+    x = torch.randn(5, 4)
+    for set_to_none in (True, False, True):
+        opt.zero_grad(set_to_none=set_to_none)
+        ((x @ w1 + w2) ** 2).sum().backward()
+        ref1, ref2 = w1.grad.clone(), w2.grad.clone()
+        flat = bucket.allreduce_()
+        assert flat.numel() == 12 + 3 + 4
+        for p, v in zip(params, bucket.views):
+            assert p.grad.data_ptr() == v.data_ptr()
+        assert torch.equal(w1.grad, ref1) and torch.equal(w2.grad, ref2) and not unused.grad.any()
+        assert torch.equal(flat[:12].view(4, 3), ref1) and torch.equal(flat[12:15], ref2)
+        before = w1.detach().clone()
+        opt.step()
+        assert torch.allclose(w1.detach(), before - 0.1 * ref1)
