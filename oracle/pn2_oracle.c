@@ -73,6 +73,19 @@ static inline float sqdist_mode(float x1, float y1, float z1, float x2, float y2
         float t = dx * dx;
         float u = fmaf(dy, dy, t);
         return fmaf(dz, dz, u);
+    } else if (mode >= 3 && mode <= 8) {
+        /* Partially contracted forms fma(p,p,q*q) + r*r, (p,q,r) a permutation of (dx,dy,dz).
+         * Not an nvcc hypothesis: this is what amdgpu LLVM's SLP vectoriser makes of the
+         * reference expression under -ffp-contract=fast (two squares in one v_pk_mul_f32, the
+         * third fused, the last add left alone -- oracle/_ref/libpn2_ref_fast.so).  Exists only so
+         * that EVERY oracle/_ref build is reproduced bit-for-bit by the restatement. */
+        static const int perm[6][3] = {{0, 1, 2}, {0, 2, 1}, {1, 0, 2}, {1, 2, 0}, {2, 0, 1}, {2, 1, 0}};
+        float dd[3] = {dx, dy, dz};
+        const int *pm = perm[mode - 3];
+        volatile float q2 = dd[pm[1]] * dd[pm[1]];
+        volatile float r2 = dd[pm[2]] * dd[pm[2]];
+        volatile float f = fmaf(dd[pm[0]], dd[pm[0]], q2);
+        return f + r2;
     } else {
         volatile float a = dx * dx;
         volatile float b = dy * dy;
