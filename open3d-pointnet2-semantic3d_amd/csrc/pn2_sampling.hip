@@ -95,23 +95,47 @@ __device__ __forceinline__ uint2 fps_wave_candidate(float best, int bestk) {
     return make_uint2((unsigned)wmax, fps_tiekey(kw));
 }
 
-// NT threads, thread t owns points k = t + NT*i (i < PPT) in VGPRs for the whole kernel.
-// Requires NT % 512 == 0 (all points of a thread share the residue t mod 512, scanned in ascending
-// k) or PPT == 1 (k == t).  A round:
-//   1. distance update (fp32 sub/mul/fma: 2-cycle VALU pipe) + integer min / max3 (4-cycle pipe);
-//   2. wave max of the VALUE by fused DPP; only the lanes holding that value (normally one) look
-//      up which of their points it was and publish the 64-bit key
-//          (dist bits << 32) | ~((k & 511) << 22 | k >> 9)
-//      with ONE LDS atomic max -- the LDS unit resolves the reference tie-break
-//      (max dist, then k mod 512, then k) across lanes and waves;
-//   3. one barrier, one broadcast read of the key, one broadcast read of the winner's xyz.
-// Three key slots rotate so the reset of a slot never races with its readers.
+__device__ __forceinline__ float wave_fmin_all(float v) {
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) v = fminf(v, __shfl_xor(v, o));
+    return v;
+}
+__device__ __forceinline__ float wave_fmax_all(float v) {
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) v = fmaxf(v, __shfl_xor(v, o));
+    return v;
+}
+__device__ __forceinline__ unsigned wave_umin_all(unsigned v) {
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) { const unsigned t = (unsigned)__shfl_xor((int)v, o); v = t < v ? t : v; }
+    return v;
+}
+
+constexpr int kFpsBias = 0x00100000;  // keeps the high word of a (td, key) pair out of the fp64 denormal range; bits(1e38f) + bias < 0x7FF00000
+__device__ __forceinline__ double fps_dmax(double a, double b) {  // exact 64-bit max of two positive normal patterns (no canonicalisation inserted)
+    double r;
+    asm("v_max_f64 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+
+// NT threads, thread t owns points k = t + NT*i (i < PPT) in VGPRs for the whole kernel: coordinates and ONE 64-bit
+// register pair per point,
+//          (td bits : ~tiekey(k))        td = running min distance (>= +0: int order == float order),
+// read as a double.  For these bit patterns v_max_f64 is an exact 64-bit max, i.e. exactly the reference's order
+// (max td, then lowest k mod 512, then lowest k; tf_sampling.cu:153-170): the tie-break key rides through every
+// max, there is no "which of my points was it" search in the round and no constraint on the thread layout.
+// A round:
+//   1. distance update (fp32 sub/mul/fma: 2-cycle VALU pipe) + v_min_i32 on the high words, v_max_f64 tree;
+//   2. wave max of the high word by fused DPP; the lanes holding it (normally one) publish their pair with ONE
+//      LDS atomic max (ds_max_u64) -- the LDS unit merges lanes and waves;
+//   3. one barrier, one broadcast read of the winning pair, one broadcast read of the winner's xyz.
+// Three key slots rotate so the reset of a slot never races with its readers.  A single-wave block (NT == 64)
+// needs neither LDS atomics nor barriers: ballot + v_readlane.
 template <int NT, int PPT, int MODE, bool LDS_XYZ>
 __global__ void __launch_bounds__(NT)
 fps_reg_kernel(int n, int m, const float* __restrict__ xyz_all, int* __restrict__ out_all,
                float* __restrict__ new_xyz_all) {
-    static_assert(NT % 512 == 0 || PPT == 1, "tie-break argument needs NT % 512 == 0 or one point per thread");
-    static_assert(NT != 64 || PPT == 1, "single-wave path keeps one point per lane");
+    static_assert(NT != 64 || LDS_XYZ, "single-wave path keeps the cloud in LDS");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     // layout: 4 x u64 key slots (3 used) | float4 xyz[n] (if LDS_XYZ) | int picks[m] (if LDS_XYZ)
     // The picks are kept in LDS and written to HBM once, coalesced, after the last round (together
@@ -129,20 +153,22 @@ fps_reg_kernel(int n, int m, const float* __restrict__ xyz_all, int* __restrict_
     float* __restrict__ nxyz = new_xyz_all ? new_xyz_all + (size_t)blockIdx.x * m * 3 : nullptr;
 
     float px[PPT], py[PPT], pz[PPT];
-    int md[PPT];  // running min distance as int bits (>= 0), or bits(-1.0f) for "no point"
+    double mk[PPT];
 #pragma unroll
     for (int i = 0; i < PPT; ++i) {
         const int k = tid + NT * i;
+        int hi;
         if (k < n) {
             px[i] = xyz[k * 3 + 0];
             py[i] = xyz[k * 3 + 1];
             pz[i] = xyz[k * 3 + 2];
-            md[i] = __float_as_int(1e38f);  // tf_sampling.cu:124-126
+            hi = __float_as_int(1e38f);  // tf_sampling.cu:124-126
             if constexpr (LDS_XYZ) sxyz[k] = make_float4(px[i], py[i], pz[i], 0.f);
         } else {
             px[i] = py[i] = pz[i] = 0.f;
-            md[i] = __float_as_int(-1.0f);  // never selected: stays below every real distance
+            hi = __float_as_int(-1.0f);  // never selected: a negative double, below every real pair
         }
+        mk[i] = __hiloint2double(hi, (int)~fps_tiekey(k));
     }
     if (tid < 4) slots[tid] = 0ull;
     if (tid == 0) {  // first pick is index 0 (tf_sampling.cu:122-123)
@@ -150,53 +176,49 @@ fps_reg_kernel(int n, int m, const float* __restrict__ xyz_all, int* __restrict_
     }
     __syncthreads();
 
-    // tiekey(tid + NT*i) = keybase + i * (NT >> 9)   (NT % 512 == 0; PPT == 1 otherwise)
-    const unsigned keybase = fps_tiekey(tid);
     int old = 0;
     int slot = 1;  // j % 3
-    float nx1 = xyz[0], ny1 = xyz[1], nz1 = xyz[2];  // NT == 64 path: coordinates of the current pick
     for (int j = 1; j < m; ++j) {
         float x1, y1, z1;
-        if constexpr (NT == 64) {
-            x1 = nx1; y1 = ny1; z1 = nz1;
-        } else if constexpr (LDS_XYZ) {
+        if constexpr (LDS_XYZ) {
             const float4 p = sxyz[old];
             x1 = p.x; y1 = p.y; z1 = p.z;
         } else {
             x1 = xyz[old * 3 + 0]; y1 = xyz[old * 3 + 1]; z1 = xyz[old * 3 + 2];
-        }
-        if constexpr (!LDS_XYZ) {
             if (nxyz && tid == 0) { nxyz[(j - 1) * 3 + 0] = x1; nxyz[(j - 1) * 3 + 1] = y1; nxyz[(j - 1) * 3 + 2] = z1; }
         }
-        int best = __float_as_int(-1.0f);
 #pragma unroll
         for (int i = 0; i < PPT; ++i) {
             const float d = pn2_sqdist<MODE>(px[i] - x1, py[i] - y1, pz[i] - z1);
-            const int di = __float_as_int(d);   // d >= +0: int order == float order
-            md[i] = di < md[i] ? di : md[i];    // min(d, td) :151
-            best = md[i] > best ? md[i] : best;
+            const int di = __float_as_int(d), oh = __double2hiint(mk[i]);  // d >= +0: int order == float order
+            mk[i] = __hiloint2double(di < oh ? di : oh, __double2loint(mk[i]));  // min(d, td) :151 on the high word
         }
+        double tr[PPT];
+#pragma unroll
+        for (int i = 0; i < PPT; ++i) tr[i] = mk[i];
+#pragma unroll
+        for (int w = PPT; w > 1; w = (w + 1) / 2) {
+#pragma unroll
+            for (int g = 0; g < w / 2; ++g) tr[g] = fps_dmax(tr[g], tr[w - 1 - g]);
+        }
+        const int best = __double2hiint(tr[0]);
         const int wmax = wave_imax(best);
         if constexpr (NT == 64) {
-            // one wave, one point per lane: winner = lowest lane holding the max; its coordinates are
-            // fetched with v_readlane -- no LDS, no barrier in the round
-            const int src = __ffsll((long long)__ballot(best == wmax)) - 1;
-            old = src;
-            nx1 = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(px[0]), src));
-            ny1 = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(py[0]), src));
-            nz1 = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(pz[0]), src));
-            if (tid == 0) { if constexpr (LDS_XYZ) spick[j] = old; else out[j] = old; }
+            // one wave: the winner is resolved with a ballot (equal td across lanes: lowest tie key = largest low
+            // word); no LDS atomic, no barrier in the round
+            const unsigned long long bal = __ballot(best == wmax);
+            const unsigned lo = (unsigned)__double2loint(tr[0]);
+            unsigned wl;
+            if (__popcll(bal) == 1) wl = (unsigned)__builtin_amdgcn_readlane((int)lo, __ffsll((long long)bal) - 1);
+            else wl = ~wave_umin_all(best == wmax ? ~lo : 0xFFFFFFFFu);
+            old = fps_untiekey(~wl);
+            if (tid == 0) spick[j] = old;
             continue;
         }
         if (best == wmax && wmax >= 0) {  // normally a single lane of the wave
-            int istar = 0;
-#pragma unroll
-            for (int i = PPT - 1; i >= 0; --i)
-                if (md[i] == best) istar = i;  // first (lowest-k) maximal point of this thread
-            const unsigned key = keybase + (unsigned)istar * (unsigned)(NT >> 9);
             // one ds_max_u64 per winning lane (normally exactly one per wave); written as asm so the
             // compiler's uniform-address atomic optimiser does not wrap it in a per-lane scalar loop
-            const unsigned long long comp = ((unsigned long long)(unsigned)wmax << 32) | (unsigned)(~key);
+            const unsigned long long comp = (unsigned long long)__double_as_longlong(tr[0]);
             const unsigned saddr = (unsigned)(size_t)(&slots[slot]);  // LDS byte address (low 32 bits of the generic pointer)
             asm volatile("ds_max_u64 %0, %1\n s_waitcnt lgkmcnt(0)" : : "v"(saddr), "v"(comp) : "memory");
         }
@@ -224,6 +246,8 @@ fps_reg_kernel(int n, int m, const float* __restrict__ xyz_all, int* __restrict_
         nxyz[(m - 1) * 3 + 0] = xyz[old * 3 + 0]; nxyz[(m - 1) * 3 + 1] = xyz[old * 3 + 1]; nxyz[(m - 1) * 3 + 2] = xyz[old * 3 + 2];
     }
 }
+
+int g_fps_variant = 0;  // tuning hook (pn2_debug_set(0, v)), see dispatch_fps
 
 // Generic fallback for n > PN2_FPS_MAX_REG_POINTS: running min in the caller's
 // `temp` rows (one row per resident block, like tf_sampling.cu:124), points
@@ -283,27 +307,35 @@ int launch_fps_reg(int b, int n, int m, const float* inp, int* out, float* nxyz,
             attr_bytes = 160 * 1024;
         }
         kern<<<b, NT, slots_bytes + xyz_bytes + pick_bytes, st>>>(n, m, inp, out, nxyz);
-    } else {
+    } else if constexpr (NT != 64) {
         fps_reg_kernel<NT, PPT, MODE, false><<<b, NT, slots_bytes, st>>>(n, m, inp, out, nxyz);
+    } else {
+        return PN2_ERANGE;  // unreachable: a single-wave cloud (n <= 256) always fits LDS unless m is absurd
     }
     PN2_RETURN_IF_LAUNCH_FAILED();
     return PN2_OK;
 }
 
-int g_fps_variant = 0;  // tuning hook (pn2_debug_set(0, v)): 0 = default, 512 = 512-thread blocks for n in (1024, 8192]
-
 template <int MODE>
 int dispatch_fps(int b, int n, int m, const float* inp, float* temp, int* out, float* nxyz, hipStream_t st) {
-    // NT % 512 == 0, or one point per thread (see fps_reg_kernel).
-    if (n <= 64) return launch_fps_reg<64, 1, MODE>(b, n, m, inp, out, nxyz, st);
-    if (n <= 128) return launch_fps_reg<128, 1, MODE>(b, n, m, inp, out, nxyz, st);
-    if (n <= 256) return launch_fps_reg<256, 1, MODE>(b, n, m, inp, out, nxyz, st);
-    if (n <= 512) return launch_fps_reg<512, 1, MODE>(b, n, m, inp, out, nxyz, st);
-    if (n <= 1024) return launch_fps_reg<1024, 1, MODE>(b, n, m, inp, out, nxyz, st);
-    if (g_fps_variant == 512) {
+    // Any (threads, points per thread) layout is exact (every point carries its own tie-break key); the choice is
+    // latency only.  A round's sync skeleton costs ~40 ns for one wave (no barrier, no LDS atomic), ~130 ns for 4
+    // waves and ~180 ns for 16 (tools/round_ubench.hip), a lone wave issues ~0.45 instructions/ns, 4 waves per SIMD ~1/ns.
+    // Measured (B=16, ns per round; profiles/r02_fps_experiments.txt): n=256 <64,4> 255 vs <256,1> 316; n=1024 <512,2> 327
+    // vs <1024,1> 355; n=2048 <512,4> 360 vs <1024,2> 391; n=4096 <1024,4> 440 vs <512,8> 451; n=8192 <1024,8> 617.
+    if (g_fps_variant == 1) {  // A/B hook: one point per thread up to 1024 threads (the round-1 layout)
+        if (n <= 64) return launch_fps_reg<64, 1, MODE>(b, n, m, inp, out, nxyz, st);
+        if (n <= 128) return launch_fps_reg<128, 1, MODE>(b, n, m, inp, out, nxyz, st);
+        if (n <= 256) return launch_fps_reg<256, 1, MODE>(b, n, m, inp, out, nxyz, st);
+        if (n <= 512) return launch_fps_reg<512, 1, MODE>(b, n, m, inp, out, nxyz, st);
+        if (n <= 1024) return launch_fps_reg<1024, 1, MODE>(b, n, m, inp, out, nxyz, st);
+    } else {
+        if (n <= 64) return launch_fps_reg<64, 1, MODE>(b, n, m, inp, out, nxyz, st);
+        if (n <= 128) return launch_fps_reg<64, 2, MODE>(b, n, m, inp, out, nxyz, st);
+        if (n <= 256) return launch_fps_reg<64, 4, MODE>(b, n, m, inp, out, nxyz, st);
+        if (n <= 512) return launch_fps_reg<256, 2, MODE>(b, n, m, inp, out, nxyz, st);
+        if (n <= 1024) return launch_fps_reg<512, 2, MODE>(b, n, m, inp, out, nxyz, st);
         if (n <= 2048) return launch_fps_reg<512, 4, MODE>(b, n, m, inp, out, nxyz, st);
-        if (n <= 4096) return launch_fps_reg<512, 8, MODE>(b, n, m, inp, out, nxyz, st);
-        if (n <= 8192) return launch_fps_reg<512, 16, MODE>(b, n, m, inp, out, nxyz, st);
     }
     if (n <= 2048) return launch_fps_reg<1024, 2, MODE>(b, n, m, inp, out, nxyz, st);
     if (n <= 4096) return launch_fps_reg<1024, 4, MODE>(b, n, m, inp, out, nxyz, st);
