@@ -333,9 +333,9 @@ def test_ssg_stack_small_vs_oracle(pn2, oracle, cuda):
     assert out.shape == (2, 2048, 128)
     got = out.cpu().numpy()
     err = np.abs(got - ref)
-    # end-to-end through 8 modules: intermediate fp32 features feed later layers, so allow 5x the
-    # single-kernel tolerance here; every individual kernel is held to 1e-5 above
-    assert (err <= 5e-5 + 5e-5 * np.abs(ref)).all(), err.max()
+    # compounded error of 8 chained modules, still inside north_star's 1e-5 (full size: test_fullsize_gpu.py)
+    print("small stack end-to-end err %.2e" % (err / (1 + np.abs(ref))).max())
+    assert (err <= 1e-5 + 1e-5 * np.abs(ref)).all(), err.max()
 
 
 def test_get_model_head_shapes(pn2, cuda):
