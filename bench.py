@@ -13,10 +13,23 @@ N > 1 is launched by torch.distributed.run, one process per GPU; the path shards
 dimension with no data-path collective (every rank runs its own 16 scenes: weak scaling); the timed
 region is bracketed by barrier + synchronize and the max over ranks is taken.
 
-Prints ONE JSON line (rank 0).  Besides the contract keys it carries
-  roofline      dominant kernel (largest share of the step's GPU time): algorithmic bytes|flops per
-                launch / its average duration measured with HIP events on the launch stream
-  kernels       the same accounting for every kernel of the step
+Prints ONE JSON line (rank 0).  `value` / `ms_per_step` are the THROUGHPUT regime: `config.batches_in_flight`
+(default 4) independent B=16 batches in flight, each its own hipGraph on its own stream -- a step is still one
+full batch through the whole stack.  The LATENCY regime (one batch in flight, what the reference's benchmark.py
+times) is reported next to it under `regimes`.  Besides the contract keys the line carries
+  regimes       {"throughput": {...}, "latency": {...}}: ms per step and points/s of both regimes, each timed
+                over the same K steps with barrier + synchronize on both sides
+  roofline      the limiter OF THE TIMED (throughput) REGIME: with several batches in flight the latency-bound FPS
+                chains (16 CUs each) hide behind the other batches' dense work and the step is the sum of the
+                chip-filling kernels, which are MFMA work: `roofline` = the dominant one of them (largest share of
+                that sum; algorithmic flops per launch / its HIP-event duration), `roofline.aggregate` = all MFMA
+                flops of a step / ms_per_step.  `traffic` is null: no counter pass runs inside bench.py (the PMC
+                passes are separate rocprofv3 runs, profiles/).
+  latency_limiter  the limiter of the latency regime: FPS, reported in its own units (ns per dependent round,
+                distance evaluations/s, share of the single-batch latency) instead of an HBM fraction
+  kernels       per-kernel accounting (algorithmic bytes|flops, HIP-event duration) for every kernel of the step
+  other_configs driver-timed lines for BASELINE configs[2] (MSG module), configs[4] (large scene, bf16) and
+                configs[3] at one GPU (training step)
   north_star    the two kernel-level targets of BASELINE.json measured at their own shape
                 (ball_query+group_point and the fused grouped MLP at B=16,N=8192,M=1024,K=32,C=128)
   cpu_baseline  the CPU oracle (oracle/, OpenMP C + numpy fp32) on the same workload, rank 0, N=1
@@ -129,24 +142,6 @@ def summarize_trace(trace, steps):
     return rows
 
 
-def pmc_traffic(kernel):
-    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes
-    (profiles/r01_pmc_hbm_traffic.json, produced by tools/pmc_mfma.sh on the same workload); None if absent."""
-    path = os.path.join(ROOT, "profiles", "r01_pmc_hbm_traffic.json")
-    names = {"farthest_point_sample": ("fps_reg_kernel<1024, 8,", "grid=16384"),
-             "fps_gather": ("fps_reg_kernel<1024, 8,", "grid=16384")}
-    if kernel not in names or not os.path.exists(path):
-        return None
-    try:
-        data = json.load(open(path))["kernels"]
-        for k, v in data.items():
-            if all(t in k for t in names[kernel]):
-                return v["traffic_bytes"]
-    except Exception:
-        return None
-    return None
-
-
 def time_call(fn, iters, warmup=3):
     for _ in range(warmup):
         fn()
@@ -203,6 +198,79 @@ def north_star_kernels(pn2, dev):
     out["fused_grouped_mlp"] = {"shape": "B16 N8192 M1024 K32 Cin131 Cout128 + max", "us": round(t_mlp * 1e3, 1),
                                 "flops": flops, "bound": "mfma", "achieved": round(ach, 2), "peak": MFMA_F32_PEAK_TF,
                                 "unit": "TFLOP/s", "frac": round(ach / MFMA_F32_PEAK_TF, 4)}
+    return out
+
+
+def other_configs(pn2, dev, hp, steps):
+    """configs[2], configs[4] and configs[3]@1GPU timed in the same run (graph replay where the path is captured)."""
+    out = {}
+    tfu, pu = pn2.util.tf_util, pn2.util.pointnet_util
+    keep = tfu.get_default_store()
+    try:
+        # configs[2]: MSG set abstraction, 3 scales (radii / K / MLPs are builder-chosen: the reference ships none)
+        B, N, M = 16, 8192, 1024
+        radii, ks, mlps = [0.25, 0.5, 1.0], [16, 32, 64], [[32, 32, 64], [64, 64, 128], [64, 96, 128]]
+        pc = torch.from_numpy(s_scene(5000, B, N)).to(dev)
+        xyz, pts = pc[:, :, :3].contiguous(), pc[:, :, 3:].contiguous()
+        tfu.set_default_store(tfu.VariableStore(device=dev, seed=1))
+        cap = pn2.runtime.CapturedForward(
+            lambda x: pu.pointnet_sa_module_msg(x, pts, M, radii, ks, mlps, False, None, scope="msg")[1], xyz)
+        t = time_call(cap.replay, steps)
+        out["configs[2]"] = {"workload": "MSG SA module, 3 scales r=(0.25,0.5,1.0) K=(16,32,64) "
+                                         "MLPs ([32,32,64],[64,64,128],[64,96,128]) (builder-chosen), B=16, N=8192, npoint=1024, fp32",
+                             "ms_per_step": round(t, 4), "points_per_s": round(B * N / (t * 1e-3), 1), "steps": steps,
+                             "launch": "one hipGraph replay per step, one batch in flight"}
+        del cap
+        # configs[4]: one large scene, N=65536 -> npoint 4096, K=64, C=128 bf16 features, fused bf16 grouped MLP
+        N4, M4, K4, C4 = 65536, 4096, 64, 128
+        xyz4 = torch.from_numpy(s_scene(5001, 1, N4)[:, :, :3].copy()).to(dev)
+        pts4 = torch.randn(1, N4, C4, device=dev).to(torch.bfloat16)
+        tfu.set_default_store(tfu.VariableStore(device=dev, seed=2))
+
+        def sa4(x):
+            _, nx = pn2.tf_ops.tf_sampling.farthest_point_sample_and_gather(M4, x)
+            idx, _ = pn2.query_ball_point(0.5, K4, x, nx)
+            with tfu.variable_scope("sa"):
+                return pu.sa_features_inference(x, nx, pts4, idx, [128, 128])
+        with torch.no_grad():
+            sa4(xyz4)
+            n4 = max(2, min(steps, 5))
+            t = time_call(lambda: sa4(xyz4), n4, warmup=1)
+            t_fps = time_call(lambda: pn2.tf_ops.tf_sampling.farthest_point_sample_and_gather(M4, xyz4), n4, warmup=1)
+        out["configs[4]"] = {"workload": "large-scene SA layer: B=1, N=65536, npoint=4096, K=64, C=128 bf16 features, "
+                                         "FPS + ball query + fused bf16 grouped MLP [128,128] + max",
+                             "ms_per_step": round(t, 4), "points_per_s": round(N4 / (t * 1e-3), 1), "steps": n4,
+                             "fps_ms": round(t_fps, 4), "launch": "eager"}
+        del xyz4, pts4
+    except Exception as ex:  # keep the headline line alive
+        out["error"] = repr(ex)
+    finally:
+        tfu.set_default_store(keep)
+    try:
+        # configs[3] on this one GPU: a full training step (forward with batch-stat BN, weighted CE, backward, Adam)
+        B, N = hp["batch_size"], hp["num_point"]
+        rs = np.random.RandomState(100)
+        pc = torch.from_numpy(np.concatenate([s_scene(3000, B, N)[:, :, :3], rs.random_sample((B, N, 3)).astype(np.float32)], 2)).to(dev)
+        labels = torch.from_numpy(rs.randint(0, 9, (B, N)).astype(np.int64)).to(dev)
+        smpw = torch.from_numpy((rs.random_sample((B, N)) + 0.5).astype(np.float32)).to(dev)
+        tr = pn2.train.Trainer(hp, 9, store=tfu.VariableStore(device=dev, seed=0), device=dev)
+        for _ in range(3):
+            tr.train_step(pc, labels, smpw)
+        torch.cuda.synchronize()
+        n3 = max(2, min(steps, 10))
+        t0 = time.perf_counter()
+        for _ in range(n3):
+            loss = tr.train_step(pc, labels, smpw)
+        torch.cuda.synchronize()
+        t = (time.perf_counter() - t0) / n3 * 1e3
+        out["configs[3]@1gpu"] = {"workload": "training step (forward with batch-stat BN + weighted CE + backward + Adam), "
+                                              "%d scenes x %d points, fp32; the multi-GPU line is `bench.py --train --gpus N`" % (B, N),
+                                  "ms_per_step": round(t, 4), "points_per_s": round(B * N / (t * 1e-3), 1), "steps": n3,
+                                  "last_loss": loss}
+    except Exception as ex:
+        out["configs[3]@1gpu"] = {"error": repr(ex)}
+    finally:
+        tfu.set_default_store(keep)
     return out
 
 
@@ -302,6 +370,7 @@ def main():
                          "profiles/r01_stream_queue_sweep.txt)")
     ap.add_argument("--pipeline", type=int, default=4, help="independent batches in flight (graphs replayed round-robin)")
     ap.add_argument("--no-north-star", action="store_true")
+    ap.add_argument("--no-other-configs", action="store_true", help="skip the configs[2] / [3]@1gpu / [4] sub-results")
     ap.add_argument("--debug-set", action="append", default=[], metavar="WHAT=VALUE",
                     help="tuning hook: pn2_debug_set(what, value) before the run (A/B experiments)")
     ap.add_argument("--dup", action="append", default=[], metavar="ENTRY",
@@ -401,15 +470,21 @@ def main():
     elapsed = pn2.dist.max_over_ranks(elapsed, device=dev)  # the slowest rank defines the step time
     assert torch.isfinite(out).all()
 
-    # ---- latency of ONE batch (graph replay, nothing else in flight) -----------------------------
+    # ---- latency regime: ONE batch in flight (what the reference's benchmark.py times), same K steps, bracketed the
+    #      same way: replay -> synchronize per step
     latency_ms = None
     if not args.eager:
         torch.cuda.synchronize()
+        if dist_on:
+            dist.barrier()
         t1 = time.perf_counter()
-        for _ in range(10):
+        for _ in range(args.steps):
             caps[0].replay()
             torch.cuda.synchronize()
-        latency_ms = (time.perf_counter() - t1) / 10 * 1e3
+        lat = time.perf_counter() - t1
+        if dist_on:
+            dist.barrier()
+        latency_ms = pn2.dist.max_over_ranks(lat, device=dev) / args.steps * 1e3
 
     # ---- instrumented pass: same steps, every launch bracketed by HIP events on its stream ----
     trace_steps = min(args.steps, 10)
@@ -423,12 +498,26 @@ def main():
     if rank == 0:
         total_points = world * B * N * args.steps
         ms_per_step = elapsed / args.steps * 1e3
-        dom = kernels[0]
+        P_eff = 1 if args.eager else max(1, args.pipeline)
+        is_fps = lambda k: k["kernel"] in ("farthest_point_sample", "fps_gather")  # noqa: E731
+        dense = [k for k in kernels if not is_fps(k)]
+        fps = [k for k in kernels if is_fps(k)]
+        sum_all = sum(k["ms_per_step"] for k in kernels)
+        sum_dense = sum(k["ms_per_step"] for k in dense)
+        mfma = [k for k in kernels if k["bound"] == "mfma"]
+        flops_step = sum(k["algorithmic_units"] * k["launches_per_step"] for k in mfma)
+        # the timed regime decides which kernel set bounds the step: with >1 batch in flight the FPS chains (16 CUs
+        # each) hide behind the other batches, the step is the serial sum of the chip-filling kernels
+        timed = dense if P_eff > 1 else kernels
+        dom = max(timed, key=lambda k: k["ms_per_step"])
+        agg_tf = flops_step / (ms_per_step * 1e-3) / 1e12
         res = {
             "metric": "points/sec through SA+FP stack (B=16,N=8192)",
             "value": round(total_points / elapsed, 1), "unit": "points/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4), "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "value_regime": "throughput: %d independent B=%d batches in flight per GPU (see regimes.latency for one batch "
+                            "in flight)" % (P_eff, B) if P_eff > 1 else "latency: one batch in flight",
             "config": {"workload": "configs[1]: full SSG PointNet++ SA x4 + FP x4 (semantic.json), inference forward, "
                                    "B=%d scenes x N=%d points xyz+rgb per GPU, fp32, S-scene synthetic input, "
                                    "random-init weights" % (B, N),
@@ -436,30 +525,50 @@ def main():
                        "arith_mode": int(pn2.config.arith_mode),
                        "launch": "eager python launches" if args.eager else "one hipGraph replay per step",
                        "streams_per_batch": 2 if (args.two_streams and not args.eager) else 1,
-                       "batches_in_flight": 1 if args.eager else max(1, args.pipeline),
+                       "batches_in_flight": P_eff,
                        "fp_front": "fused" if fused_fp else "materialised"},
-            "roofline": {"kernel": dom["kernel"], "args": dom["args"], "bound": dom["bound"],
+            "regimes": {
+                "throughput": {"batches_in_flight": P_eff, "ms_per_step": round(ms_per_step, 4),
+                               "points_per_s": round(total_points / elapsed, 1)},
+                "latency": None if latency_ms is None else {
+                    "batches_in_flight": 1, "ms_per_step": round(latency_ms, 4),
+                    "points_per_s": round(world * B * N / (latency_ms * 1e-3), 1),
+                    "note": "replay + synchronize per step: what the reference's benchmark.py times"}},
+            "roofline": {"regime": "throughput" if P_eff > 1 else "latency",
+                         "kernel": dom["kernel"], "args": dom["args"], "bound": dom["bound"],
                          "achieved": dom["achieved"], "peak": dom["peak"], "unit": dom["unit"], "frac": dom["frac"],
-                         "traffic": pmc_traffic(dom["kernel"]) if (B, N) == (16, 8192) else None,
-                         "algorithmic_bytes": dom["algorithmic_units"], "avg_us": dom["avg_us"],
-                         "share_of_step": round(dom["ms_per_step"] / max(1e-9, sum(k["ms_per_step"] for k in kernels)), 3),
-                         "note": ("farthest point sampling is a chain of M-1 dependent argmax rounds: bounded by "
-                                  "LDS/barrier latency, not by HBM or MFMA; its HBM fraction is reported as measured"
-                                  if dom["kernel"] in ("farthest_point_sample", "fps_gather") else "")},
+                         "traffic": None, "algorithmic_units": dom["algorithmic_units"], "avg_us": dom["avg_us"],
+                         "ms_per_step": dom["ms_per_step"],
+                         "share_of_timed_kernels": round(dom["ms_per_step"] / max(1e-9, sum(k["ms_per_step"] for k in timed)), 3),
+                         "aggregate": {"what": "all MFMA flops of one step / ms_per_step of the timed regime",
+                                       "flops_per_step": int(flops_step), "achieved": round(agg_tf, 2),
+                                       "peak": MFMA_F32_PEAK_TF, "unit": "TFLOP/s", "frac": round(agg_tf / MFMA_F32_PEAK_TF, 4)},
+                         "kernel_time_sums_ms": {"all": round(sum_all, 4), "without_fps": round(sum_dense, 4),
+                                                 "fps": round(sum_all - sum_dense, 4)}},
             "kernels": kernels,
             "single_batch_latency_ms": None if latency_ms is None else round(latency_ms, 4),
-            "gpu_ms_per_step_sum_of_kernels": round(sum(k["ms_per_step"] for k in kernels), 4),
+            "gpu_ms_per_step_sum_of_kernels": round(sum_all, 4),
         }
-        if dom["kernel"] in ("farthest_point_sample", "fps_gather"):
-            # FPS is reported by its own work unit as well -- dependent rounds and distance evaluations
-            fb, fn, fm = dom["args"][:3]
-            res["roofline"]["ns_per_round"] = round(dom["avg_us"] * 1e3 / max(1, fm - 1), 1)
-            res["roofline"]["distance_evals_per_s"] = round(fb * (fm - 1) * fn / (dom["avg_us"] * 1e-6), 1)
+        if fps:
+            f0 = max(fps, key=lambda k: k["ms_per_step"])
+            fb, fn, fm = f0["args"][:3]
+            res["latency_limiter"] = {
+                "kernel": f0["kernel"], "args": f0["args"], "avg_us": f0["avg_us"],
+                "bound": "latency: m-1 dependent rounds on one CU per scene (neither HBM nor MFMA)",
+                "ns_per_round": round(f0["avg_us"] * 1e3 / max(1, fm - 1), 1),
+                "distance_evals_per_s": round(fb * (fm - 1) * fn / (f0["avg_us"] * 1e-6), 1),
+                "fps_chain_ms": round(sum_all - sum_dense, 4),
+                "share_of_single_batch_latency": None if latency_ms is None else round((sum_all - sum_dense) / latency_ms, 3),
+                "hbm_frac": f0["frac"],
+                "note": "a round is a dependent chain (LDS read -> distance -> max tree -> 6 DPP steps -> LDS atomic -> "
+                        "barrier -> read) of ~250-330 ns whatever the block shape (profiles/r02_fps_experiments.txt)"}
         if not args.no_north_star:
             try:
                 res["north_star"] = north_star_kernels(pn2, dev)
             except Exception as ex:  # keep the headline line alive
                 res["north_star"] = {"error": repr(ex)}
+        if world == 1 and not args.no_other_configs:
+            res["other_configs"] = other_configs(pn2, dev, hp, args.steps)
         if world == 1 and not args.no_cpu_baseline:
             try:
                 res["cpu_baseline"] = cpu_baseline(pn2, store, pc_np, hp)

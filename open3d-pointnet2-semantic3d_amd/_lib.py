@@ -66,18 +66,19 @@ class Pn2Error(RuntimeError):
 
 
 def _load():
-    if not os.path.exists(LIB_PATH):
-        # build in-tree with hipcc (cross-compiles without a GPU); never fall back to CPU code.
-        # One process per GPU may import concurrently (torch.distributed.run): serialise the build with a file lock.
-        import fcntl
-        from . import build as _build
-        with open(os.path.join(_HERE, ".build.lock"), "w") as lock:
-            fcntl.flock(lock, fcntl.LOCK_EX)
-            try:
-                if not os.path.exists(LIB_PATH):
-                    _build.build()
-            finally:
-                fcntl.flock(lock, fcntl.LOCK_UN)
+    # Build in-tree with hipcc when the library is missing OR older than its sources (cross-compiles without a GPU);
+    # never fall back to CPU code.  One process per GPU may import concurrently (torch.distributed.run): the check
+    # and the build run under a file lock, and build.py links to a temporary file that is renamed into place, so no
+    # rank can dlopen a half-written library.
+    import fcntl
+    from . import build as _build
+    with open(os.path.join(_HERE, ".build.lock"), "w") as lock:
+        fcntl.flock(lock, fcntl.LOCK_EX)
+        try:
+            if _build._stale():
+                _build.build()
+        finally:
+            fcntl.flock(lock, fcntl.LOCK_UN)
     try:
         lib = ctypes.CDLL(LIB_PATH)
     except OSError as e:  # pragma: no cover
@@ -109,6 +110,10 @@ def _load():
 _raw = _load()
 
 
+# entry points that mutate caller state beyond their outputs (moving averages): never launched twice by the dup hook
+_STATEFUL = frozenset({"pn2_bn_relu_forward"})
+
+
 class _LibProxy:
     """Attribute proxy over the ctypes library.  When `trace` is a list, every pn2_* launch is
     bracketed by two events on torch's current stream (the stream the kernel is launched on) and
@@ -126,8 +131,8 @@ class _LibProxy:
             return fn
 
         def call(*args):
-            if name in self.dup:
-                fn(*args)  # every op is a pure function of its inputs: the second launch rewrites the same values
+            if name in self.dup and name not in _STATEFUL:
+                fn(*args)  # a pure function of its inputs: the second launch rewrites the same values
             if self.trace is None:
                 return fn(*args)
             s = torch.cuda.Event(enable_timing=True)

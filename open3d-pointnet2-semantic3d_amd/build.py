@@ -31,7 +31,7 @@ def _stale():
     if not os.path.exists(LIB):
         return True
     t = os.path.getmtime(LIB)
-    deps = [os.path.join(CSRC, f) for f in os.listdir(CSRC)] + [
+    deps = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".hip", ".h"))] + [
         os.path.join(HERE, "..", "include", "pn2_abi.h"), os.path.abspath(__file__)]
     return any(os.path.getmtime(d) > t for d in deps)
 
@@ -62,8 +62,10 @@ def build(force=False, verbose=False, extra_flags=(), out=None):
             print(out.decode(errors="replace"))
     if failed:
         raise RuntimeError("libpn2_hip.so build failed")
-    cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", target] + objs
+    tmp = target + ".tmp%d" % os.getpid()
+    cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", tmp] + objs
     subprocess.check_call(cmd)
+    os.replace(tmp, target)  # atomic: a concurrent importer sees the old or the new library, never a partial one
     return target
 
 

@@ -136,9 +136,9 @@ def get_model(point_cloud, is_training, num_class, hyperparams, bn_decay=None):
     return net, end_points
 
 
-def get_loss(pred, label, smpw):
+def get_loss(pred, label, smpw, end_points=None):
     """Weighted sparse softmax cross-entropy, tf.losses reduction SUM_BY_NONZERO_WEIGHTS
-    (model.py:152-161): sum(w * ce) / count(w != 0)."""
+    (model.py:152-161): sum(w * ce) / count(w != 0).  `end_points` is accepted and unused, as in the reference."""
     import torch
     import torch.nn.functional as F
     ce = F.cross_entropy(pred.reshape(-1, pred.shape[-1]), label.reshape(-1).long(), reduction="none")

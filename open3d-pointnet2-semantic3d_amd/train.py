@@ -33,8 +33,17 @@ class Trainer:
         self.bucket = None
 
     def _lazy_init(self, pc):
-        # variables are created by the first forward (TF-style get_variable semantics)
-        model.get_model(pc, True, self.num_class, self.hp, bn_decay=bn_decay(0, pc.shape[0]))
+        # variables are created by the first forward (TF-style get_variable semantics).  That forward must leave no
+        # trace: no autograd graph, and the moving averages restored (the reference applies ONE update per step,
+        # train.py:381-388; the HIP BN kernel updates them through raw pointers even under no_grad).
+        with torch.no_grad():
+            before = {k: v.clone() for k, v in self.store.buffers.items()}  # a pre-loaded store keeps its statistics
+            model.get_model(pc[:1], True, self.num_class, self.hp, bn_decay=bn_decay(0, pc.shape[0]))
+            for k, v in self.store.buffers.items():
+                if k in before:
+                    v.copy_(before[k])
+                else:
+                    v.fill_(0.0 if k.endswith("moving_mean") else 1.0)  # tf_util.py:571-581 initial moving averages
         params = self.store.parameters()
         pdist.broadcast_parameters(params)
         pdist.broadcast_parameters(list(self.store.buffers.values()))

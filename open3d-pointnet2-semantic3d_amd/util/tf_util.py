@@ -35,6 +35,8 @@ class VariableStore:
         self._gen = torch.Generator(device="cpu")
         self._gen.manual_seed(seed)
         self._folded = {}
+        self.train_epoch = 0  # bumped by every training-mode layer call: the HIP BN kernel updates the moving averages
+                              # through raw pointers (no autograd version bump), so folded inference weights key on it too
 
     def get_variable(self, name, shape, init):
         if name not in self.params:
@@ -79,7 +81,7 @@ class VariableStore:
 
     # folded inference weights, cached on the version counters of their sources
     def folded(self, key, sources, make):
-        stamp = tuple((id(t), t._version) for t in sources)
+        stamp = (self.train_epoch,) + tuple((id(t), t._version) for t in sources)
         hit = self._folded.get(key)
         if hit is None or hit[0] != stamp:
             with torch.no_grad():
@@ -383,6 +385,7 @@ def conv2d(inputs, num_output_channels, kernel_size, scope, stride=(1, 1), paddi
                 lead[-1] //= pool
             return y.reshape(lead + [cout])
         st, w, b, bnv = _dense_variables(cin, cout, bn, (1, 1, cin, cout))
+        st.train_epoch += 1
         return _train_layer(inputs, w.reshape(cin, cout), b, bnv, bn_decay, activation_fn is not None, pool)
 
 
@@ -401,6 +404,7 @@ def conv1d(inputs, num_output_channels, kernel_size, scope, stride=1, padding="S
                 y = y[:, :cout].contiguous()
             return y.reshape(list(inputs.shape[:-1]) + [cout])
         st, w, b, bnv = _dense_variables(cin, cout, bn, (1, cin, cout))
+        st.train_epoch += 1
         y = _train_layer(inputs, w.reshape(cin, cout), b, bnv, bn_decay, activation_fn is not None)
         return y
 

@@ -14,7 +14,7 @@ def test_bench_json_contract():
     env = dict(os.environ)
     env.pop("RANK", None); env.pop("WORLD_SIZE", None); env.pop("LOCAL_RANK", None)
     out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "4", "--warmup", "2",
-                          "--batch", "4", "--points", "2048", "--no-north-star"],
+                          "--batch", "4", "--points", "2048", "--no-north-star", "--no-other-configs"],
                          cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
     assert out.returncode == 0, out.stderr[-2000:]
     lines = [l for l in out.stdout.splitlines() if l.strip()]
@@ -32,3 +32,10 @@ def test_bench_json_contract():
     for k in ("value", "unit", "cores", "kind", "sample"):
         assert k in r["cpu_baseline"], k
     assert r["cpu_baseline"]["kind"] == "port" and r["cpu_baseline"]["value"] > 0
+    # both regimes are on the line and `value` says which one it is; the roofline block describes the timed regime:
+    # its kernel's time per step cannot exceed the step
+    assert r["regimes"]["throughput"]["ms_per_step"] == r["ms_per_step"] and r["value_regime"].startswith("throughput")
+    assert r["regimes"]["latency"]["batches_in_flight"] == 1 and r["regimes"]["latency"]["ms_per_step"] >= r["ms_per_step"]
+    assert r["roofline"]["regime"] == "throughput" and r["roofline"]["ms_per_step"] <= r["ms_per_step"]
+    assert r["roofline"]["kernel"] not in ("farthest_point_sample", "fps_gather")
+    assert r["latency_limiter"]["kernel"] in ("farthest_point_sample", "fps_gather") and r["latency_limiter"]["ns_per_round"] > 0
