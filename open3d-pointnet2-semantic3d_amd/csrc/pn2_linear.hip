@@ -270,6 +270,173 @@ int launch_linear(int rows, int cin, int cout, const float* x, const float* w, c
     return PN2_OK;
 }
 
+// ---- few-row layers (SA3/SA4/FP1-FP3: 1024 .. 16384 rows onto 256 .. 512 columns) --------------------------------------
+// linear_kernel's smallest tile (32 x 128 per workgroup, one 32x32 accumulator per wave, k-tiles of 32 staged through
+// LDS behind two barriers) leaves a 1024-row layer on 64 of the 256 CUs and spends more time in barriers and LDS
+// round trips than in its 16 MFMAs per k-tile (measured 8-35 % of the MFMA peak on these layers).  Here one workgroup
+// owns a (32*TM) x (32*TN) output tile and its 4 waves split the CONTRACTION: wave w takes k in [w*K/4, (w+1)*K/4) and
+// feeds v_mfma_f32_32x32x2_f32 straight from global memory (the operands of a few-row layer live in L2):
+//   A: lane (row = l&31, half = l>>5) loads 4 consecutive k of its row with one 16-byte load  (k = k0 + 4*half + q),
+//   B: lane (col = l&31, half)        loads w[k0 + 4*half + q][col] for q = 0..3 (128-byte segments per half-wave);
+// step q of a group contracts exactly those two k -- the MFMA only needs A and B to agree on the k of each half, so
+// this permuted visiting order is exact.  No LDS, no barrier in the loop; G groups of loads stay in flight under the
+// MFMAs of the previous ones.  The four partial tiles are added in LDS in a fixed order (deterministic), then the
+// usual bias / ReLU / max-over-32-rows epilogue.  rows/32/TM x cout/32/TN workgroups: 256 for the 1024-row layers.
+template <int TM, int TN, bool VEC_A, int G>
+__global__ void __launch_bounds__(256)
+linear_splitk_kernel(int rows, int cin, int cout, const float* __restrict__ x, const float* __restrict__ w,
+                     const float* __restrict__ bias, int relu, int pool, float* __restrict__ y) {
+    // G = groups of 8 k in flight per wave (a group's MFMAs take ~0.1 us, an L2 round trip ~0.7 us)
+    __shared__ float red[3 * TM * TN * 16 * 64];
+    const int lane = threadIdx.x & 63, half = lane >> 5, l31 = lane & 31;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int row0 = blockIdx.x * (32 * TM), col0 = blockIdx.y * (32 * TN);
+    // this wave's share of the contraction, in groups of 8 k
+    const int ngroups = (cin + 7) / 8;
+    const int g0 = (ngroups * wave) / 4, g1 = (ngroups * (wave + 1)) / 4;
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int a = 0; a < TM; ++a)
+#pragma unroll
+        for (int b = 0; b < TN; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+
+    const float* __restrict__ xr[TM];
+    bool rok[TM];
+#pragma unroll
+    for (int a = 0; a < TM; ++a) {
+        const int r = row0 + a * 32 + l31;
+        rok[a] = r < rows;
+        xr[a] = x + (size_t)(rok[a] ? r : rows - 1) * cin;
+    }
+    const float* __restrict__ wc = w + col0 + l31;
+
+    f32x4 av[G][TM];
+    float bv[G][4][TN];
+    auto fetch = [&](int g, f32x4 (&a_)[TM], float (&b_)[4][TN]) {
+        // unconditional clamped loads (counted vmcnt), out-of-range k zeroed on the A side only (B stays finite data)
+        const int k = g * 8 + 4 * half;
+#pragma unroll
+        for (int a = 0; a < TM; ++a) {
+            f32x4 v;
+            if constexpr (VEC_A) {
+                const int kc = k + 4 <= cin ? k : cin - 4;
+                v = *reinterpret_cast<const f32x4*>(xr[a] + kc);
+                if (!(k + 4 <= cin && rok[a])) v = f32x4{0.f, 0.f, 0.f, 0.f};  // VEC_A: cin % 4 == 0, so a group of 4 is all in or all out
+            } else {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int kq = k + q < cin ? k + q : cin - 1;
+                    const float e = xr[a][kq];
+                    v[q] = (k + q < cin && rok[a]) ? e : 0.f;
+                }
+            }
+            a_[a] = v;
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int kq = k + q < cin ? k + q : cin - 1;
+#pragma unroll
+            for (int b = 0; b < TN; ++b) b_[q][b] = wc[(size_t)kq * cout + b * 32];
+        }
+    };
+    auto contract = [&](const f32x4 (&a_)[TM], const float (&b_)[4][TN]) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+#pragma unroll
+            for (int a = 0; a < TM; ++a)
+#pragma unroll
+                for (int b = 0; b < TN; ++b)
+                    acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_[a][q], b_[q][b], acc[a][b], 0, 0, 0);
+    };
+    if (g0 < g1) {
+        const int last = g1 - 1;
+#pragma unroll
+        for (int u = 0; u < G; ++u) fetch(g0 + u < g1 ? g0 + u : last, av[u], bv[u]);
+        int g = g0;
+        for (; g + G <= g1; g += G) {
+#pragma unroll
+            for (int u = 0; u < G; ++u) {
+                f32x4 ca[TM];
+                float cb[4][TN];
+#pragma unroll
+                for (int a = 0; a < TM; ++a) ca[a] = av[u][a];
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+#pragma unroll
+                    for (int b = 0; b < TN; ++b) cb[q][b] = bv[u][q][b];
+                fetch(g + G + u < g1 ? g + G + u : last, av[u], bv[u]);
+                contract(ca, cb);
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < G - 1; ++u)
+            if (g + u < g1) contract(av[u], bv[u]);
+    }
+    // fixed-order reduction of the four partial tiles: waves 1..3 park theirs in LDS, wave 0 adds them 1, 2, 3
+    if (wave > 0) {
+        float* dst = red + (size_t)(wave - 1) * (TM * TN * 16 * 64);
+#pragma unroll
+        for (int a = 0; a < TM; ++a)
+#pragma unroll
+            for (int b = 0; b < TN; ++b)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) dst[((a * TN + b) * 16 + r) * 64 + lane] = acc[a][b][r];
+    }
+    __syncthreads();
+    if (wave > 0) return;
+#pragma unroll
+    for (int wv = 0; wv < 3; ++wv) {
+        const float* src = red + (size_t)wv * (TM * TN * 16 * 64);
+#pragma unroll
+        for (int a = 0; a < TM; ++a)
+#pragma unroll
+            for (int b = 0; b < TN; ++b)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[a][b][r] += src[((a * TN + b) * 16 + r) * 64 + lane];
+    }
+    // epilogue: D[i][j], j = l31, i = (r&3) + 8*(r>>2) + 4*half
+#pragma unroll
+    for (int a = 0; a < TM; ++a) {
+        const int wrow0 = row0 + a * 32;
+#pragma unroll
+        for (int b = 0; b < TN; ++b) {
+            const int col = col0 + b * 32 + l31;
+            const float bb = bias ? bias[col] : 0.f;
+            if (pool <= 1) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int row = wrow0 + (r & 3) + 8 * (r >> 2) + 4 * half;
+                    float v = acc[a][b][r] + bb;
+                    if (relu) v = fmaxf(v, 0.f);
+                    if (row < rows) y[(size_t)row * cout + col] = v;
+                }
+            } else {  // pool == 32: the tile's 32 rows are one neighbourhood
+                float v = acc[a][b][0];
+#pragma unroll
+                for (int r = 1; r < 16; ++r) v = fmaxf(v, acc[a][b][r]);
+                v = fmaxf(v, __shfl_xor(v, 32));
+                v += bb;  // max_i relu(x_i + b) == relu(max_i(x_i) + b)
+                if (relu) v = fmaxf(v, 0.f);
+                if (half == 0 && wrow0 < rows) y[(size_t)(wrow0 / 32) * cout + col] = v;
+            }
+        }
+    }
+}
+
+template <int TM, int TN, int G = 2>
+int launch_linear_splitk(int rows, int cin, int cout, const float* x, const float* w, const float* bias, int relu,
+                         int pool, float* y, hipStream_t st) {
+    dim3 grid((rows + 32 * TM - 1) / (32 * TM), cout / (32 * TN));
+    const bool vec_a = (cin % 4 == 0) && ((uintptr_t)x % 16 == 0);
+    if (vec_a) linear_splitk_kernel<TM, TN, true, G><<<grid, 256, 0, st>>>(rows, cin, cout, x, w, bias, relu, pool, y);
+    else linear_splitk_kernel<TM, TN, false, G><<<grid, 256, 0, st>>>(rows, cin, cout, x, w, bias, relu, pool, y);
+    PN2_RETURN_IF_LAUNCH_FAILED();
+    return PN2_OK;
+}
+
 // Weight gradient of a dense layer (training): dW (cin, cout) = x^T (cin, rows) . dy (rows, cout), the reduction over
 // ALL rows (524288 for SA1) that hipBLASLt runs at ~10 % of the memory roofline on these tall-skinny shapes.  One
 // wave owns a (32*TM x 32*TN) tile of dW for a chunk of rows and streams x and dy straight from HBM into the MFMA
@@ -441,7 +608,18 @@ extern "C" int pn2_linear(int rows, int cin, int cout, const float* x, const flo
      : st_depth == 3 ? launch_linear<WM_, WN_, NT_, WK_, 3>(rows, cin, cout, x, w, bias, relu, pool, y, st)    \
                      : launch_linear<WM_, WN_, NT_, WK_, 2>(rows, cin, cout, x, w, bias, relu, pool, y, st))
     const int st_depth = g_lin_stages;
-    if (cout % 128 == 0 && g_lin_cfg != 0) {  // tuning hook: force a tile configuration
+    if (g_lin_cfg >= 5 && (pool <= 1 || pool == 32)) {  // tuning hook: split-K direct-feed tiles
+        if (g_lin_cfg == 5) return launch_linear_splitk<1, 1, 2>(rows, cin, cout, x, w, bias, relu, pool, y, st);
+        if (g_lin_cfg == 6) return launch_linear_splitk<1, 1, 4>(rows, cin, cout, x, w, bias, relu, pool, y, st);
+        if (g_lin_cfg == 7) return launch_linear_splitk<1, 1, 8>(rows, cin, cout, x, w, bias, relu, pool, y, st);
+        if (g_lin_cfg == 8 && cout % 64 == 0) return launch_linear_splitk<1, 2, 4>(rows, cin, cout, x, w, bias, relu, pool, y, st);
+    }
+    // few rows (FP1: 1024): one 32x32 tile per workgroup with the contraction split over its 4 waves fills the chip
+    // where the LDS-tiled kernel leaves 3/4 of the CUs idle: 1024x768->256 15.3 -> 9.7 us, 1024x256->256 7.6 -> 6.0 us;
+    // from 4096 rows on the LDS-tiled kernel wins (operand re-reads from L2) -- profiles/r02_linear_splitk.txt
+    if (g_lin_cfg == 0 && rows <= 2048 && (pool <= 1 || pool == 32))
+        return launch_linear_splitk<1, 1, 2>(rows, cin, cout, x, w, bias, relu, pool, y, st);
+    if (cout % 128 == 0 && g_lin_cfg != 0 && g_lin_cfg < 5) {  // tuning hook: force a tile configuration
         if (g_lin_cfg == 1) return PN2_LIN(4, 1, 4, 1);
         if (g_lin_cfg == 2) return PN2_LIN(2, 2, 2, 1);
         if (g_lin_cfg == 3) return PN2_LIN(1, 4, 1, 1);

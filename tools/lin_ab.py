@@ -16,7 +16,7 @@ for (rows, cin, cout, pool) in shapes:
     y = torch.empty(rows // pool if pool else rows, cout, device=dev)
     row = ["(%d,%d,%d,p%d)" % (rows, cin, cout, pool)]
     ref = None
-    for depth in (0, 1, 2, 3, 4):
+    for depth in (0, 1, 2, 3, 4, 5, 6, 7, 8):
         raw.pn2_debug_set(8, depth)
         f = lambda: raw.pn2_linear(rows, cin, cout, P(x), P(w), P(b), 1, pool, P(y), st)
         assert f() == 0
