@@ -298,6 +298,44 @@ int pn2_interpolate_label_with_color(int num_sparse_points, int num_dense_points
                                      uint8_t *dense_colors, int knn, void *workspace,
                                      size_t workspace_bytes, void *stream);
 
+/* sample_and_group's tail for layers too wide for the fused kernel (util/pointnet_util.py:39-54: group_point(xyz) -
+ * tile(new_xyz), group_point(points), concat [xyz | points]) in one pass: out (b,m,nsample,3+c) with
+ * out[..., :3] = xyz[idx] - new_xyz and out[..., 3:] = points[idx] (c may be 0, then points may be NULL). */
+int pn2_sa_group_concat(int b, int n, int m, int nsample, int c, const float *xyz, const float *new_xyz,
+                        const float *points, const int *idx, float *out, void *stream);
+
+/* ---- the step before the path: scene sampler + voxel down-sampling ---------------- */
+
+/* SemanticFileData._extract_z_box  dataset/semantic_dataset.py:123-163, for b centre points at once.
+ * points (n,3) float64 sorted by x (as __init__ leaves them, :84-88); centers (b,3) float64; half_x/half_y =
+ * box_size/2; scene_z_size = max z - min z of the scene (:132).  out_idx (b,cap) = scene indices of every column in
+ * scene order, out_cnt (b) = their number (may exceed cap: then only the first cap indices were written). */
+int pn2_scene_extract_z_box(int n, const double *points, int b, const double *centers, double half_x,
+                            double half_y, double scene_z_size, int cap, int *out_idx, int *out_cnt,
+                            void *stream);
+
+/* _get_fix_sized_sample_mask + gathers + _center_box  semantic_dataset.py:90-121,165-186.  The reference's random
+ * draw enters as `mask` (b,cap) bytes: for a column with cnt > npts its first cnt bytes are the shuffled boolean
+ * sample mask (exactly npts non-zero); columns with cnt <= npts repeat their indices (i mod cnt) and ignore it.
+ * labels (n) int32 / colors (n,3) float64 may be NULL (zeros out).  Outputs: out_sel (b,npts) scene indices,
+ * out_centered (b,npts,3) float32 = float64 (p - shift) cast, out_raw (b,npts,3) float64, out_labels (b,npts),
+ * out_colors (b,npts,3) float32 (the last three optional).  status (b): 0 ok, 1 empty column, 2 cnt > cap,
+ * 3 mask does not select exactly npts points. */
+int pn2_scene_sample(int b, int npts, int cap, const double *points, const int *labels, const double *colors,
+                     const int *idx, const int *cnt, const unsigned char *mask, double half_x, double half_y,
+                     int *out_sel, float *out_centered, double *out_raw, int *out_labels, float *out_colors,
+                     int *status, void *stream);
+
+/* down_sample  downsample.py:46-67: Open3D (IntelVCL/Open3D @33e46f7) voxel_down_sample_and_trace with
+ * min_bound = min(points) - voxel_size/2 + np.bincount(labels).argmax() per voxel.  points/colors (n,3) float64,
+ * labels (n) int32 in [0,64) or NULL.  Outputs sized for n voxels; *out_count (device) = number of voxels, sorted by
+ * (ix,iy,iz) (Open3D's own order is unspecified).  status (device): 0 ok, 1 voxel index needs more than 21 bits,
+ * 2 label outside [0,64).  workspace: 256-byte aligned, pn2_voxel_downsample_workspace_bytes(n) bytes. */
+size_t pn2_voxel_downsample_workspace_bytes(int n);
+int pn2_voxel_downsample(int n, const double *points, const double *colors, const int *labels, double voxel_size,
+                         double *out_points, double *out_colors, int *out_labels, int *out_count, int *status,
+                         void *workspace, size_t workspace_bytes, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -4,7 +4,7 @@ libpn2_hip.so; there is no CPU fallback."""
 from . import config  # noqa: F401
 from . import _lib  # noqa: F401  (fails loudly if the HIP extension is missing)
 from . import tf_ops, util  # noqa: F401
-from . import model, runtime, dist, train  # noqa: F401
+from . import model, runtime, dist, train, dataset, downsample  # noqa: F401
 from .tf_ops.tf_sampling import farthest_point_sample, gather_point, prob_sample  # noqa: F401
 from .tf_ops.tf_grouping import query_ball_point, group_point, knn_point, select_top_k  # noqa: F401
 from .tf_ops.tf_interpolate import three_nn, three_interpolate, interpolate_label_with_color  # noqa: F401

@@ -57,6 +57,12 @@ SIGNATURES = {
                                          ctypes.c_size_t, c_void_p],
     "pn2_sa_group_concat": [c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p,
                             c_void_p, c_void_p],
+    "pn2_scene_extract_z_box": [c_int, c_void_p, c_int, c_void_p, ctypes.c_double, ctypes.c_double, ctypes.c_double, c_int,
+                                c_void_p, c_void_p, c_void_p],
+    "pn2_scene_sample": [c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, ctypes.c_double,
+                         ctypes.c_double, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p],
+    "pn2_voxel_downsample": [c_int, c_void_p, c_void_p, c_void_p, ctypes.c_double, c_void_p, c_void_p, c_void_p, c_void_p,
+                             c_void_p, c_void_p, ctypes.c_size_t, c_void_p],
 }
 PN2_EUNSUP = -4
 
@@ -96,6 +102,8 @@ def _load():
     lib.pn2_three_interpolate_grad_workspace_bytes.restype = ctypes.c_size_t
     lib.pn2_group_point_grad_workspace_bytes.argtypes = [c_int, c_int, c_int, c_int]
     lib.pn2_group_point_grad_workspace_bytes.restype = ctypes.c_size_t
+    lib.pn2_voxel_downsample_workspace_bytes.argtypes = [c_int]
+    lib.pn2_voxel_downsample_workspace_bytes.restype = ctypes.c_size_t
     lib.pn2_bn_workspace_bytes.argtypes = [c_int]
     lib.pn2_bn_workspace_bytes.restype = ctypes.c_size_t
     lib.pn2_abi_version.restype = c_int

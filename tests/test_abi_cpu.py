@@ -35,8 +35,10 @@ def test_python_signatures_cover_the_header(pn2):
     decl = set(_declared()) - {"pn2_abi_version", "pn2_build_info", "pn2_strerror",
                                "pn2_interpolate_label_workspace_bytes", "pn2_fps_large_workspace_bytes",
                                "pn2_bn_workspace_bytes", "pn2_three_interpolate_grad_workspace_bytes",
-                               "pn2_group_point_grad_workspace_bytes"}  # bound separately: size_t
-    assert decl <= set(pn2._lib.SIGNATURES) | {"pn2_sa_group_concat"}
+                               "pn2_group_point_grad_workspace_bytes", "pn2_voxel_downsample_workspace_bytes"}  # bound separately: size_t
+    assert decl <= set(pn2._lib.SIGNATURES)
+    # ... and nothing is bound that the header does not declare (no undocumented entry points in the product)
+    assert set(pn2._lib.SIGNATURES) <= decl
     assert pn2._lib.lib.pn2_interpolate_label_workspace_bytes(1000) > 2 * (1 << 21) * 4  # two cell tables + lists
 
 
@@ -54,6 +56,11 @@ def test_argument_validation_needs_no_gpu(pn2):
     assert L.pn2_interpolate_label_with_color(10, 10, nul, nul, nul, nul, nul, 3, nul, 0, nul) == -2
     assert L.pn2_fp_mlp_fused(1, 8, 4, 0, 8, nul, nul, nul, nul, 1, nul, nul, nul, nul, nul) == -2
     assert L.pn2_mlp_chain(0, 8, nul, 1, nul, nul, nul, 0, nul, nul) == -1
+    assert L.pn2_scene_extract_z_box(0, nul, 1, nul, 5.0, 5.0, 1.0, 8, nul, nul, nul) == -1
+    assert L.pn2_scene_extract_z_box(10, nul, 1, nul, 5.0, 5.0, 1.0, 8, nul, nul, nul) == -2
+    assert L.pn2_scene_sample(1, 0, 8, nul, nul, nul, nul, nul, nul, 5.0, 5.0, nul, nul, nul, nul, nul, nul, nul) == -1
+    assert L.pn2_voxel_downsample(10, nul, nul, nul, 0.0, nul, nul, nul, nul, nul, nul, 0, nul) == -1   # voxel_size > 0
+    assert L.pn2_voxel_downsample(10, nul, nul, nul, 0.05, nul, nul, nul, nul, nul, nul, 0, nul) == -2
 
 
 def test_ops_refuse_cpu_tensors_loudly(pn2):
