@@ -254,7 +254,7 @@ def other_configs(pn2, dev, hp, steps):
         labels = torch.from_numpy(rs.randint(0, 9, (B, N)).astype(np.int64)).to(dev)
         smpw = torch.from_numpy((rs.random_sample((B, N)) + 0.5).astype(np.float32)).to(dev)
         tr = pn2.train.Trainer(hp, 9, store=tfu.VariableStore(device=dev, seed=0), device=dev)
-        for _ in range(3):
+        for _ in range(tr.warmup_eager + 2):  # eager steps, then the capture, then one replay: all outside the timing
             tr.train_step(pc, labels, smpw)
         torch.cuda.synchronize()
         n3 = max(2, min(steps, 10))
@@ -331,7 +331,7 @@ def bench_train(pn2, args, hp, B, N, rank, world, dev):
     labels = torch.from_numpy(rs.randint(0, 9, (B, N)).astype(np.int64)).to(dev)
     smpw = torch.from_numpy((rs.random_sample((B, N)) + 0.5).astype(np.float32)).to(dev)
     tr = pn2.train.Trainer(hp, 9, store=pn2.util.tf_util.VariableStore(device=dev, seed=0), device=dev)
-    for _ in range(max(1, args.warmup)):
+    for _ in range(max(tr.warmup_eager + 2, args.warmup)):  # includes the one-time hipGraph capture of the step (1 GPU)
         tr.train_step(pc, labels, smpw)
     pn2.dist.barrier()
     torch.cuda.synchronize()

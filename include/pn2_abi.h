@@ -298,6 +298,37 @@ int pn2_interpolate_label_with_color(int num_sparse_points, int num_dense_points
                                      uint8_t *dense_colors, int knn, void *workspace,
                                      size_t workspace_bytes, void *stream);
 
+/* ---- training step ----------------------------------------------------------------- */
+
+/* Data gradient of a dense layer: dx (rows,cin) = dy (rows,cout) . W^T, W (cin,cout) row-major as the forward pass holds
+ * it; any cin / cout (tf.gradients of tf.nn.conv2d, util/tf_util.py:181-186). */
+int pn2_linear_dgrad(int rows, int cin, int cout, const float *dy, const float *w, float *dx, void *stream);
+
+/* model.get_loss  model.py:152-161: weighted sparse softmax cross-entropy, reduction SUM_BY_NONZERO_WEIGHTS.
+ * logits (rows,num_class) f32, labels (rows) int32 (label64 = 0) or int64 (label64 = 1), weights (rows) f32 ->
+ * *loss (device f32) = sum_r w_r*ce_r / max(1, #{w_r != 0}).  lse (rows) f32 and acc (2 doubles, zeroed by the callee)
+ * carry the forward's results to the backward.  num_class <= 64. */
+int pn2_weighted_ce_forward(int rows, int num_class, const float *logits, const void *labels, int label64,
+                            const float *weights, float *lse, double *acc, float *loss, void *stream);
+/* d loss / d logits = gout * w_r / nz * (softmax_r - onehot_r); gout: device scalar (upstream gradient) or NULL (= 1). */
+int pn2_weighted_ce_backward(int rows, int num_class, const float *logits, const void *labels, int label64,
+                             const float *weights, const float *lse, const double *acc, const float *gout,
+                             float *dlogits, void *stream);
+
+/* tf_util.dropout  util/tf_util.py:646-665 (tf.nn.dropout): y = x / keep_prob where kept, else 0; mask (n bytes) for the
+ * backward.  state: device int64[2] = {seed, step}; the draw is a pure function of (seed, step, element index), so a
+ * captured graph can be replayed while the caller advances `step` in device memory. */
+int pn2_dropout(long long n, const float *x, float keep_prob, const long long *state, float *y,
+                unsigned char *mask, void *stream);
+int pn2_dropout_grad(long long n, const float *dy, const unsigned char *mask, float keep_prob, float *dx,
+                     void *stream);
+
+/* tf.train.AdamOptimizer.apply_gradients  train.py:381-388, one launch over flat fp32 buffers of n elements:
+ * m <- b1 m + (1-b1) g;  v <- b2 v + (1-b2) g^2;  p <- p - lr_t * m / (sqrt(v) + eps), g = grads * grad_scale.
+ * hyper: DEVICE float[5] = {lr_t, beta1, beta2, epsilon, grad_scale}, lr_t = lr*sqrt(1-beta2^t)/(1-beta1^t). */
+int pn2_adam_step(long long n, float *params, const float *grads, float *m, float *v, const float *hyper,
+                  void *stream);
+
 /* sample_and_group's tail for layers too wide for the fused kernel (util/pointnet_util.py:39-54: group_point(xyz) -
  * tile(new_xyz), group_point(points), concat [xyz | points]) in one pass: out (b,m,nsample,3+c) with
  * out[..., :3] = xyz[idx] - new_xyz and out[..., 3:] = points[idx] (c may be 0, then points may be NULL). */

@@ -57,6 +57,13 @@ SIGNATURES = {
                                          ctypes.c_size_t, c_void_p],
     "pn2_sa_group_concat": [c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p,
                             c_void_p, c_void_p],
+    "pn2_linear_dgrad": [c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p],
+    "pn2_weighted_ce_forward": [c_int, c_int, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p],
+    "pn2_weighted_ce_backward": [c_int, c_int, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                                 c_void_p],
+    "pn2_dropout": [ctypes.c_longlong, c_void_p, c_float, c_void_p, c_void_p, c_void_p, c_void_p],
+    "pn2_dropout_grad": [ctypes.c_longlong, c_void_p, c_void_p, c_float, c_void_p, c_void_p],
+    "pn2_adam_step": [ctypes.c_longlong, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p],
     "pn2_scene_extract_z_box": [c_int, c_void_p, c_int, c_void_p, ctypes.c_double, ctypes.c_double, ctypes.c_double, c_int,
                                 c_void_p, c_void_p, c_void_p],
     "pn2_scene_sample": [c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, ctypes.c_double,
@@ -119,7 +126,7 @@ _raw = _load()
 
 
 # entry points that mutate caller state beyond their outputs (moving averages): never launched twice by the dup hook
-_STATEFUL = frozenset({"pn2_bn_relu_forward"})
+_STATEFUL = frozenset({"pn2_bn_relu_forward", "pn2_adam_step"})
 
 
 class _LibProxy:

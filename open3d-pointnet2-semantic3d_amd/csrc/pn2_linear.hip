@@ -49,7 +49,10 @@ __device__ __forceinline__ void atomic_max_nonneg(float* addr, float v) {
 // reduced through LDS before the epilogue): small-row layers then launch twice as many workgroups.
 // ST = register prefetch depth: the global loads of k-tile kt+ST-1 are issued under the MFMAs of tile
 // kt (ST = 2: one tile ahead; default 3, measured best: profiles/r01_linear_prefetch_depth.txt).
-template <int WM, int WN, int NT, bool VEC_A, int WK = 1, int ST = 2>
+// TB = true: the B operand is read TRANSPOSED, B(k, n) = w[n * cin + k] with `cout` REAL output columns (any value; the
+// tile is guarded) -- the data gradient of a dense layer, dx (rows, n_in) = dy (rows, n_out) . W^T with W (n_in, n_out)
+// row-major: here cin = n_out is the contraction and cout = n_in the output width.
+template <int WM, int WN, int NT, bool VEC_A, int WK = 1, int ST = 2, bool TB = false>
 __global__ void __launch_bounds__(256)
 linear_kernel(int rows, int cin, int cout, const float* __restrict__ x,
               const float* __restrict__ w, const float* __restrict__ bias, int relu, int pool,
@@ -121,10 +124,31 @@ linear_kernel(int rows, int cin, int cout, const float* __restrict__ x,
 #pragma unroll
         for (int i = 0; i < B_PER_T; ++i) {
             const int f = tid + 256 * i;
-            const int k = f / (BN / 4), n4 = f % (BN / 4);
-            const int kc = k0 + k < cin ? k0 + k : cin - 1;
-            const f32x4 v = *reinterpret_cast<const f32x4*>(w + (size_t)kc * cout + col0 + n4 * 4);
-            b_v[i] = (k0 + k < cin) ? v : z4;
+            if constexpr (TB) {
+                // thread -> (n = f / 8, four consecutive k): a 16-byte (or 4 scalar) read along a row of W
+                const int n = f >> 3, k4 = f & 7;
+                const int gn = col0 + n, gk = k0 + k4 * 4;
+                const int gnc = gn < cout ? gn : cout - 1;
+                f32x4 v;
+                if ((cin & 3) == 0) {
+                    const int gkc = gk < cin ? gk : cin - 4;
+                    v = *reinterpret_cast<const f32x4*>(w + (size_t)gnc * cin + gkc);
+                    if (!(gn < cout && gk < cin)) v = z4;
+                } else {
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const int gkq = gk + q < cin ? gk + q : cin - 1;
+                        const float e = w[(size_t)gnc * cin + gkq];
+                        v[q] = (gn < cout && gk + q < cin) ? e : 0.f;
+                    }
+                }
+                b_v[i] = v;
+            } else {
+                const int k = f / (BN / 4), n4 = f % (BN / 4);
+                const int kc = k0 + k < cin ? k0 + k : cin - 1;
+                const f32x4 v = *reinterpret_cast<const f32x4*>(w + (size_t)kc * cout + col0 + n4 * 4);
+                b_v[i] = (k0 + k < cin) ? v : z4;
+            }
         }
     };
     auto store_tile = [&](const f32x4 (&a_v)[VEC_A ? A_PER_T : 1], const float (&a_s)[VEC_A ? 1 : A_SC],
@@ -147,8 +171,16 @@ linear_kernel(int rows, int cin, int cout, const float* __restrict__ x,
 #pragma unroll
         for (int i = 0; i < B_PER_T; ++i) {
             const int f = tid + 256 * i;
-            const int k = f / (BN / 4), n4 = f % (BN / 4);
-            if (f < B_F4) *reinterpret_cast<f32x4*>(Bs + k * BS + n4 * 4) = b_v[i];
+            if constexpr (TB) {
+                const int n = f >> 3, k4 = f & 7;
+                if (f < B_F4) {
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) Bs[(4 * k4 + q) * BS + n] = b_v[i][q];
+                }
+            } else {
+                const int k = f / (BN / 4), n4 = f % (BN / 4);
+                if (f < B_F4) *reinterpret_cast<f32x4*>(Bs + k * BS + n4 * 4) = b_v[i];
+            }
         }
     };
 
@@ -215,6 +247,14 @@ linear_kernel(int rows, int cin, int cout, const float* __restrict__ x,
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) {
         const int col = col0 + wn * (NT * 32) + nt * 32 + l31;
+        if constexpr (TB) {  // plain guarded store: no bias / activation / pooling on a data gradient
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = wrow0 + (r & 3) + 8 * (r >> 2) + 4 * half;
+                if (row < rows && col < cout) y[(size_t)row * cout + col] = acc[nt][r];
+            }
+            continue;
+        }
         const float bv = bias ? bias[col] : 0.f;
         if (pool <= 1) {
 #pragma unroll
@@ -266,6 +306,17 @@ int launch_linear(int rows, int cin, int cout, const float* x, const float* w, c
         if (vec_a) linear_kernel<WM, WN, NT, true, WK, ST><<<grid, 256, 0, st>>>(rows, cin, cout, x, w, bias, relu, pool, y);
         else linear_kernel<WM, WN, NT, false, WK, ST><<<grid, 256, 0, st>>>(rows, cin, cout, x, w, bias, relu, pool, y);
     }
+    PN2_RETURN_IF_LAUNCH_FAILED();
+    return PN2_OK;
+}
+
+template <int WM, int WN, int NT>
+int launch_linear_dgrad(int rows, int n_in, int n_out, const float* dy, const float* w, float* dx, hipStream_t st) {
+    constexpr int BM = 32 * WM, BN = 32 * NT * WN;
+    dim3 grid((rows + BM - 1) / BM, (n_in + BN - 1) / BN);
+    const bool vec_a = (n_out % 4 == 0) && ((uintptr_t)dy % 16 == 0);
+    if (vec_a) linear_kernel<WM, WN, NT, true, 1, 3, true><<<grid, 256, 0, st>>>(rows, n_out, n_in, dy, w, nullptr, 0, 0, dx);
+    else linear_kernel<WM, WN, NT, false, 1, 3, true><<<grid, 256, 0, st>>>(rows, n_out, n_in, dy, w, nullptr, 0, 0, dx);
     PN2_RETURN_IF_LAUNCH_FAILED();
     return PN2_OK;
 }
@@ -639,6 +690,22 @@ extern "C" int pn2_linear(int rows, int cin, int cout, const float* x, const flo
     if (cout % 64 == 0) return PN2_LIN(4, 1, 2, 1);
     return PN2_LIN(4, 1, 1, 1);
 #undef PN2_LIN
+}
+
+// Data gradient of a dense layer (training): dx (rows, cin) = dy (rows, cout) . W^T, W (cin, cout) row-major as the forward
+// pass holds it (no transposed copy); any cin / cout.  The reference gets this from tf.gradients of tf.nn.conv2d
+// (util/tf_util.py:181-186).
+extern "C" int pn2_linear_dgrad(int rows, int cin, int cout, const float* dy, const float* w, float* dx, void* stream) {
+    if (rows <= 0 || cin <= 0 || cout <= 0) return PN2_EINVAL;
+    if (!dy || !w || !dx) return PN2_ENULL;
+    if ((long long)rows + 128 > 0x7fffffffLL) return PN2_ERANGE;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    if (cin <= 32) return launch_linear_dgrad<4, 1, 1>(rows, cin, cout, dy, w, dx, st);
+    if (cin <= 64) return launch_linear_dgrad<4, 1, 2>(rows, cin, cout, dy, w, dx, st);
+    if (cin <= 96) return launch_linear_dgrad<4, 1, 1>(rows, cin, cout, dy, w, dx, st);
+    const long long cb = (cin + 127) / 128;
+    if (((rows + 63) / 64) * cb >= 512) return launch_linear_dgrad<2, 2, 2>(rows, cin, cout, dy, w, dx, st);
+    return launch_linear_dgrad<1, 4, 1>(rows, cin, cout, dy, w, dx, st);
 }
 
 extern "C" int pn2_debug_set_linear(int what, int value) {

@@ -1,0 +1,180 @@
+// pn2_train.hip -- the training step's non-GEMM tail on the device:
+//   * weighted sparse softmax cross-entropy, reduction SUM_BY_NONZERO_WEIGHTS (reference model.py:152-161), forward + backward;
+//   * dropout (util/tf_util.py:646-665 -> tf.nn.dropout: keep with probability keep_prob, scale by 1/keep_prob);
+//   * Adam exactly as tf.train.AdamOptimizer applies it (reference train.py:381-388), ONE launch over the flat parameter buffer.
+// Step-dependent scalars (learning rate with bias correction, dropout step counter, upstream loss gradient) are read from
+// DEVICE memory, so a captured hipGraph of the whole step can be replayed while they change.
+#include "pn2_common.h"
+
+namespace {
+
+constexpr int kCeMaxClasses = 64;
+
+// one thread per point: logits row (C floats) -> lse, w * (lse - logit[label]); block partials -> two fp64 atomics
+template <typename LabelT>
+__global__ void __launch_bounds__(256)
+ce_forward_kernel(int rows, int C, const float* __restrict__ logits, const LabelT* __restrict__ labels,
+                  const float* __restrict__ w, float* __restrict__ lse_out, double* __restrict__ acc /* [sum, nonzero] */) {
+    __shared__ double s_sum[4], s_cnt[4];
+    const int r = blockIdx.x * 256 + threadIdx.x;
+    double loss = 0.0, nz = 0.0;
+    if (r < rows) {
+        const float* __restrict__ z = logits + (size_t)r * C;
+        float mx = z[0];
+        for (int c = 1; c < C; ++c) mx = fmaxf(mx, z[c]);
+        float se = 0.f;
+        for (int c = 0; c < C; ++c) se += expf(z[c] - mx);
+        const float lse = mx + logf(se);
+        lse_out[r] = lse;
+        const int lab = (int)labels[r];
+        const float wr = w[r];
+        const float ce = lse - z[lab >= 0 && lab < C ? lab : 0];
+        loss = (double)(wr * ce);
+        nz = wr != 0.f ? 1.0 : 0.0;
+    }
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) { loss += __shfl_xor(loss, o); nz += __shfl_xor(nz, o); }
+    if ((threadIdx.x & 63) == 0) { s_sum[threadIdx.x >> 6] = loss; s_cnt[threadIdx.x >> 6] = nz; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        atomicAdd(&acc[0], s_sum[0] + s_sum[1] + s_sum[2] + s_sum[3]);
+        atomicAdd(&acc[1], s_cnt[0] + s_cnt[1] + s_cnt[2] + s_cnt[3]);
+    }
+}
+
+__global__ void ce_finalize_kernel(const double* __restrict__ acc, float* __restrict__ loss) {
+    const double nz = acc[1] > 0.0 ? acc[1] : 1.0;  // tf.losses: safe division, 0 when no weight is non-zero
+    *loss = (float)(acc[0] / nz);
+}
+
+template <typename LabelT>
+__global__ void __launch_bounds__(256)
+ce_backward_kernel(long long total, int C, const float* __restrict__ logits, const LabelT* __restrict__ labels,
+                   const float* __restrict__ w, const float* __restrict__ lse, const double* __restrict__ acc,
+                   const float* __restrict__ gout, float* __restrict__ dlogits) {
+    const double nz = acc[1] > 0.0 ? acc[1] : 1.0;
+    const float scale = (gout ? *gout : 1.0f) / (float)nz;
+    for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long long)gridDim.x * 256) {
+        const long long r = e / C;
+        const int c = (int)(e - r * C);
+        const float p = expf(logits[e] - lse[r]);
+        dlogits[e] = scale * w[r] * (p - ((int)labels[r] == c ? 1.f : 0.f));
+    }
+}
+
+// counter-based RNG: one 64-bit mix per element of (seed, step, index) -- stateless, replayable, graph-safe
+__device__ __forceinline__ unsigned mix_u32(unsigned long long seed, unsigned long long step, unsigned long long i) {
+    unsigned long long x = seed ^ (step * 0x9E3779B97F4A7C15ull) ^ (i * 0xD1B54A32D192ED03ull);
+    x ^= x >> 32; x *= 0xD6E8FEB86659FD93ull;
+    x ^= x >> 32; x *= 0xD6E8FEB86659FD93ull;
+    x ^= x >> 32;
+    return (unsigned)x;
+}
+
+__global__ void __launch_bounds__(256)
+dropout_kernel(long long n, const float* __restrict__ x, float keep, const long long* __restrict__ state /* [seed, step] */,
+               float* __restrict__ y, unsigned char* __restrict__ mask) {
+    const unsigned long long seed = (unsigned long long)state[0], step = (unsigned long long)state[1];
+    const float inv = 1.0f / keep;
+    const unsigned thr = keep >= 1.f ? 0xFFFFFFFFu : (unsigned)((double)keep * 4294967296.0);
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
+        const bool k = mix_u32(seed, step, (unsigned long long)i) < thr;
+        mask[i] = k ? 1 : 0;
+        y[i] = k ? x[i] * inv : 0.f;
+    }
+}
+
+__global__ void __launch_bounds__(256)
+dropout_grad_kernel(long long n, const float* __restrict__ dy, const unsigned char* __restrict__ mask, float keep,
+                    float* __restrict__ dx) {
+    const float inv = 1.0f / keep;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256)
+        dx[i] = mask[i] ? dy[i] * inv : 0.f;
+}
+
+// tf.train.AdamOptimizer (python/training/adam.py): m <- b1 m + (1-b1) g; v <- b2 v + (1-b2) g^2;
+// p <- p - lr_t * m / (sqrt(v) + eps) with lr_t = lr * sqrt(1 - b2^t) / (1 - b1^t) supplied by the host in hyper[0].
+__global__ void __launch_bounds__(256)
+adam_kernel(long long n, float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
+            const float* __restrict__ hyper /* [lr_t, beta1, beta2, eps, grad_scale] */) {
+    const float lr_t = hyper[0], b1 = hyper[1], b2 = hyper[2], eps = hyper[3], gs = hyper[4];
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
+        const float gi = g[i] * gs;  // gs = 1/world after a summing all-reduce
+        const float mi = b1 * m[i] + (1.f - b1) * gi;
+        const float vi = b2 * v[i] + (1.f - b2) * gi * gi;
+        m[i] = mi;
+        v[i] = vi;
+        p[i] -= lr_t * mi / (sqrtf(vi) + eps);
+    }
+}
+
+inline int grid_1d(long long n) {
+    long long g = (n + 255) / 256;
+    return (int)(g < 1 ? 1 : (g > 256 * 16 ? 256 * 16 : g));
+}
+
+}  // namespace
+
+// model.get_loss (reference model.py:152-161): logits (rows,C) f32, labels (rows) int32 (label64 = 0) or int64 (label64 = 1),
+// weights (rows) f32 -> *loss = sum_r w_r * ce_r / max(1, #{w_r != 0}).  lse (rows) and acc (2 doubles) are kept for the
+// backward; acc is zeroed here.  No host synchronisation.
+extern "C" int pn2_weighted_ce_forward(int rows, int num_class, const float* logits, const void* labels, int label64,
+                                       const float* weights, float* lse, double* acc, float* loss, void* stream) {
+    if (rows <= 0 || num_class <= 0) return PN2_EINVAL;
+    if (num_class > kCeMaxClasses) return PN2_EUNSUP;
+    if (!logits || !labels || !weights || !lse || !acc || !loss) return PN2_ENULL;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    hipError_t e = hipMemsetAsync(acc, 0, 2 * sizeof(double), st);
+    if (e != hipSuccess) return (int)e;
+    const int blocks = (rows + 255) / 256;
+    if (label64) ce_forward_kernel<long long><<<blocks, 256, 0, st>>>(rows, num_class, logits, static_cast<const long long*>(labels), weights, lse, acc);
+    else ce_forward_kernel<int><<<blocks, 256, 0, st>>>(rows, num_class, logits, static_cast<const int*>(labels), weights, lse, acc);
+    ce_finalize_kernel<<<1, 1, 0, st>>>(acc, loss);
+    PN2_RETURN_IF_LAUNCH_FAILED();
+    return PN2_OK;
+}
+
+// d loss / d logits = gout * w_r / nz * (softmax_r - onehot_r); gout (device scalar) may be NULL (= 1).
+extern "C" int pn2_weighted_ce_backward(int rows, int num_class, const float* logits, const void* labels, int label64,
+                                        const float* weights, const float* lse, const double* acc, const float* gout,
+                                        float* dlogits, void* stream) {
+    if (rows <= 0 || num_class <= 0) return PN2_EINVAL;
+    if (!logits || !labels || !weights || !lse || !acc || !dlogits) return PN2_ENULL;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    const long long total = (long long)rows * num_class;
+    if (label64) ce_backward_kernel<long long><<<grid_1d(total), 256, 0, st>>>(total, num_class, logits, static_cast<const long long*>(labels), weights, lse, acc, gout, dlogits);
+    else ce_backward_kernel<int><<<grid_1d(total), 256, 0, st>>>(total, num_class, logits, static_cast<const int*>(labels), weights, lse, acc, gout, dlogits);
+    PN2_RETURN_IF_LAUNCH_FAILED();
+    return PN2_OK;
+}
+
+// tf.nn.dropout (util/tf_util.py:646-665): y = x / keep_prob where kept, 0 elsewhere; mask (n bytes) for the backward.
+// state: device int64[2] = {seed, step}: the draw is a pure function of (seed, step, element index).
+extern "C" int pn2_dropout(long long n, const float* x, float keep_prob, const long long* state, float* y,
+                           unsigned char* mask, void* stream) {
+    if (n <= 0 || !(keep_prob > 0.f) || keep_prob > 1.f) return PN2_EINVAL;
+    if (!x || !state || !y || !mask) return PN2_ENULL;
+    dropout_kernel<<<grid_1d(n), 256, 0, static_cast<hipStream_t>(stream)>>>(n, x, keep_prob, state, y, mask);
+    PN2_RETURN_IF_LAUNCH_FAILED();
+    return PN2_OK;
+}
+
+extern "C" int pn2_dropout_grad(long long n, const float* dy, const unsigned char* mask, float keep_prob, float* dx,
+                                void* stream) {
+    if (n <= 0 || !(keep_prob > 0.f) || keep_prob > 1.f) return PN2_EINVAL;
+    if (!dy || !mask || !dx) return PN2_ENULL;
+    dropout_grad_kernel<<<grid_1d(n), 256, 0, static_cast<hipStream_t>(stream)>>>(n, dy, mask, keep_prob, dx);
+    PN2_RETURN_IF_LAUNCH_FAILED();
+    return PN2_OK;
+}
+
+// One Adam step over flat fp32 buffers of n elements (parameters, gradients, first / second moments).
+// hyper: device float[5] = {lr_t, beta1, beta2, epsilon, grad_scale}, lr_t = lr * sqrt(1 - beta2^t) / (1 - beta1^t).
+extern "C" int pn2_adam_step(long long n, float* params, const float* grads, float* m, float* v, const float* hyper,
+                             void* stream) {
+    if (n <= 0) return PN2_EINVAL;
+    if (!params || !grads || !m || !v || !hyper) return PN2_ENULL;
+    adam_kernel<<<grid_1d(n), 256, 0, static_cast<hipStream_t>(stream)>>>(n, params, grads, m, v, hyper);
+    PN2_RETURN_IF_LAUNCH_FAILED();
+    return PN2_OK;
+}

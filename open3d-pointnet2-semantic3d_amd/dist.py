@@ -96,6 +96,84 @@ class FlatGradAllReduce:
         return self.flat
 
 
+class OverlappedGradAllReduce:
+    """Gradient all-reduce in TWO flat buckets so that the first one travels while the backward pass is still running.
+
+    Backward produces gradients in reverse layer order: head and feature-propagation layers first, the set-abstraction
+    layers last.  `params[split:]` (created last = differentiated first) form the EARLY bucket: a post-accumulate hook on
+    each of them counts down, and when the last one lands the bucket is packed (one multi-tensor copy) and its
+    all-reduce is launched asynchronously -- it overlaps the SA layers' backward.  `params[:split]` form the LATE
+    bucket, reduced when backward has finished.  Both buckets are slices of ONE flat buffer (`flat`), so the
+    optimizer still sees a single contiguous gradient.  Sums only: dividing by the world size is left to the optimizer
+    (pn2_adam_step's grad_scale), which saves a pass over the buffer.
+
+        bucket = OverlappedGradAllReduce(params, split);  bucket.begin();  loss.backward();  flat = bucket.finish()
+    """
+
+    def __init__(self, params, split):
+        self.params = [p for p in params]
+        self.split = int(split)
+        self.numel = sum(p.numel() for p in self.params)
+        dev = self.params[0].device if self.params else torch.device("cpu")
+        self.flat = torch.zeros(self.numel, dtype=torch.float32, device=dev)
+        self.views, off = [], 0
+        for i, p in enumerate(self.params):
+            if i == self.split:
+                self.split_off = off
+            self.views.append(self.flat[off:off + p.numel()].view_as(p))
+            off += p.numel()
+        if self.split >= len(self.params):
+            self.split_off = off
+        self.late_flat, self.early_flat = self.flat[:self.split_off], self.flat[self.split_off:]
+        self._pending, self._work, self.early_launched_in_backward = 0, None, False
+        self._hooks = [p.register_post_accumulate_grad_hook(self._on_grad) for p in self.params[self.split:]]
+
+    def world(self):
+        return dist.get_world_size() if (dist.is_available() and dist.is_initialized()) else 1
+
+    def begin(self):
+        """call before backward (after the gradients were reset)"""
+        self._pending = len(self.params) - self.split
+        self._work, self.early_launched_in_backward = None, False
+
+    def _pack(self, lo, hi):
+        src, dst = [], []
+        for p, v in zip(self.params[lo:hi], self.views[lo:hi]):
+            if p.grad is None:
+                v.zero_()
+            elif p.grad.data_ptr() != v.data_ptr():
+                src.append(p.grad)
+                dst.append(v)
+        if dst:
+            torch._foreach_copy_(dst, src)
+
+    @torch.no_grad()
+    def _on_grad(self, p):
+        self._pending -= 1
+        if self._pending == 0:  # every early-bucket gradient has landed: pack and send while backward goes on
+            self._pack(self.split, len(self.params))
+            if self.world() > 1:
+                self._work = dist.all_reduce(self.early_flat, op=dist.ReduceOp.SUM, async_op=True)
+            self.early_launched_in_backward = True
+
+    @torch.no_grad()
+    def finish(self):
+        """after backward: reduce the late bucket, wait for the early one, leave every p.grad as a view of `flat`."""
+        if not self.early_launched_in_backward:  # a parameter without gradient kept the countdown from reaching zero
+            self._pack(self.split, len(self.params))
+            if self.world() > 1:
+                self._work = dist.all_reduce(self.early_flat, op=dist.ReduceOp.SUM, async_op=True)
+        self._pack(0, self.split)
+        if self.world() > 1:
+            if self.split_off > 0:
+                dist.all_reduce(self.late_flat, op=dist.ReduceOp.SUM)
+            if self._work is not None:
+                self._work.wait()
+        for p, v in zip(self.params, self.views):
+            p.grad = v
+        return self.flat
+
+
 def broadcast_parameters(tensors, src=0):
     """Make every rank start from rank `src`'s weights (replicated parameters)."""
     if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:

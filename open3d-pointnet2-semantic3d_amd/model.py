@@ -136,12 +136,40 @@ def get_model(point_cloud, is_training, num_class, hyperparams, bn_decay=None):
     return net, end_points
 
 
+class _WeightedCE(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, pred2d, label, w):
+        from ._lib import check, lib, ptr, stream_ptr
+        rows, c = pred2d.shape
+        lse = torch.empty((rows,), dtype=torch.float32, device=pred2d.device)
+        acc = torch.empty((2,), dtype=torch.float64, device=pred2d.device)
+        loss = torch.empty((), dtype=torch.float32, device=pred2d.device)
+        with torch.cuda.device(pred2d.device):
+            check(lib.pn2_weighted_ce_forward(rows, c, ptr(pred2d), ptr(label), int(label.dtype == torch.int64), ptr(w),
+                                              ptr(lse), ptr(acc), ptr(loss), stream_ptr()), "pn2_weighted_ce_forward")
+        ctx.save_for_backward(pred2d, label, w, lse, acc)
+        return loss
+
+    @staticmethod
+    def backward(ctx, gout):
+        from ._lib import check, lib, ptr, stream_ptr
+        pred2d, label, w, lse, acc = ctx.saved_tensors
+        rows, c = pred2d.shape
+        d = torch.empty_like(pred2d)
+        g = gout.contiguous().float()
+        with torch.cuda.device(pred2d.device):
+            check(lib.pn2_weighted_ce_backward(rows, c, ptr(pred2d), ptr(label), int(label.dtype == torch.int64), ptr(w),
+                                               ptr(lse), ptr(acc), ptr(g), ptr(d), stream_ptr()), "pn2_weighted_ce_backward")
+        return d, None, None
+
+
 def get_loss(pred, label, smpw, end_points=None):
     """Weighted sparse softmax cross-entropy, tf.losses reduction SUM_BY_NONZERO_WEIGHTS
-    (model.py:152-161): sum(w * ce) / count(w != 0).  `end_points` is accepted and unused, as in the reference."""
-    import torch
-    import torch.nn.functional as F
-    ce = F.cross_entropy(pred.reshape(-1, pred.shape[-1]), label.reshape(-1).long(), reduction="none")
-    w = smpw.reshape(-1)
-    nz = (w != 0).sum().clamp(min=1)
-    return (ce * w).sum() / nz
+    (model.py:152-161): sum(w * ce) / count(w != 0), on pn2_weighted_ce_forward / _backward (one pass each, no host
+    synchronisation).  `end_points` is accepted and unused, as in the reference."""
+    from ._lib import require_cuda
+    require_cuda(pred, label, smpw)
+    if label.dtype not in (torch.int32, torch.int64):
+        label = label.long()
+    pred2d = pred.reshape(-1, pred.shape[-1]).contiguous().float()
+    return _WeightedCE.apply(pred2d, label.reshape(-1).contiguous(), smpw.reshape(-1).contiguous().float())

@@ -4,12 +4,13 @@ Restates what train.py of the reference does per batch (train.py:80-119 schedule
 minimize, model.py:152-161 loss) on the MI355X layer API: forward with batch-statistic BatchNorm
 (HIP index/gather kernels + differentiable torch layers), weighted sparse softmax cross-entropy,
 backward through the HIP gradient kernels (group_point_grad, gather_point_grad,
-three_interpolate_grad), ONE flat RCCL all-reduce, Adam.
+three_interpolate_grad, pn2_linear_dgrad / _wgrad), a two-bucket RCCL all-reduce overlapped with backward, Adam.
 """
 import torch
 
 from . import dist as pdist
 from . import model
+from ._lib import check, lib, ptr, stream_ptr
 from .util import tf_util
 
 
@@ -23,19 +24,39 @@ def bn_decay(step, batch_size, init=0.5, decay_step=200000, decay_rate=0.5, clip
     return min(clip, 1.0 - init * decay_rate ** ((step * batch_size) // decay_step))
 
 
+def adam_lr_t(lr, t, beta1=0.9, beta2=0.999):
+    """tf.train.AdamOptimizer's per-step rate: lr * sqrt(1 - beta2^t) / (1 - beta1^t), t = 1, 2, ..."""
+    return lr * (1.0 - beta2 ** t) ** 0.5 / (1.0 - beta1 ** t)
+
+
 class Trainer:
-    def __init__(self, hyperparams, num_class, store=None, device="cuda"):
+    """One process per GPU.  Everything between the input batch and the updated weights runs on the HIP library:
+    forward GEMMs (pn2_linear), batch-norm kernels, weighted CE (pn2_weighted_ce_*), dropout (pn2_dropout), data and
+    weight gradients (pn2_linear_dgrad / _wgrad), index-op gradients, and ONE Adam launch over flat parameter / moment
+    buffers (pn2_adam_step).  torch supplies memory, streams, the autograd tape and torch.distributed.
+
+    Step-dependent scalars live in device memory (learning rate with Adam's bias correction, dropout step), so on a
+    single GPU the whole step is captured into one hipGraph after `warmup_eager` ordinary steps and replayed; with
+    several GPUs the step runs eagerly and the gradient all-reduce is split in two buckets, the first one launched from
+    inside backward (dist.OverlappedGradAllReduce)."""
+
+    BETA1, BETA2, EPS = 0.9, 0.999, 1e-8  # tf.train.AdamOptimizer defaults (train.py:381-384)
+
+    def __init__(self, hyperparams, num_class, store=None, device="cuda", capture=True, warmup_eager=3):
         self.hp = dict(hyperparams)
         self.num_class = num_class
         self.store = store or tf_util.set_default_store(tf_util.VariableStore(device=device, seed=0))
         self.step_count = 0
-        self.opt = None
         self.bucket = None
+        self.capture, self.warmup_eager = bool(capture), int(warmup_eager)
+        self._graph, self._graph_decay, self._static, self._stream = None, None, None, None
 
+    # ---- set-up ------------------------------------------------------------------------------------------------
     def _lazy_init(self, pc):
         # variables are created by the first forward (TF-style get_variable semantics).  That forward must leave no
         # trace: no autograd graph, and the moving averages restored (the reference applies ONE update per step,
         # train.py:381-388; the HIP BN kernel updates them through raw pointers even under no_grad).
+        tf_util.set_default_store(self.store)
         with torch.no_grad():
             before = {k: v.clone() for k, v in self.store.buffers.items()}  # a pre-loaded store keeps its statistics
             model.get_model(pc[:1], True, self.num_class, self.hp, bn_decay=bn_decay(0, pc.shape[0]))
@@ -44,27 +65,93 @@ class Trainer:
                     v.copy_(before[k])
                 else:
                     v.fill_(0.0 if k.endswith("moving_mean") else 1.0)  # tf_util.py:571-581 initial moving averages
+        names = list(self.store.params.keys())
         params = self.store.parameters()
         pdist.broadcast_parameters(params)
         pdist.broadcast_parameters(list(self.store.buffers.values()))
-        self.opt = torch.optim.Adam(params, lr=learning_rate(0, pc.shape[0]))  # TF Adam defaults == torch defaults except eps
-        for g in self.opt.param_groups:
-            g["eps"] = 1e-8
-        self.bucket = pdist.FlatGradAllReduce(params)
+        # flat parameter / moment buffers: every parameter becomes a view of `flat_p` (same Parameter objects)
+        dev = params[0].device
+        n = sum(p.numel() for p in params)
+        self.flat_p = torch.empty(n, dtype=torch.float32, device=dev)
+        off = 0
+        with torch.no_grad():
+            for p in params:
+                v = self.flat_p[off:off + p.numel()].view_as(p)
+                v.copy_(p)
+                p.data = v
+                off += p.numel()
+        self.flat_m = torch.zeros_like(self.flat_p)
+        self.flat_v = torch.zeros_like(self.flat_p)
+        # backward reaches the head and the FP layers first: they are the early bucket (created after layer1..layer4)
+        split = next((i for i, k in enumerate(names) if not k.startswith("layer")), len(names))
+        self.bucket = pdist.OverlappedGradAllReduce(params, split)
+        self.hyper = torch.zeros(5, dtype=torch.float32, device=dev)
+        self._stream = torch.cuda.Stream(device=dev) if dev.type == "cuda" else None
+        self._hyper_host = torch.zeros(5, dtype=torch.float32).pin_memory() if dev.type == "cuda" else torch.zeros(5)
 
-    def train_step(self, pc, labels, smpw):
-        """pc (B,N,6) float32, labels (B,N) int, smpw (B,N) float32 -> loss (python float)."""
+    # ---- one step ------------------------------------------------------------------------------------------------
+    def _step_body(self, pc, labels, smpw, decay):
+        for p in self.bucket.params:
+            p.grad = None
+        logits, _ = model.get_model(pc, True, self.num_class, self.hp, bn_decay=decay)
+        loss = model.get_loss(logits, labels, smpw)
+        self.bucket.begin()
+        loss.backward()
+        flat_g = self.bucket.finish()
+        with torch.cuda.device(self.flat_p.device):
+            check(lib.pn2_adam_step(self.flat_p.numel(), ptr(self.flat_p), ptr(flat_g), ptr(self.flat_m), ptr(self.flat_v),
+                                    ptr(self.hyper), stream_ptr()), "pn2_adam_step")
+        return loss.detach()
+
+    def train_step(self, pc, labels, smpw, sync=True):
+        """pc (B,N,6) float32, labels (B,N) int, smpw (B,N) float32 -> loss (python float; the device scalar when
+        sync=False, to be read after the next synchronisation point)."""
         tf_util.set_default_store(self.store)
-        if self.opt is None:
+        if self.bucket is None:
             self._lazy_init(pc)
         b = pc.shape[0]
-        for g in self.opt.param_groups:
-            g["lr"] = learning_rate(self.step_count, b)
-        self.opt.zero_grad(set_to_none=True)
-        logits, _ = model.get_model(pc, True, self.num_class, self.hp, bn_decay=bn_decay(self.step_count, b))
-        loss = model.get_loss(logits, labels, smpw)
-        loss.backward()
-        self.bucket.allreduce_()  # one 3.87 MB all-reduce (sum / world)
-        self.opt.step()
+        world = self.bucket.world()
+        t = self.step_count + 1
+        lr = learning_rate(self.step_count, b)
+        decay = bn_decay(self.step_count, b)
+        self._hyper_host.copy_(torch.tensor([adam_lr_t(lr, t, self.BETA1, self.BETA2), self.BETA1, self.BETA2, self.EPS,
+                                             1.0 / world], dtype=torch.float32))
+        use_graph = self.capture and world == 1 and pc.is_cuda and self.step_count >= self.warmup_eager
+        if not use_graph:
+            self.hyper.copy_(self._hyper_host, non_blocking=True)
+            self.store.set_step(self.step_count)
+            loss = self._step_body(pc, labels, smpw, decay)
+        else:
+            # Replays and the per-step writes they depend on run on the trainer's OWN stream.  Launching the graph into
+            # the null stream is not safe on this stack: work queued on the null stream after hipGraphLaunch started
+            # before the graph had finished (the next step's input copy then faulted with "write access to a read-only
+            # page" around the 13th replay; a device-wide synchronise in between hid it).
+            caller = torch.cuda.current_stream()
+            self._stream.wait_stream(caller)
+            with torch.cuda.stream(self._stream):
+                if self._graph is None or self._graph_decay != decay or self._static[0].shape != pc.shape:
+                    self._capture(pc, labels, smpw, decay)
+                self.hyper.copy_(self._hyper_host, non_blocking=True)
+                self.store.set_step(self.step_count)
+                for dst, src in zip(self._static[:3], (pc, labels, smpw)):
+                    if dst.data_ptr() != src.data_ptr():
+                        dst.copy_(src, non_blocking=True)
+                self._graph.replay()
+                loss = self._static[3]
+                if sync:
+                    loss = float(loss)
+            caller.wait_stream(self._stream)
         self.step_count += 1
-        return float(loss.detach())
+        return float(loss) if sync else loss
+
+    def _capture(self, pc, labels, smpw, decay):
+        """record forward + loss + backward + Adam of one step into a hipGraph (static input buffers)."""
+        torch.cuda.synchronize()
+        st = [pc.clone(), labels.clone(), smpw.clone()]
+        for p in self.bucket.params:
+            p.grad = None
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            loss = self._step_body(st[0], st[1], st[2], decay)
+        self._graph, self._graph_decay, self._static = g, decay, st + [loss]
+        # the capture itself executed nothing: the replay that follows is this step

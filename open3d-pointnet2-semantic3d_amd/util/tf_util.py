@@ -34,9 +34,23 @@ class VariableStore:
         self.buffers = OrderedDict()  # moving averages
         self._gen = torch.Generator(device="cpu")
         self._gen.manual_seed(seed)
+        self._seed = int(seed)
+        self._dropout = {}
         self._folded = {}
         self.train_epoch = 0  # bumped by every training-mode layer call: the HIP BN kernel updates the moving averages
                               # through raw pointers (no autograd version bump), so folded inference weights key on it too
+
+    def dropout_state(self, key, salt):
+        """device int64[2] = {seed ^ salt, step} of one dropout call site; `set_step` advances every site."""
+        t = self._dropout.get(key)
+        if t is None:
+            t = torch.tensor([(self._seed * 0x9E3779B1 + 12345) ^ int(salt), 0], dtype=torch.int64, device=self.device)
+            self._dropout[key] = t
+        return t
+
+    def set_step(self, step):
+        for t in self._dropout.values():
+            t[1] = int(step)
 
     def get_variable(self, name, shape, init):
         if name not in self.params:
@@ -167,7 +181,7 @@ def folded_dense(cin, cout, bn, kernel_shape, pad_to=None, pad_in=None, rotate_r
 def hip_linear(x2d, w, b, relu=True, pool=0):
     """y = relu?(x2d @ w + b), optional max over groups of `pool` consecutive rows.
     Thin wrapper over pn2_linear (fp32 MFMA)."""
-    require_cuda(x2d, w, b)
+    require_cuda(x2d, w, b)  # b may be None (no bias)
     rows, cin = x2d.shape
     cout = w.shape[1]
     x2d = x2d.contiguous()
@@ -229,6 +243,31 @@ def hip_fp_mlp_fused(dist, idx, points1, points2, ws, bs):
     return y
 
 
+def hip_matmul(x2d, w):
+    """y = x2d @ w on pn2_linear (no bias, no activation) -- the forward GEMM of the training path.  Output widths that
+    are not a multiple of 32 (the 9-class head) run with zero-padded weight columns and are sliced back."""
+    cin, cout = w.shape
+    if cout % 32 != 0:
+        wp = F.pad(w, (0, 32 - cout % 32)).contiguous()
+        return hip_linear(x2d, wp, None, relu=False)[:, :cout].contiguous()
+    return hip_linear(x2d, w.contiguous(), None, relu=False)
+
+
+def hip_linear_dgrad(dy, w):
+    """dx (rows, cin) = dy (rows, cout) @ w^T with w (cin, cout) as the forward pass holds it (pn2_linear_dgrad)."""
+    require_cuda(dy, w)
+    rows, cout = dy.shape
+    cin = w.shape[0]
+    dy = dy.contiguous()
+    dx = torch.empty((rows, cin), dtype=torch.float32, device=dy.device)
+    with torch.cuda.device(dy.device):
+        check(lib.pn2_linear_dgrad(rows, cin, cout, ptr(dy), ptr(w.contiguous()), ptr(dx), stream_ptr()), "pn2_linear_dgrad")
+    return dx
+
+
+USE_HIP_GEMM = True  # set False to run the training path's forward / data-gradient GEMMs on torch (hipBLASLt): tests / A-B
+
+
 class _TrainMatmul(torch.autograd.Function):
     """y = x2d @ w for the training path; backward: dX = dY @ w^T (torch), dW = x2d^T @ dY on pn2_linear_wgrad (the
     reduction over all rows, ~8x faster than the library GEMM on these tall-skinny shapes)."""
@@ -236,13 +275,15 @@ class _TrainMatmul(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x2d, w):
         ctx.save_for_backward(x2d, w)
-        return x2d @ w
+        return hip_matmul(x2d, w) if USE_HIP_GEMM else x2d @ w
 
     @staticmethod
     def backward(ctx, dy):
         x2d, w = ctx.saved_tensors
         dy = dy.contiguous()
-        dx = dy @ w.t() if ctx.needs_input_grad[0] else None
+        dx = None
+        if ctx.needs_input_grad[0]:
+            dx = hip_linear_dgrad(dy, w) if USE_HIP_GEMM else dy @ w.t()
         dw = None
         if ctx.needs_input_grad[1]:
             dw = torch.empty_like(w)
@@ -280,7 +321,7 @@ class _TrainDenseBnRelu(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x2d, w, b, gamma, beta, running_mean, running_var, decay, relu, pool):
-        y = x2d @ w
+        y = hip_matmul(x2d, w) if USE_HIP_GEMM else x2d @ w
         rows, c = y.shape
         pooled = pool > 1
         z = torch.empty((rows // pool, c) if pooled else (rows, c), dtype=y.dtype, device=y.device)
@@ -315,7 +356,9 @@ class _TrainDenseBnRelu(torch.autograd.Function):
                                            ptr(save_invstd), int(ctx.relu), ctx.pool, ptr(zmax), ptr(ties), ptr(ws),
                                            ws.numel() * 8, ptr(dy), ptr(dgamma), ptr(dbeta), stream_ptr()),
                   "pn2_bn_relu_backward")
-            dx = dy @ w.t() if ctx.needs_input_grad[0] else None
+            dx = None
+            if ctx.needs_input_grad[0]:
+                dx = hip_linear_dgrad(dy, w) if USE_HIP_GEMM else dy @ w.t()
             dw = None
             if ctx.needs_input_grad[1]:
                 dw = torch.empty_like(w)
@@ -409,8 +452,40 @@ def conv1d(inputs, num_output_channels, kernel_size, scope, stride=1, padding="S
         return y
 
 
+class _Dropout(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, keep_prob, state):
+        x = x.contiguous()
+        y = torch.empty_like(x)
+        mask = torch.empty(x.shape, dtype=torch.uint8, device=x.device)
+        with torch.cuda.device(x.device):
+            check(lib.pn2_dropout(x.numel(), ptr(x), float(keep_prob), ptr(state), ptr(y), ptr(mask), stream_ptr()),
+                  "pn2_dropout")
+        ctx.save_for_backward(mask)
+        ctx.keep = float(keep_prob)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        (mask,) = ctx.saved_tensors
+        dy = dy.contiguous()
+        dx = torch.empty_like(dy)
+        with torch.cuda.device(dy.device):
+            check(lib.pn2_dropout_grad(dy.numel(), ptr(dy), ptr(mask), ctx.keep, ptr(dx), stream_ptr()), "pn2_dropout_grad")
+        return dx, None, None
+
+
 def dropout(inputs, is_training, scope, keep_prob=0.5, noise_shape=None):
-    """tf_util.py:646-665: active only while training."""
-    if is_training:
-        return F.dropout(inputs, p=1.0 - keep_prob, training=True)
-    return inputs
+    """tf_util.py:646-665: active only while training.  The draw is a pure function of (store seed ^ scope, store
+    step counter, element index) read from device memory (pn2_dropout): replayable inside a captured hipGraph; the
+    trainer advances `store.rng_state[1]` once per step."""
+    if not is_training:
+        return inputs
+    if noise_shape is not None:
+        raise NotImplementedError("noise_shape is not used on the SA/FP path")
+    require_cuda(inputs)
+    st = get_default_store()
+    import zlib
+    key = _full_name(scope)
+    state = st.dropout_state(key, zlib.crc32(key.encode()))
+    return _Dropout.apply(inputs, keep_prob, state)

@@ -116,3 +116,66 @@ def test_flat_bucket_aliases_grads_and_survives_both_zero_grad_modes():
         before = w1.detach().clone()
         opt.step()
         assert torch.allclose(w1.detach(), before - 0.1 * ref1)
+
+
+def _overlap_worker(rank, world, port, q):
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    import pn2_amd as pn2
+    d = pn2.dist
+    d.init_from_env(backend="gloo")
+    torch.manual_seed(0)
+    # "layer*" parameters first (late bucket: their gradients arrive last), then the head (early bucket)
+    net = torch.nn.Sequential(torch.nn.Linear(6, 8), torch.nn.ReLU(), torch.nn.Linear(8, 8), torch.nn.ReLU(), torch.nn.Linear(8, 3))
+    params = list(net.parameters())
+    d.broadcast_parameters(params)
+    bucket = d.OverlappedGradAllReduce(params, split=4)  # Linear0 + Linear1 late, Linear2 (head) early
+    order = []
+    for i, p in enumerate(params):
+        p.register_post_accumulate_grad_hook(lambda _p, i=i: order.append((i, bucket.early_launched_in_backward)))
+    out = {"steps": []}
+    for step in range(2):
+        for p in params:
+            p.grad = None
+        x = torch.full((5, 6), float(rank + 1 + step))
+        bucket.begin()
+        net(x).pow(2).sum().backward()
+        local = [p.grad.clone() for p in params]
+        flat = bucket.finish().clone()
+        out["steps"].append({"local": [g.flatten().tolist() for g in local], "flat": flat.tolist(),
+                             "early_in_backward": bucket.early_launched_in_backward})
+        for p, v in zip(params, bucket.views):
+            assert p.grad.data_ptr() == v.data_ptr()
+    out["order"] = order
+    out["split_off"] = bucket.split_off
+    d.barrier()
+    torch.distributed.destroy_process_group()
+    q.put((rank, out))
+
+
+@pytest.mark.timeout(180)
+def test_world2_gloo_overlapped_two_bucket_allreduce():
+    """The trainer's gradient exchange (dist.OverlappedGradAllReduce) on a world-2 gloo group: the early bucket (head) is
+    packed and sent from inside backward, BEFORE the late layers' gradients exist; both ranks end with the same SUM of
+    the local gradients in one flat buffer; every p.grad aliases it."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_overlap_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = dict(q.get(timeout=150) for _ in range(2))
+    for p in procs:
+        p.join(30)
+        assert p.exitcode == 0
+    assert res[0]["split_off"] == 6 * 8 + 8 + 8 * 8 + 8
+    for step in range(2):
+        a, b_ = res[0]["steps"][step], res[1]["steps"][step]
+        assert a["early_in_backward"] and b_["early_in_backward"]
+        assert a["flat"] == b_["flat"]  # identical on both ranks
+        want = torch.cat([torch.tensor(x) + torch.tensor(y) for x, y in zip(a["local"], b_["local"])])
+        assert torch.allclose(torch.tensor(a["flat"]), want, rtol=1e-6, atol=1e-6)  # SUM (the optimizer divides by the world size)
+    # ordering: the head's gradients (params 4, 5) land first and trigger the early launch; when the late layers'
+    # gradients (params 0..3) land, the early bucket is already on its way
+    order = res[0]["order"][:6]
+    assert sorted(i for i, _ in order[:2]) == [4, 5]
+    assert all(flag for i, flag in order if i < 4)

@@ -381,7 +381,10 @@ def test_three_interpolate_grad_gather_path(pn2, oracle, cuda, c, m):
     assert "pn2_three_interpolate_grad_ws" in [t[0] for t in calls]
     ref = oracle.three_interpolate_grad(pts, idx, w, go)
     got = pt.grad.cpu().numpy()
-    assert np.allclose(got, ref, rtol=1e-4, atol=1e-4 * max(1.0, np.abs(ref).max() * 1e-2))
+    # both sides add ~3n/m fp32 terms per source in different orders (the oracle in index order, the kernel in list
+    # order): the tolerance scales with the random-walk rounding of that many terms (m = 5: 2458 terms per source)
+    atol = 1e-4 * max(1.0, np.abs(ref).max() * 1e-2) + 2e-6 * np.sqrt(3.0 * n / m) * np.abs(go).max()
+    assert np.allclose(got, ref, rtol=1e-4, atol=atol), np.abs(got - ref).max()
     if m > 3:
         assert not got[:, 3].any()
 

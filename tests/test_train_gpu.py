@@ -1,0 +1,209 @@
+"""GPU tests of the native training-step kernels: forward GEMM / data gradient on pn2_linear(_dgrad),
+weighted cross-entropy, dropout, Adam, the captured training step, and the folded-weight cache after training passes."""
+import numpy as np
+import pytest
+
+from conftest import s_scene
+from test_layers_gpu import T, close
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("rows,cin,cout", [(4096, 67, 64), (1000, 131, 128), (524288, 32, 32), (8192, 259, 256), (1024, 768, 256),
+                                           (777, 128, 9), (131072, 128, 128), (300, 6, 32), (16384, 320, 256), (64, 512, 256)])
+def test_linear_dgrad_and_matmul_vs_fp64(pn2, cuda, rows, cin, cout):
+    """dx = dy @ W^T straight from the forward layout of W (no transposed copy), any cin / cout; y = x @ W on pn2_linear."""
+    tfu = pn2.util.tf_util
+    rs = np.random.RandomState(rows % 997 + cin)
+    dy = rs.randn(rows, cout).astype(np.float32)
+    w = (rs.randn(cin, cout) / np.sqrt(cout)).astype(np.float32)
+    dx = tfu.hip_linear_dgrad(T(dy, cuda), T(w, cuda)).cpu().numpy()
+    assert dx.shape == (rows, cin)
+    close(dx, dy.astype(np.float64) @ w.astype(np.float64).T)
+    x = rs.randn(rows, cin).astype(np.float32)
+    w2 = (rs.randn(cin, cout) / np.sqrt(cin)).astype(np.float32)
+    y = tfu.hip_matmul(T(x, cuda), T(w2, cuda)).cpu().numpy()
+    assert y.shape == (rows, cout)
+    close(y, x.astype(np.float64) @ w2.astype(np.float64))
+
+
+def test_weighted_ce_forward_backward_vs_float64(pn2, oracle, cuda):
+    import torch
+    rs = np.random.RandomState(0)
+    for rows, c in [(131072, 9), (1000, 13), (5, 2)]:
+        logits = (rs.randn(rows, c) * 3).astype(np.float32)
+        labels = rs.randint(0, c, rows)
+        w = (rs.random_sample(rows) * 2).astype(np.float32)
+        w[: rows // 7] = 0.0
+        for ldt in (np.int64, np.int32):
+            lt = T(logits, cuda).requires_grad_(True)
+            loss = pn2.model.get_loss(lt.reshape(1, rows, c), T(labels.astype(ldt), cuda).reshape(1, rows), T(w, cuda).reshape(1, rows))
+            (loss * 2.5).backward()  # a non-trivial upstream gradient
+            ref = oracle.weighted_sparse_ce(logits.astype(np.float64).reshape(1, rows, c), labels.reshape(1, rows), w.reshape(1, rows))
+            assert abs(float(loss) - ref) <= 1e-5 * max(1.0, abs(ref))
+            z = torch.from_numpy(logits).double().requires_grad_(True)
+            ce = torch.nn.functional.cross_entropy(z, torch.from_numpy(labels), reduction="none")
+            wt = torch.from_numpy(w).double()
+            ((ce * wt).sum() / max(1, int((w != 0).sum())) * 2.5).backward()
+            close(lt.grad.cpu().numpy(), z.grad.numpy())
+    zero = pn2.model.get_loss(T(logits, cuda).reshape(1, rows, c), T(labels.astype(np.int64), cuda).reshape(1, rows),
+                              torch.zeros(1, rows, device=cuda))
+    assert float(zero) == 0.0  # no non-zero weight: tf.losses' safe division
+
+
+def test_dropout_statistics_scaling_and_replay(pn2, cuda):
+    import torch
+    tfu = pn2.util.tf_util
+    store = tfu.set_default_store(tfu.VariableStore(device=cuda, seed=9))
+    x = torch.ones(16, 8192, 128, device=cuda, requires_grad=True)
+    y = tfu.dropout(x, True, "dp1", keep_prob=0.5)
+    kept = (y != 0)
+    assert abs(float(kept.float().mean()) - 0.5) < 2e-3 and float(y[kept].min()) == float(y[kept].max()) == 2.0
+    y.sum().backward()
+    assert torch.equal(x.grad, kept.float() * 2.0)                      # same mask, same 1/keep_prob scale
+    assert torch.equal(tfu.dropout(x, True, "dp1", keep_prob=0.5), y)   # a pure function of (seed, step, index)
+    store.set_step(1)
+    y1 = tfu.dropout(x, True, "dp1", keep_prob=0.5)
+    assert not torch.equal(y1, y) and abs(float(((y1 != 0) & kept).float().mean()) - 0.25) < 2e-3  # independent draws
+    assert not torch.equal(tfu.dropout(x, True, "other", keep_prob=0.5), y1)  # another call site, another stream
+    assert tfu.dropout(x, False, "dp1", keep_prob=0.5) is x              # inference: identity (tf_util.py:646-665)
+    y3 = tfu.dropout(x, True, "dp3", keep_prob=0.9)
+    assert abs(float((y3 != 0).float().mean()) - 0.9) < 2e-3
+
+
+def test_adam_step_matches_tf_formula(pn2, cuda):
+    import torch
+    L = pn2._lib
+    rs = np.random.RandomState(1)
+    n = 100003
+    p = rs.randn(n).astype(np.float32); m = np.zeros(n, np.float32); v = np.zeros(n, np.float32)
+    tp, tm, tv = T(p.copy(), cuda), T(m.copy(), cuda), T(v.copy(), cuda)
+    b1, b2, eps, lr = 0.9, 0.999, 1e-8, 1e-3
+    pr, mr, vr = p.astype(np.float64), m.astype(np.float64), v.astype(np.float64)
+    for t in range(1, 4):
+        g = rs.randn(n).astype(np.float32) * (10.0 ** rs.randint(-3, 2))
+        lr_t = pn2.train.adam_lr_t(lr, t, b1, b2)
+        hyper = T(np.array([lr_t, b1, b2, eps, 0.5], np.float32), cuda)   # grad_scale 0.5 = 1/world for two ranks
+        L.check(L.lib.pn2_adam_step(n, L.ptr(tp), L.ptr(T(g, cuda)), L.ptr(tm), L.ptr(tv), L.ptr(hyper), L.stream_ptr()), "adam")
+        ge = g.astype(np.float64) * 0.5
+        # the kernel (like TensorFlow's fp32 kernel) holds beta1, beta2 and lr_t as float32 and forms 1 - beta in float32
+        f = np.float32
+        b1f, b2f, c1, c2, lrf = float(f(b1)), float(f(b2)), float(f(1) - f(b1)), float(f(1) - f(b2)), float(f(lr_t))
+        mr = b1f * mr + c1 * ge
+        vr = b2f * vr + c2 * ge * ge
+        pr = pr - lrf * mr / (np.sqrt(vr) + float(f(eps)))   # tf.train.AdamOptimizer: epsilon OUTSIDE the bias correction
+        np.testing.assert_allclose(tp.cpu().numpy(), pr, rtol=2e-6, atol=2e-7)
+        np.testing.assert_allclose(tm.cpu().numpy(), mr, rtol=2e-6, atol=1e-9)
+        np.testing.assert_allclose(tv.cpu().numpy(), vr, rtol=2e-6, atol=1e-12)
+
+
+def test_every_gemm_of_a_real_step_is_as_accurate_as_the_library(pn2, cuda):
+    """Every forward GEMM (pn2_linear) and data-gradient GEMM (pn2_linear_dgrad) of one real training step, on the
+    tensors the step actually produces, against float64: relative error <= 1e-6 and never worse than 2x torch.mm's."""
+    import torch
+    tfu = pn2.util.tf_util
+    hp = dict(pn2.model.SEMANTIC_HYPERPARAMS)
+    hp.update(l1_npoint=256, l2_npoint=64, l3_npoint=32, l4_npoint=16)
+    pc, labels, smpw = _batch(cuda, 0)
+    seen = []
+    orig_mm, orig_dg = tfu.hip_matmul, tfu.hip_linear_dgrad
+
+    def mm(x, w):
+        y = orig_mm(x, w)
+        ref = x.double() @ w.double()
+        seen.append(("fwd", tuple(x.shape), w.shape[1], float((y.double() - ref).norm() / ref.norm()),
+                     float(((x @ w).double() - ref).norm() / ref.norm())))
+        return y
+
+    def dg(dy, w):
+        dx = orig_dg(dy, w)
+        ref = dy.double() @ w.double().t()
+        seen.append(("dgrad", tuple(dy.shape), w.shape[0], float((dx.double() - ref).norm() / ref.norm()),
+                     float(((dy @ w.t()).double() - ref).norm() / ref.norm())))
+        return dx
+
+    tfu.hip_matmul, tfu.hip_linear_dgrad = mm, dg
+    try:
+        tfu.set_default_store(tfu.VariableStore(device=cuda, seed=5))
+        logits, _ = pn2.model.get_model(pc, True, 9, hp, bn_decay=0.5)
+        pn2.model.get_loss(logits, labels, smpw).backward()
+    finally:
+        tfu.hip_matmul, tfu.hip_linear_dgrad = orig_mm, orig_dg
+    assert sum(1 for s_ in seen if s_[0] == "fwd") == 23 and sum(1 for s_ in seen if s_[0] == "dgrad") == 22
+    for kind, shape, n, e_pn2, e_torch in seen:
+        assert e_pn2 <= 1e-6 and e_pn2 <= 2.0 * e_torch + 1e-8, (kind, shape, n, e_pn2, e_torch)
+
+
+def _batch(cuda, seed=0, b=8, n=2048):
+    rs = np.random.RandomState(seed)
+    pc = T(np.concatenate([s_scene(seed + 1, b, n), rs.random_sample((b, n, 3)).astype(np.float32)], 2), cuda)
+    labels = T(rs.randint(0, 9, (b, n)).astype(np.int64), cuda)
+    smpw = T((rs.random_sample((b, n)) + 0.5).astype(np.float32), cuda)
+    return pc, labels, smpw
+
+
+def test_captured_training_step_equals_eager(pn2, cuda):
+    """The hipGraph replay of the whole step (forward, loss, backward, Adam; step-dependent scalars in device memory)
+    follows the eager trajectory: same losses and weights up to the order of the fp32 atomics in the gradient kernels."""
+    import torch
+    hp = dict(pn2.model.SEMANTIC_HYPERPARAMS)
+    hp.update(l1_npoint=256, l2_npoint=64, l3_npoint=32, l4_npoint=16)
+    batches = [_batch(cuda, s) for s in range(3)]
+    out = {}
+    for key, capture in (("eager", False), ("eager2", False), ("graph", True)):
+        tr = pn2.train.Trainer(hp, 9, store=pn2.util.tf_util.VariableStore(device=cuda, seed=3), capture=capture, warmup_eager=2)
+        losses = [tr.train_step(*batches[i % 3]) for i in range(7)]
+        assert (tr._graph is not None) == capture
+        out[key] = (losses, tr.flat_p.clone(), {k: v.clone() for k, v in tr.store.buffers.items()})
+        assert tr.step_count == 7 and all(np.isfinite(losses))
+    np.testing.assert_allclose(out["graph"][0][:2], out["eager"][0][:2], rtol=1e-6)  # the eager warm-up steps are the same code
+    np.testing.assert_allclose(out["graph"][0], out["eager"][0], rtol=1e-2)          # then the trajectories stay together
+    # Adam's m / sqrt(v) turns the run-to-run noise of the fp32 atomics (gradient kernels) into O(lr) differences of
+    # individual weights: the yardstick is a second EAGER run, not zero
+    dist = lambda a, b: float((out[a][1] - out[b][1]).norm() / out[b][1].norm())  # noqa: E731
+    noise = dist("eager2", "eager")
+    assert dist("graph", "eager") <= 3.0 * noise + 1e-4, (dist("graph", "eager"), noise)
+    # moving averages: one update per step in both modes (a double update from set-up or capture would move them by
+    # O(1)); the yardstick is again the second eager run
+    cat = lambda key: torch.cat([out[key][2][k].flatten() for k in sorted(out[key][2])])  # noqa: E731
+    bdist = lambda a, b: float((cat(a) - cat(b)).norm() / cat(b).norm())  # noqa: E731
+    assert bdist("graph", "eager") <= 3.0 * bdist("eager2", "eager") + 1e-4, (bdist("graph", "eager"), bdist("eager2", "eager"))
+
+
+def test_trainer_setup_leaves_moving_averages_untouched_and_params_flat(pn2, cuda):
+    import torch
+    hp = dict(pn2.model.SEMANTIC_HYPERPARAMS)
+    hp.update(l1_npoint=128, l2_npoint=64, l3_npoint=32, l4_npoint=16)
+    pc, labels, smpw = _batch(cuda, 5, 4, 1024)
+    tr = pn2.train.Trainer(hp, 9, store=pn2.util.tf_util.VariableStore(device=cuda, seed=4), capture=False)
+    tr._lazy_init(pc)
+    for k, v in tr.store.buffers.items():
+        assert float(v.min()) == float(v.max()) == (0.0 if k.endswith("moving_mean") else 1.0), k  # tf_util.py:571-581
+    off = 0
+    for p in tr.store.parameters():  # every parameter is a view of the flat buffer, in creation order
+        assert p.data_ptr() == tr.flat_p.data_ptr() + 4 * off and p.grad is None
+        off += p.numel()
+    assert off == tr.flat_p.numel() == tr.bucket.numel
+    names = list(tr.store.params)
+    assert all(n.startswith("layer") for n in names[:tr.bucket.split]) and not names[tr.bucket.split].startswith("layer")
+    l0 = tr.train_step(pc, labels, smpw)
+    assert tr.bucket.early_launched_in_backward  # the early bucket was packed from inside backward
+    assert np.isfinite(l0)
+
+
+def test_eval_after_training_passes_uses_fresh_statistics(pn2, cuda):
+    """the HIP BN kernel updates the moving averages through raw pointers; folded inference weights must
+    not go stale when training-mode forwards run without an optimizer step in between."""
+    import torch
+    tfu = pn2.util.tf_util
+    store = tfu.set_default_store(tfu.VariableStore(device=cuda, seed=6))
+    x = torch.randn(2, 512, 1, 16, device=cuda) * 3 + 1
+    ev0 = tfu.conv2d(x, 32, [1, 1], scope="c", bn=True, is_training=False)
+    for _ in range(2):
+        tfu.conv2d(x, 32, [1, 1], scope="c", bn=True, is_training=True, bn_decay=0.5)
+    ev1 = tfu.conv2d(x, 32, [1, 1], scope="c", bn=True, is_training=False)
+    w, b = store.params["c/weights"].reshape(16, 32), store.params["c/biases"]
+    bnv = (store.params["c/bn/beta"], store.params["c/bn/gamma"], store.buffers["c/bn/moving_mean"], store.buffers["c/bn/moving_variance"])
+    ref = torch.relu(tfu._batch_norm_eval(x @ w + b, bnv))
+    assert not torch.allclose(ev0, ev1, atol=1e-3)  # the statistics did move
+    assert torch.allclose(ev1, ref, rtol=1e-4, atol=1e-4)

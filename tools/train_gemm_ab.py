@@ -8,7 +8,7 @@ lib = ctypes.CDLL(os.path.join(ROOT, "open3d-pointnet2-semantic3d_amd", "libpn2_
 P = ctypes.c_void_p
 
 # (rows, cin, cout) of every dense layer of the semantic.json model at B=16, N=8192
-LAYERS = [(524288, 9, 32), (524288, 32, 32), (524288, 32, 64), (131072, 67, 64), (131072, 64, 64), (131072, 64, 128),
+LAYERS = [(524288, 6, 32), (524288, 32, 32), (524288, 32, 64), (131072, 67, 64), (131072, 64, 64), (131072, 64, 128),
           (32768, 131, 128), (32768, 128, 128), (32768, 128, 256), (8192, 259, 256), (8192, 256, 256), (8192, 256, 512),
           (1024, 768, 256), (1024, 256, 256), (4096, 384, 256), (4096, 256, 256), (16384, 320, 256), (16384, 256, 128),
           (131072, 134, 128), (131072, 128, 128), (131072, 128, 128), (131072, 128, 128)]
@@ -35,12 +35,12 @@ def main():
         t_fp = timeit(lambda: lib.pn2_linear(rows, cin, cout, P(x.data_ptr()), P(w.data_ptr()), None, 0, 0, P(y.data_ptr()), st)) if rc == 0 else float("nan")
         err = (y - x @ w).abs().max().item() if rc == 0 else float("nan")
         t_d = timeit(lambda: torch.mm(dy, wt, out=dx))
-        ok = cin % 32 == 0
-        t_dp = timeit(lambda: lib.pn2_linear(rows, cout, cin, P(dy.data_ptr()), P(wt.data_ptr()), None, 0, 0, P(dx.data_ptr()), st)) if ok else float("nan")
-        print(f"{rows:7d} x {cin:3d} -> {cout:3d}: fwd torch {t_f:6.1f} us  pn2_linear {t_fp:6.1f} us (err {err:.1e}) | dx torch {t_d:6.1f} us  pn2_linear {t_dp:6.1f} us", flush=True)
-        tot["fwd_torch"] += t_f; tot["fwd_pn2"] += min(t_fp, t_f) if t_fp == t_fp else t_f
-        tot["dx_torch"] += t_d; tot["dx_pn2"] += min(t_dp, t_d) if t_dp == t_dp else t_d
-    print("totals (us; pn2 columns = best of the two per layer):", {k: round(v, 1) for k, v in tot.items()})
+        t_dp = timeit(lambda: lib.pn2_linear_dgrad(rows, cin, cout, P(dy.data_ptr()), P(w.data_ptr()), P(dx.data_ptr()), st))
+        derr = (dx - dy @ wt).abs().max().item()
+        print(f"{rows:7d} x {cin:3d} -> {cout:3d}: fwd torch {t_f:6.1f} us  pn2_linear {t_fp:6.1f} us (err {err:.1e}) | dx torch {t_d:6.1f} us  pn2_linear_dgrad {t_dp:6.1f} us (err {derr:.1e})", flush=True)
+        tot["fwd_torch"] += t_f; tot["fwd_pn2"] += t_fp if t_fp == t_fp else t_f
+        tot["dx_torch"] += t_d; tot["dx_pn2"] += t_dp
+    print("totals (us):", {k: round(v, 1) for k, v in tot.items()})
 
 if __name__ == "__main__":
     main()
