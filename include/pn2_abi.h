@@ -183,6 +183,8 @@ int pn2_linear(int rows, int cin, int cout, const float *x, const float *w,
  * (The reduction over all B*M*K rows that TF / hipBLASLt run as a tall-skinny GEMM.)  fp32 MFMA, partial tiles
  * merged with fp32 atomics: the summation order varies from run to run like the reference's atomicAdd gradients. */
 int pn2_linear_wgrad(int rows, int cin, int cout, const float *x, const float *dy, float *dw, void *stream);
+/* dw += x^T . dy (no zero fill: the caller owns the initial value, e.g. a gradient arena zero-filled once per step). */
+int pn2_linear_wgrad_accumulate(int rows, int cin, int cout, const float *x, const float *dy, float *dw, void *stream);
 
 /* Training-mode batch normalisation + ReLU of a dense layer's output y (rows,c), channels last
  * (util/tf_util.py:555-581 batch_norm_template -> tf.contrib.layers.batch_norm, applied by conv2d / conv1d /
@@ -213,6 +215,16 @@ int pn2_bn_relu_backward(long long rows, int c, const float *dz, const float *y,
                          const float *beta, const float *save_mean, const float *save_invstd, int relu,
                          int pool, const float *zmax, const float *ties, void *workspace,
                          size_t workspace_bytes, float *dy, float *dgamma, float *dbeta, void *stream);
+/* The two calls above with a workspace the CALLER has already zero-filled: one fill of an arena holding the scratch of
+ * every layer of a training step replaces one memset per call (88 per step for the semantic.json model). */
+int pn2_bn_relu_forward_ws0(long long rows, int c, const float *y, const float *gamma, const float *beta,
+                            const float *bias, float eps, float decay, int relu, int pool, float *running_mean,
+                            float *running_var, void *workspace, size_t workspace_bytes, float *save_mean,
+                            float *save_invstd, float *z, float *ties, void *stream);
+int pn2_bn_relu_backward_ws0(long long rows, int c, const float *dz, const float *y, const float *gamma,
+                             const float *beta, const float *save_mean, const float *save_invstd, int relu,
+                             int pool, const float *zmax, const float *ties, void *workspace,
+                             size_t workspace_bytes, float *dy, float *dgamma, float *dbeta, void *stream);
 
 /* Fused set-abstraction MLP (pointnet_util.py:43-54 + :150-170, inference BN
  * folded): for every (b, j) group gathers nsample neighbours by idx, builds

@@ -57,6 +57,11 @@ SIGNATURES = {
                                          ctypes.c_size_t, c_void_p],
     "pn2_sa_group_concat": [c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p,
                             c_void_p, c_void_p],
+    "pn2_bn_relu_forward_ws0": [ctypes.c_longlong, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_float, c_int, c_int,
+                            c_void_p, c_void_p, c_void_p, ctypes.c_size_t, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p],
+    "pn2_bn_relu_backward_ws0": [ctypes.c_longlong, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int,
+                             c_int, c_void_p, c_void_p, c_void_p, ctypes.c_size_t, c_void_p, c_void_p, c_void_p, c_void_p],
+    "pn2_linear_wgrad_accumulate": [c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p],
     "pn2_linear_dgrad": [c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p],
     "pn2_weighted_ce_forward": [c_int, c_int, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p],
     "pn2_weighted_ce_backward": [c_int, c_int, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
@@ -126,7 +131,7 @@ _raw = _load()
 
 
 # entry points that mutate caller state beyond their outputs (moving averages): never launched twice by the dup hook
-_STATEFUL = frozenset({"pn2_bn_relu_forward", "pn2_adam_step"})
+_STATEFUL = frozenset({"pn2_bn_relu_forward", "pn2_bn_relu_forward_ws0", "pn2_adam_step", "pn2_linear_wgrad_accumulate"})
 
 
 class _LibProxy:

@@ -440,10 +440,10 @@ extern "C" int pn2_debug_set_bn(int what, int value) {
 
 extern "C" size_t pn2_bn_workspace_bytes(int c) { return c > 0 ? sizeof(double) * bn_ws_doubles(c, kBnSlots) : 0; }
 
-extern "C" int pn2_bn_relu_forward(long long rows, int c, const float* y, const float* gamma, const float* beta,
-                                   const float* bias, float eps, float decay, int relu, int pool, float* running_mean,
-                                   float* running_var, void* workspace, size_t workspace_bytes, float* save_mean,
-                                   float* save_invstd, float* z, float* ties, void* stream) {
+static int bn_relu_forward_impl(long long rows, int c, const float* y, const float* gamma, const float* beta,
+                                const float* bias, float eps, float decay, int relu, int pool, float* running_mean,
+                                float* running_var, void* workspace, size_t workspace_bytes, float* save_mean,
+                                float* save_invstd, float* z, float* ties, void* stream, bool ws_zeroed) {
     if (!y || !gamma || !beta || !workspace || !save_mean || !save_invstd || !z) return PN2_ENULL;
     if ((running_mean == nullptr) != (running_var == nullptr)) return PN2_ENULL;
     if (pool > 1 && !ties) return PN2_ENULL;
@@ -455,8 +455,10 @@ extern "C" int pn2_bn_relu_forward(long long rows, int c, const float* y, const 
     hipStream_t st = static_cast<hipStream_t>(stream);
     double* ws = static_cast<double*>(workspace);
     const double* acc = ws + kBnHead;
-    hipError_t e = hipMemsetAsync(ws, 0, sizeof(double) * bn_ws_doubles(c, p.nslots), st);
-    if (e != hipSuccess) return (int)e;
+    if (!ws_zeroed) {
+        hipError_t e = hipMemsetAsync(ws, 0, sizeof(double) * bn_ws_doubles(c, p.nslots), st);
+        if (e != hipSuccess) return (int)e;
+    }
     const int fold_blocks = (2 * c + kBnThreads - 1) / kBnThreads;
     long long pb = 1;  // pooled apply: one group per (thread row slot), grid-stride beyond 8 blocks per CU
     if (pool > 1) {
@@ -484,10 +486,27 @@ extern "C" int pn2_bn_relu_forward(long long rows, int c, const float* y, const 
     return PN2_OK;
 }
 
-extern "C" int pn2_bn_relu_backward(long long rows, int c, const float* dz, const float* y, const float* gamma,
-                                    const float* beta, const float* save_mean, const float* save_invstd, int relu,
-                                    int pool, const float* zmax, const float* ties, void* workspace,
-                                    size_t workspace_bytes, float* dy, float* dgamma, float* dbeta, void* stream) {
+extern "C" int pn2_bn_relu_forward(long long rows, int c, const float* y, const float* gamma, const float* beta,
+                                   const float* bias, float eps, float decay, int relu, int pool, float* running_mean,
+                                   float* running_var, void* workspace, size_t workspace_bytes, float* save_mean,
+                                   float* save_invstd, float* z, float* ties, void* stream) {
+    return bn_relu_forward_impl(rows, c, y, gamma, beta, bias, eps, decay, relu, pool, running_mean, running_var, workspace,
+                                workspace_bytes, save_mean, save_invstd, z, ties, stream, false);
+}
+// the same with a workspace the CALLER has already zero-filled (one fill of an arena that holds the scratch of every layer
+// of a training step replaces one memset per call)
+extern "C" int pn2_bn_relu_forward_ws0(long long rows, int c, const float* y, const float* gamma, const float* beta,
+                                       const float* bias, float eps, float decay, int relu, int pool, float* running_mean,
+                                       float* running_var, void* workspace, size_t workspace_bytes, float* save_mean,
+                                       float* save_invstd, float* z, float* ties, void* stream) {
+    return bn_relu_forward_impl(rows, c, y, gamma, beta, bias, eps, decay, relu, pool, running_mean, running_var, workspace,
+                                workspace_bytes, save_mean, save_invstd, z, ties, stream, true);
+}
+
+static int bn_relu_backward_impl(long long rows, int c, const float* dz, const float* y, const float* gamma,
+                                 const float* beta, const float* save_mean, const float* save_invstd, int relu,
+                                 int pool, const float* zmax, const float* ties, void* workspace,
+                                 size_t workspace_bytes, float* dy, float* dgamma, float* dbeta, void* stream, bool ws_zeroed) {
     if (!dz || !y || !gamma || !beta || !save_mean || !save_invstd || !workspace || !dy || !dgamma || !dbeta) return PN2_ENULL;
     if (pool > 1 && (!zmax || !ties)) return PN2_ENULL;
     if (pool > 1 && (rows % pool != 0 || dy == dz)) return PN2_EINVAL;
@@ -499,8 +518,10 @@ extern "C" int pn2_bn_relu_backward(long long rows, int c, const float* dz, cons
     hipStream_t st = static_cast<hipStream_t>(stream);
     double* ws = static_cast<double*>(workspace);
     const double* acc = ws + kBnHead;
-    hipError_t e = hipMemsetAsync(ws, 0, sizeof(double) * bn_ws_doubles(c, p.nslots), st);
-    if (e != hipSuccess) return (int)e;
+    if (!ws_zeroed) {
+        hipError_t e = hipMemsetAsync(ws, 0, sizeof(double) * bn_ws_doubles(c, p.nslots), st);
+        if (e != hipSuccess) return (int)e;
+    }
     const int fold_blocks = (2 * c + kBnThreads - 1) / kBnThreads;
 #define PN2_BN_BWD(V_)                                                                                                  \
     do {                                                                                                                \
@@ -516,4 +537,19 @@ extern "C" int pn2_bn_relu_backward(long long rows, int c, const float* dz, cons
 #undef PN2_BN_BWD
     PN2_RETURN_IF_LAUNCH_FAILED();
     return PN2_OK;
+}
+
+extern "C" int pn2_bn_relu_backward(long long rows, int c, const float* dz, const float* y, const float* gamma,
+                                    const float* beta, const float* save_mean, const float* save_invstd, int relu,
+                                    int pool, const float* zmax, const float* ties, void* workspace,
+                                    size_t workspace_bytes, float* dy, float* dgamma, float* dbeta, void* stream) {
+    return bn_relu_backward_impl(rows, c, dz, y, gamma, beta, save_mean, save_invstd, relu, pool, zmax, ties, workspace,
+                                 workspace_bytes, dy, dgamma, dbeta, stream, false);
+}
+extern "C" int pn2_bn_relu_backward_ws0(long long rows, int c, const float* dz, const float* y, const float* gamma,
+                                        const float* beta, const float* save_mean, const float* save_invstd, int relu,
+                                        int pool, const float* zmax, const float* ties, void* workspace,
+                                        size_t workspace_bytes, float* dy, float* dgamma, float* dbeta, void* stream) {
+    return bn_relu_backward_impl(rows, c, dz, y, gamma, beta, save_mean, save_invstd, relu, pool, zmax, ties, workspace,
+                                 workspace_bytes, dy, dgamma, dbeta, stream, true);
 }

@@ -310,6 +310,51 @@ int launch_linear(int rows, int cin, int cout, const float* x, const float* w, c
     return PN2_OK;
 }
 
+// Data gradient of a layer with a handful of outputs (the 9-class head): dx[r][i] = sum_o dy[r][o] * w[i][o], K = n_out <= 16.
+// An MFMA tile would pad K to 32 and gather dy with scalar loads (measured 411 us at 131072 x 128 <- 9); this is a
+// streaming kernel bound by the dx write: thread = (row, 4 consecutive inputs), W (n_in x K) staged in LDS.
+template <int K>
+__global__ void __launch_bounds__(256)
+dgrad_smallk_kernel(int rows, int n_in, const float* __restrict__ dy, const float* __restrict__ w, float* __restrict__ dx) {
+    extern __shared__ float sw[];  // n_in * K
+    for (int e = threadIdx.x; e < n_in * K; e += 256) sw[e] = w[e];
+    __syncthreads();
+    const int groups = (n_in + 3) / 4;
+    const long long total = (long long)rows * groups;
+    for (long long t = (long long)blockIdx.x * 256 + threadIdx.x; t < total; t += (long long)gridDim.x * 256) {
+        const long long r = t / groups;
+        const int i0 = (int)(t - r * groups) * 4;
+        float d[K];
+#pragma unroll
+        for (int o = 0; o < K; ++o) d[o] = dy[r * K + o];
+        float acc[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int i = i0 + q < n_in ? i0 + q : n_in - 1;
+            float a = 0.f;
+#pragma unroll
+            for (int o = 0; o < K; ++o) a = __builtin_fmaf(d[o], sw[i * K + o], a);
+            acc[q] = a;
+        }
+        if (i0 + 4 <= n_in && (n_in & 3) == 0) {
+            *reinterpret_cast<f32x4*>(dx + r * n_in + i0) = f32x4{acc[0], acc[1], acc[2], acc[3]};
+        } else {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) if (i0 + q < n_in) dx[r * n_in + i0 + q] = acc[q];
+        }
+    }
+}
+
+template <int K>
+int launch_dgrad_smallk(int rows, int n_in, const float* dy, const float* w, float* dx, hipStream_t st) {
+    const long long total = (long long)rows * ((n_in + 3) / 4);
+    long long g = (total + 255) / 256;
+    if (g > 256 * 32) g = 256 * 32;
+    dgrad_smallk_kernel<K><<<(int)g, 256, (size_t)n_in * K * sizeof(float), st>>>(rows, n_in, dy, w, dx);
+    PN2_RETURN_IF_LAUNCH_FAILED();
+    return PN2_OK;
+}
+
 template <int WM, int WN, int NT>
 int launch_linear_dgrad(int rows, int n_in, int n_out, const float* dy, const float* w, float* dx, hipStream_t st) {
     constexpr int BM = 32 * WM, BN = 32 * NT * WN;
@@ -700,6 +745,14 @@ extern "C" int pn2_linear_dgrad(int rows, int cin, int cout, const float* dy, co
     if (!dy || !w || !dx) return PN2_ENULL;
     if ((long long)rows + 128 > 0x7fffffffLL) return PN2_ERANGE;
     hipStream_t st = static_cast<hipStream_t>(stream);
+    if (cout <= 16 && (size_t)cin * cout * sizeof(float) <= 48 * 1024) {
+        switch (cout) {
+#define PN2_SK(K_) case K_: return launch_dgrad_smallk<K_>(rows, cin, dy, w, dx, st);
+            PN2_SK(1) PN2_SK(2) PN2_SK(3) PN2_SK(4) PN2_SK(5) PN2_SK(6) PN2_SK(7) PN2_SK(8) PN2_SK(9) PN2_SK(10) PN2_SK(11)
+            PN2_SK(12) PN2_SK(13) PN2_SK(14) PN2_SK(15) PN2_SK(16)
+#undef PN2_SK
+        }
+    }
     if (cin <= 32) return launch_linear_dgrad<4, 1, 1>(rows, cin, cout, dy, w, dx, st);
     if (cin <= 64) return launch_linear_dgrad<4, 1, 2>(rows, cin, cout, dy, w, dx, st);
     if (cin <= 96) return launch_linear_dgrad<4, 1, 1>(rows, cin, cout, dy, w, dx, st);
@@ -716,13 +769,15 @@ extern "C" int pn2_debug_set_linear(int what, int value) {
 }
 
 // dW = x^T . dy (see linear_wgrad_kernel): the training path's weight gradient.  dw (cin, cout) is overwritten.
-extern "C" int pn2_linear_wgrad(int rows, int cin, int cout, const float* x, const float* dy, float* dw, void* stream) {
+static int linear_wgrad_impl(int rows, int cin, int cout, const float* x, const float* dy, float* dw, void* stream, bool accumulate) {
     if (rows <= 0 || cin <= 0 || cout <= 0) return PN2_EINVAL;
     if (!x || !dy || !dw) return PN2_ENULL;
     if ((long long)rows + 128 > 0x7fffffffLL) return PN2_ERANGE;
     hipStream_t st = static_cast<hipStream_t>(stream);
-    hipError_t e = hipMemsetAsync(dw, 0, sizeof(float) * (size_t)cin * cout, st);
-    if (e != hipSuccess) return (int)e;
+    if (!accumulate) {
+        hipError_t e = hipMemsetAsync(dw, 0, sizeof(float) * (size_t)cin * cout, st);
+        if (e != hipSuccess) return (int)e;
+    }
     // tile: up to 64 x 128 of dW per wave; rows split so that ~1024 waves (256 blocks) are in flight (>= 64 rows each;
     // measured best of 256..8192 over the training layer shapes, tools/wgrad_sweep.py);
     // each block adds its four partial tiles in LDS and issues one set of atomics
@@ -745,6 +800,14 @@ extern "C" int pn2_linear_wgrad(int rows, int cin, int cout, const float* x, con
 #undef PN2_WG
     PN2_RETURN_IF_LAUNCH_FAILED();
     return PN2_OK;
+}
+
+extern "C" int pn2_linear_wgrad(int rows, int cin, int cout, const float* x, const float* dy, float* dw, void* stream) {
+    return linear_wgrad_impl(rows, cin, cout, x, dy, dw, stream, false);
+}
+// dw += x^T . dy: the caller owns the initial value (e.g. a gradient arena zero-filled once per step)
+extern "C" int pn2_linear_wgrad_accumulate(int rows, int cin, int cout, const float* x, const float* dy, float* dw, void* stream) {
+    return linear_wgrad_impl(rows, cin, cout, x, dy, dw, stream, true);
 }
 
 // internal helper (exported for the host package's unfused SA path and for tests)

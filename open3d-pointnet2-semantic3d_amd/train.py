@@ -91,6 +91,11 @@ class Trainer:
 
     # ---- one step ------------------------------------------------------------------------------------------------
     def _step_body(self, pc, labels, smpw, decay):
+        if self.store.zero_arena is None:
+            self.store.zero_arena = tf_util.ZeroArena(self.flat_p.device)  # first step: measures what the step needs
+        elif self.store.zero_arena.buf is None:
+            self.store.zero_arena.allocate()
+        self.store.zero_arena.reset()  # ONE zero fill for every accumulator of the step
         for p in self.bucket.params:
             p.grad = None
         logits, _ = model.get_model(pc, True, self.num_class, self.hp, bn_decay=decay)
