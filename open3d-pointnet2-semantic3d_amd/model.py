@@ -87,9 +87,32 @@ def _sa_fp_features_two_streams(l0_xyz, l0_points, hyperparams):
     return up, xyzs
 
 
-def get_sa_fp_features(point_cloud, is_training, hyperparams, bn_decay=None, two_streams=False):
+def compute_geometry(l0_xyz, hyperparams):
+    """The weight-independent half of the whole stack for one batch: FPS + gather + ball query of the four SA levels and
+    three_nn of the four FP levels (coordinates only, HIP index kernels, no autograd).  A trainer runs it for batch k+1
+    on a side stream while batch k trains -- the 0.7 ms chain of dependent FPS rounds (16 of 256 CUs) then sits beside
+    the dense work instead of in front of it.  -> {"xyzs": [5], "idxs": [4], "nn": [4 x (dist, idx)], coarse to fine}."""
+    with torch.no_grad():
+        xyzs, idxs = [l0_xyz.contiguous()], []
+        for li in range(4):
+            k = "l%d_" % (li + 1)
+            new_xyz, idx = pu.sa_geometry(xyzs[-1], hyperparams[k + "npoint"], hyperparams[k + "radius"],
+                                          hyperparams[k + "nsample"])
+            xyzs.append(new_xyz)
+            idxs.append(idx)
+        nn = [three_nn(xyzs[3 - fi], xyzs[4 - fi]) for fi in range(4)]
+    return {"xyzs": xyzs, "idxs": idxs, "nn": nn}
+
+
+def geometry_tensors(geo):
+    """flat list of the tensors of a geometry dict (fixed order): for copies between static graph buffers"""
+    return geo["xyzs"][1:] + geo["idxs"] + [t for pair in geo["nn"] for t in pair]
+
+
+def get_sa_fp_features(point_cloud, is_training, hyperparams, bn_decay=None, two_streams=False, geometry=None):
     """point_cloud (B,N,3 or 6) -> l0_points (B,N,128) and end_points.
-    two_streams (inference only): overlap the geometry chain with the MLP chain."""
+    two_streams (inference only): overlap the geometry chain with the MLP chain.
+    geometry (extension): compute_geometry(l0_xyz) of this very batch, computed ahead."""
     end_points = {}
     if hyperparams["use_color"]:
         feature_size = 3 * int(hyperparams["use_color"])
@@ -110,7 +133,8 @@ def get_sa_fp_features(point_cloud, is_training, hyperparams, bn_decay=None, two
         new_xyz, new_points, _ = pointnet_sa_module(
             xyzs[-1], feats[-1], npoint=hyperparams[k + "npoint"], radius=hyperparams[k + "radius"],
             nsample=hyperparams[k + "nsample"], mlp=list(SA_MLPS[li]), mlp2=None, group_all=False,
-            is_training=is_training, bn_decay=bn_decay, scope="layer%d" % (li + 1))
+            is_training=is_training, bn_decay=bn_decay, scope="layer%d" % (li + 1),
+            geometry=None if geometry is None else (geometry["xyzs"][li + 1], geometry["idxs"][li]))
         xyzs.append(new_xyz)
         feats.append(new_points)
 
@@ -119,14 +143,14 @@ def get_sa_fp_features(point_cloud, is_training, hyperparams, bn_decay=None, two
     for fi in range(4):
         lvl = 3 - fi  # target level: 3,2,1,0
         up = pointnet_fp_module(xyzs[lvl], xyzs[lvl + 1], feats[lvl], up, list(FP_MLPS[fi]), is_training, bn_decay,
-                                scope="fa_layer%d" % (fi + 1))
+                                scope="fa_layer%d" % (fi + 1), nn=None if geometry is None else geometry["nn"][fi])
     end_points["xyzs"] = xyzs
     return up, end_points
 
 
-def get_model(point_cloud, is_training, num_class, hyperparams, bn_decay=None):
+def get_model(point_cloud, is_training, num_class, hyperparams, bn_decay=None, geometry=None):
     """-> logits (B,N,num_class), end_points (model.py:22-148)."""
-    l0_points, end_points = get_sa_fp_features(point_cloud, is_training, hyperparams, bn_decay)
+    l0_points, end_points = get_sa_fp_features(point_cloud, is_training, hyperparams, bn_decay, geometry=geometry)
     net = tf_util.conv1d(l0_points, 128, 1, padding="VALID", bn=True, is_training=is_training, scope="fc1",
                          bn_decay=bn_decay)
     end_points["feats"] = net

@@ -50,6 +50,7 @@ class Trainer:
         self.bucket = None
         self.capture, self.warmup_eager = bool(capture), int(warmup_eager)
         self._graph, self._graph_decay, self._static, self._stream = None, None, None, None
+        self._static_geo, self._geo, self._geo_tag, self._geo_event, self._geo_stream = None, None, None, None, None
 
     # ---- set-up ------------------------------------------------------------------------------------------------
     def _lazy_init(self, pc):
@@ -87,10 +88,11 @@ class Trainer:
         self.bucket = pdist.OverlappedGradAllReduce(params, split)
         self.hyper = torch.zeros(5, dtype=torch.float32, device=dev)
         self._stream = torch.cuda.Stream(device=dev) if dev.type == "cuda" else None
+        self._geo_stream = torch.cuda.Stream(device=dev) if dev.type == "cuda" else None
         self._hyper_host = torch.zeros(5, dtype=torch.float32).pin_memory() if dev.type == "cuda" else torch.zeros(5)
 
     # ---- one step ------------------------------------------------------------------------------------------------
-    def _step_body(self, pc, labels, smpw, decay):
+    def _step_body(self, pc, labels, smpw, decay, geometry=None):
         if self.store.zero_arena is None:
             self.store.zero_arena = tf_util.ZeroArena(self.flat_p.device)  # first step: measures what the step needs
         elif self.store.zero_arena.buf is None:
@@ -98,7 +100,7 @@ class Trainer:
         self.store.zero_arena.reset()  # ONE zero fill for every accumulator of the step
         for p in self.bucket.params:
             p.grad = None
-        logits, _ = model.get_model(pc, True, self.num_class, self.hp, bn_decay=decay)
+        logits, _ = model.get_model(pc, True, self.num_class, self.hp, bn_decay=decay, geometry=geometry)
         loss = model.get_loss(logits, labels, smpw)
         self.bucket.begin()
         loss.backward()
@@ -108,9 +110,43 @@ class Trainer:
                                     ptr(self.hyper), stream_ptr()), "pn2_adam_step")
         return loss.detach()
 
-    def train_step(self, pc, labels, smpw, sync=True):
+    # ---- geometry prefetch -----------------------------------------------------------------------------------------
+    def _xyz_of(self, pc):
+        return pc[:, :, 0:3].contiguous() if self.hp["use_color"] else pc.contiguous()
+
+    def _geometry_for(self, pc, caller):
+        """geometry of THIS batch: taken from the prefetch when `pc` is the tensor announced as `next_pc` by the previous
+        call, computed now otherwise.  Returns with `caller` (a stream) ordered after its completion."""
+        tag = (pc.data_ptr(), pc._version, tuple(pc.shape))
+        if self._geo is not None and self._geo_tag == tag:
+            caller.wait_event(self._geo_event)
+            geo = self._geo
+            for t in model.geometry_tensors(geo):
+                t.record_stream(caller)  # allocated on the side stream, consumed on this one
+        else:
+            geo = model.compute_geometry(self._xyz_of(pc), self.hp)
+        self._geo, self._geo_tag = None, None
+        return geo
+
+    def _prefetch(self, next_pc, after_event):
+        """launch the geometry of the NEXT batch on the side stream; it may start once `after_event` has passed (the
+        consumer of the previous prefetch has taken its copy)."""
+        if next_pc is None:
+            return
+        g = self._geo_stream
+        g.wait_event(after_event)
+        with torch.cuda.stream(g):
+            self._geo = model.compute_geometry(self._xyz_of(next_pc), self.hp)
+            self._geo_event = torch.cuda.Event()
+            self._geo_event.record(g)
+        self._geo_tag = (next_pc.data_ptr(), next_pc._version, tuple(next_pc.shape))
+
+    def train_step(self, pc, labels, smpw, sync=True, next_pc=None):
         """pc (B,N,6) float32, labels (B,N) int, smpw (B,N) float32 -> loss (python float; the device scalar when
-        sync=False, to be read after the next synchronisation point)."""
+        sync=False, to be read after the next synchronisation point).
+        next_pc: the point cloud of the NEXT call (optional).  Its FPS / ball-query / three_nn chain -- weight-independent,
+        latency-bound, 16 of 256 CUs -- then runs on a side stream beside this step's dense work instead of in front of
+        the next one (what the reference's mp.Pool data loader does for its CPU pre-processing)."""
         tf_util.set_default_store(self.store)
         if self.bucket is None:
             self._lazy_init(pc)
@@ -122,25 +158,34 @@ class Trainer:
         self._hyper_host.copy_(torch.tensor([adam_lr_t(lr, t, self.BETA1, self.BETA2), self.BETA1, self.BETA2, self.EPS,
                                              1.0 / world], dtype=torch.float32))
         use_graph = self.capture and world == 1 and pc.is_cuda and self.step_count >= self.warmup_eager
+        caller = torch.cuda.current_stream()
         if not use_graph:
             self.hyper.copy_(self._hyper_host, non_blocking=True)
             self.store.set_step(self.step_count)
-            loss = self._step_body(pc, labels, smpw, decay)
+            geo = self._geometry_for(pc, caller)
+            taken = torch.cuda.Event()
+            taken.record(caller)
+            self._prefetch(next_pc, taken)
+            loss = self._step_body(pc, labels, smpw, decay, geometry=geo)
         else:
             # Replays and the per-step writes they depend on run on the trainer's OWN stream.  Launching the graph into
             # the null stream is not safe on this stack: work queued on the null stream after hipGraphLaunch started
             # before the graph had finished (the next step's input copy then faulted with "write access to a read-only
             # page" around the 13th replay; a device-wide synchronise in between hid it).
-            caller = torch.cuda.current_stream()
             self._stream.wait_stream(caller)
             with torch.cuda.stream(self._stream):
+                geo = self._geometry_for(pc, self._stream)
                 if self._graph is None or self._graph_decay != decay or self._static[0].shape != pc.shape:
-                    self._capture(pc, labels, smpw, decay)
+                    self._capture(pc, labels, smpw, decay, geo)
                 self.hyper.copy_(self._hyper_host, non_blocking=True)
                 self.store.set_step(self.step_count)
                 for dst, src in zip(self._static[:3], (pc, labels, smpw)):
                     if dst.data_ptr() != src.data_ptr():
                         dst.copy_(src, non_blocking=True)
+                torch._foreach_copy_(model.geometry_tensors(self._static_geo), model.geometry_tensors(geo))
+                taken = torch.cuda.Event()
+                taken.record(self._stream)
+                self._prefetch(next_pc, taken)
                 self._graph.replay()
                 loss = self._static[3]
                 if sync:
@@ -149,14 +194,16 @@ class Trainer:
         self.step_count += 1
         return float(loss) if sync else loss
 
-    def _capture(self, pc, labels, smpw, decay):
-        """record forward + loss + backward + Adam of one step into a hipGraph (static input buffers)."""
+    def _capture(self, pc, labels, smpw, decay, geo):
+        """record forward + loss + backward + Adam of one step into a hipGraph (static input and geometry buffers)."""
         torch.cuda.synchronize()
         st = [pc.clone(), labels.clone(), smpw.clone()]
+        sg = {"xyzs": [self._xyz_of(st[0])] + [t.clone() for t in geo["xyzs"][1:]], "idxs": [t.clone() for t in geo["idxs"]],
+              "nn": [(d.clone(), i.clone()) for d, i in geo["nn"]]}
         for p in self.bucket.params:
             p.grad = None
         g = torch.cuda.CUDAGraph()
         with torch.cuda.graph(g):
-            loss = self._step_body(st[0], st[1], st[2], decay)
-        self._graph, self._graph_decay, self._static = g, decay, st + [loss]
+            loss = self._step_body(st[0], st[1], st[2], decay, geometry=sg)
+        self._graph, self._graph_decay, self._static, self._static_geo = g, decay, st + [loss], sg
         # the capture itself executed nothing: the replay that follows is this step

@@ -22,13 +22,18 @@ from ..tf_ops.tf_interpolate import three_interpolate, three_nn
 from ..tf_ops.tf_sampling import farthest_point_sample, farthest_point_sample_and_gather, gather_point
 
 
-def sample_and_group(npoint, radius, nsample, xyz, points, knn=False, use_xyz=True):
-    """-> new_xyz (B,npoint,3), new_points (B,npoint,nsample,3+C), idx, grouped_xyz."""
-    new_xyz = gather_point(xyz, farthest_point_sample(npoint, xyz))
-    if knn:
-        _, idx = knn_point(nsample, xyz, new_xyz)
+def sample_and_group(npoint, radius, nsample, xyz, points, knn=False, use_xyz=True, geometry=None):
+    """-> new_xyz (B,npoint,3), new_points (B,npoint,nsample,3+C), idx, grouped_xyz.
+    geometry = (new_xyz, idx) (extension): the weight-independent half -- FPS, gather, ball query -- was computed
+    ahead (model.compute_geometry on a side stream); only the grouping runs here."""
+    if geometry is not None:
+        new_xyz, idx = geometry
     else:
-        idx, pts_cnt = query_ball_point(radius, nsample, xyz, new_xyz)
+        new_xyz = gather_point(xyz, farthest_point_sample(npoint, xyz))
+        if knn:
+            _, idx = knn_point(nsample, xyz, new_xyz)
+        else:
+            idx, pts_cnt = query_ball_point(radius, nsample, xyz, new_xyz)
     grouped_xyz = group_point(xyz, idx)
     grouped_xyz = grouped_xyz - new_xyz.unsqueeze(2)  # translation normalisation (:44-46)
     if points is not None:
@@ -159,8 +164,9 @@ def sa_features_inference(xyz, new_xyz, points, idx, mlp, bn=True, bn_decay=None
 
 
 def pointnet_sa_module(xyz, points, npoint, radius, nsample, mlp, mlp2, group_all, is_training, bn_decay, scope,
-                       bn=True, pooling="max", knn=False, use_xyz=True, use_nchw=False):
-    """PointNet Set Abstraction module -> new_xyz (B,npoint,3), new_points (B,npoint,mlp[-1] or mlp2[-1]), idx."""
+                       bn=True, pooling="max", knn=False, use_xyz=True, use_nchw=False, geometry=None):
+    """PointNet Set Abstraction module -> new_xyz (B,npoint,3), new_points (B,npoint,mlp[-1] or mlp2[-1]), idx.
+    geometry = (new_xyz, idx) (extension, training path): precomputed FPS / ball-query result of this level."""
     require_cuda(xyz, points)
     if use_nchw:
         raise NotImplementedError("use_nchw is a TF layout hint; the MI355X kernels are channels-last only")
@@ -168,7 +174,7 @@ def pointnet_sa_module(xyz, points, npoint, radius, nsample, mlp, mlp2, group_al
         if not is_training and not group_all and not knn and use_xyz and pooling == "max":
             # ---- inference fast path: HIP index ops + fused / MFMA MLP -------------
             xyz = xyz.contiguous()
-            new_xyz, idx = sa_geometry(xyz, npoint, radius, nsample)
+            new_xyz, idx = geometry if geometry is not None else sa_geometry(xyz, npoint, radius, nsample)
             new_points = sa_features_inference(xyz, new_xyz, points, idx, mlp, bn, bn_decay)
             new_points = new_points.unsqueeze(2)
         else:
@@ -177,7 +183,7 @@ def pointnet_sa_module(xyz, points, npoint, radius, nsample, mlp, mlp2, group_al
                 new_xyz, new_points, idx, grouped_xyz = sample_and_group_all(xyz, points, use_xyz)
             else:
                 new_xyz, new_points, idx, grouped_xyz = sample_and_group(npoint, radius, nsample, xyz, points, knn,
-                                                                         use_xyz)
+                                                                         use_xyz, geometry=geometry)
             # training: the max over K rides in the last layer's batch-norm kernels (tf_util._TrainDenseBnRelu)
             fuse_pool = bool(is_training) and pooling == "max" and len(mlp) > 0 and nsample <= 1024
             for i, cout in enumerate(mlp):
@@ -336,12 +342,12 @@ def fp_features_inference(dist, idx, points1, points2, mlp, bn=True, bn_decay=No
     return h.reshape(b, n, mlp[-1])
 
 
-def pointnet_fp_module(xyz1, xyz2, points1, points2, mlp, is_training, bn_decay, scope, bn=True):
+def pointnet_fp_module(xyz1, xyz2, points1, points2, mlp, is_training, bn_decay, scope, bn=True, nn=None):
     """Feature propagation: xyz1 (B,n1,3) dense, xyz2 (B,n2,3) sparse, points1 (B,n1,c1) or None,
-    points2 (B,n2,c2) -> (B,n1,mlp[-1])."""
+    points2 (B,n2,c2) -> (B,n1,mlp[-1]).  nn = (dist, idx) (extension): three_nn(xyz1, xyz2) computed ahead."""
     require_cuda(xyz1, xyz2, points1, points2)
     with tf_util.variable_scope(scope):
-        dist, idx = three_nn(xyz1, xyz2)
+        dist, idx = nn if nn is not None else three_nn(xyz1, xyz2)
         if not is_training:
             # weights + interpolate + concat fused, then LDS-resident MLP chains / MFMA layers
             return fp_features_inference(dist, idx, points1, points2, mlp, bn, bn_decay)

@@ -170,6 +170,31 @@ def test_captured_training_step_equals_eager(pn2, cuda):
     assert bdist("graph", "eager") <= 3.0 * bdist("eager2", "eager") + 1e-4, (bdist("graph", "eager"), bdist("eager2", "eager"))
 
 
+def test_geometry_prefetch_is_the_same_geometry(pn2, cuda):
+    """train_step(..., next_pc=...) runs the next batch's FPS / ball query / three_nn on a side stream: bit-identical
+    geometry (it is the same kernels on the same coordinates), same training trajectory; a batch that was NOT announced
+    is recomputed instead of being served stale geometry."""
+    import torch
+    hp = dict(pn2.model.SEMANTIC_HYPERPARAMS)
+    hp.update(l1_npoint=256, l2_npoint=64, l3_npoint=32, l4_npoint=16)
+    batches = [_batch(cuda, s) for s in range(3)]
+    g0 = pn2.model.compute_geometry(batches[1][0][:, :, :3].contiguous(), hp)
+    for capture in (False, True):
+        tr = pn2.train.Trainer(hp, 9, store=pn2.util.tf_util.VariableStore(device=cuda, seed=3), capture=capture, warmup_eager=2)
+        ref = pn2.train.Trainer(hp, 9, store=pn2.util.tf_util.VariableStore(device=cuda, seed=3), capture=capture, warmup_eager=2)
+        la, lb = [], []
+        for i in range(6):
+            nxt = batches[(i + 1) % 3][0] if i != 3 else batches[0][0]   # step 3 announces the WRONG batch
+            la.append(tr.train_step(*batches[i % 3], next_pc=nxt))
+            if i == 0:  # the prefetched geometry of batch 1 is what compute_geometry gives
+                torch.cuda.synchronize()
+                for a, b_ in zip(pn2.model.geometry_tensors(tr._geo), pn2.model.geometry_tensors(g0)):
+                    assert torch.equal(a, b_)
+            lb.append(ref.train_step(*batches[i % 3]))
+        np.testing.assert_allclose(la[:2], lb[:2], rtol=1e-6)
+        np.testing.assert_allclose(la, lb, rtol=1e-2)
+
+
 def test_trainer_setup_leaves_moving_averages_untouched_and_params_flat(pn2, cuda):
     import torch
     hp = dict(pn2.model.SEMANTIC_HYPERPARAMS)
