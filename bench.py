@@ -408,6 +408,8 @@ def main():
     B, N = args.batch, args.points
     for kv in args.debug_set:
         what, value = kv.split("=")
+        if not hasattr(pn2._lib._raw, "pn2_debug_set"):
+            raise SystemExit("--debug-set needs a tuning build of the library: python open3d-pointnet2-semantic3d_amd/build.py --tuning")
         assert pn2._lib._raw.pn2_debug_set(int(what), int(value)) == 0
     if args.train:
         bench_train(pn2, args, hp, B, N, rank, world, dev)

@@ -16,7 +16,8 @@
  *
  * Conventions: all tensors dense row-major contiguous DEVICE memory; float =
  * IEEE fp32; indices int32.  The caller owns every buffer (outputs and scratch);
- * the library never allocates, never synchronises and keeps no pointers.
+ * the library never allocates, never synchronises, keeps no pointers and has no mutable global state (the kernel-
+ * selection knobs of the A/B scripts exist only in a -DPN2_TUNING_HOOKS build, csrc/pn2_common.h).
  * Re-entrant; safe from several host threads on different streams.
  */
 #ifndef PN2_ABI_H_
@@ -102,6 +103,12 @@ int pn2_gather_point_grad(int b, int n, int m, const float *out_g, const int *id
 int pn2_query_ball_point(int b, int n, int m, float radius, int nsample,
                          const float *xyz1, const float *xyz2, int *idx,
                          int *pts_cnt, int arith_mode, void *stream);
+/* The same operator on an explicitly chosen kernel -- 0 by shape (= pn2_query_ball_point), 1 wave-per-queries scan,
+ * 2 lane-per-query scan, 3 LDS grid; a kernel whose preconditions do not hold falls through to the next.  Every kernel
+ * returns the same bits; this door lets the parity tests hold each of them to the oracle.  Stateless. */
+int pn2_query_ball_point_kernel(int b, int n, int m, float radius, int nsample, const float *xyz1,
+                                const float *xyz2, int *idx, int *pts_cnt, int arith_mode, int kernel,
+                                void *stream);
 
 /* Multi-radius ball query for MSG set abstraction (util/pointnet_util.py:245-250 calls query_ball_point once per
  * radius on the same xyz / new_xyz): ONE scan of xyz1, every squared distance tested against all thresholds.

@@ -24,6 +24,8 @@ SIGNATURES = {
     "pn2_gather_point": [c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p],
     "pn2_gather_point_grad": [c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p],
     "pn2_query_ball_point": [c_int, c_int, c_int, c_float, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p],
+    "pn2_query_ball_point_kernel": [c_int, c_int, c_int, c_float, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int,
+                                    c_void_p],
     "pn2_query_ball_point_multi": [c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                    c_int, c_void_p],
     "pn2_selection_sort": [c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p],

@@ -70,4 +70,8 @@ def build(force=False, verbose=False, extra_flags=(), out=None):
 
 
 if __name__ == "__main__":
-    print(build(force="--force" in sys.argv, verbose="--verbose" in sys.argv))
+    # --tuning: compile the kernel-selection knobs of the A/B scripts (tools/) as process-global variables behind
+    # pn2_debug_set (csrc/pn2_common.h PN2_TUNABLE).  Experiments only: the shipped library has no mutable global state.
+    tuning = "--tuning" in sys.argv
+    print(build(force="--force" in sys.argv or tuning, verbose="--verbose" in sys.argv,
+                extra_flags=["-DPN2_TUNING_HOOKS"] if tuning else ()))

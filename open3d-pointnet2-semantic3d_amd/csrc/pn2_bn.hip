@@ -399,7 +399,7 @@ bn_grad_apply_kernel(long long rows, int c, const float* __restrict__ dz, const 
     }
 }
 
-int g_bn_blocks = 0;  // tuning hook (pn2_debug_set(10, v)): reduction blocks, 0 = kBnBlocks
+PN2_TUNABLE(int, g_bn_blocks, 0)  // tuning hook (pn2_debug_set(10, v)): reduction blocks, 0 = kBnBlocks
 
 struct BnPlan {
     int vec, nslots;
@@ -433,10 +433,12 @@ int bn_plan(long long rows, int c, const void* a, const void* b, const void* o, 
 
 }  // namespace
 
+#ifdef PN2_TUNING_HOOKS
 extern "C" int pn2_debug_set_bn(int what, int value) {
     if (what == 10) { g_bn_blocks = value; return 0; }
     return PN2_EINVAL;
 }
+#endif  // PN2_TUNING_HOOKS
 
 extern "C" size_t pn2_bn_workspace_bytes(int c) { return c > 0 ? sizeof(double) * bn_ws_doubles(c, kBnSlots) : 0; }
 

@@ -9,6 +9,15 @@
 
 #define PN2_WAVE 64
 
+// Kernel-selection knobs used by the A/B scripts under tools/.  In the shipped library they are compile-time constants:
+// the library keeps NO mutable global state (include/pn2_abi.h).  A tuning build (`build.py --tuning`,
+// -DPN2_TUNING_HOOKS) turns them into process-global variables behind pn2_debug_set(what, value) -- experiments only.
+#ifdef PN2_TUNING_HOOKS
+#define PN2_TUNABLE(type, name, value) type name = value;
+#else
+#define PN2_TUNABLE(type, name, value) static constexpr type name = value;
+#endif
+
 #define PN2_RETURN_IF_LAUNCH_FAILED()                 \
     do {                                              \
         hipError_t e__ = hipGetLastError();           \

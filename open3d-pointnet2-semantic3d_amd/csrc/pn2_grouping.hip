@@ -747,9 +747,9 @@ int launch_ball_query_grid(int b, int n, int m, float radius, float thr, int nsa
     return PN2_OK;
 }
 
-int g_bq_variant = 0;  // tuning hook (pn2_debug_set(2, v)): 0 = auto, 1 = wave-per-queries kernel, 2 = lane kernel, 3 = LDS grid kernel
+PN2_TUNABLE(int, g_bq_variant, 0)  // tuning hook (pn2_debug_set(2, v)): 0 = auto, 1 = wave-per-queries kernel, 2 = lane kernel, 3 = LDS grid kernel
 
-int g_bq_qpw = 8;  // tuning hook (pn2_debug_set(1, v))
+PN2_TUNABLE(int, g_bq_qpw, 8)  // tuning hook (pn2_debug_set(1, v))
 
 template <int MODE, int QPW>
 int launch_ball_query_q(int b, int n, int m, float thr, int nsample, const float* xyz1,
@@ -762,18 +762,21 @@ int launch_ball_query_q(int b, int n, int m, float thr, int nsample, const float
     return PN2_OK;
 }
 
+// kernel: 0 = choose by shape, 1 = wave-per-queries scan, 2 = lane-per-query scan, 3 = LDS grid (explicit values come from
+// pn2_query_ball_point_kernel, the test / diagnostic door; every kernel returns the same bits)
 template <int MODE>
 int launch_ball_query(int b, int n, int m, float radius, float thr, int nsample, const float* xyz1,
-                      const float* xyz2, int* idx, int* cnt, hipStream_t st) {
+                      const float* xyz2, int* idx, int* cnt, hipStream_t st, int kernel = 0) {
+    if (kernel == 0) kernel = g_bq_variant;
     // per-block LDS grid: the whole cloud fits LDS, enough points / queries to amortise building it in every
     // workgroup, and a neighbourhood size (nsample <= 32 is the caller's own estimate of the hits per ball) for which
     // the hit lists stay short; dense balls are cheaper on the ordered scan kernels (profiles/r01_ball_query_grid.txt)
     const bool grid_ok = n <= kBqgMaxN && n >= 4096 && m >= 256 && nsample <= 64 && radius < 1e18f;
-    if ((g_bq_variant == 3 && n <= kBqgMaxN && nsample <= 64 && radius < 1e18f) || (g_bq_variant == 0 && grid_ok))
+    if ((kernel == 3 && n <= kBqgMaxN && nsample <= 64 && radius < 1e18f) || (kernel == 0 && grid_ok))
         return launch_ball_query_grid<MODE>(b, n, m, radius, thr, nsample, xyz1, xyz2, idx, cnt, st);
     // lane = query kernel whenever its LDS lists fit and there are enough queries to fill 64 lanes
     const bool lane_ok = nsample <= 64 && m >= 32 && n <= 65535 * kBq2Waves;
-    if (g_bq_variant == 2 || (g_bq_variant == 0 && lane_ok))
+    if ((kernel == 2 && nsample <= 64 && n <= 65535 * kBq2Waves) || (kernel == 0 && lane_ok))
         return launch_ball_query_lane<MODE>(b, n, m, thr, nsample, xyz1, xyz2, idx, cnt, st);
     // fewer queries per wave when there are too few queries to fill the chip (>= ~4 waves/SIMD wanted)
     int qpw = g_bq_qpw;
@@ -787,7 +790,7 @@ int launch_ball_query(int b, int n, int m, float radius, float thr, int nsample,
 // grid.y = batch; e indexes the (m*nsample*c/VEC) vector elements of one batch.  UNR independent
 // 16-byte gathers are in flight per thread before the first store (memory-level parallelism);
 // NT selects non-temporal stores (the output is written once and never re-read by this kernel).
-int g_gp_variant = 0;  // tuning hook (pn2_debug_set(3, v)): bit0 = plain stores, bits 4.. = blocks-per-CU override
+PN2_TUNABLE(int, g_gp_variant, 0)  // tuning hook (pn2_debug_set(3, v)): bit0 = plain stores, bits 4.. = blocks-per-CU override
 
 template <typename VT, int VEC, int UNR, bool NT>
 __global__ void __launch_bounds__(256)
@@ -912,16 +915,17 @@ inline int grid_x_for(unsigned long long total, int block, int batches) {
 
 }  // namespace
 
+#ifdef PN2_TUNING_HOOKS
 extern "C" int pn2_debug_set_grouping(int what, int value) {
     if (what == 1) { g_bq_qpw = value; return 0; }
     if (what == 2) { g_bq_variant = value; return 0; }
     if (what == 3) { g_gp_variant = value; return 0; }
     return PN2_EINVAL;
 }
+#endif  // PN2_TUNING_HOOKS
 
-extern "C" int pn2_query_ball_point(int b, int n, int m, float radius, int nsample,
-                                    const float* xyz1, const float* xyz2, int* idx, int* pts_cnt,
-                                    int arith_mode, void* stream) {
+static int query_ball_point_impl(int b, int n, int m, float radius, int nsample, const float* xyz1, const float* xyz2,
+                                 int* idx, int* pts_cnt, int arith_mode, int kernel, void* stream) {
     if (b <= 0 || n <= 0 || m <= 0 || nsample <= 0) return PN2_EINVAL;
     if (!(radius > 0.0f)) return PN2_EINVAL;  // tf_grouping.cpp:80-83 "expects positive radius"
     if (!xyz1 || !xyz2 || !idx || !pts_cnt) return PN2_ENULL;
@@ -929,11 +933,27 @@ extern "C" int pn2_query_ball_point(int b, int n, int m, float radius, int nsamp
     hipStream_t st = static_cast<hipStream_t>(stream);
     const float thr = ball_threshold(radius);
     switch (arith_mode) {
-        case PN2_ARITH_STRICT: return launch_ball_query<PN2_ARITH_STRICT>(b, n, m, radius, thr, nsample, xyz1, xyz2, idx, pts_cnt, st);
-        case PN2_ARITH_FMA: return launch_ball_query<PN2_ARITH_FMA>(b, n, m, radius, thr, nsample, xyz1, xyz2, idx, pts_cnt, st);
-        case PN2_ARITH_FMA_ALT: return launch_ball_query<PN2_ARITH_FMA_ALT>(b, n, m, radius, thr, nsample, xyz1, xyz2, idx, pts_cnt, st);
+        case PN2_ARITH_STRICT: return launch_ball_query<PN2_ARITH_STRICT>(b, n, m, radius, thr, nsample, xyz1, xyz2, idx, pts_cnt, st, kernel);
+        case PN2_ARITH_FMA: return launch_ball_query<PN2_ARITH_FMA>(b, n, m, radius, thr, nsample, xyz1, xyz2, idx, pts_cnt, st, kernel);
+        case PN2_ARITH_FMA_ALT: return launch_ball_query<PN2_ARITH_FMA_ALT>(b, n, m, radius, thr, nsample, xyz1, xyz2, idx, pts_cnt, st, kernel);
         default: return PN2_EINVAL;
     }
+}
+
+extern "C" int pn2_query_ball_point(int b, int n, int m, float radius, int nsample,
+                                    const float* xyz1, const float* xyz2, int* idx, int* pts_cnt,
+                                    int arith_mode, void* stream) {
+    return query_ball_point_impl(b, n, m, radius, nsample, xyz1, xyz2, idx, pts_cnt, arith_mode, 0, stream);
+}
+
+// Diagnostic door: the same operator on an explicitly chosen kernel (1 wave-per-queries scan, 2 lane-per-query scan,
+// 3 LDS grid; a kernel whose preconditions do not hold falls through to the next one).  Stateless -- the parity tests
+// use it to hold EVERY kernel to the oracle, not just the one the shape heuristic picks.
+extern "C" int pn2_query_ball_point_kernel(int b, int n, int m, float radius, int nsample,
+                                           const float* xyz1, const float* xyz2, int* idx, int* pts_cnt,
+                                           int arith_mode, int kernel, void* stream) {
+    if (kernel < 0 || kernel > 3) return PN2_EINVAL;
+    return query_ball_point_impl(b, n, m, radius, nsample, xyz1, xyz2, idx, pts_cnt, arith_mode, kernel, stream);
 }
 
 // One scan of xyz1 for several (radius, nsample) pairs -- see include/pn2_abi.h.

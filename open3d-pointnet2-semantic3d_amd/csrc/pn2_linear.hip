@@ -679,9 +679,9 @@ sa_group_concat_kernel(int n, int m, int nsample, int c, const float* __restrict
 
 }  // namespace
 
-int g_lin_cfg = 0;     // tuning hook (pn2_debug_set(8, v)): 0 = auto, 1..4 = force <4,1,4> / <2,2,2> / <1,4,1> / <1,2,1,split-K>
-int g_lin_stages = 3;  // tuning hook (pn2_debug_set(5, v)): register prefetch depth of linear_kernel
-int g_wgrad_waves = 0; // tuning hook (pn2_debug_set(9, v)): waves in flight targeted by pn2_linear_wgrad (0 = auto)
+PN2_TUNABLE(int, g_lin_cfg, 0)     // tuning hook (pn2_debug_set(8, v)): 0 = auto, 1..4 = force <4,1,4> / <2,2,2> / <1,4,1> / <1,2,1,split-K>
+PN2_TUNABLE(int, g_lin_stages, 3)  // tuning hook (pn2_debug_set(5, v)): register prefetch depth of linear_kernel
+PN2_TUNABLE(int, g_wgrad_waves, 0) // tuning hook (pn2_debug_set(9, v)): waves in flight targeted by pn2_linear_wgrad (0 = auto)
 
 extern "C" int pn2_linear(int rows, int cin, int cout, const float* x, const float* w,
                           const float* bias, int relu, int pool, float* y, void* stream) {
@@ -761,12 +761,14 @@ extern "C" int pn2_linear_dgrad(int rows, int cin, int cout, const float* dy, co
     return launch_linear_dgrad<1, 4, 1>(rows, cin, cout, dy, w, dx, st);
 }
 
+#ifdef PN2_TUNING_HOOKS
 extern "C" int pn2_debug_set_linear(int what, int value) {
     if (what == 5) { g_lin_stages = value; return 0; }
     if (what == 8) { g_lin_cfg = value; return 0; }
     if (what == 9) { g_wgrad_waves = value; return 0; }
     return PN2_EINVAL;
 }
+#endif  // PN2_TUNING_HOOKS
 
 // dW = x^T . dy (see linear_wgrad_kernel): the training path's weight gradient.  dw (cin, cout) is overwritten.
 static int linear_wgrad_impl(int rows, int cin, int cout, const float* x, const float* dy, float* dw, void* stream, bool accumulate) {

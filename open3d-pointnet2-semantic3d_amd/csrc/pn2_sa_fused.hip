@@ -437,8 +437,8 @@ sa_fused_kernel(SaFusedParams p) {
     }
 }
 
-int g_chain_nw = 0;      // tuning hook (pn2_debug_set(7, v)): 16 = 16-wave workgroups for the single-layer kernels
-int g_chain_grid = 256;  // tuning hook (pn2_debug_set(6, v)): persistent workgroups of the 1-per-CU configuration
+PN2_TUNABLE(int, g_chain_nw, 0)      // tuning hook (pn2_debug_set(7, v)): 16 = 16-wave workgroups for the single-layer kernels
+PN2_TUNABLE(int, g_chain_grid, 256)  // tuning hook (pn2_debug_set(6, v)): persistent workgroups of the 1-per-CU configuration
 
 template <int L, int NT1, int NT2, int NT3, bool VEC8, bool DENSE, bool POOL, bool INTERP = false>
 int launch_chain(const SaFusedParams& p, hipStream_t st) {
@@ -499,11 +499,13 @@ int launch_chain(const SaFusedParams& p, hipStream_t st) {
 
 }  // namespace
 
+#ifdef PN2_TUNING_HOOKS
 extern "C" int pn2_debug_set_fused(int what, int value) {
     if (what == 6) { g_chain_grid = value; return 0; }
     if (what == 7) { g_chain_nw = value; return 0; }
     return PN2_EINVAL;
 }
+#endif  // PN2_TUNING_HOOKS
 
 static int sa_fused_impl(int b, int n, int m, int nsample, int c, const float* xyz,
                          const float* new_xyz, const float* points, const int* idx,

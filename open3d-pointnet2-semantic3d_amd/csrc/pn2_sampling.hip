@@ -247,7 +247,7 @@ fps_reg_kernel(int n, int m, const float* __restrict__ xyz_all, int* __restrict_
     }
 }
 
-int g_fps_variant = 0;  // tuning hook (pn2_debug_set(0, v)), see dispatch_fps
+PN2_TUNABLE(int, g_fps_variant, 0)  // tuning hook (pn2_debug_set(0, v)), see dispatch_fps
 
 // Generic fallback for n > PN2_FPS_MAX_REG_POINTS: running min in the caller's
 // `temp` rows (one row per resident block, like tf_sampling.cu:124), points
@@ -481,6 +481,7 @@ extern "C" int pn2_prob_sample(int b, int n, int m, const float* inp_p, const fl
     return PN2_OK;
 }
 
+#ifdef PN2_TUNING_HOOKS
 // undocumented tuning/experiment hook (not part of the ABI header)
 extern "C" int pn2_debug_set_grouping(int what, int value);
 extern "C" int pn2_debug_set_linear(int what, int value);
@@ -493,6 +494,7 @@ extern "C" int pn2_debug_set(int what, int value) {
     if (what == 6 || what == 7) return pn2_debug_set_fused(what, value);
     return pn2_debug_set_grouping(what, value);
 }
+#endif  // PN2_TUNING_HOOKS
 
 static int fps_entry(int b, int n, int m, const float* inp, float* temp, int* out, float* nxyz,
                      int arith_mode, void* stream) {

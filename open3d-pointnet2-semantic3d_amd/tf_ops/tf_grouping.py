@@ -11,9 +11,11 @@ from .. import config
 from .._lib import check, lib, ptr, require_cuda, stream_ptr
 
 
-def query_ball_point(radius, nsample, xyz1, xyz2):
+def query_ball_point(radius, nsample, xyz1, xyz2, kernel=0):
     """radius float, nsample int, xyz1 (b,n,3) dataset, xyz2 (b,m,3) queries
-    -> idx (b,m,nsample) int32, pts_cnt (b,m) int32.  Not differentiable."""
+    -> idx (b,m,nsample) int32, pts_cnt (b,m) int32.  Not differentiable.
+    kernel (extension, tests / diagnostics): 0 = chosen by shape, 1 / 2 / 3 = a specific kernel
+    (pn2_query_ball_point_kernel); every kernel returns the same bits."""
     if not radius > 0:
         raise ValueError("QueryBallPoint expects positive radius")  # tf_grouping.cpp:80-83
     if nsample <= 0:
@@ -33,8 +35,13 @@ def query_ball_point(radius, nsample, xyz1, xyz2):
     idx = torch.empty((b, m, nsample), dtype=torch.int32, device=xyz1.device)
     cnt = torch.empty((b, m), dtype=torch.int32, device=xyz1.device)
     with torch.cuda.device(xyz1.device):
-        check(lib.pn2_query_ball_point(b, n, m, float(radius), int(nsample), ptr(xyz1), ptr(xyz2), ptr(idx),
-                                       ptr(cnt), int(config.arith_mode), stream_ptr()), "pn2_query_ball_point")
+        if kernel:
+            check(lib.pn2_query_ball_point_kernel(b, n, m, float(radius), int(nsample), ptr(xyz1), ptr(xyz2), ptr(idx),
+                                                  ptr(cnt), int(config.arith_mode), int(kernel), stream_ptr()),
+                  "pn2_query_ball_point_kernel")
+        else:
+            check(lib.pn2_query_ball_point(b, n, m, float(radius), int(nsample), ptr(xyz1), ptr(xyz2), ptr(idx),
+                                           ptr(cnt), int(config.arith_mode), stream_ptr()), "pn2_query_ball_point")
     return idx, cnt
 
 

@@ -29,6 +29,8 @@ def test_library_exports_every_declared_symbol(pn2):
         assert hasattr(lib, n), n
     assert pn2._lib.lib.pn2_abi_version() == 1
     assert b"gfx950" in pn2._lib.lib.pn2_build_info()
+    # the shipped library has no tuning hooks: no process-global kernel-selection state behind the ABI
+    assert not hasattr(lib, "pn2_debug_set") and not hasattr(lib, "pn2_debug_set_grouping")
 
 
 def test_python_signatures_cover_the_header(pn2):

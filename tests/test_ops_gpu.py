@@ -607,12 +607,9 @@ def test_query_ball_point_grid_kernel_bit_exact(pn2, oracle, cuda, case, mode):
     pn2.config.arith_mode = mode
     try:
         oi, oc = oracle.query_ball_point(r, K, xyz, q, mode)
-        assert raw.pn2_debug_set(2, 3) == 0
-        gi, gc = pn2.query_ball_point(r, K, T(xyz, cuda), T(q, cuda))
-        assert raw.pn2_debug_set(2, 2) == 0
-        si, sc = pn2.query_ball_point(r, K, T(xyz, cuda), T(q, cuda))
+        gi, gc = pn2.query_ball_point(r, K, T(xyz, cuda), T(q, cuda), kernel=3)  # LDS grid
+        si, sc = pn2.query_ball_point(r, K, T(xyz, cuda), T(q, cuda), kernel=2)  # lane-per-query scan
     finally:
-        raw.pn2_debug_set(2, 0)
         pn2.config.arith_mode = 1
     assert np.array_equal(gc.cpu().numpy(), oc) and np.array_equal(gi.cpu().numpy(), oi)
     assert np.array_equal(sc.cpu().numpy(), oc) and np.array_equal(si.cpu().numpy(), oi)
@@ -645,12 +642,11 @@ def test_query_ball_point_kernels_fuzz(pn2, oracle, cuda):
                 r = float(ext.max() * rs.choice([1, 2, 4]) / g)  # a lattice distance: sqrt(d2) == radius cases
             oi, oc = oracle.query_ball_point(r, K, xyz, q)
             for variant in (3, 2, 1):
-                raw.pn2_debug_set(2, variant)
-                gi, gc = pn2.query_ball_point(r, K, T(xyz, cuda), T(q, cuda))
+                gi, gc = pn2.query_ball_point(r, K, T(xyz, cuda), T(q, cuda), kernel=variant)
                 assert np.array_equal(gc.cpu().numpy(), oc), (it, variant, n, m, K, r)
                 assert np.array_equal(gi.cpu().numpy(), oi), (it, variant, n, m, K, r)
     finally:
-        raw.pn2_debug_set(2, 0)
+        pass
 
 
 def test_three_nn_fuzz(pn2, oracle, cuda):
