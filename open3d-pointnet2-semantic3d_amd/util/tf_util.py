@@ -333,14 +333,30 @@ def _hip_wgrad(x2d, dy, w):
     return dw
 
 
+_ones_cache = {}
+
+
+def _ones_column(rows, device):
+    """(rows, 1) of ones: x operand that turns pn2_linear_wgrad into a column sum (bias gradient)"""
+    key = (rows, str(device))
+    t = _ones_cache.get(key)
+    if t is None:
+        _ones_cache.clear()  # one size at a time is enough (the head of the network)
+        t = _ones_cache[key] = torch.ones((rows, 1), dtype=torch.float32, device=device)
+    return t
+
+
 class _TrainMatmul(torch.autograd.Function):
-    """y = x2d @ w for the training path; backward: dX = dY @ w^T (torch), dW = x2d^T @ dY on pn2_linear_wgrad (the
-    reduction over all rows, ~8x faster than the library GEMM on these tall-skinny shapes)."""
+    """y = x2d @ w (+ b) for the training path's un-normalised layers (the class head); backward: dX on
+    pn2_linear_dgrad, dW = x2d^T @ dY on pn2_linear_wgrad (the reduction over all rows, ~8x faster than the library
+    GEMM on these tall-skinny shapes), db = 1^T @ dY on the same kernel (a column sum)."""
 
     @staticmethod
-    def forward(ctx, x2d, w):
+    def forward(ctx, x2d, w, b=None):
         ctx.save_for_backward(x2d, w)
-        return hip_matmul(x2d, w) if USE_HIP_GEMM else x2d @ w
+        ctx.has_bias = b is not None
+        y = hip_matmul(x2d, w) if USE_HIP_GEMM else x2d @ w
+        return y if b is None else y.add_(b)
 
     @staticmethod
     def backward(ctx, dy):
@@ -352,7 +368,10 @@ class _TrainMatmul(torch.autograd.Function):
         dw = None
         if ctx.needs_input_grad[1]:
             dw = _hip_wgrad(x2d, dy, w)
-        return dx, dw
+        db = None
+        if ctx.has_bias and ctx.needs_input_grad[2]:
+            db = _hip_wgrad(_ones_column(dy.shape[0], dy.device), dy, dy.new_empty((1, dy.shape[1]))).reshape(-1)
+        return dx, dw, db
 
 
 USE_HIP_WGRAD = True  # set False to let torch compute dW (tests / A-B)
@@ -361,8 +380,8 @@ USE_HIP_WGRAD = True  # set False to let torch compute dW (tests / A-B)
 def _train_dense(inputs, w2d, b):
     cin, cout = w2d.shape
     if USE_HIP_WGRAD and inputs.is_cuda and inputs.dtype == torch.float32:
-        y = _TrainMatmul.apply(inputs.reshape(-1, cin).contiguous(), w2d.contiguous())
-        return y.reshape(list(inputs.shape[:-1]) + [cout]) + b
+        y = _TrainMatmul.apply(inputs.reshape(-1, cin).contiguous(), w2d.contiguous(), b)
+        return y.reshape(list(inputs.shape[:-1]) + [cout])
     return inputs @ w2d + b
 
 

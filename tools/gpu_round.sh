@@ -1,7 +1,7 @@
 #!/bin/bash
 # One gpurun call: GPU parity tests, smoke, bench, rocprofv3 kernel trace.  Logs -> gpurun_out/.
 # usage: gpurun --timeout 1500 -- 'bash tools/gpu_round.sh <tag> [pytest-args]'
-TAG=${1:-r01}; shift
+TAG=${1:-r02}; shift
 OUT=gpurun_out/$TAG; mkdir -p $OUT
 export TMPDIR=/tmp
 python -c "import torch;print(torch.cuda.get_device_name(0), torch.cuda.device_count())" > $OUT/device.txt 2>&1

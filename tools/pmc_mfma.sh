@@ -1,7 +1,7 @@
 #!/bin/bash
 mkdir -p gpurun_out/pmc; cd /tmp; export TMPDIR=/tmp
 R=$OLDPWD
-CMD="python $R/bench.py --steps 3 --warmup 1 --eager --no-cpu-baseline --no-north-star"
+CMD="python $R/bench.py --steps 3 --warmup 1 --eager --no-cpu-baseline --no-north-star --no-other-configs"
 rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU --output-format csv -d $R/gpurun_out/pmc/m1 -o b -- $CMD > $R/gpurun_out/pmc/m1.log 2>&1
 rocprofv3 --kernel-trace --pmc SQ_INSTS_LDS SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_ACTIVE_INST_VMEM SQ_INSTS_SALU --output-format csv -d $R/gpurun_out/pmc/m2 -o b -- $CMD > $R/gpurun_out/pmc/m2.log 2>&1
 rocprofv3 --kernel-trace --pmc GRBM_GUI_ACTIVE FETCH_SIZE --output-format csv -d $R/gpurun_out/pmc/m3 -o b -- $CMD > $R/gpurun_out/pmc/m3.log 2>&1
