@@ -727,7 +727,9 @@ extern "C" int pn2_linear(int rows, int cin, int cout, const float* x, const flo
         // to scratch (1.7 ms instead of 55 us at 131072 x 134 -> 128), so those shapes take the 64-row tile.
         const long long cb = cout / 128;
         const bool vec_a = (cin % 4 == 0) && ((uintptr_t)x % 16 == 0);
-        if (((rows + 127) / 128) * cb >= 512 && vec_a) return PN2_LIN(4, 1, 4, 1);
+        // one column of 128-wide tiles: the 64 x 128 tile beats the 128 x 128 one (131072 x 128 -> 128: 54.8 vs 62.0 us,
+        // 524288 x 128 -> 128 + max: 159 vs 176 us; profiles/r02_linear_splitk.txt)
+        if (((rows + 127) / 128) * cb >= 512 && vec_a && cb > 1) return PN2_LIN(4, 1, 4, 1);
         if (((rows + 63) / 64) * cb >= 512) return PN2_LIN(2, 2, 2, 1);
         if (((rows + 31) / 32) * cb >= 256 || cin < 128) return PN2_LIN(1, 4, 1, 1);
         return PN2_LIN(1, 2, 1, 2);  // few rows: 32x64 tiles, split-K in the block
