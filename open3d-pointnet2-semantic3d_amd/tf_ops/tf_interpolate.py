@@ -50,15 +50,20 @@ class _ThreeInterpolate(torch.autograd.Function):
     @staticmethod
     def backward(ctx, grad_out):
         idx, weight = ctx.saved_tensors
-        grad_out = grad_out.contiguous()
-        b, n, c = grad_out.shape
-        gp = torch.empty((b, ctx.m, c), dtype=torch.float32, device=grad_out.device)
-        nbytes = lib.pn2_three_interpolate_grad_workspace_bytes(b, n, ctx.m)
-        ws = torch.empty(nbytes // 4, dtype=torch.int32, device=grad_out.device)
-        with torch.cuda.device(grad_out.device):
-            check(lib.pn2_three_interpolate_grad_ws(b, n, c, ctx.m, ptr(grad_out), ptr(idx), ptr(weight), ptr(gp), ptr(ws),
-                                                    nbytes, stream_ptr()), "pn2_three_interpolate_grad_ws")
-        return gp, None, None  # idx, weight get no gradient (tf_interpolate.py:66-72)
+        return three_interpolate_grad(grad_out, idx, weight, ctx.m), None, None  # idx, weight get no gradient (tf_interpolate.py:66-72)
+
+
+def three_interpolate_grad(grad_out, idx, weight, m):
+    """gradient of three_interpolate w.r.t. points: (b,n,c) -> (b,m,c) (tf_interpolate.py:62-72), list-and-gather kernel"""
+    grad_out = grad_out.contiguous()
+    b, n, c = grad_out.shape
+    gp = torch.empty((b, m, c), dtype=torch.float32, device=grad_out.device)
+    nbytes = lib.pn2_three_interpolate_grad_workspace_bytes(b, n, m)
+    ws = torch.empty(nbytes // 4, dtype=torch.int32, device=grad_out.device)
+    with torch.cuda.device(grad_out.device):
+        check(lib.pn2_three_interpolate_grad_ws(b, n, c, m, ptr(grad_out), ptr(idx), ptr(weight), ptr(gp), ptr(ws),
+                                                nbytes, stream_ptr()), "pn2_three_interpolate_grad_ws")
+    return gp
 
 
 def three_interpolate(points, idx, weight):

@@ -34,6 +34,11 @@ def sample_and_group(npoint, radius, nsample, xyz, points, knn=False, use_xyz=Tr
             _, idx = knn_point(nsample, xyz, new_xyz)
         else:
             idx, pts_cnt = query_ball_point(radius, nsample, xyz, new_xyz)
+    if (USE_FUSED_TRAIN_FRONT and points is not None and use_xyz and points.dtype == torch.float32
+            and (points.requires_grad or not torch.is_grad_enabled())):
+        # gather + centre + concat in one launch; grouped_xyz is a view of its first three columns
+        new_points = _SAGroupConcat.apply(xyz.contiguous(), new_xyz.contiguous(), points.contiguous(), idx)
+        return new_xyz, new_points, idx, new_points[..., :3]
     grouped_xyz = group_point(xyz, idx)
     grouped_xyz = grouped_xyz - new_xyz.unsqueeze(2)  # translation normalisation (:44-46)
     if points is not None:
@@ -114,6 +119,59 @@ def _sa_group_concat(xyz, new_xyz, points, idx):
         check(lib.pn2_sa_group_concat(b, n, m, nsample, c, ptr(xyz), ptr(new_xyz), ptr(pts), ptr(idx), ptr(out),
                                       stream_ptr()), "pn2_sa_group_concat")
     return out
+
+
+
+class _SAGroupConcat(torch.autograd.Function):
+    """[group_point(xyz) - new_xyz | group_point(points)] in ONE launch (pn2_sa_group_concat) for the training path
+    (util/pointnet_util.py:39-54 as four TF ops: two gathers, tile + subtract, concat).  Gradient w.r.t. `points` only
+    (coordinates are data): the feature columns of the upstream gradient go through the list-and-gather
+    pn2_group_point_grad_ws."""
+
+    @staticmethod
+    def forward(ctx, xyz, new_xyz, points, idx):
+        out = _sa_group_concat(xyz, new_xyz, points, idx)
+        ctx.save_for_backward(idx)
+        ctx.n, ctx.c = xyz.shape[1], points.shape[2]
+        return out
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        (idx,) = ctx.saved_tensors
+        b, m, ns, _ = grad_out.shape
+        g = grad_out[..., 3:].contiguous()  # (b,m,ns,c)
+        gp = torch.empty((b, ctx.n, ctx.c), dtype=torch.float32, device=g.device)
+        nbytes = lib.pn2_group_point_grad_workspace_bytes(b, ctx.n, m, ns)
+        ws = torch.empty(nbytes // 4, dtype=torch.int32, device=g.device)
+        with torch.cuda.device(g.device):
+            check(lib.pn2_group_point_grad_ws(b, ctx.n, ctx.c, m, ns, ptr(g), ptr(idx), ptr(gp), ptr(ws), nbytes,
+                                              stream_ptr()), "pn2_group_point_grad_ws")
+        return None, None, gp, None
+
+
+class _FPInterpConcat(torch.autograd.Function):
+    """[three_interpolate(points2, idx, w(dist)) | points1] in ONE launch (pn2_fp_interp_concat) for the training path
+    (util/pointnet_util.py:300-311: clamp, reciprocal, sum, divide, three_interpolate, concat).  Gradients: points2
+    through pn2_three_interpolate_grad_ws with the same weights, points1 = its slice of the upstream gradient."""
+
+    @staticmethod
+    def forward(ctx, dist, idx, points1, points2):
+        out = _fp_interp_concat(dist, idx, points1, points2)
+        ctx.save_for_backward(dist, idx)
+        ctx.m, ctx.c2 = points2.shape[1], points2.shape[2]
+        ctx.c1 = 0 if points1 is None else points1.shape[2]
+        return out
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        dist, idx = ctx.saved_tensors
+        d = torch.clamp(dist, min=1e-10)
+        w = (1.0 / d)
+        w = (w / w.sum(dim=2, keepdim=True)).contiguous()
+        from ..tf_ops.tf_interpolate import three_interpolate_grad
+        g2 = three_interpolate_grad(grad_out[..., :ctx.c2].contiguous(), idx, w, ctx.m)
+        g1 = grad_out[..., ctx.c2:].contiguous() if ctx.c1 else None
+        return None, None, g1, g2
 
 
 # set False to force the unfused HIP path (group_concat + pn2_linear); used by tests/bench
@@ -269,6 +327,9 @@ def _fp_interp_concat(dist, idx, points1, points2, pad_to=1):
     return out
 
 
+USE_FUSED_TRAIN_FRONT = True  # set False: the training path's SA / FP front ends as separate ops (tests / A-B)
+
+
 USE_MLP_CHAIN = True  # set False to force one pn2_linear launch per layer (tests/bench)
 
 
@@ -351,11 +412,15 @@ def pointnet_fp_module(xyz1, xyz2, points1, points2, mlp, is_training, bn_decay,
         if not is_training:
             # weights + interpolate + concat fused, then LDS-resident MLP chains / MFMA layers
             return fp_features_inference(dist, idx, points1, points2, mlp, bn, bn_decay)
-        dist = torch.clamp(dist, min=1e-10)
-        norm = (1.0 / dist).sum(dim=2, keepdim=True)
-        weight = (1.0 / dist) / norm
-        interpolated = three_interpolate(points2, idx, weight)
-        new_points1 = torch.cat([interpolated, points1], dim=2) if points1 is not None else interpolated
+        if USE_FUSED_TRAIN_FRONT and points2.dtype == torch.float32:
+            new_points1 = _FPInterpConcat.apply(dist, idx, None if points1 is None else points1.contiguous(),
+                                                points2.contiguous())
+        else:
+            dist = torch.clamp(dist, min=1e-10)
+            norm = (1.0 / dist).sum(dim=2, keepdim=True)
+            weight = (1.0 / dist) / norm
+            interpolated = three_interpolate(points2, idx, weight)
+            new_points1 = torch.cat([interpolated, points1], dim=2) if points1 is not None else interpolated
         new_points1 = new_points1.unsqueeze(2)
         for i, cout in enumerate(mlp):
             new_points1 = tf_util.conv2d(new_points1, cout, [1, 1], padding="VALID", stride=[1, 1], bn=bn,

@@ -233,3 +233,42 @@ def test_eval_after_training_passes_uses_fresh_statistics(pn2, cuda):
     ref = torch.relu(tfu._batch_norm_eval(x @ w + b, bnv))
     assert not torch.allclose(ev0, ev1, atol=1e-3)  # the statistics did move
     assert torch.allclose(ev1, ref, rtol=1e-4, atol=1e-4)
+
+
+def test_fused_training_front_ends_equal_the_separate_ops(pn2, cuda):
+    """sample_and_group / pointnet_fp_module front ends of the training path as ONE launch each (pn2_sa_group_concat,
+    pn2_fp_interp_concat with their gradients) against the reference's op sequence (gather, centre, concat; clamp,
+    reciprocal, normalise, three_interpolate, concat): identical forward values, gradients to fp32 summation order."""
+    import torch
+    pu = pn2.util.pointnet_util
+    rs = np.random.RandomState(0)
+    xyz = T(s_scene(3, 4, 2048), cuda)
+    pts_np = rs.randn(4, 2048, 16).astype(np.float32)
+    out, grads = {}, {}
+    for fused in (True, False):
+        pu.USE_FUSED_TRAIN_FRONT = fused
+        try:
+            pts = T(pts_np, cuda).requires_grad_(True)
+            new_xyz, new_points, idx, gx = pu.sample_and_group(256, 0.8, 32, xyz, pts)
+            assert new_points.shape == (4, 256, 32, 19) and gx.shape == (4, 256, 32, 3)
+            p2 = T(rs.randn(4, 256, 24).astype(np.float32), cuda).requires_grad_(True)
+            dist, nidx = pn2.three_nn(xyz, new_xyz)
+            # the FP front end through the module with an identity-free probe: take its concat directly
+            if fused:
+                cat = pu._FPInterpConcat.apply(dist, nidx, pts, p2)
+            else:
+                d = torch.clamp(dist, min=1e-10)
+                w = (1.0 / d) / (1.0 / d).sum(dim=2, keepdim=True)
+                cat = torch.cat([pn2.three_interpolate(p2, nidx, w), pts], dim=2)
+            go1 = torch.from_numpy(np.random.RandomState(1).randn(*new_points.shape).astype(np.float32)).to(cuda)
+            go2 = torch.from_numpy(np.random.RandomState(2).randn(*cat.shape).astype(np.float32)).to(cuda)
+            ((new_points * go1).sum() + (cat * go2).sum() + (gx * gx).sum() * 0.0).backward()
+            out[fused] = (new_points.detach().clone(), gx.detach().clone(), cat.detach().clone())
+            grads[fused] = (pts.grad.clone(), p2.grad.clone())
+        finally:
+            pu.USE_FUSED_TRAIN_FRONT = True
+        rs = np.random.RandomState(0); rs.randn(4, 2048, 16)  # same p2 draw in both passes
+    assert torch.equal(out[True][0], out[False][0]) and torch.equal(out[True][1], out[False][1])
+    assert torch.allclose(out[True][2], out[False][2], rtol=1e-6, atol=1e-6)  # weights: a/b/sum vs (1/d)/sum(1/d) rounding
+    for a, b_ in zip(grads[True], grads[False]):
+        assert torch.allclose(a, b_, rtol=1e-4, atol=1e-4 * float(b_.abs().max()))
