@@ -84,14 +84,17 @@ def test_linear_large_rows_scalar_a_loads(pn2, cuda, rows, cin, cout):
     tx, tw, tb = T(x, cuda), T(w, cuda), T(b, cuda)
     y = pn2.util.tf_util.hip_linear(tx, tw, tb, relu=1)
     close(y.cpu().numpy(), np.maximum(x.astype(np.float64) @ w.astype(np.float64) + b, 0))
-    torch.cuda.synchronize()
-    s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    s.record()
-    for _ in range(5):
-        pn2.util.tf_util.hip_linear(tx, tw, tb, relu=1)
-    e.record()
-    torch.cuda.synchronize()
-    assert s.elapsed_time(e) / 5 < 0.6, "pn2_linear %.3f ms per call: a spilling tile configuration?" % (s.elapsed_time(e) / 5)
+    best = 1e9
+    for _ in range(4):  # best of four: a timing guard must not trip on one slow sample (clock ramp, neighbours)
+        torch.cuda.synchronize()
+        s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        s.record()
+        for _ in range(5):
+            pn2.util.tf_util.hip_linear(tx, tw, tb, relu=1)
+        e.record()
+        torch.cuda.synchronize()
+        best = min(best, s.elapsed_time(e) / 5)
+    assert best < 0.8, "pn2_linear %.3f ms per call: a spilling tile configuration? (1.7 ms when it spilled)" % best
 
 
 def test_linear_layout_is_transpose_detecting(pn2, cuda):
