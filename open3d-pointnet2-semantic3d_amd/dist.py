@@ -126,6 +126,8 @@ class OverlappedGradAllReduce:
             self.split_off = off
         self.late_flat, self.early_flat = self.flat[:self.split_off], self.flat[self.split_off:]
         self._pending, self._work, self.early_launched_in_backward = 0, None, False
+        self._known_zero = set()
+        self._expected_early = None
         self._hooks = [p.register_post_accumulate_grad_hook(self._on_grad) for p in self.params[self.split:]]
 
     def world(self):
@@ -133,15 +135,22 @@ class OverlappedGradAllReduce:
 
     def begin(self):
         """call before backward (after the gradients were reset)"""
-        self._pending = len(self.params) - self.split
+        # early-bucket parameters that actually receive a gradient (learned from the first step: a bias in front of batch
+        # norm never does, and must not keep the countdown from reaching zero)
+        self._pending = self._expected_early if self._expected_early is not None else len(self.params) - self.split
         self._work, self.early_launched_in_backward = None, False
 
     def _pack(self, lo, hi):
         src, dst = [], []
-        for p, v in zip(self.params[lo:hi], self.views[lo:hi]):
+        for i, (p, v) in enumerate(zip(self.params[lo:hi], self.views[lo:hi])):
             if p.grad is None:
-                v.zero_()
+                # no gradient (e.g. a bias in front of batch norm): its slice stays zero -- it was zero-filled when first
+                # seen and nothing but an all-reduce of zeros has touched it since: no fill per step
+                if (lo + i) not in self._known_zero:
+                    v.zero_()
+                    self._known_zero.add(lo + i)
             elif p.grad.data_ptr() != v.data_ptr():
+                self._known_zero.discard(lo + i)
                 src.append(p.grad)
                 dst.append(v)
         if dst:
@@ -159,7 +168,9 @@ class OverlappedGradAllReduce:
     @torch.no_grad()
     def finish(self):
         """after backward: reduce the late bucket, wait for the early one, leave every p.grad as a view of `flat`."""
-        if not self.early_launched_in_backward:  # a parameter without gradient kept the countdown from reaching zero
+        if self._expected_early is None:
+            self._expected_early = sum(1 for p in self.params[self.split:] if p.grad is not None)
+        if not self.early_launched_in_backward:  # first step, or a parameter's gradient did not arrive
             self._pack(self.split, len(self.params))
             if self.world() > 1:
                 self._work = dist.all_reduce(self.early_flat, op=dist.ReduceOp.SUM, async_op=True)

@@ -443,9 +443,9 @@ class _TrainDenseBnRelu(torch.autograd.Function):
             dw = None
             if ctx.needs_input_grad[1]:
                 dw = _hip_wgrad(x2d, dy, w)
-        # a constant in front of batch norm has no effect on the output: its gradient is exactly zero
-        db = torch.zeros(c, dtype=dy.dtype, device=dy.device) if ctx.needs_input_grad[2] else None
-        return dx, dw, db, dgamma, dbeta, None, None, None, None, None
+        # a constant in front of batch norm has no effect on the output: its gradient is exactly zero -- None, which the
+        # trainer's gradient buffer treats as (and keeps at) zero without a fill per layer
+        return dx, dw, None, dgamma, dbeta, None, None, None, None, None
 
 
 USE_HIP_BN = True  # set False to run batch norm / ReLU of the training path on torch (tests / A-B)

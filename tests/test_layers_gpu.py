@@ -816,7 +816,13 @@ def test_training_gradients_with_hip_wgrad_match_torch(pn2, cuda):
             tfu.USE_HIP_WGRAD = tfu.USE_HIP_BN = tfu.USE_HIP_GEMM = True
 
     hip, t32, ref = run("hip"), run("torch"), run("fp64")
-    assert hip.keys() == t32.keys() == ref.keys() and len(hip) > 40
+    assert t32.keys() == ref.keys() and len(hip) > 40
+    # the HIP path returns NO gradient for a bias in front of batch norm (it is exactly zero); everything else is there
+    missing = ref.keys() - hip.keys()
+    assert hip.keys() <= ref.keys() and all(k.endswith("biases") for k in missing) and len(missing) == 22
+    for k in missing:
+        assert float(ref[k].abs().max()) < 1e-6
+    ref = {k: v for k, v in ref.items() if k in hip}
     rel = {k: (float((hip[k] - ref[k]).norm()) / max(float(ref[k].norm()), 1e-30),
                float((t32[k] - ref[k]).norm()) / max(float(ref[k].norm()), 1e-30)) for k in ref if float(ref[k].norm()) > 1e-6}
     worst = max(rel, key=lambda k: rel[k][0])
@@ -976,7 +982,7 @@ def test_train_layer_hip_bn_matches_torch_autograd(pn2, cuda, pool):
             outs[use] = (z.detach(), mean, var, xx.grad, w.grad, gamma.grad, beta.grad, b.grad)
         finally:
             tfu.USE_HIP_BN = True
-    assert float(outs[True][-1].abs().max()) == 0.0       # bias in front of BN: exactly zero ...
+    assert outs[True][-1] is None                          # bias in front of BN: exactly zero -> no gradient tensor at all ...
     assert float(outs[False][-1].abs().max()) <= 5e-3     # ... where torch sums 32768 rounding errors
     for a, r in zip(outs[True][:-1], outs[False][:-1]):
         s = max(float(r.abs().max()), 1.0)
