@@ -141,6 +141,13 @@ class Trainer:
             self._geo_event.record(g)
         self._geo_tag = (next_pc.data_ptr(), next_pc._version, tuple(next_pc.shape))
 
+    def prefetch_geometry(self, next_pc):
+        """Announce the next batch AFTER the current step was enqueued (e.g. when it is itself produced on another stream,
+        examples/train_synthetic.py): its geometry chain starts once the work queued so far on the CURRENT stream is done."""
+        ev = torch.cuda.Event()
+        ev.record(torch.cuda.current_stream())
+        self._prefetch(next_pc, ev)
+
     def train_step(self, pc, labels, smpw, sync=True, next_pc=None):
         """pc (B,N,6) float32, labels (B,N) int, smpw (B,N) float32 -> loss (python float; the device scalar when
         sync=False, to be read after the next synchronisation point).

@@ -275,3 +275,40 @@ def test_fused_training_front_ends_equal_the_separate_ops(pn2, cuda):
     assert torch.allclose(out[True][2], out[False][2], rtol=1e-6, atol=1e-6)  # weights: a/b/sum vs (1/d)/sum(1/d) rounding
     for a, b_ in zip(grads[True], grads[False]):
         assert torch.allclose(a, b_, rtol=1e-4, atol=1e-4 * float(b_.abs().max()))
+
+
+def test_scene_sampler_feeds_trainer_on_the_device(pn2, cuda):
+    """N4 -> path -> N1 without leaving the device: SemanticFileData.sample_batch on a side stream produces batch k+1 while
+    step k trains; Trainer.prefetch_geometry runs its FPS / ball-query / three_nn chain behind it (examples/train_synthetic.py)."""
+    import torch
+    rs = np.random.RandomState(0)
+    n = 60000
+    pts = np.stack([rs.uniform(0, 20, n), rs.uniform(0, 20, n), np.abs(rs.normal(0, 1.0, n))], 1).astype(np.float32).astype(np.float64)
+    labels = np.clip((pts[:, 2] / 0.5).astype(np.int32) + 1, 1, 8)
+    colors = rs.uniform(0, 1, (n, 3))
+    fd = pn2.dataset.SemanticFileData(points=pts, labels=labels, colors=colors, box_size_x=10, box_size_y=10, device=cuda)
+    hp = dict(pn2.model.SEMANTIC_HYPERPARAMS)
+    hp.update(l1_npoint=256, l2_npoint=64, l3_npoint=32, l4_npoint=16)
+    tr = pn2.train.Trainer(hp, 9, store=pn2.util.tf_util.VariableStore(device=cuda, seed=1), warmup_eager=2)
+    w = torch.ones(9, device=cuda)
+
+    def batch():
+        c, _, l, col = fd.sample_batch(4, 2048, capacity=n)
+        return torch.cat([c, col], dim=2), l.long(), w[l.long()]
+
+    prep = torch.cuda.Stream()
+    cur, losses = batch(), []
+    for i in range(6):
+        losses.append(tr.train_step(*cur, sync=False))
+        with torch.cuda.stream(prep):
+            nxt = batch()
+            tr.prefetch_geometry(nxt[0])
+        torch.cuda.current_stream().wait_stream(prep)
+        for t in nxt:
+            t.record_stream(torch.cuda.current_stream())
+        cur = nxt
+    torch.cuda.synchronize()
+    fd.check_last()
+    ls = [float(x) for x in losses]
+    assert all(np.isfinite(ls)) and ls[-1] < ls[0], ls
+    assert tr._graph is not None and tr.step_count == 6
