@@ -20,8 +20,7 @@ x = torch.from_numpy(scene(1, b, n)).to(dev); q = x[:, :m].contiguous()
 idx = torch.empty((b, m, 32), dtype=torch.int32, device=dev); cnt = torch.empty((b, m), dtype=torch.int32, device=dev)
 for k in STAGES:
     L = ctypes.CDLL(os.path.join(PKG, "libpn2_bqg%d.so" % k))
-    L.pn2_debug_set(2, 3)
-    L.pn2_query_ball_point.argtypes = [ctypes.c_int] * 3 + [ctypes.c_float, ctypes.c_int] + [ctypes.c_void_p] * 4 + [ctypes.c_int, ctypes.c_void_p]
-    f = lambda: L.pn2_query_ball_point(b, n, m, 0.5, 32, P(x), P(q), P(idx), P(cnt), 1, st)
+    L.pn2_query_ball_point_kernel.argtypes = [ctypes.c_int] * 3 + [ctypes.c_float, ctypes.c_int] + [ctypes.c_void_p] * 4 + [ctypes.c_int, ctypes.c_int, ctypes.c_void_p]
+    f = lambda: L.pn2_query_ball_point_kernel(b, n, m, 0.5, 32, P(x), P(q), P(idx), P(cnt), 1, 3, st)  # kernel 3 = LDS grid
     assert f() == 0
     print("stage<=%d: %.1f us" % (k, timeit(f, 30)))
