@@ -173,6 +173,24 @@ int pn2_three_interpolate_grad_ws(int b, int n, int c, int m, const float *grad_
                                   const float *weight, float *grad_points, void *workspace,
                                   size_t workspace_bytes, void *stream);
 
+/* The list of the two *_grad_ws calls above as an object of its own.  It depends on (idx, weight) only -- geometry, not
+ * weights or activations -- so a training step builds it AHEAD (with the FPS / ball query / three_nn of the batch, beside the
+ * previous step's dense work) and its backward pass only gathers:
+ *   out[b, idx[b,e], :] = sum over the entries e with that idx of  w[b,e] * rows_in[b, e / div, 0:c]      (e < nent)
+ *   groupPointGradLauncher      (tf_grouping.cu:155-162):   nent = m*nsample, div = 1, nsrc = n, weight_kind 0 (w = 1)
+ *   threeinterpolate_grad_cpu   (tf_interpolate.cpp:397-421): nent = 3*n, div = 3, nsrc = m, weight_kind 1 (weight (b,n,3))
+ *     or 2: `weight` holds three_nn's squared distances (b,n,3) and w is the inverse-distance weight of
+ *     util/pointnet_util.py:300-303, formed with the float expressions of pn2_fp_interp_concat.
+ * idx (b,nent) int32 in [0,nsrc).  plan: 4-byte aligned, pn2_scatter_plan_bytes(b,nent,nsrc) bytes, opaque, position
+ * independent (may be copied).  apply: rows_in rows are `in_stride` floats apart (>= c: a column slice of a wider gradient
+ * is read in place), c % 4 == 0, c <= 1024, out (b,nsrc,c) 16-byte aligned, overwritten (no zero fill needed).  The order
+ * of a list (= the fp32 summation order) is fixed by the build. */
+size_t pn2_scatter_plan_bytes(int b, int nent, int nsrc);
+int pn2_scatter_plan_build(int b, int nent, int div, int nsrc, const int *idx, const float *weight, int weight_kind,
+                           void *plan, size_t plan_bytes, void *stream);
+int pn2_scatter_plan_apply(int b, int nent, int div, int c, int nsrc, const float *rows_in, int in_stride,
+                           const void *plan, size_t plan_bytes, float *out, void *stream);
+
 /* ---- fused layer kernels (new: no reference kernel; they replace the TF
  *      sub-graphs of util/pointnet_util.py:44-54,150-170 and :300-325) ------- */
 
@@ -232,6 +250,16 @@ int pn2_bn_relu_backward_ws0(long long rows, int c, const float *dz, const float
                              const float *beta, const float *save_mean, const float *save_invstd, int relu,
                              int pool, const float *zmax, const float *ties, void *workspace,
                              size_t workspace_bytes, float *dy, float *dgamma, float *dbeta, void *stream);
+/* conv2d -> batch_norm of the training path (util/tf_util.py:186-204) without the statistics pass over y:
+ * pn2_linear_bn_stats computes y (rows,cout) = x (rows,cin) . w (cin,cout) (no bias, no activation; cout % 32 == 0)
+ * and adds the column sums of y and y*y to `bn_workspace` (pn2_bn_workspace_bytes(cout) bytes, ZEROED by the caller)
+ * from the GEMM's accumulators; pn2_bn_relu_forward_stats is pn2_bn_relu_forward for such a (y, workspace) pair. */
+int pn2_linear_bn_stats(int rows, int cin, int cout, const float *x, const float *w, float *y,
+                        void *bn_workspace, size_t workspace_bytes, void *stream);
+int pn2_bn_relu_forward_stats(long long rows, int c, const float *y, const float *gamma, const float *beta,
+                              const float *bias, float eps, float decay, int relu, int pool, float *running_mean,
+                              float *running_var, void *workspace, size_t workspace_bytes, float *save_mean,
+                              float *save_invstd, float *z, float *ties, void *stream);
 
 /* Fused set-abstraction MLP (pointnet_util.py:43-54 + :150-170, inference BN
  * folded): for every (b, j) group gathers nsample neighbours by idx, builds

@@ -63,6 +63,11 @@ SIGNATURES = {
                             c_void_p, c_void_p, c_void_p, ctypes.c_size_t, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p],
     "pn2_bn_relu_backward_ws0": [ctypes.c_longlong, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int,
                              c_int, c_void_p, c_void_p, c_void_p, ctypes.c_size_t, c_void_p, c_void_p, c_void_p, c_void_p],
+    "pn2_scatter_plan_build": [c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_int, c_void_p, ctypes.c_size_t, c_void_p],
+    "pn2_scatter_plan_apply": [c_int, c_int, c_int, c_int, c_int, c_void_p, c_int, c_void_p, ctypes.c_size_t, c_void_p, c_void_p],
+    "pn2_linear_bn_stats": [c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, ctypes.c_size_t, c_void_p],
+    "pn2_bn_relu_forward_stats": [ctypes.c_longlong, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_float, c_int, c_int,
+                              c_void_p, c_void_p, c_void_p, ctypes.c_size_t, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p],
     "pn2_linear_wgrad_accumulate": [c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p],
     "pn2_linear_dgrad": [c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p],
     "pn2_weighted_ce_forward": [c_int, c_int, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p],
@@ -114,6 +119,8 @@ def _load():
     lib.pn2_interpolate_label_workspace_bytes.restype = ctypes.c_size_t
     lib.pn2_three_interpolate_grad_workspace_bytes.argtypes = [c_int, c_int, c_int]
     lib.pn2_three_interpolate_grad_workspace_bytes.restype = ctypes.c_size_t
+    lib.pn2_scatter_plan_bytes.argtypes = [c_int, c_int, c_int]
+    lib.pn2_scatter_plan_bytes.restype = ctypes.c_size_t
     lib.pn2_group_point_grad_workspace_bytes.argtypes = [c_int, c_int, c_int, c_int]
     lib.pn2_group_point_grad_workspace_bytes.restype = ctypes.c_size_t
     lib.pn2_voxel_downsample_workspace_bytes.argtypes = [c_int]
@@ -133,7 +140,8 @@ _raw = _load()
 
 
 # entry points that mutate caller state beyond their outputs (moving averages): never launched twice by the dup hook
-_STATEFUL = frozenset({"pn2_bn_relu_forward", "pn2_bn_relu_forward_ws0", "pn2_adam_step", "pn2_linear_wgrad_accumulate"})
+_STATEFUL = frozenset({"pn2_bn_relu_forward", "pn2_bn_relu_forward_ws0", "pn2_bn_relu_forward_stats", "pn2_linear_bn_stats",
+                       "pn2_adam_step", "pn2_linear_wgrad_accumulate"})
 
 
 class _LibProxy:

@@ -17,14 +17,14 @@ namespace {
 
 constexpr int kBnMaxC = 1024;   // channels held in LDS by the apply kernels
 constexpr int kBnThreads = 256;
-constexpr int kBnSlots = 64;     // most copies of the per-channel accumulators the reduction blocks spread their atomics over
+constexpr int kBnSlots = kPn2BnSlots;  // most copies of the per-channel accumulators the reduction blocks spread their atomics over
 constexpr int kBnBlocks = 512;   // most reduction blocks (2 per CU, 8 x 16-byte loads in flight per thread); the training step is
                                  // flat from 256 to 1024 and slower at 2048 (pn2_debug_set(10, v) sweep: every block ends in 2*c atomics)
 
-constexpr int kBnHead = 8;       // doubles reserved in front (alignment of the sums to 64 bytes)
+constexpr int kBnHead = kPn2BnHead;
 
-// workspace (doubles): reserved[kBnHead] | final[2][c] | slot[nslots][2][c], nslots <= kBnSlots chosen per call
-__host__ __device__ inline size_t bn_ws_doubles(int c, int nslots) { return kBnHead + (size_t)(1 + nslots) * 2 * (size_t)c; }
+// workspace layout: pn2_common.h
+__host__ __device__ inline size_t bn_ws_doubles(int c, int nslots) { return pn2_bn_ws_doubles(c, nslots); }
 
 // thread -> (row slot rr, float4 column cc): cv = c/VEC columns, rp = 256/cv rows per pass
 template <int VEC>
@@ -445,7 +445,9 @@ extern "C" size_t pn2_bn_workspace_bytes(int c) { return c > 0 ? sizeof(double) 
 static int bn_relu_forward_impl(long long rows, int c, const float* y, const float* gamma, const float* beta,
                                 const float* bias, float eps, float decay, int relu, int pool, float* running_mean,
                                 float* running_var, void* workspace, size_t workspace_bytes, float* save_mean,
-                                float* save_invstd, float* z, float* ties, void* stream, bool ws_zeroed) {
+                                float* save_invstd, float* z, float* ties, void* stream, int mode) {
+    // mode 0: zero the workspace here; 1: the caller zeroed it; 2: the caller zeroed it AND pn2_linear_bn_stats has already
+    // added the column sums of y to all kBnSlots slot copies (no statistics pass)
     if (!y || !gamma || !beta || !workspace || !save_mean || !save_invstd || !z) return PN2_ENULL;
     if ((running_mean == nullptr) != (running_var == nullptr)) return PN2_ENULL;
     if (pool > 1 && !ties) return PN2_ENULL;
@@ -457,10 +459,11 @@ static int bn_relu_forward_impl(long long rows, int c, const float* y, const flo
     hipStream_t st = static_cast<hipStream_t>(stream);
     double* ws = static_cast<double*>(workspace);
     const double* acc = ws + kBnHead;
-    if (!ws_zeroed) {
+    if (mode == 0) {
         hipError_t e = hipMemsetAsync(ws, 0, sizeof(double) * bn_ws_doubles(c, p.nslots), st);
         if (e != hipSuccess) return (int)e;
     }
+    if (mode == 2) p.nslots = kBnSlots;
     const int fold_blocks = (2 * c + kBnThreads - 1) / kBnThreads;
     long long pb = 1;  // pooled apply: one group per (thread row slot), grid-stride beyond 8 blocks per CU
     if (pool > 1) {
@@ -470,7 +473,7 @@ static int bn_relu_forward_impl(long long rows, int c, const float* y, const flo
     }
 #define PN2_BN_FWD(V_)                                                                                                   \
     do {                                                                                                                 \
-        bn_stats_kernel<V_><<<p.stat_blocks, kBnThreads, 0, st>>>(rows, c, p.slab, p.nslots, y, ws);                      \
+        if (mode != 2) bn_stats_kernel<V_><<<p.stat_blocks, kBnThreads, 0, st>>>(rows, c, p.slab, p.nslots, y, ws);       \
         bn_fold_kernel<<<fold_blocks, kBnThreads, 0, st>>>(2 * c, p.nslots, ws);                                          \
         if (pool > 1)                                                                                                    \
             bn_apply_pool_kernel<V_><<<(int)pb, kBnThreads, 0, st>>>(rows, c, pool, y, acc, gamma, beta, bias, eps, decay, \
@@ -493,7 +496,7 @@ extern "C" int pn2_bn_relu_forward(long long rows, int c, const float* y, const 
                                    float* running_var, void* workspace, size_t workspace_bytes, float* save_mean,
                                    float* save_invstd, float* z, float* ties, void* stream) {
     return bn_relu_forward_impl(rows, c, y, gamma, beta, bias, eps, decay, relu, pool, running_mean, running_var, workspace,
-                                workspace_bytes, save_mean, save_invstd, z, ties, stream, false);
+                                workspace_bytes, save_mean, save_invstd, z, ties, stream, 0);
 }
 // the same with a workspace the CALLER has already zero-filled (one fill of an arena that holds the scratch of every layer
 // of a training step replaces one memset per call)
@@ -502,7 +505,15 @@ extern "C" int pn2_bn_relu_forward_ws0(long long rows, int c, const float* y, co
                                        float* running_var, void* workspace, size_t workspace_bytes, float* save_mean,
                                        float* save_invstd, float* z, float* ties, void* stream) {
     return bn_relu_forward_impl(rows, c, y, gamma, beta, bias, eps, decay, relu, pool, running_mean, running_var, workspace,
-                                workspace_bytes, save_mean, save_invstd, z, ties, stream, true);
+                                workspace_bytes, save_mean, save_invstd, z, ties, stream, 1);
+}
+// the same for a y produced by pn2_linear_bn_stats with this workspace: the column sums are already there
+extern "C" int pn2_bn_relu_forward_stats(long long rows, int c, const float* y, const float* gamma, const float* beta,
+                                         const float* bias, float eps, float decay, int relu, int pool, float* running_mean,
+                                         float* running_var, void* workspace, size_t workspace_bytes, float* save_mean,
+                                         float* save_invstd, float* z, float* ties, void* stream) {
+    return bn_relu_forward_impl(rows, c, y, gamma, beta, bias, eps, decay, relu, pool, running_mean, running_var, workspace,
+                                workspace_bytes, save_mean, save_invstd, z, ties, stream, 2);
 }
 
 static int bn_relu_backward_impl(long long rows, int c, const float* dz, const float* y, const float* gamma,

@@ -24,6 +24,12 @@
         if (e__ != hipSuccess) return (int)e__;       \
     } while (0)
 
+// Training-mode batch-norm workspace (pn2_bn.hip; pn2_linear_bn_stats in pn2_linear.hip writes into it), in doubles:
+//   reserved[kPn2BnHead] | final[2][c] | slot[nslots][2][c], nslots <= kPn2BnSlots chosen per call
+constexpr int kPn2BnHead = 8;    // doubles reserved in front (alignment of the sums to 64 bytes)
+constexpr int kPn2BnSlots = 64;  // most copies of the per-channel accumulators the producers spread their atomics over
+__host__ __device__ inline size_t pn2_bn_ws_doubles(int c, int nslots) { return kPn2BnHead + (size_t)(1 + nslots) * 2 * (size_t)c; }
+
 // Squared distance exactly as the reference expression
 //   (x2-x1)*(x2-x1) + (y2-y1)*(y2-y1) + (z2-z1)*(z2-z1)
 // (tf_sampling.cu:149-150, tf_grouping.cu:28-30) under the three contraction

@@ -416,7 +416,7 @@ ti_csr_scan_kernel(int m, int* __restrict__ cnt_all, int* __restrict__ off_all) 
 
 __global__ void __launch_bounds__(256)
 ti_csr_fill_kernel(int n3, int m, int div, const int* __restrict__ idx_all, const float* __restrict__ weight_all,
-                   const int* __restrict__ off_all, int* __restrict__ cur_all, int* __restrict__ ent_q_all,
+                   int weight_kind, const int* __restrict__ off_all, int* __restrict__ cur_all, int* __restrict__ ent_q_all,
                    float* __restrict__ ent_w_all) {
     const int bi = blockIdx.y;
     const int* __restrict__ idx = idx_all + (size_t)bi * n3;
@@ -429,13 +429,29 @@ ti_csr_fill_kernel(int n3, int m, int div, const int* __restrict__ idx_all, cons
         const int s = idx[e];
         const int p = off[s] + atomicAdd(&cur[s], 1);
         eq[p] = e / div;   // div entries per input row (3 for three_interpolate, 1 for group_point)
-        ew[p] = w ? w[e] : 1.f;
+        float wt = 1.f;
+        if (w && weight_kind == 2) {
+            // w holds three_nn's squared distances (n, 3): the inverse-distance weights of pointnet_util.py:300-303 with the
+            // float expressions of the forward kernels (fp_interp_concat_*): IEEE divisions, (r1 + r2) + r3
+            const int r = e / 3, j = e - 3 * r;
+            const float r1 = 1.0f / fmaxf(w[r * 3 + 0], 1e-10f), r2 = 1.0f / fmaxf(w[r * 3 + 1], 1e-10f);
+            const float r3 = 1.0f / fmaxf(w[r * 3 + 2], 1e-10f);
+            const float norm = (r1 + r2) + r3;
+            wt = (j == 0 ? r1 : (j == 1 ? r2 : r3)) / norm;
+        } else if (w) {
+            wt = w[e];
+        }
+        ew[p] = wt;
     }
 }
 
-// thread -> (source slot, float4 column); each slot walks the list of its source point, four entries in flight
+// thread -> (source slot, float4 column); each slot walks the list of its source point, four entries in flight.
+// Input rows are `stride` floats apart (>= c: the caller may hand over a column slice of a wider gradient in place);
+// ALIGNED = every row starts on a 16-byte boundary, else the 16-byte loads are issued as 4-byte-aligned ones.
+typedef float f32x4_u __attribute__((ext_vector_type(4), aligned(4)));
+template <bool ALIGNED>
 __global__ void __launch_bounds__(256)
-ti_csr_gather_kernel(int n, int n3, int c, int m, const float* __restrict__ grad_out_all, const int* __restrict__ off_all,
+ti_csr_gather_kernel(int n, int n3, int c, int stride, int m, const float* __restrict__ grad_out_all, const int* __restrict__ off_all,
                      const int* __restrict__ ent_q_all, const float* __restrict__ ent_w_all,
                      float* __restrict__ grad_points_all) {
     const int cv = c >> 2;
@@ -444,7 +460,11 @@ ti_csr_gather_kernel(int n, int n3, int c, int m, const float* __restrict__ grad
     const int bi = blockIdx.y;
     const int s = blockIdx.x * spb + slot;
     if (slot >= spb || s >= m) return;
-    const f32x4* __restrict__ go = reinterpret_cast<const f32x4*>(grad_out_all + (size_t)bi * n * c);
+    const float* __restrict__ gbase = grad_out_all + (size_t)bi * n * stride + 4 * col;
+    auto row4 = [&](int q) -> f32x4 {
+        if constexpr (ALIGNED) return *reinterpret_cast<const f32x4*>(gbase + (size_t)q * stride);
+        else return *reinterpret_cast<const f32x4_u*>(gbase + (size_t)q * stride);
+    };
     const int* __restrict__ off = off_all + (size_t)bi * m;
     const int* __restrict__ eq = ent_q_all + (size_t)bi * n3;
     const float* __restrict__ ew = ent_w_all + (size_t)bi * n3;
@@ -456,7 +476,7 @@ ti_csr_gather_kernel(int n, int n3, int c, int m, const float* __restrict__ grad
 #pragma unroll
         for (int u = 0; u < 4; ++u) { q[u] = eq[e + u]; w[u] = ew[e + u]; }
 #pragma unroll
-        for (int u = 0; u < 4; ++u) g[u] = go[(size_t)q[u] * cv + col];
+        for (int u = 0; u < 4; ++u) g[u] = row4(q[u]);
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
             acc.x = __builtin_fmaf(g[u].x, w[u], acc.x); acc.y = __builtin_fmaf(g[u].y, w[u], acc.y);
@@ -464,7 +484,7 @@ ti_csr_gather_kernel(int n, int n3, int c, int m, const float* __restrict__ grad
         }
     }
     for (; e < hi; ++e) {
-        const f32x4 g = go[(size_t)eq[e] * cv + col];
+        const f32x4 g = row4(eq[e]);
         const float w = ew[e];
         acc.x = __builtin_fmaf(g.x, w, acc.x); acc.y = __builtin_fmaf(g.y, w, acc.y);
         acc.z = __builtin_fmaf(g.z, w, acc.z); acc.w = __builtin_fmaf(g.w, w, acc.w);
@@ -760,15 +780,24 @@ extern "C" int pn2_three_interpolate_grad(int b, int n, int c, int m, const floa
 }
 
 // out[b, idx[b,e], :] += weight[b,e] * rows_in[b, e/div, :] for e < nent, as a list build + gather (see ti_csr_*).
-// rows_in (b, nent/div, c), out (b, nsrc, c) overwritten.  Internal: shared by the two *_grad_ws entry points.
-extern "C" size_t pn2_scatter_rows_workspace_bytes(int b, int nent, int nsrc) {
-    return sizeof(int) * ((size_t)2 * b * nsrc + (size_t)2 * b * nent);  // cursor, offsets | entry row, entry weight
+// rows_in (b, nent/div, c), out (b, nsrc, c) overwritten.  The list depends on (idx, weight) only -- geometry -- so a
+// training step builds it ahead (pn2_scatter_plan_build, beside the previous step's dense work) and its backward pass
+// only gathers (pn2_scatter_plan_apply).  Plan layout (ints): cursor[b][nsrc] | offset[b][nsrc] | entry row[b][nent] |
+// entry weight[b][nent].
+extern "C" size_t pn2_scatter_plan_bytes(int b, int nent, int nsrc) {
+    if (b <= 0 || nent <= 0 || nsrc <= 0) return 0;
+    return sizeof(int) * ((size_t)2 * b * nsrc + (size_t)2 * b * nent);
 }
 
-extern "C" int pn2_scatter_rows_gather(int b, int nent, int div, int c, int nsrc, const float* rows_in, const int* idx,
-                                       const float* weight, float* out, void* workspace, void* stream) {
+extern "C" int pn2_scatter_plan_build(int b, int nent, int div, int nsrc, const int* idx, const float* weight, int weight_kind,
+                                      void* plan, size_t plan_bytes, void* stream) {
+    if (b <= 0 || nent <= 0 || nsrc <= 0 || div <= 0 || nent % div != 0) return PN2_EINVAL;
+    if (weight_kind < 0 || weight_kind > 2 || (weight_kind == 2 && div != 3)) return PN2_EINVAL;
+    if (!idx || !plan || (weight_kind != 0 && !weight)) return PN2_ENULL;
+    if (b > 65535) return PN2_ERANGE;
+    if (plan_bytes < pn2_scatter_plan_bytes(b, nent, nsrc) || ((uintptr_t)plan % 4) != 0) return PN2_EINVAL;
     hipStream_t st = static_cast<hipStream_t>(stream);
-    int* cnt = static_cast<int*>(workspace);
+    int* cnt = static_cast<int*>(plan);
     int* off = cnt + (size_t)b * nsrc;
     int* ent_q = off + (size_t)b * nsrc;
     float* ent_w = reinterpret_cast<float*>(ent_q + (size_t)b * nent);
@@ -777,12 +806,40 @@ extern "C" int pn2_scatter_rows_gather(int b, int nent, int div, int c, int nsrc
     dim3 ge(grid_x_for((unsigned long long)nent, 256, b), b);
     ti_csr_count_kernel<<<ge, 256, 0, st>>>(nent, nsrc, idx, cnt);
     ti_csr_scan_kernel<<<b, 256, 0, st>>>(nsrc, cnt, off);
-    ti_csr_fill_kernel<<<ge, 256, 0, st>>>(nent, nsrc, div, idx, weight, off, cnt, ent_q, ent_w);
-    const int spb = 256 / (c / 4);
-    dim3 gg((nsrc + spb - 1) / spb, b);
-    ti_csr_gather_kernel<<<gg, 256, 0, st>>>(nent / div, nent, c, nsrc, rows_in, off, ent_q, ent_w, out);
+    ti_csr_fill_kernel<<<ge, 256, 0, st>>>(nent, nsrc, div, idx, weight_kind ? weight : nullptr, weight_kind, off, cnt, ent_q, ent_w);
     PN2_RETURN_IF_LAUNCH_FAILED();
     return PN2_OK;
+}
+
+extern "C" int pn2_scatter_plan_apply(int b, int nent, int div, int c, int nsrc, const float* rows_in, int in_stride,
+                                      const void* plan, size_t plan_bytes, float* out, void* stream) {
+    if (b <= 0 || nent <= 0 || nsrc <= 0 || div <= 0 || nent % div != 0 || c <= 0 || in_stride < c) return PN2_EINVAL;
+    if (!rows_in || !plan || !out) return PN2_ENULL;
+    if (c % 4 != 0 || c > 1024 || ((uintptr_t)out % 16) != 0 || ((uintptr_t)rows_in % 4) != 0) return PN2_EUNSUP;
+    if (b > 65535) return PN2_ERANGE;
+    if (plan_bytes < pn2_scatter_plan_bytes(b, nent, nsrc) || ((uintptr_t)plan % 4) != 0) return PN2_EINVAL;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    const int* off = static_cast<const int*>(plan) + (size_t)b * nsrc;
+    const int* ent_q = off + (size_t)b * nsrc;
+    const float* ent_w = reinterpret_cast<const float*>(ent_q + (size_t)b * nent);
+    const int spb = 256 / (c / 4);
+    dim3 gg((nsrc + spb - 1) / spb, b);
+    const bool aligned = ((uintptr_t)rows_in % 16) == 0 && in_stride % 4 == 0;
+    if (aligned) ti_csr_gather_kernel<true><<<gg, 256, 0, st>>>(nent / div, nent, c, in_stride, nsrc, rows_in, off, ent_q, ent_w, out);
+    else ti_csr_gather_kernel<false><<<gg, 256, 0, st>>>(nent / div, nent, c, in_stride, nsrc, rows_in, off, ent_q, ent_w, out);
+    PN2_RETURN_IF_LAUNCH_FAILED();
+    return PN2_OK;
+}
+
+// Internal: list build + gather in one call, shared by the two *_grad_ws entry points.
+extern "C" size_t pn2_scatter_rows_workspace_bytes(int b, int nent, int nsrc) { return pn2_scatter_plan_bytes(b, nent, nsrc); }
+
+extern "C" int pn2_scatter_rows_gather(int b, int nent, int div, int c, int nsrc, const float* rows_in, const int* idx,
+                                       const float* weight, float* out, void* workspace, void* stream) {
+    const size_t bytes = pn2_scatter_plan_bytes(b, nent, nsrc);
+    const int rc = pn2_scatter_plan_build(b, nent, div, nsrc, idx, weight, weight ? 1 : 0, workspace, bytes, stream);
+    if (rc != PN2_OK) return rc;
+    return pn2_scatter_plan_apply(b, nent, div, c, nsrc, rows_in, c, workspace, bytes, out, stream);
 }
 
 extern "C" size_t pn2_three_interpolate_grad_workspace_bytes(int b, int n, int m) {

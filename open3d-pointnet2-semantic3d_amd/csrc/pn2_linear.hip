@@ -45,6 +45,28 @@ __device__ __forceinline__ void atomic_max_nonneg(float* addr, float v) {
     atomicMax(reinterpret_cast<int*>(addr), __float_as_int(v));
 }
 
+// Column sums of one 32x32 accumulator tile for the batch norm that follows (pn2_linear_bn_stats), in fp64 from the first
+// term on -- the same moments the two-pass path (bn_stats_kernel) forms, up to summation order: 48 fp64 operations per lane
+// and tile, ~23 us over all layers of a training step against the 280 us of statistics passes they replace.  One atomic
+// pair per column into slot copy `slot`.  Rows past `rows` hold exact zeros (their A operand was zeroed): they add nothing.
+__device__ __forceinline__ void push_column_stats(const f32x16& acc, int half, int col, int cout, unsigned slot,
+                                                  double* __restrict__ stats) {
+    double d1 = 0.0, d2 = 0.0;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const double d = (double)acc[r];
+        d1 += d;
+        d2 = __builtin_fma(d, d, d2);
+    }
+    d1 += __shfl_xor(d1, 32);
+    d2 += __shfl_xor(d2, 32);
+    if (half == 0 && col < cout) {
+        double* __restrict__ sl = stats + kPn2BnHead + (size_t)2 * cout * (1 + slot % (unsigned)kPn2BnSlots);
+        atomicAdd(sl + col, d1);
+        atomicAdd(sl + cout + col, d2);
+    }
+}
+
 // WK = 2 splits every k-tile between two waves of the same output tile (intra-workgroup split-K,
 // reduced through LDS before the epilogue): small-row layers then launch twice as many workgroups.
 // ST = register prefetch depth: the global loads of k-tile kt+ST-1 are issued under the MFMAs of tile
@@ -56,7 +78,7 @@ template <int WM, int WN, int NT, bool VEC_A, int WK = 1, int ST = 2, bool TB = 
 __global__ void __launch_bounds__(256)
 linear_kernel(int rows, int cin, int cout, const float* __restrict__ x,
               const float* __restrict__ w, const float* __restrict__ bias, int relu, int pool,
-              float* __restrict__ y) {
+              float* __restrict__ y, double* __restrict__ stats = nullptr) {
     static_assert(WM * WN * WK == 4, "4 waves per block");
     static_assert(WK == 1 || (WK == 2 && NT * 16 * 64 * WM * WN <= kBK * (32 * NT * WN + 4)), "reduction buffer must fit the B tile");
     constexpr int BM = 32 * WM;
@@ -264,6 +286,7 @@ linear_kernel(int rows, int cin, int cout, const float* __restrict__ x,
                 if (relu) v = fmaxf(v, 0.f);
                 if (row < rows) y[(size_t)row * cout + col] = v;
             }
+            if (stats) push_column_stats(acc[nt], half, col, cout, (unsigned)(blockIdx.x * WM + wm), stats);
         } else if (pool == 16) {
             // rows 0..15 live in regs 0..7, rows 16..31 in regs 8..15 (both halves)
             float v0 = acc[nt][0], v1 = acc[nt][8];
@@ -294,17 +317,17 @@ linear_kernel(int rows, int cin, int cout, const float* __restrict__ x,
 
 template <int WM, int WN, int NT, int WK = 1, int ST = 2>
 int launch_linear(int rows, int cin, int cout, const float* x, const float* w, const float* bias,
-                  int relu, int pool, float* y, hipStream_t st) {
+                  int relu, int pool, float* y, hipStream_t st, double* stats = nullptr) {
     constexpr int BM = 32 * WM, BN = 32 * NT * WN;
     dim3 grid((rows + BM - 1) / BM, cout / BN);
     const bool vec_a = (cin % 4 == 0) && ((uintptr_t)x % 16 == 0);
     if constexpr (WM == 4 && NT == 4) {
         // the 128x128 tile exists with 16-byte A loads only (the scalar-load variant spills its accumulators)
-        if (!vec_a) return launch_linear<2, 2, 2, 1, ST>(rows, cin, cout, x, w, bias, relu, pool, y, st);
-        linear_kernel<WM, WN, NT, true, WK, ST><<<grid, 256, 0, st>>>(rows, cin, cout, x, w, bias, relu, pool, y);
+        if (!vec_a) return launch_linear<2, 2, 2, 1, ST>(rows, cin, cout, x, w, bias, relu, pool, y, st, stats);
+        linear_kernel<WM, WN, NT, true, WK, ST><<<grid, 256, 0, st>>>(rows, cin, cout, x, w, bias, relu, pool, y, stats);
     } else {
-        if (vec_a) linear_kernel<WM, WN, NT, true, WK, ST><<<grid, 256, 0, st>>>(rows, cin, cout, x, w, bias, relu, pool, y);
-        else linear_kernel<WM, WN, NT, false, WK, ST><<<grid, 256, 0, st>>>(rows, cin, cout, x, w, bias, relu, pool, y);
+        if (vec_a) linear_kernel<WM, WN, NT, true, WK, ST><<<grid, 256, 0, st>>>(rows, cin, cout, x, w, bias, relu, pool, y, stats);
+        else linear_kernel<WM, WN, NT, false, WK, ST><<<grid, 256, 0, st>>>(rows, cin, cout, x, w, bias, relu, pool, y, stats);
     }
     PN2_RETURN_IF_LAUNCH_FAILED();
     return PN2_OK;
@@ -381,7 +404,8 @@ int launch_linear_dgrad(int rows, int n_in, int n_out, const float* dy, const fl
 template <int TM, int TN, bool VEC_A, int G>
 __global__ void __launch_bounds__(256)
 linear_splitk_kernel(int rows, int cin, int cout, const float* __restrict__ x, const float* __restrict__ w,
-                     const float* __restrict__ bias, int relu, int pool, float* __restrict__ y) {
+                     const float* __restrict__ bias, int relu, int pool, float* __restrict__ y,
+                     double* __restrict__ stats = nullptr) {
     // G = groups of 8 k in flight per wave (a group's MFMAs take ~0.1 us, an L2 round trip ~0.7 us)
     __shared__ float red[3 * TM * TN * 16 * 64];
     const int lane = threadIdx.x & 63, half = lane >> 5, l31 = lane & 31;
@@ -509,6 +533,7 @@ linear_splitk_kernel(int rows, int cin, int cout, const float* __restrict__ x, c
                     if (relu) v = fmaxf(v, 0.f);
                     if (row < rows) y[(size_t)row * cout + col] = v;
                 }
+                if (stats) push_column_stats(acc[a][b], half, col, cout, (unsigned)(blockIdx.x * TM + a), stats);
             } else {  // pool == 32: the tile's 32 rows are one neighbourhood
                 float v = acc[a][b][0];
 #pragma unroll
@@ -524,11 +549,11 @@ linear_splitk_kernel(int rows, int cin, int cout, const float* __restrict__ x, c
 
 template <int TM, int TN, int G = 2>
 int launch_linear_splitk(int rows, int cin, int cout, const float* x, const float* w, const float* bias, int relu,
-                         int pool, float* y, hipStream_t st) {
+                         int pool, float* y, hipStream_t st, double* stats = nullptr) {
     dim3 grid((rows + 32 * TM - 1) / (32 * TM), cout / (32 * TN));
     const bool vec_a = (cin % 4 == 0) && ((uintptr_t)x % 16 == 0);
-    if (vec_a) linear_splitk_kernel<TM, TN, true, G><<<grid, 256, 0, st>>>(rows, cin, cout, x, w, bias, relu, pool, y);
-    else linear_splitk_kernel<TM, TN, false, G><<<grid, 256, 0, st>>>(rows, cin, cout, x, w, bias, relu, pool, y);
+    if (vec_a) linear_splitk_kernel<TM, TN, true, G><<<grid, 256, 0, st>>>(rows, cin, cout, x, w, bias, relu, pool, y, stats);
+    else linear_splitk_kernel<TM, TN, false, G><<<grid, 256, 0, st>>>(rows, cin, cout, x, w, bias, relu, pool, y, stats);
     PN2_RETURN_IF_LAUNCH_FAILED();
     return PN2_OK;
 }
@@ -683,8 +708,8 @@ PN2_TUNABLE(int, g_lin_cfg, 0)     // tuning hook (pn2_debug_set(8, v)): 0 = aut
 PN2_TUNABLE(int, g_lin_stages, 3)  // tuning hook (pn2_debug_set(5, v)): register prefetch depth of linear_kernel
 PN2_TUNABLE(int, g_wgrad_waves, 0) // tuning hook (pn2_debug_set(9, v)): waves in flight targeted by pn2_linear_wgrad (0 = auto)
 
-extern "C" int pn2_linear(int rows, int cin, int cout, const float* x, const float* w,
-                          const float* bias, int relu, int pool, float* y, void* stream) {
+static int linear_impl(int rows, int cin, int cout, const float* x, const float* w,
+                       const float* bias, int relu, int pool, float* y, void* stream, double* stats) {
     if (rows <= 0 || cin <= 0 || cout <= 0) return PN2_EINVAL;
     if (!x || !w || !y) return PN2_ENULL;
     if (cout % 32 != 0 || ((uintptr_t)w % 16) != 0) return PN2_EUNSUP;
@@ -700,21 +725,21 @@ extern "C" int pn2_linear(int rows, int cin, int cout, const float* x, const flo
         }
     }
 #define PN2_LIN(WM_, WN_, NT_, WK_)                                                                          \
-    (st_depth >= 4 ? launch_linear<WM_, WN_, NT_, WK_, 4>(rows, cin, cout, x, w, bias, relu, pool, y, st)      \
-     : st_depth == 3 ? launch_linear<WM_, WN_, NT_, WK_, 3>(rows, cin, cout, x, w, bias, relu, pool, y, st)    \
-                     : launch_linear<WM_, WN_, NT_, WK_, 2>(rows, cin, cout, x, w, bias, relu, pool, y, st))
+    (st_depth >= 4 ? launch_linear<WM_, WN_, NT_, WK_, 4>(rows, cin, cout, x, w, bias, relu, pool, y, st, stats)      \
+     : st_depth == 3 ? launch_linear<WM_, WN_, NT_, WK_, 3>(rows, cin, cout, x, w, bias, relu, pool, y, st, stats)    \
+                     : launch_linear<WM_, WN_, NT_, WK_, 2>(rows, cin, cout, x, w, bias, relu, pool, y, st, stats))
     const int st_depth = g_lin_stages;
     if (g_lin_cfg >= 5 && (pool <= 1 || pool == 32)) {  // tuning hook: split-K direct-feed tiles
-        if (g_lin_cfg == 5) return launch_linear_splitk<1, 1, 2>(rows, cin, cout, x, w, bias, relu, pool, y, st);
-        if (g_lin_cfg == 6) return launch_linear_splitk<1, 1, 4>(rows, cin, cout, x, w, bias, relu, pool, y, st);
-        if (g_lin_cfg == 7) return launch_linear_splitk<1, 1, 8>(rows, cin, cout, x, w, bias, relu, pool, y, st);
-        if (g_lin_cfg == 8 && cout % 64 == 0) return launch_linear_splitk<1, 2, 4>(rows, cin, cout, x, w, bias, relu, pool, y, st);
+        if (g_lin_cfg == 5) return launch_linear_splitk<1, 1, 2>(rows, cin, cout, x, w, bias, relu, pool, y, st, stats);
+        if (g_lin_cfg == 6) return launch_linear_splitk<1, 1, 4>(rows, cin, cout, x, w, bias, relu, pool, y, st, stats);
+        if (g_lin_cfg == 7) return launch_linear_splitk<1, 1, 8>(rows, cin, cout, x, w, bias, relu, pool, y, st, stats);
+        if (g_lin_cfg == 8 && cout % 64 == 0) return launch_linear_splitk<1, 2, 4>(rows, cin, cout, x, w, bias, relu, pool, y, st, stats);
     }
     // few rows (FP1: 1024): one 32x32 tile per workgroup with the contraction split over its 4 waves fills the chip
     // where the LDS-tiled kernel leaves 3/4 of the CUs idle: 1024x768->256 15.3 -> 9.7 us, 1024x256->256 7.6 -> 6.0 us;
     // from 4096 rows on the LDS-tiled kernel wins (operand re-reads from L2) -- profiles/r02_linear_splitk.txt
     if (g_lin_cfg == 0 && rows <= 2048 && (pool <= 1 || pool == 32))
-        return launch_linear_splitk<1, 1, 2>(rows, cin, cout, x, w, bias, relu, pool, y, st);
+        return launch_linear_splitk<1, 1, 2>(rows, cin, cout, x, w, bias, relu, pool, y, st, stats);
     if (cout % 128 == 0 && g_lin_cfg != 0 && g_lin_cfg < 5) {  // tuning hook: force a tile configuration
         if (g_lin_cfg == 1) return PN2_LIN(4, 1, 4, 1);
         if (g_lin_cfg == 2) return PN2_LIN(2, 2, 2, 1);
@@ -737,6 +762,23 @@ extern "C" int pn2_linear(int rows, int cin, int cout, const float* x, const flo
     if (cout % 64 == 0) return PN2_LIN(4, 1, 2, 1);
     return PN2_LIN(4, 1, 1, 1);
 #undef PN2_LIN
+}
+
+extern "C" int pn2_linear(int rows, int cin, int cout, const float* x, const float* w,
+                          const float* bias, int relu, int pool, float* y, void* stream) {
+    return linear_impl(rows, cin, cout, x, w, bias, relu, pool, y, stream, nullptr);
+}
+
+// y = x . w (no bias, no activation) AND the per-column sums the following training-mode batch norm needs (tf_util.py:186-204:
+// conv2d -> batch_norm_template): every wave adds its tile's column sums of y and y^2 (16 fp32 terms per lane, then fp64) to
+// one of kPn2BnSlots copies of the accumulators in `bn_workspace` (pn2_bn_workspace_bytes(cout), ZEROED by the caller);
+// pn2_bn_relu_forward_stats folds the copies and normalises.  Saves the statistics pass over y.
+extern "C" int pn2_linear_bn_stats(int rows, int cin, int cout, const float* x, const float* w, float* y,
+                                   void* bn_workspace, size_t workspace_bytes, void* stream) {
+    if (!bn_workspace) return PN2_ENULL;
+    if (cout <= 0 || workspace_bytes < sizeof(double) * pn2_bn_ws_doubles(cout, kPn2BnSlots) || ((uintptr_t)bn_workspace % 8) != 0)
+        return PN2_EINVAL;
+    return linear_impl(rows, cin, cout, x, w, nullptr, 0, 0, y, stream, static_cast<double*>(bn_workspace));
 }
 
 // Data gradient of a dense layer (training): dx (rows, cin) = dy (rows, cout) . W^T, W (cin, cout) row-major as the forward

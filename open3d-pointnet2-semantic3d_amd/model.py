@@ -87,11 +87,14 @@ def _sa_fp_features_two_streams(l0_xyz, l0_points, hyperparams):
     return up, xyzs
 
 
-def compute_geometry(l0_xyz, hyperparams):
+def compute_geometry(l0_xyz, hyperparams, plans=False):
     """The weight-independent half of the whole stack for one batch: FPS + gather + ball query of the four SA levels and
     three_nn of the four FP levels (coordinates only, HIP index kernels, no autograd).  A trainer runs it for batch k+1
     on a side stream while batch k trains -- the 0.7 ms chain of dependent FPS rounds (16 of 256 CUs) then sits beside
-    the dense work instead of in front of it.  -> {"xyzs": [5], "idxs": [4], "nn": [4 x (dist, idx)], coarse to fine}."""
+    the dense work instead of in front of it.  plans=True (training) also builds the scatter lists of the backward pass
+    (pu.scatter_plan: group_point's and three_interpolate's gradients as gathers; they depend on idx / dist only).
+    -> {"xyzs": [5], "idxs": [4], "nn": [4 x (dist, idx)], "gplans": [4], "iplans": [4]}, coarse to fine; a plan is None
+    where the gradient kernel cannot use one (feature width not a multiple of 4) or plans=False."""
     with torch.no_grad():
         xyzs, idxs = [l0_xyz.contiguous()], []
         for li in range(4):
@@ -101,12 +104,31 @@ def compute_geometry(l0_xyz, hyperparams):
             xyzs.append(new_xyz)
             idxs.append(idx)
         nn = [three_nn(xyzs[3 - fi], xyzs[4 - fi]) for fi in range(4)]
-    return {"xyzs": xyzs, "idxs": idxs, "nn": nn}
+        gplans, iplans = [None] * 4, [None] * 4
+        if plans:
+            for li in range(4):  # level li groups the features of level li: colour (3 wide) for li = 0, else the MLP output
+                width = 3 * int(hyperparams["use_color"]) if li == 0 else SA_MLPS[li - 1][-1]
+                if width > 0 and width % 4 == 0:
+                    gplans[li] = pu.scatter_plan(idxs[li], xyzs[li].shape[1])
+            for fi in range(4):
+                width = SA_MLPS[3][-1] if fi == 0 else FP_MLPS[fi - 1][-1]
+                if width % 4 == 0:
+                    iplans[fi] = pu.scatter_plan(nn[fi][1], xyzs[4 - fi].shape[1], nn[fi][0], weight_kind=2)
+    return {"xyzs": xyzs, "idxs": idxs, "nn": nn, "gplans": gplans, "iplans": iplans}
 
 
 def geometry_tensors(geo):
     """flat list of the tensors of a geometry dict (fixed order): for copies between static graph buffers"""
-    return geo["xyzs"][1:] + geo["idxs"] + [t for pair in geo["nn"] for t in pair]
+    plans = [t for t in geo.get("gplans", []) + geo.get("iplans", []) if t is not None]
+    return geo["xyzs"][1:] + geo["idxs"] + [t for pair in geo["nn"] for t in pair] + plans
+
+
+def clone_geometry(geo, l0_xyz):
+    """a copy of a geometry dict in fresh buffers (the static buffers a captured graph reads), level 0 = l0_xyz"""
+    cl = lambda t: None if t is None else t.clone()
+    return {"xyzs": [l0_xyz] + [t.clone() for t in geo["xyzs"][1:]], "idxs": [t.clone() for t in geo["idxs"]],
+            "nn": [(d.clone(), i.clone()) for d, i in geo["nn"]],
+            "gplans": [cl(t) for t in geo.get("gplans", [None] * 4)], "iplans": [cl(t) for t in geo.get("iplans", [None] * 4)]}
 
 
 def get_sa_fp_features(point_cloud, is_training, hyperparams, bn_decay=None, two_streams=False, geometry=None):
@@ -134,7 +156,8 @@ def get_sa_fp_features(point_cloud, is_training, hyperparams, bn_decay=None, two
             xyzs[-1], feats[-1], npoint=hyperparams[k + "npoint"], radius=hyperparams[k + "radius"],
             nsample=hyperparams[k + "nsample"], mlp=list(SA_MLPS[li]), mlp2=None, group_all=False,
             is_training=is_training, bn_decay=bn_decay, scope="layer%d" % (li + 1),
-            geometry=None if geometry is None else (geometry["xyzs"][li + 1], geometry["idxs"][li]))
+            geometry=None if geometry is None else (geometry["xyzs"][li + 1], geometry["idxs"][li],
+                                                    geometry.get("gplans", [None] * 4)[li]))
         xyzs.append(new_xyz)
         feats.append(new_points)
 
@@ -143,7 +166,8 @@ def get_sa_fp_features(point_cloud, is_training, hyperparams, bn_decay=None, two
     for fi in range(4):
         lvl = 3 - fi  # target level: 3,2,1,0
         up = pointnet_fp_module(xyzs[lvl], xyzs[lvl + 1], feats[lvl], up, list(FP_MLPS[fi]), is_training, bn_decay,
-                                scope="fa_layer%d" % (fi + 1), nn=None if geometry is None else geometry["nn"][fi])
+                                scope="fa_layer%d" % (fi + 1),
+                                nn=None if geometry is None else tuple(geometry["nn"][fi]) + (geometry.get("iplans", [None] * 4)[fi],))
     end_points["xyzs"] = xyzs
     return up, end_points
 

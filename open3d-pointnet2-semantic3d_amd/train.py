@@ -124,7 +124,7 @@ class Trainer:
             for t in model.geometry_tensors(geo):
                 t.record_stream(caller)  # allocated on the side stream, consumed on this one
         else:
-            geo = model.compute_geometry(self._xyz_of(pc), self.hp)
+            geo = model.compute_geometry(self._xyz_of(pc), self.hp, plans=True)
         self._geo, self._geo_tag = None, None
         return geo
 
@@ -136,7 +136,7 @@ class Trainer:
         g = self._geo_stream
         g.wait_event(after_event)
         with torch.cuda.stream(g):
-            self._geo = model.compute_geometry(self._xyz_of(next_pc), self.hp)
+            self._geo = model.compute_geometry(self._xyz_of(next_pc), self.hp, plans=True)
             self._geo_event = torch.cuda.Event()
             self._geo_event.record(g)
         self._geo_tag = (next_pc.data_ptr(), next_pc._version, tuple(next_pc.shape))
@@ -205,8 +205,7 @@ class Trainer:
         """record forward + loss + backward + Adam of one step into a hipGraph (static input and geometry buffers)."""
         torch.cuda.synchronize()
         st = [pc.clone(), labels.clone(), smpw.clone()]
-        sg = {"xyzs": [self._xyz_of(st[0])] + [t.clone() for t in geo["xyzs"][1:]], "idxs": [t.clone() for t in geo["idxs"]],
-              "nn": [(d.clone(), i.clone()) for d, i in geo["nn"]]}
+        sg = model.clone_geometry(geo, self._xyz_of(st[0]))
         for p in self.bucket.params:
             p.grad = None
         g = torch.cuda.CUDAGraph()

@@ -24,10 +24,13 @@ from ..tf_ops.tf_sampling import farthest_point_sample, farthest_point_sample_an
 
 def sample_and_group(npoint, radius, nsample, xyz, points, knn=False, use_xyz=True, geometry=None):
     """-> new_xyz (B,npoint,3), new_points (B,npoint,nsample,3+C), idx, grouped_xyz.
-    geometry = (new_xyz, idx) (extension): the weight-independent half -- FPS, gather, ball query -- was computed
-    ahead (model.compute_geometry on a side stream); only the grouping runs here."""
+    geometry = (new_xyz, idx[, plan]) (extension): the weight-independent half -- FPS, gather, ball query, and optionally
+    the scatter plan of the grouping's gradient (scatter_plan) -- was computed ahead (model.compute_geometry on a side
+    stream); only the grouping runs here."""
+    plan = None
     if geometry is not None:
-        new_xyz, idx = geometry
+        new_xyz, idx = geometry[0], geometry[1]
+        plan = geometry[2] if len(geometry) > 2 else None
     else:
         new_xyz = gather_point(xyz, farthest_point_sample(npoint, xyz))
         if knn:
@@ -37,7 +40,7 @@ def sample_and_group(npoint, radius, nsample, xyz, points, knn=False, use_xyz=Tr
     if (USE_FUSED_TRAIN_FRONT and points is not None and use_xyz and points.dtype == torch.float32
             and (points.requires_grad or not torch.is_grad_enabled())):
         # gather + centre + concat in one launch; grouped_xyz is a view of its first three columns
-        new_points = _SAGroupConcat.apply(xyz.contiguous(), new_xyz.contiguous(), points.contiguous(), idx)
+        new_points = _SAGroupConcat.apply(xyz.contiguous(), new_xyz.contiguous(), points.contiguous(), idx, plan)
         return new_xyz, new_points, idx, new_points[..., :3]
     grouped_xyz = group_point(xyz, idx)
     grouped_xyz = grouped_xyz - new_xyz.unsqueeze(2)  # translation normalisation (:44-46)
@@ -122,23 +125,58 @@ def _sa_group_concat(xyz, new_xyz, points, idx):
 
 
 
+def scatter_plan(idx, nsrc, weight=None, weight_kind=None):
+    """The (weight-independent) list behind the gradients of group_point / three_interpolate, built ahead of the backward
+    pass (pn2_scatter_plan_build): idx (b, rows, k) int32 into nsrc source points; weight (b, rows, k) or None.
+    weight_kind 2: `weight` holds three_nn's squared distances.  -> opaque uint8 tensor."""
+    b = idx.shape[0]
+    nent = idx.shape[1] * idx.shape[2]
+    div = idx.shape[2] if weight is not None else 1
+    kind = (1 if weight_kind is None else weight_kind) if weight is not None else 0
+    nbytes = lib.pn2_scatter_plan_bytes(b, nent, nsrc)
+    plan = torch.empty(nbytes, dtype=torch.uint8, device=idx.device)
+    with torch.cuda.device(idx.device):
+        check(lib.pn2_scatter_plan_build(b, nent, div, nsrc, ptr(idx), ptr(weight), kind, ptr(plan), nbytes, stream_ptr()),
+              "pn2_scatter_plan_build")
+    return plan
+
+
+def _scatter_plan_apply(plan, rows_in, col0, c, nent, div, nsrc):
+    """columns [col0, col0+c) of rows_in (b, ..., width) (read in place) scattered through `plan` -> (b, nsrc, c)"""
+    b, width = rows_in.shape[0], rows_in.shape[-1]
+    if not rows_in.is_contiguous():
+        rows_in = rows_in.contiguous()
+    out = torch.empty((b, nsrc, c), dtype=torch.float32, device=rows_in.device)
+    with torch.cuda.device(rows_in.device):
+        check(lib.pn2_scatter_plan_apply(b, nent, div, c, nsrc, ctypes.c_void_p(rows_in.data_ptr() + 4 * col0), width,
+                                         ptr(plan), plan.numel(), ptr(out), stream_ptr()), "pn2_scatter_plan_apply")
+    return out
+
+
+def _plan_usable(plan, c):
+    return plan is not None and c % 4 == 0 and c <= 1024
+
+
 class _SAGroupConcat(torch.autograd.Function):
     """[group_point(xyz) - new_xyz | group_point(points)] in ONE launch (pn2_sa_group_concat) for the training path
     (util/pointnet_util.py:39-54 as four TF ops: two gathers, tile + subtract, concat).  Gradient w.r.t. `points` only
     (coordinates are data): the feature columns of the upstream gradient go through the list-and-gather
-    pn2_group_point_grad_ws."""
+    pn2_group_point_grad_ws -- or, with a `plan` built ahead (scatter_plan(idx, n)), through the gather alone, reading the
+    feature columns of the upstream gradient in place."""
 
     @staticmethod
-    def forward(ctx, xyz, new_xyz, points, idx):
+    def forward(ctx, xyz, new_xyz, points, idx, plan=None):
         out = _sa_group_concat(xyz, new_xyz, points, idx)
-        ctx.save_for_backward(idx)
+        ctx.save_for_backward(idx, plan)
         ctx.n, ctx.c = xyz.shape[1], points.shape[2]
         return out
 
     @staticmethod
     def backward(ctx, grad_out):
-        (idx,) = ctx.saved_tensors
+        idx, plan = ctx.saved_tensors
         b, m, ns, _ = grad_out.shape
+        if _plan_usable(plan, ctx.c):
+            return None, None, _scatter_plan_apply(plan, grad_out, 3, ctx.c, m * ns, 1, ctx.n), None, None
         g = grad_out[..., 3:].contiguous()  # (b,m,ns,c)
         gp = torch.empty((b, ctx.n, ctx.c), dtype=torch.float32, device=g.device)
         nbytes = lib.pn2_group_point_grad_workspace_bytes(b, ctx.n, m, ns)
@@ -146,32 +184,38 @@ class _SAGroupConcat(torch.autograd.Function):
         with torch.cuda.device(g.device):
             check(lib.pn2_group_point_grad_ws(b, ctx.n, ctx.c, m, ns, ptr(g), ptr(idx), ptr(gp), ptr(ws), nbytes,
                                               stream_ptr()), "pn2_group_point_grad_ws")
-        return None, None, gp, None
+        return None, None, gp, None, None
 
 
 class _FPInterpConcat(torch.autograd.Function):
     """[three_interpolate(points2, idx, w(dist)) | points1] in ONE launch (pn2_fp_interp_concat) for the training path
     (util/pointnet_util.py:300-311: clamp, reciprocal, sum, divide, three_interpolate, concat).  Gradients: points2
-    through pn2_three_interpolate_grad_ws with the same weights, points1 = its slice of the upstream gradient."""
+    through pn2_three_interpolate_grad_ws with the same weights -- or the gather of a `plan` built ahead
+    (scatter_plan(idx, m, dist, weight_kind=2)) -- points1 = its slice of the upstream gradient."""
 
     @staticmethod
-    def forward(ctx, dist, idx, points1, points2):
+    def forward(ctx, dist, idx, points1, points2, plan=None):
         out = _fp_interp_concat(dist, idx, points1, points2)
-        ctx.save_for_backward(dist, idx)
+        ctx.save_for_backward(dist, idx, plan)
         ctx.m, ctx.c2 = points2.shape[1], points2.shape[2]
         ctx.c1 = 0 if points1 is None else points1.shape[2]
         return out
 
     @staticmethod
     def backward(ctx, grad_out):
-        dist, idx = ctx.saved_tensors
+        dist, idx, plan = ctx.saved_tensors
+        g1 = grad_out[..., ctx.c2:] if ctx.c1 and ctx.needs_input_grad[2] else None
+        if not ctx.needs_input_grad[3]:
+            return None, None, g1, None, None
+        if _plan_usable(plan, ctx.c2):
+            n = idx.shape[1]
+            return None, None, g1, _scatter_plan_apply(plan, grad_out, 0, ctx.c2, 3 * n, 3, ctx.m), None
         d = torch.clamp(dist, min=1e-10)
         w = (1.0 / d)
         w = (w / w.sum(dim=2, keepdim=True)).contiguous()
         from ..tf_ops.tf_interpolate import three_interpolate_grad
         g2 = three_interpolate_grad(grad_out[..., :ctx.c2].contiguous(), idx, w, ctx.m)
-        g1 = grad_out[..., ctx.c2:].contiguous() if ctx.c1 else None
-        return None, None, g1, g2
+        return None, None, g1, g2, None
 
 
 # set False to force the unfused HIP path (group_concat + pn2_linear); used by tests/bench
@@ -224,7 +268,8 @@ def sa_features_inference(xyz, new_xyz, points, idx, mlp, bn=True, bn_decay=None
 def pointnet_sa_module(xyz, points, npoint, radius, nsample, mlp, mlp2, group_all, is_training, bn_decay, scope,
                        bn=True, pooling="max", knn=False, use_xyz=True, use_nchw=False, geometry=None):
     """PointNet Set Abstraction module -> new_xyz (B,npoint,3), new_points (B,npoint,mlp[-1] or mlp2[-1]), idx.
-    geometry = (new_xyz, idx) (extension, training path): precomputed FPS / ball-query result of this level."""
+    geometry = (new_xyz, idx[, plan]) (extension, training path): precomputed FPS / ball-query result of this level
+    (+ the scatter plan of the grouping's gradient)."""
     require_cuda(xyz, points)
     if use_nchw:
         raise NotImplementedError("use_nchw is a TF layout hint; the MI355X kernels are channels-last only")
@@ -232,7 +277,7 @@ def pointnet_sa_module(xyz, points, npoint, radius, nsample, mlp, mlp2, group_al
         if not is_training and not group_all and not knn and use_xyz and pooling == "max":
             # ---- inference fast path: HIP index ops + fused / MFMA MLP -------------
             xyz = xyz.contiguous()
-            new_xyz, idx = geometry if geometry is not None else sa_geometry(xyz, npoint, radius, nsample)
+            new_xyz, idx = geometry[:2] if geometry is not None else sa_geometry(xyz, npoint, radius, nsample)
             new_points = sa_features_inference(xyz, new_xyz, points, idx, mlp, bn, bn_decay)
             new_points = new_points.unsqueeze(2)
         else:
@@ -405,16 +450,18 @@ def fp_features_inference(dist, idx, points1, points2, mlp, bn=True, bn_decay=No
 
 def pointnet_fp_module(xyz1, xyz2, points1, points2, mlp, is_training, bn_decay, scope, bn=True, nn=None):
     """Feature propagation: xyz1 (B,n1,3) dense, xyz2 (B,n2,3) sparse, points1 (B,n1,c1) or None,
-    points2 (B,n2,c2) -> (B,n1,mlp[-1]).  nn = (dist, idx) (extension): three_nn(xyz1, xyz2) computed ahead."""
+    points2 (B,n2,c2) -> (B,n1,mlp[-1]).  nn = (dist, idx[, plan]) (extension): three_nn(xyz1, xyz2) computed ahead, and
+    optionally scatter_plan(idx, n2, dist, weight_kind=2) for the interpolation's gradient."""
     require_cuda(xyz1, xyz2, points1, points2)
     with tf_util.variable_scope(scope):
-        dist, idx = nn if nn is not None else three_nn(xyz1, xyz2)
+        dist, idx = (nn[0], nn[1]) if nn is not None else three_nn(xyz1, xyz2)
+        plan = nn[2] if nn is not None and len(nn) > 2 else None
         if not is_training:
             # weights + interpolate + concat fused, then LDS-resident MLP chains / MFMA layers
             return fp_features_inference(dist, idx, points1, points2, mlp, bn, bn_decay)
         if USE_FUSED_TRAIN_FRONT and points2.dtype == torch.float32:
             new_points1 = _FPInterpConcat.apply(dist, idx, None if points1 is None else points1.contiguous(),
-                                                points2.contiguous())
+                                                points2.contiguous(), plan)
         else:
             dist = torch.clamp(dist, min=1e-10)
             norm = (1.0 / dist).sum(dim=2, keepdim=True)

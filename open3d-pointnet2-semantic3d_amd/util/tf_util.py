@@ -50,8 +50,10 @@ class VariableStore:
         return t
 
     def set_step(self, step):
+        # a fill KERNEL on the current stream.  (`t[1] = int(step)` is a host-to-device copy of a pageable scalar: it blocks
+        # the host until everything queued before it has run -- measured 4.2 ms per training step, tools/train_host_probe.py)
         for t in self._dropout.values():
-            t[1] = int(step)
+            t[1:2].fill_(int(step))
 
     def get_variable(self, name, shape, init):
         if name not in self.params:
@@ -291,6 +293,19 @@ def hip_matmul(x2d, w):
     return hip_linear(x2d, w.contiguous(), None, relu=False)
 
 
+def hip_matmul_bn_stats(x2d, w, ws):
+    """y = x2d @ w on pn2_linear_bn_stats: the GEMM also leaves the column sums of y and y^2 in the ZEROED batch-norm
+    workspace `ws` (pn2_bn_workspace_bytes(cout) bytes) for pn2_bn_relu_forward_stats.  cout % 32 == 0."""
+    require_cuda(x2d, w)
+    rows, cin = x2d.shape
+    cout = w.shape[1]
+    y = torch.empty((rows, cout), dtype=torch.float32, device=x2d.device)
+    with torch.cuda.device(x2d.device):
+        check(lib.pn2_linear_bn_stats(rows, cin, cout, ptr(x2d.contiguous()), ptr(w.contiguous()), ptr(y), ptr(ws),
+                                      ws.numel() * ws.element_size(), stream_ptr()), "pn2_linear_bn_stats")
+    return y
+
+
 def hip_linear_dgrad(dy, w):
     """dx (rows, cin) = dy (rows, cout) @ w^T with w (cin, cout) as the forward pass holds it (pn2_linear_dgrad)."""
     require_cuda(dy, w)
@@ -314,6 +329,17 @@ def _bn_scratch(c, device, fn, fn_ws0):
     if v is not None:
         return v, fn_ws0
     return torch.empty(nbytes // 8, dtype=torch.float64, device=device), fn
+
+
+USE_GEMM_BN_STATS = True  # batch statistics from the forward GEMM's epilogue (set False: separate pass over y; tests / A-B)
+
+
+def _bn_zeroed_scratch(c, device):
+    """zero-filled batch-norm accumulators for pn2_linear_bn_stats: a slice of the step's zero arena, else a fresh fill"""
+    nbytes = lib.pn2_bn_workspace_bytes(c)
+    arena = get_default_store().zero_arena
+    v = arena.take(nbytes) if arena is not None else None
+    return v if v is not None else torch.zeros(nbytes // 8, dtype=torch.float64, device=device)
 
 
 def _hip_wgrad(x2d, dy, w):
@@ -402,14 +428,21 @@ class _TrainDenseBnRelu(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x2d, w, b, gamma, beta, running_mean, running_var, decay, relu, pool):
-        y = hip_matmul(x2d, w) if USE_HIP_GEMM else x2d @ w
-        rows, c = y.shape
+        rows, c = x2d.shape[0], w.shape[1]
+        fused_stats = USE_HIP_GEMM and USE_GEMM_BN_STATS and c % 32 == 0
+        if fused_stats:
+            # the GEMM's epilogue leaves the column sums of y in the batch-norm workspace: no statistics pass over y
+            ws = _bn_zeroed_scratch(c, x2d.device)
+            fwd = lib.pn2_bn_relu_forward_stats
+            y = hip_matmul_bn_stats(x2d, w, ws)
+        else:
+            y = hip_matmul(x2d, w) if USE_HIP_GEMM else x2d @ w
+            ws, fwd = _bn_scratch(c, y.device, lib.pn2_bn_relu_forward, lib.pn2_bn_relu_forward_ws0)
         pooled = pool > 1
         z = torch.empty((rows // pool, c) if pooled else (rows, c), dtype=y.dtype, device=y.device)
         ties = torch.empty_like(z) if pooled else None
         save_mean = torch.empty(c, dtype=torch.float32, device=y.device)
         save_invstd = torch.empty_like(save_mean)
-        ws, fwd = _bn_scratch(c, y.device, lib.pn2_bn_relu_forward, lib.pn2_bn_relu_forward_ws0)
         with torch.cuda.device(y.device):
             check(fwd(rows, c, ptr(y), ptr(gamma), ptr(beta), ptr(b), BN_EPSILON, decay, int(relu),
                       int(pool), ptr(running_mean), ptr(running_var), ptr(ws), ws.numel() * ws.element_size(),

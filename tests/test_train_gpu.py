@@ -27,6 +27,113 @@ def test_linear_dgrad_and_matmul_vs_fp64(pn2, cuda, rows, cin, cout):
     close(y, x.astype(np.float64) @ w2.astype(np.float64))
 
 
+@pytest.mark.parametrize("rows,cin,cout,pool", [(4096, 64, 64, 0), (1000, 131, 128, 0), (524288, 9, 32, 32), (8192, 259, 256, 0),
+                                                (1024, 768, 256, 0), (131072, 128, 128, 0), (2048, 256, 512, 32), (16384, 320, 256, 0),
+                                                (33, 32, 32, 0)])
+def test_gemm_epilogue_batch_statistics(pn2, cuda, rows, cin, cout, pool):
+    """pn2_linear_bn_stats + pn2_bn_relu_forward_stats (column sums from the GEMM's accumulators) against float64 moments of
+    the same y, and against the two-pass path (GEMM, then a statistics pass): every tile shape of pn2_linear, ragged row
+    counts, a channel with |mean| >> std (cancellation in E[y^2] - E[y]^2)."""
+    import torch
+    tfu = pn2.util.tf_util
+    rs = np.random.RandomState(rows % 991 + cout)
+    x = rs.randn(rows, cin).astype(np.float32)
+    x[:, 0] = 1.0
+    w = (rs.randn(cin, cout) / np.sqrt(cin)).astype(np.float32)
+    w[0, 1] = 40.0  # column 1: mean 40, std ~1
+    gamma = (1.0 + 0.1 * rs.randn(cout)).astype(np.float32)
+    beta = (0.1 * rs.randn(cout)).astype(np.float32)
+    out = {}
+    for fused in (True, False):
+        tfu.USE_GEMM_BN_STATS = fused
+        try:
+            rm, rv = torch.zeros(cout, device=cuda), torch.ones(cout, device=cuda)
+            z = tfu._TrainDenseBnRelu.apply(T(x, cuda), T(w, cuda), None, T(gamma, cuda), T(beta, cuda), rm, rv, 0.5, True, pool)
+            out[fused] = (z.cpu().numpy(), rm.cpu().numpy(), rv.cpu().numpy())
+        finally:
+            tfu.USE_GEMM_BN_STATS = True
+    y = tfu.hip_matmul(T(x, cuda), T(w, cuda)).cpu().numpy().astype(np.float64)
+    mean, var = y.mean(0), y.var(0)
+    ref = np.maximum((y - mean) / np.sqrt(var + 1e-3) * gamma + beta, 0.0)
+    if pool:
+        ref = ref.reshape(rows // pool, pool, cout).max(1)
+    for fused in (True, False):
+        z, rm, rv = out[fused]
+        np.testing.assert_allclose(rm, 0.5 * mean, rtol=2e-6, atol=1e-6)
+        np.testing.assert_allclose(rv, 0.5 + 0.5 * var * rows / (rows - 1), rtol=2e-5, atol=1e-6)
+        np.testing.assert_allclose(z, ref, rtol=1e-4, atol=2e-5)
+    np.testing.assert_allclose(out[True][0], out[False][0], rtol=1e-5, atol=1e-5)
+
+
+@pytest.mark.parametrize("b,n,m,ns,c", [(2, 512, 128, 16, 64), (3, 1000, 77, 32, 128), (1, 64, 16, 8, 4)])
+def test_scatter_plan_group_point_gradient(pn2, cuda, b, n, m, ns, c):
+    """pn2_scatter_plan_build / _apply as groupPointGradLauncher (tf_grouping.cu:155-162): the feature columns of a wider
+    upstream gradient (3 + c floats per row: rows start 12 bytes off a 16-byte boundary) read in place, against float64
+    np.add.at; and the autograd node with a plan against the one without."""
+    import torch
+    pu = pn2.util.pointnet_util
+    rs = np.random.RandomState(n + c)
+    idx = rs.randint(0, n, size=(b, m, ns)).astype(np.int32)
+    idx[:, :, 1] = idx[:, :, 0]  # duplicates inside a group, as padded ball queries have
+    g = rs.randn(b, m, ns, 3 + c).astype(np.float32)
+    plan = pu.scatter_plan(T(idx, cuda), n)
+    out = pu._scatter_plan_apply(plan, T(g, cuda), 3, c, m * ns, 1, n).cpu().numpy()
+    ref = np.zeros((b, n, c))
+    for bi in range(b):
+        np.add.at(ref[bi], idx[bi].reshape(-1), g[bi, :, :, 3:].reshape(-1, c).astype(np.float64))
+    np.testing.assert_allclose(out, ref, rtol=1e-5, atol=1e-5)
+    xyz = T(rs.rand(b, n, 3).astype(np.float32), cuda)
+    new_xyz = xyz[:, :m].contiguous()
+    grads = []
+    for pl in (plan, None):
+        pts = T(np.ones((b, n, c), np.float32), cuda)
+        pts.requires_grad_(True)
+        o = pu._SAGroupConcat.apply(xyz, new_xyz, pts, T(idx, cuda), pl)
+        o.backward(T(g, cuda))
+        grads.append(pts.grad.cpu().numpy())
+    np.testing.assert_allclose(grads[0], grads[1], rtol=1e-5, atol=1e-5)
+    np.testing.assert_allclose(grads[0], ref, rtol=1e-5, atol=1e-5)
+
+
+@pytest.mark.parametrize("b,n,m,c2,c1", [(2, 1024, 256, 64, 32), (2, 777, 100, 128, 0), (1, 64, 16, 512, 256)])
+def test_scatter_plan_three_interpolate_gradient(pn2, cuda, b, n, m, c2, c1):
+    """the plan built from three_nn's distances (weight_kind 2: the inverse-distance weights of pointnet_util.py:300-303
+    formed inside the build) as threeinterpolate_grad_cpu (tf_interpolate.cpp:397-421), the interpolated columns of the
+    upstream gradient read in place; float64 reference and the plan-less autograd node."""
+    import torch
+    pu = pn2.util.pointnet_util
+    rs = np.random.RandomState(n + c2)
+    xyz1 = rs.rand(b, n, 3).astype(np.float32)
+    xyz2 = rs.rand(b, m, 3).astype(np.float32)
+    dist, idx = pn2.tf_ops.tf_interpolate.three_nn(T(xyz1, cuda), T(xyz2, cuda))
+    g = rs.randn(b, n, c2 + c1).astype(np.float32)
+    plan = pu.scatter_plan(idx, m, dist, weight_kind=2)
+    out = pu._scatter_plan_apply(plan, T(g, cuda), 0, c2, 3 * n, 3, m).cpu().numpy()
+    d = np.maximum(dist.cpu().numpy().astype(np.float64), 1e-10)
+    w = (1.0 / d) / (1.0 / d).sum(2, keepdims=True)
+    ii = idx.cpu().numpy()
+    ref = np.zeros((b, m, c2))
+    for bi in range(b):
+        for j in range(3):
+            np.add.at(ref[bi], ii[bi, :, j], w[bi, :, j, None] * g[bi, :, :c2].astype(np.float64))
+    np.testing.assert_allclose(out, ref, rtol=2e-5, atol=2e-5)
+    p1 = T(rs.randn(b, n, c1).astype(np.float32), cuda) if c1 else None
+    grads = []
+    for pl in (plan, None):
+        p2 = T(np.ones((b, m, c2), np.float32), cuda)
+        p2.requires_grad_(True)
+        if p1 is not None:
+            p1 = p1.detach().clone().requires_grad_(True)
+        o = pu._FPInterpConcat.apply(dist, idx, p1, p2, pl)
+        o.backward(T(g, cuda))
+        grads.append((p2.grad.cpu().numpy(), None if p1 is None else p1.grad.cpu().numpy()))
+    np.testing.assert_allclose(grads[0][0], grads[1][0], rtol=2e-5, atol=2e-5)
+    np.testing.assert_allclose(grads[0][0], ref, rtol=2e-5, atol=2e-5)
+    if c1:
+        np.testing.assert_array_equal(grads[0][1], g[:, :, c2:])
+        np.testing.assert_array_equal(grads[1][1], g[:, :, c2:])
+
+
 def test_weighted_ce_forward_backward_vs_float64(pn2, oracle, cuda):
     import torch
     rs = np.random.RandomState(0)
@@ -106,10 +213,10 @@ def test_every_gemm_of_a_real_step_is_as_accurate_as_the_library(pn2, cuda):
     hp.update(l1_npoint=256, l2_npoint=64, l3_npoint=32, l4_npoint=16)
     pc, labels, smpw = _batch(cuda, 0)
     seen = []
-    orig_mm, orig_dg = tfu.hip_matmul, tfu.hip_linear_dgrad
+    orig_mm, orig_dg, orig_mms = tfu.hip_matmul, tfu.hip_linear_dgrad, tfu.hip_matmul_bn_stats
 
-    def mm(x, w):
-        y = orig_mm(x, w)
+    def mm(x, w, ws=None):
+        y = orig_mm(x, w) if ws is None else orig_mms(x, w, ws)  # ws: the GEMM that also accumulates batch statistics
         ref = x.double() @ w.double()
         seen.append(("fwd", tuple(x.shape), w.shape[1], float((y.double() - ref).norm() / ref.norm()),
                      float(((x @ w).double() - ref).norm() / ref.norm())))
@@ -122,13 +229,13 @@ def test_every_gemm_of_a_real_step_is_as_accurate_as_the_library(pn2, cuda):
                      float(((dy @ w.t()).double() - ref).norm() / ref.norm())))
         return dx
 
-    tfu.hip_matmul, tfu.hip_linear_dgrad = mm, dg
+    tfu.hip_matmul, tfu.hip_linear_dgrad, tfu.hip_matmul_bn_stats = mm, dg, mm
     try:
         tfu.set_default_store(tfu.VariableStore(device=cuda, seed=5))
         logits, _ = pn2.model.get_model(pc, True, 9, hp, bn_decay=0.5)
         pn2.model.get_loss(logits, labels, smpw).backward()
     finally:
-        tfu.hip_matmul, tfu.hip_linear_dgrad = orig_mm, orig_dg
+        tfu.hip_matmul, tfu.hip_linear_dgrad, tfu.hip_matmul_bn_stats = orig_mm, orig_dg, orig_mms
     assert sum(1 for s_ in seen if s_[0] == "fwd") == 23 and sum(1 for s_ in seen if s_[0] == "dgrad") == 22
     for kind, shape, n, e_pn2, e_torch in seen:
         assert e_pn2 <= 1e-6 and e_pn2 <= 2.0 * e_torch + 1e-8, (kind, shape, n, e_pn2, e_torch)
