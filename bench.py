@@ -96,6 +96,27 @@ def kernel_model(name, a):
             fl += 2 * rows * cin * w
             cin = w
         return "mfma", fl
+    if name == "pn2_mlp_wide":      # ints: rows, cin, x_stride, nlayers, relu_last, pool, widths...
+        rows, cin, L = a[0], a[1], a[3]
+        fl = 0
+        for w in a[6:6 + L]:
+            fl += 2 * rows * cin * w
+            cin = w
+        return "mfma", fl
+    if name == "pn2_sa_mlp_wide":   # ints: b, n, m, nsample, c, nlayers, pool, widths...
+        b, n, m, ns, c, L = a[:6]
+        cin, fl = 3 + c, 0
+        for w in a[7:7 + L]:
+            fl += 2 * b * m * ns * cin * w
+            cin = w
+        return "mfma", fl
+    if name == "pn2_fp_mlp_wide":   # ints: b, n, m, c1, c2, nlayers, widths...
+        b, n, m, c1, c2, L = a[:6]
+        cin, fl = c1 + c2, 0
+        for w in a[6:6 + L]:
+            fl += 2 * b * n * cin * w
+            cin = w
+        return "mfma", fl
     if name == "pn2_fp_mlp_fused":
         b, n, m, c1, c2, L = a[:6]
         widths = a[6:6 + L]
@@ -384,6 +405,7 @@ def main():
     ap.add_argument("--fp-front", choices=("auto", "fused", "unfused"), default="auto",
                     help="FP front end inside the first FP4 MLP kernel (pn2_fp_mlp_fused) or materialised by "
                          "pn2_fp_interp_concat; auto = fused (faster at every pipeline depth with one stream per batch)")
+    ap.add_argument("--wide", default="auto", help="A/B: off = one pn2_linear per coarse-level layer; N = pn2_*_mlp_wide from N rows on")
     ap.add_argument("--train", action="store_true",
                     help="BASELINE configs[3] instead of the headline: data-parallel TRAINING steps (forward with batch-stat "
                          "BN + weighted CE + backward + one flat RCCL gradient all-reduce + Adam), 16 scenes per GPU")
@@ -436,6 +458,10 @@ def main():
     pn2._lib.lib.dup = tuple(args.dup)
     fused_fp = args.fp_front != "unfused"
     pn2.util.pointnet_util.USE_FUSED_FP = fused_fp
+    if args.wide != "auto":  # A/B: the one-launch-per-level coarse MLPs (pn2_*_mlp_wide) on / off / from 4096 rows on
+        pn2.util.pointnet_util.USE_MLP_WIDE = args.wide != "off"
+        if args.wide.isdigit():
+            pn2.util.pointnet_util.WIDE_MIN_ROWS = int(args.wide)
 
     def step():
         with torch.no_grad():

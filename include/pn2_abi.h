@@ -317,6 +317,32 @@ int pn2_mlp_chain(int rows, int cin, const float *x, int nlayers, const int *wid
                   const float *const *w, const float *const *bias, int pool, float *y,
                   void *stream);
 
+/* Wide dense-row MLP chain for the coarse levels (SA3 tail, SA4, FP2, FP3: pointnet_util.py:150-170 and :312-325,
+ * inference BN folded): up to 3 layers with widths in {128, 256, 512},
+ *   y = act(...relu(relu(x @ W0 + b0) @ W1 + b1)...)     x (rows, x_stride >= cin)   W_l (cin_l, widths[l]) row-major
+ * one workgroup per 32-row tile through all layers (activations in LDS, weights streamed from L2); relu_last selects the
+ * activation of the last layer; pool = 32: max over each group of 32 consecutive rows, y (rows/32, w_last); pool = 0:
+ * y (rows, w_last).  w, bias, y 16-byte aligned; W0 must hold ((cin + 7) & ~7) rows (zero rows behind the cin real ones:
+ * the kernel contracts in groups of 8).  PN2_EUNSUP when the configuration does not fit (callers fall back to pn2_linear
+ * per layer). */
+int pn2_mlp_wide(int rows, int cin, int x_stride, const float *x, int nlayers, const int *widths,
+                 const float *const *w, const float *const *bias, int relu_last, int pool, float *y, void *stream);
+/* The same chain behind the SA front end (pointnet_util.py:39-54: group_point, centre, concat [xyz | features]) for
+ * nsample = 32: rows are gathered through idx (b,m,32) straight into the first layer's operand tile.  W0's rows in the
+ * order the tile is built in: [features (c rows) | x y z (3 rows) | zero rows up to a multiple of 8] (the reference's
+ * variable is [xyz | features]: the caller rotates it once).  pool != 0: max over the 32 neighbours, y (b,m,w_last);
+ * else (b,m,32,w_last). */
+int pn2_sa_mlp_wide(int b, int n, int m, int nsample, int c, const float *xyz, const float *new_xyz,
+                    const float *points, const int *idx, int nlayers, const int *widths, const float *const *w,
+                    const float *const *bias, int pool, float *y, void *stream);
+/* ... and behind the FP front end (pointnet_util.py:300-311), i.e. pn2_fp_interp_concat + pn2_mlp_wide in one kernel:
+ *   x[b,j,:] = [ three_interpolate(points2, idx, w(dist))[b,j,:] | points1[b,j,:] ]   (never stored)
+ * dist,idx (b,n,3)  points2 (b,m,c2)  points1 (b,n,c1) or NULL; n % 32 == 0, c1 % 4 == 0, c2 % 4 == 0; W0 holds
+ * ((c2 + c1 + 7) & ~7) rows, interpolated channels first  ->  y (b*n, w_last), ReLU after every layer. */
+int pn2_fp_mlp_wide(int b, int n, int m, int c1, int c2, const float *dist, const int *idx, const float *points1,
+                    const float *points2, int nlayers, const int *widths, const float *const *w,
+                    const float *const *bias, float *y, void *stream);
+
 /* Fused feature-propagation block (pointnet_util.py:300-325, inference BN folded):
  *   x[b,j,:] = [ three_interpolate(points2, idx, w(dist))[b,j,:] | points1[b,j,:] ]   (never stored)
  *   y = relu(relu(x @ W0 + b0) @ W1 + b1)                                            (nlayers 1 or 2)

@@ -63,6 +63,11 @@ SIGNATURES = {
                             c_void_p, c_void_p, c_void_p, ctypes.c_size_t, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p],
     "pn2_bn_relu_backward_ws0": [ctypes.c_longlong, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int,
                              c_int, c_void_p, c_void_p, c_void_p, ctypes.c_size_t, c_void_p, c_void_p, c_void_p, c_void_p],
+    "pn2_mlp_wide": [c_int, c_int, c_int, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p],
+    "pn2_sa_mlp_wide": [c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p,
+                        c_void_p, c_int, c_void_p, c_void_p],
+    "pn2_fp_mlp_wide": [c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p,
+                        c_void_p, c_void_p, c_void_p],
     "pn2_scatter_plan_build": [c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_int, c_void_p, ctypes.c_size_t, c_void_p],
     "pn2_scatter_plan_apply": [c_int, c_int, c_int, c_int, c_int, c_void_p, c_int, c_void_p, ctypes.c_size_t, c_void_p, c_void_p],
     "pn2_linear_bn_stats": [c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, ctypes.c_size_t, c_void_p],
@@ -180,6 +185,15 @@ class _LibProxy:
             elif name == "pn2_mlp_chain":
                 wp = ctypes.cast(args[4], ctypes.POINTER(c_int))
                 ints += [wp[i] for i in range(args[3])]
+            elif name == "pn2_mlp_wide":     # (rows, cin, x_stride, x, nlayers, widths, ...)
+                wp = ctypes.cast(args[5], ctypes.POINTER(c_int))
+                ints += [wp[i] for i in range(args[4])]
+            elif name == "pn2_fp_mlp_wide":  # (b, n, m, c1, c2, dist, idx, points1, points2, nlayers, widths, ...)
+                wp = ctypes.cast(args[10], ctypes.POINTER(c_int))
+                ints += [wp[i] for i in range(args[9])]
+            elif name == "pn2_sa_mlp_wide":  # (b, n, m, nsample, c, xyz, new_xyz, points, idx, nlayers, widths, ...)
+                wp = ctypes.cast(args[10], ctypes.POINTER(c_int))
+                ints += [wp[i] for i in range(args[9])]
             self.trace.append((name, tuple(ints), s, e))
             return rc
 

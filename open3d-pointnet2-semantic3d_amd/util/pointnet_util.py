@@ -252,6 +252,20 @@ def sa_features_inference(xyz, new_xyz, points, idx, mlp, bn=True, bn_decay=None
             h = tf_util.conv2d(h, mlp[2], [1, 1], padding="VALID", stride=[1, 1], bn=bn, is_training=False,
                                scope="conv2", bn_decay=bn_decay, pool=nsample)
             new_points = h.squeeze(2)
+    if (new_points is None and USE_MLP_WIDE and USE_FUSED_SA and nsample == 32 and points is not None
+            and points.dtype == torch.float32 and points.shape[2] % 4 == 0 and 1 <= len(mlp) <= 3
+            and all(w in (128, 256, 512) for w in mlp) and idx.shape[0] * idx.shape[1] * 32 >= WIDE_MIN_ROWS):
+        # all layers wide (SA4): gather + centre + concat + the whole MLP + max over K in one launch
+        folded, cprev = [], 3 + points.shape[2]
+        for i, cout in enumerate(mlp):
+            with tf_util.variable_scope("conv%d" % i):
+                if i == 0:  # the kernel's first-layer row order: [features | xyz | zero pad to a multiple of 8]
+                    folded.append(tf_util.folded_dense(cprev, cout, bn, (1, 1, cprev, cout), pad_to=32,
+                                                       pad_in=-(-cprev // 8) * 8, rotate_rows=cprev - 3))
+                else:
+                    folded.append(tf_util.folded_dense(cprev, cout, bn, (1, 1, cprev, cout), pad_to=32))
+            cprev = cout
+        new_points = tf_util.hip_sa_mlp_wide(xyz, new_xyz, points, idx, [f[0] for f in folded], [f[1] for f in folded])
     if new_points is None:
         h = _sa_group_concat(xyz, new_xyz, points, idx)  # (B,M,K,3+C)
         pool_ok = nsample == 16 or nsample % 32 == 0
@@ -378,6 +392,10 @@ USE_FUSED_TRAIN_FRONT = True  # set False: the training path's SA / FP front end
 USE_MLP_CHAIN = True  # set False to force one pn2_linear launch per layer (tests/bench)
 
 
+USE_MLP_WIDE = True   # set False: coarse-level MLPs as one pn2_linear launch per layer (tests / A-B)
+WIDE_MIN_ROWS = 4096  # FP2 (128 tiles) still wins with its front end fused in (28 us vs 8 + 25); FP1 (1024 rows = 32 tiles) does not
+
+
 USE_FUSED_FP = True    # set False to force pn2_fp_interp_concat + separate MLP launches (tests/bench)
 
 
@@ -414,11 +432,27 @@ def dense_mlp_inference(x2d, cin, mlp, scope_fmt, bn=True, fp_front=None):
                 if y is not None:
                     h, i = y, take
                     break
+        if (h is None and USE_FUSED_FP and USE_MLP_WIDE and WIDE_MIN_ROWS <= rows <= 65536 and dist.shape[1] % 32 == 0
+                and points2.shape[2] % 4 == 0 and (points1 is None or points1.shape[2] % 4 == 0)
+                and all(w in (128, 256, 512) for w in mlp[:3])):
+            # coarse FP levels: front end + the whole MLP in one launch (pn2_fp_mlp_wide)
+            take = min(3, len(mlp))
+            y = tf_util.hip_fp_mlp_wide(dist, idx, points1, points2, [folded[k][0] for k in range(take)],
+                                        [folded[k][1] for k in range(take)])
+            if y is not None:
+                h, i = y, take
         if h is None:
             x = _fp_interp_concat(dist, idx, points1, points2, pad_to=pad_to)
             h = x.reshape(rows, x.shape[2])
     while i < len(mlp):
         done = False
+        # coarse levels (4096 .. 32768 rows, widths 128 / 256 / 512): the remaining layers in one launch (pn2_mlp_wide)
+        if USE_MLP_WIDE and WIDE_MIN_ROWS <= h.shape[0] <= 65536 and all(w in (128, 256, 512) for w in mlp[i:i + 3]):
+            take = min(3, len(mlp) - i)
+            y = tf_util.hip_mlp_wide(h, [folded[k][0] for k in range(i, i + take)], [folded[k][1] for k in range(i, i + take)])
+            if y is not None:
+                h, i = y, i + take
+                continue
         # the LDS-resident chain pays off when there are enough 32-row tiles to fill the chip
         if USE_MLP_CHAIN and h.shape[0] >= 65536 and all(w <= 128 and w % 32 == 0 for w in mlp[i:i + 2]):
             for take in (2, 1):

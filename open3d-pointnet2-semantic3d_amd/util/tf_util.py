@@ -257,6 +257,88 @@ def hip_mlp_chain(x2d, ws, bs, pool=0):
     return y
 
 
+def _layer_arrays(ws, bs):
+    import ctypes
+    L = len(ws)
+    widths = (ctypes.c_int * L)(*[w.shape[1] for w in ws])
+    wptrs = (ctypes.c_void_p * L)(*[w.data_ptr() for w in ws])
+    bptrs = (ctypes.c_void_p * L)(*[b.data_ptr() for b in bs])
+    return L, ctypes.cast(widths, ctypes.c_void_p), ctypes.cast(wptrs, ctypes.c_void_p), ctypes.cast(bptrs, ctypes.c_void_p), (widths, wptrs, bptrs)
+
+
+def hip_mlp_wide(x2d, ws, bs, relu_last=True, pool=0):
+    """up to three dense layers of width 128 / 256 / 512 in ONE launch (pn2_mlp_wide: a workgroup carries a 32-row tile
+    through all layers); pool = 32 adds the max over each group of 32 rows.  None when the library reports the
+    configuration as unsupported (caller falls back to hip_linear per layer)."""
+    from .._lib import PN2_EUNSUP
+    require_cuda(x2d)
+    x2d = x2d.contiguous()
+    rows, cin = x2d.shape
+    if ws[0].shape[0] < -(-cin // 8) * 8:  # the kernel reads W0 in groups of 8 rows
+        ws = [F.pad(ws[0], (0, 0, 0, -(-cin // 8) * 8 - ws[0].shape[0])).contiguous()] + list(ws[1:])
+    L, widths, wptrs, bptrs, keep = _layer_arrays(ws, bs)
+    y = torch.empty((rows // pool if pool else rows, ws[-1].shape[1]), dtype=torch.float32, device=x2d.device)
+    with torch.cuda.device(x2d.device):
+        rc = lib.pn2_mlp_wide(rows, cin, cin, ptr(x2d), L, widths, wptrs, bptrs, int(bool(relu_last)), int(pool), ptr(y),
+                              stream_ptr())
+    if rc == PN2_EUNSUP:
+        return None
+    check(rc, "pn2_mlp_wide")
+    return y
+
+
+def hip_fp_mlp_wide(dist, idx, points1, points2, ws, bs):
+    """[three_interpolate(points2) | points1] -> up to three wide dense layers in ONE launch (pn2_fp_mlp_wide);
+    -> (b*n, w_last) or None when the library reports the configuration as unsupported."""
+    from .._lib import PN2_EUNSUP
+    require_cuda(dist, idx, points1, points2)
+    b, n, _ = dist.shape
+    m, c2 = points2.shape[1], points2.shape[2]
+    c1 = 0 if points1 is None else points1.shape[2]
+    need = -(-(c1 + c2) // 8) * 8
+    if ws[0].shape[0] < need:
+        ws = [F.pad(ws[0], (0, 0, 0, need - ws[0].shape[0])).contiguous()] + list(ws[1:])
+    L, widths, wptrs, bptrs, keep = _layer_arrays(ws, bs)
+    y = torch.empty((b * n, ws[-1].shape[1]), dtype=torch.float32, device=dist.device)
+    p1 = None if points1 is None else points1.contiguous()
+    with torch.cuda.device(dist.device):
+        rc = lib.pn2_fp_mlp_wide(b, n, m, c1, c2, ptr(dist.contiguous()), ptr(idx.contiguous()), ptr(p1), ptr(points2.contiguous()),
+                                 L, widths, wptrs, bptrs, ptr(y), stream_ptr())
+    if rc == PN2_EUNSUP:
+        return None
+    check(rc, "pn2_fp_mlp_wide")
+    return y
+
+
+def sa_wide_first_layer(w0):
+    """W0 (3 + c, cout) in the reference's [xyz | features] row order (pointnet_util.py:52-54) -> the row order
+    pn2_sa_mlp_wide reads: [features | xyz | zero rows up to a multiple of 8]"""
+    w = torch.cat([w0[3:], w0[:3]], dim=0)
+    pad = -w.shape[0] % 8
+    return F.pad(w, (0, 0, 0, pad)).contiguous() if pad else w.contiguous()
+
+
+def hip_sa_mlp_wide(xyz, new_xyz, points, idx, ws, bs, pool=True):
+    """SA front end (gather, centre, concat) + up to three wide dense layers + max over the 32 neighbours in ONE launch
+    (pn2_sa_mlp_wide).  ws[0] in the kernel's row order (sa_wide_first_layer / folded_dense(rotate_rows, pad_in)).
+    -> (b, m, w_last) (pool) or (b, m, 32, w_last); None when unsupported."""
+    from .._lib import PN2_EUNSUP
+    require_cuda(xyz, new_xyz, points, idx)
+    b, n, _ = xyz.shape
+    m, ns = idx.shape[1], idx.shape[2]
+    c = points.shape[2]
+    L, widths, wptrs, bptrs, keep = _layer_arrays(ws, bs)
+    wl = ws[-1].shape[1]
+    y = torch.empty((b, m, wl) if pool else (b, m, ns, wl), dtype=torch.float32, device=xyz.device)
+    with torch.cuda.device(xyz.device):
+        rc = lib.pn2_sa_mlp_wide(b, n, m, ns, c, ptr(xyz.contiguous()), ptr(new_xyz.contiguous()), ptr(points.contiguous()),
+                                 ptr(idx.contiguous()), L, widths, wptrs, bptrs, int(bool(pool)), ptr(y), stream_ptr())
+    if rc == PN2_EUNSUP:
+        return None
+    check(rc, "pn2_sa_mlp_wide")
+    return y
+
+
 def hip_fp_mlp_fused(dist, idx, points1, points2, ws, bs):
     """[three_interpolate(points2) | points1] -> up to two dense layers in ONE kernel (pn2_fp_mlp_fused);
     returns (b*n, w_last) or None when the library reports the configuration as unsupported."""

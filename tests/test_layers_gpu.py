@@ -987,3 +987,106 @@ def test_train_layer_hip_bn_matches_torch_autograd(pn2, cuda, pool):
     for a, r in zip(outs[True][:-1], outs[False][:-1]):
         s = max(float(r.abs().max()), 1.0)
         assert float((a - r).abs().max()) <= 2e-4 * s
+
+
+@pytest.mark.parametrize("rows,cin,widths,pool,relu_last", [
+    (8192, 259, (256, 256, 512), 32, True),    # SA4 of the SSG model (materialised front end: odd row width, scalar loads)
+    (16384, 320, (256, 128), 0, True),         # FP3
+    (4096, 384, (256, 256), 0, True),          # FP2
+    (32768, 128, (256,), 32, True),            # SA3's wide last layer + max over K
+    (1000, 64, (128,), 0, False),              # ragged row count, one layer, no activation
+    (96, 768, (256, 256), 0, True),            # FP1's widths (large first contraction)
+    (64, 136, (512, 128, 256), 32, True),      # every slicing of the contraction (1, 4, 2 slices)
+])
+def test_mlp_wide_vs_float64(pn2, cuda, rows, cin, widths, pool, relu_last):
+    """pn2_mlp_wide (a workgroup carries a 32-row tile through up to three 128/256/512-wide layers, weights streamed from
+    L2, contraction slices added in LDS) against float64 of the same layers (pointnet_util.py:150-170 / :312-325 with the
+    inference BN folded), and bit-for-bit run-to-run."""
+    tfu = pn2.util.tf_util
+    rs = np.random.RandomState(rows + cin)
+    x = rs.randn(rows, cin).astype(np.float32)
+    ws, bs, c = [], [], cin
+    for w_ in widths:
+        ws.append((rs.randn(c, w_) / np.sqrt(c)).astype(np.float32))
+        bs.append((0.1 * rs.randn(w_)).astype(np.float32))
+        c = w_
+    y = tfu.hip_mlp_wide(T(x, cuda), [T(w_, cuda) for w_ in ws], [T(b_, cuda) for b_ in bs], relu_last=relu_last, pool=pool)
+    assert y is not None
+    h = x.astype(np.float64)
+    for li, (w_, b_) in enumerate(zip(ws, bs)):
+        h = h @ w_.astype(np.float64) + b_
+        if li < len(ws) - 1 or relu_last:
+            h = np.maximum(h, 0.0)
+    if pool:
+        h = h.reshape(rows // pool, pool, -1).max(1)
+    assert y.shape == h.shape
+    close(y.cpu().numpy(), h)
+    y2 = tfu.hip_mlp_wide(T(x, cuda), [T(w_, cuda) for w_ in ws], [T(b_, cuda) for b_ in bs], relu_last=relu_last, pool=pool)
+    assert (y2 == y).all()
+
+
+@pytest.mark.parametrize("b,n,m,c,widths,pool", [(2, 256, 64, 256, (256, 256, 512), True), (3, 100, 10, 128, (128, 256), True),
+                                                (1, 64, 16, 64, (512,), False)])
+def test_sa_mlp_wide_vs_float64(pn2, cuda, b, n, m, c, widths, pool):
+    """pn2_sa_mlp_wide: group_point + centre + concat [xyz | features] (pointnet_util.py:39-54) feeding the wide chain, max
+    over the 32 neighbours; the weights keep the reference's row order."""
+    tfu = pn2.util.tf_util
+    rs = np.random.RandomState(n + c)
+    xyz = rs.rand(b, n, 3).astype(np.float32)
+    new_xyz = xyz[:, :m].copy()
+    pts = rs.randn(b, n, c).astype(np.float32)
+    idx = rs.randint(0, n, size=(b, m, 32)).astype(np.int32)
+    ws, bs, cc = [], [], 3 + c
+    for w_ in widths:
+        ws.append((rs.randn(cc, w_) / np.sqrt(cc)).astype(np.float32))
+        bs.append((0.1 * rs.randn(w_)).astype(np.float32))
+        cc = w_
+    kws = [tfu.sa_wide_first_layer(T(ws[0], cuda))] + [T(w_, cuda) for w_ in ws[1:]]
+    y = tfu.hip_sa_mlp_wide(T(xyz, cuda), T(new_xyz, cuda), T(pts, cuda), T(idx, cuda), kws, [T(b_, cuda) for b_ in bs], pool=pool)
+    assert y is not None
+    bi = np.arange(b)[:, None, None]
+    g = np.concatenate([xyz[bi, idx] - new_xyz[:, :, None, :], pts[bi, idx]], -1).astype(np.float64)  # (b,m,32,3+c)
+    for w_, b_ in zip(ws, bs):
+        g = np.maximum(g @ w_.astype(np.float64) + b_, 0.0)
+    ref = g.max(2) if pool else g
+    assert y.shape == ref.shape
+    close(y.cpu().numpy(), ref)
+
+
+@pytest.mark.parametrize("b,n,m,c1,c2,widths", [(2, 1024, 256, 64, 256, (256, 128)), (3, 64, 16, 0, 128, (128,)),
+                                                 (1, 256, 64, 132, 60, (512, 256, 128))])
+def test_fp_mlp_wide_vs_float64(pn2, cuda, b, n, m, c1, c2, widths):
+    """pn2_fp_mlp_wide: inverse-distance weights + three_interpolate + concat [interpolated | points1]
+    (pointnet_util.py:300-311) feeding the wide chain; against float64 and against the materialised front end
+    (pn2_fp_interp_concat) + pn2_mlp_wide (bit-identical rows -> bit-identical result)."""
+    tfu, pu = pn2.util.tf_util, pn2.util.pointnet_util
+    rs = np.random.RandomState(n + c2)
+    xyz1 = rs.rand(b, n, 3).astype(np.float32)
+    xyz2 = rs.rand(b, m, 3).astype(np.float32)
+    dist, idx = pn2.tf_ops.tf_interpolate.three_nn(T(xyz1, cuda), T(xyz2, cuda))
+    p2 = rs.randn(b, m, c2).astype(np.float32)
+    p1 = rs.randn(b, n, c1).astype(np.float32) if c1 else None
+    ws, bs, cc = [], [], c1 + c2
+    for w_ in widths:
+        ws.append((rs.randn(cc, w_) / np.sqrt(cc)).astype(np.float32))
+        bs.append((0.1 * rs.randn(w_)).astype(np.float32))
+        cc = w_
+    tw, tb = [T(w_, cuda) for w_ in ws], [T(b_, cuda) for b_ in bs]
+    tp1 = None if p1 is None else T(p1, cuda)
+    y = tfu.hip_fp_mlp_wide(dist, idx, tp1, T(p2, cuda), tw, tb)
+    assert y is not None and y.shape == (b * n, widths[-1])
+    d = np.maximum(dist.cpu().numpy().astype(np.float64), 1e-10)
+    w = (1.0 / d) / (1.0 / d).sum(2, keepdims=True)
+    ii = idx.cpu().numpy()
+    bi = np.arange(b)[:, None]
+    h = sum(w[:, :, k, None] * p2.astype(np.float64)[bi, ii[:, :, k]] for k in range(3))
+    if p1 is not None:
+        h = np.concatenate([h, p1.astype(np.float64)], -1)
+    h = h.reshape(b * n, -1)
+    for w_, b_ in zip(ws, bs):
+        h = np.maximum(h @ w_.astype(np.float64) + b_, 0.0)
+    close(y.cpu().numpy(), h)
+    x = pu._fp_interp_concat(dist, idx, tp1, T(p2, cuda), pad_to=8).reshape(b * n, -1)
+    w0 = tw[0] if x.shape[1] == tw[0].shape[0] else __import__("torch").nn.functional.pad(tw[0], (0, 0, 0, x.shape[1] - tw[0].shape[0]))
+    y2 = tfu.hip_mlp_wide(x, [w0.contiguous()] + tw[1:], tb)
+    assert (y2 == y).all()
