@@ -169,6 +169,7 @@ def get_sa_fp_features(point_cloud, is_training, hyperparams, bn_decay=None, two
                                 scope="fa_layer%d" % (fi + 1),
                                 nn=None if geometry is None else tuple(geometry["nn"][fi]) + (geometry.get("iplans", [None] * 4)[fi],))
     end_points["xyzs"] = xyzs
+    end_points["sa_features"] = feats  # [l0 .. l4] point features of the SA levels (extension: hooks of the trainer)
     return up, end_points
 
 
