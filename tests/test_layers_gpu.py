@@ -1090,3 +1090,51 @@ def test_fp_mlp_wide_vs_float64(pn2, cuda, b, n, m, c1, c2, widths):
     w0 = tw[0] if x.shape[1] == tw[0].shape[0] else __import__("torch").nn.functional.pad(tw[0], (0, 0, 0, x.shape[1] - tw[0].shape[0]))
     y2 = tfu.hip_mlp_wide(x, [w0.contiguous()] + tw[1:], tb)
     assert (y2 == y).all()
+
+
+def test_mlp_wide_random_shapes_and_argument_checks(pn2, cuda):
+    """20 random (rows, cin, widths, pool) draws of pn2_mlp_wide against float64 (ragged row counts, contraction lengths
+    that are not multiples of 8 or 4, every width combination), then the entry points' refusals."""
+    import ctypes
+    tfu = pn2.util.tf_util
+    rs = np.random.RandomState(7)
+    for _ in range(20):
+        nl = rs.randint(1, 4)
+        widths = tuple(int(rs.choice([128, 256, 512])) for _ in range(nl))
+        pool = 32 if rs.rand() < 0.4 else 0
+        rows = int(rs.randint(1, 40)) * 32 if pool else int(rs.randint(1, 1500))
+        cin = int(rs.randint(1, 300))
+        x = rs.randn(rows, cin).astype(np.float32)
+        ws, bs, c = [], [], cin
+        for w_ in widths:
+            ws.append((rs.randn(c, w_) / np.sqrt(c)).astype(np.float32))
+            bs.append((0.1 * rs.randn(w_)).astype(np.float32))
+            c = w_
+        y = tfu.hip_mlp_wide(T(x, cuda), [T(w_, cuda) for w_ in ws], [T(b_, cuda) for b_ in bs], pool=pool)
+        if y is None:  # does not fit LDS: a legitimate refusal only for wide inputs in front of a 512-wide second buffer
+            assert cin > 256 or max(widths) == 512, (rows, cin, widths)
+            continue
+        h = x.astype(np.float64)
+        for w_, b_ in zip(ws, bs):
+            h = np.maximum(h @ w_.astype(np.float64) + b_, 0.0)
+        if pool:
+            h = h.reshape(rows // 32, 32, -1).max(1)
+        close(y.cpu().numpy(), h)
+    raw, L = pn2._lib._raw, pn2._lib
+    x = T(np.zeros((64, 128), np.float32), cuda)
+    w = T(np.zeros((128, 128), np.float32), cuda)
+    b = T(np.zeros(128, np.float32), cuda)
+    y = T(np.zeros((64, 128), np.float32), cuda)
+    P = lambda t: ctypes.c_void_p(t.data_ptr())  # noqa: E731
+    wid = (ctypes.c_int * 1)(128)
+    wid_bad = (ctypes.c_int * 1)(96)
+    wp, bp = (ctypes.c_void_p * 1)(w.data_ptr()), (ctypes.c_void_p * 1)(b.data_ptr())
+    call = lambda rows, cin, stride, nl, wd, pool: raw.pn2_mlp_wide(rows, cin, stride, P(x), nl, wd, wp, bp, 1, pool, P(y), None)  # noqa: E731
+    assert call(64, 128, 128, 1, wid, 0) == 0
+    assert call(64, 128, 128, 1, wid_bad, 0) == L.PN2_EUNSUP      # width not 128 / 256 / 512
+    assert call(64, 128, 128, 4, wid, 0) == L.PN2_EUNSUP          # more than three layers
+    assert call(64, 128, 128, 1, wid, 16) == L.PN2_EUNSUP         # pool other than 0 / 32
+    assert call(70, 128, 128, 1, wid, 32) == -1         # pooled rows not a multiple of 32
+    assert call(64, 128, 64, 1, wid, 0) == -1           # row stride shorter than the row
+    assert call(0, 128, 128, 1, wid, 0) == -1
+    assert raw.pn2_mlp_wide(64, 128, 128, None, 1, wid, wp, bp, 1, 0, P(y), None) == -2
