@@ -1,7 +1,8 @@
-// pn2_mlp_wide.hip -- the coarse levels' shared MLPs (SA3 tail, SA4, FP2, FP3 of the SSG model: 4096 .. 32768 rows, layer
-// widths 128 / 256 / 512) as ONE launch per level: up to three 1x1-conv layers (+bias, ReLU; inference BN folded by the
-// host, util/tf_util.py:181-203, pointnet_util.py:150-170 and :312-325) chained inside a workgroup, optionally behind the
-// SA front end (group_point + centre + concat, pointnet_util.py:39-54) and in front of the max over the K = 32 neighbours.
+// pn2_mlp_wide.hip -- the coarse levels' shared MLPs (SA4, FP2, FP3 of the SSG model: 4096 .. 16384 rows, layer widths
+// 128 / 256 / 512) as ONE launch per level: up to three 1x1-conv layers (+bias, ReLU; inference BN folded by the host,
+// util/tf_util.py:181-203, pointnet_util.py:150-170 and :312-325) chained inside a workgroup, optionally behind the SA
+// front end (group_point + centre + concat, pointnet_util.py:39-54) or the FP front end (inverse-distance weights +
+// three_interpolate + concat, pointnet_util.py:300-311), and in front of the max over the K = 32 neighbours.
 //
 // Why not the register-resident chain of pn2_sa_fused.hip: a 256-wide layer needs 256 KB of weights (LDS holds 160 KB) and
 // 2 x 128 accumulator registers per 32-row tile.  Why not one pn2_linear per layer (round 1): each of those launches
@@ -16,8 +17,9 @@
 //   * A operand: one ds_read_b128 per 8 k (lane = row l&31, half-wave h reads k0+4h .. k0+4h+3);
 //     B operand: straight from global memory / L2 -- lane (l&31, h) loads w[k0+4h+q][cb + 4*(l&31) .. +3] with one
 //     16-byte load per k: the four floats are the B values of the wave's four accumulator tiles, i.e. tile t of a wave
-//     holds the output columns cb + 4j + t (j = 0..31).  Three groups of 8 k are in flight under the 16 MFMAs of the
-//     current one (an L2 round trip is ~1 us, a group's MFMAs ~0.4 us);
+//     holds the output columns cb + 4j + t (j = 0..31).  Four groups of 8 k are in flight under the 16 MFMAs of the
+//     current one (an L2 round trip is ~1 us, a group's MFMAs ~0.4 us); the first groups of the NEXT layer are issued
+//     before the current layer's epilogue (weights do not depend on it);
 //   * the weights stream from L2 once per workgroup and layer (256 KB x rows/32: 64 MB per 256-wide layer at 8192 rows,
 //     ~5 us of the XCDs' aggregate L2 bandwidth beside ~9 us of MFMA time).
 #include "pn2_common.h"
@@ -47,7 +49,7 @@ struct WideParams {
     const float* W[3];
     const float* bias[3];
     float* y;
-    int sa[2];      // row strides (floats) of the two activation buffers
+    int sa[2];          // row strides (floats) of the two activation buffers
     int scratch_off;    // floats from the start of LDS (dedicated scratch)
     int scratch_alias;  // 1: the K-slice partial sums are parked in the layer's (consumed) input buffer
 };
