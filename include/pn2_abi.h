@@ -191,6 +191,11 @@ int pn2_scatter_plan_build(int b, int nent, int div, int nsrc, const int *idx, c
 int pn2_scatter_plan_apply(int b, int nent, int div, int c, int nsrc, const float *rows_in, int in_stride,
                            const void *plan, size_t plan_bytes, float *out, void *stream);
 
+/* n (<= 48) independent device-to-device copies in ONE launch: dst[i][0..bytes[i]) = src[i][0..bytes[i]); the three arrays
+ * are host arrays read at call time; regions must not overlap.  Training-step plumbing: a batch's geometry tensors (mixed
+ * int32 / float32 / byte buffers) into the static buffers the captured step reads. */
+int pn2_multi_copy(int n, const void *const *srcs, void *const *dsts, const unsigned long long *bytes, void *stream);
+
 /* ---- fused layer kernels (new: no reference kernel; they replace the TF
  *      sub-graphs of util/pointnet_util.py:44-54,150-170 and :300-325) ------- */
 

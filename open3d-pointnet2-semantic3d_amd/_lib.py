@@ -68,6 +68,7 @@ SIGNATURES = {
                         c_void_p, c_int, c_void_p, c_void_p],
     "pn2_fp_mlp_wide": [c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p,
                         c_void_p, c_void_p, c_void_p],
+    "pn2_multi_copy": [c_int, c_void_p, c_void_p, c_void_p, c_void_p],
     "pn2_scatter_plan_build": [c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_int, c_void_p, ctypes.c_size_t, c_void_p],
     "pn2_scatter_plan_apply": [c_int, c_int, c_int, c_int, c_int, c_void_p, c_int, c_void_p, ctypes.c_size_t, c_void_p, c_void_p],
     "pn2_linear_bn_stats": [c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, ctypes.c_size_t, c_void_p],

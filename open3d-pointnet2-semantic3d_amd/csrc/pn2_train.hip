@@ -113,6 +113,35 @@ inline int grid_1d(long long n) {
     return (int)(g < 1 ? 1 : (g > 256 * 16 ? 256 * 16 : g));
 }
 
+
+// up to kMultiCopyMax device-to-device copies in ONE launch (the per-batch geometry tensors -- mixed int32 / float32 / byte
+// buffers -- going into the static buffers a captured training step reads: torch._foreach_copy_ falls back to one memcpy
+// per tensor for mixed dtypes, ~25 launches on the step's critical path)
+constexpr int kMultiCopyMax = 48;
+struct MultiCopyArgs {
+    const unsigned char* src[kMultiCopyMax];
+    unsigned char* dst[kMultiCopyMax];
+    unsigned long long bytes[kMultiCopyMax];
+};
+
+__global__ void __launch_bounds__(256)
+multi_copy_kernel(MultiCopyArgs a) {
+    const int t = blockIdx.y;
+    const unsigned char* __restrict__ s = a.src[t];
+    unsigned char* __restrict__ d = a.dst[t];
+    const unsigned long long nb = a.bytes[t];
+    const unsigned long long stride = (unsigned long long)gridDim.x * 256;
+    if ((((uintptr_t)s | (uintptr_t)d) & 15) == 0) {
+        const unsigned long long nv = nb >> 4;
+        const uint4* __restrict__ s4 = reinterpret_cast<const uint4*>(s);
+        uint4* __restrict__ d4 = reinterpret_cast<uint4*>(d);
+        for (unsigned long long i = (unsigned long long)blockIdx.x * 256 + threadIdx.x; i < nv; i += stride) d4[i] = s4[i];
+        for (unsigned long long i = (nv << 4) + (unsigned long long)blockIdx.x * 256 + threadIdx.x; i < nb; i += stride) d[i] = s[i];
+    } else {
+        for (unsigned long long i = (unsigned long long)blockIdx.x * 256 + threadIdx.x; i < nb; i += stride) d[i] = s[i];
+    }
+}
+
 }  // namespace
 
 // model.get_loss (reference model.py:152-161): logits (rows,C) f32, labels (rows) int32 (label64 = 0) or int64 (label64 = 1),
@@ -175,6 +204,30 @@ extern "C" int pn2_adam_step(long long n, float* params, const float* grads, flo
     if (n <= 0) return PN2_EINVAL;
     if (!params || !grads || !m || !v || !hyper) return PN2_ENULL;
     adam_kernel<<<grid_1d(n), 256, 0, static_cast<hipStream_t>(stream)>>>(n, params, grads, m, v, hyper);
+    PN2_RETURN_IF_LAUNCH_FAILED();
+    return PN2_OK;
+}
+
+// n (<= 48) independent device-to-device copies in one launch: dst[i][0 .. bytes[i]) = src[i][0 .. bytes[i]).  srcs / dsts /
+// bytes are HOST arrays (read at call time); the regions must not overlap.  Plumbing of the training step (geometry
+// tensors of a batch into the static buffers of the captured graph).
+extern "C" int pn2_multi_copy(int n, const void* const* srcs, void* const* dsts, const unsigned long long* bytes, void* stream) {
+    if (n <= 0) return PN2_EINVAL;
+    if (n > kMultiCopyMax) return PN2_ERANGE;
+    if (!srcs || !dsts || !bytes) return PN2_ENULL;
+    MultiCopyArgs a = {};
+    unsigned long long mx = 0;
+    for (int i = 0; i < n; ++i) {
+        if (!srcs[i] || !dsts[i]) return PN2_ENULL;
+        a.src[i] = static_cast<const unsigned char*>(srcs[i]);
+        a.dst[i] = static_cast<unsigned char*>(dsts[i]);
+        a.bytes[i] = bytes[i];
+        if (bytes[i] > mx) mx = bytes[i];
+    }
+    unsigned long long gx = (mx / 16 + 255) / 256;
+    if (gx < 1) gx = 1;
+    if (gx > 64) gx = 64;  // 64 x n blocks: the largest tensors (scatter plans, ~5 MB) take a few grid strides
+    multi_copy_kernel<<<dim3((unsigned)gx, (unsigned)n), 256, 0, static_cast<hipStream_t>(stream)>>>(a);
     PN2_RETURN_IF_LAUNCH_FAILED();
     return PN2_OK;
 }

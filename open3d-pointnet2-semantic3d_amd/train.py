@@ -199,21 +199,28 @@ class Trainer:
                     self._capture(pc, labels, smpw, decay, geo)
                 self.hyper.copy_(self._hyper_host, non_blocking=True)
                 self.store.set_step(self.step_count)
-                for dst, src in zip(self._static[:3], (pc, labels, smpw)):
-                    if dst.data_ptr() != src.data_ptr():
-                        dst.copy_(src, non_blocking=True)
+                # every per-step device-to-device copy (inputs, and this batch's geometry when it is not in place yet) in ONE
+                # launch: they sit between two graphs on the critical path
+                pairs = [(d, s_) for d, s_ in zip(self._static[:3], (pc, labels, smpw))
+                         if d.data_ptr() != s_.data_ptr() and s_.is_contiguous() and s_.dtype == d.dtype]
+                for d, s_ in zip(self._static[:3], (pc, labels, smpw)):
+                    if d.data_ptr() != s_.data_ptr() and not (s_.is_contiguous() and s_.dtype == d.dtype):
+                        d.copy_(s_, non_blocking=True)
                 if self.geometry_in_graph:
                     # the graph starts with (this batch's geometry) <- `_static_geo_next`, which the previous replay's branch
                     # filled when this batch was announced as its `next_pc`; otherwise it is filled here
                     if geo is not None and not recapture:
-                        torch._foreach_copy_(model.geometry_tensors(self._static_geo_next), model.geometry_tensors(geo))
+                        pairs += list(zip(model.geometry_tensors(self._static_geo_next), model.geometry_tensors(geo)))
                     if next_pc is not None:
                         self._static_next_xyz.copy_(next_pc[:, :, 0:3] if self.hp["use_color"] else next_pc, non_blocking=True)
                         self._next_tag = self._tag(next_pc)
                     else:
                         self._next_tag = None  # the branch recomputes the geometry of a stale cloud: harmless
                 else:
-                    torch._foreach_copy_(model.geometry_tensors(self._static_geo), model.geometry_tensors(geo))
+                    pairs += list(zip(model.geometry_tensors(self._static_geo), model.geometry_tensors(geo)))
+                if pairs:
+                    tf_util.multi_copy_([d for d, _ in pairs], [s_ for _, s_ in pairs])
+                if not self.geometry_in_graph:
                     taken = torch.cuda.Event()
                     taken.record(self._stream)
                     self._prefetch(next_pc, taken)
@@ -238,7 +245,7 @@ class Trainer:
         g = torch.cuda.CUDAGraph()
         with torch.cuda.graph(g):
             if self.geometry_in_graph:
-                torch._foreach_copy_(model.geometry_tensors(sg), model.geometry_tensors(self._static_geo_next))
+                tf_util.multi_copy_(model.geometry_tensors(sg), model.geometry_tensors(self._static_geo_next))
                 # fork: the NEXT batch's FPS / ball query / three_nn / scatter plans as a branch of this graph.  Forked at
                 # the very start, the 0.7 ms FPS of its first level runs beside the forward pass of SA1 / SA2 (131072 ..
                 # 524288 rows, grids of thousands of workgroups, which the 16 CUs it holds cost 6 %); forked where the
@@ -247,7 +254,7 @@ class Trainer:
                 self._geo_stream.wait_stream(main)
                 with torch.cuda.stream(self._geo_stream):
                     tmp = model.compute_geometry(self._static_next_xyz, self.hp, plans=True)
-                    torch._foreach_copy_(model.geometry_tensors(self._static_geo_next), model.geometry_tensors(tmp))
+                    tf_util.multi_copy_(model.geometry_tensors(self._static_geo_next), model.geometry_tensors(tmp))
             loss = self._step_body(st[0], st[1], st[2], decay, geometry=sg)
             if self.geometry_in_graph:
                 torch.cuda.current_stream().wait_stream(self._geo_stream)  # join

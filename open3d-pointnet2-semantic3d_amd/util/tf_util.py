@@ -257,6 +257,27 @@ def hip_mlp_chain(x2d, ws, bs, pool=0):
     return y
 
 
+def multi_copy_(dsts, srcs):
+    """dsts[i].copy_(srcs[i]) for lists of contiguous device tensors of any dtypes in ONE launch (pn2_multi_copy);
+    torch._foreach_copy_ issues one memcpy per tensor when the dtypes are mixed."""
+    import ctypes
+    n = len(dsts)
+    if n != len(srcs):
+        raise ValueError("multi_copy_: list lengths differ")
+    for d, s in zip(dsts, srcs):
+        if d.numel() * d.element_size() != s.numel() * s.element_size() or not d.is_contiguous() or not s.is_contiguous():
+            raise ValueError("multi_copy_: contiguous tensors of equal byte size expected")
+    for i0 in range(0, n, 48):
+        dd, ss = dsts[i0:i0 + 48], srcs[i0:i0 + 48]
+        k = len(dd)
+        sp = (ctypes.c_void_p * k)(*[t.data_ptr() for t in ss])
+        dp = (ctypes.c_void_p * k)(*[t.data_ptr() for t in dd])
+        nb = (ctypes.c_ulonglong * k)(*[t.numel() * t.element_size() for t in dd])
+        with torch.cuda.device(dd[0].device):
+            check(lib.pn2_multi_copy(k, ctypes.cast(sp, ctypes.c_void_p), ctypes.cast(dp, ctypes.c_void_p),
+                                     ctypes.cast(nb, ctypes.c_void_p), stream_ptr()), "pn2_multi_copy")
+
+
 def _layer_arrays(ws, bs):
     import ctypes
     L = len(ws)

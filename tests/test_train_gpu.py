@@ -134,6 +134,25 @@ def test_scatter_plan_three_interpolate_gradient(pn2, cuda, b, n, m, c2, c1):
         np.testing.assert_array_equal(grads[1][1], g[:, :, c2:])
 
 
+def test_multi_copy_mixed_dtypes(pn2, cuda):
+    """pn2_multi_copy: many device-to-device copies of mixed dtypes / odd byte counts / unaligned views in one launch."""
+    import torch
+    rs = np.random.RandomState(0)
+    srcs, dsts = [], []
+    for i, (dt, n) in enumerate([(torch.float32, 1), (torch.int32, 12345), (torch.uint8, 5000003), (torch.float32, 16 * 1024 * 3),
+                                 (torch.int32, 16 * 1024 * 32), (torch.uint8, 7), (torch.float64, 333)] * 8):
+        base = torch.from_numpy(rs.randint(0, 255, size=n * torch.empty((), dtype=dt).element_size() + 16).astype(np.uint8)).to(cuda)
+        off = 16 if i % 3 else 4 * (i % 2 + 1) if dt != torch.float64 else 8  # some sources start off a 16-byte boundary
+        nb = n * torch.empty((), dtype=dt).element_size()
+        srcs.append(base[off:off + nb].view(dt) if off % torch.empty((), dtype=dt).element_size() == 0 else base[16:16 + nb].view(dt))
+        dsts.append(torch.zeros(n, dtype=dt, device=cuda))
+    pn2.util.tf_util.multi_copy_(dsts, srcs)  # 56 tensors: two launches
+    for d, s_ in zip(dsts, srcs):
+        assert torch.equal(d.view(torch.uint8), s_.contiguous().view(torch.uint8))
+    with pytest.raises(ValueError):
+        pn2.util.tf_util.multi_copy_([dsts[0]], [srcs[1]])
+
+
 def test_weighted_ce_forward_backward_vs_float64(pn2, oracle, cuda):
     import torch
     rs = np.random.RandomState(0)

@@ -71,7 +71,7 @@ for i in range(K):
             if dst.data_ptr() != src.data_ptr():
                 dst.copy_(src, non_blocking=True)
         T("input copies", t0)
-        t0 = time.perf_counter(); torch._foreach_copy_(M.geometry_tensors(tr._static_geo), M.geometry_tensors(geo)); T("geometry foreach_copy", t0)
+        t0 = time.perf_counter(); pn2.util.tf_util.multi_copy_(M.geometry_tensors(tr._static_geo), M.geometry_tensors(geo)); T("geometry multi_copy", t0)
         t0 = time.perf_counter(); taken = torch.cuda.Event(); taken.record(tr._stream); T("event", t0)
         t0 = time.perf_counter(); tr._prefetch(nxt, taken); T("prefetch enqueue", t0)
         t0 = time.perf_counter(); tr._graph.replay(); T("graph replay", t0)
@@ -97,7 +97,7 @@ def replay_copies(i):
     with torch.cuda.stream(tr._stream):
         tr.hyper.copy_(tr._hyper_host, non_blocking=True); tr.store.set_step(i)
         tr._static[0].copy_(pcs[i % 2], non_blocking=True)
-        torch._foreach_copy_(M.geometry_tensors(tr._static_geo), M.geometry_tensors(geo_fixed))
+        pn2.util.tf_util.multi_copy_(M.geometry_tensors(tr._static_geo), M.geometry_tensors(geo_fixed))
         tr._graph.replay()
 def replay_side_geometry_independent(i):
     with torch.cuda.stream(tr._geo_stream):
