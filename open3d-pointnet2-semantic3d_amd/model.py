@@ -7,7 +7,6 @@ conv1d(128)+BN+ReLU -> dropout(0.5) -> conv1d(num_class).
 Hyper-parameter keys are the reference's semantic.json keys verbatim.
 """
 import json
-import os
 
 import torch
 

@@ -7,7 +7,7 @@ C ABI of libpn2_hip.so instead of tf.load_op_library.
 """
 import torch
 
-from .. import _lib, config
+from .. import config
 from .._lib import check, lib, ptr, require_cuda, stream_ptr
 
 

@@ -16,7 +16,7 @@ import ctypes
 import torch
 
 from . import tf_util
-from .._lib import PN2_EUNSUP, Pn2Error, check, lib, ptr, require_cuda, stream_ptr
+from .._lib import PN2_EUNSUP, check, lib, ptr, require_cuda, stream_ptr
 from ..tf_ops.tf_grouping import query_ball_point_multi, group_point, knn_point, query_ball_point
 from ..tf_ops.tf_interpolate import three_interpolate, three_nn
 from ..tf_ops.tf_sampling import farthest_point_sample, farthest_point_sample_and_gather, gather_point
