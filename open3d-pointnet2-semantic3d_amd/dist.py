@@ -126,6 +126,9 @@ class OverlappedGradAllReduce:
             self.split_off = off
         self.late_flat, self.early_flat = self.flat[:self.split_off], self.flat[self.split_off:]
         self._pending, self._work, self.early_launched_in_backward = 0, None, False
+        # defer_collectives: backward only PACKS the buckets; the caller reduces the whole flat buffer afterwards with
+        # reduce_deferred() -- for a backward pass that is captured into a hipGraph (the collective stays outside)
+        self.defer_collectives = False
         self._known_zero = set()
         self._expected_early = None
         self._hooks = [p.register_post_accumulate_grad_hook(self._on_grad) for p in self.params[self.split:]]
@@ -161,7 +164,7 @@ class OverlappedGradAllReduce:
         self._pending -= 1
         if self._pending == 0:  # every early-bucket gradient has landed: pack and send while backward goes on
             self._pack(self.split, len(self.params))
-            if self.world() > 1:
+            if self.world() > 1 and not self.defer_collectives:
                 self._work = dist.all_reduce(self.early_flat, op=dist.ReduceOp.SUM, async_op=True)
             self.early_launched_in_backward = True
 
@@ -172,16 +175,24 @@ class OverlappedGradAllReduce:
             self._expected_early = sum(1 for p in self.params[self.split:] if p.grad is not None)
         if not self.early_launched_in_backward:  # first step, or a parameter's gradient did not arrive
             self._pack(self.split, len(self.params))
-            if self.world() > 1:
+            if self.world() > 1 and not self.defer_collectives:
                 self._work = dist.all_reduce(self.early_flat, op=dist.ReduceOp.SUM, async_op=True)
         self._pack(0, self.split)
-        if self.world() > 1:
+        if self.world() > 1 and not self.defer_collectives:
             if self.split_off > 0:
                 dist.all_reduce(self.late_flat, op=dist.ReduceOp.SUM)
             if self._work is not None:
                 self._work.wait()
         for p, v in zip(self.params, self.views):
             p.grad = v
+        return self.flat
+
+
+    @torch.no_grad()
+    def reduce_deferred(self):
+        """the collective of a defer_collectives step: ONE all-reduce (sum) of the whole flat gradient on the current stream"""
+        if dist.is_available() and dist.is_initialized():
+            dist.all_reduce(self.flat, op=dist.ReduceOp.SUM)
         return self.flat
 
 

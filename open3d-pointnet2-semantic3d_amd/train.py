@@ -35,14 +35,15 @@ class Trainer:
     weight gradients (pn2_linear_dgrad / _wgrad), index-op gradients, and ONE Adam launch over flat parameter / moment
     buffers (pn2_adam_step).  torch supplies memory, streams, the autograd tape and torch.distributed.
 
-    Step-dependent scalars live in device memory (learning rate with Adam's bias correction, dropout step), so on a
-    single GPU the whole step is captured into one hipGraph after `warmup_eager` ordinary steps and replayed; with
-    several GPUs the step runs eagerly and the gradient all-reduce is split in two buckets, the first one launched from
-    inside backward (dist.OverlappedGradAllReduce)."""
+    Step-dependent scalars live in device memory (learning rate with Adam's bias correction, dropout step), so after
+    `warmup_eager` ordinary steps the step is captured and replayed: on one GPU as ONE hipGraph; with several ranks as two
+    (forward + backward with the gradients packed into the flat buffer | Adam) around ONE all-reduce of the 3.87 MB flat
+    gradient -- no collective inside a captured region.  Eager steps (the warm-up, capture=False) split the all-reduce in
+    two buckets, the first one launched from inside backward (dist.OverlappedGradAllReduce)."""
 
     BETA1, BETA2, EPS = 0.9, 0.999, 1e-8  # tf.train.AdamOptimizer defaults (train.py:381-384)
 
-    def __init__(self, hyperparams, num_class, store=None, device="cuda", capture=True, warmup_eager=3, geometry_in_graph=False):
+    def __init__(self, hyperparams, num_class, store=None, device="cuda", capture=True, warmup_eager=3, geometry_in_graph=False, split_capture=None):
         self.hp = dict(hyperparams)
         self.num_class = num_class
         self.store = store or tf_util.set_default_store(tf_util.VariableStore(device=device, seed=0))
@@ -55,6 +56,11 @@ class Trainer:
         # written to `_static_geo_next`; `_next_tag` names the batch it belongs to.  Measured equal to the default (eager
         # launches on a side stream): the 0.27 ms between graphs shrink to 0.06, the graph itself grows from 4.48 to 4.67 ms.
         self.geometry_in_graph = bool(geometry_in_graph)
+        # split_capture: the step as TWO graphs -- forward + backward (gradients packed, no collective inside), then Adam --
+        # with the gradient all-reduce launched between them: how a step is captured when there are several ranks (a
+        # collective inside a captured backward pass is avoided).  None = when world > 1; True forces it (tests).
+        self.split_capture = split_capture
+        self._graph_adam = None
         self._static_geo_next, self._static_next_xyz, self._next_tag = None, None, None
 
     # ---- set-up ------------------------------------------------------------------------------------------------
@@ -97,7 +103,7 @@ class Trainer:
         self._hyper_host = torch.zeros(5, dtype=torch.float32).pin_memory() if dev.type == "cuda" else torch.zeros(5)
 
     # ---- one step ------------------------------------------------------------------------------------------------
-    def _step_body(self, pc, labels, smpw, decay, geometry=None):
+    def _forward_backward(self, pc, labels, smpw, decay, geometry=None):
         if self.store.zero_arena is None:
             self.store.zero_arena = tf_util.ZeroArena(self.flat_p.device)  # first step: measures what the step needs
         elif self.store.zero_arena.buf is None:
@@ -109,11 +115,17 @@ class Trainer:
         loss = model.get_loss(logits, labels, smpw)
         self.bucket.begin()
         loss.backward()
-        flat_g = self.bucket.finish()
+        return loss.detach(), self.bucket.finish()
+
+    def _adam(self, flat_g):
         with torch.cuda.device(self.flat_p.device):
             check(lib.pn2_adam_step(self.flat_p.numel(), ptr(self.flat_p), ptr(flat_g), ptr(self.flat_m), ptr(self.flat_v),
                                     ptr(self.hyper), stream_ptr()), "pn2_adam_step")
-        return loss.detach()
+
+    def _step_body(self, pc, labels, smpw, decay, geometry=None):
+        loss, flat_g = self._forward_backward(pc, labels, smpw, decay, geometry)
+        self._adam(flat_g)
+        return loss
 
     # ---- geometry prefetch -----------------------------------------------------------------------------------------
     def _xyz_of(self, pc):
@@ -173,7 +185,8 @@ class Trainer:
         decay = bn_decay(self.step_count, b)
         self._hyper_host.copy_(torch.tensor([adam_lr_t(lr, t, self.BETA1, self.BETA2), self.BETA1, self.BETA2, self.EPS,
                                              1.0 / world], dtype=torch.float32))
-        use_graph = self.capture and world == 1 and pc.is_cuda and self.step_count >= self.warmup_eager
+        use_graph = self.capture and pc.is_cuda and self.step_count >= self.warmup_eager
+        split = use_graph and (world > 1 if self.split_capture is None else bool(self.split_capture))
         caller = torch.cuda.current_stream()
         if not use_graph:
             self.hyper.copy_(self._hyper_host, non_blocking=True)
@@ -196,7 +209,7 @@ class Trainer:
                 if recapture or not self.geometry_in_graph or self._next_tag != tag:
                     geo = self._geometry_for(pc, self._stream)  # eager (or eagerly prefetched: prefetch_geometry)
                 if recapture:
-                    self._capture(pc, labels, smpw, decay, geo)
+                    self._capture(pc, labels, smpw, decay, geo, split)
                 self.hyper.copy_(self._hyper_host, non_blocking=True)
                 self.store.set_step(self.step_count)
                 # every per-step device-to-device copy (inputs, and this batch's geometry when it is not in place yet) in ONE
@@ -225,6 +238,9 @@ class Trainer:
                     taken.record(self._stream)
                     self._prefetch(next_pc, taken)
                 self._graph.replay()
+                if self._graph_adam is not None:  # split capture: the collective runs between the two graphs
+                    self.bucket.reduce_deferred()
+                    self._graph_adam.replay()
                 loss = self._static[3]
                 if sync:
                     loss = float(loss)
@@ -232,8 +248,9 @@ class Trainer:
         self.step_count += 1
         return float(loss) if sync else loss
 
-    def _capture(self, pc, labels, smpw, decay, geo):
-        """record forward + loss + backward + Adam of one step into a hipGraph (static input and geometry buffers)."""
+    def _capture(self, pc, labels, smpw, decay, geo, split=False):
+        """record forward + loss + backward + Adam of one step into a hipGraph (static input and geometry buffers); split:
+        Adam in a graph of its own, the gradient all-reduce is launched between the two replays."""
         torch.cuda.synchronize()
         st = [pc.clone(), labels.clone(), smpw.clone()]
         sg = model.clone_geometry(geo, self._xyz_of(st[0]))
@@ -255,9 +272,22 @@ class Trainer:
                 with torch.cuda.stream(self._geo_stream):
                     tmp = model.compute_geometry(self._static_next_xyz, self.hp, plans=True)
                     tf_util.multi_copy_(model.geometry_tensors(self._static_geo_next), model.geometry_tensors(tmp))
-            loss = self._step_body(st[0], st[1], st[2], decay, geometry=sg)
+            if split:
+                self.bucket.defer_collectives = True
+                try:
+                    loss, flat_g = self._forward_backward(st[0], st[1], st[2], decay, geometry=sg)
+                finally:
+                    self.bucket.defer_collectives = False
+            else:
+                loss = self._step_body(st[0], st[1], st[2], decay, geometry=sg)
             if self.geometry_in_graph:
                 torch.cuda.current_stream().wait_stream(self._geo_stream)  # join
+        self._graph_adam = None
+        if split:
+            ga = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(ga):
+                self._adam(flat_g)
+            self._graph_adam = ga
         self._graph, self._graph_decay, self._static, self._static_geo = g, decay, st + [loss], sg
         self._next_tag = self._tag(pc)
         # the capture itself executed nothing: the replay that follows is this step

@@ -276,10 +276,12 @@ def test_captured_training_step_equals_eager(pn2, cuda):
     hp.update(l1_npoint=256, l2_npoint=64, l3_npoint=32, l4_npoint=16)
     batches = [_batch(cuda, s) for s in range(3)]
     out = {}
-    for key, capture in (("eager", False), ("eager2", False), ("graph", True)):
-        tr = pn2.train.Trainer(hp, 9, store=pn2.util.tf_util.VariableStore(device=cuda, seed=3), capture=capture, warmup_eager=2)
+    for key, capture in (("eager", False), ("eager2", False), ("graph", True), ("split", True)):
+        # "split": the multi-rank capture (forward + backward | all-reduce outside | Adam), forced on this single rank
+        tr = pn2.train.Trainer(hp, 9, store=pn2.util.tf_util.VariableStore(device=cuda, seed=3), capture=capture, warmup_eager=2,
+                               split_capture=(key == "split"))
         losses = [tr.train_step(*batches[i % 3]) for i in range(7)]
-        assert (tr._graph is not None) == capture
+        assert (tr._graph is not None) == capture and (tr._graph_adam is not None) == (key == "split")
         out[key] = (losses, tr.flat_p.clone(), {k: v.clone() for k, v in tr.store.buffers.items()})
         assert tr.step_count == 7 and all(np.isfinite(losses))
     np.testing.assert_allclose(out["graph"][0][:2], out["eager"][0][:2], rtol=1e-4)  # the eager warm-up steps are the same code
@@ -290,11 +292,41 @@ def test_captured_training_step_equals_eager(pn2, cuda):
     noise = dist("eager2", "eager")
     # (a wrong learning rate, a skipped or doubled update would show as O(0.1 .. 1); the floor keeps chance out of CI)
     assert dist("graph", "eager") <= 3.0 * noise + 2e-2, (dist("graph", "eager"), noise)
+    assert dist("split", "eager") <= 3.0 * noise + 2e-2, (dist("split", "eager"), noise)
+    np.testing.assert_allclose(out["split"][0], out["eager"][0], rtol=3e-2)
     # moving averages: one update per step in both modes (a double update from set-up or capture would move them by
     # O(1)); the yardstick is again the second eager run
     cat = lambda key: torch.cat([out[key][2][k].flatten() for k in sorted(out[key][2])])  # noqa: E731
     bdist = lambda a, b: float((cat(a) - cat(b)).norm() / cat(b).norm())  # noqa: E731
     assert bdist("graph", "eager") <= 3.0 * bdist("eager2", "eager") + 2e-2, (bdist("graph", "eager"), bdist("eager2", "eager"))
+
+
+def test_split_capture_with_a_process_group(pn2, cuda):
+    """the multi-rank step (two graphs around an RCCL all-reduce on the trainer's stream) with a real, single-rank "nccl"
+    process group: the collective is issued between the replays and the trajectory is the single-graph one."""
+    import torch
+    import torch.distributed as dist
+    if dist.is_initialized():
+        pytest.skip("a process group is already initialised in this process")
+    try:
+        dist.init_process_group("nccl", init_method="tcp://127.0.0.1:29531", rank=0, world_size=1,
+                                device_id=torch.device(cuda))
+    except Exception as ex:  # no RCCL on this box
+        pytest.skip("cannot initialise a single-rank nccl group: %r" % (ex,))
+    try:
+        hp = dict(pn2.model.SEMANTIC_HYPERPARAMS)
+        hp.update(l1_npoint=256, l2_npoint=64, l3_npoint=32, l4_npoint=16)
+        batches = [_batch(cuda, s) for s in range(3)]
+        out = {}
+        for key in ("graph", "split"):
+            tr = pn2.train.Trainer(hp, 9, store=pn2.util.tf_util.VariableStore(device=cuda, seed=3), warmup_eager=2,
+                                   split_capture=(key == "split"))
+            out[key] = [tr.train_step(*batches[i % 3]) for i in range(6)]
+            assert tr.bucket.world() == 1
+        np.testing.assert_allclose(out["split"][:2], out["graph"][:2], rtol=1e-4)
+        np.testing.assert_allclose(out["split"], out["graph"], rtol=3e-2)
+    finally:
+        dist.destroy_process_group()
 
 
 def test_geometry_prefetch_is_the_same_geometry(pn2, cuda):
