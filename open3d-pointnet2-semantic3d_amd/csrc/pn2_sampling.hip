@@ -46,6 +46,21 @@ __device__ __forceinline__ int wave_imax(int v) {
         : "+v"(v));
     return __builtin_amdgcn_readlane(v, 63);
 }
+// same, reading the source register in place (no copy) and without the trailing wait states (the consumer is a plain
+// VALU read): the per-pick chain of the lazy kernel's phase B
+__device__ __forceinline__ int wave_imax_from(int src) {
+    int v;
+    asm volatile(
+        "s_nop 1\n"
+        "v_max_i32_dpp %0, %1, %1 row_shr:1 row_mask:0xf bank_mask:0xf\n s_nop 1\n"
+        "v_max_i32_dpp %0, %0, %0 row_shr:2 row_mask:0xf bank_mask:0xf\n s_nop 1\n"
+        "v_max_i32_dpp %0, %0, %0 row_shr:4 row_mask:0xf bank_mask:0xf\n s_nop 1\n"
+        "v_max_i32_dpp %0, %0, %0 row_shr:8 row_mask:0xf bank_mask:0xf\n s_nop 1\n"
+        "v_max_i32_dpp %0, %0, %0 row_bcast:15 row_mask:0xa bank_mask:0xf\n s_nop 1\n"
+        "v_max_i32_dpp %0, %0, %0 row_bcast:31 row_mask:0xc bank_mask:0xf\n"
+        : "=&v"(v) : "v"(src));
+    return __builtin_amdgcn_readlane(v, 63);
+}
 // max over lanes 0..15 (row 0), result from lane 15
 __device__ __forceinline__ int row0_imax(int v) {
     asm volatile(
@@ -249,6 +264,407 @@ fps_reg_kernel(int n, int m, const float* __restrict__ xyz_all, int* __restrict_
 
 PN2_TUNABLE(int, g_fps_variant, 0)  // tuning hook (pn2_debug_set(0, v)), see dispatch_fps
 
+// ---- lazy multi-pick FPS (256 < n <= 8192) ---------------------------------------------------------------------------
+// Same picks as fps_reg_kernel (= the reference, tf_sampling.cu:111-176), but a synchronised pass over the cloud delivers
+// ~15 picks instead of one.  min() is associative, so the running minimum td(k) may lag behind the picks: td_stale(k) >=
+// td(k), and a point whose stale td is below a threshold tau cannot be the next pick while some listed point stays >= tau.
+//   PHASE A (all waves): apply the PENDING picks of the previous phase to the points, then LIST every point with
+//     td >= tau (64-bit key = (td bits : ~tiekey) as everywhere in this file) in LDS; every wave also publishes its own
+//     maximum key.                                                                                  -- barrier --
+//   PHASE B (wave 0, lane = candidate): repeatedly take the 64-bit maximum of the list (= the global maximum: unlisted
+//     points have td < tau), emit it as the next pick, and lower the candidates' td by their distance to it -- a ~25
+//     instruction dependent chain per pick with no barrier and no pass over the cloud -- until the best candidate
+//     drops below tau (or 64 picks).  The picks become the pending list.                            -- barrier --
+//   tau = (1 - eps) * (td of the last pick); eps follows the list length (target 12..42 of 64 entries).  An empty or
+//   overflowing list falls back to ONE pick from the 16 per-wave maxima (exact: the global maximum is one of them).
+// The result never depends on tau / eps / list capacity, only the number of phases does (tools/fps_lazy_sim.py: 1023
+// picks in ~60 phases at n = 8192 on scene-, normal-, uniform- and lattice-distributed clouds).
+// Phase A is pruned: the cloud is Morton-sorted inside the workgroup (LDS counting sort over 16^3 cells of the bounding
+// box) and dealt out so that (wave w, register row i) holds 64 consecutive sorted points = one compact BUCKET with an
+// exact bounding box in SGPRs.  A pending pick p can lower td inside a bucket only if lb(p, box)^2 * (1 - 1e-6) <= G, G =
+// the td of the first pending pick when it was picked (>= every stale td).  Lane p tests pick p against row i's box (one
+// VALU pass per row, ballot = work mask of the row); only the surviving (row, pick) pairs -- ~12 % of them -- run the
+// distance update.  Skipped pairs are provably no-ops, so the result is bit-identical.  Neighbouring buckets go to
+// different waves (bucket q -> wave q % NW) so the buckets around a pick spread over the SIMDs.
+// Tie-break (max td, then lowest k mod 512, then lowest k; tf_sampling.cu:153-170) rides in the low word of every key.
+__device__ __forceinline__ unsigned fps_spread4(unsigned v) {  // b3b2b1b0 -> bits 9,6,3,0
+    v = (v | (v << 4)) & 0x0C3u;
+    return (v | (v << 2)) & 0x249u;
+}
+// Index of cell (x, y, z) of a 16^3 grid along a 3-D Hilbert curve (Skilling's axes-to-transpose transform, 4 bits per
+// axis).  Unlike the Morton order it has no jumps, so 64 consecutive points never straddle two distant octants: the
+// buckets that did made their waves evaluate 2-3x the (row, pick) pairs of the others (tools/fps_lazy_sim.py).
+__device__ __forceinline__ unsigned fps_hilbert4(unsigned x0, unsigned x1, unsigned x2) {
+    unsigned X[3] = {x0, x1, x2};
+#pragma unroll
+    for (unsigned Q = 8; Q > 1; Q >>= 1) {
+        const unsigned P = Q - 1;
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            if (X[i] & Q) X[0] ^= P;
+            else { const unsigned t = (X[0] ^ X[i]) & P; X[0] ^= t; X[i] ^= t; }
+        }
+    }
+    X[1] ^= X[0]; X[2] ^= X[1];
+    unsigned t = 0;
+#pragma unroll
+    for (unsigned Q = 8; Q > 1; Q >>= 1) if (X[2] & Q) t ^= Q - 1;
+    X[0] ^= t; X[1] ^= t; X[2] ^= t;
+    return (fps_spread4(X[0]) << 2) | (fps_spread4(X[1]) << 1) | fps_spread4(X[2]);
+}
+constexpr int kFpsCells = 4096;  // 16 x 16 x 16 cells, Hilbert-ordered
+PN2_TUNABLE(long long*, g_fps_stats, nullptr)  // tuning builds: device buffer of 16 counters written by block 0 (tools/fps_ab.py)
+constexpr int kLazyCap = 64;     // candidates per phase = lanes of the picking wave
+constexpr int kLazyHead = 2176;  // bytes in front of the cloud copy (ctrl, wcand, cand, pend, bbw, wsum)
+
+__device__ __forceinline__ unsigned wave_umax_all(unsigned v) {
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) { const unsigned t = (unsigned)__shfl_xor((int)v, o); v = t > v ? t : v; }
+    return v;
+}
+
+inline size_t fps_lazy_bytes(int n, int m) {
+    size_t r = (size_t)kFpsCells * 4;
+    if ((size_t)n * 2 > r) r = (size_t)n * 2;
+    if ((size_t)m * 4 > r) r = (size_t)m * 4;
+    return kLazyHead + (size_t)n * 16 + r;
+}
+
+template <int NT, int PPT, int MODE>
+__global__ void __launch_bounds__(NT)
+fps_lazy_kernel(int n, int m, const float* __restrict__ xyz_all, int* __restrict__ out_all,
+                float* __restrict__ new_xyz_all, long long* __restrict__ stats) {
+    static_assert(NT % 64 == 0 && NT * PPT <= 8192 && kFpsCells % NT == 0 && NT / 64 <= 16, "u16 permutation; 16 wave slots");
+    constexpr int NW = NT / 64;
+    constexpr int EPT = kFpsCells / NT;  // histogram entries per thread in the scan
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    // layout: int ctrl[16] | u64 wcand[16] | u64 cand[64] | float4 pend[64] | float bbw[16][6], int wsum[16] |
+    //         float4 sxyz[n] | R: int hist[4096] -> u16 perm[n] -> int spick[m]
+    int* ctrl = reinterpret_cast<int*>(smem);  // [0] cnt (LDS atomic) | [4..7] np, j, tau_hi, G bits (one 16-byte read)
+    unsigned long long* wcand = reinterpret_cast<unsigned long long*>(smem + 64);
+    unsigned long long* cand = reinterpret_cast<unsigned long long*>(smem + 192);
+    float4* pend = reinterpret_cast<float4*>(smem + 704);
+    float* bbw = reinterpret_cast<float*>(smem + 1728);
+    int* wsum = reinterpret_cast<int*>(bbw + 6 * 16);
+    float4* sxyz = reinterpret_cast<float4*>(smem + kLazyHead);
+    int* hist = reinterpret_cast<int*>(sxyz + n);
+    unsigned short* perm = reinterpret_cast<unsigned short*>(hist);
+    int* spick = hist;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const float* __restrict__ xyz = xyz_all + (size_t)blockIdx.x * n * 3;
+    int* __restrict__ out = out_all + (size_t)blockIdx.x * m;
+    float* __restrict__ nxyz = new_xyz_all ? new_xyz_all + (size_t)blockIdx.x * m * 3 : nullptr;
+
+    float px[PPT], py[PPT], pz[PPT];
+
+    // ---- 1. load in original order, cloud copy in LDS, bounding box ----------------------------------------------
+    float lo[3] = {3e38f, 3e38f, 3e38f}, hi[3] = {-3e38f, -3e38f, -3e38f};
+#pragma unroll
+    for (int i = 0; i < PPT; ++i) {
+        const int k = tid + NT * i;
+        if (k < n) {
+            px[i] = xyz[k * 3 + 0]; py[i] = xyz[k * 3 + 1]; pz[i] = xyz[k * 3 + 2];
+            sxyz[k] = make_float4(px[i], py[i], pz[i], 0.f);
+            lo[0] = fminf(lo[0], px[i]); hi[0] = fmaxf(hi[0], px[i]);
+            lo[1] = fminf(lo[1], py[i]); hi[1] = fmaxf(hi[1], py[i]);
+            lo[2] = fminf(lo[2], pz[i]); hi[2] = fmaxf(hi[2], pz[i]);
+        }
+    }
+#pragma unroll
+    for (int a = 0; a < 3; ++a) { lo[a] = wave_fmin_all(lo[a]); hi[a] = wave_fmax_all(hi[a]); }
+    if (lane == 0) {
+#pragma unroll
+        for (int a = 0; a < 3; ++a) { bbw[wave * 6 + a] = lo[a]; bbw[wave * 6 + 3 + a] = hi[a]; }
+    }
+#pragma unroll
+    for (int e = 0; e < EPT; ++e) hist[tid + NT * e] = 0;
+    __syncthreads();
+    float scl[3];
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+        float l = bbw[a], h = bbw[3 + a];
+        for (int w = 1; w < NW; ++w) { l = fminf(l, bbw[w * 6 + a]); h = fmaxf(h, bbw[w * 6 + 3 + a]); }
+        lo[a] = l;
+        hi[a] = h - l;
+    }
+    {   // cubic cells (one scale for the three axes): buckets come out compact in every direction
+        const float ext = fmaxf(fmaxf(hi[0], hi[1]), hi[2]);
+        float s = ext > 0.f ? 16.0f / ext : 0.f;  // degenerate cloud (or inf/garbage): everything in cell 0
+        if (!(s < 3e38f)) s = 0.f;
+        scl[0] = scl[1] = scl[2] = s;
+    }
+    // ---- 2. counting sort by Morton cell: rank within the cell from the LDS atomic, exclusive scan of the histogram
+    //         (the order inside a cell is arbitrary: only locality depends on it, never the result)
+    int code[PPT], rnk[PPT];
+#pragma unroll
+    for (int i = 0; i < PPT; ++i) {
+        const int k = tid + NT * i;
+        code[i] = 0; rnk[i] = 0;
+        if (k < n) {
+            int c[3];
+            const float q[3] = {px[i], py[i], pz[i]};
+#pragma unroll
+            for (int a = 0; a < 3; ++a) {
+                const float f = (q[a] - lo[a]) * scl[a];
+                int ci = (int)f;
+                ci = ci < 0 ? 0 : (ci > 15 ? 15 : ci);
+                if (!(f == f)) ci = 0;
+                c[a] = ci;
+            }
+            code[i] = (int)fps_hilbert4((unsigned)c[0], (unsigned)c[1], (unsigned)c[2]);
+            rnk[i] = atomicAdd(&hist[code[i]], 1);
+        }
+    }
+    __syncthreads();
+    {
+        int v[EPT], s = 0;
+#pragma unroll
+        for (int e = 0; e < EPT; ++e) { v[e] = hist[tid * EPT + e]; s += v[e]; }
+        int inc = s;  // inclusive wave scan
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) { const int t = __shfl_up(inc, o); if (lane >= o) inc += t; }
+        if (lane == 63) wsum[wave] = inc;
+        __syncthreads();
+        int base = 0;
+        for (int w = 0; w < wave; ++w) base += wsum[w];
+        int run = base + inc - s;
+#pragma unroll
+        for (int e = 0; e < EPT; ++e) { hist[tid * EPT + e] = run; run += v[e]; }
+    }
+    __syncthreads();
+    int pos[PPT];
+#pragma unroll
+    for (int i = 0; i < PPT; ++i) pos[i] = hist[code[i]] + rnk[i];
+    __syncthreads();  // hist is dead from here: the permutation aliases it
+#pragma unroll
+    for (int i = 0; i < PPT; ++i) {
+        const int k = tid + NT * i;
+        if (k < n) perm[pos[i]] = (unsigned short)k;
+    }
+    __syncthreads();
+    // ---- 3. deal the sorted cloud: bucket q = 64 consecutive sorted points -> wave q % NW, register row q / NW;
+    //         exact bucket boxes as wave-uniform values (an empty bucket keeps the inverted box: lb = +inf, never touched)
+    // Box test layout: lane l tests row l / PP against pick slot l % PP, so ONE pass of ~15 VALU tests PP = 64 / PPT
+    // pending picks against all the rows of the wave; the lane keeps only its own row's box.
+    constexpr int PP = 64 / PPT;
+    static_assert(PPT >= 2 && PPT * PP == 64, "rows per wave: 2, 4, 8 or 16");
+    float bx0 = 3e38f, by0 = 3e38f, bz0 = 3e38f, bx1 = -3e38f, by1 = -3e38f, bz1 = -3e38f;
+    double mk[PPT];
+#pragma unroll
+    for (int i = 0; i < PPT; ++i) {
+        const int p = (i * NW + wave) * 64 + lane;
+        float l0 = 3e38f, l1 = 3e38f, l2 = 3e38f, h0 = -3e38f, h1 = -3e38f, h2 = -3e38f;
+        if (p < n) {
+            const int k = perm[p];
+            const float4 q = sxyz[k];
+            px[i] = q.x; py[i] = q.y; pz[i] = q.z;
+            mk[i] = __hiloint2double(__float_as_int(1e38f), (int)~fps_tiekey(k));  // tf_sampling.cu:124-126
+            l0 = h0 = q.x; l1 = h1 = q.y; l2 = h2 = q.z;
+        } else {
+            px[i] = py[i] = pz[i] = 0.f;
+            mk[i] = __hiloint2double(__float_as_int(-1.0f), 0);  // no point: a negative high word, below every real key
+        }
+        l0 = wave_fmin_all(l0); l1 = wave_fmin_all(l1); l2 = wave_fmin_all(l2);
+        h0 = wave_fmax_all(h0); h1 = wave_fmax_all(h1); h2 = wave_fmax_all(h2);
+        if (lane / PP == i) { bx0 = l0; by0 = l1; bz0 = l2; bx1 = h0; by1 = h1; bz1 = h2; }
+    }
+    __syncthreads();  // perm is dead from here: the pick list aliases it
+    if (tid == 0) {
+        spick[0] = 0;  // first pick is index 0 (tf_sampling.cu:122-123)
+        pend[0] = sxyz[0];
+        ctrl[0] = 0; ctrl[1] = 0;
+        *reinterpret_cast<int4*>(ctrl + 4) = make_int4(1, 1, __float_as_int(1e38f), __float_as_int(1e38f));
+    }
+    __syncthreads();
+
+    // ---- 4. phases ----------------------------------------------------------------------------------------------------
+    float eps = 0.2f;  // wave 0 only
+#ifdef PN2_TUNING_HOOKS
+    const bool do_stats = stats != nullptr;
+#else
+    constexpr bool do_stats = false;  // the counters below compile away in the shipped library
+#endif
+    long long st_a = 0, st_w1 = 0, st_b = 0, st_w2 = 0, st_ph = 0, st_empty = 0, st_over = 0, st_cnt = 0, st_pairs = 0, st_upd = 0;
+    const long long st_t00 = do_stats ? (long long)__builtin_readcyclecounter() : 0;
+    // the list counter alternates between ctrl[0] and ctrl[1]: a phase appends to one while wave 0 clears the other,
+    // whose last readers passed the previous phase's closing barrier
+    for (int ph = 0;; ph ^= 1) {
+        const long long st_t0 = do_stats ? (long long)__builtin_readcyclecounter() : 0;
+        const int4 cw = *reinterpret_cast<const int4*>(ctrl + 4);
+        const int np = __builtin_amdgcn_readfirstlane(cw.x);
+        const int jdone = __builtin_amdgcn_readfirstlane(cw.y);
+        if (jdone >= m) break;
+        const int tau_hi = __builtin_amdgcn_readfirstlane(cw.z);
+        const float G = __int_as_float(__builtin_amdgcn_readfirstlane(cw.w));
+        // ---- phase A: pending picks against the rows, PP picks per pass (lanes beyond the list test a point at infinity)
+        const float Gs = fmaxf(G * 1.000002f, 1e-30f);  // skip a (row, pick) pair iff lb > Gs: lb * (1 - 1e-6) > G, and never on underflow
+        for (int s0 = 0; s0 < np; s0 += PP) {
+            const int pi = s0 + (lane & (PP - 1));
+            float qx = __builtin_inff(), qy = qx, qz = qx;
+            if (pi < np) { const float4 q = pend[pi]; qx = q.x; qy = q.y; qz = q.z; }
+            const float ex = fmaxf(fmaxf(bx0 - qx, qx - bx1), 0.f);
+            const float ey = fmaxf(fmaxf(by0 - qy, qy - by1), 0.f);
+            const float ez = fmaxf(fmaxf(bz0 - qz, qz - bz1), 0.f);
+            const float lb = (ex * ex + ey * ey) + ez * ez;
+            const unsigned long long mask = __builtin_amdgcn_ballot_w64(lb <= Gs);
+            if (do_stats) st_pairs += __popcll(mask);
+#pragma unroll
+            for (int i = 0; i < PPT; ++i) {
+                unsigned mi = (unsigned)(mask >> (i * PP)) & (unsigned)((1ull << PP) - 1ull);
+                while (mi) {
+                    const int p = __builtin_ctz(mi);  // lane p (row 0's group) holds pick slot p
+                    mi &= mi - 1;
+                    const float x1 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(qx), p));
+                    const float y1 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(qy), p));
+                    const float z1 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(qz), p));
+                    const float d = pn2_sqdist<MODE>(px[i] - x1, py[i] - y1, pz[i] - z1);
+                    const int di = __float_as_int(d), oh = __double2hiint(mk[i]);  // d >= +0: int order == float order
+                    mk[i] = __hiloint2double(di < oh ? di : oh, __double2loint(mk[i]));  // min(d, td) :151 on the high word
+                }
+            }
+        }
+        const long long st_tu = do_stats ? (long long)__builtin_readcyclecounter() : 0;
+        if (do_stats) st_upd += st_tu - st_t0;
+        double tr[PPT];
+#pragma unroll
+        for (int i = 0; i < PPT; ++i) tr[i] = mk[i];
+#pragma unroll
+        for (int w = PPT; w > 1; w = (w + 1) / 2) {
+#pragma unroll
+            for (int g = 0; g < w / 2; ++g) tr[g] = fps_dmax(tr[g], tr[w - 1 - g]);
+        }
+        const int best = __double2hiint(tr[0]);
+        const unsigned bl = (unsigned)__double2loint(tr[0]);
+        if (best >= tau_hi) {  // rare lanes: list every point of mine that reaches tau (one LDS atomic per lane)
+            unsigned c = 0;
+#pragma unroll
+            for (int i = 0; i < PPT; ++i) c += __double2hiint(mk[i]) >= tau_hi ? 1u : 0u;
+            unsigned slot_i;
+            const unsigned caddr = (unsigned)(size_t)(smem) + 4u * (unsigned)ph;  // &ctrl[ph]
+            asm volatile("ds_add_rtn_u32 %0, %1, %2\n s_waitcnt lgkmcnt(0)" : "=v"(slot_i) : "v"(caddr), "v"(c) : "memory");
+#pragma unroll
+            for (int i = 0; i < PPT; ++i) {
+                if (__double2hiint(mk[i]) >= tau_hi) {
+                    if (slot_i < (unsigned)kLazyCap) cand[slot_i] = (unsigned long long)__double_as_longlong(mk[i]);
+                    ++slot_i;
+                }
+            }
+        }
+        const long long st_t1 = do_stats ? (long long)__builtin_readcyclecounter() : 0;
+        __syncthreads();
+        const long long st_t2 = do_stats ? (long long)__builtin_readcyclecounter() : 0;
+        const int cnt = __builtin_amdgcn_readfirstlane(ctrl[ph]);
+        const bool use_list = cnt >= 1 && cnt <= kLazyCap;
+        if (!use_list) {
+            // empty or overflowing list (~1 phase in 8): ONE pick from the NW per-wave maxima instead (the global maximum is
+            // one of them).  Every wave publishes its own maximum key; one more barrier.
+            const int wh = wave_imax(best);
+            const unsigned long long bal = __ballot(best == wh);
+            unsigned wl;
+            if (__popcll(bal) == 1) wl = (unsigned)__builtin_amdgcn_readlane((int)bl, __ffsll((long long)bal) - 1);
+            else wl = wave_umax_all(best == wh ? bl : 0u);  // equal td across lanes: lowest tie key = largest low word
+            if (lane == 0) wcand[wave] = ((unsigned long long)(unsigned)wh << 32) | wl;
+            __syncthreads();
+        }
+        // ---- phase B: wave 0 picks from the list
+        if (wave == 0) {
+            if (do_stats) { st_ph++; st_empty += cnt == 0; st_over += cnt > kLazyCap; st_cnt += use_list ? cnt : 0; }
+            unsigned long long key = 0x8000000000000000ull;  // negative high word: never the maximum
+            if (use_list) { if (lane < cnt) key = cand[lane]; }
+            else if (lane < NW) key = wcand[lane];
+            int chi = (int)(unsigned)(key >> 32);
+            const unsigned clo = (unsigned)key;
+            int ck = fps_untiekey(~clo);
+            if (chi < 0) ck = 0;
+            const float4 cq = sxyz[ck];
+            const int limit = use_list ? tau_hi : (int)0x80000000;
+            int maxp = use_list ? kLazyCap : 1;
+            if (maxp > m - jdone) maxp = m - jdone;
+            // Per pick: wave max of td (6 fused DPP steps), ballot of the lanes holding it (one, unless td ties: then the
+            // largest low word = lowest tie key decides), the winner's coordinates by v_readlane, every candidate's td
+            // lowered by its distance to it.  The picks are parked in lane `npick` of four registers (v_writelane) and
+            // stored after the loop: no LDS traffic and no exec juggling on the chain.
+            int npick = 0, g_first = -1, d_last = 0;
+            int pk_k = 0;
+            float pk_x = 0.f, pk_y = 0.f, pk_z = 0.f;
+            const int lim = limit < 0 ? 0 : limit;  // valid td are >= 0; lanes without a candidate are negative
+            while (npick < maxp) {
+                const int bh = wave_imax_from(chi);
+                if (bh < lim) break;
+                unsigned long long bal = __builtin_amdgcn_ballot_w64(chi == bh);
+                if (__builtin_expect(__popcll(bal) != 1, 0)) {
+                    const unsigned lm = wave_umax_all(chi == bh ? clo : 0u);
+                    bal = __builtin_amdgcn_ballot_w64(chi == bh && clo == lm);
+                }
+                const int L = __builtin_ctzll(bal);
+                const float x1 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(cq.x), L));
+                const float y1 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(cq.y), L));
+                const float z1 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(cq.z), L));
+                const int kk = __builtin_amdgcn_readlane(ck, L);
+                // (gfx9 constant bus: one SGPR per instruction, so the lane select travels in m0)
+                asm volatile("s_mov_b32 m0, %8\n v_writelane_b32 %0, %4, m0\n v_writelane_b32 %1, %5, m0\n v_writelane_b32 %2, %6, m0\n v_writelane_b32 %3, %7, m0"
+                             : "+v"(pk_k), "+v"(pk_x), "+v"(pk_y), "+v"(pk_z) : "s"(kk), "s"(x1), "s"(y1), "s"(z1), "s"(npick));  // m0 is reserved: the compiler only ever sets it right before a use
+                const float d = pn2_sqdist<MODE>(cq.x - x1, cq.y - y1, cq.z - z1);
+                const int di = __float_as_int(d);
+                chi = di < chi ? di : chi;  // invalid lanes stay negative
+                g_first = bh > g_first ? bh : g_first;  // td of the picks never increases: the maximum is the first one
+                d_last = bh;
+                ++npick;
+            }
+            if (lane < npick) {
+                spick[jdone + lane] = pk_k;
+                pend[lane] = make_float4(pk_x, pk_y, pk_z, 0.f);
+            }
+            int j = jdone + npick;
+            // eps follows the list length: the result never depends on it, only the number of phases does
+            if (cnt == 0) eps = fminf(0.5f, eps * 2.0f);
+            else if (cnt > kLazyCap) eps *= 0.5f;
+            else if (cnt < 12) eps = fminf(0.5f, eps * 1.3f);
+            else if (cnt > 42) eps *= 0.8f;
+            if (npick == 0) j = m;  // unreachable (a non-empty list always yields a pick); never spin
+            if (lane == 0) {
+                ctrl[ph ^ 1] = 0;
+                *reinterpret_cast<int4*>(ctrl + 4) = make_int4(npick, j, __float_as_int(__int_as_float(d_last) * (1.0f - eps)), g_first);
+            }
+        }
+        const long long st_t3 = do_stats ? (long long)__builtin_readcyclecounter() : 0;
+        __syncthreads();
+        if (do_stats) {
+            const long long st_t4 = (long long)__builtin_readcyclecounter();
+            st_a += st_t1 - st_t0; st_w1 += st_t2 - st_t1; st_b += st_t3 - st_t2; st_w2 += st_t4 - st_t3;
+        }
+    }
+    if (do_stats && blockIdx.x == 0 && tid == 0) {
+        stats[0] = st_ph; stats[1] = st_empty; stats[2] = st_over; stats[3] = st_cnt; stats[4] = st_a; stats[5] = st_w1;
+        stats[6] = st_b; stats[7] = st_w2; stats[8] = (long long)__builtin_readcyclecounter() - st_t00; stats[9] = st_pairs;
+    }
+    if (do_stats && blockIdx.x == 0 && lane == 0) { stats[16 + wave] = st_a; stats[32 + wave] = st_pairs; stats[48 + wave] = st_upd; }
+    for (int jj = tid; jj < m; jj += NT) {
+        const int k = spick[jj];
+        out[jj] = k;
+        if (nxyz) {
+            const float4 p = sxyz[k];
+            nxyz[jj * 3 + 0] = p.x; nxyz[jj * 3 + 1] = p.y; nxyz[jj * 3 + 2] = p.z;
+        }
+    }
+}
+
+template <int NT, int PPT, int MODE>
+int launch_fps_lazy(int b, int n, int m, const float* inp, int* out, float* nxyz, hipStream_t st) {
+    const size_t bytes = fps_lazy_bytes(n, m);
+    auto kern = fps_lazy_kernel<NT, PPT, MODE>;
+    static bool attr_set = false;  // per instantiation; benign race (idempotent call)
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (e != hipSuccess) return (int)e;
+        attr_set = true;
+    }
+    kern<<<b, NT, bytes, st>>>(n, m, inp, out, nxyz, g_fps_stats);
+    PN2_RETURN_IF_LAUNCH_FAILED();
+    return PN2_OK;
+}
+
 // Generic fallback for n > PN2_FPS_MAX_REG_POINTS: running min in the caller's
 // `temp` rows (one row per resident block, like tf_sampling.cu:124), points
 // streamed from L2.  Blocks stride over the batch (grid <= 32) so the reference's
@@ -323,6 +739,16 @@ int dispatch_fps(int b, int n, int m, const float* inp, float* temp, int* out, f
     // waves and ~180 ns for 16 (tools/round_ubench.hip), a lone wave issues ~0.45 instructions/ns, 4 waves per SIMD ~1/ns.
     // Measured (B=16, ns per round; profiles/r02_fps_experiments.txt): n=256 <64,4> 255 vs <256,1> 316; n=1024 <512,2> 327
     // vs <1024,1> 355; n=2048 <512,4> 360 vs <1024,2> 391; n=4096 <1024,4> 440 vs <512,8> 451; n=8192 <1024,8> 617.
+    // Lazy multi-pick kernel (~15 picks per synchronised pass) where it wins: n = 4096: 174 vs 225 us, n = 8192: 342 vs 633 us
+    // (B = 16; profiles/r03_fps_lazy.txt).  At n <= 2048 its serial picking wave (~400 cycles per pick) costs what a whole
+    // round of the one-pick kernels below costs (93 vs 84 us at n = 1024), so those keep the small levels.
+    // g_fps_variant (tuning builds): 2 = one-pick kernels everywhere, 3 = lazy kernel from n > 512.
+    if (g_fps_variant != 2 && n > (g_fps_variant == 3 ? 512 : 2048) && n <= 8192 && fps_lazy_bytes(n, m) <= 160 * 1024) {
+        if (n <= 1024) return launch_fps_lazy<256, 4, MODE>(b, n, m, inp, out, nxyz, st);
+        if (n <= 2048) return launch_fps_lazy<512, 4, MODE>(b, n, m, inp, out, nxyz, st);
+        if (n <= 4096) return launch_fps_lazy<1024, 4, MODE>(b, n, m, inp, out, nxyz, st);
+        return launch_fps_lazy<1024, 8, MODE>(b, n, m, inp, out, nxyz, st);
+    }
     if (g_fps_variant == 1) {  // A/B hook: one point per thread up to 1024 threads (the round-1 layout)
         if (n <= 64) return launch_fps_reg<64, 1, MODE>(b, n, m, inp, out, nxyz, st);
         if (n <= 128) return launch_fps_reg<128, 1, MODE>(b, n, m, inp, out, nxyz, st);
@@ -487,6 +913,7 @@ extern "C" int pn2_debug_set_grouping(int what, int value);
 extern "C" int pn2_debug_set_linear(int what, int value);
 extern "C" int pn2_debug_set_bn(int what, int value);
 extern "C" int pn2_debug_set_fused(int what, int value);
+extern "C" int pn2_debug_set_fps_stats(long long* dev_ptr) { g_fps_stats = dev_ptr; return 0; }
 extern "C" int pn2_debug_set(int what, int value) {
     if (what == 0) { g_fps_variant = value; return 0; }
     if (what == 5 || what == 8 || what == 9) return pn2_debug_set_linear(what, value);

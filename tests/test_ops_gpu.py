@@ -58,6 +58,48 @@ def test_fps_duplicates_and_degenerate(pn2, oracle, cuda):
     assert pn2.farthest_point_sample(1, T(x, cuda)).cpu().numpy().tolist() == [[0]]
 
 
+@pytest.mark.parametrize("case", ["ragged", "m_eq_n", "all_equal", "two_values", "coarse_lattice", "clusters", "line",
+                                  "far_outlier", "m_small"])
+def test_fps_lazy_multipick_kernel_paths(pn2, oracle, cuda, case):
+    """The lazy multi-pick kernel (2048 < n <= 8192: candidate list above a threshold, picks without a pass over the
+    cloud, pending picks applied through bounding-box tests) on the inputs that drive its special paths: list overflow
+    and empty lists (lattices, duplicates: the single-pick fallback), tau = 0 (all distances zero), clouds that are not a
+    multiple of the 64-point buckets, m == n (list capacity vs pick count), degenerate boxes (a line), a far outlier
+    (cell grid collapses), m below one phase.  Bit-exact against the oracle in all three arithmetic modes."""
+    rs = np.random.RandomState(31)
+    if case == "ragged":
+        x, m = s_scene(31, 3, 5003), 700
+    elif case == "m_eq_n":
+        x, m = s_randn(32, 2, 2100), 2100
+    elif case == "all_equal":
+        x, m = np.full((2, 3000, 3), 0.25, np.float32), 40
+    elif case == "two_values":
+        x, m = (rs.randint(0, 2, (2, 4096, 3))).astype(np.float32), 64
+    elif case == "coarse_lattice":
+        x, m = s_grid(33, 2, 8192, 8), 600  # 512 distinct positions, 16 copies each: ties everywhere
+    elif case == "clusters":
+        c = rs.uniform(-20, 20, (2, 12, 1, 3))
+        x, m = (c + 0.05 * rs.randn(2, 12, 512, 3)).reshape(2, 6144, 3).astype(np.float32), 512
+    elif case == "line":
+        x = np.zeros((2, 4100, 3), np.float32)
+        x[:, :, 1] = rs.uniform(-3, 3, (2, 4100))
+        m = 300
+    elif case == "far_outlier":
+        x = s_scene(34, 2, 8192)
+        x[:, 77] = [4.0e5, -3.0e5, 1.0e5]
+        m = 256
+    else:
+        x, m = s_scene(35, 4, 8192), 2
+    ref = {}
+    for mode in (0, 1, 2):
+        pn2.config.arith_mode = mode
+        ref = oracle.farthest_point_sample(m, x, mode)
+        idx, nx = pn2.tf_ops.tf_sampling.farthest_point_sample_and_gather(m, T(x, cuda))
+        got = idx.cpu().numpy()
+        assert np.array_equal(got, ref), "%s mode %d first diff at %s" % (case, mode, np.argwhere(got != ref)[:3])
+        assert np.array_equal(nx.cpu().numpy(), np.take_along_axis(x, ref[:, :, None].astype(np.int64), 1))
+
+
 def test_fps_streaming_kernel_large_n(pn2, oracle, cuda):
     x = s_scene(8, 2, 20000)  # n > 16384 -> global-scratch kernel
     assert np.array_equal(pn2.farthest_point_sample(40, T(x, cuda)).cpu().numpy(),
