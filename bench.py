@@ -9,9 +9,15 @@ One step = one forward pass of the stack over one batch already resident in HBM.
 
     python bench.py [--gpus N] [--steps K] [--warmup W]
 
-N > 1 is launched by torch.distributed.run, one process per GPU; the path shards over the batch
-dimension with no data-path collective (every rank runs its own 16 scenes: weak scaling); the timed
-region is bracketed by barrier + synchronize and the max over ranks is taken.
+N > 1 = one process per GPU over RCCL.  Started under torch.distributed.run (RANK / WORLD_SIZE in the
+environment, the driver's way) the process is one rank; started bare with --gpus N > 1 it launches
+`python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 ... bench.py <same args>`
+itself and exits with that job's status.  Either way the line is only printed by a job whose world size equals
+--gpus: a box with fewer than N GPUs, or a WORLD_SIZE that disagrees with --gpus, is a non-zero exit, never an
+"n_gpus: 1" line.  The path shards over the batch dimension with no data-path collective (every rank runs its own
+16 scenes: weak scaling); the timed region is bracketed by barrier + synchronize and the max over ranks is taken.
+`--dry-run` (tests/test_dist_cpu.py) runs launcher, rendezvous (gloo), barriers, max-over-ranks and the JSON line
+WITHOUT the GPU workload: the N > 1 plumbing checked on a CPU-only box.
 
 Prints ONE JSON line (rank 0).  `value` / `ms_per_step` are the THROUGHPUT regime: `config.batches_in_flight`
 (default 4) independent B=16 batches in flight, each its own hipGraph on its own stream -- a step is still one
@@ -377,12 +383,72 @@ def bench_train(pn2, args, hp, B, N, rank, world, dev):
                                    "chain prefetched on a side stream"
                                    % (B, N, tr.store.num_parameters()),
                        "global_batch": world * B, "parallelism": "dp%d" % world},
-            "last_loss": float(loss)}))
+            "last_loss": float(loss), **rccl_info(world)}))
+
+
+def _free_port():
+    import socket
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        return so.getsockname()[1]
+
+
+def launch_ranks(args):
+    """`bench.py --gpus N` started bare (no RANK in the environment): become the launcher of N ranks on this node."""
+    import subprocess
+    if not args.dry_run:
+        have = torch.cuda.device_count() if torch.cuda.is_available() else 0
+        if have < args.gpus:
+            raise SystemExit("bench.py --gpus %d: this node has %d visible GPU(s); refusing to print a line for fewer "
+                             "ranks than requested" % (args.gpus, have))
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC (RCCL across processes on this driver)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), os.path.abspath(__file__)] + sys.argv[1:]
+    raise SystemExit(subprocess.call(cmd, env=env))
+
+
+def rccl_info(world):
+    """what the collective layer really is: world size of the initialised group, backend, RCCL version."""
+    import torch.distributed as dist
+    info = {"rccl_ranks": dist.get_world_size() if dist.is_initialized() else 1,
+            "backend": dist.get_backend() if dist.is_initialized() else None}
+    try:
+        info["rccl_version"] = ".".join(str(v) for v in torch.cuda.nccl.version())
+    except Exception:
+        info["rccl_version"] = None
+    assert info["rccl_ranks"] == world, info
+    return info
+
+
+def dry_run(args, rank, world):
+    """The N > 1 plumbing without the GPU workload (gloo on CPU): rendezvous, barrier-bracketed timed region,
+    max over ranks, ONE line from rank 0."""
+    import torch.distributed as dist
+    import pn2_amd as pn2
+    pn2.dist.init_from_env(backend="gloo")
+    pn2.dist.barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        time.sleep(0.001 * (1 + rank))  # rank-dependent "work": the slowest rank must define the step
+    pn2.dist.barrier()
+    elapsed = pn2.dist.max_over_ranks(time.perf_counter() - t0)
+    if rank == 0:
+        line = {"metric": "dry run (no GPU work): launcher / rendezvous / max-over-ranks only", "value": None,
+                "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+                "ms_per_step": round(elapsed / args.steps * 1e3, 4), "dry_run": True}
+        line.update(rccl_info(world))
+        print(json.dumps(line))
+    pn2.dist.barrier()
+    if dist.is_initialized():
+        dist.destroy_process_group()
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--dry-run", action="store_true",
+                    help="launcher / rendezvous / timing plumbing only, gloo on CPU, no GPU work (tests/test_dist_cpu.py)")
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--batch", type=int, default=16)
@@ -411,11 +477,21 @@ def main():
                          "BN + weighted CE + backward + one flat RCCL gradient all-reduce + Adam), 16 scenes per GPU")
     args = ap.parse_args()
 
+    if args.gpus < 1:
+        raise SystemExit("--gpus must be >= 1")
+    if args.gpus > 1 and "RANK" not in os.environ:
+        launch_ranks(args)  # does not return
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        raise SystemExit("bench.py --gpus %d but WORLD_SIZE=%d: the line would not describe the job that ran" % (args.gpus, world))
+    if args.dry_run:
+        return dry_run(args, rank, world)
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: torch.cuda.is_available() is False (no CPU fallback)")
+    if torch.cuda.device_count() <= local_rank:
+        raise SystemExit("bench.py rank %d: LOCAL_RANK=%d but only %d GPU(s) visible" % (rank, local_rank, torch.cuda.device_count()))
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     dist_on = world > 1
@@ -582,6 +658,7 @@ def main():
             "single_batch_latency_ms": None if latency_ms is None else round(latency_ms, 4),
             "gpu_ms_per_step_sum_of_kernels": round(sum_all, 4),
         }
+        res.update(rccl_info(world))
         if fps:
             f0 = max(fps, key=lambda k: k["ms_per_step"])
             fb, fn, fm = f0["args"][:3]

@@ -179,3 +179,42 @@ def test_world2_gloo_overlapped_two_bucket_allreduce():
     order = res[0]["order"][:6]
     assert sorted(i for i, _ in order[:2]) == [4, 5]
     assert all(flag for i, flag in order if i < 4)
+
+
+# ---- bench.py --gpus N really launches N ranks ------------------------------------------------------
+def _run_bench(argv, env_extra=None, timeout=240):
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(env_extra or {})
+    return subprocess.run([sys.executable, os.path.join(root, "bench.py")] + argv, env=env, capture_output=True, text=True,
+                          timeout=timeout)
+
+
+@pytest.mark.timeout(300)
+def test_bench_gpus2_launches_two_ranks_and_prints_one_line():
+    """Bare `bench.py --gpus 2` becomes the launcher: two processes rendezvous (gloo here, --dry-run = no GPU work), the
+    timed region is barrier-bracketed, the slowest rank defines the step, rank 0 prints exactly one line with n_gpus 2."""
+    import json
+    r = _run_bench(["--gpus", "2", "--steps", "3", "--warmup", "1", "--dry-run"])
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 2 and line["rccl_ranks"] == 2 and line["backend"] == "gloo" and line["steps"] == 3
+    assert line["ms_per_step"] >= 2.0  # rank 1 sleeps 2 ms per step, rank 0 only 1 ms: max over ranks
+
+
+@pytest.mark.timeout(120)
+def test_bench_never_reports_fewer_ranks_than_requested():
+    """--gpus 2 on a node without two GPUs, or under a WORLD_SIZE that disagrees with --gpus: non-zero exit, no line."""
+    if torch.cuda.is_available() and torch.cuda.device_count() >= 2:
+        pytest.skip("this node really has two GPUs")
+    r = _run_bench(["--gpus", "2", "--steps", "2", "--warmup", "1"])
+    assert r.returncode != 0 and "{" not in r.stdout
+    assert "visible GPU" in (r.stderr + r.stdout)
+    r = _run_bench(["--gpus", "8", "--steps", "2", "--warmup", "1", "--dry-run"],
+                   env_extra=dict(RANK="0", LOCAL_RANK="0", WORLD_SIZE="1", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port())))
+    assert r.returncode != 0 and "{" not in r.stdout
+    assert "WORLD_SIZE" in (r.stderr + r.stdout)
