@@ -15,9 +15,11 @@ from .util import pointnet_util as pu
 from .util.pointnet_util import pointnet_fp_module, pointnet_sa_module
 from .tf_ops.tf_interpolate import three_nn
 
-# semantic.json:8-9,23-37 of the reference
+# semantic.json:8-9,11-15,19-21,23-37 of the reference
 SEMANTIC_HYPERPARAMS = {
     "num_point": 8192, "batch_size": 16, "use_color": 1,
+    "optimizer": "adam", "momentum": 0.9, "learning_rate": 0.001, "decay_step": 200000, "learning_rate_decay_rate": 0.7,
+    "bn_init_decay": 0.5, "bn_decay_decay_rate": 0.5, "bn_decay_clip": 0.99,
     "l1_radius": 0.5, "l1_nsample": 32, "l1_npoint": 1024,
     "l2_radius": 1.0, "l2_nsample": 32, "l2_npoint": 256,
     "l3_radius": 2.0, "l3_nsample": 32, "l3_npoint": 64,

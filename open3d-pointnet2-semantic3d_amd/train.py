@@ -45,6 +45,15 @@ class Trainer:
 
     def __init__(self, hyperparams, num_class, store=None, device="cuda", capture=True, warmup_eager=3, geometry_in_graph=False, split_capture=None):
         self.hp = dict(hyperparams)
+        # schedule / optimizer keys of the reference's semantic.json (train.py:80-119, 380-386); its defaults when absent
+        opt = str(self.hp.get("optimizer", "adam")).lower()
+        if opt != "adam":
+            raise ValueError("optimizer %r: only 'adam' (the reference's semantic.json setting, train.py:385-386) is built; "
+                             "the 'momentum' branch of train.py:380-383 is not" % (opt,))
+        self.sched = dict(base_lr=float(self.hp.get("learning_rate", 1e-3)), decay_step=int(self.hp.get("decay_step", 200000)),
+                          lr_decay_rate=float(self.hp.get("learning_rate_decay_rate", 0.7)),
+                          bn_init=float(self.hp.get("bn_init_decay", 0.5)), bn_rate=float(self.hp.get("bn_decay_decay_rate", 0.5)),
+                          bn_clip=float(self.hp.get("bn_decay_clip", 0.99)))
         self.num_class = num_class
         self.store = store or tf_util.set_default_store(tf_util.VariableStore(device=device, seed=0))
         self.step_count = 0
@@ -71,7 +80,7 @@ class Trainer:
         tf_util.set_default_store(self.store)
         with torch.no_grad():
             before = {k: v.clone() for k, v in self.store.buffers.items()}  # a pre-loaded store keeps its statistics
-            model.get_model(pc[:1], True, self.num_class, self.hp, bn_decay=bn_decay(0, pc.shape[0]))
+            model.get_model(pc[:1], True, self.num_class, self.hp, bn_decay=self._bn_decay(0, pc.shape[0]))
             for k, v in self.store.buffers.items():
                 if k in before:
                     v.copy_(before[k])
@@ -97,10 +106,21 @@ class Trainer:
         # backward reaches the head and the FP layers first: they are the early bucket (created after layer1..layer4)
         split = next((i for i, k in enumerate(names) if not k.startswith("layer")), len(names))
         self.bucket = pdist.OverlappedGradAllReduce(params, split)
-        self.hyper = torch.zeros(5, dtype=torch.float32, device=dev)
+        # pn2_adam_step's device-side scalars: [lr_t, beta1, beta2, eps, grad_scale].  Only lr_t changes per step; it is
+        # written with a fill whose value travels BY VALUE in the launch (no host buffer a run-ahead host could rewrite
+        # before an asynchronous copy has read it: with sync=False the host is several steps ahead of the device).
+        self.hyper = torch.tensor([0.0, self.BETA1, self.BETA2, self.EPS, 1.0 / self.bucket.world()], dtype=torch.float32).to(dev)
+        self._lr_slot = self.hyper[0:1]
         self._stream = torch.cuda.Stream(device=dev) if dev.type == "cuda" else None
         self._geo_stream = torch.cuda.Stream(device=dev) if dev.type == "cuda" else None
-        self._hyper_host = torch.zeros(5, dtype=torch.float32).pin_memory() if dev.type == "cuda" else torch.zeros(5)
+
+    def _learning_rate(self, step, batch_size):
+        c = self.sched
+        return learning_rate(step, batch_size, c["base_lr"], c["decay_step"], c["lr_decay_rate"])
+
+    def _bn_decay(self, step, batch_size):
+        c = self.sched
+        return bn_decay(step, batch_size, c["bn_init"], c["decay_step"], c["bn_rate"], c["bn_clip"])
 
     # ---- one step ------------------------------------------------------------------------------------------------
     def _forward_backward(self, pc, labels, smpw, decay, geometry=None):
@@ -181,15 +201,14 @@ class Trainer:
         b = pc.shape[0]
         world = self.bucket.world()
         t = self.step_count + 1
-        lr = learning_rate(self.step_count, b)
-        decay = bn_decay(self.step_count, b)
-        self._hyper_host.copy_(torch.tensor([adam_lr_t(lr, t, self.BETA1, self.BETA2), self.BETA1, self.BETA2, self.EPS,
-                                             1.0 / world], dtype=torch.float32))
+        lr = self._learning_rate(self.step_count, b)
+        decay = self._bn_decay(self.step_count, b)
+        lr_t = adam_lr_t(lr, t, self.BETA1, self.BETA2)
         use_graph = self.capture and pc.is_cuda and self.step_count >= self.warmup_eager
         split = use_graph and (world > 1 if self.split_capture is None else bool(self.split_capture))
         caller = torch.cuda.current_stream()
         if not use_graph:
-            self.hyper.copy_(self._hyper_host, non_blocking=True)
+            self._lr_slot.fill_(lr_t)
             self.store.set_step(self.step_count)
             geo = self._geometry_for(pc, caller)
             taken = torch.cuda.Event()
@@ -210,7 +229,7 @@ class Trainer:
                     geo = self._geometry_for(pc, self._stream)  # eager (or eagerly prefetched: prefetch_geometry)
                 if recapture:
                     self._capture(pc, labels, smpw, decay, geo, split)
-                self.hyper.copy_(self._hyper_host, non_blocking=True)
+                self._lr_slot.fill_(lr_t)
                 self.store.set_step(self.step_count)
                 # every per-step device-to-device copy (inputs, and this batch's geometry when it is not in place yet) in ONE
                 # launch: they sit between two graphs on the critical path
@@ -246,6 +265,10 @@ class Trainer:
                     loss = float(loss)
             caller.wait_stream(self._stream)
         self.step_count += 1
+        # A replayed graph updates parameters and moving averages through raw pointers: neither a tensor version counter
+        # nor the training-mode layer calls (which only run while capturing) tell the inference-weight cache
+        # (VariableStore.folded) that they changed.  Every step does.
+        self.store.train_epoch += 1
         return float(loss) if sync else loss
 
     def _capture(self, pc, labels, smpw, decay, geo, split=False):

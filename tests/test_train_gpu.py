@@ -301,6 +301,107 @@ def test_captured_training_step_equals_eager(pn2, cuda):
     assert bdist("graph", "eager") <= 3.0 * bdist("eager2", "eager") + 2e-2, (bdist("graph", "eager"), bdist("eager2", "eager"))
 
 
+def test_eval_after_captured_steps_uses_fresh_weights(pn2, cuda):
+    """a replayed hipGraph updates parameters and moving averages through raw pointers -- no tensor
+    version changes, no training-mode Python layer call runs -- so the folded inference weights cached by an evaluation
+    BEFORE the replays must not be served to the evaluation AFTER them.  train -> eval -> replays -> eval."""
+    import torch
+    hp = dict(pn2.model.SEMANTIC_HYPERPARAMS)
+    hp.update(l1_npoint=256, l2_npoint=64, l3_npoint=32, l4_npoint=16)
+    batches = [_batch(cuda, s) for s in range(3)]
+    store = pn2.util.tf_util.VariableStore(device=cuda, seed=5)
+    tr = pn2.train.Trainer(hp, 9, store=store, warmup_eager=2)
+    for i in range(4):  # 2 eager steps, the capture, one replay
+        tr.train_step(*batches[i % 3])
+    assert tr._graph is not None
+
+    def evaluate():
+        pn2.util.tf_util.set_default_store(store)
+        with torch.no_grad():
+            return pn2.model.get_model(batches[0][0], False, 9, hp)[0].clone()
+    ev0 = evaluate()
+    for i in range(4, 9):  # replays only
+        tr.train_step(*batches[i % 3])
+    ev1 = evaluate()
+    store._folded.clear()  # what a cold cache computes from the CURRENT parameters and moving averages
+    ev_cold = evaluate()
+    assert torch.equal(ev1, ev_cold), float((ev1 - ev_cold).abs().max())
+    assert float((ev1 - ev0).abs().max()) > 1e-3  # five Adam steps and five moving-average updates did move the logits
+    # Adam's device-side scalars after run-ahead steps (sync=False): lr_t of the LAST step, constants untouched
+    for i in range(9, 14):
+        tr.train_step(*batches[i % 3], sync=False)
+    torch.cuda.synchronize()
+    want = pn2.train.adam_lr_t(tr._learning_rate(13, 8), 14)
+    got = tr.hyper.cpu().numpy()
+    np.testing.assert_allclose(got, [want, 0.9, 0.999, 1e-8, 1.0], rtol=1e-6)
+
+
+def _ddp_worker(rank, world, port, capture, q):
+    import os
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                      HSA_ENABLE_IPC_MODE_LEGACY="0")
+    import torch
+    import torch.distributed as dist
+    import pn2_amd as pn2
+    cuda = torch.device("cuda:0")
+    torch.cuda.set_device(cuda)
+    try:
+        # two ranks on ONE GPU: RCCL refuses a duplicate device, gloo moves CUDA tensors through the host -- the collective
+        # CALLS, their stream ordering around the graph replays and the 1/world scale are what is under test
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        probe = torch.ones(4, device=cuda)
+        dist.all_reduce(probe)
+        assert float(probe[0]) == world
+    except Exception as ex:
+        q.put((rank, "skip: %r" % (ex,)))
+        return
+    hp = dict(pn2.model.SEMANTIC_HYPERPARAMS)
+    hp.update(l1_npoint=256, l2_npoint=64, l3_npoint=32, l4_npoint=16)
+    batches = [_batch(cuda, 10 * rank + s, b=4) for s in range(3)]  # different scenes on every rank
+    # different seeds: rank 0's weights must be broadcast
+    tr = pn2.train.Trainer(hp, 9, store=pn2.util.tf_util.VariableStore(device=cuda, seed=3 + rank), capture=capture, warmup_eager=2)
+    losses = [tr.train_step(*batches[i % 3]) for i in range(7)]
+    torch.cuda.synchronize()
+    split_graphs = tr._graph is not None and tr._graph_adam is not None
+    q.put((rank, dict(losses=losses, p=tr.flat_p.cpu().numpy(), split=split_graphs, world=tr.bucket.world(),
+                      scale=float(tr.hyper[4]))))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(600)
+def test_two_rank_captured_step_keeps_replicas_identical(pn2, cuda):
+    """the multi-rank captured step (forward+backward graph | ONE all-reduce of the flat gradient on the
+    trainer's stream | Adam graph) run with world = 2 -- two processes, different data, different initial seeds: after warm-up
+    + several split replays the parameters are bit-identical on both ranks (same summed gradient, same 1/world scale, same
+    Adam launch), and they follow the EAGER two-rank trajectory (two-bucket overlapped all-reduce)."""
+    import torch.multiprocessing as mp
+    import socket
+    res = {}
+    for capture in (True, False):
+        so = socket.socket(); so.bind(("127.0.0.1", 0)); port = so.getsockname()[1]; so.close()
+        ctx = mp.get_context("spawn")
+        q = ctx.Queue()
+        procs = [ctx.Process(target=_ddp_worker, args=(r, 2, port, capture, q)) for r in range(2)]
+        for p in procs:
+            p.start()
+        got = dict(q.get(timeout=400) for _ in range(2))
+        for p in procs:
+            p.join(60)
+        if any(isinstance(v, str) for v in got.values()):
+            pytest.skip("gloo cannot reduce CUDA tensors on this box: %s" % (got,))
+        res[capture] = got
+    cap, eag = res[True], res[False]
+    assert cap[0]["split"] and cap[1]["split"] and cap[0]["world"] == 2 and cap[0]["scale"] == 0.5
+    assert np.array_equal(cap[0]["p"], cap[1]["p"])  # replicas stay bit-identical through the captured steps
+    assert np.array_equal(eag[0]["p"], eag[1]["p"])
+    np.testing.assert_allclose(cap[0]["losses"][:2], eag[0]["losses"][:2], rtol=1e-4)  # the eager warm-up is the same code
+    np.testing.assert_allclose(cap[0]["losses"], eag[0]["losses"], rtol=3e-2)
+    rel = float(np.linalg.norm(cap[0]["p"] - eag[0]["p"]) / np.linalg.norm(eag[0]["p"]))
+    assert rel <= 5e-2, rel  # a missing or doubled all-reduce / a wrong 1/world would be O(0.1 .. 1)
+    assert cap[0]["losses"] != cap[1]["losses"]  # the ranks did train on different scenes
+
+
 def test_split_capture_with_a_process_group(pn2, cuda):
     """the multi-rank step (two graphs around an RCCL all-reduce on the trainer's stream) with a real, single-rank "nccl"
     process group: the collective is issued between the replays and the trajectory is the single-graph one."""

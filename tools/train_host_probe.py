@@ -59,12 +59,12 @@ torch.cuda.synchronize()
 K = 30
 for i in range(K):
     pc_i, nxt = pcs[i % 2], pcs[(i + 1) % 2]
-    t0 = time.perf_counter(); tr._hyper_host.copy_(torch.tensor([1e-3, 0.9, 0.999, 1e-8, 1.0])); T("hyper host copy", t0)
+    t0 = time.perf_counter(); tr._lr_slot.fill_(1e-3); T("hyper host copy", t0)
     caller = torch.cuda.current_stream()
     t0 = time.perf_counter(); tr._stream.wait_stream(caller); T("wait_stream", t0)
     with torch.cuda.stream(tr._stream):
         t0 = time.perf_counter(); geo = tr._geometry_for(pc_i, tr._stream); T("_geometry_for", t0)
-        t0 = time.perf_counter(); tr.hyper.copy_(tr._hyper_host, non_blocking=True); T("hyper H2D", t0)
+        t0 = time.perf_counter(); tr._lr_slot.fill_(1e-3); T("hyper H2D", t0)
         t0 = time.perf_counter(); tr.store.set_step(i); T("set_step", t0)
         t0 = time.perf_counter()
         for dst, src in zip(tr._static[:3], (pc_i, labels, smpw)):
@@ -95,7 +95,7 @@ def replay_only(i):
         tr._graph.replay()
 def replay_copies(i):
     with torch.cuda.stream(tr._stream):
-        tr.hyper.copy_(tr._hyper_host, non_blocking=True); tr.store.set_step(i)
+        tr._lr_slot.fill_(1e-3); tr.store.set_step(i)
         tr._static[0].copy_(pcs[i % 2], non_blocking=True)
         pn2.util.tf_util.multi_copy_(M.geometry_tensors(tr._static_geo), M.geometry_tensors(geo_fixed))
         tr._graph.replay()
