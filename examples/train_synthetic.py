@@ -52,7 +52,7 @@ def main():
         torch.cuda.current_stream().wait_stream(prep)    # step k+1 (enqueued next) consumes it
         for t in nxt:
             t.record_stream(torch.cuda.current_stream())
-        losses.append(loss)
+        losses.append(loss.clone())                      # the captured step returns ONE static device scalar: keep a copy per step
         cur = nxt
         if i == 7:  # eager warm-up steps and the one-time graph capture are behind us
             torch.cuda.synchronize()

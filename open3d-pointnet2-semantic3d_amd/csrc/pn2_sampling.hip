@@ -126,8 +126,13 @@ __device__ __forceinline__ unsigned wave_umin_all(unsigned v) {
     return v;
 }
 
-constexpr int kFpsBias = 0x00100000;  // keeps the high word of a (td, key) pair out of the fp64 denormal range; bits(1e38f) + bias < 0x7FF00000
-__device__ __forceinline__ double fps_dmax(double a, double b) {  // exact 64-bit max of two positive normal patterns (no canonicalisation inserted)
+// Exact 64-bit max of two (td bits : ~tiekey) pairs read as doubles.  The high word is an fp32 pattern in [0, bits(1e38f)]
+// (or bits(-1.0f) for "no point"), so the doubles are finite; pairs with td < 2^-126-ish map to fp64 DENORMALS (high word
+// < 0x00100000), which v_max_f64 orders correctly only because the kernel runs with fp64 denormals enabled -- the
+// default float mode of HIP kernels on gfx9 (FP64/FP16 denormals on, MODE.FP_DENORM = 0b11xx; only fp32 denormals are
+// affected by -fgpu-flush-denormals-to-zero).  tests/test_ops_gpu.py::test_fps_duplicates_and_degenerate and the
+// lattice tests (td == 0 everywhere) would fail if that ever changed.  (Inline asm: no canonicalisation inserted.)
+__device__ __forceinline__ double fps_dmax(double a, double b) {
     double r;
     asm("v_max_f64 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
     return r;

@@ -16,12 +16,15 @@ from ..util.point_cloud_util import load_labels, read_point_cloud_pcd
 
 class SemanticFileData:
     def __init__(self, file_path_without_ext=None, has_label=True, use_color=True, box_size_x=10, box_size_y=10,
-                 points=None, labels=None, colors=None, device="cuda"):
+                 points=None, labels=None, colors=None, device="cuda", strict=False):
         """Loads <prefix>.pcd / <prefix>.labels (semantic_dataset.py:60-82), or takes the arrays directly; sorts by x
         (:84-88) and uploads the scene once."""
         import numpy as np
         self.file_path_without_ext = file_path_without_ext
         self.box_size_x, self.box_size_y = box_size_x, box_size_y
+        # strict: sample_batch() itself raises on a bad sample (one host synchronisation per batch).  Otherwise a rejected
+        # sample (status != 0) comes back ZERO-FILLED, never as uninitialised memory, and check_last() reports it.
+        self.strict = bool(strict)
         if points is None:
             points, file_colors = read_point_cloud_pcd(file_path_without_ext + ".pcd")
             labels = load_labels(file_path_without_ext + ".labels") if has_label else np.zeros(len(points), dtype=bool)
@@ -75,22 +78,26 @@ class SemanticFileData:
             # uniform random subset of exactly npts of the first cnt entries: the npts smallest of cnt random keys
             keys = torch.rand((batch_size, cap), device=dev, generator=self.generator)
             keys.masked_fill_(torch.arange(cap, device=dev)[None, :] >= cnt[:, None], 2.0)
-            kth = torch.kthvalue(keys, min(npts, cap), dim=1).values
-            sample_masks = (keys <= kth[:, None]).to(torch.uint8)
+            # (the INDICES of the k smallest keys, not `keys <= k-th key`: two equal fp32 keys -- a few percent of the batches
+            # at 50k-100k points per column -- would select npts + 1 entries and the kernel rejects the sample, status 3)
+            pick = torch.topk(keys, min(npts, cap), dim=1, largest=False, sorted=False).indices
+            sample_masks = torch.zeros((batch_size, cap), dtype=torch.uint8, device=dev).scatter_(1, pick, 1)
         mask = sample_masks.to(dev).to(torch.uint8).contiguous()
         if mask.shape != (batch_size, cap):
             raise ValueError("sample_masks must be (batch_size, capacity)")
-        sel = torch.empty((batch_size, npts), dtype=torch.int32, device=dev)
-        centered = torch.empty((batch_size, npts, 3), dtype=torch.float32, device=dev)
-        raw = torch.empty((batch_size, npts, 3), dtype=torch.float64, device=dev)
-        labels = torch.empty((batch_size, npts), dtype=torch.int32, device=dev)
-        colors = torch.empty((batch_size, npts, 3), dtype=torch.float32, device=dev)
-        status = torch.empty((batch_size,), dtype=torch.int32, device=dev)
+        sel = torch.zeros((batch_size, npts), dtype=torch.int32, device=dev)
+        centered = torch.zeros((batch_size, npts, 3), dtype=torch.float32, device=dev)
+        raw = torch.zeros((batch_size, npts, 3), dtype=torch.float64, device=dev)
+        labels = torch.zeros((batch_size, npts), dtype=torch.int32, device=dev)
+        colors = torch.zeros((batch_size, npts, 3), dtype=torch.float32, device=dev)
+        status = torch.zeros((batch_size,), dtype=torch.int32, device=dev)
         with torch.cuda.device(dev):
             check(lib.pn2_scene_sample(batch_size, npts, cap, ptr(self.points), ptr(self.labels), ptr(self.colors), ptr(idx),
                                        ptr(cnt), ptr(mask), self.box_size_x / 2, self.box_size_y / 2, ptr(sel), ptr(centered),
                                        ptr(raw), ptr(labels), ptr(colors), ptr(status), stream_ptr()), "pn2_scene_sample")
         self.last_status, self.last_sel, self.last_cnt = status, sel, cnt
+        if self.strict:
+            self.check_last()  # one host synchronisation per batch; strict=False leaves the check to the caller
         return centered, raw, labels, colors
 
     def sample(self, num_points_per_sample, **kw):

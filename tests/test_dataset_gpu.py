@@ -102,3 +102,30 @@ def test_voxel_downsample_large_properties(pn2, cuda):
     w = counts.double()[:, None]
     assert torch.allclose((sp * w).sum(0) / n, pts.mean(0), rtol=1e-9, atol=1e-9)
     assert int(sl.min()) >= 1 and int(sl.max()) <= 8
+
+
+def test_scene_sampler_default_mask_survives_tied_random_keys(pn2, cuda, monkeypatch):
+    """the default random subset must select EXACTLY npts entries even when two random keys are equal (`keys <=
+    k-th key` selected npts + 1, the kernel rejected the sample with status 3 and returned uninitialised memory).  Forced here
+    with keys quantised to 1/64, i.e. thousands of ties per row; a rejected sample also comes back zero-filled, never garbage."""
+    import torch
+    from make_dataset_golden import scene
+    pts, labels, colors = scene(9, 150000)
+    fd = pn2.dataset.SemanticFileData(points=pts, labels=labels, colors=colors, box_size_x=10, box_size_y=10, device=cuda)
+    real_rand = torch.rand
+    monkeypatch.setattr(torch, "rand", lambda *a, **k: torch.floor(real_rand(*a, **k) * 64) / 64)
+    c, r, l, col = fd.sample_batch(8, 4096, capacity=50000)
+    monkeypatch.undo()
+    assert fd.last_status.cpu().tolist() == [0] * 8
+    fd.check_last()
+    for b in range(8):
+        if fd.last_cnt[b] > 4096:
+            assert len(np.unique(fd.last_sel[b].cpu().numpy())) == 4096
+    # a rejected sample (capacity too small) is zero-filled and reported; strict=True raises from sample_batch itself
+    c2, r2, l2, col2 = fd.sample_batch(2, 1024, capacity=64)
+    assert any(fd.last_status.cpu().tolist())
+    bad = [i for i, st in enumerate(fd.last_status.cpu().tolist()) if st]
+    assert float(c2[bad].abs().max()) == 0.0 and int(l2[bad].abs().max()) == 0
+    fds = pn2.dataset.SemanticFileData(points=pts, labels=labels, colors=colors, box_size_x=10, box_size_y=10, device=cuda, strict=True)
+    with pytest.raises(RuntimeError):
+        fds.sample_batch(2, 1024, capacity=64)
