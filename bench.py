@@ -631,7 +631,8 @@ def main():
                                    "B=%d scenes x N=%d points xyz+rgb per GPU, fp32, S-scene synthetic input, "
                                    "random-init weights" % (B, N),
                        "batch_per_gpu": B, "num_point": N, "parallelism": "batch-sharded replicas x%d, no collective" % world,
-                       "arith_mode": int(pn2.config.arith_mode),
+                       "arith_mode": {"fps": int(pn2.config.fps_mode()), "ball_query": int(pn2.config.bq_mode()),
+                                      "pinned_to": "oracle/_ref fast_noslp build of the reference's own kernels (contraction on)"},
                        "launch": "eager python launches" if args.eager else "one hipGraph replay per step",
                        "streams_per_batch": 2 if (args.two_streams and not args.eager) else 1,
                        "batches_in_flight": P_eff,

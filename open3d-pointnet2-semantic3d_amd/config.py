@@ -1,8 +1,61 @@
-"""Process-wide switches of the MI355X op library."""
+"""Arithmetic modes of the two kernels whose OUTPUT INDICES depend on how the reference's squared-distance expression
+`(x2-x1)*(x2-x1)+(y2-y1)*(y2-y1)+(z2-z1)*(z2-z1)` (tf_sampling.cu:149-150, tf_grouping.cu:28-30) is contracted
+(include/pn2_abi.h `arith_mode`).
+
+The DEFAULTS are the pair ONE complete build of the reference's own kernels produces: `oracle/_ref` built with floating-point
+contraction ON and no SLP vectorisation (`-ffp-contract=fast -fno-slp-vectorize`, oracle/Makefile) -- the analogue of
+the reference's nvcc build, whose `--fmad=true` default applies (tf_ops/CMakeLists.txt:5,13 pass no -fmad flag).  In that
+build LLVM contracts the expression as fma(dz,dz,fma(dy,dy,dx*dx)) in farthestpointsamplingKernel (mode 2) and as
+fma(dz,dz,fma(dx,dx,dy*dy)) in query_ball_point_gpu (mode 1): tests/test_ref_gpu.py runs the whole SA geometry chain of
+configs[1] with these defaults against that build, bit for bit.  (The contraction-OFF build equals (0, 0).)
+
+There is no process-global switch: every op takes `arith_mode=` per call; `arith(...)` scopes a different default to a
+`with` block of the calling THREAD (tests run whole layer chains under another mode with it).
+"""
+import contextlib
+import threading
 
 ARITH_STRICT, ARITH_FMA, ARITH_FMA_ALT = 0, 1, 2
 
-# Squared-distance contraction hypothesis used by FPS and ball query (see
-# include/pn2_abi.h and DESIGN.md "Arithmetic modes").  ARITH_FMA reproduces what
-# nvcc's default --fmad=true does to the reference expression.
-arith_mode = ARITH_FMA
+FPS_ARITH_DEFAULT = ARITH_FMA_ALT   # farthest_point_sample:  oracle/_ref "fast_noslp" build
+BQ_ARITH_DEFAULT = ARITH_FMA        # query_ball_point:       oracle/_ref "fast_noslp" build
+
+_tls = threading.local()
+
+
+def _check(mode):
+    mode = int(mode)
+    if mode not in (ARITH_STRICT, ARITH_FMA, ARITH_FMA_ALT):
+        raise ValueError("arith_mode must be 0 (strict), 1 (fma) or 2 (fma_alt), got %r" % (mode,))
+    return mode
+
+
+def fps_mode(explicit=None):
+    """mode of a farthest_point_sample call: the call's own keyword, else the enclosing `arith` scope, else the default"""
+    if explicit is not None:
+        return _check(explicit)
+    scoped = getattr(_tls, "fps", None)
+    return FPS_ARITH_DEFAULT if scoped is None else scoped
+
+
+def bq_mode(explicit=None):
+    if explicit is not None:
+        return _check(explicit)
+    scoped = getattr(_tls, "bq", None)
+    return BQ_ARITH_DEFAULT if scoped is None else scoped
+
+
+@contextlib.contextmanager
+def arith(mode=None, fps=None, bq=None):
+    """with arith(0): ...            both ops strict (== oracle/_ref "off" build)
+    with arith(fps=2, bq=1): ...   per op.   Thread-local, restored on exit."""
+    if mode is not None:
+        fps = mode if fps is None else fps
+        bq = mode if bq is None else bq
+    old = (getattr(_tls, "fps", None), getattr(_tls, "bq", None))
+    _tls.fps = old[0] if fps is None else _check(fps)
+    _tls.bq = old[1] if bq is None else _check(bq)
+    try:
+        yield
+    finally:
+        _tls.fps, _tls.bq = old

@@ -174,16 +174,21 @@ def get_sa_fp_features(point_cloud, is_training, hyperparams, bn_decay=None, two
     return up, end_points
 
 
+def get_head(l0_points, is_training, num_class, bn_decay=None, end_points=None):
+    """The classification head on per-point features (B,N,128) (model.py:131-146): conv1d(128)+BN+ReLU -> dropout(0.5)
+    -> conv1d(num_class), scopes fc1 / dp1 / fc2.  -> logits (B,N,num_class)."""
+    net = tf_util.conv1d(l0_points, 128, 1, padding="VALID", bn=True, is_training=is_training, scope="fc1",
+                         bn_decay=bn_decay)
+    if end_points is not None:
+        end_points["feats"] = net
+    net = tf_util.dropout(net, keep_prob=0.5, is_training=is_training, scope="dp1")
+    return tf_util.conv1d(net, num_class, 1, padding="VALID", activation_fn=None, scope="fc2", is_training=is_training)
+
+
 def get_model(point_cloud, is_training, num_class, hyperparams, bn_decay=None, geometry=None):
     """-> logits (B,N,num_class), end_points (model.py:22-148)."""
     l0_points, end_points = get_sa_fp_features(point_cloud, is_training, hyperparams, bn_decay, geometry=geometry)
-    net = tf_util.conv1d(l0_points, 128, 1, padding="VALID", bn=True, is_training=is_training, scope="fc1",
-                         bn_decay=bn_decay)
-    end_points["feats"] = net
-    net = tf_util.dropout(net, keep_prob=0.5, is_training=is_training, scope="dp1")
-    net = tf_util.conv1d(net, num_class, 1, padding="VALID", activation_fn=None, scope="fc2",
-                         is_training=is_training)
-    return net, end_points
+    return get_head(l0_points, is_training, num_class, bn_decay, end_points), end_points
 
 
 class _WeightedCE(torch.autograd.Function):

@@ -11,11 +11,12 @@ from .. import config
 from .._lib import check, lib, ptr, require_cuda, stream_ptr
 
 
-def query_ball_point(radius, nsample, xyz1, xyz2, kernel=0):
+def query_ball_point(radius, nsample, xyz1, xyz2, kernel=0, arith_mode=None):
     """radius float, nsample int, xyz1 (b,n,3) dataset, xyz2 (b,m,3) queries
     -> idx (b,m,nsample) int32, pts_cnt (b,m) int32.  Not differentiable.
     kernel (extension, tests / diagnostics): 0 = chosen by shape, 1 / 2 / 3 = a specific kernel
-    (pn2_query_ball_point_kernel); every kernel returns the same bits."""
+    (pn2_query_ball_point_kernel); every kernel returns the same bits.
+    arith_mode (extension): contraction of the squared-distance expression, config.BQ_ARITH_DEFAULT when None."""
     if not radius > 0:
         raise ValueError("QueryBallPoint expects positive radius")  # tf_grouping.cpp:80-83
     if nsample <= 0:
@@ -37,15 +38,15 @@ def query_ball_point(radius, nsample, xyz1, xyz2, kernel=0):
     with torch.cuda.device(xyz1.device):
         if kernel:
             check(lib.pn2_query_ball_point_kernel(b, n, m, float(radius), int(nsample), ptr(xyz1), ptr(xyz2), ptr(idx),
-                                                  ptr(cnt), int(config.arith_mode), int(kernel), stream_ptr()),
+                                                  ptr(cnt), config.bq_mode(arith_mode), int(kernel), stream_ptr()),
                   "pn2_query_ball_point_kernel")
         else:
             check(lib.pn2_query_ball_point(b, n, m, float(radius), int(nsample), ptr(xyz1), ptr(xyz2), ptr(idx),
-                                           ptr(cnt), int(config.arith_mode), stream_ptr()), "pn2_query_ball_point")
+                                           ptr(cnt), config.bq_mode(arith_mode), stream_ptr()), "pn2_query_ball_point")
     return idx, cnt
 
 
-def query_ball_point_multi(radius_list, nsample_list, xyz1, xyz2):
+def query_ball_point_multi(radius_list, nsample_list, xyz1, xyz2, arith_mode=None):
     """[(idx, pts_cnt) for each (radius, nsample)] from ONE scan of xyz1 (pn2_query_ball_point_multi): what
     pointnet_sa_module_msg needs (util/pointnet_util.py:245-250 runs query_ball_point once per radius).
     Bit-identical to separate query_ball_point calls; falls back to them when the configuration is unsupported."""
@@ -73,11 +74,11 @@ def query_ball_point_multi(radius_list, nsample_list, xyz1, xyz2):
         with torch.cuda.device(x1.device):
             rc = lib.pn2_query_ball_point_multi(b, n, m, R, ctypes.cast(radii, ctypes.c_void_p), ctypes.cast(nss, ctypes.c_void_p),
                                                 ptr(x1), ptr(x2), ctypes.cast(ip, ctypes.c_void_p),
-                                                ctypes.cast(cp, ctypes.c_void_p), int(config.arith_mode), stream_ptr())
+                                                ctypes.cast(cp, ctypes.c_void_p), config.bq_mode(arith_mode), stream_ptr())
         if rc != PN2_EUNSUP:
             check(rc, "pn2_query_ball_point_multi")
             return list(zip(idxs, cnts))
-    return [query_ball_point(r, k, xyz1, xyz2) for r, k in zip(radius_list, nsample_list)]
+    return [query_ball_point(r, k, xyz1, xyz2, arith_mode=arith_mode) for r, k in zip(radius_list, nsample_list)]
 
 
 class _GroupPoint(torch.autograd.Function):

@@ -22,7 +22,7 @@ USE_BUCKET_FPS = True  # clouds beyond 16384 points: Morton buckets + bounding-b
 FPS_REG_MAX, FPS_BUCKET_MAX = 16384, 131072
 
 
-def _fps_large(npoint, inp, want_xyz):
+def _fps_large(npoint, inp, want_xyz, arith_mode=None):
     import ctypes
     b, n, _ = inp.shape
     out = torch.empty((b, npoint), dtype=torch.int32, device=inp.device)
@@ -32,12 +32,13 @@ def _fps_large(npoint, inp, want_xyz):
     off = (-ws.data_ptr()) % 256
     with torch.cuda.device(inp.device):
         check(lib.pn2_fps_large(b, n, int(npoint), ptr(inp), ctypes.c_void_p(ws.data_ptr() + off), wbytes, ptr(out),
-                                ptr(new_xyz), int(config.arith_mode), stream_ptr()), "pn2_fps_large")
+                                ptr(new_xyz), config.fps_mode(arith_mode), stream_ptr()), "pn2_fps_large")
     return out, new_xyz
 
 
-def farthest_point_sample(npoint, inp):
-    """npoint: int; inp (b,n,3) float32 -> (b,npoint) int32.  Not differentiable."""
+def farthest_point_sample(npoint, inp, arith_mode=None):
+    """npoint: int; inp (b,n,3) float32 -> (b,npoint) int32.  Not differentiable.
+    arith_mode (extension): contraction of the squared-distance expression, config.FPS_ARITH_DEFAULT when None."""
     if npoint <= 0:
         raise ValueError("FarthestPointSample expects positive npoint")  # tf_sampling.cpp:121-123
     require_cuda(inp)
@@ -45,14 +46,14 @@ def farthest_point_sample(npoint, inp):
     inp = inp.detach().contiguous()
     b, n, _ = inp.shape
     if USE_BUCKET_FPS and FPS_REG_MAX < n <= FPS_BUCKET_MAX:
-        return _fps_large(npoint, inp, False)[0]
+        return _fps_large(npoint, inp, False, arith_mode)[0]
     out = torch.empty((b, npoint), dtype=torch.int32, device=inp.device)
     temp = None
     if n > 16384:  # PN2_FPS_MAX_REG_POINTS: the streaming kernel needs the reference's (32,n) scratch
         temp = torch.empty((min(b, 32), n), dtype=torch.float32, device=inp.device)
     with torch.cuda.device(inp.device):
         check(lib.pn2_farthest_point_sample(b, n, int(npoint), ptr(inp), ptr(temp), ptr(out),
-                                            int(config.arith_mode), stream_ptr()), "pn2_farthest_point_sample")
+                                            config.fps_mode(arith_mode), stream_ptr()), "pn2_farthest_point_sample")
     return out
 
 
@@ -91,7 +92,7 @@ def gather_point(inp, idx):
     return _GatherPoint.apply(inp.contiguous(), idx.contiguous())
 
 
-def farthest_point_sample_and_gather(npoint, inp):
+def farthest_point_sample_and_gather(npoint, inp, arith_mode=None):
     """farthest_point_sample + gather_point in one launch (inference; no gradient):
     -> idx (b,npoint) int32, new_xyz (b,npoint,3) == gather_point(inp, idx) bit for bit."""
     if npoint <= 0:
@@ -101,7 +102,7 @@ def farthest_point_sample_and_gather(npoint, inp):
     inp = inp.detach().contiguous()
     b, n, _ = inp.shape
     if USE_BUCKET_FPS and FPS_REG_MAX < n <= FPS_BUCKET_MAX:
-        return _fps_large(npoint, inp, True)
+        return _fps_large(npoint, inp, True, arith_mode)
     out = torch.empty((b, npoint), dtype=torch.int32, device=inp.device)
     new_xyz = torch.empty((b, npoint, 3), dtype=torch.float32, device=inp.device)
     temp = None
@@ -109,7 +110,7 @@ def farthest_point_sample_and_gather(npoint, inp):
         temp = torch.empty((min(b, 32), n), dtype=torch.float32, device=inp.device)
     with torch.cuda.device(inp.device):
         check(lib.pn2_fps_gather(b, n, int(npoint), ptr(inp), ptr(temp), ptr(out), ptr(new_xyz),
-                                 int(config.arith_mode), stream_ptr()), "pn2_fps_gather")
+                                 config.fps_mode(arith_mode), stream_ptr()), "pn2_fps_gather")
     return out, new_xyz
 
 

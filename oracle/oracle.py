@@ -17,7 +17,11 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 _LIB_PATH = os.path.join(_HERE, "libpn2_oracle.so")
 
 ARITH_STRICT, ARITH_FMA, ARITH_FMA_ALT = 0, 1, 2
-DEFAULT_MODE = ARITH_FMA
+# Defaults = what ONE complete build of the reference's kernels produces (oracle/_ref "fast_noslp": contraction on, as
+# under nvcc's --fmad=true default): farthestpointsamplingKernel contracts as mode 2, query_ball_point_gpu as mode 1
+# (read off the ISA, asserted by tests/test_ref_gpu.py).  The product's defaults (config.py) are the same pair.
+DEFAULT_FPS_MODE = ARITH_FMA_ALT
+DEFAULT_BQ_MODE = ARITH_FMA
 
 
 def build(force=False):
@@ -58,7 +62,7 @@ def set_num_threads(t):
     lib().oracle_set_num_threads(int(t))
 
 
-def farthest_point_sample(npoint, inp, mode=DEFAULT_MODE):
+def farthest_point_sample(npoint, inp, mode=DEFAULT_FPS_MODE):
     inp = _f32(inp)
     b, n, _ = inp.shape
     out = np.empty((b, npoint), dtype=np.int32)
@@ -85,7 +89,7 @@ def gather_point_grad(inp, idx, out_g):
     return inp_g
 
 
-def query_ball_point(radius, nsample, xyz1, xyz2, mode=DEFAULT_MODE):
+def query_ball_point(radius, nsample, xyz1, xyz2, mode=DEFAULT_BQ_MODE):
     xyz1, xyz2 = _f32(xyz1), _f32(xyz2)
     b, n, _ = xyz1.shape
     m = xyz2.shape[1]
@@ -223,11 +227,11 @@ def conv_bn_relu(x, layer, dtype=np.float64, relu=True):
     return y
 
 
-def sample_and_group(npoint, radius, nsample, xyz, points, use_xyz=True, mode=DEFAULT_MODE):
+def sample_and_group(npoint, radius, nsample, xyz, points, use_xyz=True, mode=None):
     """util/pointnet_util.py:18-60 (knn=False)."""
-    fidx = farthest_point_sample(npoint, xyz, mode)
+    fidx = farthest_point_sample(npoint, xyz, DEFAULT_FPS_MODE if mode is None else mode)  # mode: ONE value for both ops
     new_xyz = gather_point(xyz, fidx)
-    idx, _ = query_ball_point(radius, nsample, xyz, new_xyz, mode)
+    idx, _ = query_ball_point(radius, nsample, xyz, new_xyz, DEFAULT_BQ_MODE if mode is None else mode)
     grouped_xyz = group_point(xyz, idx) - new_xyz[:, :, None, :]
     if points is not None:
         gp = group_point(points, idx)
@@ -237,7 +241,7 @@ def sample_and_group(npoint, radius, nsample, xyz, points, use_xyz=True, mode=DE
     return new_xyz, new_points, idx, grouped_xyz
 
 
-def sa_module(xyz, points, npoint, radius, nsample, layers, dtype=np.float64, mode=DEFAULT_MODE):
+def sa_module(xyz, points, npoint, radius, nsample, layers, dtype=np.float64, mode=None):
     """pointnet_sa_module, pooling='max', mlp2=None, group_all=False, is_training=False
     (util/pointnet_util.py:98-216)."""
     new_xyz, new_points, idx, _ = sample_and_group(npoint, radius, nsample, xyz, points, True, mode)

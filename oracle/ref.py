@@ -7,8 +7,9 @@ tf_ops/tf_grouping.py:13,31,46).
 
 Three builds:
     "off"        -ffp-contract=off                       == oracle arithmetic mode 0
-    "fast_noslp" -ffp-contract=fast -fno-slp-vectorize   == oracle mode 1  fma(dz,dz,fma(dx,dx,dy*dy))
-                                                            (the LLVM DAG-combine contraction order)
+    "fast_noslp" -ffp-contract=fast -fno-slp-vectorize   == oracle mode 1  fma(dz,dz,fma(dx,dx,dy*dy)) in ball query,
+                                                            mode 2  fma(dz,dz,fma(dy,dy,dx*dx)) in FPS
+                                                            (the LLVM DAG-combine contraction order; THE PRODUCT'S DEFAULTS)
     "fast"       -ffp-contract=fast (hipcc's default)    == oracle mode 5  fma(dy,dy,dx*dx)+dz*dz
                                                             (amdgpu SLP: packed squares, one fused)
 """
@@ -137,3 +138,50 @@ def group_point_grad(points, idx, grad_out, build="off"):
     gp = torch.empty((b, n, c), dtype=torch.float32, device="cuda")
     _chk(lib(build).ref_group_point_grad(b, n, c, m, ns, _p(g), _p(i), _p(gp)), "group_point_grad")
     return gp.cpu().numpy()
+
+
+# ---- the reference's two dependency-free HOST functions (tf_interpolate.cpp:307-330,397-421), lifted at build time by
+#      oracle/lift_interpolate.py and compiled with the reference's host flags: oracle/_ref/libpn2_ref_interp.so.  CPU only.
+_interp = None
+
+
+def interp_available():
+    return os.path.exists(os.path.join(_DIR, "libpn2_ref_interp.so"))
+
+
+def _interp_lib():
+    global _interp
+    if _interp is None:
+        if not interp_available():
+            raise RuntimeError("oracle/_ref/libpn2_ref_interp.so not built: run `make -C oracle _ref` where /root/reference exists")
+        _interp = ctypes.CDLL(os.path.join(_DIR, "libpn2_ref_interp.so"))
+        _interp.threeinterpolate_cpu.restype = None
+        _interp.threeinterpolate_grad_cpu.restype = None
+    return _interp
+
+
+def _np(a, dtype):
+    return np.ascontiguousarray(a, dtype=dtype)
+
+
+def three_interpolate(points, idx, weight):
+    """threeinterpolate_cpu(b, m, c, n, points, idx, weight, out): points (b,m,c), idx / weight (b,n,3) -> (b,n,c)"""
+    points, idx, weight = _np(points, np.float32), _np(idx, np.int32), _np(weight, np.float32)
+    b, m, c = points.shape
+    n = idx.shape[1]
+    out = np.empty((b, n, c), np.float32)
+    vp = lambda a: a.ctypes.data_as(ctypes.c_void_p)  # noqa: E731
+    _interp_lib().threeinterpolate_cpu(b, m, c, n, vp(points), vp(idx), vp(weight), vp(out))
+    return out
+
+
+def three_interpolate_grad(points, idx, weight, grad_out):
+    """ThreeInterpolateGradOp: memset(grad_points, 0) (tf_interpolate.cpp:477) + threeinterpolate_grad_cpu(b, n, c, m, ...)"""
+    points, idx, weight = _np(points, np.float32), _np(idx, np.int32), _np(weight, np.float32)
+    grad_out = _np(grad_out, np.float32)
+    b, m, c = points.shape
+    n = idx.shape[1]
+    gp = np.zeros((b, m, c), np.float32)
+    vp = lambda a: a.ctypes.data_as(ctypes.c_void_p)  # noqa: E731
+    _interp_lib().threeinterpolate_grad_cpu(b, n, c, m, vp(grad_out), vp(idx), vp(weight), vp(gp))
+    return gp

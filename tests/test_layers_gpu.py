@@ -353,6 +353,30 @@ def test_get_model_head_shapes(pn2, cuda):
     assert torch.isfinite(logits).all()
 
 
+def test_model_head_on_oracle_features_within_1e5(pn2, oracle, cuda):
+    """the N1 head alone (fc1 conv1d(128)+BN+ReLU, dropout off, fc2 conv1d(9); model.py:131-146) on the
+    ORACLE's SA/FP features -- no compounding with the stack's own 4e-7 hidden in the tolerance -- within north_star's 1e-5
+    of (1 + |ref|) against the float64 restatement."""
+    tfu = pn2.util.tf_util
+    hp = dict(pn2.model.SEMANTIC_HYPERPARAMS)
+    hp.update(l1_npoint=128, l2_npoint=64, l3_npoint=32, l4_npoint=16)
+    store = tfu.set_default_store(tfu.VariableStore(device=cuda, seed=21))
+    rs = np.random.RandomState(4)
+    pc = np.concatenate([s_scene(5, 2, 1024), rs.random_sample((2, 1024, 3)).astype(np.float32)], 2)
+    pn2.model.get_model(T(pc, cuda), False, 9, hp)  # creates the variables
+    randomize_bn(store, 22)
+    feats = _oracle_stack(oracle, store, pc, hp, pn2).astype(np.float32)  # what the reference's stack hands to its head
+    (fc1,) = layer_dicts(store, None, ["fc1"])
+    (fc2,) = layer_dicts(store, None, ["fc2"], bn=False)
+    ref = oracle.model_head(feats.astype(np.float64), fc1, fc2)
+    import torch
+    with torch.no_grad():
+        logits = pn2.model.get_head(T(feats, cuda), False, 9)
+    err = np.abs(logits.cpu().numpy().astype(np.float64) - ref) / (1.0 + np.abs(ref))
+    print("head on oracle features: max err %.2e of (1+|ref|)" % err.max())
+    assert err.max() <= 1e-5, err.max()
+
+
 def test_get_model_logits_and_loss_vs_oracle(pn2, oracle, cuda):
     """the head (fc1 conv1d+BN+ReLU, dropout off, fc2) on top of the SA/FP stack and the weighted
     sparse cross-entropy (SUM_BY_NONZERO_WEIGHTS) against their numpy restatements."""

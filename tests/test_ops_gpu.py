@@ -18,10 +18,19 @@ def T(a, dev):
 
 
 @pytest.fixture(autouse=True)
-def _reset_mode(pn2):
-    pn2.config.arith_mode = pn2.config.ARITH_FMA
+def _arith_scope(pn2):
+    """set_mode(m): both index kernels in arithmetic mode m for the rest of THIS test (a thread-local `config.arith` scope,
+    closed when the test ends) -- the product has no process-global mode switch.  set_mode(None) = the defaults."""
+    import contextlib
+    global set_mode
+    stack = contextlib.ExitStack()
+
+    def set_mode(mode=None, fps=None, bq=None):
+        stack.close()
+        if mode is not None or fps is not None or bq is not None:
+            stack.enter_context(pn2.config.arith(mode, fps=fps, bq=bq))
     yield
-    pn2.config.arith_mode = pn2.config.ARITH_FMA
+    stack.close()
 
 
 # ------------------------------------------------------------------ FPS -------------------
@@ -31,7 +40,7 @@ def test_fps_grid_bit_exact_all_modes(pn2, oracle, cuda, n, m):
     x = s_grid(n, 3, n, 64 if n < 5000 else 1024)  # coarse grid: exact arithmetic + many ties
     ref = oracle.farthest_point_sample(m, x, 0)
     for mode in (0, 1, 2):
-        pn2.config.arith_mode = mode
+        set_mode(mode)
         got = pn2.farthest_point_sample(m, T(x, cuda)).cpu().numpy()
         assert got.dtype == np.int32 and got.shape == (3, m)
         assert np.array_equal(got, ref), "mode %d first diff at %s" % (mode, np.argwhere(got != ref)[:3])
@@ -41,7 +50,7 @@ def test_fps_grid_bit_exact_all_modes(pn2, oracle, cuda, n, m):
 @pytest.mark.parametrize("gen", ["randn", "scene"])
 def test_fps_float_inputs_bit_exact_per_mode(pn2, oracle, cuda, mode, gen):
     x = s_randn(11, 4, 2048) if gen == "randn" else s_scene(12, 4, 2048)
-    pn2.config.arith_mode = mode
+    set_mode(mode)
     got = pn2.farthest_point_sample(512, T(x, cuda)).cpu().numpy()
     assert np.array_equal(got, oracle.farthest_point_sample(512, x, mode))
 
@@ -92,7 +101,7 @@ def test_fps_lazy_multipick_kernel_paths(pn2, oracle, cuda, case):
         x, m = s_scene(35, 4, 8192), 2
     ref = {}
     for mode in (0, 1, 2):
-        pn2.config.arith_mode = mode
+        set_mode(mode)
         ref = oracle.farthest_point_sample(m, x, mode)
         idx, nx = pn2.tf_ops.tf_sampling.farthest_point_sample_and_gather(m, T(x, cuda))
         got = idx.cpu().numpy()
@@ -134,7 +143,7 @@ def test_golden_fixtures_on_gpu(pn2, cuda):
     rs = np.random.RandomState(7)
     xyz = rs.random_sample((2, 1024, 3)).astype(np.float32)
     for mode in (0, 1, 2):
-        pn2.config.arith_mode = mode
+        set_mode(mode)
         f = pn2.farthest_point_sample(256, T(xyz, cuda))
         assert np.array_equal(f.cpu().numpy(), g["cfg0_fps_m%d" % mode])
         idx, cnt = pn2.query_ball_point(0.2, 16, T(xyz, cuda), pn2.gather_point(T(xyz, cuda), f))
@@ -177,7 +186,7 @@ def test_ball_query_grid_bit_exact_all_modes(pn2, oracle, cuda, n, m, ns, r):
     q[:, ::3] += np.float32(1.0 / 128)  # off-grid-by-half queries too (still exact arithmetic)
     ri, rc = oracle.query_ball_point(r, ns, x, q, 0)
     for mode in (0, 1, 2):
-        pn2.config.arith_mode = mode
+        set_mode(mode)
         gi, gc = pn2.query_ball_point(r, ns, T(x, cuda), T(q, cuda))
         assert np.array_equal(gc.cpu().numpy(), rc)
         assert np.array_equal(gi.cpu().numpy(), ri)
@@ -185,7 +194,7 @@ def test_ball_query_grid_bit_exact_all_modes(pn2, oracle, cuda, n, m, ns, r):
 
 @pytest.mark.parametrize("mode", [0, 1, 2])
 def test_ball_query_float_inputs(pn2, oracle, cuda, mode):
-    pn2.config.arith_mode = mode
+    set_mode(mode)
     for x, r in ((s_randn(21, 3, 3000), 0.5), (s_scene(22, 3, 3000), 0.5), (s_scene(23, 3, 3000), 2.0)):
         f = oracle.farthest_point_sample(200, x, mode)
         q = oracle.gather_point(x, f)
@@ -215,7 +224,7 @@ def test_ball_query_radius_boundary_is_exact(pn2, oracle, cuda):
         q = np.zeros((1, 1, 3), np.float32)
         pts[0, 20] = 0  # the query itself
         for mode in (0, 1, 2):
-            pn2.config.arith_mode = mode
+            set_mode(mode)
             gi, gc = pn2.query_ball_point(float(r32), 16, T(pts, cuda), T(q, cuda))
             ri, rc = oracle.query_ball_point(float(r32), 16, pts, q, mode)
             assert np.array_equal(gc.cpu().numpy(), rc) and np.array_equal(gi.cpu().numpy(), ri), (r, mode)
@@ -586,7 +595,7 @@ def test_interpolate_label_large(pn2, oracle, cuda):
 @pytest.mark.parametrize("mode", [0, 1, 2])
 def test_query_ball_point_multi_equals_separate_calls(pn2, oracle, cuda, case, mode):
     """One scan for several (radius, nsample) pairs == separate query_ball_point calls == the oracle, bit for bit."""
-    pn2.config.arith_mode = mode
+    set_mode(mode)
     try:
         if case == "scene":
             xyz, m, radii, ks = s_scene(11, 3, 4096), 512, [0.25, 0.5, 1.0], [16, 32, 64]
@@ -604,7 +613,7 @@ def test_query_ball_point_multi_equals_separate_calls(pn2, oracle, cuda, case, m
             assert np.array_equal(idx.cpu().numpy(), oi) and np.array_equal(cnt.cpu().numpy(), oc)
             assert np.array_equal(si.cpu().numpy(), oi) and np.array_equal(sc.cpu().numpy(), oc)
     finally:
-        pn2.config.arith_mode = 1
+        set_mode(None)
 
 
 def test_query_ball_point_multi_falls_back_when_lists_do_not_fit(pn2, oracle, cuda):
@@ -646,13 +655,13 @@ def test_query_ball_point_grid_kernel_bit_exact(pn2, oracle, cuda, case, mode):
         xyz = s_scene(29, 2, 2048); xyz[..., 2] = 0; q = xyz[:, :128].copy()
     else:  # k64
         xyz = s_scene(30, 2, 8192); q = xyz[:, :512].copy(); K, r = 64, 1.0
-    pn2.config.arith_mode = mode
+    set_mode(mode)
     try:
         oi, oc = oracle.query_ball_point(r, K, xyz, q, mode)
         gi, gc = pn2.query_ball_point(r, K, T(xyz, cuda), T(q, cuda), kernel=3)  # LDS grid
         si, sc = pn2.query_ball_point(r, K, T(xyz, cuda), T(q, cuda), kernel=2)  # lane-per-query scan
     finally:
-        pn2.config.arith_mode = 1
+        set_mode(None)
     assert np.array_equal(gc.cpu().numpy(), oc) and np.array_equal(gi.cpu().numpy(), oi)
     assert np.array_equal(sc.cpu().numpy(), oc) and np.array_equal(si.cpu().numpy(), oi)
 
@@ -798,7 +807,7 @@ def test_fps_large_bucket_kernel_bit_exact(pn2, oracle, cuda, case, mode):
     else:  # line: degenerate bounding box on two axes
         xyz = np.zeros((1, 18000, 3), np.float32); xyz[..., 0] = rs.rand(1, 18000); m = 400
     xyz = np.ascontiguousarray(xyz, np.float32)
-    pn2.config.arith_mode = mode
+    set_mode(mode)
     try:
         ref = oracle.farthest_point_sample(m, xyz, mode)
         idx, new_xyz = sm.farthest_point_sample_and_gather(m, T(xyz, cuda))
@@ -809,7 +818,7 @@ def test_fps_large_bucket_kernel_bit_exact(pn2, oracle, cuda, case, mode):
         finally:
             sm.USE_BUCKET_FPS = True
     finally:
-        pn2.config.arith_mode = 1
+        set_mode(None)
     assert np.array_equal(idx.cpu().numpy(), ref)
     assert np.array_equal(only_idx.cpu().numpy(), ref)
     assert np.array_equal(streamed.cpu().numpy(), ref)

@@ -220,3 +220,24 @@ def test_max_pool_rows_oracle_matches_torch_amax(oracle):
     (tm * torch.tensor(dzp)).sum().backward()
     g = oracle.max_pool_rows_grad(z.reshape(48, 5), 8, dzp)
     assert np.allclose(g.reshape(6, 8, 5), tz.grad.numpy(), rtol=1e-12, atol=1e-12)
+
+
+def test_three_interpolate_restatement_equals_the_lifted_reference_functions(oracle):
+    """oracle/_ref/libpn2_ref_interp.so holds the reference's OWN threeinterpolate_cpu /
+    threeinterpolate_grad_cpu (tf_interpolate.cpp:307-330,397-421, cut out by oracle/lift_interpolate.py at build time and
+    compiled with the reference's host flags).  The C restatement must equal them bit for bit -- forward AND gradient (the
+    gradient is a sequential += loop: same order, same bits) -- at the FP shapes of configs[1] scaled to CPU seconds and on
+    the reference's own test shape (test_tf_ops.py:80-94: (1,8,16) points -> (1,128,16))."""
+    from oracle import ref as R
+    if not R.interp_available():
+        pytest.skip("oracle/_ref/libpn2_ref_interp.so not built (needs /root/reference: `make -C oracle _ref`)")
+    rs = np.random.RandomState(5)
+    for b, m, c, n in [(1, 8, 16, 128), (2, 16, 512, 64), (3, 64, 256, 256), (2, 256, 256, 1024), (2, 1024, 128, 8192), (1, 5, 3, 7)]:
+        pts = rs.randn(b, m, c).astype(np.float32)
+        idx = rs.randint(0, m, (b, n, 3)).astype(np.int32)
+        idx[:, ::7, 1] = idx[:, ::7, 0]  # duplicated neighbours (three_nn of duplicated points)
+        d = rs.rand(b, n, 3).astype(np.float32) + 1e-3
+        w = ((1.0 / d) / (1.0 / d).sum(2, keepdims=True)).astype(np.float32)  # pointnet_util.py:300-303
+        go = rs.randn(b, n, c).astype(np.float32)
+        assert np.array_equal(oracle.three_interpolate(pts, idx, w), R.three_interpolate(pts, idx, w))
+        assert np.array_equal(oracle.three_interpolate_grad(pts, idx, w, go), R.three_interpolate_grad(pts, idx, w, go))

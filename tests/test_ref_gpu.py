@@ -37,10 +37,19 @@ def ref(cuda):
 
 
 @pytest.fixture(autouse=True)
-def _reset_mode(pn2):
-    pn2.config.arith_mode = pn2.config.ARITH_FMA
+def _arith_scope(pn2):
+    """set_mode(m): both index kernels in arithmetic mode m for the rest of THIS test (a thread-local `config.arith` scope,
+    closed when the test ends) -- the product has no process-global mode switch.  set_mode(None) = the defaults."""
+    import contextlib
+    global set_mode
+    stack = contextlib.ExitStack()
+
+    def set_mode(mode=None, fps=None, bq=None):
+        stack.close()
+        if mode is not None or fps is not None or bq is not None:
+            stack.enter_context(pn2.config.arith(mode, fps=fps, bq=bq))
     yield
-    pn2.config.arith_mode = pn2.config.ARITH_FMA
+    stack.close()
 
 
 def T(a, dev):
@@ -54,12 +63,12 @@ def _gen(name, seed, b, n):
 
 
 def _hip_fps(pn2, cuda, m, x, mode):
-    pn2.config.arith_mode = mode
+    set_mode(mode)
     return pn2.farthest_point_sample(m, T(x, cuda)).cpu().numpy()
 
 
 def _hip_bq(pn2, cuda, r, k, x1, x2, mode):
-    pn2.config.arith_mode = mode
+    set_mode(mode)
     idx, cnt = pn2.query_ball_point(r, k, T(x1, cuda), T(x2, cuda))
     return idx.cpu().numpy(), cnt.cpu().numpy()
 
@@ -138,10 +147,42 @@ def test_config1_every_sa_level_all_scenes(pn2, oracle, ref, cuda, gen):
         assert np.array_equal(new_xyz, oracle.gather_point(x, f))
         _three_way_bq(pn2, oracle, ref, cuda, radius * scale, k, x, new_xyz, gen == "grid")
         # the fused entry point the layer API uses (FPS + gather in one launch) against the reference pair
-        pn2.config.arith_mode = 0
+        set_mode(0)
         hf, hxyz = pn2.tf_ops.tf_sampling.farthest_point_sample_and_gather(npoint, T(x, cuda))
         assert np.array_equal(hf.cpu().numpy(), f) and np.array_equal(hxyz.cpu().numpy(), new_xyz)
         x = new_xyz
+
+
+@pytest.mark.parametrize("gen", ["scene", "randn"])
+def test_default_configuration_is_the_contracted_reference_build(pn2, ref, cuda, gen):
+    """the configuration the product ships, bench.py times and smoke() checks -- every op on its DEFAULT
+    arithmetic mode -- equals ONE complete build of the reference's own kernels: oracle/_ref "fast_noslp" (contraction on, as
+    under nvcc's --fmad=true; FPS contracts as mode 2, ball query as mode 1).  The PRODUCT's geometry chain
+    (model.compute_geometry: FPS + gather + ball query of the four SA levels of semantic.json, each level fed by the
+    previous level's HIP output, all 16 scenes) against the same chain run on that build, bit for bit."""
+    assert (pn2.config.FPS_ARITH_DEFAULT, pn2.config.BQ_ARITH_DEFAULT) == (FPS_MODE["fast_noslp"], BQ_MODE["fast_noslp"])
+    x = _gen(gen, 3, 16, 8192)
+    hp = dict(pn2.model.SEMANTIC_HYPERPARAMS)
+    set_mode(None)  # the defaults, nothing scoped
+    geo = pn2.model.compute_geometry(T(x, cuda), hp)
+    cur = x
+    for li, (npoint, radius, k) in enumerate(SA_LEVELS):
+        f = ref.farthest_point_sample(npoint, cur, "fast_noslp")
+        new_xyz = ref.gather_point(cur, f, "fast_noslp")
+        ri, rc = ref.query_ball_point(radius, k, cur, new_xyz, "fast_noslp")
+        assert np.array_equal(geo["xyzs"][li + 1].cpu().numpy(), new_xyz), "level %d: sampled coordinates" % (li + 1)
+        assert np.array_equal(geo["idxs"][li].cpu().numpy(), ri), "level %d: ball query indices" % (li + 1)
+        cur = new_xyz
+    # and the contraction-off build is what `arith(0)` selects for the same chain
+    with pn2.config.arith(0):
+        geo0 = pn2.model.compute_geometry(T(x, cuda), hp)
+    cur = x
+    for li, (npoint, radius, k) in enumerate(SA_LEVELS):
+        f = ref.farthest_point_sample(npoint, cur, "off")
+        new_xyz = ref.gather_point(cur, f, "off")
+        ri, _ = ref.query_ball_point(radius, k, cur, new_xyz, "off")
+        assert np.array_equal(geo0["xyzs"][li + 1].cpu().numpy(), new_xyz) and np.array_equal(geo0["idxs"][li].cpu().numpy(), ri)
+        cur = new_xyz
 
 
 def test_fps_tie_heavy_grids(pn2, oracle, ref, cuda):
@@ -293,3 +334,36 @@ def test_reference_kernels_vs_hip_timing_report(pn2, ref, cuda):
     with open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out", "ref_vs_hip_timing.json"), "w") as f:
         json.dump(rep, f, indent=1)
     print(json.dumps(rep["rows"]))
+
+
+# ---------------------------------------------------------------- A8 / A8g: three_interpolate against the lifted host functions
+@pytest.mark.parametrize("b,m,c,n", [(1, 8, 16, 128), (16, 16, 512, 64), (16, 64, 256, 256), (16, 256, 256, 1024),
+                                     (16, 1024, 128, 8192), (2, 60, 131, 333), (2, 5, 3, 7)])
+def test_three_interpolate_equals_the_reference_host_functions(pn2, cuda, b, m, c, n):
+    """The HIP three_interpolate == the reference's own threeinterpolate_cpu (oracle/_ref/libpn2_ref_interp.so: lifted from
+    tf_interpolate.cpp:307-330 at build time) BIT FOR BIT at every FP level of configs[1] (B=16: m -> n = 16->64, 64->256,
+    256->1024, 1024->8192 with the channel widths of model.py:90-129) and the reference's test shape; the gradient equals
+    threeinterpolate_grad_cpu (:397-421) exactly on integer-valued operands (every product and sum exact, so the
+    order of the device atomics / gathers cannot show) and to fp32 summation order otherwise."""
+    import torch
+    from oracle import ref as R
+    if not R.interp_available():
+        pytest.skip("oracle/_ref/libpn2_ref_interp.so missing: `make -C oracle _ref` (needs /root/reference)")
+    rs = np.random.RandomState(b * 1000 + c)
+    pts = rs.randn(b, m, c).astype(np.float32)
+    idx = rs.randint(0, m, (b, n, 3)).astype(np.int32)
+    d = rs.rand(b, n, 3).astype(np.float32) + 1e-3
+    w = ((1.0 / d) / (1.0 / d).sum(2, keepdims=True)).astype(np.float32)
+    pt = T(pts, cuda).requires_grad_(True)
+    out = pn2.three_interpolate(pt, T(idx, cuda), T(w, cuda))
+    assert np.array_equal(out.detach().cpu().numpy(), R.three_interpolate(pts, idx, w))
+    go = rs.randn(b, n, c).astype(np.float32)
+    out.backward(T(go, cuda))
+    rg = R.three_interpolate_grad(pts, idx, w, go)
+    assert np.allclose(pt.grad.cpu().numpy(), rg, rtol=1e-4, atol=1e-5 * max(1.0, float(np.abs(rg).max())))
+    # exact operands: weights in {0.25, 0.5}, integer gradients -> bit-exact gradient
+    wi = rs.choice([0.25, 0.5], (b, n, 3)).astype(np.float32)
+    gi = rs.randint(-8, 9, (b, n, c)).astype(np.float32)
+    pt2 = T(pts, cuda).requires_grad_(True)
+    pn2.three_interpolate(pt2, T(idx, cuda), T(wi, cuda)).backward(T(gi, cuda))
+    assert np.array_equal(pt2.grad.cpu().numpy(), R.three_interpolate_grad(pts, idx, wi, gi))
