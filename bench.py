@@ -248,27 +248,37 @@ def other_configs(pn2, dev, hp, steps):
                              "ms_per_step": round(t, 4), "points_per_s": round(B * N / (t * 1e-3), 1), "steps": steps,
                              "launch": "one hipGraph replay per step, one batch in flight"}
         del cap
-        # configs[4]: one large scene, N=65536 -> npoint 4096, K=64, C=128 bf16 features, fused bf16 grouped MLP
+        # configs[4]: large scenes, N=65536 -> npoint 4096, K=64, C=128 bf16 features, fused bf16 grouped MLP; B=1 (eager and
+        # as a hipGraph replay) and B=16 ("B=1 (and 16 if memory allows)")
         N4, M4, K4, C4 = 65536, 4096, 64, 128
-        xyz4 = torch.from_numpy(s_scene(5001, 1, N4)[:, :, :3].copy()).to(dev)
-        pts4 = torch.randn(1, N4, C4, device=dev).to(torch.bfloat16)
         tfu.set_default_store(tfu.VariableStore(device=dev, seed=2))
+        res4 = {}
+        for B4 in (1, 16):
+            xyz4 = torch.from_numpy(s_scene(5001, B4, N4)[:, :, :3].copy()).to(dev)
+            pts4 = torch.randn(B4, N4, C4, device=dev).to(torch.bfloat16)
 
-        def sa4(x):
-            _, nx = pn2.tf_ops.tf_sampling.farthest_point_sample_and_gather(M4, x)
-            idx, _ = pn2.query_ball_point(0.5, K4, x, nx)
-            with tfu.variable_scope("sa"):
-                return pu.sa_features_inference(x, nx, pts4, idx, [128, 128])
-        with torch.no_grad():
-            sa4(xyz4)
-            n4 = max(2, min(steps, 5))
-            t = time_call(lambda: sa4(xyz4), n4, warmup=1)
-            t_fps = time_call(lambda: pn2.tf_ops.tf_sampling.farthest_point_sample_and_gather(M4, xyz4), n4, warmup=1)
+            def sa4(x):
+                _, nx = pn2.tf_ops.tf_sampling.farthest_point_sample_and_gather(M4, x)
+                idx, _ = pn2.query_ball_point(0.5, K4, x, nx)
+                with tfu.variable_scope("sa"):
+                    return pu.sa_features_inference(x, nx, pts4, idx, [128, 128])
+            with torch.no_grad():
+                sa4(xyz4)
+                n4 = max(2, min(steps, 5))
+                t_eager = time_call(lambda: sa4(xyz4), n4, warmup=1)
+                t_fps = time_call(lambda: pn2.tf_ops.tf_sampling.farthest_point_sample_and_gather(M4, xyz4), n4, warmup=1)
+            cap4 = pn2.runtime.CapturedForward(sa4, xyz4)
+            t_graph = time_call(cap4.replay, n4, warmup=1)
+            res4[B4] = (t_eager, t_graph, t_fps, n4)
+            del cap4, xyz4, pts4
+        t_eager, t_graph, t_fps, n4 = res4[1]
         out["configs[4]"] = {"workload": "large-scene SA layer: B=1, N=65536, npoint=4096, K=64, C=128 bf16 features, "
-                                         "FPS + ball query + fused bf16 grouped MLP [128,128] + max",
-                             "ms_per_step": round(t, 4), "points_per_s": round(N4 / (t * 1e-3), 1), "steps": n4,
-                             "fps_ms": round(t_fps, 4), "launch": "eager"}
-        del xyz4, pts4
+                                         "FPS (lazy multi-pick over Hilbert-sorted buckets) + ball query + fused bf16 grouped MLP [128,128] + max",
+                             "ms_per_step": round(t_graph, 4), "points_per_s": round(N4 / (t_graph * 1e-3), 1), "steps": n4,
+                             "fps_ms": round(t_fps, 4), "launch": "one hipGraph replay per step", "eager_ms_per_step": round(t_eager, 4),
+                             "B16": {"ms_per_step": round(res4[16][1], 4), "points_per_s": round(16 * N4 / (res4[16][1] * 1e-3), 1),
+                                     "fps_ms": round(res4[16][2], 4), "eager_ms_per_step": round(res4[16][0], 4),
+                                     "launch": "one hipGraph replay per step, 16 scenes per step"}}
     except Exception as ex:  # keep the headline line alive
         out["error"] = repr(ex)
     finally:

@@ -11,7 +11,8 @@ import os
 import torch  # noqa: F401  (must precede CDLL: maps torch's libamdhip64.so.7)
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libpn2_hip.so")
+# PN2_HIP_LIBRARY: load another build of the same ABI instead (the tuning build of the A/B scripts under tools/)
+LIB_PATH = os.environ.get("PN2_HIP_LIBRARY") or os.path.join(_HERE, "libpn2_hip.so")
 
 c_int, c_float, c_void_p = ctypes.c_int, ctypes.c_float, ctypes.c_void_p
 
@@ -106,7 +107,7 @@ def _load():
     with open(os.path.join(_HERE, ".build.lock"), "w") as lock:
         fcntl.flock(lock, fcntl.LOCK_EX)
         try:
-            if _build._stale():
+            if not os.environ.get("PN2_HIP_LIBRARY") and _build._stale():
                 _build.build()
         finally:
             fcntl.flock(lock, fcntl.LOCK_UN)

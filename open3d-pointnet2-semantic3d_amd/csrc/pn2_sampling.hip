@@ -17,9 +17,13 @@
 //     key (dist bits << 32 | ~((k&511)<<22 | k>>9)).
 // The kernel is latency-bound (m-1 dependent rounds), not HBM-bound: its HBM
 // traffic is b*n*12 + b*m*4 bytes in total.
-#include "pn2_common.h"
+#include "pn2_fps_common.h"
 
 namespace {
+
+using pn2fps::kLazyCap;
+using pn2fps::wave_imax_from;
+using pn2fps::wave_umax_all;
 
 constexpr int kFpsSlotsMax = 16;  // waves per workgroup <= 16
 
@@ -44,21 +48,6 @@ __device__ __forceinline__ int wave_imax(int v) {
         "v_max_i32_dpp %0, %0, %0 row_bcast:15 row_mask:0xa bank_mask:0xf\n s_nop 1\n"
         "v_max_i32_dpp %0, %0, %0 row_bcast:31 row_mask:0xc bank_mask:0xf\n s_nop 1\n"
         : "+v"(v));
-    return __builtin_amdgcn_readlane(v, 63);
-}
-// same, reading the source register in place (no copy) and without the trailing wait states (the consumer is a plain
-// VALU read): the per-pick chain of the lazy kernel's phase B
-__device__ __forceinline__ int wave_imax_from(int src) {
-    int v;
-    asm volatile(
-        "s_nop 1\n"
-        "v_max_i32_dpp %0, %1, %1 row_shr:1 row_mask:0xf bank_mask:0xf\n s_nop 1\n"
-        "v_max_i32_dpp %0, %0, %0 row_shr:2 row_mask:0xf bank_mask:0xf\n s_nop 1\n"
-        "v_max_i32_dpp %0, %0, %0 row_shr:4 row_mask:0xf bank_mask:0xf\n s_nop 1\n"
-        "v_max_i32_dpp %0, %0, %0 row_shr:8 row_mask:0xf bank_mask:0xf\n s_nop 1\n"
-        "v_max_i32_dpp %0, %0, %0 row_bcast:15 row_mask:0xa bank_mask:0xf\n s_nop 1\n"
-        "v_max_i32_dpp %0, %0, %0 row_bcast:31 row_mask:0xc bank_mask:0xf\n"
-        : "=&v"(v) : "v"(src));
     return __builtin_amdgcn_readlane(v, 63);
 }
 // max over lanes 0..15 (row 0), result from lane 15
@@ -319,14 +308,7 @@ __device__ __forceinline__ unsigned fps_hilbert4(unsigned x0, unsigned x1, unsig
 }
 constexpr int kFpsCells = 4096;  // 16 x 16 x 16 cells, Hilbert-ordered
 PN2_TUNABLE(long long*, g_fps_stats, nullptr)  // tuning builds: device buffer of 16 counters written by block 0 (tools/fps_ab.py)
-constexpr int kLazyCap = 64;     // candidates per phase = lanes of the picking wave
 constexpr int kLazyHead = 2176;  // bytes in front of the cloud copy (ctrl, wcand, cand, pend, bbw, wsum)
-
-__device__ __forceinline__ unsigned wave_umax_all(unsigned v) {
-#pragma unroll
-    for (int o = 32; o >= 1; o >>= 1) { const unsigned t = (unsigned)__shfl_xor((int)v, o); v = t > v ? t : v; }
-    return v;
-}
 
 inline size_t fps_lazy_bytes(int n, int m) {
     size_t r = (size_t)kFpsCells * 4;
@@ -586,47 +568,16 @@ fps_lazy_kernel(int n, int m, const float* __restrict__ xyz_all, int* __restrict
             const int limit = use_list ? tau_hi : (int)0x80000000;
             int maxp = use_list ? kLazyCap : 1;
             if (maxp > m - jdone) maxp = m - jdone;
-            // Per pick: wave max of td (6 fused DPP steps), ballot of the lanes holding it (one, unless td ties: then the
-            // largest low word = lowest tie key decides), the winner's coordinates by v_readlane, every candidate's td
-            // lowered by its distance to it.  The picks are parked in lane `npick` of four registers (v_writelane) and
-            // stored after the loop: no LDS traffic and no exec juggling on the chain.
-            int npick = 0, g_first = -1, d_last = 0;
-            int pk_k = 0;
-            float pk_x = 0.f, pk_y = 0.f, pk_z = 0.f;
+            int pk_k, g_first, d_last;
+            float pk_x, pk_y, pk_z;
             const int lim = limit < 0 ? 0 : limit;  // valid td are >= 0; lanes without a candidate are negative
-            while (npick < maxp) {
-                const int bh = wave_imax_from(chi);
-                if (bh < lim) break;
-                unsigned long long bal = __builtin_amdgcn_ballot_w64(chi == bh);
-                if (__builtin_expect(__popcll(bal) != 1, 0)) {
-                    const unsigned lm = wave_umax_all(chi == bh ? clo : 0u);
-                    bal = __builtin_amdgcn_ballot_w64(chi == bh && clo == lm);
-                }
-                const int L = __builtin_ctzll(bal);
-                const float x1 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(cq.x), L));
-                const float y1 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(cq.y), L));
-                const float z1 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(cq.z), L));
-                const int kk = __builtin_amdgcn_readlane(ck, L);
-                // (gfx9 constant bus: one SGPR per instruction, so the lane select travels in m0)
-                asm volatile("s_mov_b32 m0, %8\n v_writelane_b32 %0, %4, m0\n v_writelane_b32 %1, %5, m0\n v_writelane_b32 %2, %6, m0\n v_writelane_b32 %3, %7, m0"
-                             : "+v"(pk_k), "+v"(pk_x), "+v"(pk_y), "+v"(pk_z) : "s"(kk), "s"(x1), "s"(y1), "s"(z1), "s"(npick));  // m0 is reserved: the compiler only ever sets it right before a use
-                const float d = pn2_sqdist<MODE>(cq.x - x1, cq.y - y1, cq.z - z1);
-                const int di = __float_as_int(d);
-                chi = di < chi ? di : chi;  // invalid lanes stay negative
-                g_first = bh > g_first ? bh : g_first;  // td of the picks never increases: the maximum is the first one
-                d_last = bh;
-                ++npick;
-            }
+            const int npick = pn2fps::pick_phase<MODE>(chi, clo, cq.x, cq.y, cq.z, lim, maxp, pk_k, pk_x, pk_y, pk_z, g_first, d_last);
             if (lane < npick) {
                 spick[jdone + lane] = pk_k;
                 pend[lane] = make_float4(pk_x, pk_y, pk_z, 0.f);
             }
             int j = jdone + npick;
-            // eps follows the list length: the result never depends on it, only the number of phases does
-            if (cnt == 0) eps = fminf(0.5f, eps * 2.0f);
-            else if (cnt > kLazyCap) eps *= 0.5f;
-            else if (cnt < 12) eps = fminf(0.5f, eps * 1.3f);
-            else if (cnt > 42) eps *= 0.8f;
+            eps = pn2fps::adapt_eps(eps, cnt);
             if (npick == 0) j = m;  // unreachable (a non-empty list always yields a pick); never spin
             if (lane == 0) {
                 ctrl[ph ^ 1] = 0;
@@ -918,11 +869,13 @@ extern "C" int pn2_debug_set_grouping(int what, int value);
 extern "C" int pn2_debug_set_linear(int what, int value);
 extern "C" int pn2_debug_set_bn(int what, int value);
 extern "C" int pn2_debug_set_fused(int what, int value);
+extern "C" int pn2_debug_set_fps_large(int what, int value);
 extern "C" int pn2_debug_set_fps_stats(long long* dev_ptr) { g_fps_stats = dev_ptr; return 0; }
 extern "C" int pn2_debug_set(int what, int value) {
     if (what == 0) { g_fps_variant = value; return 0; }
     if (what == 5 || what == 8 || what == 9) return pn2_debug_set_linear(what, value);
     if (what == 10) return pn2_debug_set_bn(what, value);
+    if (what == 11) return pn2_debug_set_fps_large(what, value);
     if (what == 6 || what == 7) return pn2_debug_set_fused(what, value);
     return pn2_debug_set_grouping(what, value);
 }
