@@ -445,6 +445,15 @@ int pn2_voxel_downsample(int n, const double *points, const double *colors, cons
                          double *out_points, double *out_colors, int *out_labels, int *out_count, int *status,
                          void *workspace, size_t workspace_bytes, void *stream);
 
+/* Pooling over the K neighbours of a group -- the `pooling=` variants of pointnet_sa_module, util/pointnet_util.py:165-191
+ * (tf.reduce_max / reduce_mean / the exp(-5 |grouped_xyz|) weighted average / concat [avg, max]).  mode: 0 max, 1 avg,
+ * 2 weighted_avg, 3 max_and_avg.  x (rows, k, c) float32, gxyz (rows, k, 3) (mode 2 only, else NULL) ->
+ * out (rows, c), or (rows, 2c) = [avg | max] for mode 3.  The gradient is taken w.r.t. x only (grouped_xyz comes from
+ * non-differentiable index ops); a maximum shared by several neighbours splits its gradient evenly (tf.reduce_max). */
+int pn2_group_pool(long long rows, int k, int c, int mode, const float *x, const float *gxyz, float *out, void *stream);
+int pn2_group_pool_grad(long long rows, int k, int c, int mode, const float *x, const float *gxyz, const float *dout,
+                        float *dx, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

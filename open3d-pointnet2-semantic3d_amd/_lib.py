@@ -87,6 +87,8 @@ SIGNATURES = {
                                 c_void_p, c_void_p, c_void_p],
     "pn2_scene_sample": [c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, ctypes.c_double,
                          ctypes.c_double, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p],
+    "pn2_group_pool": [ctypes.c_longlong, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p],
+    "pn2_group_pool_grad": [ctypes.c_longlong, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p],
     "pn2_voxel_downsample": [c_int, c_void_p, c_void_p, c_void_p, ctypes.c_double, c_void_p, c_void_p, c_void_p, c_void_p,
                              c_void_p, c_void_p, ctypes.c_size_t, c_void_p],
 }

@@ -279,14 +279,54 @@ def sa_features_inference(xyz, new_xyz, points, idx, mlp, bn=True, bn_decay=None
     return new_points
 
 
+_POOL_MODES = {"max": 0, "avg": 1, "weighted_avg": 2, "max_and_avg": 3}
+
+
+class _GroupPool(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, gxyz, mode):
+        from .._lib import check, lib, ptr, stream_ptr
+        b, m, k, c = x.shape
+        x = x.contiguous()
+        gxyz = gxyz.contiguous() if gxyz is not None else None
+        out = torch.empty((b, m, 1, 2 * c if mode == 3 else c), dtype=torch.float32, device=x.device)
+        with torch.cuda.device(x.device):
+            check(lib.pn2_group_pool(b * m, k, c, mode, ptr(x), ptr(gxyz), ptr(out), stream_ptr()), "pn2_group_pool")
+        ctx.save_for_backward(x, gxyz if gxyz is not None else x.new_empty(0))
+        ctx.mode = mode
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        from .._lib import check, lib, ptr, stream_ptr
+        x, gxyz = ctx.saved_tensors
+        b, m, k, c = x.shape
+        dx = torch.empty_like(x)
+        with torch.cuda.device(x.device):
+            check(lib.pn2_group_pool_grad(b * m, k, c, ctx.mode, ptr(x), ptr(gxyz if gxyz.numel() else None),
+                                          ptr(dout.contiguous()), ptr(dx), stream_ptr()), "pn2_group_pool_grad")
+        return dx, None, None
+
+
+def group_pool(new_points, grouped_xyz, pooling):
+    """(B,M,K,C) -> (B,M,1,C) for max / avg / weighted_avg, (B,M,1,2C) = [avg | max] for max_and_avg, on pn2_group_pool
+    (pointnet_util.py:165-191 of the reference); differentiable w.r.t. new_points."""
+    mode = _POOL_MODES[pooling]
+    require_cuda(new_points)
+    if new_points.dtype != torch.float32:
+        raise TypeError("pooling expects float32 features")
+    return _GroupPool.apply(new_points, grouped_xyz if mode == 2 else None, mode)
+
+
 def pointnet_sa_module(xyz, points, npoint, radius, nsample, mlp, mlp2, group_all, is_training, bn_decay, scope,
                        bn=True, pooling="max", knn=False, use_xyz=True, use_nchw=False, geometry=None):
     """PointNet Set Abstraction module -> new_xyz (B,npoint,3), new_points (B,npoint,mlp[-1] or mlp2[-1]), idx.
     geometry = (new_xyz, idx[, plan]) (extension, training path): precomputed FPS / ball-query result of this level
     (+ the scatter plan of the grouping's gradient)."""
     require_cuda(xyz, points)
-    if use_nchw:
-        raise NotImplementedError("use_nchw is a TF layout hint; the MI355X kernels are channels-last only")
+    # use_nchw: accepted and ignored.  In the reference it only transposes the grouped tensor to NCHW around the conv
+    # stack and back (pointnet_util.py:143-146,165-166: a cuDNN layout hint, "faster than NHWC"); values, shapes and variable
+    # names are the same either way, and these kernels are channels-last by construction.
     with tf_util.variable_scope(scope):
         if not is_training and not group_all and not knn and use_xyz and pooling == "max":
             # ---- inference fast path: HIP index ops + fused / MFMA MLP -------------
@@ -307,21 +347,10 @@ def pointnet_sa_module(xyz, points, npoint, radius, nsample, mlp, mlp2, group_al
                 new_points = tf_util.conv2d(new_points, cout, [1, 1], padding="VALID", stride=[1, 1], bn=bn,
                                             is_training=is_training, scope="conv%d" % i, bn_decay=bn_decay,
                                             pool=nsample if (fuse_pool and i == len(mlp) - 1) else 0)
-            if pooling == "max":
-                if not fuse_pool:
-                    new_points = new_points.amax(dim=2, keepdim=True)
-            elif pooling == "avg":
-                new_points = new_points.mean(dim=2, keepdim=True)
-            elif pooling == "weighted_avg":
-                dists = torch.linalg.vector_norm(grouped_xyz, ord=2, dim=-1, keepdim=True)
-                exp_dists = torch.exp(-dists * 5)
-                weights = exp_dists / exp_dists.sum(dim=2, keepdim=True)
-                new_points = (new_points * weights).sum(dim=2, keepdim=True)
-            elif pooling == "max_and_avg":
-                new_points = torch.cat([new_points.mean(dim=2, keepdim=True), new_points.amax(dim=2, keepdim=True)],
-                                       dim=-1)
-            else:
+            if pooling not in _POOL_MODES:
                 raise ValueError("unknown pooling %r" % pooling)
+            if not (pooling == "max" and fuse_pool):
+                new_points = group_pool(new_points, grouped_xyz, pooling)  # HIP kernel (:165-191), (B,M,K,C) -> (B,M,1,C')
         if mlp2 is not None:
             for i, cout in enumerate(mlp2):
                 new_points = tf_util.conv2d(new_points, cout, [1, 1], padding="VALID", stride=[1, 1], bn=bn,

@@ -421,9 +421,6 @@ def hip_linear_dgrad(dy, w):
     return dx
 
 
-USE_HIP_GEMM = True  # set False to run the training path's forward / data-gradient GEMMs on torch (hipBLASLt): tests / A-B
-
-
 def _bn_scratch(c, device, fn, fn_ws0):
     """batch-norm accumulators: a slice of the step's zero arena (+ the entry point that trusts it) when there is one"""
     nbytes = lib.pn2_bn_workspace_bytes(c)
@@ -484,7 +481,7 @@ class _TrainMatmul(torch.autograd.Function):
     def forward(ctx, x2d, w, b=None):
         ctx.save_for_backward(x2d, w)
         ctx.has_bias = b is not None
-        y = hip_matmul(x2d, w) if USE_HIP_GEMM else x2d @ w
+        y = hip_matmul(x2d, w)
         return y if b is None else y.add_(b)
 
     @staticmethod
@@ -493,7 +490,7 @@ class _TrainMatmul(torch.autograd.Function):
         dy = dy.contiguous()
         dx = None
         if ctx.needs_input_grad[0]:
-            dx = hip_linear_dgrad(dy, w) if USE_HIP_GEMM else dy @ w.t()
+            dx = hip_linear_dgrad(dy, w)
         dw = None
         if ctx.needs_input_grad[1]:
             dw = _hip_wgrad(x2d, dy, w)
@@ -503,23 +500,14 @@ class _TrainMatmul(torch.autograd.Function):
         return dx, dw, db
 
 
-USE_HIP_WGRAD = True  # set False to let torch compute dW (tests / A-B)
-
-
 def _train_dense(inputs, w2d, b):
+    """un-normalised dense layer of the training path (the class head): GEMM, data and weight gradients on the HIP library"""
     cin, cout = w2d.shape
-    if USE_HIP_WGRAD and inputs.is_cuda and inputs.dtype == torch.float32:
-        y = _TrainMatmul.apply(inputs.reshape(-1, cin).contiguous(), w2d.contiguous(), b)
-        return y.reshape(list(inputs.shape[:-1]) + [cout])
-    return inputs @ w2d + b
-
-
-def _batch_norm_train(x, bnv, bn_decay):
-    beta, gamma, mean, var = bnv
-    decay = 0.9 if bn_decay is None else float(bn_decay)  # tf_util.py:571
-    c = x.shape[-1]
-    y = F.batch_norm(x.reshape(-1, c), mean, var, gamma, beta, training=True, momentum=1.0 - decay, eps=BN_EPSILON)
-    return y.reshape(x.shape)
+    require_cuda(inputs)
+    if inputs.dtype != torch.float32:
+        raise TypeError("the training path is float32")
+    y = _TrainMatmul.apply(inputs.reshape(-1, cin).contiguous(), w2d.contiguous(), b)
+    return y.reshape(list(inputs.shape[:-1]) + [cout])
 
 
 class _TrainDenseBnRelu(torch.autograd.Function):
@@ -532,14 +520,14 @@ class _TrainDenseBnRelu(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x2d, w, b, gamma, beta, running_mean, running_var, decay, relu, pool):
         rows, c = x2d.shape[0], w.shape[1]
-        fused_stats = USE_HIP_GEMM and USE_GEMM_BN_STATS and c % 32 == 0
+        fused_stats = USE_GEMM_BN_STATS and c % 32 == 0
         if fused_stats:
             # the GEMM's epilogue leaves the column sums of y in the batch-norm workspace: no statistics pass over y
             ws = _bn_zeroed_scratch(c, x2d.device)
             fwd = lib.pn2_bn_relu_forward_stats
             y = hip_matmul_bn_stats(x2d, w, ws)
         else:
-            y = hip_matmul(x2d, w) if USE_HIP_GEMM else x2d @ w
+            y = hip_matmul(x2d, w)
             ws, fwd = _bn_scratch(c, y.device, lib.pn2_bn_relu_forward, lib.pn2_bn_relu_forward_ws0)
         pooled = pool > 1
         z = torch.empty((rows // pool, c) if pooled else (rows, c), dtype=y.dtype, device=y.device)
@@ -575,7 +563,7 @@ class _TrainDenseBnRelu(torch.autograd.Function):
                   "pn2_bn_relu_backward")
             dx = None
             if ctx.needs_input_grad[0]:
-                dx = hip_linear_dgrad(dy, w) if USE_HIP_GEMM else dy @ w.t()
+                dx = hip_linear_dgrad(dy, w)
             dw = None
             if ctx.needs_input_grad[1]:
                 dw = _hip_wgrad(x2d, dy, w)
@@ -584,12 +572,12 @@ class _TrainDenseBnRelu(torch.autograd.Function):
         return dx, dw, None, dgamma, dbeta, None, None, None, None, None
 
 
-USE_HIP_BN = True  # set False to run batch norm / ReLU of the training path on torch (tests / A-B)
-
-
 def _train_layer(inputs, w2d, b, bnv, bn_decay, relu, pool=0):
-    """One dense layer of the training path: inputs (..., cin) -> (..., cout); pool > 1 also takes the max over
-    groups of `pool` consecutive entries of the second-to-last axis (..., W, cin) -> (..., W/pool, cout)."""
+    """One dense layer of the training path, entirely on the HIP library: inputs (..., cin) -> (..., cout); pool > 1 also
+    takes the max over groups of `pool` consecutive entries of the second-to-last axis (..., W, cin) -> (..., W/pool, cout).
+    With batch norm: _TrainDenseBnRelu; without (the class head, activation None): _TrainMatmul.  There is no torch
+    fallback: configurations the SA/FP stack and its head never use (ReLU / pooling without batch norm, widths beyond 1024
+    or not a multiple of 4 above 256) raise.  (tests/torch_layers.py holds the plain-torch reference of this function.)"""
     cin, cout = w2d.shape
     pool = int(pool) if pool and pool > 1 else 0
     lead = list(inputs.shape[:-1])
@@ -597,26 +585,20 @@ def _train_layer(inputs, w2d, b, bnv, bn_decay, relu, pool=0):
         if lead[-1] % pool:
             raise ValueError("pool must divide the grouped axis")
         lead[-1] //= pool
-    if (bnv is not None and USE_HIP_BN and USE_HIP_WGRAD and inputs.is_cuda and inputs.dtype == torch.float32
-            and cout <= 1024 and (cout % 4 == 0 or cout <= 256)):
-        beta, gamma, mean, var = bnv
-        decay = 0.9 if bn_decay is None else float(bn_decay)  # tf_util.py:571
-        z = _TrainDenseBnRelu.apply(inputs.reshape(-1, cin).contiguous(), w2d.contiguous(), b, gamma, beta, mean, var,
-                                    decay, relu, pool)
-        return z.reshape(lead + [cout])
-    y = _train_dense(inputs, w2d, b)
-    if bnv is not None:
-        y = _batch_norm_train(y, bnv, bn_decay)
-    if relu:
-        y = torch.relu(y)
-    if pool:
-        y = y.reshape(lead + [pool, cout]).amax(dim=-2)
-    return y
-
-
-def _batch_norm_eval(x, bnv):
+    require_cuda(inputs)
+    if inputs.dtype != torch.float32:
+        raise TypeError("the training path is float32")
+    if bnv is None:
+        if relu or pool:
+            raise NotImplementedError("training-mode conv without batch norm but with ReLU / pooling is not on the SA/FP path")
+        return _train_dense(inputs, w2d, b)
+    if not (cout <= 1024 and (cout % 4 == 0 or cout <= 256)):
+        raise NotImplementedError("batch-norm layer width %d: the HIP kernels take <= 1024 channels, a multiple of 4 above 256" % cout)
     beta, gamma, mean, var = bnv
-    return (x - mean) / torch.sqrt(var + BN_EPSILON) * gamma + beta
+    decay = 0.9 if bn_decay is None else float(bn_decay)  # tf_util.py:571
+    z = _TrainDenseBnRelu.apply(inputs.reshape(-1, cin).contiguous(), w2d.contiguous(), b, gamma, beta, mean, var,
+                                decay, relu, pool)
+    return z.reshape(lead + [cout])
 
 
 def conv2d(inputs, num_output_channels, kernel_size, scope, stride=(1, 1), padding="SAME", data_format="NHWC",

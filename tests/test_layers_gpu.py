@@ -621,6 +621,49 @@ def test_sa_module_group_all_and_poolings(pn2, oracle, cuda):
         close(npool.cpu().numpy(), fn(h))
 
 
+def test_group_pool_kernels_all_modes_and_use_nchw(pn2, cuda):
+    """pn2_group_pool / _grad (the `pooling=` variants of pointnet_sa_module, pointnet_util.py:165-191: max, avg,
+    weighted_avg = softmax-like exp(-5 |grouped_xyz|) weights, max_and_avg = concat [avg | max]) against the same
+    expressions in float64 torch, forward and gradient, for widths that take the 16-byte and the scalar path; and the
+    module with pooling="weighted_avg" on a ball-query level with `use_nchw=True` (a TF layout hint: accepted, same values)."""
+    import torch
+    pu, tfu = pn2.util.pointnet_util, pn2.util.tf_util
+    torch.manual_seed(3)
+    for c in (64, 37):
+        x = torch.randn(3, 50, 16, c, device=cuda)
+        x[:, ::4, 8:, :] = x[:, ::4, :1, :]  # duplicated neighbours: tied maxima split their gradient evenly (tf.reduce_max)
+        g = torch.randn(3, 50, 16, 3, device=cuda) * 0.3
+        for pooling in ("max", "avg", "weighted_avg", "max_and_avg"):
+            xx = x.clone().requires_grad_(True)
+            out = pu.group_pool(xx, g, pooling)
+            xd = x.double().requires_grad_(True)
+            if pooling == "max":
+                ref = xd.amax(2, keepdim=True)
+            elif pooling == "avg":
+                ref = xd.mean(2, keepdim=True)
+            elif pooling == "weighted_avg":
+                e = torch.exp(-torch.linalg.vector_norm(g.double(), dim=-1, keepdim=True) * 5)
+                ref = (xd * (e / e.sum(2, keepdim=True))).sum(2, keepdim=True)
+            else:
+                ref = torch.cat([xd.mean(2, keepdim=True), xd.amax(2, keepdim=True)], -1)
+            assert out.shape == ref.shape
+            assert torch.allclose(out.double(), ref, rtol=1e-5, atol=1e-6), pooling
+            probe = torch.cos(torch.arange(ref.numel(), device=cuda).double()).reshape(ref.shape)
+            (out.double() * probe).sum().backward()
+            (ref * probe).sum().backward()
+            assert torch.allclose(xx.grad.double(), xd.grad, rtol=1e-5, atol=1e-6), pooling
+    rs = np.random.RandomState(8)
+    xyz, pts = T(rs.random_sample((2, 512, 3)).astype(np.float32), cuda), T(rs.randn(2, 512, 5).astype(np.float32), cuda)
+    tfu.set_default_store(tfu.VariableStore(device=cuda, seed=9))
+    kw = dict(npoint=64, radius=0.3, nsample=16, mlp=[16, 32], mlp2=None, group_all=False, is_training=False, bn_decay=None,
+              scope="wa", pooling="weighted_avg")
+    a = pu.pointnet_sa_module(xyz, pts, **kw)
+    b_ = pu.pointnet_sa_module(xyz, pts, use_nchw=True, **kw)
+    assert a[1].shape == (2, 64, 32) and torch.equal(a[1], b_[1]) and torch.equal(a[2], b_[2])
+    with pytest.raises(ValueError):
+        pu.pointnet_sa_module(xyz, pts, **dict(kw, pooling="median"))
+
+
 def test_sa_module_msg_vs_oracle(pn2, oracle, cuda):
     """BASELINE config[2] shape family: MSG with 3 scales (radii/K/MLPs are builder-chosen: the reference
     ships no MSG hyper-parameters).  NOTE the [features, xyz] concat order of pointnet_util.py:259."""
@@ -824,11 +867,12 @@ def test_training_gradients_with_hip_wgrad_match_torch(pn2, cuda):
         return y.float()
 
     def run(mode):
+        from torch_layers import train_layer_torch
         orig = tfu._train_layer
-        tfu.USE_HIP_WGRAD = tfu.USE_HIP_BN = mode in ("hip", "hip_torchgemm")
-        tfu.USE_HIP_GEMM = mode == "hip"
         if mode == "fp64":
             tfu._train_layer = layer_fp64
+        elif mode == "torch":
+            tfu._train_layer = train_layer_torch  # library GEMMs + F.batch_norm: the plain fp32 reference
         try:
             store = tfu.set_default_store(tfu.VariableStore(device=cuda, seed=5))
             torch.manual_seed(123)  # same dropout mask in every run
@@ -837,7 +881,6 @@ def test_training_gradients_with_hip_wgrad_match_torch(pn2, cuda):
             return {k: v.grad.detach().double().clone() for k, v in store.params.items() if v.grad is not None}
         finally:
             tfu._train_layer = orig
-            tfu.USE_HIP_WGRAD = tfu.USE_HIP_BN = tfu.USE_HIP_GEMM = True
 
     hip, t32, ref = run("hip"), run("torch"), run("fp64")
     assert t32.keys() == ref.keys() and len(hip) > 40
@@ -991,8 +1034,9 @@ def test_train_layer_hip_bn_matches_torch_autograd(pn2, cuda, pool):
     oshape = (16, 64, 1 if pool else 32, 128)
     probe = torch.sin(torch.arange(int(np.prod(oshape)), device=cuda).float()).reshape(oshape)
     outs = {}
+    from torch_layers import train_layer_torch
     for use in (True, False):
-        tfu.USE_HIP_BN = use
+        layer = tfu._train_layer if use else train_layer_torch
         try:
             xx = x.clone().requires_grad_(True)
             w = w0.clone().requires_grad_(True)
@@ -1000,12 +1044,12 @@ def test_train_layer_hip_bn_matches_torch_autograd(pn2, cuda, pool):
             beta = torch.zeros(128, device=cuda, requires_grad=True)
             gamma = torch.ones(128, device=cuda, requires_grad=True)
             mean, var = torch.zeros(128, device=cuda), torch.ones(128, device=cuda)
-            z = tfu._train_layer(xx, w, b, (beta, gamma, mean, var), None, True, pool)
+            z = layer(xx, w, b, (beta, gamma, mean, var), None, True, pool)
             assert tuple(z.shape) == oshape
             (z * probe).sum().backward()
             outs[use] = (z.detach(), mean, var, xx.grad, w.grad, gamma.grad, beta.grad, b.grad)
         finally:
-            tfu.USE_HIP_BN = True
+            pass
     assert outs[True][-1] is None                          # bias in front of BN: exactly zero -> no gradient tensor at all ...
     assert float(outs[False][-1].abs().max()) <= 5e-3     # ... where torch sums 32768 rounding errors
     for a, r in zip(outs[True][:-1], outs[False][:-1]):

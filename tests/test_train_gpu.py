@@ -499,7 +499,8 @@ def test_eval_after_training_passes_uses_fresh_statistics(pn2, cuda):
     ev1 = tfu.conv2d(x, 32, [1, 1], scope="c", bn=True, is_training=False)
     w, b = store.params["c/weights"].reshape(16, 32), store.params["c/biases"]
     bnv = (store.params["c/bn/beta"], store.params["c/bn/gamma"], store.buffers["c/bn/moving_mean"], store.buffers["c/bn/moving_variance"])
-    ref = torch.relu(tfu._batch_norm_eval(x @ w + b, bnv))
+    from torch_layers import batch_norm_eval
+    ref = torch.relu(batch_norm_eval(x @ w + b, bnv))
     assert not torch.allclose(ev0, ev1, atol=1e-3)  # the statistics did move
     assert torch.allclose(ev1, ref, rtol=1e-4, atol=1e-4)
 
