@@ -445,6 +445,16 @@ int pn2_voxel_downsample(int n, const double *points, const double *colors, cons
                          double *out_points, double *out_colors, int *out_labels, int *out_count, int *status,
                          void *workspace, size_t workspace_bytes, void *stream);
 
+/* query_ball_point with the binning hoisted out: pn2_ball_query_bin sorts every cloud of a batch into the uniform grid of
+ * `radius` ONCE (one workgroup per cloud; workspace = b * pn2_ball_query_bin_bytes(n) bytes, 256-byte aligned, n <= 8192);
+ * pn2_query_ball_point_binned then answers the queries from it -- its workgroups (16 per cloud at m = 1024) copy the
+ * cell-sorted cloud instead of each re-binning it.  Same radius and xyz1 in both calls; results bit-identical to
+ * pn2_query_ball_point (tf_grouping.cu:3-43).  PN2_EUNSUP for shapes outside the grid kernel (n > 8192, nsample > 64). */
+size_t pn2_ball_query_bin_bytes(int n);
+int pn2_ball_query_bin(int b, int n, float radius, const float *xyz1, void *workspace, size_t workspace_bytes, void *stream);
+int pn2_query_ball_point_binned(int b, int n, int m, float radius, int nsample, const float *xyz1, const float *xyz2,
+                                const void *bins, int *idx, int *pts_cnt, int arith_mode, void *stream);
+
 /* Pooling over the K neighbours of a group -- the `pooling=` variants of pointnet_sa_module, util/pointnet_util.py:165-191
  * (tf.reduce_max / reduce_mean / the exp(-5 |grouped_xyz|) weighted average / concat [avg, max]).  mode: 0 max, 1 avg,
  * 2 weighted_avg, 3 max_and_avg.  x (rows, k, c) float32, gxyz (rows, k, 3) (mode 2 only, else NULL) ->

@@ -87,6 +87,9 @@ SIGNATURES = {
                                 c_void_p, c_void_p, c_void_p],
     "pn2_scene_sample": [c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, ctypes.c_double,
                          ctypes.c_double, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p],
+    "pn2_ball_query_bin": [c_int, c_int, c_float, c_void_p, c_void_p, ctypes.c_size_t, c_void_p],
+    "pn2_query_ball_point_binned": [c_int, c_int, c_int, c_float, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int,
+                                    c_void_p],
     "pn2_group_pool": [ctypes.c_longlong, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p],
     "pn2_group_pool_grad": [ctypes.c_longlong, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p],
     "pn2_voxel_downsample": [c_int, c_void_p, c_void_p, c_void_p, ctypes.c_double, c_void_p, c_void_p, c_void_p, c_void_p,
@@ -124,6 +127,8 @@ def _load():
         fn.restype = c_int
     lib.pn2_fps_large_workspace_bytes.argtypes = [c_int, c_int]
     lib.pn2_fps_large_workspace_bytes.restype = ctypes.c_size_t
+    lib.pn2_ball_query_bin_bytes.argtypes = [c_int]
+    lib.pn2_ball_query_bin_bytes.restype = ctypes.c_size_t
     lib.pn2_interpolate_label_workspace_bytes.argtypes = [c_int]
     lib.pn2_interpolate_label_workspace_bytes.restype = ctypes.c_size_t
     lib.pn2_three_interpolate_grad_workspace_bytes.argtypes = [c_int, c_int, c_int]

@@ -495,32 +495,48 @@ __device__ __forceinline__ int bqg_cell1(float x, float lo, float inv_h, int dim
     return c < 0 ? 0 : (c >= dim ? dim - 1 : c);
 }
 
-template <int MODE>
-__global__ void __launch_bounds__(kBqgThreads)
-ball_query_grid_kernel(int n, int m, float radius, float thr, int nsample, const float* __restrict__ xyz1_all,
-                       const float* __restrict__ xyz2_all, int* __restrict__ idx_all, int* __restrict__ cnt_all) {
-    extern __shared__ int smem_i[];
+// The cell-sorted form of one cloud for a given radius, as the query kernel wants it in LDS: x / y / z and original index
+// of every point in cell order, the start of every cell, the grid.  Built in LDS by bqg_build (one workgroup);
+// pn2_ball_query_bin stores it to a caller-provided workspace ONCE per cloud so that the query workgroups (16 per cloud at
+// m = 1024) copy it instead of each re-binning the whole cloud (10 of their 18 us, 3.8x the compulsory HBM traffic).
+struct BqgLds {
+    float *sx, *sy, *sz, *red;
+    int *ccount, *rowbuf;
+    BqgGrid* grid;
+    unsigned short *sidx, *cstart, *hits;
+};
+__device__ __forceinline__ BqgLds bqg_carve(int* smem_i, int np) {
     // layout (np = n rounded up to 64): sx[np] sy[np] sz[np] | ccount[kBqgCells+1] | rowbuf[W][64] | red[W][6] |
-    //         grid | sidx[np] (u16) | cstart[kBqgCells+1] (u16) | hits[W][4][kBqgCap] (u16)
-    const int np = (n + 63) & ~63;
-    float* sx = reinterpret_cast<float*>(smem_i);
-    float* sy = sx + np;
-    float* sz = sy + np;
-    int* ccount = reinterpret_cast<int*>(sz + np);
-    int* rowbuf = ccount + kBqgCells + 1;
-    float* red = reinterpret_cast<float*>(rowbuf + kBqgWaves * 64);
-    BqgGrid* grid = reinterpret_cast<BqgGrid*>(red + kBqgWaves * 6);
-    unsigned short* sidx = reinterpret_cast<unsigned short*>(grid + 1);
-    unsigned short* cstart = sidx + np;
-    unsigned short* hits = cstart + kBqgCells + 2;
+    //         grid | sidx[np] (u16) | cstart[kBqgCells+2] (u16) | hits[W][4][kBqgCap] (u16)
+    BqgLds L;
+    L.sx = reinterpret_cast<float*>(smem_i);
+    L.sy = L.sx + np;
+    L.sz = L.sy + np;
+    L.ccount = reinterpret_cast<int*>(L.sz + np);
+    L.rowbuf = L.ccount + kBqgCells + 1;
+    L.red = reinterpret_cast<float*>(L.rowbuf + kBqgWaves * 64);
+    L.grid = reinterpret_cast<BqgGrid*>(L.red + kBqgWaves * 6);
+    L.sidx = reinterpret_cast<unsigned short*>(L.grid + 1);
+    L.cstart = L.sidx + np;
+    L.hits = L.cstart + kBqgCells + 2;
+    return L;
+}
+inline size_t bqg_lds_bytes(int np) {
+    return (size_t)np * 12 + (size_t)(kBqgCells + 1) * 4 + kBqgWaves * 64 * 4 + kBqgWaves * 6 * 4 + sizeof(BqgGrid) +
+           (size_t)np * 2 + (size_t)(kBqgCells + 2) * 2 + (size_t)kBqgWaves * 4 * kBqgCap * 2 + 64;
+}
+// workspace of pn2_ball_query_bin, per cloud: float sx[np] sy[np] sz[np] | u16 sidx[np] | u16 cstart[kBqgCells+2] | BqgGrid
+__host__ __device__ inline size_t bqg_ws_stride(int n) {
+    const size_t np = ((size_t)n + 63) & ~(size_t)63;
+    return (np * 14 + (size_t)(kBqgCells + 2) * 2 + sizeof(BqgGrid) + 255) & ~(size_t)255;
+}
+
+// bounding box -> grid -> LDS histogram (the atomic returns the rank inside the cell) -> prefix sum -> scatter.
+// All kBqgThreads threads of the workgroup; ends with a barrier.
+__device__ __forceinline__ void bqg_build(const BqgLds& L, int n, float radius, const float* __restrict__ xyz1) {
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int bi = blockIdx.y;
-    const float* __restrict__ xyz1 = xyz1_all + (size_t)bi * n * 3;
-    const float* __restrict__ xyz2 = xyz2_all + (size_t)bi * m * 3;
-
-    // ---- build: bounding box ------------------------------------------------------------------------
     // thread t owns points t, t+1024, ...: a wave's load instruction covers 768 contiguous bytes.  (Tried: 8 consecutive
     // points per thread read as six 16-byte loads -- every instruction then touches 48 cache lines; +7.5 us.)
     float px[kBqgPPT], py[kBqgPPT], pz[kBqgPPT];
@@ -541,32 +557,25 @@ ball_query_grid_kernel(int n, int m, float radius, float thr, int nsample, const
             mn[a] = fminf(mn[a], __shfl_xor(mn[a], o));
             mx[a] = fmaxf(mx[a], __shfl_xor(mx[a], o));
         }
-        if (lane == 0) { red[wave * 6 + a] = mn[a]; red[wave * 6 + 3 + a] = mx[a]; }
+        if (lane == 0) { L.red[wave * 6 + a] = mn[a]; L.red[wave * 6 + 3 + a] = mx[a]; }
     }
-    for (int e = tid; e < kBqgCells + 1; e += kBqgThreads) ccount[e] = 0;
+    for (int e = tid; e < kBqgCells + 1; e += kBqgThreads) L.ccount[e] = 0;
     __syncthreads();
-    if (tid < 3) {  // one thread per axis (was one thread for all three)
+    if (tid < 3) {  // one thread per axis
         const int a = tid;
         const float h0 = radius * 1.0001f + 1e-30f;  // every hit is within radius*(1+1e-6) per axis: 27 cells suffice
-        float lo = red[a], hi = red[3 + a];
-        for (int w = 1; w < kBqgWaves; ++w) { lo = fminf(lo, red[w * 6 + a]); hi = fmaxf(hi, red[w * 6 + 3 + a]); }
+        float lo = L.red[a], hi = L.red[3 + a];
+        for (int w = 1; w < kBqgWaves; ++w) { lo = fminf(lo, L.red[w * 6 + a]); hi = fmaxf(hi, L.red[w * 6 + 3 + a]); }
         const float ext = hi - lo;
         float h = fmaxf(h0, ext * (1.00001f / kBqgDim));
         if (!(h > 0.f) || !(h < 3.0e38f)) h = 1.0f;
         const float inv = 1.0f / h;
         int d = (int)floorf(ext * inv) + 1;
         d = d < 1 ? 1 : (d > kBqgDim ? kBqgDim : d);
-        grid->lo[a] = lo; grid->inv_h[a] = inv; grid->dim[a] = d;
+        L.grid->lo[a] = lo; L.grid->inv_h[a] = inv; L.grid->dim[a] = d;
     }
     __syncthreads();
-#ifndef PN2_BQG_STAGE
-#define PN2_BQG_STAGE 9  // tools/bq_stage_ab.py builds truncated variants (timing breakdown only)
-#endif
-    if (PN2_BQG_STAGE < 2) { if (grid->dim[0] == 12345) idx_all[tid] = 1; return; }
-    const BqgGrid G = *grid;
-    // ---- build: histogram -> prefix sum -> scatter -------------------------------------------------------
-    // the histogram atomic RETURNS the point's rank inside its cell: the scatter position is start[cell] + rank, no second
-    // round of atomics (the order of a cell's points in LDS is arbitrary either way; hits are ordered by index later)
+    const BqgGrid G = *L.grid;
     int cell[kBqgPPT], rnk[kBqgPPT];
 #pragma unroll
     for (int j = 0; j < kBqgPPT; ++j) {
@@ -575,21 +584,20 @@ ball_query_grid_kernel(int n, int m, float radius, float thr, int nsample, const
         const int cy = bqg_cell1(py[j], G.lo[1], G.inv_h[1], G.dim[1]);
         const int cz = bqg_cell1(pz[j], G.lo[2], G.inv_h[2], G.dim[2]);
         cell[j] = (cz * G.dim[1] + cy) * G.dim[0] + cx;
-        rnk[j] = k < n ? atomicAdd(&ccount[cell[j]], 1) : 0;
+        rnk[j] = k < n ? atomicAdd(&L.ccount[cell[j]], 1) : 0;
     }
     __syncthreads();
-    if (PN2_BQG_STAGE < 3) { if (ccount[tid] == 12345) idx_all[tid] = 1; return; }
     {   // exclusive scan of ccount[0..kBqgCells): 4 cells per thread, wave scan, wave totals through `red`
         int v[4], s = 0;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) { v[i] = ccount[tid * 4 + i]; s += v[i]; }
+        for (int i = 0; i < 4; ++i) { v[i] = L.ccount[tid * 4 + i]; s += v[i]; }
         int inc = s;
 #pragma unroll
         for (int o = 1; o < 64; o <<= 1) {
             const int t = __shfl_up(inc, o);
             if (lane >= o) inc += t;
         }
-        int* wtot = reinterpret_cast<int*>(red);
+        int* wtot = reinterpret_cast<int*>(L.red);
         if (lane == 63) wtot[wave] = inc;
         __syncthreads();
         int base = 0;
@@ -597,31 +605,105 @@ ball_query_grid_kernel(int n, int m, float radius, float thr, int nsample, const
         int run = base + inc - s;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            cstart[tid * 4 + i] = (unsigned short)run;
+            L.cstart[tid * 4 + i] = (unsigned short)run;
             run += v[i];
         }
-        if (tid == kBqgThreads - 1) cstart[kBqgCells] = (unsigned short)run;  // == n
+        if (tid == kBqgThreads - 1) L.cstart[kBqgCells] = (unsigned short)run;  // == n
     }
     __syncthreads();
-    if (PN2_BQG_STAGE < 4) { if (cstart[tid] == 12345) idx_all[tid] = 1; return; }
 #pragma unroll
     for (int j = 0; j < kBqgPPT; ++j) {
         const int k = tid + kBqgThreads * j;
         if (k < n) {
-            const int pos = (int)cstart[cell[j]] + rnk[j];
-            sx[pos] = px[j]; sy[pos] = py[j]; sz[pos] = pz[j];
-            sidx[pos] = (unsigned short)k;
+            const int pos = (int)L.cstart[cell[j]] + rnk[j];
+            L.sx[pos] = px[j]; L.sy[pos] = py[j]; L.sz[pos] = pz[j];
+            L.sidx[pos] = (unsigned short)k;
         }
     }
     __syncthreads();
+}
 
-    if (PN2_BQG_STAGE < 5) { if (sidx[tid] == 12345) idx_all[tid] = 1; return; }
+// LDS <-> workspace copies of the cell-sorted cloud (16-byte lanes; every array is 16-byte aligned in both places except
+// cstart, whose byte length is a multiple of 4)
+template <bool TO_LDS>
+__device__ __forceinline__ void bqg_copy(const BqgLds& L, int np, unsigned char* __restrict__ ws) {
+    const int tid = threadIdx.x;
+    float* gx = reinterpret_cast<float*>(ws);
+    unsigned short* gi = reinterpret_cast<unsigned short*>(gx + 3 * (size_t)np);
+    unsigned short* gc = gi + np;
+    BqgGrid* gg = reinterpret_cast<BqgGrid*>(gc + kBqgCells + 2);
+    auto mv = [&](void* lds, void* glb, int bytes) {  // bytes % 4 == 0; widest lanes both addresses and the length allow
+        const unsigned al = ((unsigned)(size_t)lds | (unsigned)(size_t)glb | (unsigned)bytes);
+        if ((al & 15u) == 0u) {
+            uint4* a4 = reinterpret_cast<uint4*>(lds);
+            uint4* g4 = reinterpret_cast<uint4*>(glb);
+            for (int i = tid; i < bytes / 16; i += kBqgThreads) { if (TO_LDS) a4[i] = g4[i]; else g4[i] = a4[i]; }
+        } else if ((al & 7u) == 0u) {
+            uint2* a2 = reinterpret_cast<uint2*>(lds);
+            uint2* g2 = reinterpret_cast<uint2*>(glb);
+            for (int i = tid; i < bytes / 8; i += kBqgThreads) { if (TO_LDS) a2[i] = g2[i]; else g2[i] = a2[i]; }
+        } else {
+            unsigned* a = reinterpret_cast<unsigned*>(lds);
+            unsigned* g = reinterpret_cast<unsigned*>(glb);
+            for (int i = tid; i < bytes / 4; i += kBqgThreads) { if (TO_LDS) a[i] = g[i]; else g[i] = a[i]; }
+        }
+    };
+    mv(L.sx, gx, np * 12);  // sx | sy | sz are contiguous in both
+    mv(L.sidx, gi, np * 2);
+    mv(L.cstart, gc, (kBqgCells + 2) * 2);
+    mv(L.grid, gg, (int)sizeof(BqgGrid));
+}
+
+__global__ void __launch_bounds__(kBqgThreads)
+ball_query_bin_kernel(int n, float radius, const float* __restrict__ xyz1_all, unsigned char* __restrict__ ws_all, size_t stride) {
+    extern __shared__ int smem_i[];
+    const int np = (n + 63) & ~63;
+    const BqgLds L = bqg_carve(smem_i, np);
+    bqg_build(L, n, radius, xyz1_all + (size_t)blockIdx.x * n * 3);
+    bqg_copy<false>(L, np, ws_all + (size_t)blockIdx.x * stride);
+}
+
+template <int MODE, bool PRE>
+__global__ void __launch_bounds__(kBqgThreads)
+ball_query_grid_kernel(int n, int m, float radius, float thr, int nsample, const float* __restrict__ xyz1_all,
+                       const float* __restrict__ xyz2_all, int* __restrict__ idx_all, int* __restrict__ cnt_all,
+                       unsigned char* __restrict__ ws_all, size_t ws_stride) {
+    extern __shared__ int smem_i[];
+    const int np = (n + 63) & ~63;
+    const BqgLds L = bqg_carve(smem_i, np);
+    float* sx = L.sx; float* sy = L.sy; float* sz = L.sz;
+    int* ccount = L.ccount; int* rowbuf = L.rowbuf;
+    unsigned short* sidx = L.sidx; unsigned short* cstart = L.cstart; unsigned short* hits = L.hits;
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    // XCD-aware block remap (speed only; workgroup L runs on XCD L % 8): the gridDim.x workgroups of a cloud all read
+    // that cloud, so they should share ONE L2 -- in launch order they land on 8 different XCDs and every L2 fetches every
+    // cloud from HBM.
+    int bxq = blockIdx.x, bi = blockIdx.y;
+    {
+        const unsigned nwg = gridDim.x * gridDim.y;
+        if ((nwg & 7u) == 0u) {
+            const unsigned lin = blockIdx.x + gridDim.x * blockIdx.y;
+            const unsigned swz = (lin & 7u) * (nwg >> 3) + (lin >> 3);
+            bxq = (int)(swz % gridDim.x);
+            bi = (int)(swz / gridDim.x);
+        }
+    }
+    const float* __restrict__ xyz2 = xyz2_all + (size_t)bi * m * 3;
+    if constexpr (PRE) {
+        bqg_copy<true>(L, np, ws_all + (size_t)bi * ws_stride);
+        __syncthreads();
+    } else {
+        bqg_build(L, n, radius, xyz1_all + (size_t)bi * n * 3);
+    }
+    const BqgGrid G = *L.grid;
     // ---- queries: a wave answers 4 at a time, one per 16-lane group ------------------------------------------
     // (the 27 cells of a query hold ~100 candidates in 9 short runs: 64-lane steps would idle most lanes)
     const int grp = lane >> 4, l16 = lane & 15;
     unsigned short* myhits = hits + (wave * 4 + grp) * kBqgCap;
     int* myfirst = rowbuf + wave * 4 + grp;
-    const int qbase = blockIdx.x * (kBqgWaves * kBqgQPW) + wave * kBqgQPW;
+    const int qbase = bxq * (kBqgWaves * kBqgQPW) + wave * kBqgQPW;
     {
         const int q = qbase + grp;
         const bool qv = q < m;
@@ -731,20 +813,22 @@ ball_query_grid_kernel(int n, int m, float radius, float thr, int nsample, const
 
 template <int MODE>
 int launch_ball_query_grid(int b, int n, int m, float radius, float thr, int nsample, const float* xyz1,
-                           const float* xyz2, int* idx, int* cnt, hipStream_t st) {
+                           const float* xyz2, int* idx, int* cnt, hipStream_t st, unsigned char* bins = nullptr) {
     const int np = (n + 63) & ~63;
-    const size_t lds = (size_t)np * 12 + (size_t)(kBqgCells + 1) * 4 + kBqgWaves * 64 * 4 + kBqgWaves * 6 * 4 + sizeof(BqgGrid) +
-                       (size_t)np * 2 + (size_t)(kBqgCells + 2) * 2 + (size_t)kBqgWaves * 4 * kBqgCap * 2 + 64;
-    auto kern = ball_query_grid_kernel<MODE>;
+    const size_t lds = bqg_lds_bytes(np);
     static bool attr_set = false;
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(ball_query_grid_kernel<MODE, false>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (e != hipSuccess) return (int)e;
+        e = hipFuncSetAttribute(reinterpret_cast<const void*>(ball_query_grid_kernel<MODE, true>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (e != hipSuccess) return (int)e;
         attr_set = true;
     }
     dim3 grid((m + kBqgWaves * kBqgQPW - 1) / (kBqgWaves * kBqgQPW), b);
-    kern<<<grid, kBqgThreads, lds, st>>>(n, m, radius, thr, nsample, xyz1, xyz2, idx, cnt);
+    if (bins) ball_query_grid_kernel<MODE, true><<<grid, kBqgThreads, lds, st>>>(n, m, radius, thr, nsample, xyz1, xyz2, idx, cnt, bins, bqg_ws_stride(n));
+    else ball_query_grid_kernel<MODE, false><<<grid, kBqgThreads, lds, st>>>(n, m, radius, thr, nsample, xyz1, xyz2, idx, cnt, nullptr, 0);
     PN2_RETURN_IF_LAUNCH_FAILED();
     return PN2_OK;
 }
@@ -946,6 +1030,51 @@ extern "C" int pn2_query_ball_point(int b, int n, int m, float radius, int nsamp
                                     const float* xyz1, const float* xyz2, int* idx, int* pts_cnt,
                                     int arith_mode, void* stream) {
     return query_ball_point_impl(b, n, m, radius, nsample, xyz1, xyz2, idx, pts_cnt, arith_mode, 0, stream);
+}
+
+// Bin a batch of clouds once for a radius (see BqgLds): workspace = b * pn2_ball_query_bin_bytes(n) bytes, 256-byte aligned.
+// PN2_EUNSUP when the shape is outside the LDS-grid kernel's range (the caller then uses pn2_query_ball_point).
+extern "C" size_t pn2_ball_query_bin_bytes(int n) { return (n >= 1 && n <= kBqgMaxN) ? bqg_ws_stride(n) : 0; }
+
+extern "C" int pn2_ball_query_bin(int b, int n, float radius, const float* xyz1, void* workspace, size_t workspace_bytes,
+                                  void* stream) {
+    if (b <= 0 || n <= 0) return PN2_EINVAL;
+    if (!(radius > 0.0f)) return PN2_EINVAL;
+    if (!xyz1 || !workspace) return PN2_ENULL;
+    if (n > kBqgMaxN || !(radius < 1e18f)) return PN2_EUNSUP;
+    if (b > 65535) return PN2_ERANGE;
+    const size_t stride = bqg_ws_stride(n);
+    if (workspace_bytes < stride * (size_t)b || ((uintptr_t)workspace & 255) != 0) return PN2_EINVAL;
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(ball_query_bin_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (e != hipSuccess) return (int)e;
+        attr_set = true;
+    }
+    ball_query_bin_kernel<<<b, kBqgThreads, bqg_lds_bytes((n + 63) & ~63), static_cast<hipStream_t>(stream)>>>(
+        n, radius, xyz1, static_cast<unsigned char*>(workspace), stride);
+    PN2_RETURN_IF_LAUNCH_FAILED();
+    return PN2_OK;
+}
+
+// query_ball_point on a cloud binned by pn2_ball_query_bin(b, n, radius, xyz1, ...) -- same radius, same xyz1: the query
+// workgroups copy the cell-sorted cloud instead of re-binning it.  Bit-identical to pn2_query_ball_point.
+extern "C" int pn2_query_ball_point_binned(int b, int n, int m, float radius, int nsample, const float* xyz1, const float* xyz2,
+                                           const void* bins, int* idx, int* pts_cnt, int arith_mode, void* stream) {
+    if (b <= 0 || n <= 0 || m <= 0 || nsample <= 0) return PN2_EINVAL;
+    if (!(radius > 0.0f)) return PN2_EINVAL;
+    if (!xyz1 || !xyz2 || !idx || !pts_cnt || !bins) return PN2_ENULL;
+    if (n > kBqgMaxN || nsample > 64 || !(radius < 1e18f)) return PN2_EUNSUP;
+    if ((long long)m * 3 > 0x7fffffffLL || b > 65535) return PN2_ERANGE;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    const float thr = ball_threshold(radius);
+    unsigned char* ws = const_cast<unsigned char*>(static_cast<const unsigned char*>(bins));
+    switch (arith_mode) {
+        case PN2_ARITH_STRICT: return launch_ball_query_grid<PN2_ARITH_STRICT>(b, n, m, radius, thr, nsample, xyz1, xyz2, idx, pts_cnt, st, ws);
+        case PN2_ARITH_FMA: return launch_ball_query_grid<PN2_ARITH_FMA>(b, n, m, radius, thr, nsample, xyz1, xyz2, idx, pts_cnt, st, ws);
+        case PN2_ARITH_FMA_ALT: return launch_ball_query_grid<PN2_ARITH_FMA_ALT>(b, n, m, radius, thr, nsample, xyz1, xyz2, idx, pts_cnt, st, ws);
+        default: return PN2_EINVAL;
+    }
 }
 
 // Diagnostic door: the same operator on an explicitly chosen kernel (1 wave-per-queries scan, 2 lane-per-query scan,

@@ -46,6 +46,57 @@ def query_ball_point(radius, nsample, xyz1, xyz2, kernel=0, arith_mode=None):
     return idx, cnt
 
 
+BIN_MAX_N, BIN_MIN_N, BIN_MIN_M, BIN_MAX_NSAMPLE = 8192, 4096, 256, 64  # the LDS-grid kernel's range (pn2_grouping.hip)
+
+
+def ball_query_bin_alloc(xyz1):
+    """workspace of ball_query_bin for xyz1 (b,n,3), or None when n is outside the grid kernel's range"""
+    b, n, _ = xyz1.shape
+    if not (BIN_MIN_N <= n <= BIN_MAX_N):
+        return None
+    stride = int(lib.pn2_ball_query_bin_bytes(n))
+    ws = torch.empty((b * stride + 256,), dtype=torch.uint8, device=xyz1.device)
+    off = (-ws.data_ptr()) % 256
+    return ws[off:off + b * stride]
+
+
+def ball_query_bin(radius, xyz1, out=None):
+    """Extension: sort every cloud of xyz1 (b,n,3) into the uniform grid of `radius` ONCE (pn2_ball_query_bin, one workgroup
+    per cloud) -> an opaque uint8 tensor for query_ball_point_binned, or None when the shape is outside the grid kernel's
+    range (the caller then uses query_ball_point).  Depends on xyz1 only, so it can run beside the FPS of the same level."""
+    if not radius > 0:
+        raise ValueError("QueryBallPoint expects positive radius")
+    require_cuda(xyz1)
+    if xyz1.dim() != 3 or xyz1.shape[2] != 3 or xyz1.dtype != torch.float32:
+        raise ValueError("QueryBallPoint expects (batch_size, ndataset, 3) float32 xyz1")
+    b, n, _ = xyz1.shape
+    if not (BIN_MIN_N <= n <= BIN_MAX_N):
+        return None
+    xyz1 = xyz1.detach().contiguous()
+    bins = out if out is not None else ball_query_bin_alloc(xyz1)  # `out`: allocated by the caller (on ITS stream)
+    with torch.cuda.device(xyz1.device):
+        check(lib.pn2_ball_query_bin(b, n, float(radius), ptr(xyz1), ptr(bins), bins.numel(), stream_ptr()), "pn2_ball_query_bin")
+    return bins
+
+
+def query_ball_point_binned(radius, nsample, xyz1, xyz2, bins, arith_mode=None):
+    """query_ball_point(radius, nsample, xyz1, xyz2) on clouds binned by ball_query_bin(radius, xyz1): bit-identical result,
+    the query workgroups copy the cell-sorted cloud instead of each re-binning it."""
+    b, n, _ = xyz1.shape
+    m = xyz2.shape[1]
+    if bins is None or nsample > BIN_MAX_NSAMPLE or m < BIN_MIN_M:
+        return query_ball_point(radius, nsample, xyz1, xyz2, arith_mode=arith_mode)
+    require_cuda(xyz1, xyz2)
+    xyz1 = xyz1.detach().contiguous()
+    xyz2 = xyz2.detach().contiguous()
+    idx = torch.empty((b, m, nsample), dtype=torch.int32, device=xyz1.device)
+    cnt = torch.empty((b, m), dtype=torch.int32, device=xyz1.device)
+    with torch.cuda.device(xyz1.device):
+        check(lib.pn2_query_ball_point_binned(b, n, m, float(radius), int(nsample), ptr(xyz1), ptr(xyz2), ptr(bins), ptr(idx),
+                                              ptr(cnt), config.bq_mode(arith_mode), stream_ptr()), "pn2_query_ball_point_binned")
+    return idx, cnt
+
+
 def query_ball_point_multi(radius_list, nsample_list, xyz1, xyz2, arith_mode=None):
     """[(idx, pts_cnt) for each (radius, nsample)] from ONE scan of xyz1 (pn2_query_ball_point_multi): what
     pointnet_sa_module_msg needs (util/pointnet_util.py:245-250 runs query_ball_point once per radius).

@@ -17,6 +17,7 @@ import torch
 
 from . import tf_util
 from .._lib import PN2_EUNSUP, check, lib, ptr, require_cuda, stream_ptr
+from ..tf_ops import tf_grouping
 from ..tf_ops.tf_grouping import query_ball_point_multi, group_point, knn_point, query_ball_point
 from ..tf_ops.tf_interpolate import three_interpolate, three_nn
 from ..tf_ops.tf_sampling import farthest_point_sample, farthest_point_sample_and_gather, gather_point
@@ -222,13 +223,42 @@ class _FPInterpConcat(torch.autograd.Function):
 USE_FUSED_SA = True
 
 
+USE_BINNED_BALL_QUERY = True  # A/B: bin the cloud once per level on a side stream while the FPS of the level runs
+
+_bin_streams = {}
+
+
+def _bin_stream(device):
+    key = (device.type, device.index)
+    if key not in _bin_streams:
+        _bin_streams[key] = torch.cuda.Stream(device=device)
+    return _bin_streams[key]
+
+
 def sa_geometry(xyz, npoint, radius, nsample):
     """The feature-independent half of an SA layer: FPS -> gather -> ball query.
     -> new_xyz (B,npoint,3), idx (B,npoint,nsample).  Depends only on coordinates, so a model can
-    run the geometry of all levels on a side stream (see model.get_sa_fp_features)."""
+    run the geometry of all levels on a side stream (see model.get_sa_fp_features).
+    Large levels (4096..8192 points): the cloud is sorted into the ball query's grid ONCE (tf_grouping.ball_query_bin) on a
+    forked stream BESIDE the FPS -- both read the same input cloud, the FPS is a 16-CU latency chain -- and the query
+    workgroups copy the bins instead of each re-binning the cloud (a parallel branch when the caller is capturing a graph)."""
     xyz = xyz.contiguous()
+    n = xyz.shape[1]
+    bins = None
+    if (USE_BINNED_BALL_QUERY and tf_grouping.BIN_MIN_N <= n <= tf_grouping.BIN_MAX_N and npoint >= tf_grouping.BIN_MIN_M
+            and nsample <= tf_grouping.BIN_MAX_NSAMPLE):
+        cur = torch.cuda.current_stream(xyz.device)
+        side = _bin_stream(xyz.device)
+        bins = tf_grouping.ball_query_bin_alloc(xyz)  # allocated on the caller's stream, which joins the fork below
+        side.wait_stream(cur)
+        with torch.cuda.stream(side):
+            tf_grouping.ball_query_bin(radius, xyz, out=bins)
     _, new_xyz = farthest_point_sample_and_gather(npoint, xyz)  # one launch: the FPS kernel emits the coordinates
-    idx, _ = query_ball_point(radius, nsample, xyz, new_xyz)
+    if bins is not None:
+        torch.cuda.current_stream(xyz.device).wait_stream(_bin_stream(xyz.device))
+        idx, _ = tf_grouping.query_ball_point_binned(radius, nsample, xyz, new_xyz, bins)
+    else:
+        idx, _ = query_ball_point(radius, nsample, xyz, new_xyz)
     return new_xyz, idx
 
 

@@ -38,7 +38,7 @@ def test_python_signatures_cover_the_header(pn2):
                                "pn2_interpolate_label_workspace_bytes", "pn2_fps_large_workspace_bytes",
                                "pn2_bn_workspace_bytes", "pn2_three_interpolate_grad_workspace_bytes",
                                "pn2_group_point_grad_workspace_bytes", "pn2_voxel_downsample_workspace_bytes",
-                               "pn2_scatter_plan_bytes"}  # bound separately: size_t
+                               "pn2_scatter_plan_bytes", "pn2_ball_query_bin_bytes"}  # bound separately: size_t
     assert decl <= set(pn2._lib.SIGNATURES)
     # ... and nothing is bound that the header does not declare (no undocumented entry points in the product)
     assert set(pn2._lib.SIGNATURES) <= decl

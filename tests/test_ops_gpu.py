@@ -666,6 +666,50 @@ def test_query_ball_point_grid_kernel_bit_exact(pn2, oracle, cuda, case, mode):
     assert np.array_equal(sc.cpu().numpy(), oc) and np.array_equal(si.cpu().numpy(), oi)
 
 
+@pytest.mark.parametrize("mode", [0, 1, 2])
+@pytest.mark.parametrize("case", ["sa1_scene", "n4096", "ragged_n", "dense_k64", "lattice_on_radius", "flat"])
+def test_query_ball_point_binned_equals_unbinned(pn2, oracle, cuda, case, mode):
+    """pn2_ball_query_bin + pn2_query_ball_point_binned (the cloud binned ONCE per cloud, query workgroups copy the bins)
+    == pn2_query_ball_point == the oracle, bit for bit: SA1 shape, a cloud that is not a multiple of 64, dense balls that
+    overflow the hit list (bitmap path), lattice points exactly on the radius, a degenerate axis; bins reused for two
+    query sets; shapes outside the grid kernel fall back."""
+    g = pn2.tf_ops.tf_grouping
+    if case == "sa1_scene":
+        xyz, m, r, K = s_scene(61, 16, 8192), 1024, 0.5, 32
+    elif case == "n4096":
+        xyz, m, r, K = s_scene(62, 3, 4096), 512, 0.7, 32
+    elif case == "ragged_n":
+        xyz, m, r, K = s_randn(63, 2, 5003), 300, 0.3, 16
+    elif case == "dense_k64":
+        xyz, m, r, K = s_scene(64, 2, 8192), 512, 1.0, 64
+    elif case == "lattice_on_radius":
+        xyz, m, r, K = s_grid(65, 2, 6000, 32), 256, 4 / 32.0, 32
+    else:
+        xyz = s_scene(66, 2, 4100); xyz[..., 2] = 0; m, r, K = 257, 0.6, 32
+    q = xyz[:, :m].copy()
+    set_mode(mode)
+    oi, oc = oracle.query_ball_point(r, K, xyz, q, mode)
+    bins = g.ball_query_bin(r, T(xyz, cuda))
+    assert bins is not None
+    bi, bc = g.query_ball_point_binned(r, K, T(xyz, cuda), T(q, cuda), bins)
+    assert np.array_equal(bi.cpu().numpy(), oi) and np.array_equal(bc.cpu().numpy(), oc)
+    q2 = xyz[:, -m:].copy()  # the bins depend on (radius, xyz1) only
+    b2, c2 = g.query_ball_point_binned(r, K, T(xyz, cuda), T(q2, cuda), bins)
+    o2, oc2 = oracle.query_ball_point(r, K, xyz, q2, mode)
+    assert np.array_equal(b2.cpu().numpy(), o2) and np.array_equal(c2.cpu().numpy(), oc2)
+    # the layer-level chain (bins built on a forked stream beside the FPS) equals the plain chain
+    pu = pn2.util.pointnet_util
+    nx1, idx1 = pu.sa_geometry(T(xyz, cuda), m, r, K)
+    pu.USE_BINNED_BALL_QUERY = False
+    try:
+        nx0, idx0 = pu.sa_geometry(T(xyz, cuda), m, r, K)
+    finally:
+        pu.USE_BINNED_BALL_QUERY = True
+    import torch
+    assert torch.equal(nx1, nx0) and torch.equal(idx1, idx0)
+    assert g.ball_query_bin(r, T(xyz[:, :1000].copy(), cuda)) is None  # below the grid kernel's range: caller scans
+
+
 def test_query_ball_point_kernels_fuzz(pn2, oracle, cuda):
     """Differential fuzz: 40 random (cloud, queries, radius, nsample) draws, every ball-query kernel (LDS grid, lane
     scan, wave-per-queries scan) against the oracle.  Mixes float clouds, lattice clouds (hits exactly on the
