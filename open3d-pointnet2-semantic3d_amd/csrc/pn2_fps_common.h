@@ -40,9 +40,14 @@ constexpr int kLazyCap = 64;  // candidates per phase = lanes of the picking wav
 // drops below `lim` or `maxp` picks.  The picks are parked in lane `npick` of four registers (v_writelane) for the
 // caller to store: no memory traffic and no exec juggling on the chain.  Returns the number of picks; g_first = td of the
 // first pick (>= every td in the cloud when it was picked), d_last = td of the last one.
-template <int MODE>
+struct NoPost { __device__ __forceinline__ void operator()(int, int, float, float, float, int) const {} };
+
+// on_pick(npick, pk_k, pk_x, pk_y, pk_z, g_first) is called after every pick with the parked registers (the streaming
+// kernel posts the picks to the worker waves in batches from it).
+template <int MODE, class OnPick = NoPost>
 __device__ __forceinline__ int pick_phase(int chi, unsigned clo, float cx, float cy, float cz, int lim, int maxp,
-                                          int& pk_k, float& pk_x, float& pk_y, float& pk_z, int& g_first, int& d_last) {
+                                          int& pk_k, float& pk_x, float& pk_y, float& pk_z, int& g_first, int& d_last,
+                                          OnPick on_pick = OnPick()) {
     int npick = 0;
     g_first = -1; d_last = 0;
     pk_k = 0; pk_x = pk_y = pk_z = 0.f;
@@ -70,6 +75,7 @@ __device__ __forceinline__ int pick_phase(int chi, unsigned clo, float cx, float
         g_first = bh > g_first ? bh : g_first;  // td of the picks never increases: the maximum is the first one
         d_last = bh;
         ++npick;
+        on_pick(npick, pk_k, pk_x, pk_y, pk_z, g_first);
     }
     return npick;
 }

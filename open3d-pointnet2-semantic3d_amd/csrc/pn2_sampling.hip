@@ -317,45 +317,32 @@ inline size_t fps_lazy_bytes(int n, int m) {
     return kLazyHead + (size_t)n * 16 + r;
 }
 
-template <int NT, int PPT, int MODE>
-__global__ void __launch_bounds__(NT)
-fps_lazy_kernel(int n, int m, const float* __restrict__ xyz_all, int* __restrict__ out_all,
-                float* __restrict__ new_xyz_all, long long* __restrict__ stats) {
-    static_assert(NT % 64 == 0 && NT * PPT <= 8192 && kFpsCells % NT == 0 && NT / 64 <= 16, "u16 permutation; 16 wave slots");
+// Set-up shared by the lazy kernels: load the cloud (NT threads, LPT points each), copy it to LDS, sort it along the
+// Hilbert curve (LDS counting sort over 16^3 cells) and deal the buckets (64 consecutive sorted points) to the worker
+// waves -- worker wi (wave-uniform, -1 for a wave that owns no rows) holds bucket q = i * NWK + wi in register row i -- with
+// the exact box of the lane's own row (lane l: row l / (64 / PPT)).  Leaves hist / perm dead (the caller may alias them).
+template <int NT, int LPT, int PPT, int NWK>
+__device__ __forceinline__ void fps_lazy_setup(int n, int wi, const float* __restrict__ xyz, float4* sxyz, int* hist, float* bbw, int* wsum,
+                                               float (&px)[PPT], float (&py)[PPT], float (&pz)[PPT], double (&mk)[PPT],
+                                               float& bx0, float& by0, float& bz0, float& bx1, float& by1, float& bz1) {
     constexpr int NW = NT / 64;
-    constexpr int EPT = kFpsCells / NT;  // histogram entries per thread in the scan
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    // layout: int ctrl[16] | u64 wcand[16] | u64 cand[64] | float4 pend[64] | float bbw[16][6], int wsum[16] |
-    //         float4 sxyz[n] | R: int hist[4096] -> u16 perm[n] -> int spick[m]
-    int* ctrl = reinterpret_cast<int*>(smem);  // [0] cnt (LDS atomic) | [4..7] np, j, tau_hi, G bits (one 16-byte read)
-    unsigned long long* wcand = reinterpret_cast<unsigned long long*>(smem + 64);
-    unsigned long long* cand = reinterpret_cast<unsigned long long*>(smem + 192);
-    float4* pend = reinterpret_cast<float4*>(smem + 704);
-    float* bbw = reinterpret_cast<float*>(smem + 1728);
-    int* wsum = reinterpret_cast<int*>(bbw + 6 * 16);
-    float4* sxyz = reinterpret_cast<float4*>(smem + kLazyHead);
-    int* hist = reinterpret_cast<int*>(sxyz + n);
+    constexpr int EPT = (kFpsCells + NT - 1) / NT;  // histogram entries per thread in the scan
+    static_assert(NT % 64 == 0 && NW <= 16 && NWK <= NW && NT * LPT >= NWK * PPT * 64 && NWK * PPT * 64 <= 16384, "16 wave slots");
     unsigned short* perm = reinterpret_cast<unsigned short*>(hist);
-    int* spick = hist;
-
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const float* __restrict__ xyz = xyz_all + (size_t)blockIdx.x * n * 3;
-    int* __restrict__ out = out_all + (size_t)blockIdx.x * m;
-    float* __restrict__ nxyz = new_xyz_all ? new_xyz_all + (size_t)blockIdx.x * m * 3 : nullptr;
-
-    float px[PPT], py[PPT], pz[PPT];
-
+    float lx[LPT], ly[LPT], lz[LPT];
     // ---- 1. load in original order, cloud copy in LDS, bounding box ----------------------------------------------
     float lo[3] = {3e38f, 3e38f, 3e38f}, hi[3] = {-3e38f, -3e38f, -3e38f};
 #pragma unroll
-    for (int i = 0; i < PPT; ++i) {
+    for (int i = 0; i < LPT; ++i) {
         const int k = tid + NT * i;
+        lx[i] = ly[i] = lz[i] = 0.f;
         if (k < n) {
-            px[i] = xyz[k * 3 + 0]; py[i] = xyz[k * 3 + 1]; pz[i] = xyz[k * 3 + 2];
-            sxyz[k] = make_float4(px[i], py[i], pz[i], 0.f);
-            lo[0] = fminf(lo[0], px[i]); hi[0] = fmaxf(hi[0], px[i]);
-            lo[1] = fminf(lo[1], py[i]); hi[1] = fmaxf(hi[1], py[i]);
-            lo[2] = fminf(lo[2], pz[i]); hi[2] = fmaxf(hi[2], pz[i]);
+            lx[i] = xyz[k * 3 + 0]; ly[i] = xyz[k * 3 + 1]; lz[i] = xyz[k * 3 + 2];
+            sxyz[k] = make_float4(lx[i], ly[i], lz[i], 0.f);
+            lo[0] = fminf(lo[0], lx[i]); hi[0] = fmaxf(hi[0], lx[i]);
+            lo[1] = fminf(lo[1], ly[i]); hi[1] = fmaxf(hi[1], ly[i]);
+            lo[2] = fminf(lo[2], lz[i]); hi[2] = fmaxf(hi[2], lz[i]);
         }
     }
 #pragma unroll
@@ -365,9 +352,9 @@ fps_lazy_kernel(int n, int m, const float* __restrict__ xyz_all, int* __restrict
         for (int a = 0; a < 3; ++a) { bbw[wave * 6 + a] = lo[a]; bbw[wave * 6 + 3 + a] = hi[a]; }
     }
 #pragma unroll
-    for (int e = 0; e < EPT; ++e) hist[tid + NT * e] = 0;
+    for (int e = 0; e < EPT; ++e) if (tid + NT * e < kFpsCells) hist[tid + NT * e] = 0;
     __syncthreads();
-    float scl[3];
+    float scl;
 #pragma unroll
     for (int a = 0; a < 3; ++a) {
         float l = bbw[a], h = bbw[3 + a];
@@ -377,23 +364,22 @@ fps_lazy_kernel(int n, int m, const float* __restrict__ xyz_all, int* __restrict
     }
     {   // cubic cells (one scale for the three axes): buckets come out compact in every direction
         const float ext = fmaxf(fmaxf(hi[0], hi[1]), hi[2]);
-        float s = ext > 0.f ? 16.0f / ext : 0.f;  // degenerate cloud (or inf/garbage): everything in cell 0
-        if (!(s < 3e38f)) s = 0.f;
-        scl[0] = scl[1] = scl[2] = s;
+        scl = ext > 0.f ? 16.0f / ext : 0.f;  // degenerate cloud (or inf/garbage): everything in cell 0
+        if (!(scl < 3e38f)) scl = 0.f;
     }
-    // ---- 2. counting sort by Morton cell: rank within the cell from the LDS atomic, exclusive scan of the histogram
+    // ---- 2. counting sort by Hilbert cell: rank within the cell from the LDS atomic, exclusive scan of the histogram
     //         (the order inside a cell is arbitrary: only locality depends on it, never the result)
-    int code[PPT], rnk[PPT];
+    int code[LPT], rnk[LPT];
 #pragma unroll
-    for (int i = 0; i < PPT; ++i) {
+    for (int i = 0; i < LPT; ++i) {
         const int k = tid + NT * i;
         code[i] = 0; rnk[i] = 0;
         if (k < n) {
             int c[3];
-            const float q[3] = {px[i], py[i], pz[i]};
+            const float q[3] = {lx[i], ly[i], lz[i]};
 #pragma unroll
             for (int a = 0; a < 3; ++a) {
-                const float f = (q[a] - lo[a]) * scl[a];
+                const float f = (q[a] - lo[a]) * scl;
                 int ci = (int)f;
                 ci = ci < 0 ? 0 : (ci > 15 ? 15 : ci);
                 if (!(f == f)) ci = 0;
@@ -405,44 +391,42 @@ fps_lazy_kernel(int n, int m, const float* __restrict__ xyz_all, int* __restrict
     }
     __syncthreads();
     {
-        int v[EPT], s = 0;
+        int v[EPT], sum = 0;
 #pragma unroll
-        for (int e = 0; e < EPT; ++e) { v[e] = hist[tid * EPT + e]; s += v[e]; }
-        int inc = s;  // inclusive wave scan
+        for (int e = 0; e < EPT; ++e) { v[e] = tid * EPT + e < kFpsCells ? hist[tid * EPT + e] : 0; sum += v[e]; }
+        int inc = sum;  // inclusive wave scan
 #pragma unroll
         for (int o = 1; o < 64; o <<= 1) { const int t = __shfl_up(inc, o); if (lane >= o) inc += t; }
         if (lane == 63) wsum[wave] = inc;
         __syncthreads();
         int base = 0;
         for (int w = 0; w < wave; ++w) base += wsum[w];
-        int run = base + inc - s;
+        int run = base + inc - sum;
 #pragma unroll
-        for (int e = 0; e < EPT; ++e) { hist[tid * EPT + e] = run; run += v[e]; }
+        for (int e = 0; e < EPT; ++e) { if (tid * EPT + e < kFpsCells) hist[tid * EPT + e] = run; run += v[e]; }
     }
     __syncthreads();
-    int pos[PPT];
+    int pos[LPT];
 #pragma unroll
-    for (int i = 0; i < PPT; ++i) pos[i] = hist[code[i]] + rnk[i];
+    for (int i = 0; i < LPT; ++i) pos[i] = hist[code[i]] + rnk[i];
     __syncthreads();  // hist is dead from here: the permutation aliases it
 #pragma unroll
-    for (int i = 0; i < PPT; ++i) {
+    for (int i = 0; i < LPT; ++i) {
         const int k = tid + NT * i;
         if (k < n) perm[pos[i]] = (unsigned short)k;
     }
     __syncthreads();
-    // ---- 3. deal the sorted cloud: bucket q = 64 consecutive sorted points -> wave q % NW, register row q / NW;
-    //         exact bucket boxes as wave-uniform values (an empty bucket keeps the inverted box: lb = +inf, never touched)
+    // ---- 3. deal the sorted cloud; exact bucket boxes (an empty bucket keeps the inverted box: lb = +inf, never touched)
     // Box test layout: lane l tests row l / PP against pick slot l % PP, so ONE pass of ~15 VALU tests PP = 64 / PPT
     // pending picks against all the rows of the wave; the lane keeps only its own row's box.
     constexpr int PP = 64 / PPT;
     static_assert(PPT >= 2 && PPT * PP == 64, "rows per wave: 2, 4, 8 or 16");
-    float bx0 = 3e38f, by0 = 3e38f, bz0 = 3e38f, bx1 = -3e38f, by1 = -3e38f, bz1 = -3e38f;
-    double mk[PPT];
+    bx0 = by0 = bz0 = 3e38f; bx1 = by1 = bz1 = -3e38f;
 #pragma unroll
     for (int i = 0; i < PPT; ++i) {
-        const int p = (i * NW + wave) * 64 + lane;
+        const int p = (i * NWK + wi) * 64 + lane;
         float l0 = 3e38f, l1 = 3e38f, l2 = 3e38f, h0 = -3e38f, h1 = -3e38f, h2 = -3e38f;
-        if (p < n) {
+        if (wi >= 0 && p < n) {
             const int k = perm[p];
             const float4 q = sxyz[k];
             px[i] = q.x; py[i] = q.y; pz[i] = q.z;
@@ -456,7 +440,37 @@ fps_lazy_kernel(int n, int m, const float* __restrict__ xyz_all, int* __restrict
         h0 = wave_fmax_all(h0); h1 = wave_fmax_all(h1); h2 = wave_fmax_all(h2);
         if (lane / PP == i) { bx0 = l0; by0 = l1; bz0 = l2; bx1 = h0; by1 = h1; bz1 = h2; }
     }
-    __syncthreads();  // perm is dead from here: the pick list aliases it
+    __syncthreads();  // perm is dead from here
+}
+
+template <int NT, int PPT, int MODE>
+__global__ void __launch_bounds__(NT)
+fps_lazy_kernel(int n, int m, const float* __restrict__ xyz_all, int* __restrict__ out_all,
+                float* __restrict__ new_xyz_all, long long* __restrict__ stats) {
+    constexpr int NW = NT / 64;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    // layout: int ctrl[16] | u64 wcand[16] | u64 cand[64] | float4 pend[64] | float bbw[16][6], int wsum[16] |
+    //         float4 sxyz[n] | R: int hist[4096] -> u16 perm[n] -> int spick[m]
+    int* ctrl = reinterpret_cast<int*>(smem);  // [0] cnt (LDS atomic) | [4..7] np, j, tau_hi, G bits (one 16-byte read)
+    unsigned long long* wcand = reinterpret_cast<unsigned long long*>(smem + 64);
+    unsigned long long* cand = reinterpret_cast<unsigned long long*>(smem + 192);
+    float4* pend = reinterpret_cast<float4*>(smem + 704);
+    float* bbw = reinterpret_cast<float*>(smem + 1728);
+    int* wsum = reinterpret_cast<int*>(bbw + 6 * 16);
+    float4* sxyz = reinterpret_cast<float4*>(smem + kLazyHead);
+    int* hist = reinterpret_cast<int*>(sxyz + n);
+    int* spick = hist;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const float* __restrict__ xyz = xyz_all + (size_t)blockIdx.x * n * 3;
+    int* __restrict__ out = out_all + (size_t)blockIdx.x * m;
+    float* __restrict__ nxyz = new_xyz_all ? new_xyz_all + (size_t)blockIdx.x * m * 3 : nullptr;
+
+    float px[PPT], py[PPT], pz[PPT];
+    double mk[PPT];
+    float bx0, by0, bz0, bx1, by1, bz1;
+    constexpr int PP = 64 / PPT;
+    fps_lazy_setup<NT, PPT, PPT, NW>(n, wave, xyz, sxyz, hist, bbw, wsum, px, py, pz, mk, bx0, by0, bz0, bx1, by1, bz1);
     if (tid == 0) {
         spick[0] = 0;  // first pick is index 0 (tf_sampling.cu:122-123)
         pend[0] = sxyz[0];
