@@ -134,6 +134,15 @@ def kernel_model(name, a):
             fl += 2 * b * n * cin * w
             cin = w
         return "mfma", fl
+    if name == "pn2_fp_mlp_fused_pre":  # ints: b, n, m, c1, nlayers, widths...  EXECUTED flops: skip channels + later layers
+        b, n, m, c1, L = a[:5]
+        widths = a[5:5 + L]
+        fl = 2 * b * n * c1 * widths[0]
+        cin = widths[0]
+        for w in widths[1:]:
+            fl += 2 * b * n * cin * w
+            cin = w
+        return "mfma", fl
     if name in ("pn2_sa_mlp_max_fused", "pn2_sa_mlp_rows_fused"):
         b, n, m, ns, c, L = a[:6]
         widths = a[6:6 + L]
@@ -496,6 +505,8 @@ def main():
                     help="FP front end inside the first FP4 MLP kernel (pn2_fp_mlp_fused) or materialised by "
                          "pn2_fp_interp_concat; auto = fused (faster at every pipeline depth with one stream per batch)")
     ap.add_argument("--wide", default="auto", help="A/B: off = one pn2_linear per coarse-level layer; N = pn2_*_mlp_wide from N rows on")
+    ap.add_argument("--no-hoist", action="store_true", help="A/B: FP first layers computed in place (pn2_fp_mlp_fused) instead of hoisted")
+    ap.add_argument("--binned-bq", action="store_true", help="A/B: ball query on a cloud binned once per level on a forked stream (default off)")
     ap.add_argument("--train", action="store_true",
                     help="BASELINE configs[3] instead of the headline: data-parallel TRAINING steps (forward with batch-stat "
                          "BN + weighted CE + backward + one flat RCCL gradient all-reduce + Adam), 16 scenes per GPU")
@@ -555,6 +566,8 @@ def main():
             if k.endswith("moving_variance"):
                 v.copy_((torch.rand(v.shape, generator=g) + 0.5).to(dev))
 
+    pn2.util.pointnet_util.USE_HOISTED_FP = not args.no_hoist
+    pn2.util.pointnet_util.USE_BINNED_BALL_QUERY = bool(args.binned_bq)
     pn2._lib.lib.dup = tuple(args.dup)
     fused_fp = args.fp_front != "unfused"
     pn2.util.pointnet_util.USE_FUSED_FP = fused_fp

@@ -445,6 +445,16 @@ int pn2_voxel_downsample(int n, const double *points, const double *colors, cons
                          double *out_points, double *out_colors, int *out_labels, int *out_count, int *status,
                          void *workspace, size_t workspace_bytes, void *stream);
 
+/* pn2_fp_mlp_fused with the first layer's product with the INTERPOLATED channels hoisted out by linearity:
+ * three_interpolate(points2) @ W1a == three_interpolate(points2 @ W1a) (pointnet_util.py:300-311 followed by the first conv
+ * of :312-325), and z = points2 @ W1a has the m known rows per cloud instead of the n unknown ones.  z (b*m, widths[0])
+ * replaces points2; w[0] = the c1 skip-link rows of the folded first-layer weight (c1 x widths[0]; NULL when c1 == 0),
+ * w[1..] / bias[0..] as in pn2_fp_mlp_fused.  nlayers = 2 or 3 (all widths multiples of 32, <= 128, LDS-resident).
+ * fp32 results differ from the un-hoisted order by rounding only (~1e-7 of the activation scale). */
+int pn2_fp_mlp_fused_pre(int b, int n, int m, int c1, const float *dist, const int *idx, const float *points1,
+                         const float *z, int nlayers, const int *widths, const float *const *w,
+                         const float *const *bias, float *y, void *stream);
+
 /* query_ball_point with the binning hoisted out: pn2_ball_query_bin sorts every cloud of a batch into the uniform grid of
  * `radius` ONCE (one workgroup per cloud; workspace = b * pn2_ball_query_bin_bytes(n) bytes, 256-byte aligned, n <= 8192);
  * pn2_query_ball_point_binned then answers the queries from it -- its workgroups (16 per cloud at m = 1024) copy the

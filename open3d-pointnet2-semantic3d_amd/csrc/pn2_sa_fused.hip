@@ -228,7 +228,13 @@ __device__ __forceinline__ void rows_store(const f32x16 (&acc)[NT], const float*
 //                front end [ three_interpolate(points2, idx, w(dist)) | points1 ] (pointnet_util.py:300-311),
 //                same fp32 operation order as fp_interp_concat_kernel / the reference ops.
 // NW waves per workgroup share one LDS copy of the weights.
-template <int L, int NT1, int NT2, int NT3, bool VEC8, bool DENSE, bool POOL, int NW, bool INTERP = false>
+// PREZ (with INTERP): the first layer's product with the INTERPOLATED channels is hoisted out of the kernel by
+//                linearity: interp(points2) @ W1a == interp(points2 @ W1a), and Z = points2 @ W1a has m rows per cloud
+//                instead of n (8x fewer at every FP level of semantic.json).  p.points is then Z (b*m, W1): the three
+//                gathered rows of Z are blended STRAIGHT INTO the accumulator layout of layer 1 (register r of tile nt
+//                <-> channel 32 nt + (r & 3) + 8 (r >> 2) + 4 half: four consecutive channels per 16-byte load), only the
+//                c1 skip-link channels still go through the MFMA.  Same gather traffic, (c2 / 2) * NT1 fewer MFMAs per tile.
+template <int L, int NT1, int NT2, int NT3, bool VEC8, bool DENSE, bool POOL, int NW, bool INTERP = false, bool PREZ = false>
 __global__ void __launch_bounds__(NW * 64, (NW >= 8 ? NW / 4 : 2))  // NW <= 8: 2 waves/SIMD (<= 256 VGPR+AGPR per lane)
 sa_fused_kernel(SaFusedParams p) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -238,7 +244,7 @@ sa_fused_kernel(SaFusedParams p) {
     const int l31 = lane & 31;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     constexpr int W1 = NT1 * 32, W2 = NT2 * 32, W3 = NT3 * 32;
-    const int c = p.c;
+    const int c = PREZ ? 0 : p.c;  // PREZ: layer 1's LDS weights cover the skip-link channels only
     const int c1 = INTERP ? p.c1 : 0;
     const int steps1 = l1_steps(c, VEC8, DENSE, c1);
     constexpr int NTH = NW * 64;
@@ -344,6 +350,34 @@ sa_fused_kernel(SaFusedParams p) {
             const float norm = (r1 + r2) + r3;
             const float w1 = r1 / norm, w2 = r2 / norm, w3 = r3 / norm;
             const size_t kb = (prow / (size_t)p.n) * (size_t)p.m;  // first known row of this batch element
+            if constexpr (PREZ) {
+                const f32x4* __restrict__ z1 = reinterpret_cast<const f32x4*>(p.points + (kb + ir[0]) * W1) + half;
+                const f32x4* __restrict__ z2 = reinterpret_cast<const f32x4*>(p.points + (kb + ir[1]) * W1) + half;
+                const f32x4* __restrict__ z3 = reinterpret_cast<const f32x4*>(p.points + (kb + ir[2]) * W1) + half;
+                if (c1 > 0) {  // skip-link channels: the only MFMA work left in layer 1
+                    const float* __restrict__ fp = p.points1 + prow * c1;
+                    const int ns = (c1 + 1) >> 1;
+                    for (int sp = 0; sp < ns; ++sp) {
+                        const int ch = 2 * sp + half;
+                        const float v = ch < c1 ? fp[ch] : 0.f;
+                        mfma_step<NT1, LAST1>(a1, w1l + sp * 2 * W1, v);
+                    }
+                }
+#pragma unroll
+                for (int nt = 0; nt < NT1; ++nt) {
+                    f32x4 q1[4], q2[4], q3[4];
+#pragma unroll
+                    for (int rq = 0; rq < 4; ++rq) {  // float4 index of channel 32 nt + 8 rq + 4 half
+                        q1[rq] = z1[nt * 8 + rq * 2]; q2[rq] = z2[nt * 8 + rq * 2]; q3[rq] = z3[nt * 8 + rq * 2];
+                    }
+#pragma unroll
+                    for (int rq = 0; rq < 4; ++rq) {
+                        const f32x4 cur = (q1[rq] * w1 + q2[rq] * w2) + q3[rq] * w3;
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) a1[nt][4 * rq + e] += cur[e];
+                    }
+                }
+            } else {
             const f32x4* __restrict__ f1 = reinterpret_cast<const f32x4*>(p.points + (kb + ir[0]) * c) + half;
             const f32x4* __restrict__ f2 = reinterpret_cast<const f32x4*>(p.points + (kb + ir[1]) * c) + half;
             const f32x4* __restrict__ f3 = reinterpret_cast<const f32x4*>(p.points + (kb + ir[2]) * c) + half;
@@ -375,6 +409,7 @@ sa_fused_kernel(SaFusedParams p) {
                     mfma_step<NT1, LAST1>(a1, w1l + (4 * nt8 + sp) * 2 * W1, v);
                 }
             }
+            }  // !PREZ
         } else if constexpr (VEC8) {
             const f32x4* __restrict__ fp =
                 reinterpret_cast<const f32x4*>(p.points + prow * c) + half;
@@ -440,10 +475,10 @@ sa_fused_kernel(SaFusedParams p) {
 PN2_TUNABLE(int, g_chain_nw, 0)      // tuning hook (pn2_debug_set(7, v)): 16 = 16-wave workgroups for the single-layer kernels
 PN2_TUNABLE(int, g_chain_grid, 256)  // tuning hook (pn2_debug_set(6, v)): persistent workgroups of the 1-per-CU configuration
 
-template <int L, int NT1, int NT2, int NT3, bool VEC8, bool DENSE, bool POOL, bool INTERP = false>
+template <int L, int NT1, int NT2, int NT3, bool VEC8, bool DENSE, bool POOL, bool INTERP = false, bool PREZ = false>
 int launch_chain(const SaFusedParams& p, hipStream_t st) {
     constexpr int W1 = NT1 * 32, W2 = NT2 * 32, W3 = NT3 * 32;
-    const int steps1 = l1_steps(p.c, VEC8, DENSE, INTERP ? p.c1 : 0);
+    const int steps1 = l1_steps(PREZ ? 0 : p.c, VEC8, DENSE, INTERP ? p.c1 : 0);
     size_t floats = (size_t)steps1 * 2 * W1 + W1;
     if (L >= 2) floats += (size_t)W1 * W2 + W2;
     if (L >= 3) floats += (size_t)W2 * W3 + W3;
@@ -452,7 +487,7 @@ int launch_chain(const SaFusedParams& p, hipStream_t st) {
     const int need4 = (p.groups + 3) / 4;
     if constexpr (L == 1) {
         if (g_chain_nw == 16 && p.groups >= 4096) {  // one 16-wave workgroup per CU: 4 waves/SIMD share the MFMA pipe
-            auto kern = sa_fused_kernel<L, NT1, NT2, NT3, VEC8, DENSE, POOL, 16, INTERP>;
+            auto kern = sa_fused_kernel<L, NT1, NT2, NT3, VEC8, DENSE, POOL, 16, INTERP, PREZ>;
             static bool attr_set = false;
             if (!attr_set) {
                 hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
@@ -468,7 +503,7 @@ int launch_chain(const SaFusedParams& p, hipStream_t st) {
     if (bytes > 78 * 1024 && p.groups >= 2048) {
         // only one workgroup fits per CU: give it 8 waves (2 per SIMD) sharing the LDS weights.
         // (With fewer than 2048 tiles, 4-wave workgroups spread the tiles over twice as many CUs.)
-        auto kern = sa_fused_kernel<L, NT1, NT2, NT3, VEC8, DENSE, POOL, 8, INTERP>;
+        auto kern = sa_fused_kernel<L, NT1, NT2, NT3, VEC8, DENSE, POOL, 8, INTERP, PREZ>;
         static bool attr_set = false;  // per instantiation; benign race (idempotent call)
         if (!attr_set) {
             hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
@@ -481,7 +516,7 @@ int launch_chain(const SaFusedParams& p, hipStream_t st) {
         if (grid > need8) grid = need8;
         kern<<<grid, 512, bytes, st>>>(p);
     } else {
-        auto kern = sa_fused_kernel<L, NT1, NT2, NT3, VEC8, DENSE, POOL, 4, INTERP>;
+        auto kern = sa_fused_kernel<L, NT1, NT2, NT3, VEC8, DENSE, POOL, 4, INTERP, PREZ>;
         static bool attr_set = false;
         if (!attr_set) {
             hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
@@ -666,6 +701,38 @@ extern "C" int pn2_fp_mlp_fused(int b, int n, int m, int c1, int c2, const float
         case 140: return launch_chain<1, 4, 1, 1, true, true, false, true>(p, st);
         case 224: return launch_chain<2, 2, 4, 1, true, true, false, true>(p, st);
         case 120: return launch_chain<1, 2, 1, 1, true, true, false, true>(p, st);
+        default: return PN2_EUNSUP;
+    }
+}
+
+// pn2_fp_mlp_fused with the first layer's product HOISTED (see PREZ above): z = points2 @ W1[:c2] (b*m rows, widths[0]
+// wide; the caller computes it with pn2_linear, no bias, no activation -- 1/8 of the rows of the FP level) replaces
+// points2, w[0] holds only the c1 skip-link rows of W1 (c1 x widths[0]; may be NULL when c1 == 0).  nlayers counts ALL
+// layers (2 or 3); the chain after the front end is LDS-resident as in pn2_fp_mlp_fused.
+// Values: interp(points2) @ W1a == interp(points2 @ W1a) exactly in real arithmetic; in fp32 the two orders differ by
+// rounding only (1e-7 of the activation scale; tests/test_layers_gpu.py holds both to the fp64 oracle at 1e-5).
+extern "C" int pn2_fp_mlp_fused_pre(int b, int n, int m, int c1, const float* dist, const int* idx, const float* points1,
+                                    const float* z, int nlayers, const int* widths, const float* const* w,
+                                    const float* const* bias, float* y, void* stream) {
+    if (b <= 0 || n <= 0 || m <= 0 || c1 < 0 || nlayers <= 0) return PN2_EINVAL;
+    if (!dist || !idx || !z || !widths || !w || !bias || !y || (c1 > 0 && (!points1 || !w[0]))) return PN2_ENULL;
+    if ((long long)b * n > 0x7fffffffLL - 32) return PN2_ERANGE;
+    if (nlayers < 2 || nlayers > 3 || (uintptr_t)z % 16 != 0) return PN2_EUNSUP;
+    SaFusedParams p{};
+    p.n = n; p.m = m; p.c = widths[0]; p.c1 = c1; p.rows = b * n; p.groups = (b * n + 31) / 32;
+    p.points = z; p.points1 = points1; p.dist = dist; p.idx = idx; p.out = y;
+    int nt[3] = {0, 0, 0};
+    for (int l = 0; l < nlayers; ++l) {
+        if (widths[l] <= 0 || widths[l] % 32 != 0 || widths[l] > 128) return PN2_EUNSUP;
+        if (!bias[l] || (l > 0 && !w[l])) return PN2_ENULL;
+        if (w[l] && (uintptr_t)w[l] % 16 != 0) return PN2_EUNSUP;
+        p.w[l] = widths[l]; p.W[l] = w[l] ? w[l] : bias[l] /* never read: c1 == 0 */; p.bias[l] = bias[l];
+        nt[l] = widths[l] / 32;
+    }
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    switch (nlayers * 1000 + nt[0] * 100 + nt[1] * 10 + nt[2]) {
+        case 3444: return launch_chain<3, 4, 4, 4, true, true, false, true, true>(p, st);  // FP4 of semantic.json: 131 -> 128 -> 128 -> 128
+        case 2440: return launch_chain<2, 4, 4, 1, true, true, false, true, true>(p, st);
         default: return PN2_EUNSUP;
     }
 }

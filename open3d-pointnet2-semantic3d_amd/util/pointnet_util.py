@@ -223,7 +223,12 @@ class _FPInterpConcat(torch.autograd.Function):
 USE_FUSED_SA = True
 
 
-USE_BINNED_BALL_QUERY = True  # A/B: bin the cloud once per level on a side stream while the FPS of the level runs
+USE_HOISTED_FP = True  # A/B: first FP layer's product with the interpolated channels computed on the known points (linearity)
+# Bin the cloud once per level on a side stream while the FPS of the level runs (tf_grouping.ball_query_bin).  OFF by default:
+# the binned query is 15.8 vs 18.4 us at the SA1 shape, but the forked stream inside every batch's graph costs the
+# throughput regime 0.49 -> 0.64 ms per step (4 batches in flight: twice the streams per hardware queue, as with the
+# two-stream geometry capture) and the single batch nothing (0.95 -> 0.98 ms).  The ops stay available.
+USE_BINNED_BALL_QUERY = False
 
 _bin_streams = {}
 
@@ -481,7 +486,16 @@ def dense_mlp_inference(x2d, cin, mlp, scope_fmt, bn=True, fp_front=None):
         c = cout
     i, h = 0, x2d
     if h is None:
-        if (USE_FUSED_FP and USE_MLP_CHAIN and rows >= 65536 and points2.shape[2] % 8 == 0
+        if (USE_FUSED_FP and USE_MLP_CHAIN and USE_HOISTED_FP and rows >= 65536 and len(mlp) >= 2
+                and all(w <= 128 and w % 32 == 0 for w in mlp[:3])):
+            # first layer hoisted by linearity (interp(points2) @ W == interp(points2 @ W)): points2 @ W1a on the m known
+            # rows, then front end + up to three LDS-resident layers in one kernel
+            take = min(3, len(mlp))
+            y = tf_util.hip_fp_mlp_fused_pre(dist, idx, points1, points2, [folded[k][0] for k in range(take)],
+                                             [folded[k][1] for k in range(take)])
+            if y is not None:
+                h, i = y, take
+        if (h is None and USE_FUSED_FP and USE_MLP_CHAIN and rows >= 65536 and points2.shape[2] % 8 == 0
                 and mlp[0] <= 128 and mlp[0] % 32 == 0):
             for take in (2, 1):
                 if take > len(mlp) or any(w > 128 or w % 32 for w in mlp[:take]):

@@ -386,6 +386,51 @@ def hip_fp_mlp_fused(dist, idx, points1, points2, ws, bs):
     return y
 
 
+def split_first_layer(w2, c2, c1, key):
+    """(W1a, W1b) = the rows of a folded first-layer weight (c2 + c1 [+ pad], cout) that multiply the INTERPOLATED channels
+    (first c2) and the skip-link channels (next c1), as contiguous tensors; cached with the folded weight they come from."""
+    st = get_default_store()
+
+    def make():
+        w1b = w2[c2:c2 + c1].contiguous() if c1 > 0 else None
+        return w2[:c2].contiguous(), w1b
+    return st.folded((_full_name("split"), key, c2, c1), [w2], make)
+
+
+def hip_fp_mlp_fused_pre(dist, idx, points1, points2, ws, bs):
+    """The FP block with the first layer's product hoisted out by linearity (pn2_fp_mlp_fused_pre):
+    interp(points2) @ W1a == interp(points2 @ W1a), and Z = points2 @ W1a has the m KNOWN rows per cloud instead of the n
+    unknown ones (8x fewer at every level of semantic.json).  Z is one pn2_linear call (no bias, no activation); the fused
+    kernel blends three gathered rows of Z straight into its layer-1 accumulators and only the skip-link channels still
+    go through the MFMA.  ws[0] = the folded first-layer weight ((c2 + c1 [+ pad]) x w1), 2 or 3 layers, all <= 128 wide.
+    Returns (b*n, w_last), or None when the library reports the configuration as unsupported."""
+    import ctypes
+    from .._lib import PN2_EUNSUP
+    require_cuda(dist, idx, points1, points2)
+    b, n, _ = dist.shape
+    m, c2 = points2.shape[1], points2.shape[2]
+    c1 = 0 if points1 is None else points1.shape[2]
+    L = len(ws)
+    if L < 2 or L > 3 or any(w.shape[1] % 32 or w.shape[1] > 128 for w in ws):
+        return None
+    w1a, w1b = split_first_layer(ws[0], c2, c1, "fp_pre")
+    z = hip_linear(points2.reshape(b * m, c2), w1a, None, relu=False)  # (b*m, w1): the hoisted product
+    p1 = None if points1 is None else points1.contiguous()
+    widths = (ctypes.c_int * L)(*[w.shape[1] for w in ws])
+    wlist = [w1b] + list(ws[1:])
+    wptrs = (ctypes.c_void_p * L)(*[(w.data_ptr() if w is not None else None) for w in wlist])
+    bptrs = (ctypes.c_void_p * L)(*[bb.data_ptr() for bb in bs])
+    y = torch.empty((b * n, ws[-1].shape[1]), dtype=torch.float32, device=dist.device)
+    with torch.cuda.device(dist.device):
+        rc = lib.pn2_fp_mlp_fused_pre(b, n, m, c1, ptr(dist.contiguous()), ptr(idx.contiguous()), ptr(p1), ptr(z), L,
+                                      ctypes.cast(widths, ctypes.c_void_p), ctypes.cast(wptrs, ctypes.c_void_p),
+                                      ctypes.cast(bptrs, ctypes.c_void_p), ptr(y), stream_ptr())
+    if rc == PN2_EUNSUP:
+        return None
+    check(rc, "pn2_fp_mlp_fused_pre")
+    return y
+
+
 def hip_matmul(x2d, w):
     """y = x2d @ w on pn2_linear (no bias, no activation) -- the forward GEMM of the training path.  Output widths that
     are not a multiple of 32 (the 9-class head) run with zero-padded weight columns and are sliced back."""

@@ -487,6 +487,7 @@ def test_fp_module_chain_equals_per_layer_linear(pn2, oracle, cuda):
         pu.USE_MLP_CHAIN = True
     ref = oracle.fp_module(xyz1, xyz2, p1, p2, layer_dicts(store, "fp4", ["conv_0", "conv_1", "conv_2"]))
     close(a, ref)
+    close(outs[False], ref)
     close(b, ref)
 
 
@@ -545,13 +546,20 @@ def test_fp_module_fused_front_end_full_size(pn2, oracle, cuda):
     args = (T(xyz1, cuda), T(xyz2, cuda), T(p1, cuda), T(p2, cuda), [128, 128, 128], False, None)
     pu.pointnet_fp_module(*args, scope="fp4")
     randomize_bn(store, 34)
-    calls = []
-    pn2._lib.lib.trace = calls
-    try:
-        a = pu.pointnet_fp_module(*args, scope="fp4").cpu().numpy()
-    finally:
-        pn2._lib.lib.trace = None
-    assert "pn2_fp_mlp_fused" in [c[0] for c in calls] and "pn2_fp_interp_concat" not in [c[0] for c in calls]
+    outs = {}
+    for hoist in (True, False):  # first layer hoisted by linearity (pn2_fp_mlp_fused_pre) / computed in place (pn2_fp_mlp_fused)
+        calls = []
+        pn2._lib.lib.trace = calls
+        pu.USE_HOISTED_FP = hoist
+        try:
+            outs[hoist] = pu.pointnet_fp_module(*args, scope="fp4").cpu().numpy()
+        finally:
+            pn2._lib.lib.trace = None
+            pu.USE_HOISTED_FP = True
+        names = [c[0] for c in calls]
+        assert ("pn2_fp_mlp_fused_pre" if hoist else "pn2_fp_mlp_fused") in names and "pn2_fp_interp_concat" not in names
+    a = outs[True]
+    np.testing.assert_allclose(outs[True], outs[False], rtol=1e-5, atol=1e-5)  # same values up to fp32 summation order
     pu.USE_FUSED_FP = False
     try:
         b = pu.pointnet_fp_module(*args, scope="fp4").cpu().numpy()
@@ -560,6 +568,7 @@ def test_fp_module_fused_front_end_full_size(pn2, oracle, cuda):
     np.testing.assert_allclose(a, b, rtol=1e-5, atol=1e-5)
     ref = oracle.fp_module(xyz1, xyz2, p1, p2, layer_dicts(store, "fp4", ["conv_0", "conv_1", "conv_2"]))
     close(a, ref)
+    close(outs[False], ref)
 
 
 def test_training_step_single_gpu(pn2, cuda):

@@ -699,12 +699,12 @@ def test_query_ball_point_binned_equals_unbinned(pn2, oracle, cuda, case, mode):
     assert np.array_equal(b2.cpu().numpy(), o2) and np.array_equal(c2.cpu().numpy(), oc2)
     # the layer-level chain (bins built on a forked stream beside the FPS) equals the plain chain
     pu = pn2.util.pointnet_util
-    nx1, idx1 = pu.sa_geometry(T(xyz, cuda), m, r, K)
-    pu.USE_BINNED_BALL_QUERY = False
+    nx0, idx0 = pu.sa_geometry(T(xyz, cuda), m, r, K)
+    pu.USE_BINNED_BALL_QUERY = True
     try:
-        nx0, idx0 = pu.sa_geometry(T(xyz, cuda), m, r, K)
+        nx1, idx1 = pu.sa_geometry(T(xyz, cuda), m, r, K)
     finally:
-        pu.USE_BINNED_BALL_QUERY = True
+        pu.USE_BINNED_BALL_QUERY = False
     import torch
     assert torch.equal(nx1, nx0) and torch.equal(idx1, idx0)
     assert g.ball_query_bin(r, T(xyz[:, :1000].copy(), cuda)) is None  # below the grid kernel's range: caller scans
