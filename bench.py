@@ -134,6 +134,15 @@ def kernel_model(name, a):
             fl += 2 * b * n * cin * w
             cin = w
         return "mfma", fl
+    if name == "pn2_sa_mlp_fused_pre":  # ints: b, n, m, nsample, nlayers, pool, widths...  EXECUTED flops (xyz rows + later layers)
+        b, n, m, ns, L = a[:5]
+        widths = a[6:6 + L]
+        fl = 2 * b * m * ns * 3 * widths[0]
+        cin = widths[0]
+        for w in widths[1:]:
+            fl += 2 * b * m * ns * cin * w
+            cin = w
+        return "mfma", fl
     if name == "pn2_fp_mlp_fused_pre":  # ints: b, n, m, c1, nlayers, widths...  EXECUTED flops: skip channels + later layers
         b, n, m, c1, L = a[:5]
         widths = a[5:5 + L]
@@ -567,6 +576,7 @@ def main():
                 v.copy_((torch.rand(v.shape, generator=g) + 0.5).to(dev))
 
     pn2.util.pointnet_util.USE_HOISTED_FP = not args.no_hoist
+    pn2.util.pointnet_util.USE_HOISTED_SA = not args.no_hoist
     pn2.util.pointnet_util.USE_BINNED_BALL_QUERY = bool(args.binned_bq)
     pn2._lib.lib.dup = tuple(args.dup)
     fused_fp = args.fp_front != "unfused"

@@ -455,6 +455,16 @@ int pn2_fp_mlp_fused_pre(int b, int n, int m, int c1, const float *dist, const i
                          const float *z, int nlayers, const int *widths, const float *const *w,
                          const float *const *bias, float *y, void *stream);
 
+/* pn2_sa_mlp_max_fused / pn2_sa_mlp_rows_fused with the FEATURE part of the first layer hoisted by linearity:
+ * [xyz - centre | features] @ W1 = (xyz - centre) @ W1[:3] + (features @ W1[3:])[idx], and zf = features @ W1[3:] has one
+ * row per source point (b*n) instead of one per grouped neighbour (b*m*nsample).  zf (b*n, widths[0]) replaces `points`,
+ * w[0] = the 3 xyz rows of the folded first-layer weight.  pool != 0: max over the neighbours -> (b, m, w_last); else the
+ * un-pooled rows (b, m, nsample, w_last).  nsample = 32; widths multiples of 32, <= 128 ([64,64,128] pooled,
+ * [128,128] un-pooled, [128,128,128] pooled); PN2_EUNSUP otherwise. */
+int pn2_sa_mlp_fused_pre(int b, int n, int m, int nsample, const float *xyz, const float *new_xyz, const float *zf,
+                         const int *idx, int nlayers, const int *widths, const float *const *w,
+                         const float *const *bias, int pool, float *out, void *stream);
+
 /* query_ball_point with the binning hoisted out: pn2_ball_query_bin sorts every cloud of a batch into the uniform grid of
  * `radius` ONCE (one workgroup per cloud; workspace = b * pn2_ball_query_bin_bytes(n) bytes, 256-byte aligned, n <= 8192);
  * pn2_query_ball_point_binned then answers the queries from it -- its workgroups (16 per cloud at m = 1024) copy the

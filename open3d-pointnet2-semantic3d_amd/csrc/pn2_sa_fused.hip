@@ -410,6 +410,22 @@ sa_fused_kernel(SaFusedParams p) {
                 }
             }
             }  // !PREZ
+        } else if constexpr (PREZ) {
+            // set abstraction with the FEATURE part of layer 1 hoisted: [x - c | f] @ W1 = (x - c) @ W1[:3] + (f @ W1[3:]), and
+            // zf = points @ W1[3:] has one row per SOURCE point (n per cloud) instead of one per grouped neighbour (m K):
+            // the neighbour's row of zf is added straight into the accumulator layout.  (The xyz part stays on the MFMA --
+            // hoisting it too would subtract two large products, x @ W and c @ W, to get a small one.)
+            const f32x4* __restrict__ zr = reinterpret_cast<const f32x4*>(p.points + prow * W1) + half;
+#pragma unroll
+            for (int nt = 0; nt < NT1; ++nt) {
+                f32x4 q[4];
+#pragma unroll
+                for (int rq = 0; rq < 4; ++rq) q[rq] = zr[nt * 8 + rq * 2];
+#pragma unroll
+                for (int rq = 0; rq < 4; ++rq)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) a1[nt][4 * rq + e] += q[rq][e];
+            }
         } else if constexpr (VEC8) {
             const f32x4* __restrict__ fp =
                 reinterpret_cast<const f32x4*>(p.points + prow * c) + half;
@@ -735,4 +751,38 @@ extern "C" int pn2_fp_mlp_fused_pre(int b, int n, int m, int c1, const float* di
         case 2440: return launch_chain<2, 4, 4, 1, true, true, false, true, true>(p, st);
         default: return PN2_EUNSUP;
     }
+}
+
+// pn2_sa_mlp_max_fused / pn2_sa_mlp_rows_fused with the FEATURE part of the first layer hoisted by linearity:
+// zf = points @ W1[3:] (b*n rows, widths[0] wide: one per source point, computed by the caller with pn2_linear) replaces
+// `points`; w[0] = the 3 xyz rows of the folded first-layer weight (3 x widths[0]).  pool != 0: max over the K neighbours
+// (nsample = 32 only here), else the un-pooled (b, m, nsample, w_last) rows.  Same products, summed in a different order.
+extern "C" int pn2_sa_mlp_fused_pre(int b, int n, int m, int nsample, const float* xyz, const float* new_xyz, const float* zf,
+                                    const int* idx, int nlayers, const int* widths, const float* const* w,
+                                    const float* const* bias, int pool, float* out, void* stream) {
+    if (b <= 0 || n <= 0 || m <= 0 || nsample <= 0 || nlayers <= 0) return PN2_EINVAL;
+    if (!xyz || !new_xyz || !zf || !idx || !widths || !w || !bias || !out) return PN2_ENULL;
+    if (nlayers > 3 || nsample != 32 || (uintptr_t)zf % 16 != 0) return PN2_EUNSUP;
+    if ((long long)b * m * nsample > 0x7fffffffLL - 64) return PN2_ERANGE;
+    SaFusedParams p{};
+    p.n = n; p.m = m; p.c = widths[0]; p.kshift = 5;
+    p.groups = (int)(((long long)b * m * nsample) / 32); p.rows = p.groups * 32;
+    p.xyz = xyz; p.new_xyz = new_xyz; p.points = zf; p.idx = idx; p.out = out;
+    int nt[3] = {0, 0, 0};
+    for (int l = 0; l < nlayers; ++l) {
+        if (widths[l] <= 0 || widths[l] % 32 != 0 || widths[l] > 128) return PN2_EUNSUP;
+        if (!w[l] || !bias[l]) return PN2_ENULL;
+        if ((uintptr_t)w[l] % 16 != 0) return PN2_EUNSUP;
+        p.w[l] = widths[l]; p.W[l] = w[l]; p.bias[l] = bias[l];
+        nt[l] = widths[l] / 32;
+    }
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    const int key = nlayers * 1000 + nt[0] * 100 + nt[1] * 10 + nt[2];
+    if (pool) {
+        if (key == 3224) return launch_chain<3, 2, 2, 4, true, false, true, false, true>(p, st);  // SA2 of semantic.json: [64,64,128]
+        if (key == 3444) return launch_chain<3, 4, 4, 4, true, false, true, false, true>(p, st);
+        return PN2_EUNSUP;
+    }
+    if (key == 2440) return launch_chain<2, 4, 4, 1, true, false, false, false, true>(p, st);      // SA3: [128,128 | 256 on pn2_linear]
+    return PN2_EUNSUP;
 }

@@ -97,10 +97,26 @@ def _sa_fused_inference(xyz, new_xyz, points, idx, mlp, bn, conv_scope_fmt, pool
         cin = cout
     L = len(mlp)
     widths = (ctypes.c_int * L)(*mlp)
-    wptrs = (ctypes.c_void_p * L)(*[t.data_ptr() for t in ws])
-    bptrs = (ctypes.c_void_p * L)(*[t.data_ptr() for t in bs])
     oshape = (b, m, mlp[-1]) if pool else (b, m, nsample, mlp[-1])
     out = torch.empty(oshape, dtype=torch.float32, device=xyz.device)
+    if (USE_HOISTED_SA and not bf16 and nsample == 32 and c >= 32 and c % 4 == 0
+            and ((pool and tuple(mlp) in ((64, 64, 128), (128, 128, 128))) or (not pool and tuple(mlp) == (128, 128)))):
+        # feature part of the first layer hoisted by linearity: zf = points @ W1[3:] on the n source points (8x fewer rows
+        # than the m*K grouped neighbours at every level of semantic.json), its rows gathered into the accumulators
+        w1x, w1f = tf_util.split_first_layer(ws[0], 3, c, "sa_pre")   # rows [0,3) = xyz, [3, 3+c) = features
+        zf = tf_util.hip_linear(points.reshape(b * n, c), w1f, None, relu=False)
+        wl = [w1x] + ws[1:]
+        wptrs = (ctypes.c_void_p * L)(*[t.data_ptr() for t in wl])
+        bptrs = (ctypes.c_void_p * L)(*[t.data_ptr() for t in bs])
+        with torch.cuda.device(xyz.device):
+            rc = lib.pn2_sa_mlp_fused_pre(b, n, m, nsample, ptr(xyz), ptr(new_xyz), ptr(zf), ptr(idx), L,
+                                          ctypes.cast(widths, ctypes.c_void_p), ctypes.cast(wptrs, ctypes.c_void_p),
+                                          ctypes.cast(bptrs, ctypes.c_void_p), int(bool(pool)), ptr(out), stream_ptr())
+        if rc != PN2_EUNSUP:
+            check(rc, "pn2_sa_mlp_fused_pre")
+            return out
+    wptrs = (ctypes.c_void_p * L)(*[t.data_ptr() for t in ws])
+    bptrs = (ctypes.c_void_p * L)(*[t.data_ptr() for t in bs])
     pts = None if points is None else points.contiguous()
     fn = lib.pn2_sa_mlp_max_fused_bf16 if bf16 else (lib.pn2_sa_mlp_max_fused if pool else lib.pn2_sa_mlp_rows_fused)
     with torch.cuda.device(xyz.device):
@@ -223,6 +239,7 @@ class _FPInterpConcat(torch.autograd.Function):
 USE_FUSED_SA = True
 
 
+USE_HOISTED_SA = True  # A/B: feature part of the first SA layer computed on the source points (linearity)
 USE_HOISTED_FP = True  # A/B: first FP layer's product with the interpolated channels computed on the known points (linearity)
 # Bin the cloud once per level on a side stream while the FPS of the level runs (tf_grouping.ball_query_bin).  OFF by default:
 # the binned query is 15.8 vs 18.4 us at the SA1 shape, but the forked stream inside every batch's graph costs the

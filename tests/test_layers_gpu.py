@@ -467,6 +467,39 @@ def test_mlp_chain_rejects_what_does_not_fit(pn2, cuda):
     assert pn2.util.tf_util.hip_mlp_chain(x, [w], [b]) is None  # width 256 > 128 -> caller falls back
 
 
+@pytest.mark.parametrize("mlp,c,m", [([64, 64, 128], 64, 256), ([128, 128, 256], 128, 64), ([128, 128, 128], 32, 50)])
+def test_sa_module_hoisted_first_layer_equals_in_place(pn2, oracle, cuda, mlp, c, m):
+    """pn2_sa_mlp_fused_pre: the FEATURE part of the first SA layer computed once per source point (zf = points @ W1[3:],
+    n rows instead of m*K grouped rows) and gathered into the accumulators, the xyz part still on the MFMA.  Same products in
+    a different summation order: equals the in-place kernel to fp32 rounding and the fp64 oracle at 1e-5 (SA2 / SA3 shapes of
+    semantic.json + an odd one)."""
+    tfu, pu = pn2.util.tf_util, pn2.util.pointnet_util
+    rs = np.random.RandomState(m)
+    xyz = s_scene(m, 2, 1024)
+    pts = rs.randn(2, 1024, c).astype(np.float32)
+    store = tfu.set_default_store(tfu.VariableStore(device=cuda, seed=51))
+    kw = dict(npoint=m, radius=1.0, nsample=32, mlp=mlp, mlp2=None, group_all=False, is_training=False, bn_decay=None, scope="sa")
+    pu.pointnet_sa_module(T(xyz, cuda), T(pts, cuda), **kw)
+    randomize_bn(store, 52)
+    outs = {}
+    for hoist in (True, False):
+        calls = []
+        pn2._lib.lib.trace = calls
+        pu.USE_HOISTED_SA = hoist
+        try:
+            _, outs[hoist], idx = pu.pointnet_sa_module(T(xyz, cuda), T(pts, cuda), **kw)
+        finally:
+            pn2._lib.lib.trace = None
+            pu.USE_HOISTED_SA = True
+        assert ("pn2_sa_mlp_fused_pre" in [c_[0] for c_ in calls]) == hoist
+    a, b_ = outs[True].cpu().numpy(), outs[False].cpu().numpy()
+    np.testing.assert_allclose(a, b_, rtol=1e-5, atol=1e-5)
+    _, ref, ridx = oracle.sa_module(xyz, pts, m, 1.0, 32, layer_dicts(store, "sa", ["conv0", "conv1", "conv2"]))
+    assert np.array_equal(idx.cpu().numpy(), ridx)
+    close(a, ref)
+    close(b_, ref)
+
+
 def test_fp_module_chain_equals_per_layer_linear(pn2, oracle, cuda):
     """FP4-shaped module: the chained path and the one-launch-per-layer path agree to fp32 rounding."""
     tfu, pu = pn2.util.tf_util, pn2.util.pointnet_util
@@ -487,7 +520,6 @@ def test_fp_module_chain_equals_per_layer_linear(pn2, oracle, cuda):
         pu.USE_MLP_CHAIN = True
     ref = oracle.fp_module(xyz1, xyz2, p1, p2, layer_dicts(store, "fp4", ["conv_0", "conv_1", "conv_2"]))
     close(a, ref)
-    close(outs[False], ref)
     close(b, ref)
 
 
