@@ -134,6 +134,22 @@ def kernel_model(name, a):
             fl += 2 * b * n * cin * w
             cin = w
         return "mfma", fl
+    if name == "pn2_fp_mlp_wide_pre":  # ints: b, n, m, c1, nlayers, widths...   EXECUTED flops
+        b, n, m, c1, L = a[:5]
+        widths = a[5:5 + L]
+        fl, cin = 2 * b * n * c1 * widths[0], widths[0]
+        for w in widths[1:]:
+            fl += 2 * b * n * cin * w
+            cin = w
+        return "mfma", fl
+    if name == "pn2_sa_mlp_wide_pre":  # ints: b, n, m, nsample, nlayers, pool, widths...
+        b, n, m, ns, L = a[:5]
+        widths = a[6:6 + L]
+        fl, cin = 2 * b * m * ns * 3 * widths[0], widths[0]
+        for w in widths[1:]:
+            fl += 2 * b * m * ns * cin * w
+            cin = w
+        return "mfma", fl
     if name == "pn2_sa_mlp_fused_pre":  # ints: b, n, m, nsample, nlayers, pool, widths...  EXECUTED flops (xyz rows + later layers)
         b, n, m, ns, L = a[:5]
         widths = a[6:6 + L]

@@ -465,6 +465,17 @@ int pn2_sa_mlp_fused_pre(int b, int n, int m, int nsample, const float *xyz, con
                          const int *idx, int nlayers, const int *widths, const float *const *w,
                          const float *const *bias, int pool, float *out, void *stream);
 
+/* The wide-layer versions (pn2_fp_mlp_wide / pn2_sa_mlp_wide: widths 128 / 256 / 512, one launch per level) of the same
+ * hoisting.  FP: z = points2 @ W0[:c2] (b*m, widths[0]); w[0] = the c1 skip-link rows of the folded first-layer weight
+ * zero-padded to a multiple of 8 rows (c1 > 0, c1 % 4 == 0, n % 32 == 0).  SA: zf = points @ W0[feature rows]
+ * (b*n, widths[0]); w[0] = the 3 xyz rows + 5 zero rows (8 x widths[0]); nsample = 32. */
+int pn2_fp_mlp_wide_pre(int b, int n, int m, int c1, const float *dist, const int *idx, const float *points1,
+                        const float *z, int nlayers, const int *widths, const float *const *w,
+                        const float *const *bias, float *y, void *stream);
+int pn2_sa_mlp_wide_pre(int b, int n, int m, int nsample, const float *xyz, const float *new_xyz, const float *zf,
+                        const int *idx, int nlayers, const int *widths, const float *const *w,
+                        const float *const *bias, int pool, float *y, void *stream);
+
 /* query_ball_point with the binning hoisted out: pn2_ball_query_bin sorts every cloud of a batch into the uniform grid of
  * `radius` ONCE (one workgroup per cloud; workspace = b * pn2_ball_query_bin_bytes(n) bytes, 256-byte aligned, n <= 8192);
  * pn2_query_ball_point_binned then answers the queries from it -- its workgroups (16 per cloud at m = 1024) copy the

@@ -91,6 +91,10 @@ SIGNATURES = {
                              c_void_p, c_void_p, c_void_p],
     "pn2_sa_mlp_fused_pre": [c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p,
                              c_void_p, c_int, c_void_p, c_void_p],
+    "pn2_fp_mlp_wide_pre": [c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p,
+                            c_void_p, c_void_p, c_void_p],
+    "pn2_sa_mlp_wide_pre": [c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p,
+                            c_void_p, c_int, c_void_p, c_void_p],
     "pn2_ball_query_bin": [c_int, c_int, c_float, c_void_p, c_void_p, ctypes.c_size_t, c_void_p],
     "pn2_query_ball_point_binned": [c_int, c_int, c_int, c_float, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int,
                                     c_void_p],
@@ -195,6 +199,9 @@ class _LibProxy:
             elif name == "pn2_fp_mlp_fused":
                 wp = ctypes.cast(args[10], ctypes.POINTER(c_int))
                 ints += [wp[i] for i in range(args[9])]
+            elif name in ("pn2_fp_mlp_wide_pre", "pn2_sa_mlp_wide_pre"):  # (..4 ints.., 4 pointers, nlayers, widths, ...)
+                wp = ctypes.cast(args[9], ctypes.POINTER(c_int))
+                ints += [wp[i] for i in range(args[8])]
             elif name == "pn2_sa_mlp_fused_pre":  # (b, n, m, nsample, xyz, new_xyz, zf, idx, nlayers, widths, w, bias, pool, ...)
                 wp = ctypes.cast(args[9], ctypes.POINTER(c_int))
                 ints += [wp[i] for i in range(args[8])]

@@ -49,6 +49,11 @@ struct WideParams {
     const float* W[3];
     const float* bias[3];
     float* y;
+    // first layer hoisted by linearity (pn2_*_mlp_wide_pre): zpre = (source rows, w[0]) = points2 @ W0[interpolated rows]
+    // (FP, b*m rows) or points @ W0[feature rows] (SA, b*n rows).  The layer-0 tile then holds only the skip-link channels
+    // (FP: cin = c1) or dx dy dz (SA: cin = 3), and the layer-0 epilogue adds the blended / gathered rows of zpre.
+    const float* zpre;
+    int rowtab_off;     // floats from the start of LDS: the FP front end's 32 x 8 row table when zpre is set
     int sa[2];          // row strides (floats) of the two activation buffers
     int scratch_off;    // floats from the start of LDS (dedicated scratch)
     int scratch_alias;  // 1: the K-slice partial sums are parked in the layer's (consumed) input buffer
@@ -142,16 +147,25 @@ mlp_wide_kernel(WideParams p) {
             const float* __restrict__ ctr = p.new_xyz + (size_t)tile * 3;
             dx = q[0] - ctr[0]; dy = q[1] - ctr[1]; dz = q[2] - ctr[2];  // pointnet_util.py:44-46
         }
+        if (p.zpre) {  // features hoisted: the tile is [dx dy dz | 0 0 0 0 0]
+            if (tid < 32) {
+                myrow[0] = dx; myrow[1] = dy; myrow[2] = dz;
+                for (int k = 3; k < K0; ++k) myrow[k] = 0.f;
+            }
+        } else {
         stage4(32 * cv, cv, p.sa[0], [&](int r, int j) { return pts + (size_t)idx[r] * c + 4 * j; });
         if (tid < 32) {
             myrow[c] = dx; myrow[c + 1] = dy; myrow[c + 2] = dz;
             for (int k = c + 3; k < K0; ++k) myrow[k] = 0.f;
         }
+        }
     } else if constexpr (MODE == kWideInterp) {
         const int c2 = p.c2, c1 = p.c1, cv2 = c2 >> 2, cv1 = c1 >> 2;  // both % 4 == 0
         const int bi = row0 / p.n;  // p.n % 32 == 0: a tile never straddles two clouds
         const float* __restrict__ p2 = p.points + (size_t)bi * p.m * c2;
-        float* rowtab = smem + buf_off[1];  // 8 floats per row: w1 w2 w3 - | i1 i2 i3 - (buffer 1 is idle until layer 0 ends)
+        // 8 floats per row: w1 w2 w3 - | i1 i2 i3 -  (buffer 1 is idle until layer 0 ends; with zpre the table is still
+        // needed in the layer-0 epilogue, which writes buffer 1: a region of its own)
+        float* rowtab = smem + (p.zpre ? p.rowtab_off : buf_off[1]);
         if (tid < 32) {
             const size_t r = (size_t)row0 + tid;
             const float d1 = fmaxf(p.dist[r * 3 + 0], 1e-10f), d2 = fmaxf(p.dist[r * 3 + 1], 1e-10f);
@@ -163,7 +177,7 @@ mlp_wide_kernel(WideParams p) {
                 f32x4{__int_as_float(p.idx[r * 3 + 0]), __int_as_float(p.idx[r * 3 + 1]), __int_as_float(p.idx[r * 3 + 2]), 0.f};
         }
         __syncthreads();
-        const int count4 = 32 * cv2;
+        const int count4 = p.zpre ? 0 : 32 * cv2;  // interpolated channels hoisted: nothing to stage for them
         for (int base = 0; base < count4; base += 256 * 4) {  // 4 elements x 3 gathers in flight per thread
             f32x4 v[4];
 #pragma unroll
@@ -191,7 +205,7 @@ mlp_wide_kernel(WideParams p) {
             const float* __restrict__ p1 = p.points1 + (size_t)row0 * c1;
             for (int e = tid; e < 32 * cv1; e += 256) {
                 const int r = e / cv1, j = e - r * cv1;
-                *reinterpret_cast<f32x4*>(buf0 + r * p.sa[0] + c2 + 4 * j) = *reinterpret_cast<const f32x4*>(p1 + (size_t)r * c1 + 4 * j);
+                *reinterpret_cast<f32x4*>(buf0 + r * p.sa[0] + (p.zpre ? 0 : c2) + 4 * j) = *reinterpret_cast<const f32x4*>(p1 + (size_t)r * c1 + 4 * j);
             }
         }
         if (K0 > p.cin) {
@@ -338,6 +352,35 @@ mlp_wide_kernel(WideParams p) {
                 if (ks == 0) add(nq);
             }
         }
+        if (ks == 0 && l == 0 && p.zpre) {
+            // hoisted part of layer 0: this lane's four output columns (cb + 4 l31 .. +3) of the source rows of zpre
+            if constexpr (MODE == kWideInterp) {
+                const float* __restrict__ zb = p.zpre + (size_t)(row0 / p.n) * p.m * N + cb + 4 * l31;
+                const float* rowtab = smem + p.rowtab_off;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int row = (r & 3) + 8 * (r >> 2) + 4 * half;
+                    const f32x4 wq = *reinterpret_cast<const f32x4*>(rowtab + row * 8);
+                    const f32x4 iq = *reinterpret_cast<const f32x4*>(rowtab + row * 8 + 4);
+                    const f32x4 z1 = *reinterpret_cast<const f32x4*>(zb + (size_t)__float_as_int(iq[0]) * N);
+                    const f32x4 z2 = *reinterpret_cast<const f32x4*>(zb + (size_t)__float_as_int(iq[1]) * N);
+                    const f32x4 z3 = *reinterpret_cast<const f32x4*>(zb + (size_t)__float_as_int(iq[2]) * N);
+                    const f32x4 z = (z1 * wq[0] + z2 * wq[1]) + z3 * wq[2];
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) acc[t][r] += z[t];
+                }
+            } else if constexpr (MODE == kWideGather) {
+                const float* __restrict__ zb = p.zpre + (size_t)(tile / p.m) * p.n * N + cb + 4 * l31;
+                const int* __restrict__ idx = p.idx + (size_t)tile * 32;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int row = (r & 3) + 8 * (r >> 2) + 4 * half;
+                    const f32x4 z = *reinterpret_cast<const f32x4*>(zb + (size_t)idx[row] * N);
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) acc[t][r] += z[t];
+                }
+            }
+        }
         if (ks == 0) {
             const f32x4 bv = *reinterpret_cast<const f32x4*>(p.bias[l] + cb + 4 * l31);
             const bool relu = !lastl || p.relu_last;
@@ -400,7 +443,8 @@ int launch_mlp_wide(WideParams& p, int mode, hipStream_t st) {
     (void)kin;
     p.scratch_off = 32 * (p.sa[0] + p.sa[1]);
     p.scratch_alias = sliced && alias_ok;
-    const size_t lds = sizeof(float) * ((size_t)p.scratch_off + (sliced && !alias_ok ? (size_t)2 * 64 * 64 : 0));
+    p.rowtab_off = p.scratch_off + (sliced && !alias_ok ? 2 * 64 * 64 : 0);
+    const size_t lds = sizeof(float) * ((size_t)p.rowtab_off + (p.zpre && mode == kWideInterp ? 32 * 8 : 0));
     if (lds > 160 * 1024) return PN2_EUNSUP;
     const void* kern = mode == kWideGather ? reinterpret_cast<const void*>(mlp_wide_kernel<kWideGather>)
                        : mode == kWideInterp ? reinterpret_cast<const void*>(mlp_wide_kernel<kWideInterp>)
@@ -479,4 +523,41 @@ extern "C" int pn2_fp_mlp_wide(int b, int n, int m, int c1, int c2, const float*
     p.n = n; p.m = m; p.c1 = c1; p.c2 = c2; p.dist = dist; p.idx = idx; p.points = points2; p.points1 = points1; p.y = y;
     for (int l = 0; l < nlayers; ++l) { p.w[l] = widths[l]; p.W[l] = w[l]; p.bias[l] = bias[l]; }
     return launch_mlp_wide(p, kWideInterp, static_cast<hipStream_t>(stream));
+}
+
+// pn2_fp_mlp_wide with the first layer's product with the interpolated channels hoisted by linearity (see
+// pn2_fp_mlp_fused_pre): z = points2 @ W0[:c2] (b*m rows, widths[0] wide) replaces points2; w[0] = the c1 skip-link rows of
+// the folded first-layer weight, zero-padded to a multiple of 8 rows.  c1 > 0, c1 % 4 == 0.
+extern "C" int pn2_fp_mlp_wide_pre(int b, int n, int m, int c1, const float* dist, const int* idx, const float* points1,
+                                   const float* z, int nlayers, const int* widths, const float* const* w,
+                                   const float* const* bias, float* y, void* stream) {
+    if (b <= 0 || n <= 0 || m < 3 || c1 <= 0) return PN2_EINVAL;
+    if (!dist || !idx || !z || !y || !points1) return PN2_ENULL;
+    if (n % 32 != 0 || c1 % 4 != 0 || (((uintptr_t)z | (uintptr_t)points1 | (uintptr_t)y) & 15)) return PN2_EUNSUP;
+    int rc = check_layers(nlayers, widths, w, bias);
+    if (rc != PN2_OK) return rc;
+    if ((long long)b * n + 64 > 0x7fffffffLL) return PN2_ERANGE;
+    WideParams p = {};
+    p.rows = b * n; p.cin = c1; p.nlayers = nlayers; p.pool = 0; p.relu_last = 1;
+    p.n = n; p.m = m; p.c1 = c1; p.c2 = 0; p.dist = dist; p.idx = idx; p.points = nullptr; p.points1 = points1; p.y = y; p.zpre = z;
+    for (int l = 0; l < nlayers; ++l) { p.w[l] = widths[l]; p.W[l] = w[l]; p.bias[l] = bias[l]; }
+    return launch_mlp_wide(p, kWideInterp, static_cast<hipStream_t>(stream));
+}
+
+// pn2_sa_mlp_wide with the FEATURE part of the first layer hoisted (see pn2_sa_mlp_fused_pre): zf = points @ W0[3:] (b*n
+// rows, widths[0] wide) replaces points; w[0] = the 3 xyz rows of the folded first-layer weight + 5 zero rows (8 x widths[0]).
+extern "C" int pn2_sa_mlp_wide_pre(int b, int n, int m, int nsample, const float* xyz, const float* new_xyz, const float* zf,
+                                   const int* idx, int nlayers, const int* widths, const float* const* w,
+                                   const float* const* bias, int pool, float* y, void* stream) {
+    if (b <= 0 || n <= 0 || m <= 0) return PN2_EINVAL;
+    if (!xyz || !new_xyz || !zf || !idx || !y) return PN2_ENULL;
+    if (nsample != 32 || (((uintptr_t)zf | (uintptr_t)y) & 15)) return PN2_EUNSUP;
+    int rc = check_layers(nlayers, widths, w, bias);
+    if (rc != PN2_OK) return rc;
+    if ((long long)b * m * 32 + 64 > 0x7fffffffLL) return PN2_ERANGE;
+    WideParams p = {};
+    p.rows = b * m * 32; p.cin = 3; p.x_stride = 0; p.nlayers = nlayers; p.pool = pool ? 32 : 0; p.relu_last = 1;
+    p.n = n; p.m = m; p.c = 4; p.xyz = xyz; p.new_xyz = new_xyz; p.points = zf; p.idx = idx; p.y = y; p.zpre = zf;
+    for (int l = 0; l < nlayers; ++l) { p.w[l] = widths[l]; p.W[l] = w[l]; p.bias[l] = bias[l]; }
+    return launch_mlp_wide(p, kWideGather, static_cast<hipStream_t>(stream));
 }

@@ -317,7 +317,10 @@ def sa_features_inference(xyz, new_xyz, points, idx, mlp, bn=True, bn_decay=None
                 else:
                     folded.append(tf_util.folded_dense(cprev, cout, bn, (1, 1, cprev, cout), pad_to=32))
             cprev = cout
-        new_points = tf_util.hip_sa_mlp_wide(xyz, new_xyz, points, idx, [f[0] for f in folded], [f[1] for f in folded])
+        if USE_HOISTED_SA:
+            new_points = tf_util.hip_sa_mlp_wide_pre(xyz, new_xyz, points, idx, [f[0] for f in folded], [f[1] for f in folded])
+        if new_points is None:
+            new_points = tf_util.hip_sa_mlp_wide(xyz, new_xyz, points, idx, [f[0] for f in folded], [f[1] for f in folded])
     if new_points is None:
         h = _sa_group_concat(xyz, new_xyz, points, idx)  # (B,M,K,3+C)
         pool_ok = nsample == 16 or nsample % 32 == 0
@@ -527,8 +530,13 @@ def dense_mlp_inference(x2d, cin, mlp, scope_fmt, bn=True, fp_front=None):
                 and all(w in (128, 256, 512) for w in mlp[:3])):
             # coarse FP levels: front end + the whole MLP in one launch (pn2_fp_mlp_wide)
             take = min(3, len(mlp))
-            y = tf_util.hip_fp_mlp_wide(dist, idx, points1, points2, [folded[k][0] for k in range(take)],
-                                        [folded[k][1] for k in range(take)])
+            y = None
+            if USE_HOISTED_FP and points1 is not None:
+                y = tf_util.hip_fp_mlp_wide_pre(dist, idx, points1, points2, [folded[k][0] for k in range(take)],
+                                                [folded[k][1] for k in range(take)])
+            if y is None:
+                y = tf_util.hip_fp_mlp_wide(dist, idx, points1, points2, [folded[k][0] for k in range(take)],
+                                            [folded[k][1] for k in range(take)])
             if y is not None:
                 h, i = y, take
         if h is None:

@@ -360,6 +360,51 @@ def hip_sa_mlp_wide(xyz, new_xyz, points, idx, ws, bs, pool=True):
     return y
 
 
+def hip_fp_mlp_wide_pre(dist, idx, points1, points2, ws, bs):
+    """pn2_fp_mlp_wide with the first layer hoisted by linearity (see hip_fp_mlp_fused_pre): z = points2 @ W0[:c2] on the
+    known points; the kernel's layer-0 tile holds only the skip-link channels.  -> (b*n, w_last) or None when unsupported."""
+    from .._lib import PN2_EUNSUP
+    require_cuda(dist, idx, points1, points2)
+    if points1 is None:
+        return None
+    b, n, _ = dist.shape
+    m, c2 = points2.shape[1], points2.shape[2]
+    c1 = points1.shape[2]
+    w0a, w0b = split_first_layer(ws[0], c2, c1, "fp_wide_pre", pad_b_rows=8)
+    z = hip_linear(points2.reshape(b * m, c2), w0a, None, relu=False)
+    L, widths, wptrs, bptrs, keep = _layer_arrays([w0b] + list(ws[1:]), bs)
+    y = torch.empty((b * n, ws[-1].shape[1]), dtype=torch.float32, device=dist.device)
+    with torch.cuda.device(dist.device):
+        rc = lib.pn2_fp_mlp_wide_pre(b, n, m, c1, ptr(dist.contiguous()), ptr(idx.contiguous()), ptr(points1.contiguous()), ptr(z),
+                                     L, widths, wptrs, bptrs, ptr(y), stream_ptr())
+    if rc == PN2_EUNSUP:
+        return None
+    check(rc, "pn2_fp_mlp_wide_pre")
+    return y
+
+
+def hip_sa_mlp_wide_pre(xyz, new_xyz, points, idx, ws, bs, pool=True):
+    """pn2_sa_mlp_wide with the feature part of the first layer hoisted: zf = points @ W0[feature rows] on the source points.
+    ws[0] in the wide kernel's row order [features (c) | xyz (3) | zero pad].  -> (b, m, w_last) or None when unsupported."""
+    from .._lib import PN2_EUNSUP
+    require_cuda(xyz, new_xyz, points, idx)
+    b, n, _ = xyz.shape
+    m, ns = idx.shape[1], idx.shape[2]
+    c = points.shape[2]
+    w0f, w0x = split_first_layer(ws[0], c, 3, "sa_wide_pre", pad_b_rows=8)
+    zf = hip_linear(points.reshape(b * n, c), w0f, None, relu=False)
+    L, widths, wptrs, bptrs, keep = _layer_arrays([w0x] + list(ws[1:]), bs)
+    wl = ws[-1].shape[1]
+    y = torch.empty((b, m, wl) if pool else (b, m, ns, wl), dtype=torch.float32, device=xyz.device)
+    with torch.cuda.device(xyz.device):
+        rc = lib.pn2_sa_mlp_wide_pre(b, n, m, ns, ptr(xyz.contiguous()), ptr(new_xyz.contiguous()), ptr(zf), ptr(idx.contiguous()),
+                                     L, widths, wptrs, bptrs, int(bool(pool)), ptr(y), stream_ptr())
+    if rc == PN2_EUNSUP:
+        return None
+    check(rc, "pn2_sa_mlp_wide_pre")
+    return y
+
+
 def hip_fp_mlp_fused(dist, idx, points1, points2, ws, bs):
     """[three_interpolate(points2) | points1] -> up to two dense layers in ONE kernel (pn2_fp_mlp_fused);
     returns (b*n, w_last) or None when the library reports the configuration as unsupported."""
@@ -386,15 +431,18 @@ def hip_fp_mlp_fused(dist, idx, points1, points2, ws, bs):
     return y
 
 
-def split_first_layer(w2, c2, c1, key):
-    """(W1a, W1b) = the rows of a folded first-layer weight (c2 + c1 [+ pad], cout) that multiply the INTERPOLATED channels
-    (first c2) and the skip-link channels (next c1), as contiguous tensors; cached with the folded weight they come from."""
+def split_first_layer(w2, c2, c1, key, pad_b_rows=None):
+    """(W1a, W1b) = rows [0, c2) and [c2, c2 + c1) of a folded first-layer weight (>= c2 + c1 rows, cout) as contiguous
+    tensors (the part whose product is hoisted / the part that stays in the kernel); W1b zero-padded to a multiple of
+    pad_b_rows rows when given.  Cached with the folded weight they come from."""
     st = get_default_store()
 
     def make():
-        w1b = w2[c2:c2 + c1].contiguous() if c1 > 0 else None
-        return w2[:c2].contiguous(), w1b
-    return st.folded((_full_name("split"), key, c2, c1), [w2], make)
+        w1b = w2[c2:c2 + c1] if c1 > 0 else None
+        if w1b is not None and pad_b_rows and c1 % pad_b_rows:
+            w1b = F.pad(w1b, (0, 0, 0, pad_b_rows - c1 % pad_b_rows))
+        return w2[:c2].contiguous(), (None if w1b is None else w1b.contiguous())
+    return st.folded((_full_name("split"), key, c2, c1, pad_b_rows), [w2], make)
 
 
 def hip_fp_mlp_fused_pre(dist, idx, points1, points2, ws, bs):
