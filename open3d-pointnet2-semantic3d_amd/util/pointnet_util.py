@@ -104,7 +104,7 @@ def _sa_fused_inference(xyz, new_xyz, points, idx, mlp, bn, conv_scope_fmt, pool
         # feature part of the first layer hoisted by linearity: zf = points @ W1[3:] on the n source points (8x fewer rows
         # than the m*K grouped neighbours at every level of semantic.json), its rows gathered into the accumulators
         w1x, w1f = tf_util.split_first_layer(ws[0], 3, c, "sa_pre")   # rows [0,3) = xyz, [3, 3+c) = features
-        zf = tf_util.hip_linear(points.reshape(b * n, c), w1f, None, relu=False)
+        zf = tf_util.hoist_gemm(points.reshape(b * n, c), w1f)
         wl = [w1x] + ws[1:]
         wptrs = (ctypes.c_void_p * L)(*[t.data_ptr() for t in wl])
         bptrs = (ctypes.c_void_p * L)(*[t.data_ptr() for t in bs])
