@@ -179,6 +179,28 @@ def kernel_model(name, a):
     return "hbm", 0
 
 
+def reference_flops(pn2, hp, B, N):
+    """MFMA flops of one step in the reference's own formulation (every 1x1 conv of every SA / FP module applied to the
+    grouped / concatenated tensor: SURVEY.md 8(d)'s 2*rows*cin*cout).  The product executes fewer: the first layer of a
+    module is applied to the SOURCE rows where linearity allows (DESIGN.md 4 'hoisting')."""
+    mdl = pn2.model
+    npts = [N] + [hp["l%d_npoint" % i] for i in (1, 2, 3, 4)]
+    width = [3 * int(hp["use_color"])] + [w[-1] for w in mdl.SA_MLPS]
+    fl = 0
+    for li in range(4):
+        rows, cin = B * npts[li + 1] * hp["l%d_nsample" % (li + 1)], 3 + width[li]
+        for w in mdl.SA_MLPS[li]:
+            fl, cin = fl + 2 * rows * cin * w, w
+    up = width[4]
+    for fi in range(4):
+        lvl = 3 - fi
+        rows, cin = B * npts[lvl], width[lvl] + up
+        for w in mdl.FP_MLPS[fi]:
+            fl, cin = fl + 2 * rows * cin * w, w
+        up = cin
+    return fl
+
+
 def summarize_trace(trace, steps):
     """aggregate (name, args) -> avg ms per launch, launches per step, roofline numbers."""
     agg = {}
@@ -234,21 +256,23 @@ def north_star_kernels(pn2, dev):
     idx_b, _ = g.query_ball_point_binned(0.5, K, xyz, new_xyz, bins)
     assert torch.equal(idx_b, idx)
     t_bq_self = time_call(lambda: pn2.query_ball_point(0.5, K, xyz, new_xyz), 20)           # every workgroup bins the cloud itself
-    t_bq = time_call(lambda: g.query_ball_point_binned(0.5, K, xyz, new_xyz, bins), 20)     # the product path (sa_geometry)
+    t_bq = time_call(lambda: g.query_ball_point_binned(0.5, K, xyz, new_xyz, bins), 20)     # variant: cloud binned once
     t_gp = time_call(lambda: pn2.group_point(feat, idx), 20)
     bq_bytes = B * N * 12 + B * M * 12 + B * M * K * 4 + B * M * 4
     gp_bytes = B * M * K * 4 + B * N * C * 4 + B * M * K * C * 4
-    ach = (bq_bytes + gp_bytes) / ((t_bq + t_gp) * 1e-3) / 1e9
-    ach_all = (bq_bytes + gp_bytes) / ((t_bin + t_bq + t_gp) * 1e-3) / 1e9
+    gbs = lambda t: (bq_bytes + gp_bytes) / (t * 1e-3) / 1e9  # noqa: E731
+    ach = gbs(t_bq_self + t_gp)                                # the default product path: pn2_query_ball_point + pn2_group_point
     out = {"ball_query_group_point": {
-        "shape": "B16 N8192 M1024 K32 C128", "ball_query_us": round(t_bq * 1e3, 1),
-        "ball_query_note": "query on a cloud binned once per cloud (pn2_ball_query_bin: one workgroup per cloud, 16 CUs, runs beside "
-                           "the FPS of the level in the model); bin_us / self_binning_us / frac_including_bin report the rest",
-        "bin_us": round(t_bin * 1e3, 1), "ball_query_self_binning_us": round(t_bq_self * 1e3, 1),
+        "shape": "B16 N8192 M1024 K32 C128", "ball_query_us": round(t_bq_self * 1e3, 1),
         "group_point_us": round(t_gp * 1e3, 1), "bytes": bq_bytes + gp_bytes, "bound": "hbm",
         "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4),
-        "frac_including_bin": round(ach_all / HBM_PEAK_GBS, 4),
-        "group_point_alone_GBs": round(gp_bytes / (t_gp * 1e-3) / 1e9, 1)}}
+        "group_point_alone_GBs": round(gp_bytes / (t_gp * 1e-3) / 1e9, 1),
+        "binned_once_variant": {
+            "note": "pn2_ball_query_bin once per cloud + pn2_query_ball_point_binned (same indices); off by default in the model "
+                    "(util/pointnet_util.py USE_BINNED_BALL_QUERY: the binning launch costs throughput when 4 batches are in flight)",
+            "bin_us": round(t_bin * 1e3, 1), "ball_query_us": round(t_bq * 1e3, 1),
+            "frac_query_only": round(gbs(t_bq + t_gp) / HBM_PEAK_GBS, 4),
+            "frac_including_bin": round(gbs(t_bin + t_bq + t_gp) / HBM_PEAK_GBS, 4)}}}
     # the achievable copy bandwidth next to the 8 TB/s peak (device-to-device copy of the same 268 MB)
     grouped = pn2.group_point(feat, idx)
     dst = torch.empty_like(grouped)
@@ -683,6 +707,8 @@ def main():
         timed = dense if P_eff > 1 else kernels
         dom = max(timed, key=lambda k: k["ms_per_step"])
         agg_tf = flops_step / (ms_per_step * 1e-3) / 1e12
+        ref_flops = reference_flops(pn2, hp, B, N)
+        eff_tf = ref_flops / (ms_per_step * 1e-3) / 1e12
         res = {
             "metric": "points/sec through SA+FP stack (B=16,N=8192)",
             "value": round(total_points / elapsed, 1), "unit": "points/s", "n_gpus": world, "steps": args.steps,
@@ -713,9 +739,17 @@ def main():
                          "traffic": None, "algorithmic_units": dom["algorithmic_units"], "avg_us": dom["avg_us"],
                          "ms_per_step": dom["ms_per_step"],
                          "share_of_timed_kernels": round(dom["ms_per_step"] / max(1e-9, sum(k["ms_per_step"] for k in timed)), 3),
-                         "aggregate": {"what": "all MFMA flops of one step / ms_per_step of the timed regime",
+                         "flops_counted": "EXECUTED MFMA flops of the launch (a *_pre kernel runs its first layer only on the "
+                                          "channels that were not hoisted onto the source rows; the hoisted product is its own "
+                                          "linear launch in 'kernels')",
+                         "aggregate": {"what": "all EXECUTED MFMA flops of one step / ms_per_step of the timed regime",
                                        "flops_per_step": int(flops_step), "achieved": round(agg_tf, 2),
                                        "peak": MFMA_F32_PEAK_TF, "unit": "TFLOP/s", "frac": round(agg_tf / MFMA_F32_PEAK_TF, 4)},
+                         "aggregate_reference_formulation": {
+                             "what": "flops the reference's formulation spends on the same step (SURVEY 8d: every conv on the "
+                                     "grouped tensor) / ms_per_step: the rate a kernel set without hoisting would need",
+                             "flops_per_step": int(ref_flops), "effective": round(eff_tf, 2), "unit": "TFLOP/s",
+                             "frac_of_peak_equivalent": round(eff_tf / MFMA_F32_PEAK_TF, 4)},
                          "kernel_time_sums_ms": {"all": round(sum_all, 4), "without_fps": round(sum_dense, 4),
                                                  "fps": round(sum_all - sum_dense, 4)}},
             "kernels": kernels,

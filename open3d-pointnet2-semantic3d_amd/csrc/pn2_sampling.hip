@@ -258,7 +258,7 @@ fps_reg_kernel(int n, int m, const float* __restrict__ xyz_all, int* __restrict_
 
 PN2_TUNABLE(int, g_fps_variant, 0)  // tuning hook (pn2_debug_set(0, v)), see dispatch_fps
 
-// ---- lazy multi-pick FPS (256 < n <= 8192) ---------------------------------------------------------------------------
+// ---- lazy multi-pick FPS (2048 < n <= 8192) --------------------------------------------------------------------------
 // Same picks as fps_reg_kernel (= the reference, tf_sampling.cu:111-176), but a synchronised pass over the cloud delivers
 // ~15 picks instead of one.  min() is associative, so the running minimum td(k) may lag behind the picks: td_stale(k) >=
 // td(k), and a point whose stale td is below a threshold tau cannot be the next pick while some listed point stays >= tau.
@@ -273,8 +273,8 @@ PN2_TUNABLE(int, g_fps_variant, 0)  // tuning hook (pn2_debug_set(0, v)), see di
 //   overflowing list falls back to ONE pick from the 16 per-wave maxima (exact: the global maximum is one of them).
 // The result never depends on tau / eps / list capacity, only the number of phases does (tools/fps_lazy_sim.py: 1023
 // picks in ~60 phases at n = 8192 on scene-, normal-, uniform- and lattice-distributed clouds).
-// Phase A is pruned: the cloud is Morton-sorted inside the workgroup (LDS counting sort over 16^3 cells of the bounding
-// box) and dealt out so that (wave w, register row i) holds 64 consecutive sorted points = one compact BUCKET with an
+// Phase A is pruned: the cloud is sorted along a Hilbert curve inside the workgroup (LDS counting sort over 16^3 cells of
+// the bounding box) and dealt out so that (wave w, register row i) holds 64 consecutive sorted points = one compact BUCKET with an
 // exact bounding box in SGPRs.  A pending pick p can lower td inside a bucket only if lb(p, box)^2 * (1 - 1e-6) <= G, G =
 // the td of the first pending pick when it was picked (>= every stale td).  Lane p tests pick p against row i's box (one
 // VALU pass per row, ballot = work mask of the row); only the surviving (row, pick) pairs -- ~12 % of them -- run the
