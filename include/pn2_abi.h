@@ -381,6 +381,22 @@ int pn2_interpolate_label_with_color(int num_sparse_points, int num_dense_points
 /* Data gradient of a dense layer: dx (rows,cin) = dy (rows,cout) . W^T, W (cin,cout) row-major as the forward pass holds
  * it; any cin / cout (tf.gradients of tf.nn.conv2d, util/tf_util.py:181-186). */
 int pn2_linear_dgrad(int rows, int cin, int cout, const float *dy, const float *w, float *dx, void *stream);
+/* The same when dx IS the gradient reaching the batch norm (+ReLU) of the layer below (the layer whose output is this
+ * layer's input, consumed by nothing else): y_below (rows,cin) = that layer's pre-normalisation output, gamma / beta /
+ * save_mean / save_invstd its parameters and saved batch moments, relu its activation flag.  While the accumulator tiles of
+ * dx are at hand the kernel adds sum g and sum g*xhat per channel (g = dx * [ReLU mask], xhat = (y-mean)*invstd) to that
+ * layer's ZEROED batch-norm workspace (pn2_bn_workspace_bytes(cin) bytes); pn2_bn_relu_backward_stats -- pn2_bn_relu_backward
+ * for such a (dz, workspace) pair, pool <= 1 -- then skips its reduction pass over (dz, y).  Same results up to fp64
+ * summation order.  PN2_EUNSUP for cout <= 16 (streaming kernel): use pn2_linear_dgrad + pn2_bn_relu_backward.
+ * (tf.gradients through tf_util.py:186-204: conv2d -> batch_norm -> relu.) */
+int pn2_linear_dgrad_bn_grad_stats(int rows, int cin, int cout, const float *dy, const float *w, float *dx,
+                                   const float *y_below, const float *gamma, const float *beta, const float *save_mean,
+                                   const float *save_invstd, int relu, void *bn_workspace, size_t workspace_bytes,
+                                   void *stream);
+int pn2_bn_relu_backward_stats(long long rows, int c, const float *dz, const float *y, const float *gamma,
+                               const float *beta, const float *save_mean, const float *save_invstd, int relu,
+                               int pool, const float *zmax, const float *ties, void *workspace,
+                               size_t workspace_bytes, float *dy, float *dgamma, float *dbeta, void *stream);
 
 /* model.get_loss  model.py:152-161: weighted sparse softmax cross-entropy, reduction SUM_BY_NONZERO_WEIGHTS.
  * logits (rows,num_class) f32, labels (rows) int32 (label64 = 0) or int64 (label64 = 1), weights (rows) f32 ->

@@ -91,14 +91,28 @@ __device__ __forceinline__ void bn_block_sums(const BnMap<VEC>& mp, int c, int n
 // final[col] = sum over the slot copies.  A launch of its own rather than a "last block folds" epilogue: that variant
 // needs a ticket counter and device-scope fences in every reduction block and measured the same step time (8.2-8.7 ms
 // for 128-512 blocks) -- the kernel boundary gives the ordering for free.
+// Eight threads per column, each with its share of the copies in flight at once: with one thread per column and the copies
+// read eight at a time the kernel was eight dependent L2 round trips long (4.9 us x 45 launches per training step).
+constexpr int kBnFoldParts = 8;
 __global__ void __launch_bounds__(kBnThreads)
 bn_fold_kernel(int cols, int nslots, double* __restrict__ ws) {
-    const int col = blockIdx.x * kBnThreads + threadIdx.x;
-    if (col >= cols) return;
+    const int part = threadIdx.x & (kBnFoldParts - 1);
+    const int col = blockIdx.x * (kBnThreads / kBnFoldParts) + (threadIdx.x >> 3);
     double t = 0.0;
-#pragma unroll 8
-    for (int k = 0; k < nslots; ++k) t += ws[kBnHead + (size_t)cols * (1 + k) + col];
-    ws[kBnHead + col] = t;
+    if (col < cols) {
+        double v[kPn2BnSlots / kBnFoldParts];
+#pragma unroll
+        for (int i = 0; i < kPn2BnSlots / kBnFoldParts; ++i) {
+            const int k = part + i * kBnFoldParts;
+            v[i] = k < nslots ? ws[kBnHead + (size_t)cols * (1 + k) + col] : 0.0;
+        }
+#pragma unroll
+        for (int i = 0; i < kPn2BnSlots / kBnFoldParts; ++i) t += v[i];
+    }
+    t += __shfl_xor(t, 1);
+    t += __shfl_xor(t, 2);
+    t += __shfl_xor(t, 4);
+    if (col < cols && part == 0) ws[kBnHead + col] = t;
 }
 
 // acc[0][ch] = sum_r y[r][ch], acc[1][ch] = sum_r y[r][ch]^2 over the block's slab of rows
@@ -142,13 +156,7 @@ bn_stats_kernel(long long rows, int c, long long slab, int nslots, const float* 
     bn_block_sums<VEC, 2>(mp, c, nslots, part, ws);
 }
 
-// per-channel constants of the normalisation, identical float expressions in the forward and the backward kernels so
-// that the ReLU mask recomputed in the backward is the forward's: z = fma(y, sc, sh), sc = gamma*invstd,
-// sh = fma(-mean, sc, beta)
-__device__ __forceinline__ void bn_scale_shift(float gamma, float beta, float mean, float invstd, float& sc, float& sh) {
-    sc = gamma * invstd;
-    sh = __builtin_fmaf(-mean, sc, beta);
-}
+// bn_scale_shift (the per-channel constants of the normalisation): pn2_common.h
 
 // Per-channel (scale, shift) of the forward into LDS.  Every block derives (mean, invstd) of all channels from the fp64
 // sums (c rsqrt's: noise next to its share of the stream); block 0 also publishes them for the backward and moves
@@ -464,7 +472,7 @@ static int bn_relu_forward_impl(long long rows, int c, const float* y, const flo
         if (e != hipSuccess) return (int)e;
     }
     if (mode == 2) p.nslots = kBnSlots;
-    const int fold_blocks = (2 * c + kBnThreads - 1) / kBnThreads;
+    const int fold_blocks = (2 * c * kBnFoldParts + kBnThreads - 1) / kBnThreads;
     long long pb = 1;  // pooled apply: one group per (thread row slot), grid-stride beyond 8 blocks per CU
     if (pool > 1) {
         const int rp = kBnThreads / (c / p.vec);
@@ -519,10 +527,13 @@ extern "C" int pn2_bn_relu_forward_stats(long long rows, int c, const float* y, 
 static int bn_relu_backward_impl(long long rows, int c, const float* dz, const float* y, const float* gamma,
                                  const float* beta, const float* save_mean, const float* save_invstd, int relu,
                                  int pool, const float* zmax, const float* ties, void* workspace,
-                                 size_t workspace_bytes, float* dy, float* dgamma, float* dbeta, void* stream, bool ws_zeroed) {
+                                 size_t workspace_bytes, float* dy, float* dgamma, float* dbeta, void* stream, int mode) {
+    // mode 0: zero the workspace here; 1: the caller zeroed it; 2: the caller zeroed it AND pn2_linear_dgrad_bn_grad_stats has
+    // already added (sum g, sum g * xhat) to all kBnSlots slot copies while it produced dz (no reduction pass; pool <= 1)
     if (!dz || !y || !gamma || !beta || !save_mean || !save_invstd || !workspace || !dy || !dgamma || !dbeta) return PN2_ENULL;
     if (pool > 1 && (!zmax || !ties)) return PN2_ENULL;
     if (pool > 1 && (rows % pool != 0 || dy == dz)) return PN2_EINVAL;
+    if (mode == 2 && pool > 1) return PN2_EINVAL;
     BnPlan p;
     int rc = bn_plan(rows, c, dz, y, dy, p);
     if (rc != PN2_OK) return rc;
@@ -531,15 +542,17 @@ static int bn_relu_backward_impl(long long rows, int c, const float* dz, const f
     hipStream_t st = static_cast<hipStream_t>(stream);
     double* ws = static_cast<double*>(workspace);
     const double* acc = ws + kBnHead;
-    if (!ws_zeroed) {
+    if (mode == 0) {
         hipError_t e = hipMemsetAsync(ws, 0, sizeof(double) * bn_ws_doubles(c, p.nslots), st);
         if (e != hipSuccess) return (int)e;
     }
-    const int fold_blocks = (2 * c + kBnThreads - 1) / kBnThreads;
+    if (mode == 2) p.nslots = kBnSlots;
+    const int fold_blocks = (2 * c * kBnFoldParts + kBnThreads - 1) / kBnThreads;
 #define PN2_BN_BWD(V_)                                                                                                  \
     do {                                                                                                                \
-        bn_grad_reduce_kernel<V_><<<p.stat_blocks, kBnThreads, 0, st>>>(rows, c, p.slab, p.nslots, dz, y, gamma, beta,   \
-                                                                      save_mean, save_invstd, relu, pool, zmax, ties, ws); \
+        if (mode != 2)                                                                                                  \
+            bn_grad_reduce_kernel<V_><<<p.stat_blocks, kBnThreads, 0, st>>>(rows, c, p.slab, p.nslots, dz, y, gamma, beta, \
+                                                                          save_mean, save_invstd, relu, pool, zmax, ties, ws); \
         bn_fold_kernel<<<fold_blocks, kBnThreads, 0, st>>>(2 * c, p.nslots, ws);                                         \
         bn_grad_apply_kernel<V_><<<p.apply_blocks, kBnThreads, 0, st>>>(rows, c, dz, y, acc, gamma, beta, save_mean,     \
                                                                       save_invstd, relu, pool, zmax, ties, dy, dgamma,  \
@@ -557,12 +570,20 @@ extern "C" int pn2_bn_relu_backward(long long rows, int c, const float* dz, cons
                                     int pool, const float* zmax, const float* ties, void* workspace,
                                     size_t workspace_bytes, float* dy, float* dgamma, float* dbeta, void* stream) {
     return bn_relu_backward_impl(rows, c, dz, y, gamma, beta, save_mean, save_invstd, relu, pool, zmax, ties, workspace,
-                                 workspace_bytes, dy, dgamma, dbeta, stream, false);
+                                 workspace_bytes, dy, dgamma, dbeta, stream, 0);
 }
 extern "C" int pn2_bn_relu_backward_ws0(long long rows, int c, const float* dz, const float* y, const float* gamma,
                                         const float* beta, const float* save_mean, const float* save_invstd, int relu,
                                         int pool, const float* zmax, const float* ties, void* workspace,
                                         size_t workspace_bytes, float* dy, float* dgamma, float* dbeta, void* stream) {
     return bn_relu_backward_impl(rows, c, dz, y, gamma, beta, save_mean, save_invstd, relu, pool, zmax, ties, workspace,
-                                 workspace_bytes, dy, dgamma, dbeta, stream, true);
+                                 workspace_bytes, dy, dgamma, dbeta, stream, 1);
+}
+// the same for a dz produced by pn2_linear_dgrad_bn_grad_stats with this workspace: the two sums are already there
+extern "C" int pn2_bn_relu_backward_stats(long long rows, int c, const float* dz, const float* y, const float* gamma,
+                                          const float* beta, const float* save_mean, const float* save_invstd, int relu,
+                                          int pool, const float* zmax, const float* ties, void* workspace,
+                                          size_t workspace_bytes, float* dy, float* dgamma, float* dbeta, void* stream) {
+    return bn_relu_backward_impl(rows, c, dz, y, gamma, beta, save_mean, save_invstd, relu, pool, zmax, ties, workspace,
+                                 workspace_bytes, dy, dgamma, dbeta, stream, 2);
 }

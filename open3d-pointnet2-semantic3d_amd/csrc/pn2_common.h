@@ -30,6 +30,28 @@ constexpr int kPn2BnHead = 8;    // doubles reserved in front (alignment of the 
 constexpr int kPn2BnSlots = 64;  // most copies of the per-channel accumulators the producers spread their atomics over
 __host__ __device__ inline size_t pn2_bn_ws_doubles(int c, int nslots) { return kPn2BnHead + (size_t)(1 + nslots) * 2 * (size_t)c; }
 
+// per-channel constants of the normalisation, identical float expressions in the forward and the backward kernels so
+// that the ReLU mask recomputed in the backward is the forward's: z = fma(y, sc, sh), sc = gamma*invstd,
+// sh = fma(-mean, sc, beta)
+__device__ __forceinline__ void bn_scale_shift(float gamma, float beta, float mean, float invstd, float& sc, float& sh) {
+    sc = gamma * invstd;
+    sh = __builtin_fmaf(-mean, sc, beta);
+}
+
+// Epilogue of a data-gradient GEMM whose output dx IS the gradient dz reaching the batch norm (+ReLU) of the layer below
+// (pn2_linear_dgrad_bn_grad_stats): the first backward reduction of that batch norm -- sum g and sum g * xhat per channel,
+// g = dz * [relu mask], xhat = (y - mean) * invstd -- is taken from the accumulator tiles, so bn_grad_reduce_kernel's pass
+// over (dz, y) is not run.  ws = null: plain data gradient.
+struct Pn2BnGradEpilogue {
+    const float* y;        // (rows, c) pre-normalisation output of the layer below (c = width of dx)
+    const float* gamma;
+    const float* beta;
+    const float* mean;
+    const float* invstd;
+    double* ws;            // its ZEROED batch-norm workspace (all kPn2BnSlots slot copies are used)
+    int relu;
+};
+
 // Squared distance exactly as the reference expression
 //   (x2-x1)*(x2-x1) + (y2-y1)*(y2-y1) + (z2-z1)*(z2-z1)
 // (tf_sampling.cu:149-150, tf_grouping.cu:28-30) under the three contraction

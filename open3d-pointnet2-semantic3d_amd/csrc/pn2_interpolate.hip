@@ -20,6 +20,7 @@ constexpr int kNnThreads = 256;
 constexpr int kNnWaves = kNnThreads / 64;
 constexpr int kNnQ = 8;        // queries per wave
 constexpr int kNnList = 32;    // per-query candidate list (LDS)
+PN2_TUNABLE(int, g_nn_blocks, 2048)  // target workgroups per launch (sweep: 16384 = one group per wave 42.1 us, 2048 39.6, 1024 43.0, 512 45.8); tuning hook 12
 
 struct NnPoint { float x, y, z; };
 
@@ -42,6 +43,11 @@ __device__ __forceinline__ int nn_wave_imax(int v) {
 __device__ __forceinline__ float nn_fmin(float a, float b) {
     float r;
     asm("v_min_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+__device__ __forceinline__ float nn_fmin3(float a, float b, float c) {
+    float r;
+    asm("v_min3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
     return r;
 }
 
@@ -80,8 +86,8 @@ __device__ __forceinline__ void nn_merge3(float& t0, float& t1, float& t2, float
 //           thr = v3 + 3E absorbs the rounding of the addition.
 //   pass 2  the few lanes whose minimum is inside thr re-test their own candidates and append the hits
 //           (s <= thr, a handful per query) to the query's list in LDS, in arbitrary order;
-//           together with their exact float64 distance (raw coordinates re-read), in arbitrary order;
-//   refine  8 lanes per query rank the listed candidates by (distance, index); ranks 0..2 are written --
+//   refine  8 lanes per query take the exact float64 distance of the listed candidates (raw coordinates re-read, all
+//           loads of the wave in flight together) and rank them by (distance, index); ranks 0..2 are written --
 //           exactly what a strict '<' insertion over a full ascending scan yields (ties -> lowest index).
 // A list overflow (> 32 candidates inside thr: heavy duplication, or a dynamic range (extent/spacing)^2
 // approaching 2^24 that makes E useless) falls back to a full float64 scan of that query by one lane.
@@ -101,8 +107,14 @@ three_nn_kernel(int n, int m, const float* __restrict__ xyz1_all,
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int bi = blockIdx.y;
-    const int q0 = (blockIdx.x * kNnWaves + wave) * kNnQ;
-    if (q0 >= n) return;  // wave-uniform, no barriers in this kernel
+    // PERSISTENT waves (r03): a wave keeps the candidates in registers (m <= 64 * kNnChunks: the common case) and walks
+    // query groups grp, grp + stride, ...; the next group's coordinates are fetched (one coalesced load, 24 lanes) while
+    // this group is worked on.  With one group per wave the kernel was bound by the latency of its own start-up loads
+    // (48 candidate + 24 query loads in front of 0.3 us of pass-1 arithmetic), not by VALU issue.
+    const int ngroups = (n + kNnQ - 1) / kNnQ;
+    const int gstride = gridDim.x * kNnWaves;
+    int grp = blockIdx.x * kNnWaves + wave;
+    if (grp >= ngroups) return;  // wave-uniform, no barriers in this kernel
     const float* __restrict__ xyz1 = xyz1_all + (size_t)bi * n * 3;
     const float* __restrict__ xyz2 = xyz2_all + (size_t)bi * m * 3;
     const NnPoint* __restrict__ cand = reinterpret_cast<const NnPoint*>(xyz2);
@@ -114,23 +126,10 @@ three_nn_kernel(int n, int m, const float* __restrict__ xyz1_all,
     int* wc = scnt + wave * kNnQ;
 
     const float ox = xyz2[0], oy = xyz2[1], oz = xyz2[2];
-    float ax[kNnQ], ay[kNnQ], az[kNnQ];
-    float rq = 0.f;
-#pragma unroll
-    for (int q = 0; q < kNnQ; ++q) {
-        const int jq = q0 + q < n ? q0 + q : n - 1;
-        const float rx = __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(xyz1[jq * 3 + 0])));
-        const float ry = __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(xyz1[jq * 3 + 1])));
-        const float rz = __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(xyz1[jq * 3 + 2])));
-        if (lane == 0) *reinterpret_cast<f32x4*>(wr + q * 4) = f32x4{rx, ry, rz, 0.f};
-        const float x = rx - ox, y = ry - oy, z = rz - oz;
-        ax[q] = -2.0f * x; ay[q] = -2.0f * y; az[q] = -2.0f * z;  // exact scalings
-        rq = fmaxf(rq, fmaxf(fabsf(x), fmaxf(fabsf(y), fabsf(z))));
-    }
     const int last = m - 1;
     const int nblk = (m + 64 * kNnChunks - 1) / (64 * kNnChunks);
     float cx[kNnChunks], cy[kNnChunks], cz[kNnChunks], cc[kNnChunks];
-    float rc = 0.f;  // largest |component| of this lane's centred candidates
+    float rc = 0.f;  // largest |component| of this lane's centred candidates (grows monotonically: E stays a bound)
     auto load_block = [&](int blk) {
 #pragma unroll
         for (int t = 0; t < kNnChunks; ++t) {
@@ -142,6 +141,31 @@ three_nn_kernel(int n, int m, const float* __restrict__ xyz1_all,
             rc = fmaxf(rc, fmaxf(fabsf(x), fmaxf(fabsf(y), fabsf(z))));
         }
     };
+    // lane l < 24 holds coordinate l % 3 of query q0 + l / 3 (queries past n re-read the last one; never written)
+    auto load_queries = [&](int g) {
+        const int l = lane < 3 * kNnQ ? lane : 3 * kNnQ - 1;
+        int jq = g * kNnQ + l / 3;
+        jq = jq < n ? jq : n - 1;
+        return xyz1[jq * 3 + l % 3];
+    };
+    float qnext = load_queries(grp);
+    if (nblk == 1) load_block(0);
+  for (; grp < ngroups; grp += gstride) {
+    const int q0 = grp * kNnQ;
+    const float qv = qnext;
+    if (grp + gstride < ngroups) qnext = load_queries(grp + gstride);
+    float ax[kNnQ], ay[kNnQ], az[kNnQ];
+    float rq = 0.f;
+#pragma unroll
+    for (int q = 0; q < kNnQ; ++q) {
+        const float rx = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(qv), 3 * q + 0));
+        const float ry = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(qv), 3 * q + 1));
+        const float rz = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(qv), 3 * q + 2));
+        if (lane == 0) *reinterpret_cast<f32x4*>(wr + q * 4) = f32x4{rx, ry, rz, 0.f};
+        const float x = rx - ox, y = ry - oy, z = rz - oz;
+        ax[q] = -2.0f * x; ay[q] = -2.0f * y; az[q] = -2.0f * z;  // exact scalings
+        rq = fmaxf(rq, fmaxf(fabsf(x), fmaxf(fabsf(y), fabsf(z))));
+    }
     auto rank = [&](int q, int t) {
         return __builtin_fmaf(ax[q], cx[t], __builtin_fmaf(ay[q], cy[t], __builtin_fmaf(az[q], cz[t], cc[t])));
     };
@@ -151,9 +175,8 @@ three_nn_kernel(int n, int m, const float* __restrict__ xyz1_all,
 #pragma unroll
     for (int q = 0; q < kNnQ; ++q) mn[q] = INFINITY;
     for (int blk = 0; blk < nblk; ++blk) {
-        load_block(blk);
-#pragma unroll
-        for (int t = 0; t < kNnChunks; ++t) {
+        if (nblk > 1) load_block(blk);  // single block: resident for the whole kernel
+        auto one_chunk = [&](int t) {
             const int k = (blk * kNnChunks + t) * 64 + lane;
             const int cbase = (blk * kNnChunks + t) * 64;
             if (cbase + 64 <= m) {  // full chunk (wave-uniform): no masking
@@ -164,6 +187,20 @@ three_nn_kernel(int n, int m, const float* __restrict__ xyz1_all,
 #pragma unroll
                 for (int q = 0; q < kNnQ; ++q) mn[q] = nn_fmin(mn[q], valid ? rank(q, t) : INFINITY);
             }
+        };
+        if constexpr (kNnChunks >= 2) {
+#pragma unroll
+            for (int t = 0; t < kNnChunks; t += 2) {
+                if ((blk * kNnChunks + t + 2) * 64 <= m) {  // two full chunks (wave-uniform): one v_min3 per query
+#pragma unroll
+                    for (int q = 0; q < kNnQ; ++q) mn[q] = nn_fmin3(mn[q], rank(q, t), rank(q, t + 1));
+                } else {
+                    one_chunk(t);
+                    one_chunk(t + 1);
+                }
+            }
+        } else {
+            one_chunk(0);
         }
     }
     if constexpr (PN2_NN_STAGES < 2) {
@@ -171,7 +208,7 @@ three_nn_kernel(int n, int m, const float* __restrict__ xyz1_all,
 #pragma unroll
         for (int q = 0; q < kNnQ; ++q) acc += mn[q];
         if (acc == 12345.f) dist_all[lane] = acc;
-        return;
+        continue;
     }
     // E = 64 u R^2 (rounded up)
     const float R = fmaxf(__int_as_float(nn_wave_imax(__float_as_int(rc))), rq);
@@ -210,7 +247,7 @@ three_nn_kernel(int n, int m, const float* __restrict__ xyz1_all,
 #pragma unroll
         for (int q = 0; q < kNnQ; ++q) acc += thr[q];
         if (acc == 12345.f) dist_all[lane] = acc;
-        return;
+        continue;
     }
     // ---- pass 2: collect ----------------------------------------------------------------------
     // Only lanes whose pass-1 minimum is inside thr hold a candidate of that query (typically 3-5 of
@@ -251,15 +288,7 @@ three_nn_kernel(int n, int m, const float* __restrict__ xyz1_all,
                 hm &= hm - 1u;
                 const int kk = (blk * kNnChunks + t) * 64 + lane;
                 const int pos = atomicAdd(&wc[q], 1);  // may exceed kNnList: overflow marker
-                if (pos < kNnList) {
-                    // exact float64 distance from the RAW coordinates (the centred ones are rounded)
-                    const f32x4 qr = *reinterpret_cast<const f32x4*>(wr + q * 4);
-                    const double dx = (double)qr[0] - (double)xyz2[kk * 3 + 0];
-                    const double dy = (double)qr[1] - (double)xyz2[kk * 3 + 1];
-                    const double dz = (double)qr[2] - (double)xyz2[kk * 3 + 2];
-                    wl[q * kNnList + pos] = kk;
-                    wd[q * kNnList + pos] = (dx * dx + dy * dy) + dz * dz;  // contraction is off
-                }
+                if (pos < kNnList) wl[q * kNnList + pos] = kk;  // the exact distance is taken in the refine step
             }
         }
     }
@@ -272,7 +301,7 @@ three_nn_kernel(int n, int m, const float* __restrict__ xyz1_all,
 #pragma unroll
         for (int q = 0; q < kNnQ; ++q) acc += cnt[q];
         if (acc == 12345) idx_all[lane] = acc + wl[lane];
-        return;
+        continue;
     }
     // ---- refine: 8 lanes per query; every listed candidate is ranked by (distance, index) ---------
     // rank = number of listed candidates that precede it; ranks 0..2 are the answer -- exactly what a
@@ -286,14 +315,29 @@ three_nn_kernel(int n, int m, const float* __restrict__ xyz1_all,
         if (q0 + g < n) {
             const size_t o = ((size_t)bi * n + q0 + g) * 3;
             if (cg <= kNnList) {
+                // exact float64 distances from the RAW coordinates (the centred ones are rounded): every lane fetches its
+                // own entries, all of a wave's loads in flight together (inside pass 2's divergent loop each hit paid
+                // its own global round trip)
+                const double qx = (double)wr[g * 4 + 0], qy = (double)wr[g * 4 + 1], qz = (double)wr[g * 4 + 2];
+                for (int e = part; e < cg; e += 8) {
+                    const int kk = wl[g * kNnList + e];
+                    const double dx = qx - (double)xyz2[kk * 3 + 0];
+                    const double dy = qy - (double)xyz2[kk * 3 + 1];
+                    const double dz = qz - (double)xyz2[kk * 3 + 2];
+                    wd[g * kNnList + e] = (dx * dx + dy * dy) + dz * dz;  // contraction is off
+                }
                 for (int e = part; e < cg; e += 8) {
                     const double d = wd[g * kNnList + e];
                     const int kk = wl[g * kNnList + e];
                     int rank = 0;
-                    for (int j = 0; j < cg; ++j) {
-                        const double dj = wd[g * kNnList + j];
-                        const int kj = wl[g * kNnList + j];
-                        rank += (dj < d || (dj == d && kj < kk)) ? 1 : 0;
+                    for (int j0 = 0; j0 < cg; j0 += 8) {  // 8 entries per LDS round trip (slots past cg: stale, masked)
+                        double dj[8];
+                        int kj[8];
+#pragma unroll
+                        for (int u = 0; u < 8; ++u) { dj[u] = wd[g * kNnList + j0 + u]; kj[u] = wl[g * kNnList + j0 + u]; }
+#pragma unroll
+                        for (int u = 0; u < 8; ++u)
+                            rank += (j0 + u < cg && (dj[u] < d || (dj[u] == d && kj[u] < kk))) ? 1 : 0;
                     }
                     if (rank < 3) { dist_all[o + rank] = (float)d; idx_all[o + rank] = kk; }
                 }
@@ -318,6 +362,7 @@ three_nn_kernel(int n, int m, const float* __restrict__ xyz1_all,
             }
         }
     }
+  }  // query groups
 }
 
 // out[row, :] = (p1*w1 + p2*w2) + p3*w3, unfused fp32 (tf_interpolate.cpp:322-324).
@@ -726,12 +771,20 @@ inline int grid_x_for(unsigned long long total, int block, int batches) {
 
 }  // namespace
 
+#ifdef PN2_TUNING_HOOKS
+extern "C" int pn2_debug_set_interp(int what, int value) { if (what == 12) { g_nn_blocks = value; return 0; } return -1; }
+#endif
+
 extern "C" int pn2_three_nn(int b, int n, int m, const float* xyz1, const float* xyz2, float* dist,
                             int* idx, void* stream) {
     if (b <= 0 || n <= 0 || m < 3) return PN2_EINVAL;
     if (!xyz1 || !xyz2 || !dist || !idx) return PN2_ENULL;
     if ((long long)n * 3 > 0x7fffffffLL || (long long)m * 3 > 0x7fffffffLL || b > 65535) return PN2_ERANGE;
-    dim3 grid((n + kNnWaves * kNnQ - 1) / (kNnWaves * kNnQ), b);
+    // persistent waves: ~4 workgroups per CU over the whole batch, every wave takes the same number of query groups
+    const int blocks_all = (n + kNnWaves * kNnQ - 1) / (kNnWaves * kNnQ);
+    int per = (b * blocks_all + g_nn_blocks - 1) / g_nn_blocks;        // groups per wave
+    if (per < 1) per = 1;
+    dim3 grid((blocks_all + per - 1) / per, b);
     hipStream_t st = static_cast<hipStream_t>(stream);
     if (m <= 64) three_nn_kernel<1><<<grid, kNnThreads, 0, st>>>(n, m, xyz1, xyz2, dist, idx);
     else if (m <= 256) three_nn_kernel<4><<<grid, kNnThreads, 0, st>>>(n, m, xyz1, xyz2, dist, idx);

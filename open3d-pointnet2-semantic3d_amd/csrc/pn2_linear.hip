@@ -67,6 +67,40 @@ __device__ __forceinline__ void push_column_stats(const f32x16& acc, int half, i
     }
 }
 
+// The same for the data gradient that reaches a batch norm (+ReLU): column sums of g = dz * [mask] and g * xhat over one
+// 32x32 tile of dz (see Pn2BnGradEpilogue); float expressions of bn_grad_reduce_kernel, fp64 accumulation.
+__device__ __forceinline__ void push_column_grad_stats(const f32x16& acc, int half, int wrow0, int rows, int col, int c,
+                                                       unsigned slot, const Pn2BnGradEpilogue& e) {
+    double d1 = 0.0, d2 = 0.0;
+    if (col < c) {
+        const float mean = e.mean[col], invstd = e.invstd[col];
+        float sc, sh;
+        bn_scale_shift(e.gamma[col], e.beta[col], mean, invstd, sc, sh);
+        float a[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int row = wrow0 + (r & 3) + 8 * (r >> 2) + 4 * half;
+            a[r] = e.y[(size_t)(row < rows ? row : rows - 1) * c + col];
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int row = wrow0 + (r & 3) + 8 * (r >> 2) + 4 * half;
+            const bool on = row < rows && (!e.relu || __builtin_fmaf(a[r], sc, sh) > 0.f);
+            const double gd = on ? (double)acc[r] : 0.0;
+            const double xh = (double)((a[r] - mean) * invstd);
+            d1 += gd;
+            d2 = __builtin_fma(gd, xh, d2);
+        }
+    }
+    d1 += __shfl_xor(d1, 32);
+    d2 += __shfl_xor(d2, 32);
+    if (half == 0 && col < c) {
+        double* __restrict__ sl = e.ws + kPn2BnHead + (size_t)2 * c * (1 + slot % (unsigned)kPn2BnSlots);
+        atomicAdd(sl + col, d1);
+        atomicAdd(sl + c + col, d2);
+    }
+}
+
 // WK = 2 splits every k-tile between two waves of the same output tile (intra-workgroup split-K,
 // reduced through LDS before the epilogue): small-row layers then launch twice as many workgroups.
 // ST = register prefetch depth: the global loads of k-tile kt+ST-1 are issued under the MFMAs of tile
@@ -78,7 +112,7 @@ template <int WM, int WN, int NT, bool VEC_A, int WK = 1, int ST = 2, bool TB = 
 __global__ void __launch_bounds__(256)
 linear_kernel(int rows, int cin, int cout, const float* __restrict__ x,
               const float* __restrict__ w, const float* __restrict__ bias, int relu, int pool,
-              float* __restrict__ y, double* __restrict__ stats = nullptr) {
+              float* __restrict__ y, double* __restrict__ stats = nullptr, Pn2BnGradEpilogue gepi = Pn2BnGradEpilogue{}) {
     static_assert(WM * WN * WK == 4, "4 waves per block");
     static_assert(WK == 1 || (WK == 2 && NT * 16 * 64 * WM * WN <= kBK * (32 * NT * WN + 4)), "reduction buffer must fit the B tile");
     constexpr int BM = 32 * WM;
@@ -275,6 +309,7 @@ linear_kernel(int rows, int cin, int cout, const float* __restrict__ x,
                 const int row = wrow0 + (r & 3) + 8 * (r >> 2) + 4 * half;
                 if (row < rows && col < cout) y[(size_t)row * cout + col] = acc[nt][r];
             }
+            if (gepi.ws) push_column_grad_stats(acc[nt], half, wrow0, rows, col, cout, (unsigned)(blockIdx.x * WM + wm), gepi);
             continue;
         }
         const float bv = bias ? bias[col] : 0.f;
@@ -379,12 +414,13 @@ int launch_dgrad_smallk(int rows, int n_in, const float* dy, const float* w, flo
 }
 
 template <int WM, int WN, int NT>
-int launch_linear_dgrad(int rows, int n_in, int n_out, const float* dy, const float* w, float* dx, hipStream_t st) {
+int launch_linear_dgrad(int rows, int n_in, int n_out, const float* dy, const float* w, float* dx, hipStream_t st,
+                        const Pn2BnGradEpilogue& gepi = Pn2BnGradEpilogue{}) {
     constexpr int BM = 32 * WM, BN = 32 * NT * WN;
     dim3 grid((rows + BM - 1) / BM, (n_in + BN - 1) / BN);
     const bool vec_a = (n_out % 4 == 0) && ((uintptr_t)dy % 16 == 0);
-    if (vec_a) linear_kernel<WM, WN, NT, true, 1, 3, true><<<grid, 256, 0, st>>>(rows, n_out, n_in, dy, w, nullptr, 0, 0, dx);
-    else linear_kernel<WM, WN, NT, false, 1, 3, true><<<grid, 256, 0, st>>>(rows, n_out, n_in, dy, w, nullptr, 0, 0, dx);
+    if (vec_a) linear_kernel<WM, WN, NT, true, 1, 3, true><<<grid, 256, 0, st>>>(rows, n_out, n_in, dy, w, nullptr, 0, 0, dx, nullptr, gepi);
+    else linear_kernel<WM, WN, NT, false, 1, 3, true><<<grid, 256, 0, st>>>(rows, n_out, n_in, dy, w, nullptr, 0, 0, dx, nullptr, gepi);
     PN2_RETURN_IF_LAUNCH_FAILED();
     return PN2_OK;
 }
@@ -784,12 +820,14 @@ extern "C" int pn2_linear_bn_stats(int rows, int cin, int cout, const float* x, 
 // Data gradient of a dense layer (training): dx (rows, cin) = dy (rows, cout) . W^T, W (cin, cout) row-major as the forward
 // pass holds it (no transposed copy); any cin / cout.  The reference gets this from tf.gradients of tf.nn.conv2d
 // (util/tf_util.py:181-186).
-extern "C" int pn2_linear_dgrad(int rows, int cin, int cout, const float* dy, const float* w, float* dx, void* stream) {
+static int linear_dgrad_impl(int rows, int cin, int cout, const float* dy, const float* w, float* dx, void* stream,
+                             const Pn2BnGradEpilogue& gepi) {
     if (rows <= 0 || cin <= 0 || cout <= 0) return PN2_EINVAL;
     if (!dy || !w || !dx) return PN2_ENULL;
     if ((long long)rows + 128 > 0x7fffffffLL) return PN2_ERANGE;
     hipStream_t st = static_cast<hipStream_t>(stream);
     if (cout <= 16 && (size_t)cin * cout * sizeof(float) <= 48 * 1024) {
+        if (gepi.ws) return PN2_EUNSUP;  // the streaming kernel has no accumulator tiles to take the sums from
         switch (cout) {
 #define PN2_SK(K_) case K_: return launch_dgrad_smallk<K_>(rows, cin, dy, w, dx, st);
             PN2_SK(1) PN2_SK(2) PN2_SK(3) PN2_SK(4) PN2_SK(5) PN2_SK(6) PN2_SK(7) PN2_SK(8) PN2_SK(9) PN2_SK(10) PN2_SK(11)
@@ -797,12 +835,34 @@ extern "C" int pn2_linear_dgrad(int rows, int cin, int cout, const float* dy, co
 #undef PN2_SK
         }
     }
-    if (cin <= 32) return launch_linear_dgrad<4, 1, 1>(rows, cin, cout, dy, w, dx, st);
-    if (cin <= 64) return launch_linear_dgrad<4, 1, 2>(rows, cin, cout, dy, w, dx, st);
-    if (cin <= 96) return launch_linear_dgrad<4, 1, 1>(rows, cin, cout, dy, w, dx, st);
+    if (cin <= 32) return launch_linear_dgrad<4, 1, 1>(rows, cin, cout, dy, w, dx, st, gepi);
+    if (cin <= 64) return launch_linear_dgrad<4, 1, 2>(rows, cin, cout, dy, w, dx, st, gepi);
+    if (cin <= 96) return launch_linear_dgrad<4, 1, 1>(rows, cin, cout, dy, w, dx, st, gepi);
     const long long cb = (cin + 127) / 128;
-    if (((rows + 63) / 64) * cb >= 512) return launch_linear_dgrad<2, 2, 2>(rows, cin, cout, dy, w, dx, st);
-    return launch_linear_dgrad<1, 4, 1>(rows, cin, cout, dy, w, dx, st);
+    if (((rows + 63) / 64) * cb >= 512) return launch_linear_dgrad<2, 2, 2>(rows, cin, cout, dy, w, dx, st, gepi);
+    return launch_linear_dgrad<1, 4, 1>(rows, cin, cout, dy, w, dx, st, gepi);
+}
+
+extern "C" int pn2_linear_dgrad(int rows, int cin, int cout, const float* dy, const float* w, float* dx, void* stream) {
+    return linear_dgrad_impl(rows, cin, cout, dy, w, dx, stream, Pn2BnGradEpilogue{});
+}
+
+// pn2_linear_dgrad whose output dx (rows, cin) is the gradient reaching the batch norm (+ReLU) of the layer BELOW (the
+// layer that produced this layer's input): y_below (rows, cin) is that layer's pre-normalisation output, gamma / beta /
+// save_mean / save_invstd its batch-norm parameters and saved moments.  While the accumulator tiles of dx are at hand the
+// kernel adds sum g and sum g * xhat per channel (g = dx * [relu mask]) to the ZEROED batch-norm workspace of that layer
+// (pn2_bn_workspace_bytes(cin)); pn2_bn_relu_backward_stats then skips its reduction pass over (dz, y) -- one of the two
+// passes of the reference's batch-norm gradient (util/tf_util.py:555-581 via tf.gradients).  PN2_EUNSUP for cout <= 16
+// (streaming kernel): call pn2_linear_dgrad + pn2_bn_relu_backward.
+extern "C" int pn2_linear_dgrad_bn_grad_stats(int rows, int cin, int cout, const float* dy, const float* w, float* dx,
+                                              const float* y_below, const float* gamma, const float* beta,
+                                              const float* save_mean, const float* save_invstd, int relu,
+                                              void* bn_workspace, size_t workspace_bytes, void* stream) {
+    if (!y_below || !gamma || !beta || !save_mean || !save_invstd || !bn_workspace) return PN2_ENULL;
+    if (cin <= 0 || workspace_bytes < sizeof(double) * pn2_bn_ws_doubles(cin, kPn2BnSlots) || ((uintptr_t)bn_workspace % 8) != 0)
+        return PN2_EINVAL;
+    Pn2BnGradEpilogue e{y_below, gamma, beta, save_mean, save_invstd, static_cast<double*>(bn_workspace), relu};
+    return linear_dgrad_impl(rows, cin, cout, dy, w, dx, stream, e);
 }
 
 #ifdef PN2_TUNING_HOOKS

@@ -71,25 +71,53 @@ __device__ __forceinline__ unsigned mix_u32(unsigned long long seed, unsigned lo
     return (unsigned)x;
 }
 
+// VEC = 4: 16-byte lanes (x, y) and one 32-bit word of four mask bytes per thread; the draw of element i does not depend on VEC
+template <int VEC>
 __global__ void __launch_bounds__(256)
 dropout_kernel(long long n, const float* __restrict__ x, float keep, const long long* __restrict__ state /* [seed, step] */,
                float* __restrict__ y, unsigned char* __restrict__ mask) {
     const unsigned long long seed = (unsigned long long)state[0], step = (unsigned long long)state[1];
     const float inv = 1.0f / keep;
     const unsigned thr = keep >= 1.f ? 0xFFFFFFFFu : (unsigned)((double)keep * 4294967296.0);
-    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
-        const bool k = mix_u32(seed, step, (unsigned long long)i) < thr;
-        mask[i] = k ? 1 : 0;
-        y[i] = k ? x[i] * inv : 0.f;
+    const long long nv = n / VEC;
+    for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < nv; e += (long long)gridDim.x * 256) {
+        if constexpr (VEC == 4) {
+            const float4 v = reinterpret_cast<const float4*>(x)[e];
+            const float in[4] = {v.x, v.y, v.z, v.w};
+            float out[4];
+            unsigned mw = 0;
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const bool k = mix_u32(seed, step, (unsigned long long)(e * 4 + u)) < thr;
+                mw |= (k ? 1u : 0u) << (8 * u);
+                out[u] = k ? in[u] * inv : 0.f;
+            }
+            reinterpret_cast<unsigned*>(mask)[e] = mw;
+            reinterpret_cast<float4*>(y)[e] = make_float4(out[0], out[1], out[2], out[3]);
+        } else {
+            const bool k = mix_u32(seed, step, (unsigned long long)e) < thr;
+            mask[e] = k ? 1 : 0;
+            y[e] = k ? x[e] * inv : 0.f;
+        }
     }
 }
 
+template <int VEC>
 __global__ void __launch_bounds__(256)
 dropout_grad_kernel(long long n, const float* __restrict__ dy, const unsigned char* __restrict__ mask, float keep,
                     float* __restrict__ dx) {
     const float inv = 1.0f / keep;
-    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256)
-        dx[i] = mask[i] ? dy[i] * inv : 0.f;
+    const long long nv = n / VEC;
+    for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < nv; e += (long long)gridDim.x * 256) {
+        if constexpr (VEC == 4) {
+            const float4 v = reinterpret_cast<const float4*>(dy)[e];
+            const unsigned mw = reinterpret_cast<const unsigned*>(mask)[e];
+            reinterpret_cast<float4*>(dx)[e] = make_float4((mw & 0xffu) ? v.x * inv : 0.f, (mw & 0xff00u) ? v.y * inv : 0.f,
+                                                           (mw & 0xff0000u) ? v.z * inv : 0.f, (mw & 0xff000000u) ? v.w * inv : 0.f);
+        } else {
+            dx[e] = mask[e] ? dy[e] * inv : 0.f;
+        }
+    }
 }
 
 // tf.train.AdamOptimizer (python/training/adam.py): m <- b1 m + (1-b1) g; v <- b2 v + (1-b2) g^2;
@@ -183,7 +211,10 @@ extern "C" int pn2_dropout(long long n, const float* x, float keep_prob, const l
                            unsigned char* mask, void* stream) {
     if (n <= 0 || !(keep_prob > 0.f) || keep_prob > 1.f) return PN2_EINVAL;
     if (!x || !state || !y || !mask) return PN2_ENULL;
-    dropout_kernel<<<grid_1d(n), 256, 0, static_cast<hipStream_t>(stream)>>>(n, x, keep_prob, state, y, mask);
+    if (n % 4 == 0 && (((uintptr_t)x | (uintptr_t)y | (uintptr_t)mask) % 16) == 0)
+        dropout_kernel<4><<<grid_1d(n / 4), 256, 0, static_cast<hipStream_t>(stream)>>>(n, x, keep_prob, state, y, mask);
+    else
+        dropout_kernel<1><<<grid_1d(n), 256, 0, static_cast<hipStream_t>(stream)>>>(n, x, keep_prob, state, y, mask);
     PN2_RETURN_IF_LAUNCH_FAILED();
     return PN2_OK;
 }
@@ -192,7 +223,10 @@ extern "C" int pn2_dropout_grad(long long n, const float* dy, const unsigned cha
                                 void* stream) {
     if (n <= 0 || !(keep_prob > 0.f) || keep_prob > 1.f) return PN2_EINVAL;
     if (!dy || !mask || !dx) return PN2_ENULL;
-    dropout_grad_kernel<<<grid_1d(n), 256, 0, static_cast<hipStream_t>(stream)>>>(n, dy, mask, keep_prob, dx);
+    if (n % 4 == 0 && (((uintptr_t)dy | (uintptr_t)dx | (uintptr_t)mask) % 16) == 0)
+        dropout_grad_kernel<4><<<grid_1d(n / 4), 256, 0, static_cast<hipStream_t>(stream)>>>(n, dy, mask, keep_prob, dx);
+    else
+        dropout_grad_kernel<1><<<grid_1d(n), 256, 0, static_cast<hipStream_t>(stream)>>>(n, dy, mask, keep_prob, dx);
     PN2_RETURN_IF_LAUNCH_FAILED();
     return PN2_OK;
 }

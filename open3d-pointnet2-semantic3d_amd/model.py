@@ -137,6 +137,8 @@ def get_sa_fp_features(point_cloud, is_training, hyperparams, bn_decay=None, two
     two_streams (inference only): overlap the geometry chain with the MLP chain.
     geometry (extension): compute_geometry(l0_xyz) of this very batch, computed ahead."""
     end_points = {}
+    if is_training:
+        tf_util.reset_bn_links()  # producer records of the previous forward pass (tf_util._TrainDenseBnRelu)
     if hyperparams["use_color"]:
         feature_size = 3 * int(hyperparams["use_color"])
         l0_xyz = point_cloud[:, :, 0:3].contiguous()

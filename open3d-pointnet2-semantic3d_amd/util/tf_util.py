@@ -623,6 +623,42 @@ def _train_dense(inputs, w2d, b):
     return y.reshape(list(inputs.shape[:-1]) + [cout])
 
 
+# ---- cross-layer link: the first batch-norm reduction of layer i rides in the data-gradient GEMM of layer i+1 -----------
+# When the output z of a dense+BN(+ReLU) layer is consumed by exactly one other such layer, the gradient dz reaching the
+# batch norm is the dX of that consumer's data-gradient GEMM.  pn2_linear_dgrad_bn_grad_stats forms the two per-channel
+# sums of the batch-norm gradient (sum g, sum g * xhat) from its accumulator tiles, so the producer's backward skips the
+# reduction pass over (dz, y) (pn2_bn_relu_backward_stats).  The link is keyed by the storage address of z and checked
+# again in the backward: only when the tensor arriving as dz IS the linked GEMM's output (a second consumer makes autograd
+# hand over a sum in a new tensor) is the shortcut taken.
+USE_DGRAD_BN_STATS = True
+_bn_links = {}
+
+
+class _BnLink:
+    __slots__ = ("shape", "y", "gamma", "beta", "mean", "invstd", "relu", "ws", "dz_ptr", "dz_keep")
+
+
+def reset_bn_links():
+    """forget the producer records of the previous forward pass (model.get_model calls this when training)"""
+    _bn_links.clear()
+
+
+def hip_linear_dgrad_linked(dy, w, link):
+    """hip_linear_dgrad whose result is the gradient reaching the batch norm of the layer recorded in `link`: the GEMM also
+    leaves that batch norm's two gradient sums in a zeroed workspace (pn2_linear_dgrad_bn_grad_stats) and notes both on the
+    record for the producer's backward."""
+    rows, cin = dy.shape[0], w.shape[0]
+    pws = _bn_zeroed_scratch(cin, dy.device)
+    dx = torch.empty((rows, cin), dtype=torch.float32, device=dy.device)
+    with torch.cuda.device(dy.device):
+        check(lib.pn2_linear_dgrad_bn_grad_stats(rows, cin, w.shape[1], ptr(dy), ptr(w.contiguous()), ptr(dx), ptr(link.y),
+                                                 ptr(link.gamma), ptr(link.beta), ptr(link.mean), ptr(link.invstd),
+                                                 int(link.relu), ptr(pws), pws.numel() * pws.element_size(), stream_ptr()),
+              "pn2_linear_dgrad_bn_grad_stats")
+    link.ws, link.dz_ptr, link.dz_keep = pws, dx.data_ptr(), dx
+    return dx
+
+
 class _TrainDenseBnRelu(torch.autograd.Function):
     """relu?(batch_norm(x2d @ w + b)) [-> max over groups of `pool` rows] for the training path, with the
     normalisation on the HIP library: forward = GEMM -> pn2_bn_relu_forward (fp64 batch moments, normalise + ReLU
@@ -657,6 +693,17 @@ class _TrainDenseBnRelu(torch.autograd.Function):
         else:
             ctx.save_for_backward(x2d, w, y, gamma, beta, save_mean, save_invstd)
         ctx.relu, ctx.pool = bool(relu), int(pool)
+        # producer of this layer's input (if it was an un-pooled dense+BN layer of this forward pass) / this layer as a producer
+        prev = _bn_links.get(x2d.data_ptr()) if USE_DGRAD_BN_STATS else None
+        ctx.prev = prev if (prev is not None and prev.y is not None and prev.shape == tuple(x2d.shape) and w.shape[1] > 16) else None
+        ctx.link = None
+        if USE_DGRAD_BN_STATS and not pooled:
+            if len(_bn_links) > 256:
+                _bn_links.clear()
+            lk = _BnLink()
+            lk.shape, lk.y, lk.gamma, lk.beta, lk.mean, lk.invstd, lk.relu = tuple(z.shape), y, gamma, beta, save_mean, save_invstd, bool(relu)
+            lk.ws = lk.dz_ptr = lk.dz_keep = None
+            _bn_links[z.data_ptr()] = ctx.link = lk
         return z
 
     @staticmethod
@@ -668,7 +715,13 @@ class _TrainDenseBnRelu(torch.autograd.Function):
         dy = torch.empty_like(y)
         dgamma = torch.empty_like(gamma)
         dbeta = torch.empty_like(beta)
-        ws, bwd = _bn_scratch(c, y.device, lib.pn2_bn_relu_backward, lib.pn2_bn_relu_backward_ws0)
+        lk = ctx.link
+        if lk is not None and lk.ws is not None and lk.dz_ptr == dz.data_ptr() and dz.shape == y.shape:
+            ws, bwd = lk.ws, lib.pn2_bn_relu_backward_stats  # the consumer's data-gradient GEMM left the two sums there
+        else:
+            ws, bwd = _bn_scratch(c, y.device, lib.pn2_bn_relu_backward, lib.pn2_bn_relu_backward_ws0)
+        if lk is not None:  # this layer's backward runs once: drop what the record kept alive
+            lk.ws = lk.dz_keep = lk.dz_ptr = lk.y = lk.gamma = lk.beta = lk.mean = lk.invstd = None
         with torch.cuda.device(y.device):
             check(bwd(rows, c, ptr(dz), ptr(y), ptr(gamma), ptr(beta), ptr(save_mean),
                       ptr(save_invstd), int(ctx.relu), ctx.pool, ptr(zmax), ptr(ties), ptr(ws),
@@ -676,7 +729,8 @@ class _TrainDenseBnRelu(torch.autograd.Function):
                   "pn2_bn_relu_backward")
             dx = None
             if ctx.needs_input_grad[0]:
-                dx = hip_linear_dgrad(dy, w)
+                pv = ctx.prev
+                dx = hip_linear_dgrad_linked(dy, w, pv) if (pv is not None and pv.y is not None) else hip_linear_dgrad(dy, w)
             dw = None
             if ctx.needs_input_grad[1]:
                 dw = _hip_wgrad(x2d, dy, w)

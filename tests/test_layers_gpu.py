@@ -1098,6 +1098,61 @@ def test_train_layer_hip_bn_matches_torch_autograd(pn2, cuda, pool):
         assert float((a - r).abs().max()) <= 2e-4 * s
 
 
+@pytest.mark.parametrize("widths,pool,rows_shape", [
+    ((32, 32, 64), 32, (4, 40, 32, 6)),        # SA1's stack (ragged tile counts, narrow layers)
+    ((128, 128, 128), 0, (2, 1000, 1, 131)),   # FP4's stack (odd input width, 2000 rows)
+    ((256, 96), 0, (3, 70, 1, 320)),           # widths that are not a multiple of 128 / rows not a multiple of 32
+])
+def test_bn_grad_sums_from_the_next_layers_dgrad(pn2, cuda, widths, pool, rows_shape):
+    """The first reduction of a layer's batch-norm gradient taken from the accumulator tiles of the NEXT layer's data-gradient
+    GEMM (pn2_linear_dgrad_bn_grad_stats + pn2_bn_relu_backward_stats, tf_util._BnLink) against the two-pass backward
+    (pn2_linear_dgrad + pn2_bn_relu_backward): same gradients up to fp64 summation order, and the shortcut really ran for
+    every link of the stack.  Reference semantics: tf.gradients through conv2d -> batch_norm -> relu, tf_util.py:186-204."""
+    import torch
+    tfu = pn2.util.tf_util
+    torch.manual_seed(3)
+    x0 = torch.randn(*rows_shape, device=cuda)
+    cin = rows_shape[-1]
+    ws = []
+    c = cin
+    for wd in widths:
+        ws.append(torch.randn(c, wd, device=cuda) / np.sqrt(c))
+        c = wd
+    oshape = list(rows_shape[:-1]) + [widths[-1]]
+    if pool:
+        oshape[-2] //= pool
+    probe = torch.cos(torch.arange(int(np.prod(oshape)), device=cuda).float() * 0.37).reshape(oshape)
+    calls = []
+    real = pn2._lib.lib.pn2_bn_relu_backward_stats
+    outs = {}
+    for use in (True, False):
+        tfu.USE_DGRAD_BN_STATS = use
+        tfu.reset_bn_links()
+        try:
+            if use:
+                pn2._lib.lib.pn2_bn_relu_backward_stats = lambda *a: (calls.append(a[1]), real(*a))[1]
+            xx = x0.clone().requires_grad_(True)
+            params, h = [], xx
+            for i, wd in enumerate(widths):
+                w = ws[i].clone().requires_grad_(True)
+                gamma = (1.0 + 0.1 * torch.sin(torch.arange(wd, device=cuda).float())).requires_grad_(True)
+                beta = (0.05 * torch.cos(torch.arange(wd, device=cuda).float())).requires_grad_(True)
+                mean, var = torch.zeros(wd, device=cuda), torch.ones(wd, device=cuda)
+                last = i == len(widths) - 1
+                h = tfu._train_layer(h, w, torch.zeros(wd, device=cuda), (beta, gamma, mean, var), None, True,
+                                     pool if last else 0)
+                params += [w, gamma, beta]
+            (h * probe).sum().backward()
+            outs[use] = [h.detach(), xx.grad] + [p_.grad for p_ in params]
+        finally:
+            tfu.USE_DGRAD_BN_STATS = True
+            pn2._lib.lib.pn2_bn_relu_backward_stats = real
+    assert calls == list(widths[:-1][::-1]), calls   # every layer but the last got its sums from the layer above
+    for a, r in zip(outs[True], outs[False]):
+        s = max(float(r.abs().max()), 1e-3)
+        assert float((a - r).abs().max()) <= 2e-5 * s
+
+
 @pytest.mark.parametrize("rows,cin,widths,pool,relu_last", [
     (8192, 259, (256, 256, 512), 32, True),    # SA4 of the SSG model (materialised front end: odd row width, scalar loads)
     (16384, 320, (256, 128), 0, True),         # FP3

@@ -232,7 +232,7 @@ def test_every_gemm_of_a_real_step_is_as_accurate_as_the_library(pn2, cuda):
     hp.update(l1_npoint=256, l2_npoint=64, l3_npoint=32, l4_npoint=16)
     pc, labels, smpw = _batch(cuda, 0)
     seen = []
-    orig_mm, orig_dg, orig_mms = tfu.hip_matmul, tfu.hip_linear_dgrad, tfu.hip_matmul_bn_stats
+    orig_mm, orig_dg, orig_mms, orig_dgl = tfu.hip_matmul, tfu.hip_linear_dgrad, tfu.hip_matmul_bn_stats, tfu.hip_linear_dgrad_linked
 
     def mm(x, w, ws=None):
         y = orig_mm(x, w) if ws is None else orig_mms(x, w, ws)  # ws: the GEMM that also accumulates batch statistics
@@ -241,20 +241,20 @@ def test_every_gemm_of_a_real_step_is_as_accurate_as_the_library(pn2, cuda):
                      float(((x @ w).double() - ref).norm() / ref.norm())))
         return y
 
-    def dg(dy, w):
-        dx = orig_dg(dy, w)
+    def dg(dy, w, link=None):  # link: the GEMM that also accumulates the batch-norm gradient sums of the layer below
+        dx = orig_dg(dy, w) if link is None else orig_dgl(dy, w, link)
         ref = dy.double() @ w.double().t()
         seen.append(("dgrad", tuple(dy.shape), w.shape[0], float((dx.double() - ref).norm() / ref.norm()),
                      float(((dy @ w.t()).double() - ref).norm() / ref.norm())))
         return dx
 
-    tfu.hip_matmul, tfu.hip_linear_dgrad, tfu.hip_matmul_bn_stats = mm, dg, mm
+    tfu.hip_matmul, tfu.hip_linear_dgrad, tfu.hip_matmul_bn_stats, tfu.hip_linear_dgrad_linked = mm, dg, mm, dg
     try:
         tfu.set_default_store(tfu.VariableStore(device=cuda, seed=5))
         logits, _ = pn2.model.get_model(pc, True, 9, hp, bn_decay=0.5)
         pn2.model.get_loss(logits, labels, smpw).backward()
     finally:
-        tfu.hip_matmul, tfu.hip_linear_dgrad, tfu.hip_matmul_bn_stats = orig_mm, orig_dg, orig_mms
+        tfu.hip_matmul, tfu.hip_linear_dgrad, tfu.hip_matmul_bn_stats, tfu.hip_linear_dgrad_linked = orig_mm, orig_dg, orig_mms, orig_dgl
     assert sum(1 for s_ in seen if s_[0] == "fwd") == 23 and sum(1 for s_ in seen if s_[0] == "dgrad") == 22
     for kind, shape, n, e_pn2, e_torch in seen:
         assert e_pn2 <= 1e-6 and e_pn2 <= 2.0 * e_torch + 1e-8, (kind, shape, n, e_pn2, e_torch)
