@@ -511,6 +511,19 @@ int pn2_group_pool(long long rows, int k, int c, int mode, const float *x, const
 int pn2_group_pool_grad(long long rows, int k, int c, int mode, const float *x, const float *gxyz, const float *dout,
                         float *dx, void *stream);
 
+/* First layer of an SA / FP module of the TRAINING path with its feature half applied to the source rows (gather and
+ * interpolation are linear and commute with a 1x1 conv):
+ *   SA (pointnet_util.py:39-54,150-156):  y (b,m,nsample,cout) = (group_point(xyz, idx) - new_xyz) . w_xyz (3,cout) + z[b, idx]
+ *      with z (b,n,cout) = points . W[3:] from pn2_linear; gxyz (b,m,nsample,3), optional: the centred coordinates.
+ *   FP (pointnet_util.py:300-312):        y (b,n,cout) = three_interpolate(z, idx, w(dist)) + points1 (b,n,c1) . w1 (c1,cout)
+ *      with z (b,m,cout) = points2 . W[:c2]; weights from three_nn's squared distances as in pn2_fp_interp_concat; 1 <= c1 <= 8.
+ * cout % 4 == 0, <= 1024; z, y, w 16-byte aligned.  The data and weight gradients of the feature half are then GEMMs over
+ * the source rows (pn2_scatter_plan_apply of dy -> dz, pn2_linear_dgrad / pn2_linear_wgrad on n resp. m rows). */
+int pn2_sa_hoist_rows(int b, int n, int m, int nsample, int cout, const float *xyz, const float *new_xyz, const int *idx,
+                      const float *z, const float *w_xyz, float *y, float *gxyz, void *stream);
+int pn2_fp_hoist_rows(int b, int n, int m, int c1, int cout, const float *dist, const int *idx, const float *points1,
+                      const float *z, const float *w1, float *y, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -15,7 +15,7 @@ CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libpn2_hip.so")
 SOURCES = ["pn2_abi.hip", "pn2_sampling.hip", "pn2_grouping.hip", "pn2_interpolate.hip",
            "pn2_linear.hip", "pn2_sa_fused.hip", "pn2_sa_fused_bf16.hip", "pn2_label_interp.hip", "pn2_fps_bucket.hip",
-           "pn2_bn.hip", "pn2_scene.hip", "pn2_train.hip", "pn2_mlp_wide.hip", "pn2_pool.hip"]
+           "pn2_bn.hip", "pn2_scene.hip", "pn2_train.hip", "pn2_mlp_wide.hip", "pn2_pool.hip", "pn2_hoist.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off",
          "-munsafe-fp-atomics", "-fno-gpu-rdc", "-fno-slp-vectorize", "-Wall", "-Wno-unused-function"]
 

@@ -91,28 +91,16 @@ __device__ __forceinline__ void bn_block_sums(const BnMap<VEC>& mp, int c, int n
 // final[col] = sum over the slot copies.  A launch of its own rather than a "last block folds" epilogue: that variant
 // needs a ticket counter and device-scope fences in every reduction block and measured the same step time (8.2-8.7 ms
 // for 128-512 blocks) -- the kernel boundary gives the ordering for free.
-// Eight threads per column, each with its share of the copies in flight at once: with one thread per column and the copies
-// read eight at a time the kernel was eight dependent L2 round trips long (4.9 us x 45 launches per training step).
-constexpr int kBnFoldParts = 8;
+// (Eight threads per column with all their copies in flight at once measured the same 4.9 us per launch: the duration of
+// this kernel is a fixed cost, not its eight dependent L2 round trips.)
 __global__ void __launch_bounds__(kBnThreads)
 bn_fold_kernel(int cols, int nslots, double* __restrict__ ws) {
-    const int part = threadIdx.x & (kBnFoldParts - 1);
-    const int col = blockIdx.x * (kBnThreads / kBnFoldParts) + (threadIdx.x >> 3);
+    const int col = blockIdx.x * kBnThreads + threadIdx.x;
+    if (col >= cols) return;
     double t = 0.0;
-    if (col < cols) {
-        double v[kPn2BnSlots / kBnFoldParts];
-#pragma unroll
-        for (int i = 0; i < kPn2BnSlots / kBnFoldParts; ++i) {
-            const int k = part + i * kBnFoldParts;
-            v[i] = k < nslots ? ws[kBnHead + (size_t)cols * (1 + k) + col] : 0.0;
-        }
-#pragma unroll
-        for (int i = 0; i < kPn2BnSlots / kBnFoldParts; ++i) t += v[i];
-    }
-    t += __shfl_xor(t, 1);
-    t += __shfl_xor(t, 2);
-    t += __shfl_xor(t, 4);
-    if (col < cols && part == 0) ws[kBnHead + col] = t;
+#pragma unroll 8
+    for (int k = 0; k < nslots; ++k) t += ws[kBnHead + (size_t)cols * (1 + k) + col];
+    ws[kBnHead + col] = t;
 }
 
 // acc[0][ch] = sum_r y[r][ch], acc[1][ch] = sum_r y[r][ch]^2 over the block's slab of rows
@@ -472,7 +460,7 @@ static int bn_relu_forward_impl(long long rows, int c, const float* y, const flo
         if (e != hipSuccess) return (int)e;
     }
     if (mode == 2) p.nslots = kBnSlots;
-    const int fold_blocks = (2 * c * kBnFoldParts + kBnThreads - 1) / kBnThreads;
+    const int fold_blocks = (2 * c + kBnThreads - 1) / kBnThreads;
     long long pb = 1;  // pooled apply: one group per (thread row slot), grid-stride beyond 8 blocks per CU
     if (pool > 1) {
         const int rp = kBnThreads / (c / p.vec);
@@ -547,7 +535,7 @@ static int bn_relu_backward_impl(long long rows, int c, const float* dz, const f
         if (e != hipSuccess) return (int)e;
     }
     if (mode == 2) p.nslots = kBnSlots;
-    const int fold_blocks = (2 * c * kBnFoldParts + kBnThreads - 1) / kBnThreads;
+    const int fold_blocks = (2 * c + kBnThreads - 1) / kBnThreads;
 #define PN2_BN_BWD(V_)                                                                                                  \
     do {                                                                                                                \
         if (mode != 2)                                                                                                  \

@@ -1,0 +1,192 @@
+// pn2_hoist.hip -- first layer of an SA / FP module of the TRAINING path with its feature half applied to the source rows.
+//
+// The first 1x1 conv of pointnet_sa_module acts on concat[grouped_xyz - new_xyz | group_point(points)]
+// (util/pointnet_util.py:39-54,150-156), that of pointnet_fp_module on concat[three_interpolate(points2) | points1]
+// (:300-312).  Gathering and interpolating are linear and act row-wise, so they commute with the conv:
+//     SA:  y[b,j,k,:] = (xyz[b,idx] - new_xyz[b,j]) @ W[:3]  +  (points @ W[3:])[b, idx[b,j,k], :]
+//     FP:  y[b,i,:]   = sum_k w_k (points2 @ W[:c2])[b, idx[b,i,k], :]  +  points1[b,i,:] @ W[c2:]
+// The product z = points @ W[3:] resp. points2 @ W[:c2] is one GEMM over the SOURCE rows (8x fewer than the grouped /
+// interpolated rows for K = 32 neighbours over 4x fewer centres, resp. n / m = 4..8), and so are its data and weight
+// gradients; the kernels here do what is left per output row: gather 1 (SA) or 3 weighted (FP) rows of z and add the
+// 3-channel (xyz) resp. c1 <= 8 channel (points1) product.  HBM-bound: one write of y, the gathers are served by L2
+// (workgroup L runs on XCD L % 8: whole batch elements per XCD).  Inference uses the fused *_pre kernels instead
+// (pn2_sa_fused.hip, pn2_mlp_wide.hip); batch norm needs y in memory, so training keeps it.
+#include "pn2_common.h"
+
+namespace {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int kHoistMaxCa = 8;
+
+struct HoistParams {
+    int rows;      // output rows per batch element (SA: m * nsample, FP: n)
+    int nsrc;      // rows of z per batch element
+    int cout;      // width of z and y, % 4 == 0, <= 1024
+    int ca;        // channels of the direct operand (SA: 3, FP: c1 <= 8)
+    int nsample;   // SA: neighbours per centre
+    int m;         // SA: centres per batch element
+    const int* idx;        // SA (b, m, nsample), FP (b, n, 3)
+    const float* dist;     // FP (b, n, 3) squared distances of three_nn
+    const float* z;        // (b, nsrc, cout)
+    const float* xyz;      // SA (b, nsrc, 3)
+    const float* new_xyz;  // SA (b, m, 3)
+    const float* points1;  // FP (b, n, ca)
+    const float* wa;       // (ca, cout)
+    float* y;              // (b, rows, cout)
+    float* gxyz;           // SA (b, rows, 3) centred coordinates (operand of the weight gradient), may be null
+};
+
+template <bool SA, int CA>
+__global__ void __launch_bounds__(256)
+hoist_rows_kernel(HoistParams p) {
+    int bx = blockIdx.x, bi = blockIdx.y;
+    {   // XCD-aware block remap (speed only), as in fp_interp_concat_rows_kernel
+        const unsigned nwg = gridDim.x * gridDim.y;
+        if ((nwg & 7u) == 0u) {
+            const unsigned lin = blockIdx.x + gridDim.x * blockIdx.y;
+            const unsigned swz = (lin & 7u) * (nwg >> 3) + (lin >> 3);
+            bx = (int)(swz % gridDim.x);
+            bi = (int)(swz / gridDim.x);
+        }
+    }
+    const int cv = p.cout >> 2;                 // float4 columns
+    const int rp = 256 / cv;                    // rows per pass of the block (cv <= 256)
+    const int rr = (int)threadIdx.x / cv, cc = (int)threadIdx.x - rr * cv;
+    if (rr >= rp) return;
+    const f32x4* __restrict__ z = reinterpret_cast<const f32x4*>(p.z + (size_t)bi * p.nsrc * p.cout);
+    f32x4* __restrict__ y = reinterpret_cast<f32x4*>(p.y + (size_t)bi * p.rows * p.cout);
+    f32x4 wa[CA];
+#pragma unroll
+    for (int a = 0; a < CA; ++a) wa[a] = *reinterpret_cast<const f32x4*>(p.wa + (size_t)a * p.cout + cc * 4);
+    constexpr int U = 4;  // rows in flight per thread
+    for (int r0 = bx * rp * U + rr; r0 < p.rows; r0 += gridDim.x * rp * U) {
+        f32x4 acc[U];
+        float av[U][CA];
+        int rows_[U];
+        if constexpr (SA) {
+            const int* __restrict__ idx = p.idx + (size_t)bi * p.rows;
+            const float* __restrict__ xyz = p.xyz + (size_t)bi * p.nsrc * 3;
+            const float* __restrict__ nx = p.new_xyz + (size_t)bi * p.m * 3;
+            int src[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int r = r0 + u * rp;
+                rows_[u] = r;
+                const int rc = r < p.rows ? r : p.rows - 1;
+                src[u] = idx[rc];
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int rc = rows_[u] < p.rows ? rows_[u] : p.rows - 1;
+                const int j = rc / p.nsample;
+                acc[u] = z[(size_t)src[u] * cv + cc];
+#pragma unroll
+                for (int a = 0; a < 3; ++a) av[u][a] = xyz[(size_t)src[u] * 3 + a] - nx[(size_t)j * 3 + a];
+            }
+            if (p.gxyz && cc == 0) {
+#pragma unroll
+                for (int u = 0; u < U; ++u)
+                    if (rows_[u] < p.rows) {
+                        float* __restrict__ g = p.gxyz + ((size_t)bi * p.rows + rows_[u]) * 3;
+                        g[0] = av[u][0]; g[1] = av[u][1]; g[2] = av[u][2];
+                    }
+            }
+        } else {
+            const int* __restrict__ idx = p.idx + (size_t)bi * p.rows * 3;
+            const float* __restrict__ dist = p.dist + (size_t)bi * p.rows * 3;
+            const float* __restrict__ p1 = p.points1 + (size_t)bi * p.rows * CA;
+            int i1[U], i2[U], i3[U];
+            float w1[U], w2[U], w3[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int r = r0 + u * rp;
+                rows_[u] = r;
+                const int rc = r < p.rows ? r : p.rows - 1;
+                i1[u] = idx[rc * 3 + 0]; i2[u] = idx[rc * 3 + 1]; i3[u] = idx[rc * 3 + 2];
+                // the weights of pointnet_util.py:300-303 with fp_interp_concat's float expressions
+                const float d1 = fmaxf(dist[rc * 3 + 0], 1e-10f), d2 = fmaxf(dist[rc * 3 + 1], 1e-10f);
+                const float d3 = fmaxf(dist[rc * 3 + 2], 1e-10f);
+                const float q1 = 1.0f / d1, q2 = 1.0f / d2, q3 = 1.0f / d3;
+                const float norm = (q1 + q2) + q3;
+                w1[u] = q1 / norm; w2[u] = q2 / norm; w3[u] = q3 / norm;
+#pragma unroll
+                for (int a = 0; a < CA; ++a) av[u][a] = p1[(size_t)rc * CA + a];
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const f32x4 a = z[(size_t)i1[u] * cv + cc], b = z[(size_t)i2[u] * cv + cc], c = z[(size_t)i3[u] * cv + cc];
+                acc[u] = (a * w1[u] + b * w2[u]) + c * w3[u];
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            f32x4 v = acc[u];
+#pragma unroll
+            for (int a = 0; a < CA; ++a) {
+                v[0] = __builtin_fmaf(av[u][a], wa[a][0], v[0]);
+                v[1] = __builtin_fmaf(av[u][a], wa[a][1], v[1]);
+                v[2] = __builtin_fmaf(av[u][a], wa[a][2], v[2]);
+                v[3] = __builtin_fmaf(av[u][a], wa[a][3], v[3]);
+            }
+            if (rows_[u] < p.rows) y[(size_t)rows_[u] * cv + cc] = v;
+        }
+    }
+}
+
+template <bool SA, int CA>
+int launch_hoist(int b, const HoistParams& p, hipStream_t st) {
+    const int cv = p.cout / 4, rp = 256 / cv;
+    long long blocks = ((long long)p.rows + rp * 4 - 1) / (rp * 4);
+    const long long cap = 2048 / (b < 1 ? 1 : b) < 8 ? 8 : 2048 / b;   // ~8 workgroups per CU over the batch
+    if (blocks > cap) blocks = cap;
+    if (blocks < 1) blocks = 1;
+    if ((blocks * b) % 8 != 0 && blocks > 8) blocks -= blocks % 8;     // keeps the XCD remap active
+    hoist_rows_kernel<SA, CA><<<dim3((unsigned)blocks, b), 256, 0, st>>>(p);
+    PN2_RETURN_IF_LAUNCH_FAILED();
+    return PN2_OK;
+}
+
+}  // namespace
+
+// SA: y (b, m, nsample, cout) = (group_point(xyz, idx) - new_xyz) @ w_xyz (3, cout) + z[b, idx] with z (b, n, cout) =
+// points @ W[3:] computed by the caller (pn2_linear); gxyz (b, m, nsample, 3) (optional) receives the centred coordinates
+// (x operand of w_xyz's gradient).  cout % 4 == 0, cout <= 1024.
+extern "C" int pn2_sa_hoist_rows(int b, int n, int m, int nsample, int cout, const float* xyz, const float* new_xyz,
+                                 const int* idx, const float* z, const float* w_xyz, float* y, float* gxyz, void* stream) {
+    if (b <= 0 || n <= 0 || m <= 0 || nsample <= 0 || cout <= 0) return PN2_EINVAL;
+    if (!xyz || !new_xyz || !idx || !z || !w_xyz || !y) return PN2_ENULL;
+    if (cout % 4 != 0 || cout > 1024) return PN2_EUNSUP;
+    if ((((uintptr_t)z | (uintptr_t)y | (uintptr_t)w_xyz) % 16) != 0) return PN2_EINVAL;
+    if ((long long)m * nsample > 0x7fffffffLL || b > 65535) return PN2_ERANGE;
+    HoistParams p = {};
+    p.rows = m * nsample; p.nsrc = n; p.cout = cout; p.ca = 3; p.nsample = nsample; p.m = m;
+    p.idx = idx; p.z = z; p.xyz = xyz; p.new_xyz = new_xyz; p.wa = w_xyz; p.y = y; p.gxyz = gxyz;
+    return launch_hoist<true, 3>(b, p, static_cast<hipStream_t>(stream));
+}
+
+// FP: y (b, n, cout) = three_interpolate(z, idx, w(dist)) + points1 (b, n, c1) @ w1 (c1, cout) with z (b, m, cout) =
+// points2 @ W[:c2] computed by the caller; the weights are formed from three_nn's squared distances as in
+// pn2_fp_interp_concat.  1 <= c1 <= 8 (the level-0 module: colours / no features use pn2_three_interpolate alone).
+extern "C" int pn2_fp_hoist_rows(int b, int n, int m, int c1, int cout, const float* dist, const int* idx,
+                                 const float* points1, const float* z, const float* w1, float* y, void* stream) {
+    if (b <= 0 || n <= 0 || m <= 0 || cout <= 0) return PN2_EINVAL;
+    if (!dist || !idx || !points1 || !z || !w1 || !y) return PN2_ENULL;
+    if (c1 < 1 || c1 > kHoistMaxCa || cout % 4 != 0 || cout > 1024) return PN2_EUNSUP;
+    if ((((uintptr_t)z | (uintptr_t)y | (uintptr_t)w1) % 16) != 0) return PN2_EINVAL;
+    if ((long long)n * 3 > 0x7fffffffLL || b > 65535) return PN2_ERANGE;
+    HoistParams p = {};
+    p.rows = n; p.nsrc = m; p.cout = cout; p.ca = c1;
+    p.idx = idx; p.dist = dist; p.z = z; p.points1 = points1; p.wa = w1; p.y = y;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    switch (c1) {
+        case 1: return launch_hoist<false, 1>(b, p, st);
+        case 2: return launch_hoist<false, 2>(b, p, st);
+        case 3: return launch_hoist<false, 3>(b, p, st);
+        case 4: return launch_hoist<false, 4>(b, p, st);
+        case 5: return launch_hoist<false, 5>(b, p, st);
+        case 6: return launch_hoist<false, 6>(b, p, st);
+        case 7: return launch_hoist<false, 7>(b, p, st);
+        default: return launch_hoist<false, 8>(b, p, st);
+    }
+}

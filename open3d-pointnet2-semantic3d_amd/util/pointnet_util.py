@@ -390,7 +390,19 @@ def pointnet_sa_module(xyz, points, npoint, radius, nsample, mlp, mlp2, group_al
             new_points = sa_features_inference(xyz, new_xyz, points, idx, mlp, bn, bn_decay)
             new_points = new_points.unsqueeze(2)
         else:
-            if group_all:
+            # training, features of >= 16 channels, geometry + scatter plan computed ahead: the feature half of the first
+            # conv runs on the n SOURCE points instead of the m * nsample grouped rows (tf_util._TrainHoistedBnRelu)
+            hoist = (bool(is_training) and tf_util.USE_HOISTED_TRAIN and not group_all and not knn and use_xyz and bn
+                     and pooling == "max" and points is not None and points.dtype == torch.float32 and points.shape[2] >= 16
+                     and len(mlp) > 0 and mlp[0] % 4 == 0 and nsample <= 1024 and geometry is not None and len(geometry) > 2
+                     and _plan_usable(geometry[2], mlp[0]))
+            first = 0
+            if hoist:
+                new_xyz, idx, grouped_xyz = geometry[0], geometry[1], None
+                new_points = tf_util.conv2d_hoisted_first("sa", points, (xyz, new_xyz, idx), geometry[2], 3 + points.shape[2],
+                                                          mlp[0], "conv0", bn_decay, pool=nsample if len(mlp) == 1 else 0)
+                first = 1
+            elif group_all:
                 nsample = xyz.shape[1]
                 new_xyz, new_points, idx, grouped_xyz = sample_and_group_all(xyz, points, use_xyz)
             else:
@@ -399,6 +411,8 @@ def pointnet_sa_module(xyz, points, npoint, radius, nsample, mlp, mlp2, group_al
             # training: the max over K rides in the last layer's batch-norm kernels (tf_util._TrainDenseBnRelu)
             fuse_pool = bool(is_training) and pooling == "max" and len(mlp) > 0 and nsample <= 1024
             for i, cout in enumerate(mlp):
+                if i < first:
+                    continue
                 new_points = tf_util.conv2d(new_points, cout, [1, 1], padding="VALID", stride=[1, 1], bn=bn,
                                             is_training=is_training, scope="conv%d" % i, bn_decay=bn_decay,
                                             pool=nsample if (fuse_pool and i == len(mlp) - 1) else 0)
@@ -591,6 +605,18 @@ def pointnet_fp_module(xyz1, xyz2, points1, points2, mlp, is_training, bn_decay,
         if not is_training:
             # weights + interpolate + concat fused, then LDS-resident MLP chains / MFMA layers
             return fp_features_inference(dist, idx, points1, points2, mlp, bn, bn_decay)
+        # the level-0 module (points1 = a few input channels, data): the interpolated half of the first conv runs on the
+        # n2 known points instead of the n1 dense ones (tf_util._TrainHoistedBnRelu)
+        if (tf_util.USE_HOISTED_TRAIN and bn and points1 is not None and 1 <= points1.shape[2] <= 8 and not points1.requires_grad
+                and points1.dtype == torch.float32 and points2.dtype == torch.float32 and len(mlp) > 0 and mlp[0] % 4 == 0
+                and _plan_usable(plan, mlp[0])):
+            h = tf_util.conv2d_hoisted_first("fp", points2, (dist, idx, points1), plan, points2.shape[2] + points1.shape[2],
+                                             mlp[0], "conv_0", bn_decay)
+            for i, cout in enumerate(mlp):
+                if i > 0:
+                    h = tf_util.conv2d(h, cout, [1, 1], padding="VALID", stride=[1, 1], bn=bn, is_training=is_training,
+                                       scope="conv_%d" % i, bn_decay=bn_decay)
+            return h.squeeze(2)
         if USE_FUSED_TRAIN_FRONT and points2.dtype == torch.float32:
             new_points1 = _FPInterpConcat.apply(dist, idx, None if points1 is None else points1.contiguous(),
                                                 points2.contiguous(), plan)

@@ -659,6 +659,63 @@ def hip_linear_dgrad_linked(dy, w, link):
     return dx
 
 
+def _bn_train_forward(y, b, gamma, beta, running_mean, running_var, decay, relu, pool, stats_ws=None):
+    """batch norm (+ReLU, + max over groups of `pool` rows) of a layer output y (rows, c) on pn2_bn_relu_forward; stats_ws: the
+    workspace pn2_linear_bn_stats has already left the column sums in.  -> z, ties, save_mean, save_invstd"""
+    rows, c = y.shape
+    if stats_ws is not None:
+        ws, fwd = stats_ws, lib.pn2_bn_relu_forward_stats
+    else:
+        ws, fwd = _bn_scratch(c, y.device, lib.pn2_bn_relu_forward, lib.pn2_bn_relu_forward_ws0)
+    pooled = pool > 1
+    z = torch.empty((rows // pool, c) if pooled else (rows, c), dtype=y.dtype, device=y.device)
+    ties = torch.empty_like(z) if pooled else None
+    save_mean = torch.empty(c, dtype=torch.float32, device=y.device)
+    save_invstd = torch.empty_like(save_mean)
+    with torch.cuda.device(y.device):
+        check(fwd(rows, c, ptr(y), ptr(gamma), ptr(beta), ptr(b), BN_EPSILON, decay, int(relu),
+                  int(pool), ptr(running_mean), ptr(running_var), ptr(ws), ws.numel() * ws.element_size(),
+                  ptr(save_mean), ptr(save_invstd), ptr(z), ptr(ties), stream_ptr()),
+              "pn2_bn_relu_forward")
+    return z, ties, save_mean, save_invstd
+
+
+def _bn_register_producer(z, y, gamma, beta, save_mean, save_invstd, relu, pooled):
+    """record an un-pooled dense+BN layer as the possible producer of the next layer's input (see _BnLink) -> link or None"""
+    if not USE_DGRAD_BN_STATS or pooled:
+        return None
+    if len(_bn_links) > 256:
+        _bn_links.clear()
+    lk = _BnLink()
+    lk.shape, lk.y, lk.gamma, lk.beta, lk.mean, lk.invstd, lk.relu = tuple(z.shape), y, gamma, beta, save_mean, save_invstd, bool(relu)
+    lk.ws = lk.dz_ptr = lk.dz_keep = None
+    _bn_links[z.data_ptr()] = lk
+    return lk
+
+
+def _bn_train_backward(dz, y, gamma, beta, save_mean, save_invstd, relu, pool, zmax, ties, lk):
+    """gradient of _bn_train_forward on pn2_bn_relu_backward -> dy (rows, c), dgamma, dbeta.  lk: this layer's producer
+    record; when the consumer's data-gradient GEMM has already left the two reduction sums there (and dz is that GEMM's
+    output), the reduction pass is skipped."""
+    rows, c = y.shape
+    dz = dz.contiguous()
+    dy = torch.empty_like(y)
+    dgamma = torch.empty_like(gamma)
+    dbeta = torch.empty_like(beta)
+    if lk is not None and lk.ws is not None and lk.dz_ptr == dz.data_ptr() and dz.shape == y.shape:
+        ws, bwd = lk.ws, lib.pn2_bn_relu_backward_stats
+    else:
+        ws, bwd = _bn_scratch(c, y.device, lib.pn2_bn_relu_backward, lib.pn2_bn_relu_backward_ws0)
+    if lk is not None:  # this layer's backward runs once: drop what the record kept alive
+        lk.ws = lk.dz_keep = lk.dz_ptr = lk.y = lk.gamma = lk.beta = lk.mean = lk.invstd = None
+    with torch.cuda.device(y.device):
+        check(bwd(rows, c, ptr(dz), ptr(y), ptr(gamma), ptr(beta), ptr(save_mean),
+                  ptr(save_invstd), int(relu), int(pool), ptr(zmax), ptr(ties), ptr(ws),
+                  ws.numel() * ws.element_size(), ptr(dy), ptr(dgamma), ptr(dbeta), stream_ptr()),
+              "pn2_bn_relu_backward")
+    return dy, dgamma, dbeta
+
+
 class _TrainDenseBnRelu(torch.autograd.Function):
     """relu?(batch_norm(x2d @ w + b)) [-> max over groups of `pool` rows] for the training path, with the
     normalisation on the HIP library: forward = GEMM -> pn2_bn_relu_forward (fp64 batch moments, normalise + ReLU
@@ -668,26 +725,15 @@ class _TrainDenseBnRelu(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x2d, w, b, gamma, beta, running_mean, running_var, decay, relu, pool):
-        rows, c = x2d.shape[0], w.shape[1]
-        fused_stats = USE_GEMM_BN_STATS and c % 32 == 0
-        if fused_stats:
+        c = w.shape[1]
+        if USE_GEMM_BN_STATS and c % 32 == 0:
             # the GEMM's epilogue leaves the column sums of y in the batch-norm workspace: no statistics pass over y
             ws = _bn_zeroed_scratch(c, x2d.device)
-            fwd = lib.pn2_bn_relu_forward_stats
             y = hip_matmul_bn_stats(x2d, w, ws)
         else:
-            y = hip_matmul(x2d, w)
-            ws, fwd = _bn_scratch(c, y.device, lib.pn2_bn_relu_forward, lib.pn2_bn_relu_forward_ws0)
+            ws, y = None, hip_matmul(x2d, w)
+        z, ties, save_mean, save_invstd = _bn_train_forward(y, b, gamma, beta, running_mean, running_var, decay, relu, pool, ws)
         pooled = pool > 1
-        z = torch.empty((rows // pool, c) if pooled else (rows, c), dtype=y.dtype, device=y.device)
-        ties = torch.empty_like(z) if pooled else None
-        save_mean = torch.empty(c, dtype=torch.float32, device=y.device)
-        save_invstd = torch.empty_like(save_mean)
-        with torch.cuda.device(y.device):
-            check(fwd(rows, c, ptr(y), ptr(gamma), ptr(beta), ptr(b), BN_EPSILON, decay, int(relu),
-                      int(pool), ptr(running_mean), ptr(running_var), ptr(ws), ws.numel() * ws.element_size(),
-                      ptr(save_mean), ptr(save_invstd), ptr(z), ptr(ties), stream_ptr()),
-                  "pn2_bn_relu_forward")
         if pooled:
             ctx.save_for_backward(x2d, w, y, gamma, beta, save_mean, save_invstd, z, ties)
         else:
@@ -696,47 +742,123 @@ class _TrainDenseBnRelu(torch.autograd.Function):
         # producer of this layer's input (if it was an un-pooled dense+BN layer of this forward pass) / this layer as a producer
         prev = _bn_links.get(x2d.data_ptr()) if USE_DGRAD_BN_STATS else None
         ctx.prev = prev if (prev is not None and prev.y is not None and prev.shape == tuple(x2d.shape) and w.shape[1] > 16) else None
-        ctx.link = None
-        if USE_DGRAD_BN_STATS and not pooled:
-            if len(_bn_links) > 256:
-                _bn_links.clear()
-            lk = _BnLink()
-            lk.shape, lk.y, lk.gamma, lk.beta, lk.mean, lk.invstd, lk.relu = tuple(z.shape), y, gamma, beta, save_mean, save_invstd, bool(relu)
-            lk.ws = lk.dz_ptr = lk.dz_keep = None
-            _bn_links[z.data_ptr()] = ctx.link = lk
+        ctx.link = _bn_register_producer(z, y, gamma, beta, save_mean, save_invstd, relu, pooled)
         return z
 
     @staticmethod
     def backward(ctx, dz):
         x2d, w, y, gamma, beta, save_mean, save_invstd = ctx.saved_tensors[:7]
         zmax, ties = ctx.saved_tensors[7:] if ctx.pool > 1 else (None, None)
-        rows, c = y.shape
-        dz = dz.contiguous()
-        dy = torch.empty_like(y)
-        dgamma = torch.empty_like(gamma)
-        dbeta = torch.empty_like(beta)
-        lk = ctx.link
-        if lk is not None and lk.ws is not None and lk.dz_ptr == dz.data_ptr() and dz.shape == y.shape:
-            ws, bwd = lk.ws, lib.pn2_bn_relu_backward_stats  # the consumer's data-gradient GEMM left the two sums there
-        else:
-            ws, bwd = _bn_scratch(c, y.device, lib.pn2_bn_relu_backward, lib.pn2_bn_relu_backward_ws0)
-        if lk is not None:  # this layer's backward runs once: drop what the record kept alive
-            lk.ws = lk.dz_keep = lk.dz_ptr = lk.y = lk.gamma = lk.beta = lk.mean = lk.invstd = None
-        with torch.cuda.device(y.device):
-            check(bwd(rows, c, ptr(dz), ptr(y), ptr(gamma), ptr(beta), ptr(save_mean),
-                      ptr(save_invstd), int(ctx.relu), ctx.pool, ptr(zmax), ptr(ties), ptr(ws),
-                      ws.numel() * ws.element_size(), ptr(dy), ptr(dgamma), ptr(dbeta), stream_ptr()),
-                  "pn2_bn_relu_backward")
-            dx = None
-            if ctx.needs_input_grad[0]:
-                pv = ctx.prev
-                dx = hip_linear_dgrad_linked(dy, w, pv) if (pv is not None and pv.y is not None) else hip_linear_dgrad(dy, w)
-            dw = None
-            if ctx.needs_input_grad[1]:
-                dw = _hip_wgrad(x2d, dy, w)
+        dy, dgamma, dbeta = _bn_train_backward(dz, y, gamma, beta, save_mean, save_invstd, ctx.relu, ctx.pool, zmax, ties, ctx.link)
+        dx = None
+        if ctx.needs_input_grad[0]:
+            pv = ctx.prev
+            dx = hip_linear_dgrad_linked(dy, w, pv) if (pv is not None and pv.y is not None) else hip_linear_dgrad(dy, w)
+        dw = None
+        if ctx.needs_input_grad[1]:
+            dw = _hip_wgrad(x2d, dy, w)
         # a constant in front of batch norm has no effect on the output: its gradient is exactly zero -- None, which the
         # trainer's gradient buffer treats as (and keeps at) zero without a fill per layer
         return dx, dw, None, dgamma, dbeta, None, None, None, None, None
+
+
+USE_HOISTED_TRAIN = True  # first layer of SA2-SA4 / FP4 with its feature half applied to the source rows (A/B, tests)
+
+
+def _hip_wgrad_into(x2d, dy, dw_rows):
+    """dw_rows (a zero-filled row block of a weight-gradient tile) += x2d^T @ dy on pn2_linear_wgrad_accumulate"""
+    with torch.cuda.device(dy.device):
+        check(lib.pn2_linear_wgrad_accumulate(x2d.shape[0], x2d.shape[1], dy.shape[1], ptr(x2d), ptr(dy), ptr(dw_rows), stream_ptr()),
+              "pn2_linear_wgrad_accumulate")
+
+
+class _TrainHoistedBnRelu(torch.autograd.Function):
+    """First layer of an SA / FP module, training path, with the feature half of the 1x1 conv applied to the SOURCE rows
+    (gather / interpolation are linear and commute with it; csrc/pn2_hoist.hip):
+        SA: y = (group_point(xyz, idx) - new_xyz) @ W[:3] + (points @ W[3:])[idx]              (pointnet_util.py:39-54,150-156)
+        FP: y = three_interpolate(points2 @ W[:c2], idx, w(dist)) + points1 @ W[c2:]             (pointnet_util.py:300-312)
+    then batch norm + ReLU (+ max pool) as in _TrainDenseBnRelu.  The grouped / concatenated tensor is never built, and the
+    GEMM, its data gradient and its weight gradient run on n (resp. m) rows instead of m * nsample (resp. n).  Backward:
+    dy from the batch-norm kernels; dz = the scatter of dy through the precomputed plan (the same list the gradient of
+    group_point / three_interpolate uses); d(points) = dz @ Wb^T, dWb = points^T dz on the source rows; dWa = a^T dy with
+    a = the centred coordinates (SA) resp. points1 (FP, <= 8 channels, data: no gradient)."""
+
+    @staticmethod
+    def forward(ctx, src, w, b, gamma, beta, running_mean, running_var, decay, relu, pool, kind, g0, g1, g2, plan):
+        bsz, nsrc, c = src.shape
+        cout = w.shape[1]
+        src2d = src.reshape(-1, c)
+        if kind == "sa":
+            xyz, new_xyz, idx = g0, g1, g2
+            m, ns = idx.shape[1], idx.shape[2]
+            wa, wb = w[:3], w[3:]
+            rows_b = m * ns
+        else:
+            dist, idx, points1 = g0, g1, g2
+            n, c1 = points1.shape[1], points1.shape[2]
+            wb, wa = w[:c], w[c:]
+            rows_b = n
+        z = hip_matmul(src2d, wb)  # (b * nsrc, cout)
+        y = torch.empty((bsz * rows_b, cout), dtype=torch.float32, device=src.device)
+        with torch.cuda.device(src.device):
+            if kind == "sa":
+                a = torch.empty((bsz * rows_b, 3), dtype=torch.float32, device=src.device)
+                check(lib.pn2_sa_hoist_rows(bsz, nsrc, m, ns, cout, ptr(xyz), ptr(new_xyz), ptr(idx), ptr(z), ptr(wa), ptr(y),
+                                            ptr(a), stream_ptr()), "pn2_sa_hoist_rows")
+            else:
+                a = points1.reshape(-1, c1)
+                check(lib.pn2_fp_hoist_rows(bsz, n, nsrc, c1, cout, ptr(dist), ptr(idx), ptr(a), ptr(z), ptr(wa), ptr(y),
+                                            stream_ptr()), "pn2_fp_hoist_rows")
+        zact, ties, save_mean, save_invstd = _bn_train_forward(y, b, gamma, beta, running_mean, running_var, decay, relu, pool)
+        pooled = pool > 1
+        ctx.save_for_backward(src2d, w, y, gamma, beta, save_mean, save_invstd, a, plan, *((zact, ties) if pooled else ()))
+        ctx.relu, ctx.pool, ctx.kind, ctx.dims = bool(relu), int(pool), kind, (bsz, nsrc, rows_b, c)
+        ctx.link = _bn_register_producer(zact, y, gamma, beta, save_mean, save_invstd, relu, pooled)
+        return zact
+
+    @staticmethod
+    def backward(ctx, dz):
+        src2d, w, y, gamma, beta, save_mean, save_invstd, a, plan = ctx.saved_tensors[:9]
+        zmax, ties = ctx.saved_tensors[9:] if ctx.pool > 1 else (None, None)
+        bsz, nsrc, rows_b, c = ctx.dims
+        cout = w.shape[1]
+        dy, dgamma, dbeta = _bn_train_backward(dz, y, gamma, beta, save_mean, save_invstd, ctx.relu, ctx.pool, zmax, ties, ctx.link)
+        sa = ctx.kind == "sa"
+        wa, wb = (w[:3], w[3:]) if sa else (w[c:], w[:c])
+        from .pointnet_util import _scatter_plan_apply
+        dzs = _scatter_plan_apply(plan, dy.view(bsz, rows_b, cout), 0, cout, rows_b if sa else 3 * rows_b, 1 if sa else 3, nsrc)
+        dzs2d = dzs.view(-1, cout)
+        dsrc = hip_linear_dgrad(dzs2d, wb).view(bsz, nsrc, c) if ctx.needs_input_grad[0] else None
+        dw = None
+        if ctx.needs_input_grad[1]:
+            arena = get_default_store().zero_arena
+            v = arena.take(w.numel() * 4) if arena is not None else None
+            dw = v[:w.numel() * 4].view(torch.float32).view_as(w) if v is not None else torch.zeros_like(w)
+            dwa, dwb = (dw[:3], dw[3:]) if sa else (dw[c:], dw[:c])
+            _hip_wgrad_into(src2d, dzs2d, dwb)
+            _hip_wgrad_into(a, dy, dwa)
+        return (dsrc, dw, None, dgamma, dbeta) + (None,) * 10
+
+
+def conv2d_hoisted_first(kind, src, geo, plan, cin, num_output_channels, scope, bn_decay=None, pool=0):
+    """conv2d(concat-of-a-gathered-tensor, ..., bn=True, is_training=True, activation relu) -- the FIRST layer of an SA
+    (kind "sa": geo = (xyz, new_xyz, idx)) or FP (kind "fp": geo = (dist, idx, points1)) module -- without building the
+    gathered tensor: _TrainHoistedBnRelu.  Same variables (names, shapes, initialisation) as tf_util.conv2d under `scope`;
+    cin = width of the tensor the reference convolves (3 + c resp. c2 + c1).
+    -> (b, m, nsample or nsample/pool, cout) resp. (b, n, 1, cout)."""
+    cout = int(num_output_channels)
+    with variable_scope(scope):
+        st, w, b, bnv = _dense_variables(cin, cout, True, (1, 1, cin, cout))
+        st.train_epoch += 1
+        beta, gamma, mean, var = bnv
+        decay = 0.9 if bn_decay is None else float(bn_decay)
+        pool = int(pool) if pool and pool > 1 else 0
+        z = _TrainHoistedBnRelu.apply(src.contiguous(), w.reshape(cin, cout), b, gamma, beta, mean, var, decay, True, pool, kind,
+                                      geo[0].contiguous(), geo[1].contiguous(), geo[2].contiguous(), plan)
+    if kind == "sa":
+        m, ns = geo[2].shape[1], geo[2].shape[2]
+        return z.reshape(src.shape[0], m, ns // pool if pool else ns, cout)
+    return z.reshape(src.shape[0], geo[2].shape[1], 1, cout)
 
 
 def _train_layer(inputs, w2d, b, bnv, bn_decay, relu, pool=0):

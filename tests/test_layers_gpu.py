@@ -500,6 +500,65 @@ def test_sa_module_hoisted_first_layer_equals_in_place(pn2, oracle, cuda, mlp, c
     close(b_, ref)
 
 
+@pytest.mark.parametrize("kind,mlp,c", [("sa", [64, 64, 128], 64), ("sa", [128], 32), ("sa", [256, 512], 256),
+                                        ("fp", [128, 128, 128], 128), ("fp", [64], 32)])
+def test_training_first_layer_on_the_source_rows_equals_the_grouped_form(pn2, cuda, kind, mlp, c):
+    """Training path: the feature half of a module's first conv applied to the SOURCE rows (tf_util._TrainHoistedBnRelu,
+    pn2_sa_hoist_rows / pn2_fp_hoist_rows; the grouped / concatenated tensor is never built, GEMM + data + weight gradient on
+    n resp. m rows) against the grouped form (pn2_sa_group_concat / pn2_fp_interp_concat + conv2d): module output, moving
+    averages, gradient w.r.t. the source features and every parameter gradient.  Reference maths:
+    pointnet_util.py:39-54,150-170 (SA) and :300-325 (FP) with batch-statistics BN (tf_util.py:555-581)."""
+    import torch
+    tfu, pu = pn2.util.tf_util, pn2.util.pointnet_util
+    rs = np.random.RandomState(len(mlp) + c)
+    b, n = 2, 1024
+    xyz = T(s_scene(c, b, n), cuda)
+    if kind == "sa":
+        m, ns = 128, 16
+        src0 = T(rs.randn(b, n, c).astype(np.float32), cuda)
+        new_xyz, idx = pu.sa_geometry(xyz, m, 0.8, ns)
+        plan = pu.scatter_plan(idx, n)
+        oshape = (b, m, mlp[-1])
+    else:
+        m = 128
+        xyz2 = xyz[:, :m].contiguous()
+        src0 = T(rs.randn(b, m, c).astype(np.float32), cuda)
+        p1 = T(rs.rand(b, n, 3).astype(np.float32), cuda)
+        dist, idx = pn2.three_nn(xyz, xyz2)
+        plan = pu.scatter_plan(idx, m, dist, weight_kind=2)
+        oshape = (b, n, mlp[-1])
+    probe = torch.sin(torch.arange(int(np.prod(oshape)), device=cuda).float() * 0.11).reshape(oshape)
+    outs = {}
+    for hoist in (True, False):
+        tfu.USE_HOISTED_TRAIN = hoist
+        store = tfu.set_default_store(tfu.VariableStore(device=cuda, seed=9))
+        calls = []
+        pn2._lib.lib.trace = calls
+        try:
+            tfu.reset_bn_links()
+            src = src0.clone().requires_grad_(True)
+            if kind == "sa":
+                _, out, _ = pu.pointnet_sa_module(xyz, src, m, 0.8, ns, mlp, None, False, True, 0.5, "mod",
+                                                  geometry=(new_xyz, idx, plan))
+            else:
+                out = pu.pointnet_fp_module(xyz, xyz2, p1, src, mlp, True, 0.5, "mod", nn=(dist, idx, plan))
+            assert tuple(out.shape) == oshape
+            (out * probe).sum().backward()
+        finally:
+            pn2._lib.lib.trace = None
+            tfu.USE_HOISTED_TRAIN = True
+        names = [c_[0] for c_ in calls]
+        assert (("pn2_sa_hoist_rows" if kind == "sa" else "pn2_fp_hoist_rows") in names) == hoist
+        assert (("pn2_sa_group_concat" if kind == "sa" else "pn2_fp_interp_concat") in names) == (not hoist)
+        outs[hoist] = [out.detach(), src.grad] + [p_.grad for _, p_ in sorted(store.params.items()) if p_.grad is not None] + \
+                      [v.clone() for _, v in sorted(store.buffers.items())]
+    assert len(outs[True]) == len(outs[False]) and len(outs[True]) >= 4
+    for a, r in zip(outs[True], outs[False]):
+        assert a.shape == r.shape
+        sc = max(float(r.abs().max()), 1e-3)
+        assert float((a - r).abs().max()) <= 3e-4 * sc, (a.shape, float((a - r).abs().max()), sc)
+
+
 def test_fp_module_chain_equals_per_layer_linear(pn2, oracle, cuda):
     """FP4-shaped module: the chained path and the one-launch-per-layer path agree to fp32 rounding."""
     tfu, pu = pn2.util.tf_util, pn2.util.pointnet_util

@@ -109,6 +109,33 @@ def test_fps_lazy_multipick_kernel_paths(pn2, oracle, cuda, case):
         assert np.array_equal(nx.cpu().numpy(), np.take_along_axis(x, ref[:, :, None].astype(np.int64), 1))
 
 
+def test_fps_random_shapes_differential_fuzz(pn2, oracle, cuda):
+    """Random (b, n, m, distribution) draws across every kernel boundary of the dispatcher -- one-pick register kernels
+    (n <= 2048), lazy multi-pick (<= 8192), streaming (<= 16384), Hilbert-bucket lazy kernel (pn2_fps_large) -- against the
+    oracle (tf_sampling.cu:111-176), default arithmetic mode; also pn2_fps_gather's new_xyz."""
+    rs = np.random.RandomState(77)
+    sizes = [2049, 2111, 3000, 4097, 6007, 8191, 8193, 12000, 16384, 16385, 20011, 40000]
+    for n in sizes:
+        b = int(rs.randint(1, 4))
+        m = int(rs.choice([1, 2, 63, 65, 300, 777, min(n, 1500)]))
+        kind = rs.randint(0, 4)
+        if kind == 0:
+            x = s_scene(n, b, n)
+        elif kind == 1:
+            x = s_randn(n, b, n) * np.float32(rs.choice([1e-3, 1.0, 1e3]))
+        elif kind == 2:
+            x = (rs.randint(-6, 7, (b, n, 3)) * 0.5).astype(np.float32)          # lattice: ties, duplicates
+        else:
+            x = np.concatenate([s_randn(n, b, n - n // 3), np.repeat(s_randn(n + 1, b, 1), n // 3, 1) +
+                                1e-4 * s_randn(n + 2, b, n // 3)], 1).astype(np.float32)  # a third of the cloud in one tight clump
+        ref = oracle.farthest_point_sample(m, x)
+        xt = T(x, cuda)
+        idx, nx = pn2.tf_ops.tf_sampling.farthest_point_sample_and_gather(m, xt)  # n > 16384 -> pn2_fps_large
+        got = idx.cpu().numpy()
+        assert np.array_equal(got, ref), "n=%d m=%d kind=%d first diff at %s" % (n, m, kind, np.argwhere(got != ref)[:3])
+        assert np.array_equal(nx.cpu().numpy(), np.take_along_axis(x, ref[:, :, None].astype(np.int64), 1))
+
+
 def test_fps_streaming_kernel_large_n(pn2, oracle, cuda):
     x = s_scene(8, 2, 20000)  # n > 16384 -> global-scratch kernel
     assert np.array_equal(pn2.farthest_point_sample(40, T(x, cuda)).cpu().numpy(),
