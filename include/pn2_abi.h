@@ -511,6 +511,22 @@ int pn2_group_pool(long long rows, int k, int c, int mode, const float *x, const
 int pn2_group_pool_grad(long long rows, int k, int c, int mode, const float *x, const float *gxyz, const float *dout,
                         float *dx, void *stream);
 
+/* conv2d -> batch_norm -> relu -> conv2d of the training path (tf_util.py:186-204 twice) without writing the normalised
+ * activation of the lower layer: pn2_bn_relu_forward_deferred turns the statistics of y (stats_done = 1: left in the zeroed
+ * workspace by pn2_linear_bn_stats; 0: taken here, workspace zeroed by the caller) into save_mean / save_invstd, the moving
+ * averages and per-channel (scale, shift) with z = relu?(fma(y, scale, shift)); pn2_linear_bn_stats_xf (the upper layer's
+ * forward GEMM + statistics) and pn2_linear_wgrad_accumulate_xf (its weight gradient) apply them to y while loading it.
+ * Only valid when the lower activation has no other consumer.  _xf: cin % 4 == 0, rows > 2048, 16-byte aligned operands,
+ * else PN2_EUNSUP. */
+int pn2_bn_relu_forward_deferred(long long rows, int c, const float *y, const float *gamma, const float *beta,
+                                 const float *bias, float eps, float decay, int stats_done, float *running_mean,
+                                 float *running_var, void *workspace, size_t workspace_bytes, float *save_mean,
+                                 float *save_invstd, float *scale, float *shift, void *stream);
+int pn2_linear_bn_stats_xf(int rows, int cin, int cout, const float *x_raw, const float *w, float *y, void *bn_workspace,
+                           size_t workspace_bytes, const float *a_scale, const float *a_shift, int a_relu, void *stream);
+int pn2_linear_wgrad_accumulate_xf(int rows, int cin, int cout, const float *x_raw, const float *dy, float *dw,
+                                   const float *a_scale, const float *a_shift, int a_relu, void *stream);
+
 /* First layer of an SA / FP module of the TRAINING path with its feature half applied to the source rows (gather and
  * interpolation are linear and commute with a 1x1 conv):
  *   SA (pointnet_util.py:39-54,150-156):  y (b,m,nsample,cout) = (group_point(xyz, idx) - new_xyz) . w_xyz (3,cout) + z[b, idx]

@@ -77,6 +77,11 @@ SIGNATURES = {
                               c_void_p, c_void_p, c_void_p, ctypes.c_size_t, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p],
     "pn2_linear_wgrad_accumulate": [c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p],
     "pn2_linear_dgrad": [c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p],
+    "pn2_bn_relu_forward_deferred": [ctypes.c_longlong, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_float, c_int,
+                                     c_void_p, c_void_p, c_void_p, ctypes.c_size_t, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p],
+    "pn2_linear_bn_stats_xf": [c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, ctypes.c_size_t, c_void_p, c_void_p,
+                               c_int, c_void_p],
+    "pn2_linear_wgrad_accumulate_xf": [c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p],
     "pn2_sa_hoist_rows": [c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                           c_void_p],
     "pn2_fp_hoist_rows": [c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p],

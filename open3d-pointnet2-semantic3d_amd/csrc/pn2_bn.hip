@@ -180,6 +180,44 @@ __device__ __forceinline__ void bn_forward_constants(long long rows, int c, cons
     __syncthreads();
 }
 
+// The deferred form of the forward (pn2_bn_relu_forward_deferred): fold the slot copies and publish the per-channel constants
+// -- saved moments, moving averages, and (scale, shift) of z = relu?(fma(y, scale, shift)) -- without writing z: the NEXT
+// layer's GEMM and weight gradient apply them while loading y (pn2_linear_bn_stats_xf, pn2_linear_wgrad_accumulate_xf).
+__global__ void __launch_bounds__(kBnThreads)
+bn_constants_kernel(long long rows, int c, int nslots, double* __restrict__ ws, const float* __restrict__ gamma,
+                    const float* __restrict__ beta, const float* __restrict__ bias, float eps, float decay,
+                    float* __restrict__ running_mean, float* __restrict__ running_var, float* __restrict__ save_mean,
+                    float* __restrict__ save_invstd, float* __restrict__ scale, float* __restrict__ shift) {
+    const int ch = blockIdx.x * kBnThreads + threadIdx.x;
+    if (ch >= c) return;
+    double s1 = 0.0, s2 = 0.0;
+#pragma unroll 8
+    for (int k = 0; k < nslots; ++k) {
+        s1 += ws[kBnHead + (size_t)2 * c * (1 + k) + ch];
+        s2 += ws[kBnHead + (size_t)2 * c * (1 + k) + c + ch];
+    }
+    ws[kBnHead + ch] = s1;
+    ws[kBnHead + c + ch] = s2;
+    const double inv_n = 1.0 / (double)rows;
+    const double mean_d = s1 * inv_n;
+    double var_d = s2 * inv_n - mean_d * mean_d;
+    var_d = var_d > 0.0 ? var_d : 0.0;
+    const float mean = (float)mean_d;
+    const float invstd = (float)(1.0 / __builtin_sqrt(var_d + (double)eps));
+    float sc, sh;
+    bn_scale_shift(gamma[ch], beta[ch], mean, invstd, sc, sh);
+    scale[ch] = sc;
+    shift[ch] = sh;
+    save_mean[ch] = mean;
+    save_invstd[ch] = invstd;
+    if (running_mean) {  // as bn_forward_constants
+        const double m_out = mean_d + (bias ? (double)bias[ch] : 0.0);
+        const double var_unb = rows > 1 ? var_d * ((double)rows / (double)(rows - 1)) : var_d;
+        running_mean[ch] = (float)((double)decay * running_mean[ch] + (1.0 - (double)decay) * m_out);
+        running_var[ch] = (float)((double)decay * running_var[ch] + (1.0 - (double)decay) * var_unb);
+    }
+}
+
 // z = relu?(fma(y, sc[ch], sh[ch]))
 template <int VEC>
 __global__ void __launch_bounds__(kBnThreads)
@@ -510,6 +548,38 @@ extern "C" int pn2_bn_relu_forward_stats(long long rows, int c, const float* y, 
                                          float* save_invstd, float* z, float* ties, void* stream) {
     return bn_relu_forward_impl(rows, c, y, gamma, beta, bias, eps, decay, relu, pool, running_mean, running_var, workspace,
                                 workspace_bytes, save_mean, save_invstd, z, ties, stream, 2);
+}
+
+// Batch norm of the training path WITHOUT writing the normalised activation: the statistics (stats_done = 1: already left in
+// the zeroed workspace by pn2_linear_bn_stats; 0: taken here with one pass over y, workspace zeroed by the caller) are folded
+// and turned into save_mean / save_invstd, the moving averages and the per-channel (scale, shift) of
+// z = relu?(fma(y, scale, shift)); the consumer applies them while it loads y (pn2_linear_bn_stats_xf /
+// pn2_linear_wgrad_accumulate_xf), so the write and the re-read of z disappear.  tf_util.py:555-581 followed by :186-204 of the
+// next layer.
+extern "C" int pn2_bn_relu_forward_deferred(long long rows, int c, const float* y, const float* gamma, const float* beta,
+                                            const float* bias, float eps, float decay, int stats_done, float* running_mean,
+                                            float* running_var, void* workspace, size_t workspace_bytes, float* save_mean,
+                                            float* save_invstd, float* scale, float* shift, void* stream) {
+    if (!y || !gamma || !beta || !workspace || !save_mean || !save_invstd || !scale || !shift) return PN2_ENULL;
+    if ((running_mean == nullptr) != (running_var == nullptr)) return PN2_ENULL;
+    BnPlan p;
+    const int rc = bn_plan(rows, c, y, y, y, p);
+    if (rc != PN2_OK) return rc;
+    if (workspace_bytes < pn2_bn_workspace_bytes(c) || ((uintptr_t)workspace % 8) != 0) return PN2_EINVAL;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    double* ws = static_cast<double*>(workspace);
+    if (stats_done) {
+        p.nslots = kBnSlots;
+    } else if (p.vec == 4) {
+        bn_stats_kernel<4><<<p.stat_blocks, kBnThreads, 0, st>>>(rows, c, p.slab, p.nslots, y, ws);
+    } else {
+        bn_stats_kernel<1><<<p.stat_blocks, kBnThreads, 0, st>>>(rows, c, p.slab, p.nslots, y, ws);
+    }
+    bn_constants_kernel<<<(c + kBnThreads - 1) / kBnThreads, kBnThreads, 0, st>>>(rows, c, p.nslots, ws, gamma, beta, bias, eps,
+                                                                                 decay, running_mean, running_var, save_mean,
+                                                                                 save_invstd, scale, shift);
+    PN2_RETURN_IF_LAUNCH_FAILED();
+    return PN2_OK;
 }
 
 static int bn_relu_backward_impl(long long rows, int c, const float* dz, const float* y, const float* gamma,

@@ -38,6 +38,14 @@ __device__ __forceinline__ void bn_scale_shift(float gamma, float beta, float me
     sh = __builtin_fmaf(-mean, sc, beta);
 }
 
+// Operand transform of the training GEMMs that read the PRE-normalisation output of the layer below: the batch norm (+ReLU)
+// of that layer, a = relu?(fma(x, scale[k], shift[k])) per input channel k (pn2_bn_relu_forward_deferred publishes scale / shift).
+struct Pn2LoadTransform {
+    const float* scale;
+    const float* shift;
+    int relu;
+};
+
 // Epilogue of a data-gradient GEMM whose output dx IS the gradient dz reaching the batch norm (+ReLU) of the layer below
 // (pn2_linear_dgrad_bn_grad_stats): the first backward reduction of that batch norm -- sum g and sum g * xhat per channel,
 // g = dz * [relu mask], xhat = (y - mean) * invstd -- is taken from the accumulator tiles, so bn_grad_reduce_kernel's pass

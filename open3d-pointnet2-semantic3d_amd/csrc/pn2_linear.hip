@@ -108,11 +108,16 @@ __device__ __forceinline__ void push_column_grad_stats(const f32x16& acc, int ha
 // TB = true: the B operand is read TRANSPOSED, B(k, n) = w[n * cin + k] with `cout` REAL output columns (any value; the
 // tile is guarded) -- the data gradient of a dense layer, dx (rows, n_in) = dy (rows, n_out) . W^T with W (n_in, n_out)
 // row-major: here cin = n_out is the contraction and cout = n_in the output width.
-template <int WM, int WN, int NT, bool VEC_A, int WK = 1, int ST = 2, bool TB = false>
+// XF = true (training, VEC_A): the A operand is the PRE-normalisation output of the layer below; its batch norm (+ReLU) is
+// applied per input channel k while the tile moves from the prefetch registers to LDS, a = relu?(fma(x, xf.scale[k],
+// xf.shift[k])) -- the normalised activation is never written (pn2_bn_relu_forward_deferred).
+template <int WM, int WN, int NT, bool VEC_A, int WK = 1, int ST = 2, bool TB = false, bool XF = false>
 __global__ void __launch_bounds__(256)
 linear_kernel(int rows, int cin, int cout, const float* __restrict__ x,
               const float* __restrict__ w, const float* __restrict__ bias, int relu, int pool,
-              float* __restrict__ y, double* __restrict__ stats = nullptr, Pn2BnGradEpilogue gepi = Pn2BnGradEpilogue{}) {
+              float* __restrict__ y, double* __restrict__ stats = nullptr, Pn2BnGradEpilogue gepi = Pn2BnGradEpilogue{},
+              Pn2LoadTransform xf = Pn2LoadTransform{}) {
+    static_assert(!XF || (VEC_A && !TB && WK == 1), "the load transform exists for the forward GEMM with 16-byte A loads");
     static_assert(WM * WN * WK == 4, "4 waves per block");
     static_assert(WK == 1 || (WK == 2 && NT * 16 * 64 * WM * WN <= kBK * (32 * NT * WN + 4)), "reduction buffer must fit the B tile");
     constexpr int BM = 32 * WM;
@@ -146,9 +151,10 @@ linear_kernel(int rows, int cin, int cout, const float* __restrict__ x,
     f32x4 a_vs[ST][VEC_A ? A_PER_T : 1];
     float a_ss[ST][VEC_A ? 1 : A_SC];
     f32x4 b_vs[ST][B_PER_T];
+    f32x4 x_sc[XF ? ST : 1], x_sh[XF ? ST : 1];  // XF: (scale, shift) of this thread's four k of the tile (k4 = tid & 7 for every i)
 
     auto load_tile = [&](int kt, f32x4 (&a_v)[VEC_A ? A_PER_T : 1], float (&a_s)[VEC_A ? 1 : A_SC],
-                         f32x4 (&b_v)[B_PER_T]) {
+                         f32x4 (&b_v)[B_PER_T], f32x4& xsc, f32x4& xsh) {
         // Every load is unconditional (addresses clamped into the buffers, out-of-range elements zeroed
         // afterwards): straight-line loads let the compiler use counted s_waitcnt vmcnt(N), which is what
         // keeps ST-1 tiles in flight; loads under a divergent branch force vmcnt(0).
@@ -163,7 +169,14 @@ linear_kernel(int rows, int cin, int cout, const float* __restrict__ x,
                 const int grc = gr < rows ? gr : rows - 1;
                 const int gkc = gk < cin ? gk : cin - 4;  // VEC_A: cin % 4 == 0
                 const f32x4 v = *reinterpret_cast<const f32x4*>(x + (size_t)grc * cin + gkc);
-                a_v[i] = (gr < rows && gk < cin) ? v : z4;
+                if constexpr (XF) a_v[i] = v;  // transformed, then zeroed, in store_tile
+                else a_v[i] = (gr < rows && gk < cin) ? v : z4;
+            }
+            if constexpr (XF) {
+                const int gk = k0 + (tid & 7) * 4;
+                const int gkc = gk < cin ? gk : cin - 4;
+                xsc = *reinterpret_cast<const f32x4*>(xf.scale + gkc);
+                xsh = *reinterpret_cast<const f32x4*>(xf.shift + gkc);
             }
         } else {
 #pragma unroll
@@ -207,14 +220,24 @@ linear_kernel(int rows, int cin, int cout, const float* __restrict__ x,
             }
         }
     };
-    auto store_tile = [&](const f32x4 (&a_v)[VEC_A ? A_PER_T : 1], const float (&a_s)[VEC_A ? 1 : A_SC],
-                          const f32x4 (&b_v)[B_PER_T]) {
+    auto store_tile = [&](int kt, const f32x4 (&a_v)[VEC_A ? A_PER_T : 1], const float (&a_s)[VEC_A ? 1 : A_SC],
+                          const f32x4 (&b_v)[B_PER_T], const f32x4& xsc, const f32x4& xsh) {
         if constexpr (VEC_A) {
 #pragma unroll
             for (int i = 0; i < A_PER_T; ++i) {
                 const int f = tid + 256 * i;
                 const int r = f >> 3, k4 = f & 7;
-                if (f < A_F4) *reinterpret_cast<f32x4*>(As + r * kAS + k4 * 4) = a_v[i];
+                f32x4 v = a_v[i];
+                if constexpr (XF) {
+                    const bool live = row0 + r < rows && kt * kBK + k4 * 4 < cin;
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        float t = __builtin_fmaf(v[q], xsc[q], xsh[q]);
+                        t = xf.relu ? fmaxf(t, 0.f) : t;
+                        v[q] = live ? t : 0.f;
+                    }
+                }
+                if (f < A_F4) *reinterpret_cast<f32x4*>(As + r * kAS + k4 * 4) = v;
             }
         } else {
 #pragma unroll
@@ -242,16 +265,16 @@ linear_kernel(int rows, int cin, int cout, const float* __restrict__ x,
 
     const int nkt = (cin + kBK - 1) / kBK;
 #pragma unroll
-    for (int u = 0; u < ST - 1; ++u) load_tile(u < nkt ? u : nkt - 1, a_vs[u], a_ss[u], b_vs[u]);
+    for (int u = 0; u < ST - 1; ++u) load_tile(u < nkt ? u : nkt - 1, a_vs[u], a_ss[u], b_vs[u], x_sc[XF ? u : 0], x_sh[XF ? u : 0]);
     auto tile_step = [&](auto uc, int kt) {  // statically unrolled: the prefetch ring slots are compile-time
         constexpr int u = decltype(uc)::value;
         __syncthreads();  // previous tile fully consumed
-        store_tile(a_vs[u], a_ss[u], b_vs[u]);
+        store_tile(kt, a_vs[u], a_ss[u], b_vs[u], x_sc[XF ? u : 0], x_sh[XF ? u : 0]);
         __syncthreads();
         constexpr int un = (u + ST - 1) % ST;
         // always issued (tile index clamped: the last ST-1 prefetches re-read the last tile and are
         // never stored) so that the loop body stays branch-free around the loads
-        load_tile(kt + ST - 1 < nkt ? kt + ST - 1 : nkt - 1, a_vs[un], a_ss[un], b_vs[un]);
+        load_tile(kt + ST - 1 < nkt ? kt + ST - 1 : nkt - 1, a_vs[un], a_ss[un], b_vs[un], x_sc[XF ? un : 0], x_sh[XF ? un : 0]);
         const float* as = As + (wm * 32 + l31) * kAS + 4 * half;
         const float* bs = Bs + (4 * half) * BS + wn * (NT * 32) + l31;
 #pragma unroll
@@ -364,6 +387,18 @@ int launch_linear(int rows, int cin, int cout, const float* x, const float* w, c
         if (vec_a) linear_kernel<WM, WN, NT, true, WK, ST><<<grid, 256, 0, st>>>(rows, cin, cout, x, w, bias, relu, pool, y, stats);
         else linear_kernel<WM, WN, NT, false, WK, ST><<<grid, 256, 0, st>>>(rows, cin, cout, x, w, bias, relu, pool, y, stats);
     }
+    PN2_RETURN_IF_LAUNCH_FAILED();
+    return PN2_OK;
+}
+
+// pn2_linear_bn_stats_xf: the forward GEMM + statistics epilogue with the load transform (ST = 3, 16-byte A loads)
+template <int WM, int WN, int NT>
+int launch_linear_xf(int rows, int cin, int cout, const float* x, const float* w, float* y, hipStream_t st, double* stats,
+                     const Pn2LoadTransform& xf) {
+    constexpr int BM = 32 * WM, BN = 32 * NT * WN;
+    dim3 grid((rows + BM - 1) / BM, cout / BN);
+    linear_kernel<WM, WN, NT, true, 1, 3, false, true><<<grid, 256, 0, st>>>(rows, cin, cout, x, w, nullptr, 0, 0, y, stats,
+                                                                            Pn2BnGradEpilogue{}, xf);
     PN2_RETURN_IF_LAUNCH_FAILED();
     return PN2_OK;
 }
@@ -600,10 +635,12 @@ int launch_linear_splitk(int rows, int cin, int cout, const float* x, const floa
 // operands -- a 32x32x2 step contracts two rows: lanes 0-31 carry row r, lanes 32-63 row r+1, each a contiguous
 // 128-byte segment of x (A operand, m = cin index) and of dy (B operand, n = cout index) -- then adds its partial
 // tile to dW with fp32 atomics (dW zeroed by the entry point).  Memory-bound: every row is read once per tile column.
-template <int TM, int TN>
+// XF: x is the pre-normalisation output of the layer below, the operand is relu?(fma(x, scale[m], shift[m])) (per lane: its
+// TM input channels), see linear_kernel.
+template <int TM, int TN, bool XF = false>
 __global__ void __launch_bounds__(256, 2)
 linear_wgrad_kernel(int rows, int cin, int cout, int chunk, const float* __restrict__ x,
-                    const float* __restrict__ dy, float* __restrict__ dw) {
+                    const float* __restrict__ dy, float* __restrict__ dw, Pn2LoadTransform xf = Pn2LoadTransform{}) {
     const int lane = threadIdx.x & 63, half = lane >> 5, l31 = lane & 31;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // row bookkeeping stays in SGPRs
     const long long c0 = ((long long)blockIdx.x * 4 + wave) * chunk;
@@ -620,6 +657,13 @@ linear_wgrad_kernel(int rows, int cin, int cout, int chunk, const float* __restr
     for (int t = 0; t < TM; ++t) { const int m = m0 + t * 32 + l31; offa[t] = (unsigned)(hoff * cin + (m < cin ? m : cin - 1)); }
 #pragma unroll
     for (int t = 0; t < TN; ++t) { const int n = n0 + t * 32 + l31; offb[t] = (unsigned)(hoff * cout + (n < cout ? n : cout - 1)); }
+    float xsc[TM], xsh[TM];
+#pragma unroll
+    for (int t = 0; t < TM; ++t) {
+        const int m = m0 + t * 32 + l31;
+        xsc[t] = XF ? xf.scale[m < cin ? m : cin - 1] : 1.f;
+        xsh[t] = XF ? xf.shift[m < cin ? m : cin - 1] : 0.f;
+    }
     f32x16 acc[TM][TN];
 #pragma unroll
     for (int a = 0; a < TM; ++a)
@@ -654,7 +698,12 @@ linear_wgrad_kernel(int rows, int cin, int cout, int chunk, const float* __restr
             const bool rv = loaded >= r + 2 * u && loaded < r1;
 #pragma unroll
             for (int a = 0; a < TM; ++a) {
-                const float av_m = rv ? av[u][a] : 0.f;
+                float av_t = av[u][a];
+                if constexpr (XF) {
+                    av_t = __builtin_fmaf(av_t, xsc[a], xsh[a]);
+                    av_t = xf.relu ? fmaxf(av_t, 0.f) : av_t;
+                }
+                const float av_m = rv ? av_t : 0.f;
 #pragma unroll
                 for (int b = 0; b < TN; ++b)
                     acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(av_m, bv[u][b], acc[a][b], 0, 0, 0);
@@ -817,6 +866,32 @@ extern "C" int pn2_linear_bn_stats(int rows, int cin, int cout, const float* x, 
     return linear_impl(rows, cin, cout, x, w, nullptr, 0, 0, y, stream, static_cast<double*>(bn_workspace));
 }
 
+// pn2_linear_bn_stats on the PRE-normalisation output x_raw of the layer below: the A operand is
+// relu?(fma(x_raw, a_scale[k], a_shift[k])) formed while the tile is staged (a_scale / a_shift (cin) from
+// pn2_bn_relu_forward_deferred).  cin % 4 == 0, x_raw / a_scale / a_shift 16-byte aligned, rows > 2048 (the few-row split-K
+// tiles have no staging step); otherwise PN2_EUNSUP.
+extern "C" int pn2_linear_bn_stats_xf(int rows, int cin, int cout, const float* x_raw, const float* w, float* y,
+                                      void* bn_workspace, size_t workspace_bytes, const float* a_scale, const float* a_shift,
+                                      int a_relu, void* stream) {
+    if (rows <= 0 || cin <= 0 || cout <= 0) return PN2_EINVAL;
+    if (!x_raw || !w || !y || !bn_workspace || !a_scale || !a_shift) return PN2_ENULL;
+    if (workspace_bytes < sizeof(double) * pn2_bn_ws_doubles(cout, kPn2BnSlots) || ((uintptr_t)bn_workspace % 8) != 0) return PN2_EINVAL;
+    if (cout % 32 != 0 || cin % 4 != 0 || rows <= 2048) return PN2_EUNSUP;
+    if ((((uintptr_t)x_raw | (uintptr_t)w | (uintptr_t)a_scale | (uintptr_t)a_shift) % 16) != 0) return PN2_EUNSUP;
+    if ((long long)rows + 128 > 0x7fffffffLL) return PN2_ERANGE;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    double* stats = static_cast<double*>(bn_workspace);
+    const Pn2LoadTransform xf{a_scale, a_shift, a_relu};
+    if (cout % 128 == 0) {  // the tile choice of linear_impl, without its 128 x 128 tile (with the transform's registers its
+                            // accumulators spill: 630 us instead of ~45 at 32768 x 128 -> 256)
+        const long long cb = cout / 128;
+        if (((rows + 63) / 64) * cb >= 512) return launch_linear_xf<2, 2, 2>(rows, cin, cout, x_raw, w, y, st, stats, xf);
+        return launch_linear_xf<1, 4, 1>(rows, cin, cout, x_raw, w, y, st, stats, xf);
+    }
+    if (cout % 64 == 0) return launch_linear_xf<4, 1, 2>(rows, cin, cout, x_raw, w, y, st, stats, xf);
+    return launch_linear_xf<4, 1, 1>(rows, cin, cout, x_raw, w, y, st, stats, xf);
+}
+
 // Data gradient of a dense layer (training): dx (rows, cin) = dy (rows, cout) . W^T, W (cin, cout) row-major as the forward
 // pass holds it (no transposed copy); any cin / cout.  The reference gets this from tf.gradients of tf.nn.conv2d
 // (util/tf_util.py:181-186).
@@ -875,7 +950,8 @@ extern "C" int pn2_debug_set_linear(int what, int value) {
 #endif  // PN2_TUNING_HOOKS
 
 // dW = x^T . dy (see linear_wgrad_kernel): the training path's weight gradient.  dw (cin, cout) is overwritten.
-static int linear_wgrad_impl(int rows, int cin, int cout, const float* x, const float* dy, float* dw, void* stream, bool accumulate) {
+static int linear_wgrad_impl(int rows, int cin, int cout, const float* x, const float* dy, float* dw, void* stream, bool accumulate,
+                             const Pn2LoadTransform* xf = nullptr) {
     if (rows <= 0 || cin <= 0 || cout <= 0) return PN2_EINVAL;
     if (!x || !dy || !dw) return PN2_ENULL;
     if ((long long)rows + 128 > 0x7fffffffLL) return PN2_ERANGE;
@@ -896,7 +972,11 @@ static int linear_wgrad_impl(int rows, int cin, int cout, const float* x, const 
     if (chunk < 64) chunk = 64;
     const int nchunks = (rows + chunk - 1) / chunk;
     dim3 grid((nchunks + 3) / 4, gy, gz);
-#define PN2_WG(TM_, TN_) linear_wgrad_kernel<TM_, TN_><<<grid, 256, 0, st>>>(rows, cin, cout, chunk, x, dy, dw)
+#define PN2_WG(TM_, TN_)                                                                                       \
+    do {                                                                                                       \
+        if (xf) linear_wgrad_kernel<TM_, TN_, true><<<grid, 256, 0, st>>>(rows, cin, cout, chunk, x, dy, dw, *xf); \
+        else linear_wgrad_kernel<TM_, TN_><<<grid, 256, 0, st>>>(rows, cin, cout, chunk, x, dy, dw);             \
+    } while (0)
     if (tm == 1 && tn == 1) PN2_WG(1, 1);
     else if (tm == 1 && tn == 2) PN2_WG(1, 2);
     else if (tm == 1 && tn == 4) PN2_WG(1, 4);
@@ -914,6 +994,14 @@ extern "C" int pn2_linear_wgrad(int rows, int cin, int cout, const float* x, con
 // dw += x^T . dy: the caller owns the initial value (e.g. a gradient arena zero-filled once per step)
 extern "C" int pn2_linear_wgrad_accumulate(int rows, int cin, int cout, const float* x, const float* dy, float* dw, void* stream) {
     return linear_wgrad_impl(rows, cin, cout, x, dy, dw, stream, true);
+}
+
+// pn2_linear_wgrad_accumulate with x = the pre-normalisation output of the layer below (see pn2_linear_bn_stats_xf)
+extern "C" int pn2_linear_wgrad_accumulate_xf(int rows, int cin, int cout, const float* x_raw, const float* dy, float* dw,
+                                              const float* a_scale, const float* a_shift, int a_relu, void* stream) {
+    if (!a_scale || !a_shift) return PN2_ENULL;
+    const Pn2LoadTransform xf{a_scale, a_shift, a_relu};
+    return linear_wgrad_impl(rows, cin, cout, x_raw, dy, dw, stream, true, &xf);
 }
 
 // internal helper (exported for the host package's unfused SA path and for tests)

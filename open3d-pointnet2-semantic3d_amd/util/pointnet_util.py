@@ -397,10 +397,15 @@ def pointnet_sa_module(xyz, points, npoint, radius, nsample, mlp, mlp2, group_al
                      and len(mlp) > 0 and mlp[0] % 4 == 0 and nsample <= 1024 and geometry is not None and len(geometry) > 2
                      and _plan_usable(geometry[2], mlp[0]))
             first = 0
+            # a layer whose output feeds only the next conv2d of this loop may hand over its UN-normalised output
+            # (tf_util.USE_BN_ON_LOAD): the next layer applies the batch norm + ReLU while loading it
+            defer = lambda i, rows: (bool(is_training) and bn and i + 1 < len(mlp)  # noqa: E731
+                                     and tf_util.can_defer_bn(rows, mlp[i], mlp[i + 1]))
             if hoist:
                 new_xyz, idx, grouped_xyz = geometry[0], geometry[1], None
                 new_points = tf_util.conv2d_hoisted_first("sa", points, (xyz, new_xyz, idx), geometry[2], 3 + points.shape[2],
-                                                          mlp[0], "conv0", bn_decay, pool=nsample if len(mlp) == 1 else 0)
+                                                          mlp[0], "conv0", bn_decay, pool=nsample if len(mlp) == 1 else 0,
+                                                          defer_bn=defer(0, idx.numel()))
                 first = 1
             elif group_all:
                 nsample = xyz.shape[1]
@@ -415,7 +420,8 @@ def pointnet_sa_module(xyz, points, npoint, radius, nsample, mlp, mlp2, group_al
                     continue
                 new_points = tf_util.conv2d(new_points, cout, [1, 1], padding="VALID", stride=[1, 1], bn=bn,
                                             is_training=is_training, scope="conv%d" % i, bn_decay=bn_decay,
-                                            pool=nsample if (fuse_pool and i == len(mlp) - 1) else 0)
+                                            pool=nsample if (fuse_pool and i == len(mlp) - 1) else 0,
+                                            defer_bn=defer(i, new_points.numel() // new_points.shape[-1]))
             if pooling not in _POOL_MODES:
                 raise ValueError("unknown pooling %r" % pooling)
             if not (pooling == "max" and fuse_pool):
@@ -610,12 +616,14 @@ def pointnet_fp_module(xyz1, xyz2, points1, points2, mlp, is_training, bn_decay,
         if (tf_util.USE_HOISTED_TRAIN and bn and points1 is not None and 1 <= points1.shape[2] <= 8 and not points1.requires_grad
                 and points1.dtype == torch.float32 and points2.dtype == torch.float32 and len(mlp) > 0 and mlp[0] % 4 == 0
                 and _plan_usable(plan, mlp[0])):
+            rows = points1.shape[0] * points1.shape[1]
+            defer = lambda i: bn and i + 1 < len(mlp) and tf_util.can_defer_bn(rows, mlp[i], mlp[i + 1])  # noqa: E731
             h = tf_util.conv2d_hoisted_first("fp", points2, (dist, idx, points1), plan, points2.shape[2] + points1.shape[2],
-                                             mlp[0], "conv_0", bn_decay)
+                                             mlp[0], "conv_0", bn_decay, defer_bn=defer(0))
             for i, cout in enumerate(mlp):
                 if i > 0:
                     h = tf_util.conv2d(h, cout, [1, 1], padding="VALID", stride=[1, 1], bn=bn, is_training=is_training,
-                                       scope="conv_%d" % i, bn_decay=bn_decay)
+                                       scope="conv_%d" % i, bn_decay=bn_decay, defer_bn=defer(i))
             return h.squeeze(2)
         if USE_FUSED_TRAIN_FRONT and points2.dtype == torch.float32:
             new_points1 = _FPInterpConcat.apply(dist, idx, None if points1 is None else points1.contiguous(),
@@ -627,7 +635,10 @@ def pointnet_fp_module(xyz1, xyz2, points1, points2, mlp, is_training, bn_decay,
             interpolated = three_interpolate(points2, idx, weight)
             new_points1 = torch.cat([interpolated, points1], dim=2) if points1 is not None else interpolated
         new_points1 = new_points1.unsqueeze(2)
+        rows = new_points1.shape[0] * new_points1.shape[1]
         for i, cout in enumerate(mlp):
+            # un-normalised hand-over to the next layer of the stack (tf_util.USE_BN_ON_LOAD)
+            dfr = bool(is_training) and bn and i + 1 < len(mlp) and tf_util.can_defer_bn(rows, cout, mlp[i + 1])
             new_points1 = tf_util.conv2d(new_points1, cout, [1, 1], padding="VALID", stride=[1, 1], bn=bn,
-                                         is_training=is_training, scope="conv_%d" % i, bn_decay=bn_decay)
+                                         is_training=is_training, scope="conv_%d" % i, bn_decay=bn_decay, defer_bn=dfr)
         return new_points1.squeeze(2)

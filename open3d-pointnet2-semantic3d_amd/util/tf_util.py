@@ -522,6 +522,19 @@ def hip_matmul_bn_stats(x2d, w, ws):
     return y
 
 
+def hip_matmul_bn_stats_xf(x_raw, w, ws, sc, sh, relu):
+    """hip_matmul_bn_stats on relu?(fma(x_raw, sc, sh)) formed while the operand is staged (pn2_linear_bn_stats_xf)"""
+    require_cuda(x_raw, w)
+    rows, cin = x_raw.shape
+    cout = w.shape[1]
+    y = torch.empty((rows, cout), dtype=torch.float32, device=x_raw.device)
+    with torch.cuda.device(x_raw.device):
+        check(lib.pn2_linear_bn_stats_xf(rows, cin, cout, ptr(x_raw.contiguous()), ptr(w.contiguous()), ptr(y), ptr(ws),
+                                         ws.numel() * ws.element_size(), ptr(sc), ptr(sh), int(relu), stream_ptr()),
+              "pn2_linear_bn_stats_xf")
+    return y
+
+
 def hip_linear_dgrad(dy, w):
     """dx (rows, cin) = dy (rows, cout) @ w^T with w (cin, cout) as the forward pass holds it (pn2_linear_dgrad)."""
     require_cuda(dy, w)
@@ -555,13 +568,18 @@ def _bn_zeroed_scratch(c, device):
     return v if v is not None else torch.zeros(nbytes // 8, dtype=torch.float64, device=device)
 
 
-def _hip_wgrad(x2d, dy, w):
+def _hip_wgrad(x2d, dy, w, xf=None):
     """dW = x2d^T @ dy on pn2_linear_wgrad; the tile is added to with atomics, so it starts from the zero arena when the
-    step has one (no memset of its own)."""
+    step has one (no memset of its own).  xf = (scale, shift, relu): x2d is the producer's un-normalised output, the
+    kernel applies its batch norm while loading (pn2_linear_wgrad_accumulate_xf)."""
     arena = get_default_store().zero_arena
     v = arena.take(w.numel() * 4) if arena is not None else None
     with torch.cuda.device(w.device):
-        if v is not None:
+        if xf is not None:
+            dw = v[:w.numel() * 4].view(torch.float32).view_as(w) if v is not None else torch.zeros_like(w)
+            check(lib.pn2_linear_wgrad_accumulate_xf(x2d.shape[0], w.shape[0], w.shape[1], ptr(x2d), ptr(dy), ptr(dw), ptr(xf[0]),
+                                                     ptr(xf[1]), int(xf[2]), stream_ptr()), "pn2_linear_wgrad_accumulate_xf")
+        elif v is not None:
             dw = v[:w.numel() * 4].view(torch.float32).view_as(w)
             check(lib.pn2_linear_wgrad_accumulate(x2d.shape[0], w.shape[0], w.shape[1], ptr(x2d), ptr(dy), ptr(dw), stream_ptr()),
                   "pn2_linear_wgrad_accumulate")
@@ -635,7 +653,24 @@ _bn_links = {}
 
 
 class _BnLink:
-    __slots__ = ("shape", "y", "gamma", "beta", "mean", "invstd", "relu", "ws", "dz_ptr", "dz_keep")
+    __slots__ = ("shape", "y", "gamma", "beta", "mean", "invstd", "relu", "ws", "dz_ptr", "dz_keep", "sc", "sh")
+
+
+# ---- deferred normalisation: layer i publishes (scale, shift) and hands its PRE-normalisation output y to layer i+1 -------
+# (pn2_bn_relu_forward_deferred); layer i+1's forward GEMM and weight gradient apply relu(fma(y, scale, shift)) while they
+# load y (pn2_linear_bn_stats_xf, pn2_linear_wgrad_accumulate_xf): the normalised activation is never written or re-read.
+# Decided by the module code (conv2d(..., defer_bn=True)) for layers whose output feeds exactly the next conv2d of the stack.
+USE_BN_ON_LOAD = True
+
+
+def can_defer_bn(rows, c, c_next):
+    """may a layer of width c over `rows` rows hand its un-normalised output to a following layer of width c_next?"""
+    return bool(USE_BN_ON_LOAD and USE_DGRAD_BN_STATS and rows > 2048 and c % 4 == 0 and c_next % 32 == 0)
+
+
+def _deferred_producer(x2d):
+    lk = _bn_links.get(x2d.data_ptr())
+    return lk if (lk is not None and lk.sc is not None and lk.y is not None and lk.shape == tuple(x2d.shape)) else None
 
 
 def reset_bn_links():
@@ -680,8 +715,23 @@ def _bn_train_forward(y, b, gamma, beta, running_mean, running_var, decay, relu,
     return z, ties, save_mean, save_invstd
 
 
-def _bn_register_producer(z, y, gamma, beta, save_mean, save_invstd, relu, pooled):
-    """record an un-pooled dense+BN layer as the possible producer of the next layer's input (see _BnLink) -> link or None"""
+def _bn_train_forward_deferred(y, b, gamma, beta, running_mean, running_var, decay, stats_ws=None):
+    """the statistics half of _bn_train_forward only (pn2_bn_relu_forward_deferred) -> save_mean, save_invstd, scale, shift"""
+    rows, c = y.shape
+    ws = stats_ws if stats_ws is not None else _bn_zeroed_scratch(c, y.device)
+    save_mean = torch.empty(c, dtype=torch.float32, device=y.device)
+    save_invstd, sc, sh = torch.empty_like(save_mean), torch.empty_like(save_mean), torch.empty_like(save_mean)
+    with torch.cuda.device(y.device):
+        check(lib.pn2_bn_relu_forward_deferred(rows, c, ptr(y), ptr(gamma), ptr(beta), ptr(b), BN_EPSILON, decay,
+                                               int(stats_ws is not None), ptr(running_mean), ptr(running_var), ptr(ws),
+                                               ws.numel() * ws.element_size(), ptr(save_mean), ptr(save_invstd), ptr(sc), ptr(sh),
+                                               stream_ptr()), "pn2_bn_relu_forward_deferred")
+    return save_mean, save_invstd, sc, sh
+
+
+def _bn_register_producer(z, y, gamma, beta, save_mean, save_invstd, relu, pooled, sc=None, sh=None):
+    """record an un-pooled dense+BN layer as the possible producer of the next layer's input (see _BnLink) -> link or None;
+    sc / sh: the layer deferred its normalisation, z IS y"""
     if not USE_DGRAD_BN_STATS or pooled:
         return None
     if len(_bn_links) > 256:
@@ -689,6 +739,7 @@ def _bn_register_producer(z, y, gamma, beta, save_mean, save_invstd, relu, poole
     lk = _BnLink()
     lk.shape, lk.y, lk.gamma, lk.beta, lk.mean, lk.invstd, lk.relu = tuple(z.shape), y, gamma, beta, save_mean, save_invstd, bool(relu)
     lk.ws = lk.dz_ptr = lk.dz_keep = None
+    lk.sc, lk.sh = sc, sh
     _bn_links[z.data_ptr()] = lk
     return lk
 
@@ -707,7 +758,7 @@ def _bn_train_backward(dz, y, gamma, beta, save_mean, save_invstd, relu, pool, z
     else:
         ws, bwd = _bn_scratch(c, y.device, lib.pn2_bn_relu_backward, lib.pn2_bn_relu_backward_ws0)
     if lk is not None:  # this layer's backward runs once: drop what the record kept alive
-        lk.ws = lk.dz_keep = lk.dz_ptr = lk.y = lk.gamma = lk.beta = lk.mean = lk.invstd = None
+        lk.ws = lk.dz_keep = lk.dz_ptr = lk.y = lk.gamma = lk.beta = lk.mean = lk.invstd = lk.sc = lk.sh = None
     with torch.cuda.device(y.device):
         check(bwd(rows, c, ptr(dz), ptr(y), ptr(gamma), ptr(beta), ptr(save_mean),
                   ptr(save_invstd), int(relu), int(pool), ptr(zmax), ptr(ties), ptr(ws),
@@ -724,24 +775,39 @@ class _TrainDenseBnRelu(torch.autograd.Function):
     -> dX = dY @ w^T, dW on pn2_linear_wgrad.  Replaces nine elementwise / reduction kernels per layer."""
 
     @staticmethod
-    def forward(ctx, x2d, w, b, gamma, beta, running_mean, running_var, decay, relu, pool):
+    def forward(ctx, x2d, w, b, gamma, beta, running_mean, running_var, decay, relu, pool, defer):
         c = w.shape[1]
-        if USE_GEMM_BN_STATS and c % 32 == 0:
+        pooled = pool > 1
+        # producer of this layer's input (if it was an un-pooled dense+BN layer of this forward pass)
+        prev = _bn_links.get(x2d.data_ptr()) if USE_DGRAD_BN_STATS else None
+        prev = prev if (prev is not None and prev.y is not None and prev.shape == tuple(x2d.shape)) else None
+        xf = prev is not None and prev.sc is not None  # x2d is the producer's UN-normalised output
+        if xf:
+            if c % 32 != 0:
+                raise RuntimeError("a deferred batch-norm output reached a layer that cannot apply it")
+            ws = _bn_zeroed_scratch(c, x2d.device)
+            y = hip_matmul_bn_stats_xf(x2d, w, ws, prev.sc, prev.sh, prev.relu)
+        elif USE_GEMM_BN_STATS and c % 32 == 0:
             # the GEMM's epilogue leaves the column sums of y in the batch-norm workspace: no statistics pass over y
             ws = _bn_zeroed_scratch(c, x2d.device)
             y = hip_matmul_bn_stats(x2d, w, ws)
         else:
             ws, y = None, hip_matmul(x2d, w)
+        ctx.xf = (prev.sc, prev.sh, bool(prev.relu)) if xf else None
+        ctx.relu, ctx.pool = bool(relu), int(pool)
+        ctx.prev = prev if (prev is not None and w.shape[1] > 16) else None
+        if defer and not pooled:
+            save_mean, save_invstd, sc, sh = _bn_train_forward_deferred(y, b, gamma, beta, running_mean, running_var, decay, ws)
+            ctx.save_for_backward(x2d, w, y, gamma, beta, save_mean, save_invstd)
+            ctx.link = _bn_register_producer(y, y, gamma, beta, save_mean, save_invstd, relu, False, sc, sh)
+            if ctx.link is None:
+                raise RuntimeError("deferred batch norm needs the producer links (USE_DGRAD_BN_STATS)")
+            return y  # un-normalised: only the next dense layer of the stack may consume it
         z, ties, save_mean, save_invstd = _bn_train_forward(y, b, gamma, beta, running_mean, running_var, decay, relu, pool, ws)
-        pooled = pool > 1
         if pooled:
             ctx.save_for_backward(x2d, w, y, gamma, beta, save_mean, save_invstd, z, ties)
         else:
             ctx.save_for_backward(x2d, w, y, gamma, beta, save_mean, save_invstd)
-        ctx.relu, ctx.pool = bool(relu), int(pool)
-        # producer of this layer's input (if it was an un-pooled dense+BN layer of this forward pass) / this layer as a producer
-        prev = _bn_links.get(x2d.data_ptr()) if USE_DGRAD_BN_STATS else None
-        ctx.prev = prev if (prev is not None and prev.y is not None and prev.shape == tuple(x2d.shape) and w.shape[1] > 16) else None
         ctx.link = _bn_register_producer(z, y, gamma, beta, save_mean, save_invstd, relu, pooled)
         return z
 
@@ -756,10 +822,10 @@ class _TrainDenseBnRelu(torch.autograd.Function):
             dx = hip_linear_dgrad_linked(dy, w, pv) if (pv is not None and pv.y is not None) else hip_linear_dgrad(dy, w)
         dw = None
         if ctx.needs_input_grad[1]:
-            dw = _hip_wgrad(x2d, dy, w)
+            dw = _hip_wgrad(x2d, dy, w, ctx.xf)
         # a constant in front of batch norm has no effect on the output: its gradient is exactly zero -- None, which the
         # trainer's gradient buffer treats as (and keeps at) zero without a fill per layer
-        return dx, dw, None, dgamma, dbeta, None, None, None, None, None
+        return dx, dw, None, dgamma, dbeta, None, None, None, None, None, None
 
 
 USE_HOISTED_TRAIN = True  # first layer of SA2-SA4 / FP4 with its feature half applied to the source rows (A/B, tests)
@@ -784,7 +850,7 @@ class _TrainHoistedBnRelu(torch.autograd.Function):
     a = the centred coordinates (SA) resp. points1 (FP, <= 8 channels, data: no gradient)."""
 
     @staticmethod
-    def forward(ctx, src, w, b, gamma, beta, running_mean, running_var, decay, relu, pool, kind, g0, g1, g2, plan):
+    def forward(ctx, src, w, b, gamma, beta, running_mean, running_var, decay, relu, pool, kind, g0, g1, g2, plan, defer):
         bsz, nsrc, c = src.shape
         cout = w.shape[1]
         src2d = src.reshape(-1, c)
@@ -809,10 +875,17 @@ class _TrainHoistedBnRelu(torch.autograd.Function):
                 a = points1.reshape(-1, c1)
                 check(lib.pn2_fp_hoist_rows(bsz, n, nsrc, c1, cout, ptr(dist), ptr(idx), ptr(a), ptr(z), ptr(wa), ptr(y),
                                             stream_ptr()), "pn2_fp_hoist_rows")
-        zact, ties, save_mean, save_invstd = _bn_train_forward(y, b, gamma, beta, running_mean, running_var, decay, relu, pool)
         pooled = pool > 1
-        ctx.save_for_backward(src2d, w, y, gamma, beta, save_mean, save_invstd, a, plan, *((zact, ties) if pooled else ()))
         ctx.relu, ctx.pool, ctx.kind, ctx.dims = bool(relu), int(pool), kind, (bsz, nsrc, rows_b, c)
+        if defer and not pooled:
+            save_mean, save_invstd, sc, sh = _bn_train_forward_deferred(y, b, gamma, beta, running_mean, running_var, decay)
+            ctx.save_for_backward(src2d, w, y, gamma, beta, save_mean, save_invstd, a, plan)
+            ctx.link = _bn_register_producer(y, y, gamma, beta, save_mean, save_invstd, relu, False, sc, sh)
+            if ctx.link is None:
+                raise RuntimeError("deferred batch norm needs the producer links (USE_DGRAD_BN_STATS)")
+            return y
+        zact, ties, save_mean, save_invstd = _bn_train_forward(y, b, gamma, beta, running_mean, running_var, decay, relu, pool)
+        ctx.save_for_backward(src2d, w, y, gamma, beta, save_mean, save_invstd, a, plan, *((zact, ties) if pooled else ()))
         ctx.link = _bn_register_producer(zact, y, gamma, beta, save_mean, save_invstd, relu, pooled)
         return zact
 
@@ -837,10 +910,10 @@ class _TrainHoistedBnRelu(torch.autograd.Function):
             dwa, dwb = (dw[:3], dw[3:]) if sa else (dw[c:], dw[:c])
             _hip_wgrad_into(src2d, dzs2d, dwb)
             _hip_wgrad_into(a, dy, dwa)
-        return (dsrc, dw, None, dgamma, dbeta) + (None,) * 10
+        return (dsrc, dw, None, dgamma, dbeta) + (None,) * 11
 
 
-def conv2d_hoisted_first(kind, src, geo, plan, cin, num_output_channels, scope, bn_decay=None, pool=0):
+def conv2d_hoisted_first(kind, src, geo, plan, cin, num_output_channels, scope, bn_decay=None, pool=0, defer_bn=False):
     """conv2d(concat-of-a-gathered-tensor, ..., bn=True, is_training=True, activation relu) -- the FIRST layer of an SA
     (kind "sa": geo = (xyz, new_xyz, idx)) or FP (kind "fp": geo = (dist, idx, points1)) module -- without building the
     gathered tensor: _TrainHoistedBnRelu.  Same variables (names, shapes, initialisation) as tf_util.conv2d under `scope`;
@@ -854,14 +927,15 @@ def conv2d_hoisted_first(kind, src, geo, plan, cin, num_output_channels, scope, 
         decay = 0.9 if bn_decay is None else float(bn_decay)
         pool = int(pool) if pool and pool > 1 else 0
         z = _TrainHoistedBnRelu.apply(src.contiguous(), w.reshape(cin, cout), b, gamma, beta, mean, var, decay, True, pool, kind,
-                                      geo[0].contiguous(), geo[1].contiguous(), geo[2].contiguous(), plan)
+                                      geo[0].contiguous(), geo[1].contiguous(), geo[2].contiguous(), plan,
+                                      bool(defer_bn) and not pool)
     if kind == "sa":
         m, ns = geo[2].shape[1], geo[2].shape[2]
         return z.reshape(src.shape[0], m, ns // pool if pool else ns, cout)
     return z.reshape(src.shape[0], geo[2].shape[1], 1, cout)
 
 
-def _train_layer(inputs, w2d, b, bnv, bn_decay, relu, pool=0):
+def _train_layer(inputs, w2d, b, bnv, bn_decay, relu, pool=0, defer=False):
     """One dense layer of the training path, entirely on the HIP library: inputs (..., cin) -> (..., cout); pool > 1 also
     takes the max over groups of `pool` consecutive entries of the second-to-last axis (..., W, cin) -> (..., W/pool, cout).
     With batch norm: _TrainDenseBnRelu; without (the class head, activation None): _TrainMatmul.  There is no torch
@@ -880,19 +954,21 @@ def _train_layer(inputs, w2d, b, bnv, bn_decay, relu, pool=0):
     if bnv is None:
         if relu or pool:
             raise NotImplementedError("training-mode conv without batch norm but with ReLU / pooling is not on the SA/FP path")
+        if _deferred_producer(inputs.reshape(-1, cin)) is not None:
+            raise RuntimeError("a deferred batch-norm output reached a layer without batch norm")
         return _train_dense(inputs, w2d, b)
     if not (cout <= 1024 and (cout % 4 == 0 or cout <= 256)):
         raise NotImplementedError("batch-norm layer width %d: the HIP kernels take <= 1024 channels, a multiple of 4 above 256" % cout)
     beta, gamma, mean, var = bnv
     decay = 0.9 if bn_decay is None else float(bn_decay)  # tf_util.py:571
     z = _TrainDenseBnRelu.apply(inputs.reshape(-1, cin).contiguous(), w2d.contiguous(), b, gamma, beta, mean, var,
-                                decay, relu, pool)
+                                decay, relu, pool, bool(defer) and not pool and relu)
     return z.reshape(lead + [cout])
 
 
 def conv2d(inputs, num_output_channels, kernel_size, scope, stride=(1, 1), padding="SAME", data_format="NHWC",
            use_xavier=True, stddev=1e-3, weight_decay=None, activation_fn=torch.relu, bn=False, bn_decay=None,
-           is_training=None, pool=0):
+           is_training=None, pool=0, defer_bn=False):
     """1x1 conv over an NHWC tensor (B,H,W,C) = matmul over C (tf_util.py:128-204).
     Only the configuration the SA/FP stack uses is implemented: kernel [1,1],
     stride [1,1], NHWC.  `pool` (extension): max over groups of `pool` rows of W,
@@ -915,7 +991,9 @@ def conv2d(inputs, num_output_channels, kernel_size, scope, stride=(1, 1), paddi
             return y.reshape(lead + [cout])
         st, w, b, bnv = _dense_variables(cin, cout, bn, (1, 1, cin, cout))
         st.train_epoch += 1
-        return _train_layer(inputs, w.reshape(cin, cout), b, bnv, bn_decay, activation_fn is not None, pool)
+        # defer_bn (extension, training): hand the UN-normalised output to the next conv2d of the stack (see USE_BN_ON_LOAD)
+        return _train_layer(inputs, w.reshape(cin, cout), b, bnv, bn_decay, activation_fn is not None, pool,
+                            defer=bool(defer_bn) and bn)
 
 
 def conv1d(inputs, num_output_channels, kernel_size, scope, stride=1, padding="SAME", use_xavier=True,

@@ -559,6 +559,63 @@ def test_training_first_layer_on_the_source_rows_equals_the_grouped_form(pn2, cu
         assert float((a - r).abs().max()) <= 3e-4 * sc, (a.shape, float((a - r).abs().max()), sc)
 
 
+@pytest.mark.parametrize("kind,mlp,c,plan_on", [("sa", [32, 32, 64], 3, False), ("sa", [64, 64, 128], 64, True),
+                                                ("fp", [256, 128], 64, False), ("fp", [128, 128, 128], 128, True)])
+def test_training_stack_with_batch_norm_applied_on_load_equals_the_materialised_form(pn2, cuda, kind, mlp, c, plan_on):
+    """Training path: inside an MLP stack a layer publishes its batch-norm (scale, shift) and hands over the UN-normalised
+    output (pn2_bn_relu_forward_deferred); the next layer's forward GEMM and weight gradient apply relu(fma(y, scale, shift))
+    while loading it (pn2_linear_bn_stats_xf / pn2_linear_wgrad_accumulate_xf).  Against the form that writes the normalised
+    activation (tf_util.USE_BN_ON_LOAD = False): module output, moving averages, source gradient, every parameter
+    gradient -- for plain stacks and for stacks whose first layer runs on the source rows.  tf_util.py:186-204,555-581."""
+    import torch
+    tfu, pu = pn2.util.tf_util, pn2.util.pointnet_util
+    rs = np.random.RandomState(len(mlp) + c)
+    b, n = 3, 1024
+    xyz = T(s_scene(c + 1, b, n), cuda)
+    if kind == "sa":
+        m, ns = 128, 16
+        src0 = T(rs.randn(b, n, c).astype(np.float32), cuda)
+        new_xyz, idx = pu.sa_geometry(xyz, m, 0.8, ns)
+        geo = (new_xyz, idx, pu.scatter_plan(idx, n)) if plan_on else (new_xyz, idx)
+        oshape = (b, m, mlp[-1])
+    else:
+        m = 128
+        xyz2 = xyz[:, :m].contiguous()
+        src0 = T(rs.randn(b, m, 96).astype(np.float32), cuda)
+        p1 = T(rs.rand(b, n, 3 if plan_on else c).astype(np.float32), cuda)
+        dist, idx = pn2.three_nn(xyz, xyz2)
+        nn = (dist, idx, pu.scatter_plan(idx, m, dist, weight_kind=2)) if plan_on else (dist, idx)
+        oshape = (b, n, mlp[-1])
+    probe = torch.sin(torch.arange(int(np.prod(oshape)), device=cuda).float() * 0.13).reshape(oshape)
+    outs = {}
+    for on in (True, False):
+        tfu.USE_BN_ON_LOAD = on
+        store = tfu.set_default_store(tfu.VariableStore(device=cuda, seed=11))
+        calls = []
+        pn2._lib.lib.trace = calls
+        try:
+            tfu.reset_bn_links()
+            src = src0.clone().requires_grad_(True)
+            if kind == "sa":
+                _, out, _ = pu.pointnet_sa_module(xyz, src, m, 0.8, ns, mlp, None, False, True, 0.5, "mod", geometry=geo)
+            else:
+                out = pu.pointnet_fp_module(xyz, xyz2, p1, src, mlp, True, 0.5, "mod", nn=nn)
+            (out * probe).sum().backward()
+        finally:
+            pn2._lib.lib.trace = None
+            tfu.USE_BN_ON_LOAD = True
+        names = [c_[0] for c_ in calls]
+        assert names.count("pn2_bn_relu_forward_deferred") == (len(mlp) - 1 if on else 0), names
+        assert names.count("pn2_linear_bn_stats_xf") == (len(mlp) - 1 if on else 0)
+        assert names.count("pn2_linear_wgrad_accumulate_xf") == (len(mlp) - 1 if on else 0)
+        outs[on] = [out.detach(), src.grad] + [p_.grad for _, p_ in sorted(store.params.items()) if p_.grad is not None] + \
+                   [v.clone() for _, v in sorted(store.buffers.items())]
+    assert len(outs[True]) == len(outs[False]) and len(outs[True]) >= 6
+    for a, r in zip(outs[True], outs[False]):
+        sc = max(float(r.abs().max()), 1e-3)
+        assert float((a - r).abs().max()) <= 2e-4 * sc, (a.shape, float((a - r).abs().max()), sc)
+
+
 def test_fp_module_chain_equals_per_layer_linear(pn2, oracle, cuda):
     """FP4-shaped module: the chained path and the one-launch-per-layer path agree to fp32 rounding."""
     tfu, pu = pn2.util.tf_util, pn2.util.pointnet_util
@@ -954,7 +1011,7 @@ def test_training_gradients_with_hip_wgrad_match_torch(pn2, cuda):
     labels = T(rs.randint(0, 9, (8, 2048)).astype(np.int64), cuda)
     smpw = T((rs.random_sample((8, 2048)) + 0.5).astype(np.float32), cuda)
 
-    def layer_fp64(inputs, w2d, b, bnv, bn_decay, relu, pool=0):
+    def layer_fp64(inputs, w2d, b, bnv, bn_decay, relu, pool=0, defer=False):
         y = inputs.double() @ w2d.double() + b.double()
         if bnv is not None:
             beta, gamma, mean, var = bnv

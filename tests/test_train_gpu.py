@@ -48,7 +48,7 @@ def test_gemm_epilogue_batch_statistics(pn2, cuda, rows, cin, cout, pool):
         tfu.USE_GEMM_BN_STATS = fused
         try:
             rm, rv = torch.zeros(cout, device=cuda), torch.ones(cout, device=cuda)
-            z = tfu._TrainDenseBnRelu.apply(T(x, cuda), T(w, cuda), None, T(gamma, cuda), T(beta, cuda), rm, rv, 0.5, True, pool)
+            z = tfu._TrainDenseBnRelu.apply(T(x, cuda), T(w, cuda), None, T(gamma, cuda), T(beta, cuda), rm, rv, 0.5, True, pool, False)
             out[fused] = (z.cpu().numpy(), rm.cpu().numpy(), rv.cpu().numpy())
         finally:
             tfu.USE_GEMM_BN_STATS = True
@@ -233,9 +233,19 @@ def test_every_gemm_of_a_real_step_is_as_accurate_as_the_library(pn2, cuda):
     pc, labels, smpw = _batch(cuda, 0)
     seen = []
     orig_mm, orig_dg, orig_mms, orig_dgl = tfu.hip_matmul, tfu.hip_linear_dgrad, tfu.hip_matmul_bn_stats, tfu.hip_linear_dgrad_linked
+    orig_mmx = tfu.hip_matmul_bn_stats_xf
 
     def mm(x, w, ws=None):
         y = orig_mm(x, w) if ws is None else orig_mms(x, w, ws)  # ws: the GEMM that also accumulates batch statistics
+        ref = x.double() @ w.double()
+        seen.append(("fwd", tuple(x.shape), w.shape[1], float((y.double() - ref).norm() / ref.norm()),
+                     float(((x @ w).double() - ref).norm() / ref.norm())))
+        return y
+
+    def mmx(x_raw, w, ws, sc, sh, relu):  # the GEMM that applies the batch norm (+ReLU) of the layer below while loading its input
+        y = orig_mmx(x_raw, w, ws, sc, sh, relu)
+        x = torch.addcmul(sh, x_raw, sc)   # one fma per element, as the kernel forms it
+        x = torch.relu(x) if relu else x
         ref = x.double() @ w.double()
         seen.append(("fwd", tuple(x.shape), w.shape[1], float((y.double() - ref).norm() / ref.norm()),
                      float(((x @ w).double() - ref).norm() / ref.norm())))
@@ -249,12 +259,14 @@ def test_every_gemm_of_a_real_step_is_as_accurate_as_the_library(pn2, cuda):
         return dx
 
     tfu.hip_matmul, tfu.hip_linear_dgrad, tfu.hip_matmul_bn_stats, tfu.hip_linear_dgrad_linked = mm, dg, mm, dg
+    tfu.hip_matmul_bn_stats_xf = mmx
     try:
         tfu.set_default_store(tfu.VariableStore(device=cuda, seed=5))
         logits, _ = pn2.model.get_model(pc, True, 9, hp, bn_decay=0.5)
         pn2.model.get_loss(logits, labels, smpw).backward()
     finally:
         tfu.hip_matmul, tfu.hip_linear_dgrad, tfu.hip_matmul_bn_stats, tfu.hip_linear_dgrad_linked = orig_mm, orig_dg, orig_mms, orig_dgl
+        tfu.hip_matmul_bn_stats_xf = orig_mmx
     assert sum(1 for s_ in seen if s_[0] == "fwd") == 23 and sum(1 for s_ in seen if s_[0] == "dgrad") == 22
     for kind, shape, n, e_pn2, e_torch in seen:
         assert e_pn2 <= 1e-6 and e_pn2 <= 2.0 * e_torch + 1e-8, (kind, shape, n, e_pn2, e_torch)

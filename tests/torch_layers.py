@@ -20,7 +20,7 @@ def batch_norm_train(x, bnv, bn_decay):
     return y.reshape(x.shape)
 
 
-def train_layer_torch(inputs, w2d, b, bnv, bn_decay, relu, pool=0):
+def train_layer_torch(inputs, w2d, b, bnv, bn_decay, relu, pool=0, defer=False):  # defer: an optimisation hint of the HIP layer, nothing to do here
     """same signature and semantics as tf_util._train_layer, all on torch ops (autograd gives the gradients)"""
     cout = w2d.shape[1]
     pool = int(pool) if pool and pool > 1 else 0
