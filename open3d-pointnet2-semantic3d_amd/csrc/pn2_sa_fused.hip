@@ -44,7 +44,22 @@ struct SaFusedParams {
     const float* W[3];
     const float* bias[3];
     float* out;
+    int prio;  // 1: stagger the two waves of a SIMD (see the kernel)
+#ifdef PN2_TUNING_HOOKS
+    long long* stats;  // tuning builds: cycle stamps of the first workgroups (tools/chain_stage_ab.py)
+#endif
 };
+
+// stage stamp k of tile t (tuning builds only): lane 0 of waves 0 and NW/2 of workgroups 0..3
+#ifdef PN2_TUNING_HOOKS
+#define PN2_CHAIN_STAMP(k_)                                                                                              \
+    do {                                                                                                                 \
+        if (p.stats && blockIdx.x < 4 && lane == 0 && (wave == 0 || wave == NW / 2) && tile_no < 4)                      \
+            p.stats[((blockIdx.x * 2 + (wave ? 1 : 0)) * 4 + tile_no) * 8 + (k_)] = (long long)__builtin_readcyclecounter(); \
+    } while (0)
+#else
+#define PN2_CHAIN_STAMP(k_) do { } while (0)
+#endif
 
 __device__ __forceinline__ int acc_chan(int r, int half) { return (r & 3) + 8 * (r >> 2) + 4 * half; }
 
@@ -249,6 +264,17 @@ sa_fused_kernel(SaFusedParams p) {
     const int steps1 = l1_steps(c, VEC8, DENSE, c1);
     constexpr int NTH = NW * 64;
 
+    int tile_no = 0;
+    (void)tile_no;
+    PN2_CHAIN_STAMP(0);
+    // Waves w and w + NW/2 share a SIMD and run in lockstep: all gather (the CU's vector-memory pipe is the limit: 8 waves
+    // x 48 KB), then all want the matrix pipe, then all store -- the matrix pipe idles during the gather / store phases,
+    // 35-40 % of a tile (stage stamps, tools/chain_stage_ab.py; profiles/r03_fp4_chain_stages.txt).  STAGGER (tuning
+    // experiment, off): the second half of the waves holds its first tile back until its SIMD partner has finished the MFMA
+    // layers of its own first tile.  Measured: no gain -- ONE wave drives the matrix pipe at half rate (34 k cycles for a
+    // 128 -> 128 layer alone, 2 x 16 k for two waves together), so a SIMD needs both of its waves in the MFMA phase, and a
+    // third wave per SIMD does not fit the register budget (12-wave workgroups: 128 vs 98 us).
+    const bool stagger = NW == 8 && L >= 2 && p.prio != 0;
     // ---- LDS carve + weight staging (once per persistent workgroup) -----------
     float* wp1 = smem;
     float* wp2 = wp1 + steps1 * 2 * W1;
@@ -256,6 +282,8 @@ sa_fused_kernel(SaFusedParams p) {
     float* sb1 = wp3 + (L >= 3 ? W2 * W3 : 0);
     float* sb2 = sb1 + W1;
     float* sb3 = sb2 + (L >= 2 ? W2 : 0);
+    int* stagger_flag = reinterpret_cast<int*>(sb3 + (L >= 3 ? W3 : 0));  // NW ints behind the biases (launch_chain sizes them in)
+    if (stagger && tid < NW) stagger_flag[tid] = 0;
     // Weight staging, 8 independent global loads in flight per thread (the permutation index maths is
     // cheap; what must be hidden is the L2 latency -- a workgroup may own only a handful of tiles).
     // 16-byte version: index_of(e4) returns the global FLOAT index of 4 consecutive columns (or -1).
@@ -303,6 +331,7 @@ sa_fused_kernel(SaFusedParams p) {
         stage1(sb3, W3, p.bias[2]);
     }
     __syncthreads();
+    PN2_CHAIN_STAMP(1);
 
     constexpr int WOUT = L == 1 ? W1 : (L == 2 ? W2 : W3);
     // XCD-aware tile order (speed only): the dispatcher places workgroup w on XCD w % 8.  Giving XCD x the
@@ -315,7 +344,8 @@ sa_fused_kernel(SaFusedParams p) {
         g_hi = (xcd + 1) * per;
         g_step = (gridDim.x >> 3) * NW;
     }
-    for (int g = g_lo; g < g_hi; g += g_step) {
+    for (int g = g_lo; g < g_hi; g += g_step, ++tile_no) {
+        PN2_CHAIN_STAMP(2);
         size_t prow;  // row of the feature matrix feeding this lane
         f32x16 a1[NT1];
         zero_acc<NT1>(a1);
@@ -363,6 +393,8 @@ sa_fused_kernel(SaFusedParams p) {
                         mfma_step<NT1, LAST1>(a1, w1l + sp * 2 * W1, v);
                     }
                 }
+                // (All 3 x 4 NT1 gathers in flight at once instead of per column tile: no change -- the phase is bound by the
+                // CU's vector-memory pipe, 8 waves x 48 KB at the same time, not by round trips; tools/chain_stage_ab.py.)
 #pragma unroll
                 for (int nt = 0; nt < NT1; ++nt) {
                     f32x4 q1[4], q2[4], q3[4];
@@ -456,6 +488,11 @@ sa_fused_kernel(SaFusedParams p) {
             }
         }
         float* __restrict__ orow = p.out + (size_t)g * WOUT;
+        PN2_CHAIN_STAMP(3);
+        if (stagger && tile_no == 0 && wave >= NW / 2) {
+            while (__hip_atomic_load(&stagger_flag[wave - NW / 2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) == 0)
+                __builtin_amdgcn_s_sleep(8);
+        }
         if constexpr (L == 1) {
             if constexpr (POOL) {
                 if (DENSE || p.kshift == 5) pool_store<NT1>(a1, sb1, orow, half, l31);
@@ -467,6 +504,9 @@ sa_fused_kernel(SaFusedParams p) {
             f32x16 a2[NT2];
             zero_acc<NT2>(a2);
             layer_from_regs<NT1, NT2, L == 2>(a1, a2, wp2, W2, half, l31);
+            PN2_CHAIN_STAMP(4);
+            if (L == 2 && stagger && tile_no == 0 && wave < NW / 2 && lane == 0)
+                __hip_atomic_store(&stagger_flag[wave], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
             if constexpr (L == 2) {
                 if constexpr (POOL) {
                 if (DENSE || p.kshift == 5) pool_store<NT2>(a2, sb2, orow, half, l31);
@@ -478,6 +518,9 @@ sa_fused_kernel(SaFusedParams p) {
                 f32x16 a3[NT3];
                 zero_acc<NT3>(a3);
                 layer_from_regs<NT2, NT3, true>(a2, a3, wp3, W3, half, l31);
+                PN2_CHAIN_STAMP(5);
+                if (stagger && tile_no == 0 && wave < NW / 2 && lane == 0)
+                    __hip_atomic_store(&stagger_flag[wave], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                 if constexpr (POOL) {
                 if (DENSE || p.kshift == 5) pool_store<NT3>(a3, sb3, orow, half, l31);
                 else pool_store_k<NT3>(a3, sb3, p.out, WOUT, g, p.kshift, half, l31);
@@ -485,20 +528,31 @@ sa_fused_kernel(SaFusedParams p) {
                 else rows_store<NT3>(a3, sb3, p.out, WOUT, g * 32, p.rows, half, l31);
             }
         }
+        PN2_CHAIN_STAMP(6);
     }
+    // a wave of the first half without a (complete) first tile must not leave its partner waiting
+    if (stagger && wave < NW / 2 && lane == 0)
+        __hip_atomic_store(&stagger_flag[wave], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 }
 
+PN2_TUNABLE(int, g_chain_prio, 0)    // tuning hook (pn2_debug_set(13, v)): 1 = stagger the two waves of a SIMD (experiment, see the kernel)
+PN2_TUNABLE(long long*, g_chain_stats, nullptr)  // tuning hook: device buffer of 4 x 2 x 4 x 8 cycle stamps
 PN2_TUNABLE(int, g_chain_nw, 0)      // tuning hook (pn2_debug_set(7, v)): 16 = 16-wave workgroups for the single-layer kernels
 PN2_TUNABLE(int, g_chain_grid, 256)  // tuning hook (pn2_debug_set(6, v)): persistent workgroups of the 1-per-CU configuration
 
 template <int L, int NT1, int NT2, int NT3, bool VEC8, bool DENSE, bool POOL, bool INTERP = false, bool PREZ = false>
-int launch_chain(const SaFusedParams& p, hipStream_t st) {
+int launch_chain(const SaFusedParams& p_in, hipStream_t st) {
+    SaFusedParams p = p_in;
+    p.prio = g_chain_prio;
+#ifdef PN2_TUNING_HOOKS
+    p.stats = g_chain_stats;
+#endif
     constexpr int W1 = NT1 * 32, W2 = NT2 * 32, W3 = NT3 * 32;
     const int steps1 = l1_steps(PREZ ? 0 : p.c, VEC8, DENSE, INTERP ? p.c1 : 0);
     size_t floats = (size_t)steps1 * 2 * W1 + W1;
     if (L >= 2) floats += (size_t)W1 * W2 + W2;
     if (L >= 3) floats += (size_t)W2 * W3 + W3;
-    const size_t bytes = floats * sizeof(float);
+    const size_t bytes = floats * sizeof(float) + 64;  // + the stagger flags
     if (bytes > 150 * 1024) return PN2_EUNSUP;
     const int need4 = (p.groups + 3) / 4;
     if constexpr (L == 1) {
@@ -551,9 +605,11 @@ int launch_chain(const SaFusedParams& p, hipStream_t st) {
 }  // namespace
 
 #ifdef PN2_TUNING_HOOKS
+extern "C" int pn2_debug_set_chain_stats(long long* dev_ptr) { g_chain_stats = dev_ptr; return 0; }
 extern "C" int pn2_debug_set_fused(int what, int value) {
     if (what == 6) { g_chain_grid = value; return 0; }
     if (what == 7) { g_chain_nw = value; return 0; }
+    if (what == 13) { g_chain_prio = value; return 0; }
     return PN2_EINVAL;
 }
 #endif  // PN2_TUNING_HOOKS

@@ -1,0 +1,52 @@
+"""Stage anatomy of the fused three-layer FP4 kernel (pn2_fp_mlp_fused_pre) from cycle stamps written by a tuning build
+(build.py --tuning, PN2_HIP_LIBRARY=.../libpn2_tune.so): workgroups 0-3, waves 0 and 4, first tiles.
+usage: PN2_HIP_LIBRARY=$PWD/open3d-pointnet2-semantic3d_amd/libpn2_tune.so python tools/chain_stage_ab.py"""
+import ctypes, os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np, torch
+import pn2_amd as pn2
+dev = torch.device("cuda:0")
+L = ctypes.CDLL(os.environ["PN2_HIP_LIBRARY"])
+stats = torch.zeros(4 * 2 * 4 * 8, dtype=torch.int64, device=dev)
+if len(sys.argv) > 1:
+    assert L.pn2_debug_set(13, int(sys.argv[1])) == 0   # issue priority of the first half of the waves on / off
+tfu, pu = pn2.util.tf_util, pn2.util.pointnet_util
+B, N, M = 16, 8192, 1024
+rs = np.random.RandomState(0)
+xyz1 = torch.from_numpy(rs.rand(B, N, 3).astype(np.float32)).to(dev)
+xyz2 = xyz1[:, :M].contiguous()
+p1 = torch.from_numpy(rs.rand(B, N, 3).astype(np.float32)).to(dev)
+p2 = torch.from_numpy(rs.randn(B, M, 128).astype(np.float32)).to(dev)
+dist, idx = pn2.three_nn(xyz1, xyz2)
+tfu.set_default_store(tfu.VariableStore(device=dev, seed=1))
+with tfu.variable_scope("fp"):
+    f = lambda: pu.fp_features_inference(dist, idx, p1, p2, [128, 128, 128])
+    for _ in range(3):
+        f()
+    torch.cuda.synchronize()
+    L.pn2_debug_set_chain_stats(ctypes.c_void_p(stats.data_ptr()))
+    f()
+    torch.cuda.synchronize()
+    L.pn2_debug_set_chain_stats(ctypes.c_void_p(0))
+    pn2._lib.lib.trace = []
+    for _ in range(10):
+        f()
+    torch.cuda.synchronize()
+    tr, pn2._lib.lib.trace = pn2._lib.lib.trace, None
+    agg = {}
+    for name, args, s_, e_ in tr:
+        agg.setdefault(name, []).append(s_.elapsed_time(e_) * 1e3)
+    print("  ".join("%s %.1f us" % (k, sum(v) / len(v)) for k, v in agg.items()))
+st = stats.cpu().numpy().reshape(4, 2, 4, 8)
+names = ["start", "staged", "tile begin", "layer-1 input ready", "layer 2 done", "layer 3 done", "stored"]
+for blk in range(4):
+    for w in range(2):
+        t0 = st[blk, w, 0, 0]
+        row = ["wg %d wave %d: staging %6d cyc" % (blk, w * 4, st[blk, w, 0, 1] - t0)]
+        for t in range(4):
+            if st[blk, w, t, 2] == 0:
+                continue
+            v = st[blk, w, t]
+            row.append("tile %d @%7d: gather+blend %6d, layer2 %6d, layer3 %6d, store %6d" % (
+                t, v[2] - t0, v[3] - v[2], v[4] - v[3], v[5] - v[4], v[6] - v[5]))
+        print("\n   ".join(row))
