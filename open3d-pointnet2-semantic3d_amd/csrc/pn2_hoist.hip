@@ -35,6 +35,7 @@ struct HoistParams {
     const float* wa;       // (ca, cout)
     float* y;              // (b, rows, cout)
     float* gxyz;           // SA (b, rows, 3) centred coordinates (operand of the weight gradient), may be null
+    int accumulate;        // FP with ca == 0: y already holds points1 @ W[c2:] (a GEMM of the caller), the blended rows are added
 };
 
 template <bool SA, int CA>
@@ -56,13 +57,13 @@ hoist_rows_kernel(HoistParams p) {
     if (rr >= rp) return;
     const f32x4* __restrict__ z = reinterpret_cast<const f32x4*>(p.z + (size_t)bi * p.nsrc * p.cout);
     f32x4* __restrict__ y = reinterpret_cast<f32x4*>(p.y + (size_t)bi * p.rows * p.cout);
-    f32x4 wa[CA];
+    f32x4 wa[CA > 0 ? CA : 1];
 #pragma unroll
     for (int a = 0; a < CA; ++a) wa[a] = *reinterpret_cast<const f32x4*>(p.wa + (size_t)a * p.cout + cc * 4);
     constexpr int U = 4;  // rows in flight per thread
     for (int r0 = bx * rp * U + rr; r0 < p.rows; r0 += gridDim.x * rp * U) {
         f32x4 acc[U];
-        float av[U][CA];
+        float av[U][CA > 0 ? CA : 1];
         int rows_[U];
         if constexpr (SA) {
             const int* __restrict__ idx = p.idx + (size_t)bi * p.rows;
@@ -95,7 +96,7 @@ hoist_rows_kernel(HoistParams p) {
         } else {
             const int* __restrict__ idx = p.idx + (size_t)bi * p.rows * 3;
             const float* __restrict__ dist = p.dist + (size_t)bi * p.rows * 3;
-            const float* __restrict__ p1 = p.points1 + (size_t)bi * p.rows * CA;
+            const float* __restrict__ p1 = CA > 0 ? p.points1 + (size_t)bi * p.rows * CA : nullptr;
             int i1[U], i2[U], i3[U];
             float w1[U], w2[U], w3[U];
 #pragma unroll
@@ -117,6 +118,7 @@ hoist_rows_kernel(HoistParams p) {
             for (int u = 0; u < U; ++u) {
                 const f32x4 a = z[(size_t)i1[u] * cv + cc], b = z[(size_t)i2[u] * cv + cc], c = z[(size_t)i3[u] * cv + cc];
                 acc[u] = (a * w1[u] + b * w2[u]) + c * w3[u];
+                if (CA == 0 && p.accumulate) acc[u] += y[(size_t)(rows_[u] < p.rows ? rows_[u] : p.rows - 1) * cv + cc];
             }
         }
 #pragma unroll
@@ -167,19 +169,24 @@ extern "C" int pn2_sa_hoist_rows(int b, int n, int m, int nsample, int cout, con
 
 // FP: y (b, n, cout) = three_interpolate(z, idx, w(dist)) + points1 (b, n, c1) @ w1 (c1, cout) with z (b, m, cout) =
 // points2 @ W[:c2] computed by the caller; the weights are formed from three_nn's squared distances as in
-// pn2_fp_interp_concat.  1 <= c1 <= 8 (the level-0 module: colours / no features use pn2_three_interpolate alone).
+// pn2_fp_interp_concat.  1 <= c1 <= 8: the product with points1 is formed here (the level-0 module: colours).
+// c1 == 0 with points1 == w1 == NULL: y += three_interpolate(...), y holding the caller's GEMM points1 @ W[c2:] (wider skip
+// links: that product is a real GEMM).
 extern "C" int pn2_fp_hoist_rows(int b, int n, int m, int c1, int cout, const float* dist, const int* idx,
                                  const float* points1, const float* z, const float* w1, float* y, void* stream) {
     if (b <= 0 || n <= 0 || m <= 0 || cout <= 0) return PN2_EINVAL;
-    if (!dist || !idx || !points1 || !z || !w1 || !y) return PN2_ENULL;
-    if (c1 < 1 || c1 > kHoistMaxCa || cout % 4 != 0 || cout > 1024) return PN2_EUNSUP;
+    if (!dist || !idx || !z || !y) return PN2_ENULL;
+    if (c1 > 0 && (!points1 || !w1)) return PN2_ENULL;
+    if (c1 < 0 || c1 > kHoistMaxCa || cout % 4 != 0 || cout > 1024) return PN2_EUNSUP;
     if ((((uintptr_t)z | (uintptr_t)y | (uintptr_t)w1) % 16) != 0) return PN2_EINVAL;
     if ((long long)n * 3 > 0x7fffffffLL || b > 65535) return PN2_ERANGE;
     HoistParams p = {};
     p.rows = n; p.nsrc = m; p.cout = cout; p.ca = c1;
     p.idx = idx; p.dist = dist; p.z = z; p.points1 = points1; p.wa = w1; p.y = y;
+    p.accumulate = c1 == 0;
     hipStream_t st = static_cast<hipStream_t>(stream);
     switch (c1) {
+        case 0: return launch_hoist<false, 0>(b, p, st);
         case 1: return launch_hoist<false, 1>(b, p, st);
         case 2: return launch_hoist<false, 2>(b, p, st);
         case 3: return launch_hoist<false, 3>(b, p, st);

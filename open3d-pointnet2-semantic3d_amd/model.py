@@ -132,10 +132,13 @@ def clone_geometry(geo, l0_xyz):
             "gplans": [cl(t) for t in geo.get("gplans", [None] * 4)], "iplans": [cl(t) for t in geo.get("iplans", [None] * 4)]}
 
 
-def get_sa_fp_features(point_cloud, is_training, hyperparams, bn_decay=None, two_streams=False, geometry=None):
+def get_sa_fp_features(point_cloud, is_training, hyperparams, bn_decay=None, two_streams=False, geometry=None,
+                       head_width=0):
     """point_cloud (B,N,3 or 6) -> l0_points (B,N,128) and end_points.
     two_streams (inference only): overlap the geometry chain with the MLP chain.
-    geometry (extension): compute_geometry(l0_xyz) of this very batch, computed ahead."""
+    geometry (extension): compute_geometry(l0_xyz) of this very batch, computed ahead.
+    head_width (extension, training; get_model passes 128): the result goes to ONE batch-normalised layer of that width and
+    nowhere else, so the last FP layer may hand over its un-normalised output (pointnet_fp_module defer_last_bn)."""
     end_points = {}
     if is_training:
         tf_util.reset_bn_links()  # producer records of the previous forward pass (tf_util._TrainDenseBnRelu)
@@ -170,7 +173,8 @@ def get_sa_fp_features(point_cloud, is_training, hyperparams, bn_decay=None, two
         lvl = 3 - fi  # target level: 3,2,1,0
         up = pointnet_fp_module(xyzs[lvl], xyzs[lvl + 1], feats[lvl], up, list(FP_MLPS[fi]), is_training, bn_decay,
                                 scope="fa_layer%d" % (fi + 1),
-                                nn=None if geometry is None else tuple(geometry["nn"][fi]) + (geometry.get("iplans", [None] * 4)[fi],))
+                                nn=None if geometry is None else tuple(geometry["nn"][fi]) + (geometry.get("iplans", [None] * 4)[fi],),
+                                defer_last_bn=head_width if (fi == 3 and is_training) else 0)
     end_points["xyzs"] = xyzs
     end_points["sa_features"] = feats  # [l0 .. l4] point features of the SA levels (extension: hooks of the trainer)
     return up, end_points
@@ -189,7 +193,8 @@ def get_head(l0_points, is_training, num_class, bn_decay=None, end_points=None):
 
 def get_model(point_cloud, is_training, num_class, hyperparams, bn_decay=None, geometry=None):
     """-> logits (B,N,num_class), end_points (model.py:22-148)."""
-    l0_points, end_points = get_sa_fp_features(point_cloud, is_training, hyperparams, bn_decay, geometry=geometry)
+    l0_points, end_points = get_sa_fp_features(point_cloud, is_training, hyperparams, bn_decay, geometry=geometry,
+                                               head_width=128 if is_training else 0)
     return get_head(l0_points, is_training, num_class, bn_decay, end_points), end_points
 
 

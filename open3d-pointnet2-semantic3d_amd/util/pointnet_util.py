@@ -600,10 +600,13 @@ def fp_features_inference(dist, idx, points1, points2, mlp, bn=True, bn_decay=No
     return h.reshape(b, n, mlp[-1])
 
 
-def pointnet_fp_module(xyz1, xyz2, points1, points2, mlp, is_training, bn_decay, scope, bn=True, nn=None):
+def pointnet_fp_module(xyz1, xyz2, points1, points2, mlp, is_training, bn_decay, scope, bn=True, nn=None, defer_last_bn=0):
     """Feature propagation: xyz1 (B,n1,3) dense, xyz2 (B,n2,3) sparse, points1 (B,n1,c1) or None,
     points2 (B,n2,c2) -> (B,n1,mlp[-1]).  nn = (dist, idx[, plan]) (extension): three_nn(xyz1, xyz2) computed ahead, and
-    optionally scatter_plan(idx, n2, dist, weight_kind=2) for the interpolation's gradient."""
+    optionally scatter_plan(idx, n2, dist, weight_kind=2) for the interpolation's gradient.
+    defer_last_bn = w > 0 (extension, training): the caller feeds the result to exactly ONE conv1d / conv2d of width w with
+    batch norm (model.get_model: the head's fc1) and nothing else -- the last layer then hands over its UN-normalised output
+    (tf_util.USE_BN_ON_LOAD) and that layer applies the batch norm + ReLU while loading it."""
     require_cuda(xyz1, xyz2, points1, points2)
     with tf_util.variable_scope(scope):
         dist, idx = (nn[0], nn[1]) if nn is not None else three_nn(xyz1, xyz2)
@@ -611,13 +614,16 @@ def pointnet_fp_module(xyz1, xyz2, points1, points2, mlp, is_training, bn_decay,
         if not is_training:
             # weights + interpolate + concat fused, then LDS-resident MLP chains / MFMA layers
             return fp_features_inference(dist, idx, points1, points2, mlp, bn, bn_decay)
-        # the level-0 module (points1 = a few input channels, data): the interpolated half of the first conv runs on the
-        # n2 known points instead of the n1 dense ones (tf_util._TrainHoistedBnRelu)
-        if (tf_util.USE_HOISTED_TRAIN and bn and points1 is not None and 1 <= points1.shape[2] <= 8 and not points1.requires_grad
-                and points1.dtype == torch.float32 and points2.dtype == torch.float32 and len(mlp) > 0 and mlp[0] % 4 == 0
+        # the interpolated half of the first conv runs on the n2 known points instead of the n1 dense ones
+        # (tf_util._TrainHoistedBnRelu); points1 = a few input channels (the level-0 module) or SA features
+        c1 = 0 if points1 is None else points1.shape[2]
+        if (tf_util.USE_HOISTED_TRAIN and bn and points1 is not None
+                and ((1 <= c1 <= 8 and not points1.requires_grad) or (tf_util.HOIST_WIDE_SKIP and c1 >= 16 and c1 % 4 == 0))
+                and points1.dtype == torch.float32 and points2.dtype == torch.float32 and len(mlp) > 0 and mlp[0] % 32 == 0
                 and _plan_usable(plan, mlp[0])):
             rows = points1.shape[0] * points1.shape[1]
-            defer = lambda i: bn and i + 1 < len(mlp) and tf_util.can_defer_bn(rows, mlp[i], mlp[i + 1])  # noqa: E731
+            nxt = list(mlp[1:]) + [int(defer_last_bn)]  # width of the layer that consumes layer i (0: unknown -> materialise)
+            defer = lambda i: bn and nxt[i] > 0 and tf_util.can_defer_bn(rows, mlp[i], nxt[i])  # noqa: E731
             h = tf_util.conv2d_hoisted_first("fp", points2, (dist, idx, points1), plan, points2.shape[2] + points1.shape[2],
                                              mlp[0], "conv_0", bn_decay, defer_bn=defer(0))
             for i, cout in enumerate(mlp):
@@ -636,9 +642,10 @@ def pointnet_fp_module(xyz1, xyz2, points1, points2, mlp, is_training, bn_decay,
             new_points1 = torch.cat([interpolated, points1], dim=2) if points1 is not None else interpolated
         new_points1 = new_points1.unsqueeze(2)
         rows = new_points1.shape[0] * new_points1.shape[1]
+        nxt = list(mlp[1:]) + [int(defer_last_bn)]
         for i, cout in enumerate(mlp):
             # un-normalised hand-over to the next layer of the stack (tf_util.USE_BN_ON_LOAD)
-            dfr = bool(is_training) and bn and i + 1 < len(mlp) and tf_util.can_defer_bn(rows, cout, mlp[i + 1])
+            dfr = bool(is_training) and bn and nxt[i] > 0 and tf_util.can_defer_bn(rows, cout, nxt[i])
             new_points1 = tf_util.conv2d(new_points1, cout, [1, 1], padding="VALID", stride=[1, 1], bn=bn,
                                          is_training=is_training, scope="conv_%d" % i, bn_decay=bn_decay, defer_bn=dfr)
         return new_points1.squeeze(2)

@@ -500,9 +500,10 @@ def test_sa_module_hoisted_first_layer_equals_in_place(pn2, oracle, cuda, mlp, c
     close(b_, ref)
 
 
-@pytest.mark.parametrize("kind,mlp,c", [("sa", [64, 64, 128], 64), ("sa", [128], 32), ("sa", [256, 512], 256),
-                                        ("fp", [128, 128, 128], 128), ("fp", [64], 32)])
-def test_training_first_layer_on_the_source_rows_equals_the_grouped_form(pn2, cuda, kind, mlp, c):
+@pytest.mark.parametrize("kind,mlp,c,c1", [("sa", [64, 64, 128], 64, 0), ("sa", [128], 32, 0), ("sa", [256, 512], 256, 0),
+                                           ("fp", [128, 128, 128], 128, 3), ("fp", [64], 32, 3),
+                                           ("fp", [256, 128], 256, 64), ("fp", [256, 256], 512, 256)])
+def test_training_first_layer_on_the_source_rows_equals_the_grouped_form(pn2, cuda, kind, mlp, c, c1):
     """Training path: the feature half of a module's first conv applied to the SOURCE rows (tf_util._TrainHoistedBnRelu,
     pn2_sa_hoist_rows / pn2_fp_hoist_rows; the grouped / concatenated tensor is never built, GEMM + data + weight gradient on
     n resp. m rows) against the grouped form (pn2_sa_group_concat / pn2_fp_interp_concat + conv2d): module output, moving
@@ -523,7 +524,7 @@ def test_training_first_layer_on_the_source_rows_equals_the_grouped_form(pn2, cu
         m = 128
         xyz2 = xyz[:, :m].contiguous()
         src0 = T(rs.randn(b, m, c).astype(np.float32), cuda)
-        p1 = T(rs.rand(b, n, 3).astype(np.float32), cuda)
+        p1_0 = T(rs.rand(b, n, c1).astype(np.float32), cuda)
         dist, idx = pn2.three_nn(xyz, xyz2)
         plan = pu.scatter_plan(idx, m, dist, weight_kind=2)
         oshape = (b, n, mlp[-1])
@@ -531,6 +532,7 @@ def test_training_first_layer_on_the_source_rows_equals_the_grouped_form(pn2, cu
     outs = {}
     for hoist in (True, False):
         tfu.USE_HOISTED_TRAIN = hoist
+        tfu.HOIST_WIDE_SKIP = True  # off by default (slower at the model's shapes); the c1 > 8 cases test it
         store = tfu.set_default_store(tfu.VariableStore(device=cuda, seed=9))
         calls = []
         pn2._lib.lib.trace = calls
@@ -541,17 +543,21 @@ def test_training_first_layer_on_the_source_rows_equals_the_grouped_form(pn2, cu
                 _, out, _ = pu.pointnet_sa_module(xyz, src, m, 0.8, ns, mlp, None, False, True, 0.5, "mod",
                                                   geometry=(new_xyz, idx, plan))
             else:
+                p1 = p1_0.clone().requires_grad_(c1 > 8)  # a wide skip link carries a gradient (SA features), colours do not
                 out = pu.pointnet_fp_module(xyz, xyz2, p1, src, mlp, True, 0.5, "mod", nn=(dist, idx, plan))
             assert tuple(out.shape) == oshape
             (out * probe).sum().backward()
         finally:
             pn2._lib.lib.trace = None
             tfu.USE_HOISTED_TRAIN = True
+            tfu.HOIST_WIDE_SKIP = False
         names = [c_[0] for c_ in calls]
         assert (("pn2_sa_hoist_rows" if kind == "sa" else "pn2_fp_hoist_rows") in names) == hoist
         assert (("pn2_sa_group_concat" if kind == "sa" else "pn2_fp_interp_concat") in names) == (not hoist)
         outs[hoist] = [out.detach(), src.grad] + [p_.grad for _, p_ in sorted(store.params.items()) if p_.grad is not None] + \
                       [v.clone() for _, v in sorted(store.buffers.items())]
+        if kind == "fp" and c1 > 8:
+            outs[hoist].append(p1.grad)
     assert len(outs[True]) == len(outs[False]) and len(outs[True]) >= 4
     for a, r in zip(outs[True], outs[False]):
         assert a.shape == r.shape
