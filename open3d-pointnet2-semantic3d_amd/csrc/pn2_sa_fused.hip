@@ -570,7 +570,7 @@ int launch_chain(const SaFusedParams& p_in, hipStream_t st) {
             return PN2_OK;
         }
     }
-    if (bytes > 78 * 1024 && p.groups >= 2048) {
+    if (bytes > 78 * 1024 && p.groups >= 2048 && g_chain_nw != 4) {  // g_chain_nw == 4 (tuning): one wave per SIMD
         // only one workgroup fits per CU: give it 8 waves (2 per SIMD) sharing the LDS weights.
         // (With fewer than 2048 tiles, 4-wave workgroups spread the tiles over twice as many CUs.)
         auto kern = sa_fused_kernel<L, NT1, NT2, NT3, VEC8, DENSE, POOL, 8, INTERP, PREZ>;

@@ -9,7 +9,9 @@ dev = torch.device("cuda:0")
 L = ctypes.CDLL(os.environ["PN2_HIP_LIBRARY"])
 stats = torch.zeros(4 * 2 * 4 * 8, dtype=torch.int64, device=dev)
 if len(sys.argv) > 1:
-    assert L.pn2_debug_set(13, int(sys.argv[1])) == 0   # issue priority of the first half of the waves on / off
+    assert L.pn2_debug_set(13, int(sys.argv[1])) == 0   # stagger the two waves of a SIMD on / off
+if len(sys.argv) > 2:
+    assert L.pn2_debug_set(7, int(sys.argv[2])) == 0    # 4: four-wave workgroups (one wave per SIMD)
 tfu, pu = pn2.util.tf_util, pn2.util.pointnet_util
 B, N, M = 16, 8192, 1024
 rs = np.random.RandomState(0)
