@@ -653,7 +653,7 @@ _bn_links = {}
 
 
 class _BnLink:
-    __slots__ = ("shape", "y", "gamma", "beta", "mean", "invstd", "relu", "ws", "dz_ptr", "dz_keep", "sc", "sh")
+    __slots__ = ("shape", "y", "gamma", "beta", "mean", "invstd", "relu", "ws", "dz_ptr", "dz_keep", "sc", "sh", "consumed")
 
 
 # ---- deferred normalisation: layer i publishes (scale, shift) and hands its PRE-normalisation output y to layer i+1 -------
@@ -739,7 +739,7 @@ def _bn_register_producer(z, y, gamma, beta, save_mean, save_invstd, relu, poole
     lk = _BnLink()
     lk.shape, lk.y, lk.gamma, lk.beta, lk.mean, lk.invstd, lk.relu = tuple(z.shape), y, gamma, beta, save_mean, save_invstd, bool(relu)
     lk.ws = lk.dz_ptr = lk.dz_keep = None
-    lk.sc, lk.sh = sc, sh
+    lk.sc, lk.sh, lk.consumed = sc, sh, False
     _bn_links[z.data_ptr()] = lk
     return lk
 
@@ -757,6 +757,9 @@ def _bn_train_backward(dz, y, gamma, beta, save_mean, save_invstd, relu, pool, z
         ws, bwd = lk.ws, lib.pn2_bn_relu_backward_stats
     else:
         ws, bwd = _bn_scratch(c, y.device, lib.pn2_bn_relu_backward, lib.pn2_bn_relu_backward_ws0)
+    if lk is not None and lk.sc is not None and not lk.consumed:
+        # the un-normalised output went somewhere else than into the next dense layer: whatever read it saw wrong values
+        raise RuntimeError("a deferred batch-norm output (conv2d(..., defer_bn=True)) was not consumed by a following conv2d")
     if lk is not None:  # this layer's backward runs once: drop what the record kept alive
         lk.ws = lk.dz_keep = lk.dz_ptr = lk.y = lk.gamma = lk.beta = lk.mean = lk.invstd = lk.sc = lk.sh = None
     with torch.cuda.device(y.device):
@@ -787,6 +790,7 @@ class _TrainDenseBnRelu(torch.autograd.Function):
                 raise RuntimeError("a deferred batch-norm output reached a layer that cannot apply it")
             ws = _bn_zeroed_scratch(c, x2d.device)
             y = hip_matmul_bn_stats_xf(x2d, w, ws, prev.sc, prev.sh, prev.relu)
+            prev.consumed = True
         elif USE_GEMM_BN_STATS and c % 32 == 0:
             # the GEMM's epilogue leaves the column sums of y in the batch-norm workspace: no statistics pass over y
             ws = _bn_zeroed_scratch(c, x2d.device)

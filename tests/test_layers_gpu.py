@@ -622,6 +622,24 @@ def test_training_stack_with_batch_norm_applied_on_load_equals_the_materialised_
         assert float((a - r).abs().max()) <= 2e-4 * sc, (a.shape, float((a - r).abs().max()), sc)
 
 
+def test_deferred_batch_norm_output_must_reach_a_dense_layer(pn2, cuda):
+    """conv2d(..., defer_bn=True) hands over an UN-normalised tensor; if anything but the next batch-normalised conv2d
+    consumes it the backward pass raises instead of training on wrong values, and a layer without batch norm refuses it."""
+    import torch
+    tfu = pn2.util.tf_util
+    tfu.set_default_store(tfu.VariableStore(device=cuda, seed=2))
+    tfu.reset_bn_links()
+    x = torch.randn(2, 2048, 1, 16, device=cuda, requires_grad=True)
+    h = tfu.conv2d(x, 32, [1, 1], padding="VALID", stride=[1, 1], bn=True, is_training=True, scope="a", bn_decay=0.5, defer_bn=True)
+    with pytest.raises(RuntimeError):
+        h.sum().backward()     # consumed by a reduction, not by a dense layer
+    tfu.reset_bn_links()
+    h = tfu.conv2d(x, 32, [1, 1], padding="VALID", stride=[1, 1], bn=True, is_training=True, scope="a", bn_decay=0.5, defer_bn=True)
+    with pytest.raises(RuntimeError):
+        tfu.conv2d(h, 32, [1, 1], padding="VALID", stride=[1, 1], bn=False, activation_fn=None, is_training=True, scope="b")
+    tfu.reset_bn_links()
+
+
 def test_fp_module_chain_equals_per_layer_linear(pn2, oracle, cuda):
     """FP4-shaped module: the chained path and the one-launch-per-layer path agree to fp32 rounding."""
     tfu, pu = pn2.util.tf_util, pn2.util.pointnet_util
