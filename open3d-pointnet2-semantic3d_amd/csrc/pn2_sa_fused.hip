@@ -274,7 +274,11 @@ sa_fused_kernel(SaFusedParams p) {
     // layers of its own first tile.  Measured: no gain -- ONE wave drives the matrix pipe at half rate (34 k cycles for a
     // 128 -> 128 layer alone, 2 x 16 k for two waves together), so a SIMD needs both of its waves in the MFMA phase, and a
     // third wave per SIMD does not fit the register budget (12-wave workgroups: 128 vs 98 us).
+#ifdef PN2_TUNING_HOOKS
     const bool stagger = NW == 8 && L >= 2 && p.prio != 0;
+#else
+    constexpr bool stagger = false;  // the experiment is compiled out of the shipped library
+#endif
     // ---- LDS carve + weight staging (once per persistent workgroup) -----------
     float* wp1 = smem;
     float* wp2 = wp1 + steps1 * 2 * W1;
