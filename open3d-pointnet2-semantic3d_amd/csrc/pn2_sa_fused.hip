@@ -574,6 +574,31 @@ int launch_chain(const SaFusedParams& p_in, hipStream_t st) {
             return PN2_OK;
         }
     }
+    if constexpr (L == 3 && INTERP && PREZ) {
+#ifdef PN2_FP4_NW12
+        constexpr bool nw12 = true;   // A/B build without the tuning hooks' register cost: build.py extra_flags -DPN2_FP4_NW12
+#else
+        const bool nw12 = g_chain_nw == 12;
+#endif
+        // three waves per SIMD (168 registers, 12 B of scratch): 128-131 us against 101 for two -- measured twice, with and
+        // without spills; not used
+        if (nw12 && bytes > 78 * 1024 && p.groups >= 2048) {
+            auto kern = sa_fused_kernel<L, NT1, NT2, NT3, VEC8, DENSE, POOL, 12, INTERP, PREZ>;
+            static bool attr_set = false;
+            if (!attr_set) {
+                hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                                   hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+                if (e != hipSuccess) return (int)e;
+                attr_set = true;
+            }
+            int grid = g_chain_grid;
+            const int need12 = (p.groups + 11) / 12;
+            if (grid > need12) grid = need12;
+            kern<<<grid, 768, bytes, st>>>(p);
+            PN2_RETURN_IF_LAUNCH_FAILED();
+            return PN2_OK;
+        }
+    }
     if (bytes > 78 * 1024 && p.groups >= 2048 && g_chain_nw != 4) {  // g_chain_nw == 4 (tuning): one wave per SIMD
         // only one workgroup fits per CU: give it 8 waves (2 per SIMD) sharing the LDS weights.
         // (With fewer than 2048 tiles, 4-wave workgroups spread the tiles over twice as many CUs.)
