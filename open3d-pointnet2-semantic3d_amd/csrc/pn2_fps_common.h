@@ -67,7 +67,9 @@ __device__ __forceinline__ int pick_phase(int chi, unsigned clo, float cx, float
         const int kk = __builtin_amdgcn_readlane(ck, L);
         // (gfx9 constant bus: one SGPR per instruction, so the lane select travels in m0, which the compiler only ever
         // sets right before a use of its own)
-        asm volatile("s_mov_b32 m0, %8\n v_writelane_b32 %0, %4, m0\n v_writelane_b32 %1, %5, m0\n v_writelane_b32 %2, %6, m0\n v_writelane_b32 %3, %7, m0"
+        // s_nop: the parked values come out of v_readlane (a VALU write of an SGPR); gfx940+ wants 2 wait states before a VALU
+        // reads such an SGPR, and the hazard recogniser does not insert them in front of inline asm that CONSUMES a register
+        asm volatile("s_mov_b32 m0, %8\n s_nop 0\n v_writelane_b32 %0, %4, m0\n v_writelane_b32 %1, %5, m0\n v_writelane_b32 %2, %6, m0\n v_writelane_b32 %3, %7, m0"
                      : "+v"(pk_k), "+v"(pk_x), "+v"(pk_y), "+v"(pk_z) : "s"(kk), "s"(x1), "s"(y1), "s"(z1), "s"(npick));
         const float d = pn2_sqdist<MODE>(cx - x1, cy - y1, cz - z1);
         const int di = __float_as_int(d);
