@@ -164,3 +164,67 @@ def test_config2_msg_full_size(pn2, oracle, cuda):
                 h = oracle.conv_bn_relu(h, l)
             close(got[sl, :, col:col + width], h.max(2))
         col += width
+
+
+@pytest.mark.parametrize("level", ["SA2", "SA3"])
+def test_training_first_layer_kernels_vs_float64_at_full_size(pn2, cuda, level):
+    """pn2_sa_hoist_rows at the SA2 / SA3 shapes of configs[1] (B = 16): the un-normalised first-layer output
+    y = (group_point(xyz) - new_xyz) @ W[:3] + (points @ W[3:])[idx] against float64 of the REFERENCE formulation -- concat
+    [grouped_xyz - new_xyz | group_point(points)] @ W (pointnet_util.py:39-54,150-156) -- at 1e-5 of (1 + |ref|); and the
+    centred coordinates it emits for the weight gradient, bit for bit."""
+    import torch
+    check, lib, ptr, stream_ptr = pn2._lib.check, pn2._lib.lib, pn2._lib.ptr, pn2._lib.stream_ptr
+    n, m, c, cout, r = {"SA2": (1024, 256, 64, 64, 1.0), "SA3": (256, 64, 128, 128, 2.0)}[level]
+    b, ns = 16, 32
+    rs = np.random.RandomState(n)
+    xyz = s_scene(n, b, n)
+    pts = rs.randn(b, n, c).astype(np.float32)
+    w = (rs.randn(3 + c, cout) / np.sqrt(3 + c)).astype(np.float32)
+    x_t, p_t, w_t = T(xyz, cuda), T(pts, cuda), T(w, cuda)
+    new_xyz, idx = pn2.util.pointnet_util.sa_geometry(x_t, m, r, ns)
+    z = pn2.util.tf_util.hip_matmul(p_t.reshape(-1, c), w_t[3:].contiguous())
+    y = torch.empty((b * m * ns, cout), dtype=torch.float32, device=cuda)
+    g = torch.empty((b * m * ns, 3), dtype=torch.float32, device=cuda)
+    with torch.cuda.device(cuda):
+        wx_t = w_t[:3].contiguous()   # kept alive: raw pointer below
+        check(lib.pn2_sa_hoist_rows(b, n, m, ns, cout, ptr(x_t), ptr(new_xyz), ptr(idx), ptr(z), ptr(wx_t), ptr(y), ptr(g),
+                                    stream_ptr()), "pn2_sa_hoist_rows")
+    ii = idx.cpu().numpy().astype(np.int64)
+    gx = np.take_along_axis(xyz[:, None].repeat(m, 1), ii[..., None], 2) - new_xyz.cpu().numpy()[:, :, None]   # float32, as the op
+    gp = np.take_along_axis(pts[:, None].repeat(m, 1), ii[..., None], 2)
+    ref = np.concatenate([gx, gp], -1).astype(np.float64).reshape(-1, 3 + c) @ w.astype(np.float64)
+    assert np.array_equal(g.cpu().numpy(), gx.reshape(-1, 3))
+    close(y.cpu().numpy(), ref)
+
+
+def test_training_fp4_first_layer_kernel_vs_float64_at_full_size(pn2, cuda):
+    """pn2_fp_hoist_rows at FP4's shape (B = 16, n = 8192, m = 1024, c2 = 128, c1 = 3 -> 128): y = three_interpolate(points2 @
+    W[:c2]) + points1 @ W[c2:] against float64 of concat[three_interpolate(points2) | points1] @ W
+    (pointnet_util.py:300-312) with the float32 inverse-distance weights the reference forms, at 1e-5 of (1 + |ref|)."""
+    import torch
+    check, lib, ptr, stream_ptr = pn2._lib.check, pn2._lib.lib, pn2._lib.ptr, pn2._lib.stream_ptr
+    b, n, m, c2, c1, cout = 16, 8192, 1024, 128, 3, 128
+    rs = np.random.RandomState(4)
+    xyz1 = s_scene(4, b, n)
+    p1 = rs.rand(b, n, c1).astype(np.float32)
+    p2 = rs.randn(b, m, c2).astype(np.float32)
+    w = (rs.randn(c2 + c1, cout) / np.sqrt(c2 + c1)).astype(np.float32)
+    x1 = T(xyz1, cuda)
+    x2 = pn2.gather_point(x1, pn2.farthest_point_sample(m, x1))
+    dist, idx = pn2.three_nn(x1, x2)
+    w_t = T(w, cuda)
+    p2_t = T(p2, cuda)
+    z = pn2.util.tf_util.hip_matmul(p2_t.reshape(-1, c2), w_t[:c2].contiguous())
+    y = torch.empty((b * n, cout), dtype=torch.float32, device=cuda)
+    with torch.cuda.device(cuda):
+        p1_t, wa_t = T(p1, cuda), w_t[c2:].contiguous()   # kept alive: raw pointers below
+        check(lib.pn2_fp_hoist_rows(b, n, m, c1, cout, ptr(dist), ptr(idx), ptr(p1_t), ptr(z), ptr(wa_t), ptr(y), stream_ptr()),
+              "pn2_fp_hoist_rows")
+    d = np.maximum(dist.cpu().numpy(), np.float32(1e-10))
+    rw = (np.float32(1.0) / d)
+    wgt = rw / rw.sum(2, keepdims=True, dtype=np.float32)                      # float32 like tf (pointnet_util.py:300-303)
+    ii = idx.cpu().numpy().astype(np.int64)
+    nb = p2[np.arange(b)[:, None, None], ii]                                   # (b, n, 3, c2)
+    interp = (nb.astype(np.float64) * wgt.astype(np.float64)[..., None]).sum(2)
+    ref = np.concatenate([interp, p1.astype(np.float64)], -1).reshape(-1, c2 + c1) @ w.astype(np.float64)
+    close(y.cpu().numpy(), ref)

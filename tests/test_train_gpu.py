@@ -223,6 +223,68 @@ def test_adam_step_matches_tf_formula(pn2, cuda):
         np.testing.assert_allclose(tv.cpu().numpy(), vr, rtol=2e-6, atol=1e-12)
 
 
+@pytest.mark.parametrize("rows,cin,cout,relu", [(4096, 64, 64, 1), (40000, 128, 256, 1), (131072, 32, 32, 1), (5000, 96, 160, 0)])
+def test_deferred_batch_norm_constants_and_load_transform_vs_float64(pn2, cuda, rows, cin, cout, relu):
+    """pn2_bn_relu_forward_deferred (statistics -> save_mean / save_invstd / moving averages / scale, shift, both from the GEMM
+    epilogue's sums and from its own pass) and the two kernels that apply relu(fma(y, scale, shift)) while loading y --
+    pn2_linear_bn_stats_xf (forward GEMM + statistics of the NEXT layer) and pn2_linear_wgrad_accumulate_xf (its weight
+    gradient) -- against float64 of batch norm -> relu -> conv (tf_util.py:555-581,186-204)."""
+    import torch
+    tfu = pn2.util.tf_util
+    lib, ptr, sp, check = pn2._lib.lib, pn2._lib.ptr, pn2._lib.stream_ptr, pn2._lib.check
+    rs = np.random.RandomState(rows % 97 + cin)
+    x = (rs.randn(rows, cin) * (1 + rs.rand(cin)) + rs.randn(cin)).astype(np.float32)    # the lower layer's un-normalised output
+    gamma, beta = (1 + 0.2 * rs.randn(cin)).astype(np.float32), (0.1 * rs.randn(cin)).astype(np.float32)
+    bias = (0.05 * rs.randn(cin)).astype(np.float32)
+    w = (rs.randn(cin, cout) / np.sqrt(cin)).astype(np.float32)
+    dy = rs.randn(rows, cout).astype(np.float32)
+    xd = x.astype(np.float64)
+    mean, var = xd.mean(0), xd.var(0)
+    invstd = 1.0 / np.sqrt(var + 1e-3)
+    zref = (xd - mean) * invstd * gamma + beta
+    zref = np.maximum(zref, 0) if relu else zref
+    x_t, g_t, b_t, bias_t, w_t, dy_t = (T(a_, cuda) for a_ in (x, gamma, beta, bias, w, dy))  # kept alive: raw pointers below
+    for stats_done in (0, 1):
+        nbytes = lib.pn2_bn_workspace_bytes(cin)
+        ws = torch.zeros(nbytes // 8, dtype=torch.float64, device=cuda)
+        if stats_done:   # the sums as pn2_linear_bn_stats leaves them: x itself = identity GEMM output is not available -> use its epilogue
+            eye = torch.eye(cin, device=cuda)
+            if cin % 32 != 0:
+                continue
+            y_same = torch.empty_like(x_t)
+            check(lib.pn2_linear_bn_stats(rows, cin, cin, ptr(x_t), ptr(eye), ptr(y_same), ptr(ws), nbytes, sp()), "pn2_linear_bn_stats")
+            assert torch.equal(y_same, x_t)
+        rm, rv = torch.zeros(cin, device=cuda), torch.ones(cin, device=cuda)
+        sm, si, sc, sh = (torch.empty(cin, device=cuda) for _ in range(4))
+        check(lib.pn2_bn_relu_forward_deferred(rows, cin, ptr(x_t), ptr(g_t), ptr(b_t), ptr(bias_t), 1e-3,
+                                               0.5, stats_done, ptr(rm), ptr(rv), ptr(ws), nbytes, ptr(sm), ptr(si), ptr(sc), ptr(sh),
+                                               sp()), "pn2_bn_relu_forward_deferred")
+        np.testing.assert_allclose(sm.cpu().numpy(), mean, rtol=1e-5, atol=1e-6)
+        np.testing.assert_allclose(si.cpu().numpy(), invstd, rtol=1e-5)
+        np.testing.assert_allclose(sc.cpu().numpy(), gamma * invstd, rtol=2e-5, atol=1e-7)
+        np.testing.assert_allclose(sh.cpu().numpy(), beta - mean * gamma * invstd, rtol=2e-5, atol=2e-6)
+        np.testing.assert_allclose(rm.cpu().numpy(), 0.5 * (mean + bias), rtol=1e-5, atol=1e-6)          # bias folded into the mean
+        np.testing.assert_allclose(rv.cpu().numpy(), 0.5 + 0.5 * var * rows / (rows - 1), rtol=1e-5)
+    # the next layer: forward GEMM (+ its own statistics) and weight gradient with the transform applied on load
+    ws2 = torch.zeros(lib.pn2_bn_workspace_bytes(cout) // 8, dtype=torch.float64, device=cuda)
+    y2 = torch.empty((rows, cout), dtype=torch.float32, device=cuda)
+    if cout % 32 == 0:
+        check(lib.pn2_linear_bn_stats_xf(rows, cin, cout, ptr(x_t), ptr(w_t), ptr(y2), ptr(ws2), ws2.numel() * 8, ptr(sc), ptr(sh),
+                                         relu, sp()), "pn2_linear_bn_stats_xf")
+        ref = zref @ w.astype(np.float64)
+        assert np.abs(y2.cpu().numpy() - ref).max() <= 2e-5 * max(1.0, np.abs(ref).max())
+        sums = ws2.cpu().numpy()
+        head = 8
+        got = sums[head + 2 * cout:].reshape(-1, 2, cout).sum(0)      # slot copies [nslots][2][cout]
+        np.testing.assert_allclose(got[0], ref.sum(0), rtol=1e-4, atol=1e-2 * np.sqrt(rows))
+        np.testing.assert_allclose(got[1], (ref ** 2).sum(0), rtol=1e-4)
+    dw = torch.zeros((cin, cout), dtype=torch.float32, device=cuda)
+    check(lib.pn2_linear_wgrad_accumulate_xf(rows, cin, cout, ptr(x_t), ptr(dy_t), ptr(dw), ptr(sc), ptr(sh), relu, sp()),
+          "pn2_linear_wgrad_accumulate_xf")
+    refw = zref.T @ dy.astype(np.float64)
+    assert np.abs(dw.cpu().numpy() - refw).max() <= 3e-5 * max(1.0, np.abs(refw).max())
+
+
 def test_every_gemm_of_a_real_step_is_as_accurate_as_the_library(pn2, cuda):
     """Every forward GEMM (pn2_linear) and data-gradient GEMM (pn2_linear_dgrad) of one real training step, on the
     tensors the step actually produces, against float64: relative error <= 1e-6 and never worse than 2x torch.mm's."""
