@@ -188,6 +188,33 @@ class OverlappedGradAllReduce:
         return self.flat
 
 
+    # ---- a backward pass run in two pieces (train.Trainer: three captured segments) -----------------------------------
+    @torch.no_grad()
+    def pack_early(self):
+        """after the first piece (loss -> head -> FP): the early bucket's gradients into their slice of `flat`"""
+        self._pack(self.split, len(self.params))
+
+    @torch.no_grad()
+    def pack_late_and_bind(self):
+        """after the second piece (-> SA): the late bucket into `flat`; every p.grad becomes a view of `flat`"""
+        self._pack(0, self.split)
+        for p, v in zip(self.params, self.views):
+            p.grad = v
+        return self.flat
+
+    def reduce_early_async(self):
+        """the early bucket's all-reduce (sum), asynchronous: it travels while the second piece of backward runs"""
+        if dist.is_available() and dist.is_initialized():
+            return dist.all_reduce(self.early_flat, op=dist.ReduceOp.SUM, async_op=True)
+        return None
+
+    def reduce_late_and_wait(self, work):
+        if dist.is_available() and dist.is_initialized() and self.split_off > 0:
+            dist.all_reduce(self.late_flat, op=dist.ReduceOp.SUM)
+        if work is not None:
+            work.wait()
+        return self.flat
+
     @torch.no_grad()
     def reduce_deferred(self):
         """the collective of a defer_collectives step: ONE all-reduce (sum) of the whole flat gradient on the current stream"""

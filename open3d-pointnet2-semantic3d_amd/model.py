@@ -133,12 +133,15 @@ def clone_geometry(geo, l0_xyz):
 
 
 def get_sa_fp_features(point_cloud, is_training, hyperparams, bn_decay=None, two_streams=False, geometry=None,
-                       head_width=0):
+                       head_width=0, cut_sa_fp=False):
     """point_cloud (B,N,3 or 6) -> l0_points (B,N,128) and end_points.
     two_streams (inference only): overlap the geometry chain with the MLP chain.
     geometry (extension): compute_geometry(l0_xyz) of this very batch, computed ahead.
     head_width (extension, training; get_model passes 128): the result goes to ONE batch-normalised layer of that width and
-    nowhere else, so the last FP layer may hand over its un-normalised output (pointnet_fp_module defer_last_bn)."""
+    nowhere else, so the last FP layer may hand over its un-normalised output (pointnet_fp_module defer_last_bn).
+    cut_sa_fp (extension, training): the FP modules read DETACHED copies of the SA outputs (end_points["sa_features_cut"],
+    requiring grad), so the backward pass can be run in two pieces -- loss -> head -> FP -> the cut, then the cut -> SA --
+    with the gradient all-reduce of the first piece's parameters travelling during the second (train.Trainer)."""
     end_points = {}
     if is_training:
         tf_util.reset_bn_links()  # producer records of the previous forward pass (tf_util._TrainDenseBnRelu)
@@ -168,10 +171,14 @@ def get_sa_fp_features(point_cloud, is_training, hyperparams, bn_decay=None, two
         feats.append(new_points)
 
     # feature propagation, coarse to fine (model.py:90-129)
-    up = feats[4]
+    fp_in = feats
+    if cut_sa_fp and is_training:
+        fp_in = [feats[0]] + [f.detach().requires_grad_(True) for f in feats[1:]]
+        end_points["sa_features_cut"] = fp_in[1:]
+    up = fp_in[4]
     for fi in range(4):
         lvl = 3 - fi  # target level: 3,2,1,0
-        up = pointnet_fp_module(xyzs[lvl], xyzs[lvl + 1], feats[lvl], up, list(FP_MLPS[fi]), is_training, bn_decay,
+        up = pointnet_fp_module(xyzs[lvl], xyzs[lvl + 1], fp_in[lvl], up, list(FP_MLPS[fi]), is_training, bn_decay,
                                 scope="fa_layer%d" % (fi + 1),
                                 nn=None if geometry is None else tuple(geometry["nn"][fi]) + (geometry.get("iplans", [None] * 4)[fi],),
                                 defer_last_bn=head_width if (fi == 3 and is_training) else 0)
@@ -191,10 +198,10 @@ def get_head(l0_points, is_training, num_class, bn_decay=None, end_points=None):
     return tf_util.conv1d(net, num_class, 1, padding="VALID", activation_fn=None, scope="fc2", is_training=is_training)
 
 
-def get_model(point_cloud, is_training, num_class, hyperparams, bn_decay=None, geometry=None):
-    """-> logits (B,N,num_class), end_points (model.py:22-148)."""
+def get_model(point_cloud, is_training, num_class, hyperparams, bn_decay=None, geometry=None, cut_sa_fp=False):
+    """-> logits (B,N,num_class), end_points (model.py:22-148).  cut_sa_fp: see get_sa_fp_features."""
     l0_points, end_points = get_sa_fp_features(point_cloud, is_training, hyperparams, bn_decay, geometry=geometry,
-                                               head_width=128 if is_training else 0)
+                                               head_width=128 if is_training else 0, cut_sa_fp=cut_sa_fp)
     return get_head(l0_points, is_training, num_class, bn_decay, end_points), end_points
 
 

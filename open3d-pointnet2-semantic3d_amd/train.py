@@ -36,14 +36,15 @@ class Trainer:
     buffers (pn2_adam_step).  torch supplies memory, streams, the autograd tape and torch.distributed.
 
     Step-dependent scalars live in device memory (learning rate with Adam's bias correction, dropout step), so after
-    `warmup_eager` ordinary steps the step is captured and replayed: on one GPU as ONE hipGraph; with several ranks as two
-    (forward + backward with the gradients packed into the flat buffer | Adam) around ONE all-reduce of the 3.87 MB flat
-    gradient -- no collective inside a captured region.  Eager steps (the warm-up, capture=False) split the all-reduce in
-    two buckets, the first one launched from inside backward (dist.OverlappedGradAllReduce)."""
+    `warmup_eager` ordinary steps the step is captured and replayed: on one GPU as ONE hipGraph; with several ranks as three
+    (forward + head/FP backward | SA backward | Adam) with the two buckets' all-reduces between them, the first one
+    asynchronous so that it travels while the second graph replays -- no collective inside a captured region.  Eager steps
+    (the warm-up, capture=False) launch the first bucket's all-reduce from inside backward (dist.OverlappedGradAllReduce)."""
 
     BETA1, BETA2, EPS = 0.9, 0.999, 1e-8  # tf.train.AdamOptimizer defaults (train.py:381-384)
 
-    def __init__(self, hyperparams, num_class, store=None, device="cuda", capture=True, warmup_eager=3, geometry_in_graph=False, split_capture=None):
+    def __init__(self, hyperparams, num_class, store=None, device="cuda", capture=True, warmup_eager=3, geometry_in_graph=False,
+                 split_capture=None, overlap_collective=True):
         self.hp = dict(hyperparams)
         # schedule / optimizer keys of the reference's semantic.json (train.py:80-119, 380-386); its defaults when absent
         opt = str(self.hp.get("optimizer", "adam")).lower()
@@ -69,7 +70,12 @@ class Trainer:
         # with the gradient all-reduce launched between them: how a step is captured when there are several ranks (a
         # collective inside a captured backward pass is avoided).  None = when world > 1; True forces it (tests).
         self.split_capture = split_capture
-        self._graph_adam = None
+        # overlap_collective (with a split capture): THREE graphs -- forward + the backward pass down to the FP / SA boundary |
+        # the SA part of the backward pass | Adam -- so that the all-reduce of the head + FP gradients (launched asynchronously
+        # after the first) travels while the second replays; the SA bucket's all-reduce follows it.  False: two graphs around
+        # ONE all-reduce of the whole flat gradient.
+        self.overlap_collective = bool(overlap_collective)
+        self._graph_adam, self._graph_late = None, None
         self._static_geo_next, self._static_next_xyz, self._next_tag = None, None, None
 
     # ---- set-up ------------------------------------------------------------------------------------------------
@@ -136,6 +142,33 @@ class Trainer:
         self.bucket.begin()
         loss.backward()
         return loss.detach(), self.bucket.finish()
+
+    def _forward_backward_early(self, pc, labels, smpw, decay, geometry=None):
+        """first piece of a cut step: forward, loss, and the backward pass of the head and the FP modules down to (detached
+        copies of) the SA outputs; the early bucket is packed.  -> loss"""
+        if self.store.zero_arena is None:
+            self.store.zero_arena = tf_util.ZeroArena(self.flat_p.device)
+        elif self.store.zero_arena.buf is None:
+            self.store.zero_arena.allocate()
+        self.store.zero_arena.reset()
+        for p in self.bucket.params:
+            p.grad = None
+        logits, ep = model.get_model(pc, True, self.num_class, self.hp, bn_decay=decay, geometry=geometry, cut_sa_fp=True)
+        loss = model.get_loss(logits, labels, smpw)
+        early = list(self.bucket.params[self.bucket.split:])
+        cut = list(ep["sa_features_cut"])
+        grads = torch.autograd.grad(loss, early + cut, allow_unused=True)
+        for p, g in zip(early, grads[:len(early)]):
+            p.grad = g
+        self.bucket.pack_early()
+        self._cut = [(t, g) for t, g in zip(ep["sa_features"][1:], grads[len(early):]) if g is not None]
+        return loss.detach()
+
+    def _backward_late(self):
+        """second piece: the SA modules' backward pass from the gradients at the cut; the late bucket is packed"""
+        torch.autograd.backward([t for t, _ in self._cut], [g for _, g in self._cut])
+        self._cut = None
+        return self.bucket.pack_late_and_bind()
 
     def _adam(self, flat_g):
         with torch.cuda.device(self.flat_p.device):
@@ -257,7 +290,12 @@ class Trainer:
                     taken.record(self._stream)
                     self._prefetch(next_pc, taken)
                 self._graph.replay()
-                if self._graph_adam is not None:  # split capture: the collective runs between the two graphs
+                if self._graph_late is not None:  # three segments: the early bucket travels while the SA backward replays
+                    work = self.bucket.reduce_early_async()
+                    self._graph_late.replay()
+                    self.bucket.reduce_late_and_wait(work)
+                    self._graph_adam.replay()
+                elif self._graph_adam is not None:  # split capture: the collective runs between the two graphs
                     self.bucket.reduce_deferred()
                     self._graph_adam.replay()
                 loss = self._static[3]
@@ -295,7 +333,9 @@ class Trainer:
                 with torch.cuda.stream(self._geo_stream):
                     tmp = model.compute_geometry(self._static_next_xyz, self.hp, plans=True)
                     tf_util.multi_copy_(model.geometry_tensors(self._static_geo_next), model.geometry_tensors(tmp))
-            if split:
+            if split and self.overlap_collective:
+                loss = self._forward_backward_early(st[0], st[1], st[2], decay, geometry=sg)
+            elif split:
                 self.bucket.defer_collectives = True
                 try:
                     loss, flat_g = self._forward_backward(st[0], st[1], st[2], decay, geometry=sg)
@@ -305,7 +345,12 @@ class Trainer:
                 loss = self._step_body(st[0], st[1], st[2], decay, geometry=sg)
             if self.geometry_in_graph:
                 torch.cuda.current_stream().wait_stream(self._geo_stream)  # join
-        self._graph_adam = None
+        self._graph_adam, self._graph_late = None, None
+        if split and self.overlap_collective:
+            gl = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(gl, pool=g.pool()):
+                flat_g = self._backward_late()
+            self._graph_late = gl
         if split:
             ga = torch.cuda.CUDAGraph()
             with torch.cuda.graph(ga):
