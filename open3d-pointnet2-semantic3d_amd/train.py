@@ -320,8 +320,12 @@ class Trainer:
             self._static_geo_next = model.clone_geometry(geo, self._static_next_xyz)  # = this batch's: the replay that follows
         for p in self.bucket.params:
             p.grad = None
+        # capture_error_mode thread_local: with a process group alive, RCCL's watchdog thread polls the events of earlier
+        # collectives (hipEventQuery); under the default GLOBAL mode that call is illegal while ANY thread captures and takes the
+        # process down (seen as an abort in destroy_process_group after a full test session)
+        mode = dict(capture_error_mode="thread_local")
         g = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(g):
+        with torch.cuda.graph(g, **mode):
             if self.geometry_in_graph:
                 tf_util.multi_copy_(model.geometry_tensors(sg), model.geometry_tensors(self._static_geo_next))
                 # fork: the NEXT batch's FPS / ball query / three_nn / scatter plans as a branch of this graph.  Forked at
@@ -348,12 +352,12 @@ class Trainer:
         self._graph_adam, self._graph_late = None, None
         if split and self.overlap_collective:
             gl = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(gl, pool=g.pool()):
+            with torch.cuda.graph(gl, pool=g.pool(), **mode):
                 flat_g = self._backward_late()
             self._graph_late = gl
         if split:
             ga = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(ga):
+            with torch.cuda.graph(ga, **mode):
                 self._adam(flat_g)
             self._graph_adam = ga
         self._graph, self._graph_decay, self._static, self._static_geo = g, decay, st + [loss], sg
