@@ -21,7 +21,9 @@ class CapturedForward:
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
         self.graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self.graph), torch.no_grad():
+        # thread-local error mode: with a process group alive (bench.py --gpus N) RCCL's watchdog thread may poll events while
+        # this thread captures; in the default global mode that is an error for the whole process
+        with torch.cuda.graph(self.graph, capture_error_mode="thread_local"), torch.no_grad():
             self.static_outputs = fn(*self.static_inputs)
 
     def __call__(self, *inputs):
