@@ -64,12 +64,32 @@ def s_scene(seed, b, n):
     return np.concatenate([xy, z, rgb], axis=2).astype(np.float32)
 
 
+def s_randn(seed, b, n):
+    """S-randn: the reference benchmark's own input (benchmark.py:16-18: np.random.randn(batch, num_point, 6))"""
+    return np.random.RandomState(seed).randn(b, n, 6).astype(np.float32)
+
+
+def s_dup25(seed, b, n):
+    """S-dup25: S-scene with a quarter of its rows duplicates of other rows (xyz and colour), shuffled -- how the reference
+    fills a cloud shorter than num_points_per_sample (dataset/semantic_dataset.py:101-106: np.random.choice of its own rows)"""
+    rs = np.random.RandomState(seed + 7919)
+    x = s_scene(seed, b, n)
+    nd = n // 4
+    for i in range(b):
+        x[i, n - nd:] = x[i, rs.randint(0, n - nd, nd)]
+        x[i] = x[i][rs.permutation(n)]
+    return x
+
+
+FPS_KERNELS = ("farthest_point_sample", "fps_gather", "fps_nested")
+
+
 # ---- algorithmic work per launch (SURVEY.md section 8d: compulsory traffic) -----------------
 def kernel_model(name, a):
     """-> (bound, units) with units = algorithmic bytes (hbm) or flops (mfma) of ONE launch."""
-    if name in ("pn2_farthest_point_sample", "pn2_fps_gather"):
+    if name in ("pn2_farthest_point_sample", "pn2_fps_gather", "pn2_fps_nested"):
         b, n, m = a[0], a[1], a[2]
-        return "hbm", b * n * 12 + b * m * 4 + (b * m * 12 if name == "pn2_fps_gather" else 0)
+        return "hbm", b * n * 12 + b * m * 4 + (b * m * 12 if name != "pn2_farthest_point_sample" else 0)
     if name == "pn2_gather_point":
         b, n, m = a[:3]
         return "hbm", b * m * 4 + b * m * 12 * 2
@@ -559,6 +579,7 @@ def main():
     ap.add_argument("--train", action="store_true",
                     help="BASELINE configs[3] instead of the headline: data-parallel TRAINING steps (forward with batch-stat "
                          "BN + weighted CE + backward + one flat RCCL gradient all-reduce + Adam), 16 scenes per GPU")
+    ap.add_argument("--no-other-inputs", action="store_true", help="skip the S-randn / S-dup25 legs of the line")
     args = ap.parse_args()
 
     if args.gpus < 1:
@@ -626,12 +647,12 @@ def main():
         if args.wide.isdigit():
             pn2.util.pointnet_util.WIDE_MIN_ROWS = int(args.wide)
 
-    def step():
+    def eager_on(x):
         with torch.no_grad():
-            out, _ = pn2.model.get_sa_fp_features(pc, False, hp)
+            out, _ = pn2.model.get_sa_fp_features(x, False, hp)
         return out
 
-    eager_step = step
+    step = eager_step = lambda: eager_on(pc)  # noqa: E731
     if not args.eager:
         # one hipGraph per forward: replay removes the ~40 Python-side launches from the step.
         # --pipeline P: P independent batches in flight (P graphs with their own buffers, replayed
@@ -695,7 +716,7 @@ def main():
         total_points = world * B * N * args.steps
         ms_per_step = elapsed / args.steps * 1e3
         P_eff = 1 if args.eager else max(1, args.pipeline)
-        is_fps = lambda k: k["kernel"] in ("farthest_point_sample", "fps_gather")  # noqa: E731
+        is_fps = lambda k: k["kernel"] in FPS_KERNELS  # noqa: E731
         dense = [k for k in kernels if not is_fps(k)]
         fps = [k for k in kernels if is_fps(k)]
         sum_all = sum(k["ms_per_step"] for k in kernels)
@@ -770,6 +791,50 @@ def main():
                 "hbm_frac": f0["frac"],
                 "note": "a round is a dependent chain (LDS read -> distance -> max tree -> 6 DPP steps -> LDS atomic -> "
                         "barrier -> read) of ~250-330 ns whatever the block shape (profiles/r02_fps_experiments.txt)"}
+        if world == 1 and not args.eager and not args.no_other_inputs:
+            # the data-dependent kernels (lazy FPS pruning, the grid ball query's >64-hit path, three_nn's
+            # overflow rescan) on the reference benchmark's own input and on a duplicate-heavy cloud: SAME graphs (the
+            # static input buffers are overwritten), same K, both regimes, per-kernel times from an eager pass
+            res["other_inputs"] = {}
+            base = {(k["kernel"], tuple(k["args"])): k["avg_us"] for k in kernels}
+            for nm, gen in (("S-randn", s_randn), ("S-dup25", s_dup25)):
+                arrs = [torch.from_numpy(gen(3000 + 10 * rank + i, B, N)).to(dev) for i in range(P_eff)]
+                for c_, a_ in zip(caps, arrs):
+                    c_.static_inputs[0].copy_(a_)
+                for _ in range(args.warmup):
+                    step()
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                for _ in range(args.steps):
+                    step()
+                torch.cuda.synchronize()
+                thr = (time.perf_counter() - t0) / args.steps * 1e3
+                t0 = time.perf_counter()
+                for _ in range(args.steps):
+                    caps[0].replay()
+                    torch.cuda.synchronize()
+                lat = (time.perf_counter() - t0) / args.steps * 1e3
+                pn2._lib.lib.trace = []
+                for _ in range(trace_steps):
+                    eager_on(arrs[0])
+                torch.cuda.synchronize()
+                tr, pn2._lib.lib.trace = pn2._lib.lib.trace, None
+                ks = summarize_trace(tr, trace_steps)
+                pick = lambda names: [{"args": k["args"], "avg_us": k["avg_us"]} for k in ks if k["kernel"] in names]  # noqa: E731
+                slow = [{"kernel": k["kernel"], "args": k["args"], "avg_us": k["avg_us"],
+                         "S-scene_avg_us": base[(k["kernel"], tuple(k["args"]))],
+                         "ratio": round(k["avg_us"] / base[(k["kernel"], tuple(k["args"]))], 2)}
+                        for k in ks if (k["kernel"], tuple(k["args"])) in base
+                        and k["avg_us"] > 1.5 * base[(k["kernel"], tuple(k["args"]))] and k["avg_us"] > 5.0]
+                res["other_inputs"][nm] = {
+                    "ms_per_step": round(thr, 4), "points_per_s": round(B * N / (thr * 1e-3), 1),
+                    "single_batch_latency_ms": round(lat, 4),
+                    "fps_us": pick(FPS_KERNELS), "query_ball_point_us": pick(("query_ball_point", "query_ball_point_binned")),
+                    "three_nn_us": pick(("three_nn",)),
+                    "gpu_ms_per_step_sum_of_kernels": round(sum(k["ms_per_step"] for k in ks), 4),
+                    "slower_than_1.5x_S-scene": slow}
+            for c_, a_ in zip(caps, batches):  # back to S-scene for whatever follows
+                c_.static_inputs[0].copy_(a_)
         if not args.no_north_star:
             try:
                 res["north_star"] = north_star_kernels(pn2, dev)

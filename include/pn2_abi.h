@@ -67,6 +67,20 @@ int pn2_farthest_point_sample(int b, int n, int m, const float *inp, float *temp
 int pn2_fps_gather(int b, int n, int m, const float *inp, float *temp, int *out,
                    float *new_xyz, int arith_mode, void *stream);
 
+/* Nested sampling: the SA levels chain farthest_point_sample on each other's output (util/pointnet_util.py:36-37 called
+ * by model.py:104-113 with l1_xyz, l2_xyz, l3_xyz).  When inp is the new_xyz of an FPS run over a larger cloud, its rows
+ * are that run's picks in pick order and sampling them again retraces the same picks -- idx = 0..m-1 -- unless the parent
+ * run met a TIE (two points holding the maximum distance) before step m: only then can this level's tie-break
+ * (tf_sampling.cu:153-170: lowest k mod 512, then k, in THIS cloud's numbering) choose differently.
+ *   tie_in  (b) int32 or NULL: first tied step of the run that produced inp (0x7fffffff = none).  A cloud with
+ *           tie_in[i] >= m gets idx = 0..m-1 and new_xyz = its first m rows, no sampling; any other cloud (and every cloud
+ *           when tie_in is NULL) is sampled exactly as pn2_fps_gather does.  The result is bit-identical either way.
+ *   tie_out (b) int32 or NULL: this level's record, to be passed as the next level's tie_in.  Ties between points of equal
+ *           coordinates do not count until the distance maximum reaches 0 (their twin is then picked too).
+ * new_xyz (b,m,3) may be NULL (indices only).  temp as for pn2_farthest_point_sample. */
+int pn2_fps_nested(int b, int n, int m, const float *inp, float *temp, int *out, float *new_xyz,
+                   const int *tie_in, int *tie_out, int arith_mode, void *stream);
+
 /* probsampleLauncher(b,n,m,inp_p,inp_r,temp,out)  tf_sampling.cu:212-216, tf_sampling.cpp:72.  inp_p (b,n)
  * non-negative weights, inp_r (b,m) uniforms in [0,1) -> out (b,m) int32: the index at which the running sum of
  * the weights reaches inp_r * total (the reference's exact fp32 summation order and branch-free binary search).

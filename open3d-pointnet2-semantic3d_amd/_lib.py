@@ -20,6 +20,7 @@ c_int, c_float, c_void_p = ctypes.c_int, ctypes.c_float, ctypes.c_void_p
 SIGNATURES = {
     "pn2_farthest_point_sample": [c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_int, c_void_p],
     "pn2_fps_gather": [c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p],
+    "pn2_fps_nested": [c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p],
     "pn2_prob_sample": [c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p],
     "pn2_fps_large": [c_int, c_int, c_int, c_void_p, c_void_p, ctypes.c_size_t, c_void_p, c_void_p, c_int, c_void_p],
     "pn2_gather_point": [c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p],

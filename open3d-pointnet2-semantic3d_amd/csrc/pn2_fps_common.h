@@ -25,6 +25,21 @@ __device__ __forceinline__ int wave_imax_from(int src) {
         : "=&v"(v) : "v"(src));
     return __builtin_amdgcn_readlane(v, 63);
 }
+// wave64 max of an unsigned key by fused DPP (uniform result); the tie paths use it, so clouds with many duplicated rows
+// (every pick of a row that has a twin is a tie) pay 6 VALU instead of 6 cross-lane shuffles per tied pick
+__device__ __forceinline__ unsigned wave_umax_dpp(unsigned src) {
+    unsigned v;
+    asm volatile(
+        "s_nop 1\n"
+        "v_max_u32_dpp %0, %1, %1 row_shr:1 row_mask:0xf bank_mask:0xf\n s_nop 1\n"
+        "v_max_u32_dpp %0, %0, %0 row_shr:2 row_mask:0xf bank_mask:0xf\n s_nop 1\n"
+        "v_max_u32_dpp %0, %0, %0 row_shr:4 row_mask:0xf bank_mask:0xf\n s_nop 1\n"
+        "v_max_u32_dpp %0, %0, %0 row_shr:8 row_mask:0xf bank_mask:0xf\n s_nop 1\n"
+        "v_max_u32_dpp %0, %0, %0 row_bcast:15 row_mask:0xa bank_mask:0xf\n s_nop 1\n"
+        "v_max_u32_dpp %0, %0, %0 row_bcast:31 row_mask:0xc bank_mask:0xf\n"
+        : "=&v"(v) : "v"(src));
+    return (unsigned)__builtin_amdgcn_readlane((int)v, 63);
+}
 __device__ __forceinline__ unsigned wave_umax_all(unsigned v) {
 #pragma unroll
     for (int o = 32; o >= 1; o >>= 1) { const unsigned t = (unsigned)__shfl_xor((int)v, o); v = t > v ? t : v; }
@@ -42,12 +57,30 @@ constexpr int kLazyCap = 64;  // candidates per phase = lanes of the picking wav
 // first pick (>= every td in the cloud when it was picked), d_last = td of the last one.
 struct NoPost { __device__ __forceinline__ void operator()(int, int, float, float, float, int) const {} };
 
+// Tie bookkeeping of the nested-sampling shortcut (pn2_fps_nested, pn2_sampling.hip).  A pick is TIED when more than one
+// point of the cloud holds the maximum td at that step.  `strict` = first step with a tie between points of different
+// coordinates, or with td == 0 (every remaining point is a duplicate of a picked one); `benign` = first step whose tied
+// points all coincide with the winner (their td drops to 0 with the pick: they are picked only once td == 0 everywhere).
+// Steps are pick numbers (pick 0 = index 0 is never a choice); kNoTie = no such step.
+constexpr int kNoTie = 0x7fffffff;
+// The record lives in three LDS words {strict, benign, zero} written from the rare tie branches only (a register copy
+// would ride through the pick loop as loop-carried values: +10 scalar moves on a ~50 instruction dependent chain).
+__device__ __forceinline__ void tie_init(int* t) { t[0] = kNoTie; t[1] = kNoTie; t[2] = 0; }
+__device__ __forceinline__ void tie_note(int* t, int step, bool is_strict, bool is_zero) {  // ONE lane calls this
+    atomicMin(&t[is_strict ? 0 : 1], step);
+    if (is_zero) t[2] = 1;  // the maximum td reached 0 (always a strict step): from there on coincident twins are picked too
+}
+// first step at which FPS restricted to this run's picks could leave the identity: the first strict tie -- or the first
+// benign one when the run went on until td == 0, because only then the coincident twin is among the picks
+__device__ __forceinline__ int tie_first(const int* t) { return t[2] != 0 && t[1] < t[0] ? t[1] : t[0]; }
+
 // on_pick(npick, pk_k, pk_x, pk_y, pk_z, g_first) is called after every pick with the parked registers (the streaming
 // kernel posts the picks to the worker waves in batches from it).
-template <int MODE, class OnPick = NoPost>
+// TRACK: record tied picks in the LDS words tt[3] (steps counted from jbase; lane = lane id); all of it lives in the rare tie branch.
+template <int MODE, class OnPick = NoPost, bool TRACK = false>
 __device__ __forceinline__ int pick_phase(int chi, unsigned clo, float cx, float cy, float cz, int lim, int maxp,
                                           int& pk_k, float& pk_x, float& pk_y, float& pk_z, int& g_first, int& d_last,
-                                          OnPick on_pick = OnPick()) {
+                                          OnPick on_pick = OnPick(), int* tt = nullptr, int jbase = 0, int lane = 0) {
     int npick = 0;
     g_first = -1; d_last = 0;
     pk_k = 0; pk_x = pk_y = pk_z = 0.f;
@@ -57,7 +90,17 @@ __device__ __forceinline__ int pick_phase(int chi, unsigned clo, float cx, float
         if (bh < lim) break;
         unsigned long long bal = __builtin_amdgcn_ballot_w64(chi == bh);
         if (__builtin_expect(__popcll(bal) != 1, 0)) {
-            const unsigned lm = wave_umax_all(chi == bh ? clo : 0u);
+            if constexpr (TRACK) {
+                // do the holders of the maximum all coincide?  (compared with the FIRST holder, not the winner: the hot path
+                // below must not share a value with this branch, or the compiler threads the branch through it)
+                const int Lr = __builtin_ctzll(bal);
+                const float rx = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(cx), Lr));
+                const float ry = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(cy), Lr));
+                const float rz = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(cz), Lr));
+                const unsigned long long other = __builtin_amdgcn_ballot_w64(chi == bh && (cx != rx || cy != ry || cz != rz));
+                if (lane == 0) tie_note(tt, jbase + npick, bh == 0 || other != 0ull, bh == 0);
+            }
+            const unsigned lm = wave_umax_dpp(chi == bh ? clo : 0u);
             bal = __builtin_amdgcn_ballot_w64(chi == bh && clo == lm);
         }
         const int L = __builtin_ctzll(bal);

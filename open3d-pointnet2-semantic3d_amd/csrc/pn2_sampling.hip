@@ -26,6 +26,7 @@ using pn2fps::wave_imax_from;
 using pn2fps::wave_umax_all;
 
 constexpr int kFpsSlotsMax = 16;  // waves per workgroup <= 16
+constexpr int kFpsRegHead = 48;   // fps_reg_kernel: bytes of LDS in front of the cloud copy (key slots + tie record)
 
 __device__ __forceinline__ unsigned fps_tiekey(int k) {
     return (((unsigned)k & 511u) << 22) | ((unsigned)k >> 9);
@@ -127,6 +128,26 @@ __device__ __forceinline__ double fps_dmax(double a, double b) {
     return r;
 }
 
+// Nested sampling (pn2_fps_nested).  When `inp` is itself the (b,n,3) output of an FPS + gather of a larger cloud, its
+// rows are that run's picks in pick order, and FPS restricted to those rows retraces them: at step j the row j holds
+// the maximum td over the WHOLE parent cloud, hence over the subset, with bit-identical td values (same operands, same
+// expression) -- the pick is j itself unless another row TIES with it (then this level's tie-break by (j mod 512, j)
+// may differ from the parent's).  The parent run reports per cloud the first step at which its maximum was not unique
+// (pn2fps::TieTrack); a level asked for m <= that step is the identity: idx = 0..m-1, new_xyz = the first m rows.  The
+// answer is exact, not approximate: tests/test_ref_gpu.py holds it against the reference's kernel on tie-free and
+// tie-heavy clouds.  Returns true when the workgroup took the shortcut (uniform per workgroup).
+__device__ __forceinline__ bool fps_nested_shortcut(int n, int m, const float* __restrict__ xyz, int* __restrict__ out,
+                                                    float* __restrict__ nxyz, const int* __restrict__ tie_in,
+                                                    int* __restrict__ tie_out, int nthreads) {
+    if (tie_in == nullptr) return false;
+    const int T = __builtin_amdgcn_readfirstlane(tie_in[blockIdx.x]);
+    if (T < m || m > n) return false;
+    for (int jj = threadIdx.x; jj < m; jj += nthreads) out[jj] = jj;
+    if (nxyz) for (int e = threadIdx.x; e < m * 3; e += nthreads) nxyz[e] = xyz[e];
+    if (tie_out && threadIdx.x == 0) tie_out[blockIdx.x] = T;  // the prefix of a prefix: the same bound holds below
+    return true;
+}
+
 // NT threads, thread t owns points k = t + NT*i (i < PPT) in VGPRs for the whole kernel: coordinates and ONE 64-bit
 // register pair per point,
 //          (td bits : ~tiekey(k))        td = running min distance (>= +0: int order == float order),
@@ -140,18 +161,20 @@ __device__ __forceinline__ double fps_dmax(double a, double b) {
 //   3. one barrier, one broadcast read of the winning pair, one broadcast read of the winner's xyz.
 // Three key slots rotate so the reset of a slot never races with its readers.  A single-wave block (NT == 64)
 // needs neither LDS atomics nor barriers: ballot + v_readlane.
-template <int NT, int PPT, int MODE, bool LDS_XYZ>
+// TRACK: also write the run's tie record (pn2fps::tie_*) for the level below.
+template <int NT, int PPT, int MODE, bool LDS_XYZ, bool TRACK>
 __global__ void __launch_bounds__(NT)
 fps_reg_kernel(int n, int m, const float* __restrict__ xyz_all, int* __restrict__ out_all,
-               float* __restrict__ new_xyz_all) {
+               float* __restrict__ new_xyz_all, const int* __restrict__ tie_in, int* __restrict__ tie_out) {
     static_assert(NT != 64 || LDS_XYZ, "single-wave path keeps the cloud in LDS");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    // layout: 4 x u64 key slots (3 used) | float4 xyz[n] (if LDS_XYZ) | int picks[m] (if LDS_XYZ)
+    // layout: 4 x u64 key slots (3 used), 4 x i32 tie record (3 used) | float4 xyz[n] (if LDS_XYZ) | int picks[m] (if LDS_XYZ)
     // The picks are kept in LDS and written to HBM once, coalesced, after the last round (together
     // with their coordinates when the fused gather is requested): no global store sits on the
     // round-to-round critical path of wave 0.
     unsigned long long* slots = reinterpret_cast<unsigned long long*>(smem);
-    float4* sxyz = reinterpret_cast<float4*>(smem + 4 * sizeof(unsigned long long));
+    int* ttl = reinterpret_cast<int*>(smem + 4 * sizeof(unsigned long long));  // pn2fps::tie_* (TRACK only)
+    float4* sxyz = reinterpret_cast<float4*>(smem + kFpsRegHead);
     int* spick = reinterpret_cast<int*>(sxyz + (LDS_XYZ ? n : 0));
 
     const int tid = threadIdx.x;
@@ -160,6 +183,11 @@ fps_reg_kernel(int n, int m, const float* __restrict__ xyz_all, int* __restrict_
     // optional fused gather_point (tf_sampling.cu:178-191): the coordinates of every pick pass through
     // this kernel anyway, so new_xyz[j] = xyz[out[j]] costs three extra stores per round
     float* __restrict__ nxyz = new_xyz_all ? new_xyz_all + (size_t)blockIdx.x * m * 3 : nullptr;
+    if (fps_nested_shortcut(n, m, xyz, out, nxyz, tie_in, tie_out, NT)) return;
+    // TRACK: a second holder of the previous round's maximum is looked for at the top of the next round, when the winner's
+    // coordinates are at hand anyway
+    int pw_hi = -2;               // the previous winner's td bits (-2: none yet, never a point's high word)
+    unsigned pw_lo = 0u;
 
     float px[PPT], py[PPT], pz[PPT];
     double mk[PPT];
@@ -180,6 +208,7 @@ fps_reg_kernel(int n, int m, const float* __restrict__ xyz_all, int* __restrict_
         mk[i] = __hiloint2double(hi, (int)~fps_tiekey(k));
     }
     if (tid < 4) slots[tid] = 0ull;
+    if (TRACK && tid == 0) pn2fps::tie_init(ttl);
     if (tid == 0) {  // first pick is index 0 (tf_sampling.cu:122-123)
         if constexpr (LDS_XYZ) spick[0] = 0; else out[0] = 0;
     }
@@ -195,6 +224,25 @@ fps_reg_kernel(int n, int m, const float* __restrict__ xyz_all, int* __restrict_
         } else {
             x1 = xyz[old * 3 + 0]; y1 = xyz[old * 3 + 1]; z1 = xyz[old * 3 + 2];
             if (nxyz && tid == 0) { nxyz[(j - 1) * 3 + 0] = x1; nxyz[(j - 1) * 3 + 1] = y1; nxyz[(j - 1) * 3 + 2] = z1; }
+        }
+        if constexpr (TRACK) {
+            // mk still holds the td the previous maximum was taken over: exactly ONE point of the cloud -- the winner, owned
+            // by lane (old % NT) -- may carry its value.  Branch-free count per wave: OR and XOR of the per-row ballots differ
+            // when one lane holds it twice, the population of the OR counts the lanes.
+            unsigned long long m_or = 0ull, m_xor = 0ull;
+#pragma unroll
+            for (int i = 0; i < PPT; ++i) {
+                const unsigned long long hb = __builtin_amdgcn_ballot_w64(__double2hiint(mk[i]) == pw_hi);
+                m_or |= hb; m_xor ^= hb;
+            }
+            const int expect = (((old & (NT - 1)) >> 6) == (tid >> 6)) ? 1 : 0;
+            if (__builtin_expect(m_or != m_xor || __popcll(m_or) != expect, 0)) {
+#pragma unroll
+                for (int i = 0; i < PPT; ++i) {
+                    if (__double2hiint(mk[i]) == pw_hi && (unsigned)__double2loint(mk[i]) != pw_lo)
+                        pn2fps::tie_note(ttl, j - 1, pw_hi == 0 || px[i] != x1 || py[i] != y1 || pz[i] != z1, pw_hi == 0);
+                }
+            }
         }
 #pragma unroll
         for (int i = 0; i < PPT; ++i) {
@@ -222,6 +270,7 @@ fps_reg_kernel(int n, int m, const float* __restrict__ xyz_all, int* __restrict_
             else wl = ~wave_umin_all(best == wmax ? ~lo : 0xFFFFFFFFu);
             old = fps_untiekey(~wl);
             if (tid == 0) spick[j] = old;
+            if constexpr (TRACK) { pw_hi = wmax; pw_lo = wl; }
             continue;
         }
         if (best == wmax && wmax >= 0) {  // normally a single lane of the wave
@@ -234,6 +283,7 @@ fps_reg_kernel(int n, int m, const float* __restrict__ xyz_all, int* __restrict_
         __syncthreads();
         const unsigned long long win = slots[slot];
         old = fps_untiekey(~(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)win));
+        if constexpr (TRACK) { pw_hi = (int)(unsigned)(win >> 32); pw_lo = (unsigned)win; }
         const int nxt = slot == 2 ? 0 : slot + 1;          // (j+1) % 3
         if (tid == 0) {
             slots[nxt == 2 ? 0 : nxt + 1] = 0ull;          // (j+2) % 3: last read after barrier j-1, next used in round j+2
@@ -253,6 +303,10 @@ fps_reg_kernel(int n, int m, const float* __restrict__ xyz_all, int* __restrict_
         }
     } else if (nxyz && tid == 0) {  // coordinates of the last pick
         nxyz[(m - 1) * 3 + 0] = xyz[old * 3 + 0]; nxyz[(m - 1) * 3 + 1] = xyz[old * 3 + 1]; nxyz[(m - 1) * 3 + 2] = xyz[old * 3 + 2];
+    }
+    if constexpr (TRACK) {  // (ties of the LAST pick are not looked at: a consumer asks for fewer picks than this level made)
+        __syncthreads();
+        if (tid == 0 && tie_out) tie_out[blockIdx.x] = pn2fps::tie_first(ttl);
     }
 }
 
@@ -443,10 +497,11 @@ __device__ __forceinline__ void fps_lazy_setup(int n, int wi, const float* __res
     __syncthreads();  // perm is dead from here
 }
 
-template <int NT, int PPT, int MODE>
+template <int NT, int PPT, int MODE, bool TRACK>
 __global__ void __launch_bounds__(NT)
 fps_lazy_kernel(int n, int m, const float* __restrict__ xyz_all, int* __restrict__ out_all,
-                float* __restrict__ new_xyz_all, long long* __restrict__ stats) {
+                float* __restrict__ new_xyz_all, long long* __restrict__ stats, const int* __restrict__ tie_in,
+                int* __restrict__ tie_out) {
     constexpr int NW = NT / 64;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     // layout: int ctrl[16] | u64 wcand[16] | u64 cand[64] | float4 pend[64] | float bbw[16][6], int wsum[16] |
@@ -465,6 +520,10 @@ fps_lazy_kernel(int n, int m, const float* __restrict__ xyz_all, int* __restrict
     const float* __restrict__ xyz = xyz_all + (size_t)blockIdx.x * n * 3;
     int* __restrict__ out = out_all + (size_t)blockIdx.x * m;
     float* __restrict__ nxyz = new_xyz_all ? new_xyz_all + (size_t)blockIdx.x * m * 3 : nullptr;
+    if (fps_nested_shortcut(n, m, xyz, out, nxyz, tie_in, tie_out, NT)) return;
+    constexpr bool track = TRACK;
+    int* ttl = ctrl + 8;                          // pn2fps::tie_* record {strict, benign, zero}, written by wave 0
+    int* wtie = reinterpret_cast<int*>(bbw);      // per-wave tie class of the one-pick fallback (bbw is dead after the set-up)
 
     float px[PPT], py[PPT], pz[PPT];
     double mk[PPT];
@@ -475,6 +534,7 @@ fps_lazy_kernel(int n, int m, const float* __restrict__ xyz_all, int* __restrict
         spick[0] = 0;  // first pick is index 0 (tf_sampling.cu:122-123)
         pend[0] = sxyz[0];
         ctrl[0] = 0; ctrl[1] = 0;
+        pn2fps::tie_init(ttl);
         *reinterpret_cast<int4*>(ctrl + 4) = make_int4(1, 1, __float_as_int(1e38f), __float_as_int(1e38f));
     }
     __syncthreads();
@@ -566,6 +626,24 @@ fps_lazy_kernel(int n, int m, const float* __restrict__ xyz_all, int* __restrict
             if (__popcll(bal) == 1) wl = (unsigned)__builtin_amdgcn_readlane((int)bl, __ffsll((long long)bal) - 1);
             else wl = wave_umax_all(best == wh ? bl : 0u);  // equal td across lanes: lowest tie key = largest low word
             if (lane == 0) wcand[wave] = ((unsigned long long)(unsigned)wh << 32) | wl;
+            if (track) {
+                // ties INSIDE the wave are invisible in its published maximum: class 0 = my maximum is unique in my rows,
+                // 1 = shared only by points coinciding with my winner, 2 = shared by a point elsewhere
+                int cls = 0;
+                if (wh >= 0) {
+                    const float4 wq = sxyz[fps_untiekey(~wl)];
+                    int ct = 0;
+                    unsigned long long oth = 0ull;
+#pragma unroll
+                    for (int i = 0; i < PPT; ++i) {
+                        const bool t = __double2hiint(mk[i]) == wh;
+                        ct += __popcll(__builtin_amdgcn_ballot_w64(t));
+                        oth |= __builtin_amdgcn_ballot_w64(t && (px[i] != wq.x || py[i] != wq.y || pz[i] != wq.z));
+                    }
+                    cls = oth != 0ull ? 2 : (ct > 1 ? 1 : 0);
+                }
+                if (lane == 0) wtie[wave] = cls;
+            }
             __syncthreads();
         }
         // ---- phase B: wave 0 picks from the list
@@ -585,7 +663,13 @@ fps_lazy_kernel(int n, int m, const float* __restrict__ xyz_all, int* __restrict
             int pk_k, g_first, d_last;
             float pk_x, pk_y, pk_z;
             const int lim = limit < 0 ? 0 : limit;  // valid td are >= 0; lanes without a candidate are negative
-            const int npick = pn2fps::pick_phase<MODE>(chi, clo, cq.x, cq.y, cq.z, lim, maxp, pk_k, pk_x, pk_y, pk_z, g_first, d_last);
+            const int npick = pn2fps::pick_phase<MODE, pn2fps::NoPost, TRACK>(chi, clo, cq.x, cq.y, cq.z, lim, maxp, pk_k, pk_x, pk_y, pk_z,
+                                                                               g_first, d_last, pn2fps::NoPost(), ttl, jdone, lane);
+            if (track && !use_list && npick == 1) {  // the waves holding the maximum: their own in-wave tie classes
+                const int cls = (lane < NW && chi == g_first) ? wtie[lane] : 0;
+                const unsigned long long c2 = __builtin_amdgcn_ballot_w64(cls == 2), c1 = __builtin_amdgcn_ballot_w64(cls == 1);
+                if ((c1 | c2) != 0ull && lane == 0) pn2fps::tie_note(ttl, jdone, g_first == 0 || c2 != 0ull, g_first == 0);
+            }
             if (lane < npick) {
                 spick[jdone + lane] = pk_k;
                 pend[lane] = make_float4(pk_x, pk_y, pk_z, 0.f);
@@ -610,6 +694,7 @@ fps_lazy_kernel(int n, int m, const float* __restrict__ xyz_all, int* __restrict
         stats[6] = st_b; stats[7] = st_w2; stats[8] = (long long)__builtin_readcyclecounter() - st_t00; stats[9] = st_pairs;
     }
     if (do_stats && blockIdx.x == 0 && lane == 0) { stats[16 + wave] = st_a; stats[32 + wave] = st_pairs; stats[48 + wave] = st_upd; }
+    if (track && tid == 0 && tie_out) tie_out[blockIdx.x] = pn2fps::tie_first(ttl);
     for (int jj = tid; jj < m; jj += NT) {
         const int k = spick[jj];
         out[jj] = k;
@@ -621,16 +706,16 @@ fps_lazy_kernel(int n, int m, const float* __restrict__ xyz_all, int* __restrict
 }
 
 template <int NT, int PPT, int MODE>
-int launch_fps_lazy(int b, int n, int m, const float* inp, int* out, float* nxyz, hipStream_t st) {
+int launch_fps_lazy(int b, int n, int m, const float* inp, int* out, float* nxyz, const int* tie_in, int* tie_out, hipStream_t st) {
     const size_t bytes = fps_lazy_bytes(n, m);
-    auto kern = fps_lazy_kernel<NT, PPT, MODE>;
-    static bool attr_set = false;  // per instantiation; benign race (idempotent call)
-    if (!attr_set) {
+    auto kern = tie_out ? fps_lazy_kernel<NT, PPT, MODE, true> : fps_lazy_kernel<NT, PPT, MODE, false>;
+    static bool attr_set[2] = {false, false};  // per instantiation; benign race (idempotent call)
+    if (!attr_set[tie_out != nullptr]) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (e != hipSuccess) return (int)e;
-        attr_set = true;
+        attr_set[tie_out != nullptr] = true;
     }
-    kern<<<b, NT, bytes, st>>>(n, m, inp, out, nxyz, g_fps_stats);
+    kern<<<b, NT, bytes, st>>>(n, m, inp, out, nxyz, g_fps_stats, tie_in, tie_out);
     PN2_RETURN_IF_LAUNCH_FAILED();
     return PN2_OK;
 }
@@ -678,23 +763,24 @@ fps_stream_kernel(int b, int n, int m, const float* __restrict__ xyz_all,
 }
 
 template <int NT, int PPT, int MODE>
-int launch_fps_reg(int b, int n, int m, const float* inp, int* out, float* nxyz, hipStream_t st) {
-    const size_t slots_bytes = 4 * sizeof(unsigned long long);
+int launch_fps_reg(int b, int n, int m, const float* inp, int* out, float* nxyz, const int* tie_in, int* tie_out, hipStream_t st) {
+    const size_t slots_bytes = kFpsRegHead;
     const size_t xyz_bytes = (size_t)n * sizeof(float4);
     // 160 KiB LDS per CU; keep the cloud (and the pick list) in LDS when they fit (n <= 8192 -> 128 KiB + 4m)
     const size_t pick_bytes = (size_t)m * sizeof(int);
     if (slots_bytes + xyz_bytes + pick_bytes <= 158 * 1024) {
-        auto kern = fps_reg_kernel<NT, PPT, MODE, true>;
-        static int attr_bytes = 0;  // per instantiation; benign race (idempotent call)
-        if (attr_bytes < (int)(slots_bytes + xyz_bytes + pick_bytes)) {
+        auto kern = tie_out ? fps_reg_kernel<NT, PPT, MODE, true, true> : fps_reg_kernel<NT, PPT, MODE, true, false>;
+        static int attr_bytes[2] = {0, 0};  // per instantiation; benign race (idempotent call)
+        if (attr_bytes[tie_out != nullptr] < (int)(slots_bytes + xyz_bytes + pick_bytes)) {
             hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
             if (e != hipSuccess) return (int)e;
-            attr_bytes = 160 * 1024;
+            attr_bytes[tie_out != nullptr] = 160 * 1024;
         }
-        kern<<<b, NT, slots_bytes + xyz_bytes + pick_bytes, st>>>(n, m, inp, out, nxyz);
+        kern<<<b, NT, slots_bytes + xyz_bytes + pick_bytes, st>>>(n, m, inp, out, nxyz, tie_in, tie_out);
     } else if constexpr (NT != 64) {
-        fps_reg_kernel<NT, PPT, MODE, false><<<b, NT, slots_bytes, st>>>(n, m, inp, out, nxyz);
+        auto kern = tie_out ? fps_reg_kernel<NT, PPT, MODE, false, true> : fps_reg_kernel<NT, PPT, MODE, false, false>;
+        kern<<<b, NT, slots_bytes, st>>>(n, m, inp, out, nxyz, tie_in, tie_out);
     } else {
         return PN2_ERANGE;  // unreachable: a single-wave cloud (n <= 256) always fits LDS unless m is absurd
     }
@@ -703,7 +789,8 @@ int launch_fps_reg(int b, int n, int m, const float* inp, int* out, float* nxyz,
 }
 
 template <int MODE>
-int dispatch_fps(int b, int n, int m, const float* inp, float* temp, int* out, float* nxyz, hipStream_t st) {
+int dispatch_fps(int b, int n, int m, const float* inp, float* temp, int* out, float* nxyz, const int* tie_in, int* tie_out,
+                 hipStream_t st) {
     // Any (threads, points per thread) layout is exact (every point carries its own tie-break key); the choice is
     // latency only.  A round's sync skeleton costs ~40 ns for one wave (no barrier, no LDS atomic), ~130 ns for 4
     // waves and ~180 ns for 16 (tools/round_ubench.hip), a lone wave issues ~0.45 instructions/ns, 4 waves per SIMD ~1/ns.
@@ -714,31 +801,35 @@ int dispatch_fps(int b, int n, int m, const float* inp, float* temp, int* out, f
     // round of the one-pick kernels below costs (93 vs 84 us at n = 1024), so those keep the small levels.
     // g_fps_variant (tuning builds): 2 = one-pick kernels everywhere, 3 = lazy kernel from n > 512.
     if (g_fps_variant != 2 && n > (g_fps_variant == 3 ? 512 : 2048) && n <= 8192 && fps_lazy_bytes(n, m) <= 160 * 1024) {
-        if (n <= 1024) return launch_fps_lazy<256, 4, MODE>(b, n, m, inp, out, nxyz, st);
-        if (n <= 2048) return launch_fps_lazy<512, 4, MODE>(b, n, m, inp, out, nxyz, st);
-        if (n <= 4096) return launch_fps_lazy<1024, 4, MODE>(b, n, m, inp, out, nxyz, st);
-        return launch_fps_lazy<1024, 8, MODE>(b, n, m, inp, out, nxyz, st);
+        if (n <= 1024) return launch_fps_lazy<256, 4, MODE>(b, n, m, inp, out, nxyz, tie_in, tie_out, st);
+        if (n <= 2048) return launch_fps_lazy<512, 4, MODE>(b, n, m, inp, out, nxyz, tie_in, tie_out, st);
+        if (n <= 4096) return launch_fps_lazy<1024, 4, MODE>(b, n, m, inp, out, nxyz, tie_in, tie_out, st);
+        return launch_fps_lazy<1024, 8, MODE>(b, n, m, inp, out, nxyz, tie_in, tie_out, st);
     }
     if (g_fps_variant == 1) {  // A/B hook: one point per thread up to 1024 threads (the round-1 layout)
-        if (n <= 64) return launch_fps_reg<64, 1, MODE>(b, n, m, inp, out, nxyz, st);
-        if (n <= 128) return launch_fps_reg<128, 1, MODE>(b, n, m, inp, out, nxyz, st);
-        if (n <= 256) return launch_fps_reg<256, 1, MODE>(b, n, m, inp, out, nxyz, st);
-        if (n <= 512) return launch_fps_reg<512, 1, MODE>(b, n, m, inp, out, nxyz, st);
-        if (n <= 1024) return launch_fps_reg<1024, 1, MODE>(b, n, m, inp, out, nxyz, st);
+        if (n <= 64) return launch_fps_reg<64, 1, MODE>(b, n, m, inp, out, nxyz, tie_in, tie_out, st);
+        if (n <= 128) return launch_fps_reg<128, 1, MODE>(b, n, m, inp, out, nxyz, tie_in, tie_out, st);
+        if (n <= 256) return launch_fps_reg<256, 1, MODE>(b, n, m, inp, out, nxyz, tie_in, tie_out, st);
+        if (n <= 512) return launch_fps_reg<512, 1, MODE>(b, n, m, inp, out, nxyz, tie_in, tie_out, st);
+        if (n <= 1024) return launch_fps_reg<1024, 1, MODE>(b, n, m, inp, out, nxyz, tie_in, tie_out, st);
     } else {
-        if (n <= 64) return launch_fps_reg<64, 1, MODE>(b, n, m, inp, out, nxyz, st);
-        if (n <= 128) return launch_fps_reg<64, 2, MODE>(b, n, m, inp, out, nxyz, st);
-        if (n <= 256) return launch_fps_reg<64, 4, MODE>(b, n, m, inp, out, nxyz, st);
-        if (n <= 512) return launch_fps_reg<256, 2, MODE>(b, n, m, inp, out, nxyz, st);
-        if (n <= 1024) return launch_fps_reg<512, 2, MODE>(b, n, m, inp, out, nxyz, st);
-        if (n <= 2048) return launch_fps_reg<512, 4, MODE>(b, n, m, inp, out, nxyz, st);
+        if (n <= 64) return launch_fps_reg<64, 1, MODE>(b, n, m, inp, out, nxyz, tie_in, tie_out, st);
+        if (n <= 128) return launch_fps_reg<64, 2, MODE>(b, n, m, inp, out, nxyz, tie_in, tie_out, st);
+        if (n <= 256) return launch_fps_reg<64, 4, MODE>(b, n, m, inp, out, nxyz, tie_in, tie_out, st);
+        if (n <= 512) return launch_fps_reg<256, 2, MODE>(b, n, m, inp, out, nxyz, tie_in, tie_out, st);
+        if (n <= 1024) return launch_fps_reg<512, 2, MODE>(b, n, m, inp, out, nxyz, tie_in, tie_out, st);
+        if (n <= 2048) return launch_fps_reg<512, 4, MODE>(b, n, m, inp, out, nxyz, tie_in, tie_out, st);
     }
-    if (n <= 2048) return launch_fps_reg<1024, 2, MODE>(b, n, m, inp, out, nxyz, st);
-    if (n <= 4096) return launch_fps_reg<1024, 4, MODE>(b, n, m, inp, out, nxyz, st);
-    if (n <= 8192) return launch_fps_reg<1024, 8, MODE>(b, n, m, inp, out, nxyz, st);
-    if (n <= 16384) return launch_fps_reg<1024, 16, MODE>(b, n, m, inp, out, nxyz, st);
+    if (n <= 2048) return launch_fps_reg<1024, 2, MODE>(b, n, m, inp, out, nxyz, tie_in, tie_out, st);
+    if (n <= 4096) return launch_fps_reg<1024, 4, MODE>(b, n, m, inp, out, nxyz, tie_in, tie_out, st);
+    if (n <= 8192) return launch_fps_reg<1024, 8, MODE>(b, n, m, inp, out, nxyz, tie_in, tie_out, st);
+    if (n <= 16384) return launch_fps_reg<1024, 16, MODE>(b, n, m, inp, out, nxyz, tie_in, tie_out, st);
     if (!temp) return PN2_ENULL;
     const int grid = b < 32 ? b : 32;
+    if (tie_out) {  // the streaming kernel keeps no tie record: "tied at step 0" = the next level always samples for real
+        hipError_t e = hipMemsetAsync(tie_out, 0, sizeof(int) * (size_t)b, st);
+        if (e != hipSuccess) return (int)e;
+    }
     fps_stream_kernel<MODE><<<grid, 1024, 0, st>>>(b, n, m, inp, temp, out);
     PN2_RETURN_IF_LAUNCH_FAILED();
     return nxyz ? 1000000 : PN2_OK;  // sentinel: caller still has to run the separate gather
@@ -898,15 +989,15 @@ extern "C" int pn2_debug_set(int what, int value) {
 #endif  // PN2_TUNING_HOOKS
 
 static int fps_entry(int b, int n, int m, const float* inp, float* temp, int* out, float* nxyz,
-                     int arith_mode, void* stream) {
+                     int arith_mode, void* stream, const int* tie_in = nullptr, int* tie_out = nullptr) {
     if (b <= 0 || n <= 0 || m <= 0) return PN2_EINVAL;
     if (!inp || !out) return PN2_ENULL;
     if ((long long)n * 3 > 0x7fffffffLL) return PN2_ERANGE;
     hipStream_t st = static_cast<hipStream_t>(stream);
     switch (arith_mode) {
-        case PN2_ARITH_STRICT: return dispatch_fps<PN2_ARITH_STRICT>(b, n, m, inp, temp, out, nxyz, st);
-        case PN2_ARITH_FMA: return dispatch_fps<PN2_ARITH_FMA>(b, n, m, inp, temp, out, nxyz, st);
-        case PN2_ARITH_FMA_ALT: return dispatch_fps<PN2_ARITH_FMA_ALT>(b, n, m, inp, temp, out, nxyz, st);
+        case PN2_ARITH_STRICT: return dispatch_fps<PN2_ARITH_STRICT>(b, n, m, inp, temp, out, nxyz, tie_in, tie_out, st);
+        case PN2_ARITH_FMA: return dispatch_fps<PN2_ARITH_FMA>(b, n, m, inp, temp, out, nxyz, tie_in, tie_out, st);
+        case PN2_ARITH_FMA_ALT: return dispatch_fps<PN2_ARITH_FMA_ALT>(b, n, m, inp, temp, out, nxyz, tie_in, tie_out, st);
         default: return PN2_EINVAL;
     }
 }
@@ -926,6 +1017,18 @@ extern "C" int pn2_fps_gather(int b, int n, int m, const float* inp, float* temp
                               float* new_xyz, int arith_mode, void* stream) {
     if (!new_xyz) return PN2_ENULL;
     const int rc = fps_entry(b, n, m, inp, temp, out, new_xyz, arith_mode, stream);
+    if (rc == 1000000) return pn2_gather_point(b, n, m, inp, out, new_xyz, stream);
+    return rc;
+}
+
+// Nested farthest point sampling: pn2_farthest_point_sample / pn2_fps_gather (new_xyz may be NULL) with the tie record
+// of the level above.  tie_in (b) int32 or NULL: the first tied step of the run that PRODUCED inp (inp = that run's
+// new_xyz, rows in pick order); a cloud with tie_in[i] >= m gets idx = 0..m-1 and new_xyz = its first m rows without
+// sampling (bit-identical to the sampled result, see fps_nested_shortcut), any other cloud is sampled as always.
+// tie_out (b) int32 or NULL: this level's record for the level below.
+extern "C" int pn2_fps_nested(int b, int n, int m, const float* inp, float* temp, int* out, float* new_xyz,
+                              const int* tie_in, int* tie_out, int arith_mode, void* stream) {
+    const int rc = fps_entry(b, n, m, inp, temp, out, new_xyz, arith_mode, stream, tie_in, tie_out);
     if (rc == 1000000) return pn2_gather_point(b, n, m, inp, out, new_xyz, stream);
     return rc;
 }

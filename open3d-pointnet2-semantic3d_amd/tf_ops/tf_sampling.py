@@ -18,6 +18,44 @@ def _chk_xyz(t, name, op):
         raise TypeError("%s expects float32 %s" % (op, name))
 
 
+# Nested sampling (pn2_fps_nested): the new_xyz an FPS run returns carries that run's tie record as a Python attribute; a
+# later farthest_point_sample ON THAT VERY TENSOR (the SA levels chain exactly so, util/pointnet_util.py:36-37) hands the
+# record to the kernel, which answers idx = 0..m-1 for every cloud whose parent run met no tie before step m -- the
+# sampled answer bit for bit -- and samples the others.  False = always sample (A/B, tests).
+USE_NESTED_FPS = True
+_TIE_ATTR = "_pn2_fps_tie"
+
+
+def tag_fps_output(new_xyz, tie, arith_mode=None):
+    """mark new_xyz (b,m,3) as the gathered picks, in pick order, of the FPS run (arithmetic mode `arith_mode`) whose tie
+    record is `tie` (b,) int32"""
+    if tie is not None:
+        try:
+            setattr(new_xyz, _TIE_ATTR, (tie, new_xyz._version, config.fps_mode(arith_mode)))
+        except (RuntimeError, AttributeError):  # inference-mode tensors keep no version counter: no tag, always sample
+            pass
+    return new_xyz
+
+
+def fps_tie_record(inp, arith_mode=None):
+    """the tie record of the run that produced `inp`, or None (untagged, modified in place since, other batch / device /
+    arithmetic mode: the distances of the two levels are only bit-identical under the same contraction)"""
+    if not USE_NESTED_FPS:
+        return None
+    tag = getattr(inp, _TIE_ATTR, None)
+    if tag is None:
+        return None
+    tie, version, mode = tag
+    try:
+        if inp._version != version or mode != config.fps_mode(arith_mode):
+            return None
+    except RuntimeError:
+        return None
+    if tie.device != inp.device or tie.shape[0] != inp.shape[0] or not inp.is_contiguous():
+        return None
+    return tie
+
+
 USE_BUCKET_FPS = True  # clouds beyond 16384 points: Morton buckets + bounding-box skipping (pn2_fps_large); False = streaming kernel
 FPS_REG_MAX, FPS_BUCKET_MAX = 16384, 131072
 
@@ -39,22 +77,32 @@ def _fps_large(npoint, inp, want_xyz, arith_mode=None):
 def farthest_point_sample(npoint, inp, arith_mode=None):
     """npoint: int; inp (b,n,3) float32 -> (b,npoint) int32.  Not differentiable.
     arith_mode (extension): contraction of the squared-distance expression, config.FPS_ARITH_DEFAULT when None."""
+    return farthest_point_sample_with_ties(npoint, inp, arith_mode)[0]
+
+
+def farthest_point_sample_with_ties(npoint, inp, arith_mode=None, want_xyz=False):
+    """farthest_point_sample that also returns the run's tie record for the level below (extension):
+    -> idx (b,npoint) int32, tie (b,) int32 or None (clouds beyond 16384 points keep no record), new_xyz or None."""
     if npoint <= 0:
         raise ValueError("FarthestPointSample expects positive npoint")  # tf_sampling.cpp:121-123
     require_cuda(inp)
     _chk_xyz(inp, "inp", "FarthestPointSample")
+    tie_in = fps_tie_record(inp, arith_mode)
     inp = inp.detach().contiguous()
     b, n, _ = inp.shape
     if USE_BUCKET_FPS and FPS_REG_MAX < n <= FPS_BUCKET_MAX:
-        return _fps_large(npoint, inp, False, arith_mode)[0]
+        out, new_xyz = _fps_large(npoint, inp, want_xyz, arith_mode)
+        return out, None, new_xyz
     out = torch.empty((b, npoint), dtype=torch.int32, device=inp.device)
+    new_xyz = torch.empty((b, npoint, 3), dtype=torch.float32, device=inp.device) if want_xyz else None
+    tie = torch.empty((b,), dtype=torch.int32, device=inp.device) if USE_NESTED_FPS else None
     temp = None
     if n > 16384:  # PN2_FPS_MAX_REG_POINTS: the streaming kernel needs the reference's (32,n) scratch
         temp = torch.empty((min(b, 32), n), dtype=torch.float32, device=inp.device)
     with torch.cuda.device(inp.device):
-        check(lib.pn2_farthest_point_sample(b, n, int(npoint), ptr(inp), ptr(temp), ptr(out),
-                                            config.fps_mode(arith_mode), stream_ptr()), "pn2_farthest_point_sample")
-    return out
+        check(lib.pn2_fps_nested(b, n, int(npoint), ptr(inp), ptr(temp), ptr(out), ptr(new_xyz), ptr(tie_in), ptr(tie),
+                                 config.fps_mode(arith_mode), stream_ptr()), "pn2_fps_nested")
+    return out, tie, new_xyz
 
 
 class _GatherPoint(torch.autograd.Function):
@@ -95,23 +143,8 @@ def gather_point(inp, idx):
 def farthest_point_sample_and_gather(npoint, inp, arith_mode=None):
     """farthest_point_sample + gather_point in one launch (inference; no gradient):
     -> idx (b,npoint) int32, new_xyz (b,npoint,3) == gather_point(inp, idx) bit for bit."""
-    if npoint <= 0:
-        raise ValueError("FarthestPointSample expects positive npoint")
-    require_cuda(inp)
-    _chk_xyz(inp, "inp", "FarthestPointSample")
-    inp = inp.detach().contiguous()
-    b, n, _ = inp.shape
-    if USE_BUCKET_FPS and FPS_REG_MAX < n <= FPS_BUCKET_MAX:
-        return _fps_large(npoint, inp, True, arith_mode)
-    out = torch.empty((b, npoint), dtype=torch.int32, device=inp.device)
-    new_xyz = torch.empty((b, npoint, 3), dtype=torch.float32, device=inp.device)
-    temp = None
-    if n > 16384:
-        temp = torch.empty((min(b, 32), n), dtype=torch.float32, device=inp.device)
-    with torch.cuda.device(inp.device):
-        check(lib.pn2_fps_gather(b, n, int(npoint), ptr(inp), ptr(temp), ptr(out), ptr(new_xyz),
-                                 config.fps_mode(arith_mode), stream_ptr()), "pn2_fps_gather")
-    return out, new_xyz
+    out, tie, new_xyz = farthest_point_sample_with_ties(npoint, inp, arith_mode, want_xyz=True)
+    return out, tag_fps_output(new_xyz, tie, arith_mode)
 
 
 def prob_sample(inp, inpr):

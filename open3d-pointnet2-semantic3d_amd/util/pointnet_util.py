@@ -20,7 +20,8 @@ from .._lib import PN2_EUNSUP, check, lib, ptr, require_cuda, stream_ptr
 from ..tf_ops import tf_grouping
 from ..tf_ops.tf_grouping import query_ball_point_multi, group_point, knn_point, query_ball_point
 from ..tf_ops.tf_interpolate import three_interpolate, three_nn
-from ..tf_ops.tf_sampling import farthest_point_sample, farthest_point_sample_and_gather, gather_point
+from ..tf_ops.tf_sampling import (farthest_point_sample, farthest_point_sample_and_gather, farthest_point_sample_with_ties,
+                                  gather_point, tag_fps_output)
 
 
 def sample_and_group(npoint, radius, nsample, xyz, points, knn=False, use_xyz=True, geometry=None):
@@ -33,7 +34,8 @@ def sample_and_group(npoint, radius, nsample, xyz, points, knn=False, use_xyz=Tr
         new_xyz, idx = geometry[0], geometry[1]
         plan = geometry[2] if len(geometry) > 2 else None
     else:
-        new_xyz = gather_point(xyz, farthest_point_sample(npoint, xyz))
+        fps_idx, fps_tie, _ = farthest_point_sample_with_ties(npoint, xyz)  # (:36-37; the tie record rides on new_xyz, see
+        new_xyz = tag_fps_output(gather_point(xyz, fps_idx), fps_tie)         #  tf_sampling.USE_NESTED_FPS)
         if knn:
             _, idx = knn_point(nsample, xyz, new_xyz)
         else:
@@ -442,7 +444,8 @@ def pointnet_sa_module_msg(xyz, points, npoint, radius_list, nsample_list, mlp_l
     require_cuda(xyz, points)
     with tf_util.variable_scope(scope):
         xyz = xyz.contiguous()
-        new_xyz = gather_point(xyz, farthest_point_sample(npoint, xyz))
+        fps_idx, fps_tie, _ = farthest_point_sample_with_ties(npoint, xyz)  # (:36-37; the tie record rides on new_xyz, see
+        new_xyz = tag_fps_output(gather_point(xyz, fps_idx), fps_tie)         #  tf_sampling.USE_NESTED_FPS)
         outs = []
         # one scan of xyz for all radii (the reference re-scans once per radius, :245-250)
         queries = query_ball_point_multi(radius_list, nsample_list, xyz, new_xyz)

@@ -71,6 +71,16 @@ def farthest_point_sample(npoint, inp, mode=DEFAULT_FPS_MODE):
     return out
 
 
+def fps_first_tie(npoint, inp, mode=DEFAULT_FPS_MODE):
+    """first tied step of the FPS run (checker of pn2_fps_nested's tie record; see oracle_fps_first_tie) -> (b,) int32"""
+    inp = _f32(inp)
+    b, n, _ = inp.shape
+    out = np.empty((b,), dtype=np.int32)
+    rc = lib().oracle_fps_first_tie(b, n, int(npoint), _p(inp), _p(out), int(mode))
+    assert rc == 0, rc
+    return out
+
+
 def gather_point(inp, idx):
     inp, idx = _f32(inp), _i32(idx)
     b, n, _ = inp.shape

@@ -159,6 +159,50 @@ int oracle_fps(int b, int n, int m, const float *inp, int *out, int mode) {
     return err ? -2 : 0;
 }
 
+/* Tie record of an FPS run (checker of pn2_fps_nested's tie_out; no counterpart in the reference, it analyses the run
+ * of tf_sampling.cu:111-176 restated above).  At step j (1 <= j < m) the pick is the point with the maximum running
+ * distance; the step is TIED when another point holds the same value.  strict: a tied point has other coordinates
+ * than the pick, or the maximum is 0; benign: every tied point coincides with the pick (its distance drops to 0 with
+ * the pick, so it is picked itself only once the maximum is 0).  Result per cloud: the first strict step -- or the
+ * first benign step when that comes earlier AND the maximum reached 0 within the m picks; 0x7fffffff = none. */
+int oracle_fps_first_tie(int b, int n, int m, const float *inp, int *tie, int mode) {
+    if (b <= 0 || n <= 0 || m <= 0 || !inp || !tie) return -1;
+#pragma omp parallel for schedule(dynamic, 1)
+    for (int i = 0; i < b; ++i) {
+        const float *xyz = inp + (size_t)i * n * 3;
+        float *temp = (float *)malloc(sizeof(float) * (size_t)n);
+        int *idxs = (int *)malloc(sizeof(int) * (size_t)m);
+        int strict = 0x7fffffff, benign = 0x7fffffff, zero = 0;
+        fps_one(n, m, xyz, idxs, temp, mode); /* the picks (reference order) */
+        for (int k = 0; k < n; ++k) temp[k] = 1e38f;
+        for (int j = 1; j < m; ++j) {
+            int old = idxs[j - 1];
+            float best = -1.0f;
+            for (int k = 0; k < n; ++k) {
+                float d = sqdist_mode(xyz[old * 3], xyz[old * 3 + 1], xyz[old * 3 + 2], xyz[k * 3], xyz[k * 3 + 1],
+                                      xyz[k * 3 + 2], mode);
+                if (d < temp[k]) temp[k] = d;
+                if (temp[k] > best) best = temp[k];
+            }
+            int w = idxs[j], tied = 0, other = 0;
+            for (int k = 0; k < n; ++k) {
+                if (k == w || temp[k] != best) continue;
+                tied = 1;
+                if (xyz[k * 3] != xyz[w * 3] || xyz[k * 3 + 1] != xyz[w * 3 + 1] || xyz[k * 3 + 2] != xyz[w * 3 + 2]) other = 1;
+            }
+            if (tied) {
+                if (best == 0.0f) zero = 1;
+                if (other || best == 0.0f) { if (j < strict) strict = j; }
+                else if (j < benign) benign = j;
+            }
+        }
+        tie[i] = (zero && benign < strict) ? benign : strict;
+        free(temp);
+        free(idxs);
+    }
+    return 0;
+}
+
 /* ------------------------------------------------------------------------- */
 int oracle_gather_point(int b, int n, int m, const float *inp, const int *idx,
                         float *out) {

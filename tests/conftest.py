@@ -53,3 +53,16 @@ def s_scene(seed, b, n):
     xy = rs.uniform(-5, 5, (b, n, 2))
     z = np.clip(np.abs(rs.normal(0, 1.5, (b, n, 1))), 0, 8)
     return np.concatenate([xy, z], axis=2).astype(np.float32)
+
+
+def s_dup(seed, b, n, frac=0.25):
+    """S-scene with `frac` of its rows duplicates of other rows, order shuffled: how the reference fills a cloud that is
+    shorter than num_points_per_sample (dataset/semantic_dataset.py:101-106 appends np.random.choice of the same rows)."""
+    rs = np.random.RandomState(seed + 7919)
+    x = s_scene(seed, b, n)
+    nd = int(n * frac)
+    for i in range(b):
+        src = rs.randint(0, n - nd, nd)
+        x[i, n - nd:] = x[i, src]
+        x[i] = x[i][rs.permutation(n)]
+    return x

@@ -37,5 +37,11 @@ def test_bench_json_contract():
     assert r["regimes"]["throughput"]["ms_per_step"] == r["ms_per_step"] and r["value_regime"].startswith("throughput")
     assert r["regimes"]["latency"]["batches_in_flight"] == 1 and r["regimes"]["latency"]["ms_per_step"] >= r["ms_per_step"]
     assert r["roofline"]["regime"] == "throughput" and r["roofline"]["ms_per_step"] <= r["ms_per_step"]
-    assert r["roofline"]["kernel"] not in ("farthest_point_sample", "fps_gather")
-    assert r["latency_limiter"]["kernel"] in ("farthest_point_sample", "fps_gather") and r["latency_limiter"]["ns_per_round"] > 0
+    fps = ("farthest_point_sample", "fps_gather", "fps_nested")
+    assert r["roofline"]["kernel"] not in fps
+    assert r["latency_limiter"]["kernel"] in fps and r["latency_limiter"]["ns_per_round"] > 0
+    # the reference benchmark's own input and a duplicate-heavy cloud, same graphs, on the line
+    for nm in ("S-randn", "S-dup25"):
+        o = r["other_inputs"][nm]
+        assert o["ms_per_step"] > 0 and o["single_batch_latency_ms"] >= o["ms_per_step"]
+        assert len(o["fps_us"]) == 4 and len(o["query_ball_point_us"]) == 4 and len(o["three_nn_us"]) == 4

@@ -18,7 +18,7 @@ On S-grid inputs every operation is exact, all builds and all modes must agree.
 import numpy as np
 import pytest
 
-from conftest import s_grid, s_randn, s_scene
+from conftest import s_dup, s_grid, s_randn, s_scene
 
 pytestmark = pytest.mark.gpu
 
@@ -183,6 +183,117 @@ def test_default_configuration_is_the_contracted_reference_build(pn2, ref, cuda,
         ri, _ = ref.query_ball_point(radius, k, cur, new_xyz, "off")
         assert np.array_equal(geo0["xyzs"][li + 1].cpu().numpy(), new_xyz) and np.array_equal(geo0["idxs"][li].cpu().numpy(), ri)
         cur = new_xyz
+
+
+NO_TIE = 0x7FFFFFFF
+
+
+def _nested_chain(pn2, cuda, x, levels, mode):
+    """the product's chain: every level samples the TENSOR the previous level returned (tagged with its tie record)"""
+    S = pn2.tf_ops.tf_sampling
+    set_mode(fps=mode)
+    cur, out = T(x, cuda), []
+    for m in levels:
+        idx, new_xyz = S.farthest_point_sample_and_gather(m, cur)
+        tie = S.fps_tie_record(new_xyz)
+        assert tie is not None
+        out.append((idx.cpu().numpy(), new_xyz.cpu().numpy(), tie.cpu().numpy()))
+        cur = new_xyz
+    return out
+
+
+@pytest.mark.parametrize("gen,n,levels", [
+    ("scene", 8192, (1024, 256, 64, 16)), ("randn", 8192, (1024, 256, 64, 16)), ("dup25", 8192, (1024, 256, 64, 16)),
+    ("grid1024", 8192, (1024, 256, 64, 16)), ("grid16", 8192, (1024, 256, 64, 16)), ("grid4", 4096, (1024, 256, 64, 16)),
+    ("scene", 1024, (256, 64, 16)), ("grid64", 2048, (600, 256, 64)), ("dup25", 700, (300, 100, 30)),
+    ("few", 3000, (1024, 600, 128))])
+def test_nested_fps_chain_equals_the_reference_chain(pn2, oracle, ref, cuda, gen, n, levels):
+    """VERDICT r03 #1.  pn2_fps_nested: a level whose input is the previous level's output answers idx = 0..m-1 without
+    sampling when the parent run met no tie before step m, and samples otherwise -- either way the reference's own kernel
+    (tf_sampling.cu:111-176, oracle/_ref) run level by level on the same clouds gives the same bits.  Held here: the
+    chain (both contraction builds the HIP kernels offer), the tie record against the oracle's analysis of the run, and
+    WHICH path each cloud took: real-valued clouds and clouds with duplicated rows (dataset/semantic_dataset.py:101-106)
+    take the shortcut at every nested level, tie-heavy lattices are sampled."""
+    b = 16 if n >= 4096 else 5
+    if gen == "few":  # 3000 rows, 750 distinct: the running maximum reaches 0 inside the first level
+        base = s_scene(11, b, n // 4)
+        x = np.concatenate([base] * 4, axis=1)
+        rs = np.random.RandomState(5)
+        for i in range(b):
+            x[i] = x[i][rs.permutation(n)]
+    elif gen == "dup25":
+        x = s_dup(2, b, n)
+    elif gen.startswith("grid"):
+        x = s_grid(n, b, n, int(gen[4:]))
+    else:
+        x = _gen(gen, 1, b, n)
+    for build in ("off", "fast_noslp"):
+        mode = FPS_MODE[build]
+        got = _nested_chain(pn2, cuda, x, levels, mode)
+        cur, record, took = x, None, []
+        for li, m in enumerate(levels):
+            f = ref.farthest_point_sample(m, cur, build)
+            new_xyz = ref.gather_point(cur, f, build)
+            own = oracle.fps_first_tie(m, cur, mode)
+            assert np.array_equal(got[li][0], f), "%s level %d (m=%d, %s): picks differ at %s" % (
+                gen, li, m, build, np.argwhere(got[li][0] != f)[:3])
+            assert np.array_equal(got[li][1], new_xyz)
+            if record is None:
+                expect = own
+            else:
+                short = record >= m
+                took.append(short)
+                assert np.array_equal(f[short], np.broadcast_to(np.arange(m, dtype=np.int32), f[short].shape))
+                expect = np.where(short, record, own)
+            # the record: exact up to step m-2 (the one-pick kernels do not look at the last pick; nobody asks for m picks of m)
+            assert np.array_equal(np.minimum(got[li][2], m - 1), np.minimum(expect, m - 1)), (gen, li, build, got[li][2], expect)
+            record, cur = got[li][2], new_xyz
+        took = np.stack(took)
+        if gen in ("scene", "randn", "dup25"):
+            assert took.all(), "a real-valued cloud left the shortcut"
+        if gen in ("grid16", "grid4", "few"):
+            assert not took[0].any(), "a tie-heavy cloud took the shortcut at the first nested level"
+
+
+def test_nested_fps_device_side_branch(pn2, oracle, cuda):
+    """The choice is made per cloud ON THE DEVICE from tie_in (one graph node either way): a forged record makes the kernel
+    answer the identity where it is wrong, a zero record forces the sampler where the identity would have been right."""
+    import torch
+    from pn2_amd import _lib
+    lib, ptr = _lib.lib, _lib.ptr
+    for n, m in [(1024, 256), (256, 64), (4096, 700), (8192, 1024)]:
+        x = np.concatenate([s_grid(n, 2, n, 8), s_scene(n, 2, n)], axis=0)   # clouds 0,1 tie-heavy, 2,3 real-valued
+        want = oracle.farthest_point_sample(m, x, 2)
+        xt = T(x, cuda)
+        for tie_in, ident in [(None, [False] * 4), ([NO_TIE] * 4, [True] * 4), ([0] * 4, [False] * 4),
+                              ([NO_TIE, m - 1, m, 0], [True, False, True, False])]:
+            out = torch.full((4, m), -1, dtype=torch.int32, device=cuda)
+            nx = torch.zeros((4, m, 3), dtype=torch.float32, device=cuda)
+            tout = torch.full((4,), -7, dtype=torch.int32, device=cuda)
+            tin = None if tie_in is None else torch.tensor(tie_in, dtype=torch.int32, device=cuda)
+            _lib.check(lib.pn2_fps_nested(4, n, m, ptr(xt), None, ptr(out), ptr(nx), ptr(tin), ptr(tout), 2,
+                                          _lib.stream_ptr()), "pn2_fps_nested")
+            o, t = out.cpu().numpy(), tout.cpu().numpy()
+            for i in range(4):
+                if ident[i]:
+                    assert np.array_equal(o[i], np.arange(m)) and t[i] == tie_in[i]
+                    assert np.array_equal(nx[i].cpu().numpy(), x[i, :m])
+                else:
+                    assert np.array_equal(o[i], want[i])
+                    assert np.array_equal(nx[i].cpu().numpy(), x[i][want[i]])
+        assert not np.array_equal(want[0], np.arange(m))  # the forged identity above really was a different answer
+
+
+def test_nested_fps_tag_is_dropped_when_it_no_longer_describes_the_tensor(pn2, cuda):
+    S = pn2.tf_ops.tf_sampling
+    x = T(s_scene(0, 2, 2048), cuda)
+    _, a = S.farthest_point_sample_and_gather(512, x)
+    assert S.fps_tie_record(a) is not None
+    assert S.fps_tie_record(a.clone()) is None and S.fps_tie_record(a[:, :100]) is None and S.fps_tie_record(a * 1.0) is None
+    with pn2.config.arith(fps=0):
+        assert S.fps_tie_record(a) is None          # sampled under another contraction: distances differ in the last bit
+    a.add_(1.0)
+    assert S.fps_tie_record(a) is None              # modified in place since
 
 
 def test_fps_tie_heavy_grids(pn2, oracle, ref, cuda):
