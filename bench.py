@@ -472,8 +472,12 @@ def bench_train(pn2, args, hp, B, N, rank, world, dev):
     for i in range(i0, i0 + args.steps):  # no host synchronisation inside the timed region: the loss stays on the device
         loss = tr.train_step(pcs[i % 2], labels, smpw, next_pc=pcs[(i + 1) % 2], sync=False)
     torch.cuda.synchronize()
+    local = time.perf_counter() - t0  # this rank's own clock, before the closing barrier
     pn2.dist.barrier()
     elapsed = pn2.dist.max_over_ranks(time.perf_counter() - t0, device=dev)
+    per_rank = pn2.dist.gather_over_ranks(local / args.steps * 1e3, device=dev)
+    # ---- diagnosis legs, AFTER the measured region (they perturb the replicas): where a step's time goes when N > 1
+    diag = train_comm_diagnosis(pn2, tr, args, pcs, labels, smpw, dev, world, elapsed / args.steps * 1e3)
     if rank == 0:
         print(json.dumps({
             "metric": "training points/sec through SA+FP stack + head (B=16/GPU, N=%d)" % N,
@@ -485,7 +489,46 @@ def bench_train(pn2, args, hp, B, N, rank, world, dev):
                                    "chain prefetched on a side stream"
                                    % (B, N, tr.store.num_parameters()),
                        "global_batch": world * B, "parallelism": "dp%d" % world},
+            "per_rank_ms_per_step": [round(v, 4) for v in per_rank], **diag,
             "last_loss": float(loss), **rccl_info(world)}))
+
+
+def train_comm_diagnosis(pn2, tr, args, pcs, labels, smpw, dev, world, ms_per_step):
+    """the keys that let a sub-linear N > 1 result be read from the record.
+      allreduce_early_ms / allreduce_late_ms   each bucket's all-reduce alone (nothing to hide behind): the wire
+      exposed_comm_ms                          in a real step: end of the SA backward graph -> both buckets reduced (HIP
+                                               events on the trainer's stream); what the step waits for the collectives
+      ms_per_step_no_comm, scaling_efficiency  the SAME job stepping with its collectives skipped (max over ranks), and
+                                               that over the measured step: 1.0 = the collectives cost nothing"""
+    k = max(4, min(args.steps, 10))
+    out = {"allreduce_early_ms": 0.0, "allreduce_late_ms": 0.0, "exposed_comm_ms": 0.0,
+           "ms_per_step_no_comm": round(ms_per_step, 4), "scaling_efficiency": 1.0}
+    if world == 1:
+        return out
+    i0 = tr.step_count
+    tr.comm_events = []
+    for i in range(i0, i0 + k):
+        tr.train_step(pcs[i % 2], labels, smpw, next_pc=pcs[(i + 1) % 2], sync=False)
+    torch.cuda.synchronize()
+    ev, tr.comm_events = tr.comm_events, None
+    if ev:
+        out["exposed_comm_ms"] = round(sum(e1.elapsed_time(e2) for _, e1, e2 in ev) / len(ev), 4)
+        out["early_launch_to_reduced_ms"] = round(sum(e0.elapsed_time(e2) for e0, _, e2 in ev) / len(ev), 4)
+    out["exposed_comm_ms"] = round(pn2.dist.max_over_ranks(out["exposed_comm_ms"], device=dev), 4)
+    pn2.dist.barrier()
+    tr.bucket.skip_collectives = True
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(i0 + k, i0 + 2 * k):
+        tr.train_step(pcs[i % 2], labels, smpw, next_pc=pcs[(i + 1) % 2], sync=False)
+    torch.cuda.synchronize()
+    no_comm = pn2.dist.max_over_ranks((time.perf_counter() - t0) / k * 1e3, device=dev)
+    tr.bucket.skip_collectives = False
+    out["ms_per_step_no_comm"] = round(no_comm, 4)
+    out["scaling_efficiency"] = round(no_comm / ms_per_step, 4)
+    tc = tr.bucket.time_collectives(iters=k)
+    out.update({kk: (round(pn2.dist.max_over_ranks(v, device=dev), 4) if kk.endswith("_ms") else v) for kk, v in tc.items()})
+    return out
 
 
 def _free_port():
@@ -533,12 +576,37 @@ def dry_run(args, rank, world):
     t0 = time.perf_counter()
     for _ in range(args.steps):
         time.sleep(0.001 * (1 + rank))  # rank-dependent "work": the slowest rank must define the step
+    local = time.perf_counter() - t0
     pn2.dist.barrier()
     elapsed = pn2.dist.max_over_ranks(time.perf_counter() - t0)
+    per_rank = pn2.dist.gather_over_ranks(local / args.steps * 1e3)
+    line = {"metric": "dry run (no GPU work): launcher / rendezvous / max-over-ranks only", "value": None,
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(elapsed / args.steps * 1e3, 4), "dry_run": True,
+            "per_rank_ms_per_step": [round(v, 4) for v in per_rank],
+            "per_rank_points_per_s": [round(args.batch * args.points / (v * 1e-3), 1) for v in per_rank]}
+    if args.train:
+        # the diagnosis keys of `--train --gpus N` on the same two-bucket exchange (gloo, CPU tensors of the real sizes:
+        # 967945 gradients, the head + FP layers in the early bucket)
+        params = [torch.nn.Parameter(torch.zeros(n_)) for n_ in (300000, 667945)]
+        bucket = pn2.dist.OverlappedGradAllReduce(params, 1)
+        tc = bucket.time_collectives(iters=3)
+        t1 = time.perf_counter()
+        work = bucket.reduce_early_async()
+        time.sleep(0.002)  # "the SA backward graph"
+        t2 = time.perf_counter()
+        bucket.reduce_late_and_wait(work)
+        exposed = (time.perf_counter() - t2) * 1e3
+        bucket.skip_collectives = True
+        assert bucket.reduce_early_async() is None and bucket.world() == 1
+        bucket.skip_collectives = False
+        no_comm = line["ms_per_step"]
+        line.update({k: (round(pn2.dist.max_over_ranks(v), 4) if k.endswith("_ms") else v) for k, v in tc.items()})
+        line.update({"exposed_comm_ms": round(pn2.dist.max_over_ranks(exposed), 4),
+                     "early_launch_to_reduced_ms": round((time.perf_counter() - t1) * 1e3, 4),
+                     "ms_per_step_no_comm": no_comm,
+                     "scaling_efficiency": round(no_comm / (no_comm + pn2.dist.max_over_ranks(exposed)), 4)})
     if rank == 0:
-        line = {"metric": "dry run (no GPU work): launcher / rendezvous / max-over-ranks only", "value": None,
-                "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-                "ms_per_step": round(elapsed / args.steps * 1e3, 4), "dry_run": True}
         line.update(rccl_info(world))
         print(json.dumps(line))
     pn2.dist.barrier()
@@ -684,6 +752,7 @@ def main():
         dist.barrier()
         torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
+    per_rank_pps = [B * N * args.steps / v for v in pn2.dist.gather_over_ranks(elapsed, device=dev)]
     elapsed = pn2.dist.max_over_ranks(elapsed, device=dev)  # the slowest rank defines the step time
     assert torch.isfinite(out).all()
 
@@ -773,6 +842,7 @@ def main():
                              "frac_of_peak_equivalent": round(eff_tf / MFMA_F32_PEAK_TF, 4)},
                          "kernel_time_sums_ms": {"all": round(sum_all, 4), "without_fps": round(sum_dense, 4),
                                                  "fps": round(sum_all - sum_dense, 4)}},
+            "per_rank_points_per_s": [round(v, 1) for v in per_rank_pps],
             "kernels": kernels,
             "single_batch_latency_ms": None if latency_ms is None else round(latency_ms, 4),
             "gpu_ms_per_step_sum_of_kernels": round(sum_all, 4),

@@ -48,6 +48,16 @@ def max_over_ranks(value, device=None):
     return float(t.item())
 
 
+def gather_over_ranks(value, device=None):
+    """the python float of every rank, in rank order (bench: per-rank step times on the line, so a slow rank is visible)"""
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        return [float(value)]
+    t = torch.tensor([float(value)], dtype=torch.float64, device=device)
+    out = [torch.zeros_like(t) for _ in range(dist.get_world_size())]
+    dist.all_gather(out, t)
+    return [float(o.item()) for o in out]
+
+
 def barrier():
     if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
         dist.barrier()
@@ -129,12 +139,46 @@ class OverlappedGradAllReduce:
         # defer_collectives: backward only PACKS the buckets; the caller reduces the whole flat buffer afterwards with
         # reduce_deferred() -- for a backward pass that is captured into a hipGraph (the collective stays outside)
         self.defer_collectives = False
+        # skip_collectives: run the step as a lone rank would (bench: the no-communication step time of the SAME job, the
+        # denominator of its scaling efficiency); the replicas diverge, so only after the measured region
+        self.skip_collectives = False
         self._known_zero = set()
         self._expected_early = None
         self._hooks = [p.register_post_accumulate_grad_hook(self._on_grad) for p in self.params[self.split:]]
 
     def world(self):
+        if self.skip_collectives:
+            return 1
         return dist.get_world_size() if (dist.is_available() and dist.is_initialized()) else 1
+
+    def _comm_on(self):
+        return dist.is_available() and dist.is_initialized() and not self.skip_collectives
+
+    @torch.no_grad()
+    def time_collectives(self, iters=10):
+        """each bucket's all-reduce ALONE (nothing to overlap with), ms per call: what the wire costs, to hold against the
+        exposed time of a real step.  Sums garbage into `flat`: call it after the measured region only."""
+        out = {"early_bytes": int(self.early_flat.numel()) * 4, "late_bytes": int(self.late_flat.numel()) * 4,
+               "allreduce_early_ms": 0.0, "allreduce_late_ms": 0.0}
+        if not self._comm_on() or dist.get_world_size() == 1:
+            return out
+        import time
+        cuda = self.flat.is_cuda
+        for key, buf in (("allreduce_early_ms", self.early_flat), ("allreduce_late_ms", self.late_flat)):
+            if buf.numel() == 0:
+                continue
+            buf.zero_()
+            dist.all_reduce(buf, op=dist.ReduceOp.SUM)  # warm-up (connection set-up of this size)
+            if cuda:
+                torch.cuda.synchronize()
+            dist.barrier()
+            t0 = time.perf_counter()
+            for _ in range(iters):
+                dist.all_reduce(buf, op=dist.ReduceOp.SUM)
+            if cuda:
+                torch.cuda.synchronize()
+            out[key] = (time.perf_counter() - t0) / iters * 1e3
+        return out
 
     def begin(self):
         """call before backward (after the gradients were reset)"""
@@ -204,12 +248,12 @@ class OverlappedGradAllReduce:
 
     def reduce_early_async(self):
         """the early bucket's all-reduce (sum), asynchronous: it travels while the second piece of backward runs"""
-        if dist.is_available() and dist.is_initialized():
+        if self._comm_on():
             return dist.all_reduce(self.early_flat, op=dist.ReduceOp.SUM, async_op=True)
         return None
 
     def reduce_late_and_wait(self, work):
-        if dist.is_available() and dist.is_initialized() and self.split_off > 0:
+        if self._comm_on() and self.split_off > 0:
             dist.all_reduce(self.late_flat, op=dist.ReduceOp.SUM)
         if work is not None:
             work.wait()
@@ -218,7 +262,7 @@ class OverlappedGradAllReduce:
     @torch.no_grad()
     def reduce_deferred(self):
         """the collective of a defer_collectives step: ONE all-reduce (sum) of the whole flat gradient on the current stream"""
-        if dist.is_available() and dist.is_initialized():
+        if self._comm_on():
             dist.all_reduce(self.flat, op=dist.ReduceOp.SUM)
         return self.flat
 

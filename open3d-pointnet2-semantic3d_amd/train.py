@@ -77,6 +77,10 @@ class Trainer:
         self.overlap_collective = bool(overlap_collective)
         self._graph_adam, self._graph_late = None, None
         self._static_geo_next, self._static_next_xyz, self._next_tag = None, None, None
+        # comm_events (bench.py --train): a list that receives, per captured multi-rank step, three HIP events on the
+        # trainer's stream: early bucket launched | SA backward graph done | both buckets reduced
+        self.comm_events = None
+        self._world0 = None
 
     # ---- set-up ------------------------------------------------------------------------------------------------
     def _lazy_init(self, pc):
@@ -117,6 +121,7 @@ class Trainer:
         # before an asynchronous copy has read it: with sync=False the host is several steps ahead of the device).
         self.hyper = torch.tensor([0.0, self.BETA1, self.BETA2, self.EPS, 1.0 / self.bucket.world()], dtype=torch.float32).to(dev)
         self._lr_slot = self.hyper[0:1]
+        self._world0 = self.bucket.world()  # frozen into grad_scale above: a process group created later would mis-scale
         self._stream = torch.cuda.Stream(device=dev) if dev.type == "cuda" else None
         self._geo_stream = torch.cuda.Stream(device=dev) if dev.type == "cuda" else None
 
@@ -233,6 +238,9 @@ class Trainer:
             self._lazy_init(pc)
         b = pc.shape[0]
         world = self.bucket.world()
+        if world != self._world0 and not self.bucket.skip_collectives:
+            raise RuntimeError("the process group changed after the trainer's first step (world %d -> %d): the gradient scale "
+                               "1/world is part of the optimizer state; build a new Trainer" % (self._world0, world))
         t = self.step_count + 1
         lr = self._learning_rate(self.step_count, b)
         decay = self._bn_decay(self.step_count, b)
@@ -291,9 +299,18 @@ class Trainer:
                     self._prefetch(next_pc, taken)
                 self._graph.replay()
                 if self._graph_late is not None:  # three segments: the early bucket travels while the SA backward replays
+                    ev = self.comm_events  # bench: [(early launched, SA backward done, both buckets reduced)] per step
+                    if ev is not None:
+                        e0, e1, e2 = (torch.cuda.Event(enable_timing=True) for _ in range(3))
+                        e0.record(self._stream)
                     work = self.bucket.reduce_early_async()
                     self._graph_late.replay()
+                    if ev is not None:
+                        e1.record(self._stream)
                     self.bucket.reduce_late_and_wait(work)
+                    if ev is not None:
+                        e2.record(self._stream)
+                        ev.append((e0, e1, e2))
                     self._graph_adam.replay()
                 elif self._graph_adam is not None:  # split capture: the collective runs between the two graphs
                     self.bucket.reduce_deferred()

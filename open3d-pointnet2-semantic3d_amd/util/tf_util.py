@@ -970,7 +970,9 @@ def _train_layer(inputs, w2d, b, bnv, bn_decay, relu, pool=0, defer=False):
         raise TypeError("the training path is float32")
     if bnv is None:
         if relu or pool:
-            raise NotImplementedError("training-mode conv without batch norm but with ReLU / pooling is not on the SA/FP path")
+            raise NotImplementedError("is_training=True with bn=False and a ReLU / pooling: the training kernels of this package "
+                                      "fuse the activation into the batch-norm kernels (pn2_bn_relu_*); there is no HIP "
+                                      "bias + ReLU training kernel and no torch fallback (INTEGRATION.md, limitations)")
         if _deferred_producer(inputs.reshape(-1, cin)) is not None:
             raise RuntimeError("a deferred batch-norm output reached a layer without batch norm")
         return _train_dense(inputs, w2d, b)

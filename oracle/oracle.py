@@ -251,14 +251,29 @@ def sample_and_group(npoint, radius, nsample, xyz, points, use_xyz=True, mode=No
     return new_xyz, new_points, idx, grouped_xyz
 
 
-def sa_module(xyz, points, npoint, radius, nsample, layers, dtype=np.float64, mode=None):
-    """pointnet_sa_module, pooling='max', mlp2=None, group_all=False, is_training=False
-    (util/pointnet_util.py:98-216)."""
-    new_xyz, new_points, idx, _ = sample_and_group(npoint, radius, nsample, xyz, points, True, mode)
+def sa_module(xyz, points, npoint, radius, nsample, layers, dtype=np.float64, mode=None, layers2=None, use_xyz=True,
+              group_all=False):
+    """pointnet_sa_module, pooling='max', is_training=False (util/pointnet_util.py:98-216).  layers2: the `mlp2` stack
+    applied to the pooled (B,npoint,1,C) tensor (:194-211); use_xyz=False: grouped features only (:52-58);
+    group_all=True: one group of all points around the origin, [xyz, features] (:63-95,137-141)."""
+    if group_all:
+        b, n, _ = xyz.shape
+        new_xyz = np.zeros((b, 1, 3), np.float32)                       # :81
+        idx = np.tile(np.arange(n, dtype=np.int32).reshape(1, 1, n), (b, 1, 1))  # :82
+        gx = _f32(xyz).reshape(b, 1, n, 3)                              # :83
+        if points is not None:
+            new_points = np.concatenate([gx, _f32(points)[:, None]], axis=-1) if use_xyz else _f32(points)[:, None]  # :85-90
+        else:
+            new_points = gx
+    else:
+        new_xyz, new_points, idx, _ = sample_and_group(npoint, radius, nsample, xyz, points, use_xyz, mode)
     h = new_points
     for layer in layers:
         h = conv_bn_relu(h, layer, dtype)
-    return new_xyz, h.max(axis=2), idx
+    h = h.max(axis=2, keepdims=True)
+    for layer in (layers2 or []):
+        h = conv_bn_relu(h, layer, dtype)
+    return new_xyz, h[:, :, 0], idx
 
 
 def fp_module(xyz1, xyz2, points1, points2, layers, dtype=np.float64):

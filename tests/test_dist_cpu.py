@@ -264,6 +264,28 @@ def test_bench_gpus2_launches_two_ranks_and_prints_one_line():
     line = json.loads(lines[0])
     assert line["n_gpus"] == 2 and line["rccl_ranks"] == 2 and line["backend"] == "gloo" and line["steps"] == 3
     assert line["ms_per_step"] >= 2.0  # rank 1 sleeps 2 ms per step, rank 0 only 1 ms: max over ranks
+    # every rank's own time is on the line (rank 1 is the slow one), as points/s for the inference bench
+    assert len(line["per_rank_ms_per_step"]) == 2 and line["per_rank_ms_per_step"][1] > line["per_rank_ms_per_step"][0] >= 1.0
+    assert len(line["per_rank_points_per_s"]) == 2 and line["per_rank_points_per_s"][0] > line["per_rank_points_per_s"][1] > 0
+
+
+@pytest.mark.timeout(300)
+def test_bench_train_line_decomposes_the_multi_rank_step():
+    """`bench.py --train --gpus N` must let a sub-linear result be diagnosed from the record alone: each bucket's all-reduce
+    alone, the time a step is exposed to the collectives, the same job's step with the collectives skipped, their ratio,
+    and every rank's own step time (gloo world 2, --dry-run: the two-bucket exchange of dist.py on CPU tensors)."""
+    import json
+    r = _run_bench(["--gpus", "2", "--steps", "3", "--warmup", "1", "--dry-run", "--train"])
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    line = json.loads(lines[0])
+    for k in ("allreduce_early_ms", "allreduce_late_ms", "exposed_comm_ms", "ms_per_step_no_comm", "scaling_efficiency",
+              "per_rank_ms_per_step", "early_bytes", "late_bytes"):
+        assert k in line, k
+    assert line["allreduce_early_ms"] > 0 and line["allreduce_late_ms"] > 0 and line["exposed_comm_ms"] >= 0
+    assert line["early_bytes"] + line["late_bytes"] == 967945 * 4
+    assert 0 < line["scaling_efficiency"] <= 1.0 and len(line["per_rank_ms_per_step"]) == 2
 
 
 @pytest.mark.timeout(120)

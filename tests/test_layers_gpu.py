@@ -802,6 +802,62 @@ def test_sa_module_group_all_and_poolings(pn2, oracle, cuda):
         close(npool.cpu().numpy(), fn(h))
 
 
+API_BRANCHES = [
+    # (id, C, mlp, mlp2, use_xyz, bn, group_all)   -- the arguments of pointnet_sa_module the model itself never varies
+    ("mlp2", 16, [32, 64], [64, 32], True, True, False),                 # pointnet_util.py:194-211
+    ("mlp2-one-layer", 3, [32, 32, 64], [128], True, True, False),
+    ("use_xyz=False", 16, [32, 64], None, False, True, False),            # :52-58: grouped features only
+    ("use_xyz=False+mlp2", 64, [64, 128], [64], False, True, False),
+    ("bn=False", 16, [32, 32, 64], None, True, False, False),             # tf_util.py:191-203 without the batch norm
+    ("bn=False+mlp2", 64, [64, 64, 128], [128, 64], True, False, False),
+    ("bn=False+use_xyz=False", 32, [64], None, False, False, False),
+    ("group_all+mlp2", 8, [32, 64], [64, 16], True, True, True),          # :137-141 with :194-211
+    ("group_all+use_xyz=False+bn=False", 8, [32], [16], False, False, True),
+]
+
+
+@pytest.mark.parametrize("case", API_BRANCHES, ids=[c[0] for c in API_BRANCHES])
+def test_sa_module_api_branches_vs_oracle(pn2, oracle, cuda, case):
+    """`mlp2`, `use_xyz=False`, `bn=False` and `group_all` with `mlp2` (util/pointnet_util.py:52-58,137-141,
+    194-211) against the fp64 restatement: indices bit-exact, features within 1e-5."""
+    name, C, mlp, mlp2, use_xyz, bn, group_all = case
+    tfu, pu = pn2.util.tf_util, pn2.util.pointnet_util
+    rs = np.random.RandomState(len(name) * 7 + C)
+    B, N, npoint, radius, K = 2, (96 if group_all else 640), 80, 0.3, 32
+    xyz = rs.random_sample((B, N, 3)).astype(np.float32)
+    pts = rs.randn(B, N, C).astype(np.float32)
+    store = tfu.set_default_store(tfu.VariableStore(device=cuda, seed=5))
+    kw = dict(npoint=None if group_all else npoint, radius=None if group_all else radius, nsample=None if group_all else K,
+              mlp=mlp, mlp2=mlp2, group_all=group_all, is_training=False, bn_decay=None, scope="br", bn=bn, use_xyz=use_xyz)
+    pu.pointnet_sa_module(T(xyz, cuda), T(pts, cuda), **kw)  # creates the variables
+    randomize_bn(store, 9)
+    new_xyz, new_points, idx = pu.pointnet_sa_module(T(xyz, cuda), T(pts, cuda), **kw)
+    if not bn:
+        assert not any("bn/" in k for k in store.params), "bn=False must not create batch-norm variables"
+    layers = layer_dicts(store, "br", ["conv%d" % i for i in range(len(mlp))], bn=bn)
+    layers2 = layer_dicts(store, "br", ["conv_post_%d" % i for i in range(len(mlp2 or []))], bn=bn)
+    cin = (3 if use_xyz else 0) + C
+    assert layers[0]["W"].shape == (cin, mlp[0])
+    r_xyz, r_pts, r_idx = oracle.sa_module(xyz, pts, npoint, radius, K, layers, layers2=layers2, use_xyz=use_xyz,
+                                           group_all=group_all)
+    assert np.array_equal(idx.cpu().numpy(), r_idx) and np.array_equal(new_xyz.cpu().numpy(), r_xyz)
+    assert new_points.shape == (B, 1 if group_all else npoint, (mlp2 or mlp)[-1])
+    close(new_points.cpu().numpy(), r_pts)
+
+
+def test_sa_module_training_without_batch_norm_is_refused_loudly(pn2, cuda):
+    """the reference accepts pointnet_sa_module(..., bn=False, is_training=True); this package has no HIP
+    bias + ReLU training kernel for it and no torch fallback -- it must say so, not compute something else."""
+    tfu, pu = pn2.util.tf_util, pn2.util.pointnet_util
+    rs = np.random.RandomState(0)
+    xyz = T(rs.random_sample((2, 256, 3)).astype(np.float32), cuda)
+    pts = T(rs.randn(2, 256, 8).astype(np.float32), cuda).requires_grad_(True)
+    tfu.set_default_store(tfu.VariableStore(device=cuda, seed=5))
+    with pytest.raises(NotImplementedError, match="bn=False"):
+        pu.pointnet_sa_module(xyz, pts, npoint=32, radius=0.3, nsample=16, mlp=[32], mlp2=None, group_all=False,
+                              is_training=True, bn_decay=None, scope="nb", bn=False)
+
+
 def test_group_pool_kernels_all_modes_and_use_nchw(pn2, cuda):
     """pn2_group_pool / _grad (the `pooling=` variants of pointnet_sa_module, pointnet_util.py:165-191: max, avg,
     weighted_avg = softmax-like exp(-5 |grouped_xyz|) weights, max_and_avg = concat [avg | max]) against the same

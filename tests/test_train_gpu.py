@@ -441,8 +441,14 @@ def _ddp_worker(rank, world, port, capture, q):
     losses = [tr.train_step(*batches[i % 3]) for i in range(7)]
     torch.cuda.synchronize()
     split_graphs = tr._graph is not None and tr._graph_adam is not None
-    q.put((rank, dict(losses=losses, p=tr.flat_p.cpu().numpy(), split=split_graphs, world=tr.bucket.world(),
-                      scale=float(tr.hyper[4]), late=tr._graph_late is not None)))
+    res = dict(losses=losses, p=tr.flat_p.cpu().numpy(), split=split_graphs, world=tr.bucket.world(),
+               scale=float(tr.hyper[4]), late=tr._graph_late is not None)
+    if capture:  # bench.py --train's diagnosis legs on this very job (they perturb the replicas: after the snapshot above)
+        import argparse
+        import bench
+        res["diag"] = bench.train_comm_diagnosis(pn2, tr, argparse.Namespace(steps=4), [batches[0][0], batches[1][0]],
+                                                 batches[0][1], batches[0][2], cuda, world, 1e9)
+    q.put((rank, res))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -480,6 +486,12 @@ def test_two_rank_captured_step_keeps_replicas_identical(pn2, cuda):
     rel = float(np.linalg.norm(cap[0]["p"] - eag[0]["p"]) / np.linalg.norm(eag[0]["p"]))
     assert rel <= 5e-2, rel  # a missing or doubled all-reduce / a wrong 1/world would be O(0.1 .. 1)
     assert cap[0]["losses"] != cap[1]["losses"]  # the ranks did train on different scenes
+    # the keys bench.py --train --gpus N prints to decompose a multi-rank step, measured on this job
+    d = cap[0]["diag"]
+    assert d["allreduce_early_ms"] > 0 and d["allreduce_late_ms"] > 0 and d["early_bytes"] + d["late_bytes"] == 967945 * 4
+    assert d["exposed_comm_ms"] > 0 and d["early_launch_to_reduced_ms"] >= d["exposed_comm_ms"]
+    assert d["ms_per_step_no_comm"] > 0 and d["scaling_efficiency"] > 0
+    assert d == cap[1]["diag"] or d["exposed_comm_ms"] == cap[1]["diag"]["exposed_comm_ms"]  # maxima over ranks: rank-independent
 
 
 def test_split_capture_with_a_process_group(pn2, cuda):
