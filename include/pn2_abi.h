@@ -485,6 +485,14 @@ int pn2_fp_mlp_fused_pre(int b, int n, int m, int c1, const float *dist, const i
                          const float *z, int nlayers, const int *widths, const float *const *w,
                          const float *const *bias, float *y, void *stream);
 
+/* pn2_fp_mlp_fused_pre with the kernel SCHEDULE named by the caller (stateless door for parity tests / A-B timing):
+ * 0 = lockstep kernel (8 waves: gather, MFMA layers, store), 1 = software-pipelined kernel (one wave per SIMD builds the next
+ * tile's first-layer accumulator between the MFMA groups of the current tile; three 128-wide layers, c1 <= 8, else
+ * PN2_EUNSUP).  Same bits either way; pn2_fp_mlp_fused_pre picks 1 where it applies. */
+int pn2_fp_mlp_fused_pre_schedule(int b, int n, int m, int c1, const float *dist, const int *idx, const float *points1,
+                                  const float *z, int nlayers, const int *widths, const float *const *w,
+                                  const float *const *bias, float *y, int schedule, void *stream);
+
 /* pn2_sa_mlp_max_fused / pn2_sa_mlp_rows_fused with the FEATURE part of the first layer hoisted by linearity:
  * [xyz - centre | features] @ W1 = (xyz - centre) @ W1[:3] + (features @ W1[3:])[idx], and zf = features @ W1[3:] has one
  * row per source point (b*n) instead of one per grouped neighbour (b*m*nsample).  zf (b*n, widths[0]) replaces `points`,

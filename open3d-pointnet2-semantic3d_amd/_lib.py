@@ -102,6 +102,8 @@ SIGNATURES = {
                          ctypes.c_double, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p],
     "pn2_fp_mlp_fused_pre": [c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p,
                              c_void_p, c_void_p, c_void_p],
+    "pn2_fp_mlp_fused_pre_schedule": [c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p,
+                                      c_void_p, c_void_p, c_void_p, c_int, c_void_p],
     "pn2_sa_mlp_fused_pre": [c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p,
                              c_void_p, c_int, c_void_p, c_void_p],
     "pn2_fp_mlp_wide_pre": [c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p,
@@ -218,7 +220,7 @@ class _LibProxy:
             elif name == "pn2_sa_mlp_fused_pre":  # (b, n, m, nsample, xyz, new_xyz, zf, idx, nlayers, widths, w, bias, pool, ...)
                 wp = ctypes.cast(args[9], ctypes.POINTER(c_int))
                 ints += [wp[i] for i in range(args[8])]
-            elif name == "pn2_fp_mlp_fused_pre":  # (b, n, m, c1, dist, idx, points1, z, nlayers, widths, ...)
+            elif name in ("pn2_fp_mlp_fused_pre", "pn2_fp_mlp_fused_pre_schedule"):  # (b, n, m, c1, dist, idx, points1, z, nlayers, widths, ...)
                 wp = ctypes.cast(args[9], ctypes.POINTER(c_int))
                 ints += [wp[i] for i in range(args[8])]
             elif name == "pn2_mlp_chain":

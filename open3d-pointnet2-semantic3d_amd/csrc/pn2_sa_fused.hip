@@ -23,6 +23,8 @@
 // Weights (<= 3 layers, widths <= 128) stay resident in LDS for the whole
 // persistent workgroup.
 #include "pn2_common.h"
+#include <type_traits>
+#include <utility>
 
 namespace {
 
@@ -45,6 +47,7 @@ struct SaFusedParams {
     const float* bias[3];
     float* out;
     int prio;  // 1: stagger the two waves of a SIMD (see the kernel)
+    int schedule;  // FP chain: 0 = lockstep kernel, 1 = software-pipelined kernel, -1 = the default (pipelined where it applies)
 #ifdef PN2_TUNING_HOOKS
     long long* stats;  // tuning builds: cycle stamps of the first workgroups (tools/chain_stage_ab.py)
 #endif
@@ -539,9 +542,271 @@ sa_fused_kernel(SaFusedParams p) {
         __hip_atomic_store(&stagger_flag[wave], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 }
 
+// ---- software-pipelined feature-propagation chain (FP4 of semantic.json: 131072 rows, 3 x 128) ----------------------------
+// Same arithmetic, bit for bit, as sa_fused_kernel<3, 4, 4, 4, VEC8, DENSE, !POOL, NW, INTERP, PREZ> -- same MFMA order, same
+// blend expression -- with another SCHEDULE.  There, the 8 waves of a CU gather in lockstep (3 rows of z x 512 B per output
+// row = 48 KB per wave and tile through a vector L1 that turns around ~16 B per cycle: 18-31 k cycles), then all run their
+// MFMA layers, then all store: the phases add up (profiles/r03_fp4_chain_stages.txt).  What CAN overlap on this machine is
+// memory latency with MFMA issue -- not instruction issue: while a SIMD's matrix pipe is busy, neither the issuing wave nor
+// its SIMD partner gets VALU or vector-memory instructions through (tools/mfma_interference_ubench.hip: a partner's VALU chain
+// runs at one instruction per ~180 cycles beside a saturating MFMA stream; the MFMA wave itself keeps 95 % of the pipe alone).
+// So: ONE wave per SIMD (4-wave workgroups, 512 registers per lane) owns 4 tiles and issues the loads of tile t + 1 between
+// the MFMA steps of tile t, a column chunk at a time (12 x 16 B per lane), blending a chunk into the layer-1 accumulator
+// ~24 steps (6 k cycles) after its loads went out.  Column tile c of that accumulator is dead once layer 2 has consumed its 16
+// steps, and is rebuilt in place (zero, skip-link MFMAs, blend): no second copy.  The first tile's gather overlaps the weight
+// staging; exposed are its tail and the last tile's store.
+// compile-time loop: f(integral_constant<int, 0>) ... f(integral_constant<int, N - 1>), unrolled by construction (a `#pragma
+// unroll` over a body of this size is declined by the unroller, and a rolled loop indexes the accumulators dynamically)
+template <int... I, class F>
+__device__ __forceinline__ void static_for_impl(std::integer_sequence<int, I...>, F&& f) { (f(std::integral_constant<int, I>{}), ...); }
+template <int N, class F>
+__device__ __forceinline__ void static_for(F&& f) { static_for_impl(std::make_integer_sequence<int, N>{}, f); }
+
+constexpr int kPipeSkipSteps = 4;  // skip-link channels c1 <= 8 (two per MFMA step)
+// NS: skip-link MFMA steps executed per column tile (2: c1 <= 4, the FP4 layer; 4: c1 <= 8).  Steps beyond (c1 + 1) / 2 multiply
+// zero-filled weight rows by zero values: no run-time branch around an accumulator update (a branch there turns every
+// 16-register accumulator tuple into a phi of two paths, and the compiler then moves whole tuples around at each merge).
+
+template <int NT2, int NT3, int NS>
+__global__ void __launch_bounds__(256, 1)
+fp_chain_pipe_kernel(SaFusedParams p) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    constexpr int NW = 4, NTH = 256, NT1 = 4;
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int half = lane >> 5;
+    const int l31 = lane & 31;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    constexpr int W1 = NT1 * 32, W2 = NT2 * 32, W3 = NT3 * 32;
+    static_assert(NT2 == 4 && NT3 == 4, "side-job schedule written for three 128-wide layers");
+    const int c1 = p.c1;
+    constexpr int steps1 = NS;  // rows beyond the c1 skip-link channels are staged as zeros (l1_chan -> -1)
+    float* wp1 = smem;
+    float* wp2 = wp1 + steps1 * 2 * W1;
+    float* wp3 = wp2 + W1 * W2;
+    float* sb1 = wp3 + W2 * W3;
+    float* sb2 = sb1 + W1;
+    float* sb3 = sb2 + W2;
+    int tile_no = 0;
+    (void)tile_no;
+    PN2_CHAIN_STAMP(0);
+#ifdef PN2_TUNING_HOOKS
+    const long long t_begin = (long long)__builtin_readcyclecounter();
+    const long long t_real0 = (long long)__builtin_amdgcn_s_memrealtime();
+#endif
+    // XCD-aware tile order, as sa_fused_kernel
+    int g_lo = blockIdx.x * NW + wave, g_hi = p.groups, g_step = gridDim.x * NW;
+    if ((gridDim.x & 7u) == 0u && (p.groups & 7) == 0) {
+        const int per = p.groups >> 3, xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+        g_lo = xcd * per + slot * NW + wave;
+        g_hi = (xcd + 1) * per;
+        g_step = (gridDim.x >> 3) * NW;
+    }
+    const bool any_tile = g_lo < g_hi;
+    const float* w1l = wp1 + half * W1 + l31;
+    const float* w2l = wp2 + half * W2 + l31;
+    const float* w3l = wp3 + half * W3 + l31;
+
+    // ---- front end of a tile, in slices.  fi / fd / fsk: raw loads; fw*: blend weights; fz*: this lane's three rows of z
+    int fi0 = 0, fi1 = 0, fi2 = 0;
+    float fd0 = 0.f, fd1 = 0.f, fd2 = 0.f, fw1 = 0.f, fw2 = 0.f, fw3 = 0.f;
+    float fsk[NS];
+    size_t frow = 0;
+    const f32x4* __restrict__ fz1 = nullptr;
+    const f32x4* __restrict__ fz2 = nullptr;
+    const f32x4* __restrict__ fz3 = nullptr;
+    auto front_issue = [&](int g) {  // indices, distances, skip-link values: 6 + NS loads per lane
+        const int row = g * 32 + l31;
+        frow = (size_t)(row < p.rows ? row : p.rows - 1);
+        const float* __restrict__ dr = p.dist + frow * 3;
+        const int* __restrict__ ir = p.idx + frow * 3;
+        fi0 = ir[0]; fi1 = ir[1]; fi2 = ir[2];
+        fd0 = dr[0]; fd1 = dr[1]; fd2 = dr[2];
+#pragma unroll
+        for (int sp = 0; sp < NS; ++sp) {
+            const int ch = 2 * sp + half;
+            fsk[sp] = ch < c1 ? p.points1[frow * c1 + ch] : 0.f;
+        }
+    };
+    auto front_weights = [&]() {  // inverse-distance weights exactly as fp_interp_concat_kernel (IEEE divisions)
+        const float d1 = fmaxf(fd0, 1e-10f), d2 = fmaxf(fd1, 1e-10f), d3 = fmaxf(fd2, 1e-10f);
+        const float r1 = 1.0f / d1, r2 = 1.0f / d2, r3 = 1.0f / d3;
+        const float norm = (r1 + r2) + r3;
+        fw1 = r1 / norm; fw2 = r2 / norm; fw3 = r3 / norm;
+        const size_t kb = (frow / (size_t)p.n) * (size_t)p.m;
+        fz1 = reinterpret_cast<const f32x4*>(p.points + (kb + fi0) * W1) + half;
+        fz2 = reinterpret_cast<const f32x4*>(p.points + (kb + fi1) * W1) + half;
+        fz3 = reinterpret_cast<const f32x4*>(p.points + (kb + fi2) * W1) + half;
+    };
+    auto chunk_issue = [&](int nt, f32x4 (&q1)[4], f32x4 (&q2)[4], f32x4 (&q3)[4]) {
+#pragma unroll
+        for (int rq = 0; rq < 4; ++rq) {  // float4 index of channel 32 nt + 8 rq + 4 half
+            q1[rq] = fz1[nt * 8 + rq * 2]; q2[rq] = fz2[nt * 8 + rq * 2]; q3[rq] = fz3[nt * 8 + rq * 2];
+        }
+    };
+    auto chunk_blend = [&](f32x16& ax, const f32x4 (&q1)[4], const f32x4 (&q2)[4], const f32x4 (&q3)[4]) {
+#pragma unroll
+        for (int rq = 0; rq < 4; ++rq) {
+            const f32x4 cur = (q1[rq] * fw1 + q2[rq] * fw2) + q3[rq] * fw3;  // tf_interpolate.cpp:322-324 order, unfused
+#pragma unroll
+            for (int e = 0; e < 4; ++e) ax[4 * rq + e] += cur[e];
+        }
+    };
+    const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+
+    // ---- first tile: its gather goes out BEFORE the weight staging and lands while the 128 KB of weights are staged
+    f32x4 pq1[NT1][4], pq2[NT1][4], pq3[NT1][4];
+    if (any_tile) {
+        front_issue(g_lo);
+        front_weights();
+#pragma unroll
+        for (int nt = 0; nt < NT1; ++nt) chunk_issue(nt, pq1[nt], pq2[nt], pq3[nt]);
+    }
+    // ---- weight staging: the layout of sa_fused_kernel (PREZ: layer 1 holds the skip-link rows only)
+    auto stage4 = [&](float* dst, int count4, const float* __restrict__ src, auto index_of) {
+        for (int base = 0; base < count4; base += NTH * 8) {
+            f32x4 v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int e = base + u * NTH + tid;
+                const int gi = e < count4 ? index_of(e) : -1;
+                const f32x4 t = *reinterpret_cast<const f32x4*>(src + (gi >= 0 ? gi : 0));
+                const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+                v[u] = gi >= 0 ? t : z;
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int e = base + u * NTH + tid;
+                if (e < count4) *reinterpret_cast<f32x4*>(dst + e * 4) = v[u];
+            }
+        }
+    };
+    auto stage1 = [&](float* dst, int count, const float* __restrict__ src) {
+        for (int e = tid; e < count; e += NTH) dst[e] = src[e];
+    };
+    stage4(wp1, steps1 * 2 * W1 / 4, p.W[0], [&](int e4) {
+        const int col = (e4 % (W1 / 4)) * 4, sh = e4 / (W1 / 4);
+        const int ch = l1_chan(sh >> 1, sh & 1, 0, true, true, c1);
+        return ch >= 0 ? ch * W1 + col : -1;
+    });
+    stage1(sb1, W1, p.bias[0]);
+    stage4(wp2, W1 * W2 / 4, p.W[1], [&](int e4) {
+        const int col = (e4 % (W2 / 4)) * 4, sh = e4 / (W2 / 4);
+        const int s = sh >> 1, h = sh & 1;
+        return ((s >> 4) * 32 + acc_chan(s & 15, h)) * W2 + col;
+    });
+    stage1(sb2, W2, p.bias[1]);
+    stage4(wp3, W2 * W3 / 4, p.W[2], [&](int e4) {
+        const int col = (e4 % (W3 / 4)) * 4, sh = e4 / (W3 / 4);
+        const int s = sh >> 1, h = sh & 1;
+        return ((s >> 4) * 32 + acc_chan(s & 15, h)) * W3 + col;
+    });
+    stage1(sb3, W3, p.bias[2]);
+    __syncthreads();
+    PN2_CHAIN_STAMP(1);
+    if (!any_tile) return;
+
+    f32x16 a1[NT1];  // layer-1 accumulators of the CURRENT tile during layer 2; rebuilt column tile by column tile for the NEXT
+    PN2_CHAIN_STAMP(2);
+#pragma unroll
+    for (int nt = 0; nt < NT1; ++nt) {
+#pragma unroll
+        for (int sp = 0; sp < NS; ++sp) {
+            if (sp == 0) a1[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(w1l[sp * 2 * W1 + nt * 32], fsk[sp], zero16, 0, 0, 0);
+            else a1[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(w1l[sp * 2 * W1 + nt * 32], fsk[sp], a1[nt], 0, 0, 0);
+        }
+        chunk_blend(a1[nt], pq1[nt], pq2[nt], pq3[nt]);
+    }
+
+    for (int g = g_lo; g < g_hi; g += g_step) {
+        const int gnx = g + g_step;
+        const int gn = gnx < g_hi ? gnx : g;  // the last tile rebuilds a1 for itself again: cached loads, a result nobody reads
+        f32x16 a2[NT2], a3[NT3];
+        f32x4 q1[4], q2[4], q3[4];  // one column chunk of the next tile's z gather in flight
+        if (tile_no > 0) PN2_CHAIN_STAMP(2);
+        PN2_CHAIN_STAMP(3);
+        // side job of MFMA step s (0..63 layer 2, 64..127 layer 3): the next tile's front end.  Chunk c: loads at LS, a1[c] zeroed
+        // by the first skip-link MFMA (C = 0) at ZS >= 16 (c + 1) (layer 2 has consumed a1[c]), blend at BS
+        auto side = [&](auto s_c) __attribute__((always_inline)) {
+            constexpr int s = decltype(s_c)::value;
+            constexpr int LS[4] = {13, 38, 63, 88}, ZS[4] = {25, 40, 64, 90}, BS[4] = {37, 62, 87, 112};
+            if constexpr (s == 0) front_issue(gn);
+            if constexpr (s == 10) front_weights();
+            static_for<4>([&](auto c_c) __attribute__((always_inline)) {
+                constexpr int c = decltype(c_c)::value;
+                if constexpr (s == LS[c]) chunk_issue(c, q1, q2, q3);
+                if constexpr (s == ZS[c]) {
+#pragma unroll
+                    for (int sp = 0; sp < NS; ++sp) {
+                        if (sp == 0) a1[c] = __builtin_amdgcn_mfma_f32_32x32x2f32(w1l[sp * 2 * W1 + c * 32], fsk[sp], zero16, 0, 0, 0);
+                        else a1[c] = __builtin_amdgcn_mfma_f32_32x32x2f32(w1l[sp * 2 * W1 + c * 32], fsk[sp], a1[c], 0, 0, 0);
+                    }
+                }
+                if constexpr (s == BS[c]) chunk_blend(a1[c], q1, q2, q3);
+            });
+        };
+        bias_relu_T<NT1>(a1, sb1, half);
+        {
+            float wq[kPF][NT2];
+#pragma unroll
+            for (int pf = 0; pf < kPF; ++pf) load_w<NT2>(wq[pf], w2l + pf * 2 * W2);
+            static_for<NT1 * 16>([&](auto s_c) __attribute__((always_inline)) {
+                constexpr int s = decltype(s_c)::value;
+#pragma unroll
+                for (int nt = 0; nt < NT2; ++nt) {
+                    if constexpr (s == 0) a2[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(wq[s % kPF][nt], a1[s >> 4][s & 15], zero16, 0, 0, 0);
+                    else a2[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(wq[s % kPF][nt], a1[s >> 4][s & 15], a2[nt], 0, 0, 0);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                if constexpr (s + kPF < NT1 * 16) load_w<NT2>(wq[s % kPF], w2l + (s + kPF) * 2 * W2);
+                __builtin_amdgcn_sched_barrier(0);
+                side(std::integral_constant<int, s>{});
+                __builtin_amdgcn_sched_barrier(0);
+            });
+        }
+        PN2_CHAIN_STAMP(4);
+        bias_relu_T<NT2>(a2, sb2, half);
+        {
+            float wq[kPF][NT3];
+#pragma unroll
+            for (int pf = 0; pf < kPF; ++pf) load_w<NT3>(wq[pf], w3l + pf * 2 * W3);
+            static_for<NT2 * 16>([&](auto s_c) __attribute__((always_inline)) {
+                constexpr int s = decltype(s_c)::value;
+#pragma unroll
+                for (int nt = 0; nt < NT3; ++nt) {
+                    if constexpr (s == 0) a3[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a2[s >> 4][s & 15], wq[s % kPF][nt], zero16, 0, 0, 0);
+                    else a3[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a2[s >> 4][s & 15], wq[s % kPF][nt], a3[nt], 0, 0, 0);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                if constexpr (s + kPF < NT2 * 16) load_w<NT3>(wq[s % kPF], w3l + (s + kPF) * 2 * W3);
+                __builtin_amdgcn_sched_barrier(0);
+                side(std::integral_constant<int, NT1 * 16 + s>{});
+                __builtin_amdgcn_sched_barrier(0);
+            });
+        }
+        PN2_CHAIN_STAMP(5);
+        rows_store<NT3>(a3, sb3, p.out, W3, g * 32, p.rows, half, l31);
+        PN2_CHAIN_STAMP(6);
+        ++tile_no;
+    }
+#ifdef PN2_TUNING_HOOKS
+    if (p.stats && lane == 0) {  // every wave's whole-kernel cycles, and its XCC / CU (tools/chain_stage_ab.py)
+        p.stats[256 + blockIdx.x * NW + wave] = (long long)__builtin_readcyclecounter() - t_begin;
+        unsigned hwid;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
+        unsigned xcc;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+        p.stats[256 + 1024 + blockIdx.x * NW + wave] = ((long long)xcc << 32) | hwid;
+        p.stats[256 + 2048 + blockIdx.x * NW + wave] = (long long)__builtin_amdgcn_s_memrealtime();  // 100 MHz, chip-wide: end
+        p.stats[256 + 3072 + blockIdx.x * NW + wave] = t_real0;
+    }
+#endif
+}
+
 PN2_TUNABLE(int, g_chain_prio, 0)    // tuning hook (pn2_debug_set(13, v)): 1 = stagger the two waves of a SIMD (experiment, see the kernel)
 PN2_TUNABLE(long long*, g_chain_stats, nullptr)  // tuning hook: device buffer of 4 x 2 x 4 x 8 cycle stamps
 PN2_TUNABLE(int, g_chain_nw, 0)      // tuning hook (pn2_debug_set(7, v)): 16 = 16-wave workgroups for the single-layer kernels
+PN2_TUNABLE(int, g_chain_pipe, 1)    // tuning hook (pn2_debug_set(14, v)): 0 = the lockstep schedule for the FP4 chain (A/B)
 PN2_TUNABLE(int, g_chain_grid, 256)  // tuning hook (pn2_debug_set(6, v)): persistent workgroups of the 1-per-CU configuration
 
 template <int L, int NT1, int NT2, int NT3, bool VEC8, bool DENSE, bool POOL, bool INTERP = false, bool PREZ = false>
@@ -570,6 +835,28 @@ int launch_chain(const SaFusedParams& p_in, hipStream_t st) {
                 attr_set = true;
             }
             kern<<<g_chain_grid, 1024, bytes, st>>>(p);
+            PN2_RETURN_IF_LAUNCH_FAILED();
+            return PN2_OK;
+        }
+    }
+    if constexpr (L == 3 && INTERP && PREZ && DENSE && !POOL && NT1 == 4) {
+        // the software-pipelined schedule (bit-identical values): one wave per SIMD, 4 tiles per wave at the FP4 shape
+        const bool want_pipe = p.schedule < 0 ? g_chain_pipe != 0 : p.schedule == 1;
+        if (p.schedule == 1 && p.c1 > 2 * kPipeSkipSteps) return PN2_EUNSUP;
+        if (want_pipe && p.c1 <= 2 * kPipeSkipSteps && (p.groups >= 2048 || p.schedule == 1)) {
+            const bool ns2 = p.c1 <= 4;
+            auto kern = ns2 ? fp_chain_pipe_kernel<NT2, NT3, 2> : fp_chain_pipe_kernel<NT2, NT3, 4>;
+            static bool attr_set[2] = {false, false};
+            if (!attr_set[ns2]) {
+                hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                                   hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+                if (e != hipSuccess) return (int)e;
+                attr_set[ns2] = true;
+            }
+            const size_t pbytes = ((size_t)(ns2 ? 2 : 4) * 2 * W1 + W1 + (size_t)W1 * W2 + W2 + (size_t)W2 * W3 + W3) * sizeof(float);
+            int grid = g_chain_grid;
+            if (grid > need4) grid = need4;
+            kern<<<grid, 256, pbytes, st>>>(p);
             PN2_RETURN_IF_LAUNCH_FAILED();
             return PN2_OK;
         }
@@ -639,6 +926,7 @@ extern "C" int pn2_debug_set_fused(int what, int value) {
     if (what == 6) { g_chain_grid = value; return 0; }
     if (what == 7) { g_chain_nw = value; return 0; }
     if (what == 13) { g_chain_prio = value; return 0; }
+    if (what == 14) { g_chain_pipe = value; return 0; }
     return PN2_EINVAL;
 }
 #endif  // PN2_TUNING_HOOKS
@@ -680,6 +968,7 @@ static int sa_fused_impl(int b, int n, int m, int nsample, int c, const float* x
     if (kshift == 4 && (((long long)b * m) & 1)) return PN2_EUNSUP;
     if ((long long)b * m * nsample > 0x7fffffffLL - 64) return PN2_ERANGE;
     SaFusedParams p{};
+    p.schedule = -1;
     p.n = n; p.m = m; p.c = c; p.kshift = kshift;
     p.groups = (int)(((long long)b * m * nsample) / 32); p.rows = p.groups * 32;
     p.xyz = xyz; p.new_xyz = new_xyz; p.points = points; p.idx = idx; p.out = out;
@@ -741,6 +1030,7 @@ extern "C" int pn2_mlp_chain(int rows, int cin, const float* x, int nlayers, con
     if (nlayers > 2 || (pool != 0 && pool != 32)) return PN2_EUNSUP;
     if (pool == 32 && rows % 32 != 0) return PN2_EINVAL;
     SaFusedParams p{};
+    p.schedule = -1;
     p.c = cin; p.rows = rows; p.groups = (rows + 31) / 32;
     p.points = x; p.out = y;
     int nt[2] = {0, 0};
@@ -786,6 +1076,7 @@ extern "C" int pn2_fp_mlp_fused(int b, int n, int m, int c1, int c2, const float
     if ((long long)b * n > 0x7fffffffLL - 32) return PN2_ERANGE;
     if (nlayers > 2 || c2 % 8 != 0 || (uintptr_t)points2 % 16 != 0) return PN2_EUNSUP;
     SaFusedParams p{};
+    p.schedule = -1;
     p.n = n; p.m = m; p.c = c2; p.c1 = c1; p.rows = b * n; p.groups = (b * n + 31) / 32;
     p.points = points2; p.points1 = points1; p.dist = dist; p.idx = idx; p.out = y;
     int nt[2] = {0, 0};
@@ -812,14 +1103,37 @@ extern "C" int pn2_fp_mlp_fused(int b, int n, int m, int c1, int c2, const float
 // layers (2 or 3); the chain after the front end is LDS-resident as in pn2_fp_mlp_fused.
 // Values: interp(points2) @ W1a == interp(points2 @ W1a) exactly in real arithmetic; in fp32 the two orders differ by
 // rounding only (1e-7 of the activation scale; tests/test_layers_gpu.py holds both to the fp64 oracle at 1e-5).
+static int fp_mlp_fused_pre_impl(int b, int n, int m, int c1, const float* dist, const int* idx, const float* points1,
+                                 const float* z, int nlayers, const int* widths, const float* const* w,
+                                 const float* const* bias, float* y, int schedule, void* stream);
+
 extern "C" int pn2_fp_mlp_fused_pre(int b, int n, int m, int c1, const float* dist, const int* idx, const float* points1,
                                     const float* z, int nlayers, const int* widths, const float* const* w,
                                     const float* const* bias, float* y, void* stream) {
+    return fp_mlp_fused_pre_impl(b, n, m, c1, dist, idx, points1, z, nlayers, widths, w, bias, y, -1, stream);
+}
+
+// The same call with the kernel SCHEDULE named by the caller (stateless door for the parity tests and A/B timing):
+// 0 = the lockstep kernel (8 waves per workgroup: gather, then MFMA layers, then store), 1 = the software-pipelined kernel
+// (one wave per SIMD builds the next tile's first-layer accumulator between the MFMA groups of the current tile; three
+// 128-wide layers, c1 <= 8: PN2_EUNSUP otherwise).  Both produce the same bits.
+extern "C" int pn2_fp_mlp_fused_pre_schedule(int b, int n, int m, int c1, const float* dist, const int* idx,
+                                             const float* points1, const float* z, int nlayers, const int* widths,
+                                             const float* const* w, const float* const* bias, float* y, int schedule,
+                                             void* stream) {
+    if (schedule != 0 && schedule != 1) return PN2_EINVAL;
+    return fp_mlp_fused_pre_impl(b, n, m, c1, dist, idx, points1, z, nlayers, widths, w, bias, y, schedule, stream);
+}
+
+static int fp_mlp_fused_pre_impl(int b, int n, int m, int c1, const float* dist, const int* idx, const float* points1,
+                                 const float* z, int nlayers, const int* widths, const float* const* w,
+                                 const float* const* bias, float* y, int schedule, void* stream) {
     if (b <= 0 || n <= 0 || m <= 0 || c1 < 0 || nlayers <= 0) return PN2_EINVAL;
     if (!dist || !idx || !z || !widths || !w || !bias || !y || (c1 > 0 && (!points1 || !w[0]))) return PN2_ENULL;
     if ((long long)b * n > 0x7fffffffLL - 32) return PN2_ERANGE;
     if (nlayers < 2 || nlayers > 3 || (uintptr_t)z % 16 != 0) return PN2_EUNSUP;
     SaFusedParams p{};
+    p.schedule = schedule;
     p.n = n; p.m = m; p.c = widths[0]; p.c1 = c1; p.rows = b * n; p.groups = (b * n + 31) / 32;
     p.points = z; p.points1 = points1; p.dist = dist; p.idx = idx; p.out = y;
     int nt[3] = {0, 0, 0};
@@ -833,7 +1147,7 @@ extern "C" int pn2_fp_mlp_fused_pre(int b, int n, int m, int c1, const float* di
     hipStream_t st = static_cast<hipStream_t>(stream);
     switch (nlayers * 1000 + nt[0] * 100 + nt[1] * 10 + nt[2]) {
         case 3444: return launch_chain<3, 4, 4, 4, true, true, false, true, true>(p, st);  // FP4 of semantic.json: 131 -> 128 -> 128 -> 128
-        case 2440: return launch_chain<2, 4, 4, 1, true, true, false, true, true>(p, st);
+        case 2440: return schedule == 1 ? PN2_EUNSUP : launch_chain<2, 4, 4, 1, true, true, false, true, true>(p, st);
         default: return PN2_EUNSUP;
     }
 }
@@ -850,6 +1164,7 @@ extern "C" int pn2_sa_mlp_fused_pre(int b, int n, int m, int nsample, const floa
     if (nlayers > 3 || nsample != 32 || (uintptr_t)zf % 16 != 0) return PN2_EUNSUP;
     if ((long long)b * m * nsample > 0x7fffffffLL - 64) return PN2_ERANGE;
     SaFusedParams p{};
+    p.schedule = -1;
     p.n = n; p.m = m; p.c = widths[0]; p.kshift = 5;
     p.groups = (int)(((long long)b * m * nsample) / 32); p.rows = p.groups * 32;
     p.xyz = xyz; p.new_xyz = new_xyz; p.points = zf; p.idx = idx; p.out = out;

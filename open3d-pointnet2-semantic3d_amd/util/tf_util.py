@@ -465,12 +465,14 @@ def split_first_layer(w2, c2, c1, key, pad_b_rows=None):
     return st.folded((_full_name("split"), key, c2, c1, pad_b_rows), [w2], make)
 
 
-def hip_fp_mlp_fused_pre(dist, idx, points1, points2, ws, bs):
+def hip_fp_mlp_fused_pre(dist, idx, points1, points2, ws, bs, schedule=None):
     """The FP block with the first layer's product hoisted out by linearity (pn2_fp_mlp_fused_pre):
     interp(points2) @ W1a == interp(points2 @ W1a), and Z = points2 @ W1a has the m KNOWN rows per cloud instead of the n
     unknown ones (8x fewer at every level of semantic.json).  Z is one pn2_linear call (no bias, no activation); the fused
     kernel blends three gathered rows of Z straight into its layer-1 accumulators and only the skip-link channels still
     go through the MFMA.  ws[0] = the folded first-layer weight ((c2 + c1 [+ pad]) x w1), 2 or 3 layers, all <= 128 wide.
+    schedule (tests, A/B): 0 = the lockstep kernel, 1 = the software-pipelined one (pn2_fp_mlp_fused_pre_schedule); None = the
+    library's choice.  Same bits either way.
     Returns (b*n, w_last), or None when the library reports the configuration as unsupported."""
     import ctypes
     from .._lib import PN2_EUNSUP
@@ -490,9 +492,13 @@ def hip_fp_mlp_fused_pre(dist, idx, points1, points2, ws, bs):
     bptrs = (ctypes.c_void_p * L)(*[bb.data_ptr() for bb in bs])
     y = torch.empty((b * n, ws[-1].shape[1]), dtype=torch.float32, device=dist.device)
     with torch.cuda.device(dist.device):
-        rc = lib.pn2_fp_mlp_fused_pre(b, n, m, c1, ptr(dist.contiguous()), ptr(idx.contiguous()), ptr(p1), ptr(z), L,
-                                      ctypes.cast(widths, ctypes.c_void_p), ctypes.cast(wptrs, ctypes.c_void_p),
-                                      ctypes.cast(bptrs, ctypes.c_void_p), ptr(y), stream_ptr())
+        common = (b, n, m, c1, ptr(dist.contiguous()), ptr(idx.contiguous()), ptr(p1), ptr(z), L,
+                  ctypes.cast(widths, ctypes.c_void_p), ctypes.cast(wptrs, ctypes.c_void_p),
+                  ctypes.cast(bptrs, ctypes.c_void_p), ptr(y))
+        if schedule is None:
+            rc = lib.pn2_fp_mlp_fused_pre(*common, stream_ptr())
+        else:
+            rc = lib.pn2_fp_mlp_fused_pre_schedule(*common, int(schedule), stream_ptr())
     if rc == PN2_EUNSUP:
         return None
     check(rc, "pn2_fp_mlp_fused_pre")

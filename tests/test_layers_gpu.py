@@ -694,6 +694,44 @@ def test_fp_mlp_fused_vs_oracle(pn2, oracle, cuda, b, n, m, c1, c2, widths):
     close(y.cpu().numpy(), ref)
 
 
+@pytest.mark.parametrize("b,n,m,c1", [(16, 8192, 1024, 3), (3, 1000, 128, 0), (2, 2048, 256, 8), (1, 4099, 300, 5), (5, 97, 16, 1)])
+def test_fp_chain_pipelined_schedule_is_bit_identical_to_the_lockstep_kernel(pn2, oracle, cuda, b, n, m, c1):
+    """the software-pipelined FP4 chain (one wave per SIMD gathers the next tile's rows of z between the MFMA
+    groups of the current tile) against the lockstep kernel it replaces: torch.equal -- same MFMA order, same blend
+    expression, another schedule -- at the FP4 shape of configs[1] (16 x 8192 rows, 131 -> 128 -> 128 -> 128), at ragged row
+    counts (last tile partly out of range, fewer tiles than waves) and skip-link widths 0..8; and within 1e-5 of fp64."""
+    import torch
+    tfu = pn2.util.tf_util
+    rs = np.random.RandomState(n + c1)
+    xyz1 = rs.random_sample((b, n, 3)).astype(np.float32)
+    xyz2 = xyz1[:, rs.permutation(n)[:m]].copy()      # known points are a subset: zero distances, the 1e-10 clamp
+    c2 = 256
+    p1 = rs.randn(b, n, c1).astype(np.float32) if c1 else None
+    p2 = rs.randn(b, m, c2).astype(np.float32)
+    dist, idx = pn2.three_nn(T(xyz1, cuda), T(xyz2, cuda))
+    ws, bs, c = [], [], c1 + c2
+    for w_ in (128, 128, 128):
+        ws.append(T((rs.randn(c, w_) / np.sqrt(c)).astype(np.float32), cuda))
+        bs.append(T((rs.randn(w_) * 0.1).astype(np.float32), cuda))
+        c = w_
+    args = (dist, idx, None if p1 is None else T(p1, cuda), T(p2, cuda), ws, bs)
+    y0 = tfu.hip_fp_mlp_fused_pre(*args, schedule=0)
+    y1 = tfu.hip_fp_mlp_fused_pre(*args, schedule=1)
+    yd = tfu.hip_fp_mlp_fused_pre(*args)              # the library's own choice
+    assert y0 is not None and y1 is not None and yd is not None
+    assert torch.equal(y0, y1) and torch.equal(yd, y0)
+    if b * n <= 40000:
+        x = oracle.three_interpolate(p2, idx.cpu().numpy(), oracle.fp_weights(dist.cpu().numpy()))
+        if c1:
+            x = np.concatenate([x, p1], axis=2)
+        ref = x.reshape(b * n, c1 + c2).astype(np.float64)
+        for W, bb in zip(ws, bs):
+            ref = np.maximum(ref @ W.cpu().numpy().astype(np.float64) + bb.cpu().numpy(), 0)
+        close(y1.cpu().numpy(), ref)
+    # two 128-wide layers only / skip link wider than 8 channels: the pipelined kernel says so
+    assert tfu.hip_fp_mlp_fused_pre(dist, idx, args[2], args[3], ws[:2], bs[:2], schedule=1) is None
+
+
 def test_fp_mlp_fused_rejects_unsupported(pn2, cuda):
     import torch
     tfu = pn2.util.tf_util
