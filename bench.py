@@ -626,10 +626,6 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--eager", action="store_true", help="launch from Python instead of replaying a hipGraph")
     ap.add_argument("--one-stream", action="store_true", help="(default since r01q; kept for old scripts)")
-    ap.add_argument("--two-streams", action="store_true",
-                    help="capture the geometry chain and the MLP chain of a batch on two streams inside its graph "
-                         "(measured: no gain for one batch, -25%% throughput with several batches in flight: "
-                         "profiles/r01_stream_queue_sweep.txt)")
     ap.add_argument("--pipeline", type=int, default=4, help="independent batches in flight (graphs replayed round-robin)")
     ap.add_argument("--no-north-star", action="store_true")
     ap.add_argument("--no-other-configs", action="store_true", help="skip the configs[2] / [3]@1gpu / [4] sub-results")
@@ -727,7 +723,7 @@ def main():
         # round-robin on P streams), so one batch's latency-bound FPS (16 CUs) overlaps the MFMA
         # layers of the previous batch.  Every step is still one full forward over one batch.
         P = max(1, args.pipeline)
-        fwd = lambda x: pn2.model.get_sa_fp_features(x, False, hp, two_streams=args.two_streams)[0]  # noqa: E731
+        fwd = lambda x: pn2.model.get_sa_fp_features(x, False, hp)[0]  # noqa: E731
         batches = [pc] + [torch.from_numpy(s_scene(2000 + 10 * rank + i, B, N)).to(dev) for i in range(1, P)]
         caps = [pn2.runtime.CapturedForward(fwd, b_) for b_ in batches]
         streams = [torch.cuda.Stream() for _ in range(P)]
@@ -813,7 +809,7 @@ def main():
                        "arith_mode": {"fps": int(pn2.config.fps_mode()), "ball_query": int(pn2.config.bq_mode()),
                                       "pinned_to": "oracle/_ref fast_noslp build of the reference's own kernels (contraction on)"},
                        "launch": "eager python launches" if args.eager else "one hipGraph replay per step",
-                       "streams_per_batch": 2 if (args.two_streams and not args.eager) else 1,
+                       "streams_per_batch": 1,
                        "batches_in_flight": P_eff,
                        "fp_front": "fused" if fused_fp else "materialised"},
             "regimes": {

@@ -35,57 +35,6 @@ def load_hyperparams(path):
         return json.load(f)
 
 
-_geo_streams = {}
-
-
-def _geometry_stream(device):
-    key = (device.type, device.index)
-    if key not in _geo_streams:
-        _geo_streams[key] = torch.cuda.Stream(device=device)
-    return _geo_streams[key]
-
-
-def _sa_fp_features_two_streams(l0_xyz, l0_points, hyperparams):
-    """Inference forward with the geometry chain on its own HIP stream.
-
-    FPS, gather, ball query and three_nn of every level depend only on coordinates.  They run
-    back-to-back on a side stream (FPS is a long latency-bound kernel that occupies 16 of the 256
-    CUs) while the main stream runs the MFMA layers of the levels whose geometry is already done;
-    events order the two chains level by level.  Under hipGraph capture this becomes a two-branch
-    graph.  Numerically identical to the sequential path (same kernels, same inputs)."""
-    main = torch.cuda.current_stream()
-    geo = _geometry_stream(l0_xyz.device)
-    geo.wait_stream(main)
-    xyzs, idxs, nn, ev_sa, ev_nn = [l0_xyz], [], [None] * 4, [], [None] * 4
-    with torch.cuda.stream(geo):
-        for li in range(4):
-            k = "l%d_" % (li + 1)
-            new_xyz, idx = pu.sa_geometry(xyzs[-1], hyperparams[k + "npoint"], hyperparams[k + "radius"],
-                                          hyperparams[k + "nsample"])
-            xyzs.append(new_xyz)
-            idxs.append(idx)
-            ev = torch.cuda.Event()
-            ev.record(geo)
-            ev_sa.append(ev)
-        for fi in range(4):  # coarse-to-fine, the order the FP layers consume them
-            lvl = 3 - fi
-            nn[fi] = three_nn(xyzs[lvl], xyzs[lvl + 1])
-            ev = torch.cuda.Event()
-            ev.record(geo)
-            ev_nn[fi] = ev
-    feats = [l0_points]
-    for li in range(4):
-        main.wait_event(ev_sa[li])
-        with tf_util.variable_scope("layer%d" % (li + 1)):
-            feats.append(pu.sa_features_inference(xyzs[li], xyzs[li + 1], feats[li], idxs[li], list(SA_MLPS[li])))
-    up = feats[4]
-    for fi in range(4):
-        lvl = 3 - fi
-        main.wait_event(ev_nn[fi])
-        with tf_util.variable_scope("fa_layer%d" % (fi + 1)):
-            up = pu.fp_features_inference(nn[fi][0], nn[fi][1], feats[lvl], up, list(FP_MLPS[fi]))
-    main.wait_stream(geo)
-    return up, xyzs
 
 
 def compute_geometry(l0_xyz, hyperparams, plans=False):
@@ -132,10 +81,9 @@ def clone_geometry(geo, l0_xyz):
             "gplans": [cl(t) for t in geo.get("gplans", [None] * 4)], "iplans": [cl(t) for t in geo.get("iplans", [None] * 4)]}
 
 
-def get_sa_fp_features(point_cloud, is_training, hyperparams, bn_decay=None, two_streams=False, geometry=None,
+def get_sa_fp_features(point_cloud, is_training, hyperparams, bn_decay=None, geometry=None,
                        head_width=0, cut_sa_fp=False):
     """point_cloud (B,N,3 or 6) -> l0_points (B,N,128) and end_points.
-    two_streams (inference only): overlap the geometry chain with the MLP chain.
     geometry (extension): compute_geometry(l0_xyz) of this very batch, computed ahead.
     head_width (extension, training; get_model passes 128): the result goes to ONE batch-normalised layer of that width and
     nowhere else, so the last FP layer may hand over its un-normalised output (pointnet_fp_module defer_last_bn).
@@ -153,11 +101,6 @@ def get_sa_fp_features(point_cloud, is_training, hyperparams, bn_decay=None, two
         l0_xyz = point_cloud.contiguous()
         l0_points = None
     end_points["l0_xyz"] = l0_xyz
-    if two_streams and not is_training:
-        up, xyzs = _sa_fp_features_two_streams(l0_xyz, l0_points, hyperparams)
-        end_points["xyzs"] = xyzs
-        return up, end_points
-
     xyzs, feats = [l0_xyz], [l0_points]
     for li in range(4):
         k = "l%d_" % (li + 1)

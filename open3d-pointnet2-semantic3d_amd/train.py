@@ -43,7 +43,7 @@ class Trainer:
 
     BETA1, BETA2, EPS = 0.9, 0.999, 1e-8  # tf.train.AdamOptimizer defaults (train.py:381-384)
 
-    def __init__(self, hyperparams, num_class, store=None, device="cuda", capture=True, warmup_eager=3, geometry_in_graph=False,
+    def __init__(self, hyperparams, num_class, store=None, device="cuda", capture=True, warmup_eager=3,
                  split_capture=None, overlap_collective=True):
         self.hp = dict(hyperparams)
         # schedule / optimizer keys of the reference's semantic.json (train.py:80-119, 380-386); its defaults when absent
@@ -62,10 +62,6 @@ class Trainer:
         self.capture, self.warmup_eager = bool(capture), int(warmup_eager)
         self._graph, self._graph_decay, self._static, self._stream = None, None, None, None
         self._static_geo, self._geo, self._geo_tag, self._geo_event, self._geo_stream = None, None, None, None, None
-        # geometry_in_graph (option, captured steps only): the NEXT batch's geometry chain as a branch of the step's own graph,
-        # written to `_static_geo_next`; `_next_tag` names the batch it belongs to.  Measured equal to the default (eager
-        # launches on a side stream): the 0.27 ms between graphs shrink to 0.06, the graph itself grows from 4.48 to 4.67 ms.
-        self.geometry_in_graph = bool(geometry_in_graph)
         # split_capture: the step as TWO graphs -- forward + backward (gradients packed, no collective inside), then Adam --
         # with the gradient all-reduce launched between them: how a step is captured when there are several ranks (a
         # collective inside a captured backward pass is avoided).  None = when world > 1; True forces it (tests).
@@ -76,7 +72,6 @@ class Trainer:
         # ONE all-reduce of the whole flat gradient.
         self.overlap_collective = bool(overlap_collective)
         self._graph_adam, self._graph_late = None, None
-        self._static_geo_next, self._static_next_xyz, self._next_tag = None, None, None
         # comm_events (bench.py --train): a list that receives, per captured multi-rank step, three HIP events on the
         # trainer's stream: early bucket launched | SA backward graph done | both buckets reduced
         self.comm_events = None
@@ -263,11 +258,8 @@ class Trainer:
             # page" around the 13th replay; a device-wide synchronise in between hid it).
             self._stream.wait_stream(caller)
             with torch.cuda.stream(self._stream):
-                tag = self._tag(pc)
                 recapture = self._graph is None or self._graph_decay != decay or self._static[0].shape != pc.shape
-                geo = None
-                if recapture or not self.geometry_in_graph or self._next_tag != tag:
-                    geo = self._geometry_for(pc, self._stream)  # eager (or eagerly prefetched: prefetch_geometry)
+                geo = self._geometry_for(pc, self._stream)  # eager (or eagerly prefetched: prefetch_geometry)
                 if recapture:
                     self._capture(pc, labels, smpw, decay, geo, split)
                 self._lr_slot.fill_(lr_t)
@@ -279,24 +271,12 @@ class Trainer:
                 for d, s_ in zip(self._static[:3], (pc, labels, smpw)):
                     if d.data_ptr() != s_.data_ptr() and not (s_.is_contiguous() and s_.dtype == d.dtype):
                         d.copy_(s_, non_blocking=True)
-                if self.geometry_in_graph:
-                    # the graph starts with (this batch's geometry) <- `_static_geo_next`, which the previous replay's branch
-                    # filled when this batch was announced as its `next_pc`; otherwise it is filled here
-                    if geo is not None and not recapture:
-                        pairs += list(zip(model.geometry_tensors(self._static_geo_next), model.geometry_tensors(geo)))
-                    if next_pc is not None:
-                        self._static_next_xyz.copy_(next_pc[:, :, 0:3] if self.hp["use_color"] else next_pc, non_blocking=True)
-                        self._next_tag = self._tag(next_pc)
-                    else:
-                        self._next_tag = None  # the branch recomputes the geometry of a stale cloud: harmless
-                else:
-                    pairs += list(zip(model.geometry_tensors(self._static_geo), model.geometry_tensors(geo)))
+                pairs += list(zip(model.geometry_tensors(self._static_geo), model.geometry_tensors(geo)))
                 if pairs:
                     tf_util.multi_copy_([d for d, _ in pairs], [s_ for _, s_ in pairs])
-                if not self.geometry_in_graph:
-                    taken = torch.cuda.Event()
-                    taken.record(self._stream)
-                    self._prefetch(next_pc, taken)
+                taken = torch.cuda.Event()
+                taken.record(self._stream)
+                self._prefetch(next_pc, taken)
                 self._graph.replay()
                 if self._graph_late is not None:  # three segments: the early bucket travels while the SA backward replays
                     ev = self.comm_events  # bench: [(early launched, SA backward done, both buckets reduced)] per step
@@ -332,9 +312,6 @@ class Trainer:
         torch.cuda.synchronize()
         st = [pc.clone(), labels.clone(), smpw.clone()]
         sg = model.clone_geometry(geo, self._xyz_of(st[0]))
-        if self.geometry_in_graph:
-            self._static_next_xyz = self._xyz_of(pc).clone()
-            self._static_geo_next = model.clone_geometry(geo, self._static_next_xyz)  # = this batch's: the replay that follows
         for p in self.bucket.params:
             p.grad = None
         # capture_error_mode thread_local: with a process group alive, RCCL's watchdog thread polls the events of earlier
@@ -343,17 +320,6 @@ class Trainer:
         mode = dict(capture_error_mode="thread_local")
         g = torch.cuda.CUDAGraph()
         with torch.cuda.graph(g, **mode):
-            if self.geometry_in_graph:
-                tf_util.multi_copy_(model.geometry_tensors(sg), model.geometry_tensors(self._static_geo_next))
-                # fork: the NEXT batch's FPS / ball query / three_nn / scatter plans as a branch of this graph.  Forked at
-                # the very start, the 0.7 ms FPS of its first level runs beside the forward pass of SA1 / SA2 (131072 ..
-                # 524288 rows, grids of thousands of workgroups, which the 16 CUs it holds cost 6 %); forked where the
-                # backward pass reaches those layers it finished after the main branch (4.95 ms per step vs 4.7).
-                main = torch.cuda.current_stream()
-                self._geo_stream.wait_stream(main)
-                with torch.cuda.stream(self._geo_stream):
-                    tmp = model.compute_geometry(self._static_next_xyz, self.hp, plans=True)
-                    tf_util.multi_copy_(model.geometry_tensors(self._static_geo_next), model.geometry_tensors(tmp))
             if split and self.overlap_collective:
                 loss = self._forward_backward_early(st[0], st[1], st[2], decay, geometry=sg)
             elif split:
@@ -364,8 +330,6 @@ class Trainer:
                     self.bucket.defer_collectives = False
             else:
                 loss = self._step_body(st[0], st[1], st[2], decay, geometry=sg)
-            if self.geometry_in_graph:
-                torch.cuda.current_stream().wait_stream(self._geo_stream)  # join
         self._graph_adam, self._graph_late = None, None
         if split and self.overlap_collective:
             gl = torch.cuda.CUDAGraph()
@@ -378,5 +342,4 @@ class Trainer:
                 self._adam(flat_g)
             self._graph_adam = ga
         self._graph, self._graph_decay, self._static, self._static_geo = g, decay, st + [loss], sg
-        self._next_tag = self._tag(pc)
         # the capture itself executed nothing: the replay that follows is this step

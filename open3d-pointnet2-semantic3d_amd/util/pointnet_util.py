@@ -621,7 +621,7 @@ def pointnet_fp_module(xyz1, xyz2, points1, points2, mlp, is_training, bn_decay,
         # (tf_util._TrainHoistedBnRelu); points1 = a few input channels (the level-0 module) or SA features
         c1 = 0 if points1 is None else points1.shape[2]
         if (tf_util.USE_HOISTED_TRAIN and bn and points1 is not None
-                and ((1 <= c1 <= 8 and not points1.requires_grad) or (tf_util.HOIST_WIDE_SKIP and c1 >= 16 and c1 % 4 == 0))
+                and 1 <= c1 <= 8 and not points1.requires_grad
                 and points1.dtype == torch.float32 and points2.dtype == torch.float32 and len(mlp) > 0 and mlp[0] % 32 == 0
                 and _plan_usable(plan, mlp[0])):
             rows = points1.shape[0] * points1.shape[1]

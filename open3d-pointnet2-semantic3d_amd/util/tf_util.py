@@ -839,9 +839,8 @@ class _TrainDenseBnRelu(torch.autograd.Function):
 
 
 USE_HOISTED_TRAIN = True  # first layer of SA2-SA4 / FP4 with its feature half applied to the source rows (A/B, tests)
-HOIST_WIDE_SKIP = False   # ... also for FP1-FP3, whose skip link (SA features) needs a GEMM of its own: tested and kept, but OFF --
-                          # measured 4.13 vs 4.05 ms per step (tools/train_flags_ab.py): two few-row GEMMs + an in-place pass cost
-                          # more than one GEMM over the concatenated rows at 1024-16384 rows
+# (FP1-FP3, whose skip link is a wide SA feature tensor that needs a GEMM of its own, keep the concatenated form: the hoisted
+# variant was built and measured slower -- 4.13 vs 4.05 ms per step, DESIGN.md section 9 -- and removed in round 4.)
 
 
 def _hip_wgrad_into(x2d, dy, dw_rows):
@@ -860,9 +859,8 @@ class _TrainHoistedBnRelu(torch.autograd.Function):
     GEMM, its data gradient and its weight gradient run on n (resp. m) rows instead of m * nsample (resp. n).  Backward:
     dy from the batch-norm kernels; dz = the scatter of dy through the precomputed plan (the same list the gradient of
     group_point / three_interpolate uses); d(points) = dz @ Wb^T, dWb = points^T dz on the source rows; dWa = a^T dy with
-    a = the centred coordinates (SA) resp. points1 (FP); points1 of more than 8 channels (SA features: FP1-FP3) gets its
-    product from a GEMM of its own (y = points1 @ W[c2:], then the blended rows are added in place) and its gradient
-    dy @ W[c2:]^T."""
+    a = the centred coordinates (SA) resp. points1 (FP: at most 8 skip-link channels that carry no gradient -- the colours
+    of the level-0 module)."""
 
     @staticmethod
     def forward(ctx, src, w, b, gamma, beta, running_mean, running_var, decay, relu, pool, kind, g0, g1, g2, plan, defer):
@@ -888,13 +886,10 @@ class _TrainHoistedBnRelu(torch.autograd.Function):
                                             ptr(a), stream_ptr()), "pn2_sa_hoist_rows")
             else:
                 a = points1.reshape(-1, c1)
-                if c1 <= 8:   # a few input channels: their product is formed inside the kernel
-                    check(lib.pn2_fp_hoist_rows(bsz, n, nsrc, c1, cout, ptr(dist), ptr(idx), ptr(a), ptr(z), ptr(wa), ptr(y),
-                                                stream_ptr()), "pn2_fp_hoist_rows")
-                else:         # a wide skip link: its product is a GEMM of its own, the blended rows are added to it
-                    y = hip_matmul(a, wa.contiguous())
-                    check(lib.pn2_fp_hoist_rows(bsz, n, nsrc, 0, cout, ptr(dist), ptr(idx), None, ptr(z), None, ptr(y),
-                                                stream_ptr()), "pn2_fp_hoist_rows")
+                if c1 > 8:
+                    raise ValueError("the hoisted FP front end takes at most 8 skip-link channels")
+                check(lib.pn2_fp_hoist_rows(bsz, n, nsrc, c1, cout, ptr(dist), ptr(idx), ptr(a), ptr(z), ptr(wa), ptr(y),
+                                            stream_ptr()), "pn2_fp_hoist_rows")
         pooled = pool > 1
         ctx.relu, ctx.pool, ctx.kind, ctx.dims = bool(relu), int(pool), kind, (bsz, nsrc, rows_b, c)
         if defer and not pooled:
@@ -930,10 +925,7 @@ class _TrainHoistedBnRelu(torch.autograd.Function):
             dwa, dwb = (dw[:3], dw[3:]) if sa else (dw[c:], dw[:c])
             _hip_wgrad_into(src2d, dzs2d, dwb)
             _hip_wgrad_into(a, dy, dwa)
-        da = None
-        if not sa and ctx.needs_input_grad[13]:  # points1 of an FP module that carries a gradient (SA features)
-            da = hip_linear_dgrad(dy, wa.contiguous()).view(bsz, rows_b, a.shape[1])
-        return (dsrc, dw, None, dgamma, dbeta) + (None,) * 8 + (da, None, None)
+        return (dsrc, dw, None, dgamma, dbeta) + (None,) * 11
 
 
 def conv2d_hoisted_first(kind, src, geo, plan, cin, num_output_channels, scope, bn_decay=None, pool=0, defer_bn=False):

@@ -1,5 +1,5 @@
 """A/B of the training-path switches: python tools/train_flags_ab.py NAME=0|1 ... [-- bench args]
-e.g. python tools/train_flags_ab.py HOIST_WIDE_SKIP=0 USE_BN_ON_LOAD=1 -- --steps 20 --warmup 5"""
+e.g. python tools/train_flags_ab.py USE_BN_ON_LOAD=1 -- --steps 20 --warmup 5"""
 import json, os, sys, io, contextlib
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import pn2_amd as pn2
