@@ -83,6 +83,24 @@ def s_dup25(seed, b, n):
 
 FPS_KERNELS = ("farthest_point_sample", "fps_gather", "fps_nested")
 
+# HBM bytes per launch of the roofline kernel: PMC counters are a separate rocprofv3 pass (--pmc FETCH_SIZE / WRITE_SIZE cannot
+# share a run with the timed region), so the line cites the committed summary of that pass (tools/gpu_round4.sh,
+# tools/pmc_to_profiles.py: gfx950 corrections as MI355X_MICROARCH.md prescribes) instead of carrying `null`.
+PMC_FILE = "profiles/r04_pmc_hbm_traffic.json"
+PMC_KERNEL_OF = {"fp_mlp_fused_pre": "fp_chain_pipe_kernel", "fp_mlp_fused": "sa_fused_kernel<2", "sa_mlp_max_fused": "sa_fused_kernel<3, 1, 1, 2"}
+
+
+def pmc_traffic(kernel):
+    """bytes per launch of `kernel` from the committed PMC summary, or None (file absent / kernel not in it)"""
+    try:
+        with open(os.path.join(ROOT, PMC_FILE)) as f:
+            ks = json.load(f)["kernels"]
+    except (OSError, ValueError, KeyError):
+        return None
+    key = PMC_KERNEL_OF.get(kernel, kernel)
+    hits = [v["traffic_bytes"] for k, v in ks.items() if key in k]
+    return max(hits) if hits else None
+
 
 # ---- algorithmic work per launch (SURVEY.md section 8d: compulsory traffic) -----------------
 def kernel_model(name, a):
@@ -643,6 +661,9 @@ def main():
     ap.add_argument("--train", action="store_true",
                     help="BASELINE configs[3] instead of the headline: data-parallel TRAINING steps (forward with batch-stat "
                          "BN + weighted CE + backward + one flat RCCL gradient all-reduce + Adam), 16 scenes per GPU")
+    ap.add_argument("--only-north-star", action="store_true",
+                    help="run only the two north-star kernel measurements and print them (the command the rocprofv3 / PMC passes "
+                         "of tools/gpu_round4.sh profile: profiles/r04_pmc_north_star.json)")
     ap.add_argument("--no-other-inputs", action="store_true", help="skip the S-randn / S-dup25 legs of the line")
     args = ap.parse_args()
 
@@ -678,6 +699,10 @@ def main():
         if not hasattr(pn2._lib._raw, "pn2_debug_set"):
             raise SystemExit("--debug-set needs a tuning build of the library: python open3d-pointnet2-semantic3d_amd/build.py --tuning")
         assert pn2._lib._raw.pn2_debug_set(int(what), int(value)) == 0
+    if args.only_north_star:
+        if rank == 0:
+            print(json.dumps({"north_star": north_star_kernels(pn2, dev)}))
+        return
     if args.train:
         bench_train(pn2, args, hp, B, N, rank, world, dev)
         if dist_on:
@@ -768,6 +793,17 @@ def main():
             dist.barrier()
         latency_ms = pn2.dist.max_over_ranks(lat, device=dev) / args.steps * 1e3
 
+    # ---- the same throughput regime over a 10x longer region (K = 20 steps is a 9 ms region that starts
+    #      with empty queues; this figure says how far `value` is from the steady state) -- never `value`
+    steady_ms = None
+    if not args.eager and world == 1:
+        torch.cuda.synchronize()
+        t2 = time.perf_counter()
+        for _ in range(10 * args.steps):
+            step()
+        torch.cuda.synchronize()
+        steady_ms = (time.perf_counter() - t2) / (10 * args.steps) * 1e3
+
     # ---- instrumented pass: same steps, every launch bracketed by HIP events on its stream ----
     trace_steps = min(args.steps, 10)
     pn2._lib.lib.trace = []
@@ -818,11 +854,16 @@ def main():
                 "latency": None if latency_ms is None else {
                     "batches_in_flight": 1, "ms_per_step": round(latency_ms, 4),
                     "points_per_s": round(world * B * N / (latency_ms * 1e-3), 1),
-                    "note": "replay + synchronize per step: what the reference's benchmark.py times"}},
+                    "note": "replay + synchronize per step: what the reference's benchmark.py times"},
+                "throughput_steady_state": None if steady_ms is None else {
+                    "steps": 10 * args.steps, "ms_per_step": round(steady_ms, 4),
+                    "points_per_s": round(B * N / (steady_ms * 1e-3), 1),
+                    "note": "the throughput regime over a 10x longer timed region (not `value`)"}},
             "roofline": {"regime": "throughput" if P_eff > 1 else "latency",
                          "kernel": dom["kernel"], "args": dom["args"], "bound": dom["bound"],
                          "achieved": dom["achieved"], "peak": dom["peak"], "unit": dom["unit"], "frac": dom["frac"],
-                         "traffic": None, "algorithmic_units": dom["algorithmic_units"], "avg_us": dom["avg_us"],
+                         "traffic": pmc_traffic(dom["kernel"]), "traffic_source": PMC_FILE,
+                         "algorithmic_units": dom["algorithmic_units"], "avg_us": dom["avg_us"],
                          "ms_per_step": dom["ms_per_step"],
                          "share_of_timed_kernels": round(dom["ms_per_step"] / max(1e-9, sum(k["ms_per_step"] for k in timed)), 3),
                          "flops_counted": "EXECUTED MFMA flops of the launch (a *_pre kernel runs its first layer only on the "

@@ -9,6 +9,12 @@ build LLVM contracts the expression as fma(dz,dz,fma(dy,dy,dx*dx)) in farthestpo
 fma(dz,dz,fma(dx,dx,dy*dy)) in query_ball_point_gpu (mode 1): tests/test_ref_gpu.py runs the whole SA geometry chain of
 configs[1] with these defaults against that build, bit for bit.  (The contraction-OFF build equals (0, 0).)
 
+What this pins and what it cannot: parity is with the HIPCC builds of the reference's files (the only builds that can run
+here).  Which contraction the reference's real nvcc build chose is unobservable without CUDA -- nvcc commonly emits
+mul(dx,dx); fma(dy,dy,.); fma(dz,dz,.) = mode 2 for BOTH kernels, in which case the ball-query default (mode 1) would differ from
+it in the last bit of distances that sit on the radius.  An integrator holding an nvcc SASS dump passes the matching mode per
+call (or scopes it with `arith`); every mode is bit-exact against the oracle and the matching `_ref` build.
+
 There is no process-global switch: every op takes `arith_mode=` per call; `arith(...)` scopes a different default to a
 `with` block of the calling THREAD (tests run whole layer chains under another mode with it).
 """

@@ -76,6 +76,9 @@ def ball_query_bin(radius, xyz1, out=None):
     bins = out if out is not None else ball_query_bin_alloc(xyz1)  # `out`: allocated by the caller (on ITS stream)
     with torch.cuda.device(xyz1.device):
         check(lib.pn2_ball_query_bin(b, n, float(radius), ptr(xyz1), ptr(bins), bins.numel(), stream_ptr()), "pn2_ball_query_bin")
+    # what the bins describe: the C entry point takes an opaque pointer and cannot check it -- bins of a smaller
+    # cloud would be read out of bounds, bins of a smaller radius would silently miss neighbours
+    bins._pn2_bins_of = (float(radius), b, n)
     return bins
 
 
@@ -89,6 +92,14 @@ def query_ball_point_binned(radius, nsample, xyz1, xyz2, bins, arith_mode=None):
     require_cuda(xyz1, xyz2)
     xyz1 = xyz1.detach().contiguous()
     xyz2 = xyz2.detach().contiguous()
+    made = getattr(bins, "_pn2_bins_of", None)
+    if made is None:
+        raise ValueError("bins must come from ball_query_bin(radius, xyz1)")
+    if made != (float(radius), b, n):
+        raise ValueError("bins were built for radius %g on a (%d, %d, 3) cloud: they do not describe this query (radius %g, "
+                         "cloud (%d, %d, 3))" % (made[0], made[1], made[2], radius, b, n))
+    if bins.dtype != torch.uint8 or bins.data_ptr() % 256 != 0 or bins.numel() < b * int(lib.pn2_ball_query_bin_bytes(n)):
+        raise ValueError("bins: expected a 256-byte aligned uint8 tensor of b * pn2_ball_query_bin_bytes(n) bytes")
     idx = torch.empty((b, m, nsample), dtype=torch.int32, device=xyz1.device)
     cnt = torch.empty((b, m), dtype=torch.int32, device=xyz1.device)
     with torch.cuda.device(xyz1.device):

@@ -720,6 +720,11 @@ def test_query_ball_point_binned_equals_unbinned(pn2, oracle, cuda, case, mode):
     assert bins is not None
     bi, bc = g.query_ball_point_binned(r, K, T(xyz, cuda), T(q, cuda), bins)
     assert np.array_equal(bi.cpu().numpy(), oi) and np.array_equal(bc.cpu().numpy(), oc)
+    # bins that do not describe the query are refused (the C entry point takes an opaque pointer)
+    with pytest.raises(ValueError, match="do not describe"):
+        g.query_ball_point_binned(r * 0.5, K, T(xyz, cuda), T(q, cuda), bins)
+    with pytest.raises(ValueError, match="do not describe"):
+        g.query_ball_point_binned(r, K, T(xyz[:1], cuda), T(q[:1], cuda), bins)
     q2 = xyz[:, -m:].copy()  # the bins depend on (radius, xyz1) only
     b2, c2 = g.query_ball_point_binned(r, K, T(xyz, cuda), T(q2, cuda), bins)
     o2, oc2 = oracle.query_ball_point(r, K, xyz, q2, mode)
