@@ -714,11 +714,13 @@ ball_query_grid_kernel(int n, int m, float radius, float thr, int nsample, const
         const int cz = bqg_cell1(qz, G.lo[2], G.inv_h[2], G.dim[2]);
         const int x0 = cx > 0 ? cx - 1 : 0, x1 = cx + 1 < G.dim[0] ? cx + 1 : G.dim[0] - 1;
         int nh = 0;
+        // a query whose hit list overflows (dense balls: unit-normal clouds at r = 0.5 have ~270 hits around their centre) is
+        // redone by the whole wave below; its list pass stops at the overflow instead of scanning the remaining cells
 #pragma unroll 1
         for (int r = 0; r < 9; ++r) {
             const int z = cz + r / 3 - 1, y = cy + r % 3 - 1;
             int s0 = 0, e0 = 0;
-            if (qv && z >= 0 && z < G.dim[2] && y >= 0 && y < G.dim[1]) {
+            if (qv && nh <= kBqgCap && z >= 0 && z < G.dim[2] && y >= 0 && y < G.dim[1]) {
                 const int rowc = (z * G.dim[1] + y) * G.dim[0];
                 s0 = cstart[rowc + x0];
                 e0 = cstart[rowc + x1 + 1];  // the 3 x-cells are contiguous in the sorted arrays
@@ -734,9 +736,9 @@ ball_query_grid_kernel(int n, int m, float radius, float thr, int nsample, const
                     if (pos < kBqgCap) myhits[pos] = sidx[pc];
                 }
                 nh += __popc(gm);
+                if (nh > kBqgCap) e0 = 0;  // overflow: this group is done with the list pass (nh is recounted from the bitmap)
             }
         }
-        int cnt = nh < nsample ? nh : nsample;
         int* __restrict__ out = idx_all + ((size_t)bi * m + qc) * nsample;
         const bool sparse = nh <= kBqgCap;
         if (qv && sparse) {
@@ -788,6 +790,8 @@ ball_query_grid_kernel(int n, int m, float radius, float thr, int nsample, const
                 if (lane >= o) inc += t;
             }
             int pos = inc - mine;
+            const int total = __builtin_amdgcn_readlane(inc, 63);  // every hit of the ball (the list pass may have been skipped)
+            if (grp == g2) nh = total;
             int* __restrict__ o2 = idx_all + ((size_t)bi * m + q2) * nsample;
 #pragma unroll
             for (int w = 0; w < 4; ++w) {
@@ -803,6 +807,7 @@ ball_query_grid_kernel(int n, int m, float radius, float thr, int nsample, const
             }
         }
         // short rows repeat the first hit (tf_grouping.cu:32-36); empty rows are zero (documented divergence)
+        const int cnt = nh < nsample ? nh : nsample;
         if (qv) {
             const int first = cnt > 0 ? *myfirst : 0;
             for (int l = cnt + l16; l < nsample; l += 16) out[l] = first;
