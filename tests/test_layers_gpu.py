@@ -1169,6 +1169,79 @@ def test_training_gradients_with_hip_wgrad_match_torch(pn2, cuda):
     assert rel[worst][0] < 3e-2 and float(np.median([v[0] for v in rel.values()])) < 1.5e-2, rel[worst]
 
 
+def test_training_gradients_match_float64_on_the_same_activation_pattern(pn2, cuda):
+    """the 3 % bound of the test above is the chaos of 23 batch norms -- which side of zero a
+    pre-activation within rounding of it falls on, and which of two near-equal neighbours wins a max pool, differ between any
+    two fp32 evaluations, and every such flip moves the gradients by far more than rounding.  Here the float64 network is
+    evaluated ON THE HIP PATH'S OWN PATTERN: every ReLU uses the mask the HIP layer's output shows (z > 0), every max pool
+    selects the neighbour whose float64 value is closest to the value the HIP pool returned.  What remains is rounding of the
+    kernels themselves (GEMMs, batch-norm statistics, their gradients, the scatter-add of the grouping gradients): every
+    parameter gradient of the whole model within 1e-4 of its norm (measured: worst 7.8e-6, median 5.8e-6 over 68 tensors)."""
+    import torch
+    import torch.nn.functional as F
+    tfu = pn2.util.tf_util
+    hp = dict(pn2.model.SEMANTIC_HYPERPARAMS)
+    hp.update(l1_npoint=256, l2_npoint=64, l3_npoint=32, l4_npoint=16)
+    rs = np.random.RandomState(0)
+    pc = T(np.concatenate([s_scene(1, 8, 2048), rs.random_sample((8, 2048, 3)).astype(np.float32)], 2), cuda)
+    labels = T(rs.randint(0, 9, (8, 2048)).astype(np.int64), cuda)
+    smpw = T((rs.random_sample((8, 2048)) + 0.5).astype(np.float32), cuda)
+    orig = tfu._train_layer
+    seen = []   # the HIP run's layer outputs, in call order
+    cursor = [0]
+
+    def layer_recording(inputs, w2d, b, bnv, bn_decay, relu, pool=0, defer=False):
+        z = orig(inputs, w2d, b, bnv, bn_decay, relu, pool, False)
+        seen.append(z.detach())
+        return z
+
+    def layer_fp64_forced(inputs, w2d, b, bnv, bn_decay, relu, pool=0, defer=False):
+        z_hip = seen[cursor[0]].double()
+        cursor[0] += 1
+        y = inputs.double() @ w2d.double() + b.double()
+        if bnv is not None:
+            beta, gamma, mean, var = bnv
+            c = y.shape[-1]
+            y = F.batch_norm(y.reshape(-1, c), None, None, gamma.double(), beta.double(), training=True,
+                             eps=tfu.BN_EPSILON).reshape(y.shape)
+        if pool and pool > 1:
+            w = y.shape[-2] // pool
+            yw = y.reshape(list(y.shape[:-2]) + [w, pool, y.shape[-1]])
+            zt = z_hip.reshape(list(y.shape[:-2]) + [w, 1, y.shape[-1]])
+            # ReLU and max commute; the HIP pool returned max(relu(.)): where it is positive it names the winner
+            pick = (torch.relu(yw.detach()) - zt).abs().argmin(dim=-2, keepdim=True)
+            y = torch.gather(yw, -2, pick).squeeze(-2)
+        if relu:
+            y = y * (z_hip.reshape(y.shape) > 0)
+        assert y.shape == z_hip.reshape(y.shape).shape
+        return y.float()
+
+    def run(layer):
+        tfu._train_layer = layer
+        keep = tfu.USE_BN_ON_LOAD
+        tfu.USE_BN_ON_LOAD = False  # every layer hands over its normalised activation (what is recorded / replaced)
+        try:
+            store = tfu.set_default_store(tfu.VariableStore(device=cuda, seed=5))
+            torch.manual_seed(123)  # same dropout mask in every run
+            logits, _ = pn2.model.get_model(pc, True, 9, hp, bn_decay=0.5)
+            pn2.model.get_loss(logits, labels, smpw).backward()
+            return {k: v.grad.detach().double().clone() for k, v in store.params.items() if v.grad is not None}, logits.detach()
+        finally:
+            tfu._train_layer = orig
+            tfu.USE_BN_ON_LOAD = keep
+
+    hip, lh = run(layer_recording)
+    ref, lr = run(layer_fp64_forced)
+    assert cursor[0] == len(seen) > 20
+    assert float((lh.double() - lr.double()).abs().max()) < 1e-4 * max(1.0, float(lr.abs().max()))  # same pattern: logits agree
+    ref = {k: v for k, v in ref.items() if k in hip}
+    rel = {k: float((hip[k] - ref[k]).norm()) / max(float(ref[k].norm()), 1e-30) for k in ref if float(ref[k].norm()) > 1e-6}
+    worst = max(rel, key=rel.get)
+    print("gradient error vs float64 on the HIP path's activation pattern: worst %.2e at %s, median %.2e over %d tensors"
+          % (rel[worst], worst, float(np.median(list(rel.values()))), len(rel)))
+    assert rel[worst] < 1e-4 and float(np.median(list(rel.values()))) < 5e-5, (worst, rel[worst])
+
+
 # ------------------------------------------------------------------ training: batch norm + relu kernels ------
 @pytest.mark.parametrize("rows,c,relu", [(4096, 32, 1), (1000, 64, 1), (333, 128, 0), (8192, 512, 1), (257, 9, 1), (64, 1024, 1),
                                          (5000, 36, 1), (1, 32, 1)])
