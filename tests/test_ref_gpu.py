@@ -284,6 +284,52 @@ def test_nested_fps_device_side_branch(pn2, oracle, cuda):
         assert not np.array_equal(want[0], np.arange(m))  # the forged identity above really was a different answer
 
 
+def test_nested_fps_edge_shapes(pn2, oracle, cuda):
+    """pn2_fps_nested at the edges: more clouds than the reference's 32 blocks, m == n (every point picked: the record must
+    not send the next level to the shortcut when the maximum reached 0), a single-wave cloud, indices only (new_xyz NULL),
+    the idx-only API chained through gather_point (the training path of sample_and_group), and the switch off."""
+    import torch
+    from pn2_amd import _lib
+    S = pn2.tf_ops.tf_sampling
+    lib, ptr = _lib.lib, _lib.ptr
+    for b, n, levels in [(40, 777, (300, 120, 40)), (3, 64, (64, 32, 8)), (2, 300, (300, 150, 20)), (33, 2100, (512, 64))]:
+        x = s_scene(b + n, b, n)
+        if n == 300:
+            x[:, 150:] = x[:, :150]          # every point has a twin: with m == n the maximum reaches 0 at step 150
+        cur, cur_ref = T(x, cuda), x
+        for m in levels:
+            idx, new_xyz = S.farthest_point_sample_and_gather(m, cur)
+            want = oracle.farthest_point_sample(m, cur_ref, 2)
+            assert np.array_equal(idx.cpu().numpy(), want), (b, n, m)
+            cur_ref = oracle.gather_point(cur_ref, want)
+            assert np.array_equal(new_xyz.cpu().numpy(), cur_ref)
+            cur = new_xyz
+    # indices only, record in / out through the raw entry point
+    x = s_scene(5, 4, 1024)
+    xt = T(x, cuda)
+    out = torch.empty((4, 256), dtype=torch.int32, device=cuda)
+    tie = torch.empty((4,), dtype=torch.int32, device=cuda)
+    _lib.check(lib.pn2_fps_nested(4, 1024, 256, ptr(xt), None, ptr(out), None, None, ptr(tie), 2, _lib.stream_ptr()), "pn2_fps_nested")
+    assert np.array_equal(out.cpu().numpy(), oracle.farthest_point_sample(256, x, 2))
+    assert np.array_equal(np.minimum(tie.cpu().numpy(), 255), np.minimum(oracle.fps_first_tie(256, x, 2), 255))
+    # the idx-only API (sample_and_group's training path): farthest_point_sample -> gather_point -> tag -> next level
+    pu = pn2.util.pointnet_util
+    nx1, _, _, _ = pn2.sample_and_group(256, 0.3, 8, xt, None)
+    assert S.fps_tie_record(nx1) is not None
+    nx2, _, _, _ = pn2.sample_and_group(64, 0.5, 8, nx1, None)
+    r1 = oracle.gather_point(x, oracle.farthest_point_sample(256, x, 2))
+    r2 = oracle.gather_point(r1, oracle.farthest_point_sample(64, r1, 2))
+    assert np.array_equal(nx1.cpu().numpy(), r1) and np.array_equal(nx2.cpu().numpy(), r2)
+    S.USE_NESTED_FPS = False
+    try:
+        _, a = S.farthest_point_sample_and_gather(256, xt)
+        assert S.fps_tie_record(a) is None
+        _, b2 = S.farthest_point_sample_and_gather(64, a)
+        assert np.array_equal(b2.cpu().numpy(), r2)
+    finally:
+        S.USE_NESTED_FPS = True
+
+
 def test_nested_fps_tag_is_dropped_when_it_no_longer_describes_the_tensor(pn2, cuda):
     S = pn2.tf_ops.tf_sampling
     x = T(s_scene(0, 2, 2048), cuda)
