@@ -16,6 +16,10 @@ LIB = os.path.join(HERE, "libpn2_hip.so")
 SOURCES = ["pn2_abi.hip", "pn2_sampling.hip", "pn2_grouping.hip", "pn2_interpolate.hip",
            "pn2_linear.hip", "pn2_sa_fused.hip", "pn2_sa_fused_bf16.hip", "pn2_label_interp.hip", "pn2_fps_bucket.hip",
            "pn2_bn.hip", "pn2_scene.hip", "pn2_train.hip", "pn2_mlp_wide.hip", "pn2_pool.hip", "pn2_hoist.hip"]
+# per-file additions.  pn2_sa_fused.hip: MFMA results in VGPRs where they fit (the fused chains feed every accumulator back into
+# the next layer's MFMA as an A / B operand, which must be an arch VGPR: with AGPR accumulators each of those 128 values per
+# tile costs a v_accvgpr_read, and non-MFMA instructions cost their full issue time on a SIMD whose matrix pipe is busy)
+FILE_FLAGS = {"pn2_sa_fused.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form"]}
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off",
          "-munsafe-fp-atomics", "-fno-gpu-rdc", "-fno-slp-vectorize", "-Wall", "-Wno-unused-function"]
 
@@ -47,7 +51,7 @@ def build(force=False, verbose=False, extra_flags=(), out=None):
     procs = []
     for src in SOURCES:
         obj = os.path.join(CSRC, src.replace(".hip", tag + ".o"))
-        cmd = [hipcc] + FLAGS + list(extra_flags) + ["-c", os.path.join(CSRC, src), "-o", obj]
+        cmd = [hipcc] + FLAGS + FILE_FLAGS.get(src, []) + list(extra_flags) + ["-c", os.path.join(CSRC, src), "-o", obj]
         if verbose:
             print(" ".join(cmd))
         procs.append((src, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)))

@@ -120,6 +120,24 @@ __device__ __forceinline__ void bias_relu_T(f32x16 (&acc)[NT], const float* __re
             acc[nt][r] = fmaxf(acc[nt][r] + sbias[nt * 32 + acc_chan(r, half)], 0.f);
 }
 
+// The same epilogue with a quarter of the LDS reads and half of the adds: registers 4q .. 4q+3 of a column tile hold the
+// channels 32 nt + 8 q + 4 half + (0..3), i.e. FOUR CONSECUTIVE biases -- one ds_read_b128 -- and the adds go two at a time
+// (v_pk_add_f32).  Same operations on the same values: bit-identical to bias_relu_T.
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+template <int NT>
+__device__ __forceinline__ void bias_relu_T_pk(f32x16 (&acc)[NT], const float* __restrict__ sbias_half /* sbias + 4 * half */) {
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const f32x4 b = *reinterpret_cast<const f32x4*>(sbias_half + nt * 32 + 8 * q);
+            const f32x2 lo = f32x2{acc[nt][4 * q], acc[nt][4 * q + 1]} + f32x2{b[0], b[1]};
+            const f32x2 hi = f32x2{acc[nt][4 * q + 2], acc[nt][4 * q + 3]} + f32x2{b[2], b[3]};
+            acc[nt][4 * q] = fmaxf(lo[0], 0.f); acc[nt][4 * q + 1] = fmaxf(lo[1], 0.f);
+            acc[nt][4 * q + 2] = fmaxf(hi[0], 0.f); acc[nt][4 * q + 3] = fmaxf(hi[1], 0.f);
+        }
+}
+
 // dense layer fed from the previous layer's accumulators.  The weight reads of
 // step s+1 are issued ahead of the MFMAs of step s and a sched_barrier pins that
 // order: without it the scheduler hoists all NTP*16*NT ds_reads of the unrolled
@@ -235,6 +253,25 @@ __device__ __forceinline__ void rows_store(const f32x16 (&acc)[NT], const float*
         for (int r = 0; r < 16; ++r) {
             const int row = row0 + acc_chan(r, half);
             if (row < rows) obase[(size_t)row * wout + nt * 32 + l31] = fmaxf(acc[nt][r] + bv, 0.f);
+        }
+    }
+}
+
+// rows_store for whole tiles with the bias added two registers at a time (same values as rows_store)
+template <int NT>
+__device__ __forceinline__ void rows_store_pk(const f32x16 (&acc)[NT], const float* __restrict__ sbias, float* __restrict__ obase,
+                                              int wout, int row0, int rows, int half, int l31) {
+    if (row0 + 32 > rows) { rows_store<NT>(acc, sbias, obase, wout, row0, rows, half, l31); return; }
+    float* __restrict__ o = obase + (size_t)(row0 + 4 * half) * wout + l31;
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+        const float bv = sbias[nt * 32 + l31];
+        const f32x2 b2 = {bv, bv};
+#pragma unroll
+        for (int r = 0; r < 16; r += 2) {
+            const f32x2 v = f32x2{acc[nt][r], acc[nt][r + 1]} + b2;
+            o[((r & 3) + 8 * (r >> 2)) * wout + nt * 32] = fmaxf(v[0], 0.f);
+            o[(((r + 1) & 3) + 8 * ((r + 1) >> 2)) * wout + nt * 32] = fmaxf(v[1], 0.f);
         }
     }
 }
@@ -604,8 +641,11 @@ fp_chain_pipe_kernel(SaFusedParams p) {
     }
     const bool any_tile = g_lo < g_hi;
     const float* w1l = wp1 + half * W1 + l31;
-    const float* w2l = wp2 + half * W2 + l31;
-    const float* w3l = wp3 + half * W3 + l31;
+    // layers 2 / 3: the four column tiles' weights of a (k-step, half-wave) are stored INTERLEAVED, [l31][nt], so that a lane
+    // fetches its four B (resp. A) values with ONE ds_read_b128 instead of two ds_read2_b32 and an address add -- every
+    // non-MFMA instruction costs its full issue time here (see the header comment)
+    const f32x4* w2l = reinterpret_cast<const f32x4*>(wp2 + half * W2) + l31;
+    const f32x4* w3l = reinterpret_cast<const f32x4*>(wp3 + half * W3) + l31;
 
     // ---- front end of a tile, in slices.  fi / fd / fsk: raw loads; fw*: blend weights; fz*: this lane's three rows of z
     int fi0 = 0, fi1 = 0, fi2 = 0;
@@ -645,12 +685,19 @@ fp_chain_pipe_kernel(SaFusedParams p) {
         }
     };
     auto chunk_blend = [&](f32x16& ax, const f32x4 (&q1)[4], const f32x4 (&q2)[4], const f32x4 (&q3)[4]) {
+        // (z1 w1 + z2 w2) + z3 w3, unfused (tf_interpolate.cpp:322-324 order), two channels per instruction (v_pk_mul_f32 /
+        // v_pk_add_f32: the same IEEE operations as the scalar forms)
+        const f32x2 W1p = {fw1, fw1}, W2p = {fw2, fw2}, W3p = {fw3, fw3};
 #pragma unroll
-        for (int rq = 0; rq < 4; ++rq) {
-            const f32x4 cur = (q1[rq] * fw1 + q2[rq] * fw2) + q3[rq] * fw3;  // tf_interpolate.cpp:322-324 order, unfused
+        for (int rq = 0; rq < 4; ++rq)
 #pragma unroll
-            for (int e = 0; e < 4; ++e) ax[4 * rq + e] += cur[e];
-        }
+            for (int h = 0; h < 2; ++h) {
+                const f32x2 z1 = {q1[rq][2 * h], q1[rq][2 * h + 1]}, z2 = {q2[rq][2 * h], q2[rq][2 * h + 1]};
+                const f32x2 z3 = {q3[rq][2 * h], q3[rq][2 * h + 1]};
+                const f32x2 cur = (z1 * W1p + z2 * W2p) + z3 * W3p;
+                const f32x2 acc2 = f32x2{ax[4 * rq + 2 * h], ax[4 * rq + 2 * h + 1]} + cur;
+                ax[4 * rq + 2 * h] = acc2[0]; ax[4 * rq + 2 * h + 1] = acc2[1];
+            }
     };
     const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 
@@ -690,17 +737,33 @@ fp_chain_pipe_kernel(SaFusedParams p) {
         return ch >= 0 ? ch * W1 + col : -1;
     });
     stage1(sb1, W1, p.bias[0]);
-    stage4(wp2, W1 * W2 / 4, p.W[1], [&](int e4) {
-        const int col = (e4 % (W2 / 4)) * 4, sh = e4 / (W2 / 4);
-        const int s = sh >> 1, h = sh & 1;
-        return ((s >> 4) * 32 + acc_chan(s & 15, h)) * W2 + col;
-    });
+    // same (k-step, half) row order as sa_fused_kernel; inside a row column 32 nt + l goes to position 4 l + nt
+    auto stage4i = [&](float* dst, int W, int count4, const float* __restrict__ src) {
+        for (int base = 0; base < count4; base += NTH * 8) {
+            f32x4 v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int e = base + u * NTH + tid;
+                const int ec = e < count4 ? e : 0;
+                const int col = (ec % (W / 4)) * 4, sh = ec / (W / 4);
+                const int s = sh >> 1, h = sh & 1;
+                v[u] = *reinterpret_cast<const f32x4*>(src + ((s >> 4) * 32 + acc_chan(s & 15, h)) * W + col);
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int e = base + u * NTH + tid;
+                if (e < count4) {
+                    const int col = (e % (W / 4)) * 4, sh = e / (W / 4);
+                    float* __restrict__ d = dst + sh * W + (col & 31) * 4 + (col >> 5);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) d[4 * j] = v[u][j];
+                }
+            }
+        }
+    };
+    stage4i(wp2, W2, W1 * W2 / 4, p.W[1]);
     stage1(sb2, W2, p.bias[1]);
-    stage4(wp3, W2 * W3 / 4, p.W[2], [&](int e4) {
-        const int col = (e4 % (W3 / 4)) * 4, sh = e4 / (W3 / 4);
-        const int s = sh >> 1, h = sh & 1;
-        return ((s >> 4) * 32 + acc_chan(s & 15, h)) * W3 + col;
-    });
+    stage4i(wp3, W3, W2 * W3 / 4, p.W[2]);
     stage1(sb3, W3, p.bias[2]);
     __syncthreads();
     PN2_CHAIN_STAMP(1);
@@ -745,11 +808,11 @@ fp_chain_pipe_kernel(SaFusedParams p) {
                 if constexpr (s == BS[c]) chunk_blend(a1[c], q1, q2, q3);
             });
         };
-        bias_relu_T<NT1>(a1, sb1, half);
+        bias_relu_T_pk<NT1>(a1, sb1 + 4 * half);
         {
-            float wq[kPF][NT2];
+            f32x4 wq[kPF];
 #pragma unroll
-            for (int pf = 0; pf < kPF; ++pf) load_w<NT2>(wq[pf], w2l + pf * 2 * W2);
+            for (int pf = 0; pf < kPF; ++pf) wq[pf] = w2l[pf * 2 * (W2 / 4)];
             static_for<NT1 * 16>([&](auto s_c) __attribute__((always_inline)) {
                 constexpr int s = decltype(s_c)::value;
 #pragma unroll
@@ -758,18 +821,18 @@ fp_chain_pipe_kernel(SaFusedParams p) {
                     else a2[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(wq[s % kPF][nt], a1[s >> 4][s & 15], a2[nt], 0, 0, 0);
                 }
                 __builtin_amdgcn_sched_barrier(0);
-                if constexpr (s + kPF < NT1 * 16) load_w<NT2>(wq[s % kPF], w2l + (s + kPF) * 2 * W2);
+                if constexpr (s + kPF < NT1 * 16) wq[s % kPF] = w2l[(s + kPF) * 2 * (W2 / 4)];
                 __builtin_amdgcn_sched_barrier(0);
                 side(std::integral_constant<int, s>{});
                 __builtin_amdgcn_sched_barrier(0);
             });
         }
         PN2_CHAIN_STAMP(4);
-        bias_relu_T<NT2>(a2, sb2, half);
+        bias_relu_T_pk<NT2>(a2, sb2 + 4 * half);
         {
-            float wq[kPF][NT3];
+            f32x4 wq[kPF];
 #pragma unroll
-            for (int pf = 0; pf < kPF; ++pf) load_w<NT3>(wq[pf], w3l + pf * 2 * W3);
+            for (int pf = 0; pf < kPF; ++pf) wq[pf] = w3l[pf * 2 * (W3 / 4)];
             static_for<NT2 * 16>([&](auto s_c) __attribute__((always_inline)) {
                 constexpr int s = decltype(s_c)::value;
 #pragma unroll
@@ -778,14 +841,14 @@ fp_chain_pipe_kernel(SaFusedParams p) {
                     else a3[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a2[s >> 4][s & 15], wq[s % kPF][nt], a3[nt], 0, 0, 0);
                 }
                 __builtin_amdgcn_sched_barrier(0);
-                if constexpr (s + kPF < NT2 * 16) load_w<NT3>(wq[s % kPF], w3l + (s + kPF) * 2 * W3);
+                if constexpr (s + kPF < NT2 * 16) wq[s % kPF] = w3l[(s + kPF) * 2 * (W3 / 4)];
                 __builtin_amdgcn_sched_barrier(0);
                 side(std::integral_constant<int, NT1 * 16 + s>{});
                 __builtin_amdgcn_sched_barrier(0);
             });
         }
         PN2_CHAIN_STAMP(5);
-        rows_store<NT3>(a3, sb3, p.out, W3, g * 32, p.rows, half, l31);
+        rows_store_pk<NT3>(a3, sb3, p.out, W3, g * 32, p.rows, half, l31);
         PN2_CHAIN_STAMP(6);
         ++tile_no;
     }
