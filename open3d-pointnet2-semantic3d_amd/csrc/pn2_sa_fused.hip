@@ -262,7 +262,11 @@ template <int NT>
 __device__ __forceinline__ void rows_store_pk(const f32x16 (&acc)[NT], const float* __restrict__ sbias, float* __restrict__ obase,
                                               int wout, int row0, int rows, int half, int l31) {
     if (row0 + 32 > rows) { rows_store<NT>(acc, sbias, obase, wout, row0, rows, half, l31); return; }
-    float* __restrict__ o = obase + (size_t)(row0 + 4 * half) * wout + l31;
+    // four row-group bases (rows 8 q + 4 half + 0..3): every store then addresses base + a constant below 4 KB, instead of a
+    // 64-bit add per store
+    float* __restrict__ oq[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) oq[q] = obase + (size_t)(row0 + 4 * half + 8 * q) * wout + l31;
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) {
         const float bv = sbias[nt * 32 + l31];
@@ -270,8 +274,8 @@ __device__ __forceinline__ void rows_store_pk(const f32x16 (&acc)[NT], const flo
 #pragma unroll
         for (int r = 0; r < 16; r += 2) {
             const f32x2 v = f32x2{acc[nt][r], acc[nt][r + 1]} + b2;
-            o[((r & 3) + 8 * (r >> 2)) * wout + nt * 32] = fmaxf(v[0], 0.f);
-            o[(((r + 1) & 3) + 8 * ((r + 1) >> 2)) * wout + nt * 32] = fmaxf(v[1], 0.f);
+            oq[r >> 2][(r & 3) * wout + nt * 32] = fmaxf(v[0], 0.f);
+            oq[r >> 2][((r + 1) & 3) * wout + nt * 32] = fmaxf(v[1], 0.f);
         }
     }
 }
