@@ -548,7 +548,7 @@ sa_fused_kernel(SaFusedParams p) {
             }
             else rows_store<NT1>(a1, sb1, p.out, WOUT, g * 32, p.rows, half, l31);
         } else {
-            bias_relu_T<NT1>(a1, sb1, half);
+            bias_relu_T_pk<NT1>(a1, sb1 + 4 * half);
             f32x16 a2[NT2];
             zero_acc<NT2>(a2);
             layer_from_regs<NT1, NT2, L == 2>(a1, a2, wp2, W2, half, l31);
@@ -562,7 +562,7 @@ sa_fused_kernel(SaFusedParams p) {
             }
                 else rows_store<NT2>(a2, sb2, p.out, WOUT, g * 32, p.rows, half, l31);
             } else {
-                bias_relu_T<NT2>(a2, sb2, half);
+                bias_relu_T_pk<NT2>(a2, sb2 + 4 * half);
                 f32x16 a3[NT3];
                 zero_acc<NT3>(a3);
                 layer_from_regs<NT2, NT3, true>(a2, a3, wp3, W3, half, l31);
