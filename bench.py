@@ -24,21 +24,29 @@ Prints ONE JSON line (rank 0).  `value` / `ms_per_step` are the THROUGHPUT regim
 full batch through the whole stack.  The LATENCY regime (one batch in flight, what the reference's benchmark.py
 times) is reported next to it under `regimes`.  Besides the contract keys the line carries
   regimes       {"throughput": {...}, "latency": {...}}: ms per step and points/s of both regimes, each timed
-                over the same K steps with barrier + synchronize on both sides
+                over the same K steps with barrier + synchronize on both sides; "throughput_steady_state": the throughput
+                regime over 10 x K steps (K = 20 is a 9 ms region that starts with empty queues) -- never `value`
   roofline      the limiter OF THE TIMED (throughput) REGIME: with several batches in flight the latency-bound FPS
                 chains (16 CUs each) hide behind the other batches' dense work and the step is the sum of the
                 chip-filling kernels, which are MFMA work: `roofline` = the dominant one of them (largest share of
                 that sum; algorithmic flops per launch / its HIP-event duration), `roofline.aggregate` = all MFMA
-                flops of a step / ms_per_step.  `traffic` is null: no counter pass runs inside bench.py (the PMC
-                passes are separate rocprofv3 runs, profiles/).
+                flops of a step / ms_per_step.  `traffic` = HBM bytes per launch of that kernel from the committed PMC pass
+                (`traffic_source`; counters cannot share a run with the timed region: tools/gpu_round4.sh).
   latency_limiter  the limiter of the latency regime: FPS, reported in its own units (ns per dependent round,
                 distance evaluations/s, share of the single-batch latency) instead of an HBM fraction
   kernels       per-kernel accounting (algorithmic bytes|flops, HIP-event duration) for every kernel of the step
+  other_inputs  the same graphs on the reference benchmark's own input (S-randn, benchmark.py:16-18) and on a cloud with a
+                quarter of its rows duplicated (S-dup25): both regimes, the times of the data-dependent kernels (FPS, ball
+                query, three_nn) and which of them are more than 1.5 x slower than on S-scene
+  per_rank_points_per_s   every rank's own rate (N > 1: a slow rank is visible on the line)
   other_configs driver-timed lines for BASELINE configs[2] (MSG module), configs[4] (large scene, bf16) and
                 configs[3] at one GPU (training step)
   north_star    the two kernel-level targets of BASELINE.json measured at their own shape
                 (ball_query+group_point and the fused grouped MLP at B=16,N=8192,M=1024,K=32,C=128)
   cpu_baseline  the CPU oracle (oracle/, OpenMP C + numpy fp32) on the same workload, rank 0, N=1
+`--train` (BASELINE configs[3]) prints the training line instead; at N > 1 it decomposes the step: allreduce_early_ms /
+allreduce_late_ms (each gradient bucket's all-reduce alone), exposed_comm_ms (what a real step waits for them), ms_per_step_no_comm
+and scaling_efficiency (the same job with its collectives skipped), per_rank_ms_per_step.
 """
 import argparse
 import json
