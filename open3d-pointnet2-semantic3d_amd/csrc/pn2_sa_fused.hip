@@ -91,14 +91,33 @@ __device__ __forceinline__ int l1_chan(int s, int h, int c, bool vec8, bool dens
     return ch < c ? base + ch : -1;
 }
 
+// LDS weight layout of sa_fused_kernel (r04): row (k-step s, half-wave h) = w floats at Wp[(2 s + h) w]; inside a row the NT
+// column tiles are INTERLEAVED -- column 32 nt + l sits at l NT + nt -- so that a lane fetches its NT operands of a k-step with
+// ONE LDS read (ds_read_b128 at NT = 4, b64 at 2) instead of NT reads at stride 32: non-MFMA instructions cost their full
+// issue time on a SIMD whose matrix pipe is busy (fp_chain_pipe_kernel's header).  `wrow` = Wp + (2 s + h) w + l31 NT.
+typedef float f32x2w __attribute__((ext_vector_type(2)));
+template <int NT>
+__device__ __forceinline__ void load_w(float (&wv)[NT], const float* __restrict__ wrow) {
+    if constexpr (NT == 4) {
+        const f32x4 v = *reinterpret_cast<const f32x4*>(wrow);
+        wv[0] = v[0]; wv[1] = v[1]; wv[2] = v[2]; wv[3] = v[3];
+    } else if constexpr (NT == 2) {
+        const f32x2w v = *reinterpret_cast<const f32x2w*>(wrow);
+        wv[0] = v[0]; wv[1] = v[1];
+    } else {
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) wv[nt] = wrow[nt];
+    }
+}
+
 template <int NT, bool LAST>
 __device__ __forceinline__ void mfma_step(f32x16 (&acc)[NT], const float* __restrict__ wrow, float act) {
-    // wrow points at Wp[(s*2+half)*w + l31]
+    float wv[NT];
+    load_w<NT>(wv, wrow);
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) {
-        const float wv = wrow[nt * 32];
-        if constexpr (LAST) acc[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(act, wv, acc[nt], 0, 0, 0);
-        else acc[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(wv, act, acc[nt], 0, 0, 0);
+        if constexpr (LAST) acc[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(act, wv[nt], acc[nt], 0, 0, 0);
+        else acc[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(wv[nt], act, acc[nt], 0, 0, 0);
     }
 }
 
@@ -142,11 +161,6 @@ __device__ __forceinline__ void bias_relu_T_pk(f32x16 (&acc)[NT], const float* _
 // step s+1 are issued ahead of the MFMAs of step s and a sched_barrier pins that
 // order: without it the scheduler hoists all NTP*16*NT ds_reads of the unrolled
 // body to the top and the kernel spills.
-template <int NT>
-__device__ __forceinline__ void load_w(float (&wv)[NT], const float* __restrict__ wrow) {
-#pragma unroll
-    for (int nt = 0; nt < NT; ++nt) wv[nt] = wrow[nt * 32];
-}
 
 template <int NT, bool LAST>
 __device__ __forceinline__ void mfma_regs(f32x16 (&acc)[NT], const float (&wv)[NT], float act) {
@@ -165,7 +179,7 @@ constexpr int kPF = 4;
 template <int NTP, int NT, bool LAST>
 __device__ __forceinline__ void layer_from_regs(const f32x16 (&in)[NTP], f32x16 (&acc)[NT],
                                                 const float* __restrict__ wp, int w, int half, int l31) {
-    const float* __restrict__ wl = wp + half * w + l31;
+    const float* __restrict__ wl = wp + half * w + l31 * NT;
     constexpr int S = NTP * 16;
     float wq[kPF][NT];
 #pragma unroll
@@ -335,7 +349,8 @@ sa_fused_kernel(SaFusedParams p) {
     // Weight staging, 8 independent global loads in flight per thread (the permutation index maths is
     // cheap; what must be hidden is the L2 latency -- a workgroup may own only a handful of tiles).
     // 16-byte version: index_of(e4) returns the global FLOAT index of 4 consecutive columns (or -1).
-    auto stage4 = [&](float* dst, int count4, const float* __restrict__ src, auto index_of) {
+    auto stage4 = [&](float* dst, int count4, const float* __restrict__ src, auto index_of, int ntw) {
+        const int W = ntw * 32;
         for (int base = 0; base < count4; base += NTH * 8) {
             f32x4 v[8];
 #pragma unroll
@@ -349,7 +364,16 @@ sa_fused_kernel(SaFusedParams p) {
 #pragma unroll
             for (int u = 0; u < 8; ++u) {
                 const int e = base + u * NTH + tid;
-                if (e < count4) *reinterpret_cast<f32x4*>(dst + e * 4) = v[u];
+                if (e < count4) {
+                    if (ntw == 1) {
+                        *reinterpret_cast<f32x4*>(dst + e * 4) = v[u];
+                    } else {  // columns col .. col+3 of row sh share their column tile: position (col & 31) ntw + (col >> 5), stride ntw
+                        const int col = (e % (W / 4)) * 4, sh = e / (W / 4);
+                        float* __restrict__ d = dst + sh * W + (col & 31) * ntw + (col >> 5);
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) d[j * ntw] = v[u][j];
+                    }
+                }
             }
         }
     };
@@ -360,14 +384,14 @@ sa_fused_kernel(SaFusedParams p) {
         const int col = (e4 % (W1 / 4)) * 4, sh = e4 / (W1 / 4);
         const int ch = l1_chan(sh >> 1, sh & 1, c, VEC8, DENSE, c1);
         return ch >= 0 ? ch * W1 + col : -1;
-    });
+    }, NT1);
     stage1(sb1, W1, p.bias[0]);
     if constexpr (L >= 2) {
         stage4(wp2, W1 * W2 / 4, p.W[1], [&](int e4) {
             const int col = (e4 % (W2 / 4)) * 4, sh = e4 / (W2 / 4);
             const int s = sh >> 1, h = sh & 1;
             return ((s >> 4) * 32 + acc_chan(s & 15, h)) * W2 + col;
-        });
+        }, NT2);
         stage1(sb2, W2, p.bias[1]);
     }
     if constexpr (L >= 3) {
@@ -375,7 +399,7 @@ sa_fused_kernel(SaFusedParams p) {
             const int col = (e4 % (W3 / 4)) * 4, sh = e4 / (W3 / 4);
             const int s = sh >> 1, h = sh & 1;
             return ((s >> 4) * 32 + acc_chan(s & 15, h)) * W3 + col;
-        });
+        }, NT3);
         stage1(sb3, W3, p.bias[2]);
     }
     __syncthreads();
@@ -398,7 +422,7 @@ sa_fused_kernel(SaFusedParams p) {
         f32x16 a1[NT1];
         zero_acc<NT1>(a1);
         constexpr bool LAST1 = (L == 1);
-        const float* w1l = wp1 + half * W1 + l31;
+        const float* w1l = wp1 + half * W1 + l31 * NT1;
         constexpr int S0 = DENSE ? 0 : 2;  // first feature k-step
         if constexpr (DENSE) {
             const int row = g * 32 + l31;
