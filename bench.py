@@ -90,6 +90,8 @@ def s_dup25(seed, b, n):
 
 
 FPS_KERNELS = ("farthest_point_sample", "fps_gather", "fps_nested")
+# one workgroup per cloud, latency-bound like the samplers (they hide behind the other batches when several are in flight)
+LATENCY_KERNELS = FPS_KERNELS + ("coarse_geometry",)
 
 # HBM bytes per launch of the roofline kernel: PMC counters are a separate rocprofv3 pass (--pmc FETCH_SIZE / WRITE_SIZE cannot
 # share a run with the timed region), so the line cites the committed summary of that pass (tools/gpu_round4.sh,
@@ -116,6 +118,13 @@ def kernel_model(name, a):
     if name in ("pn2_farthest_point_sample", "pn2_fps_gather", "pn2_fps_nested"):
         b, n, m = a[0], a[1], a[2]
         return "hbm", b * n * 12 + b * m * 4 + (b * m * 12 if name != "pn2_farthest_point_sample" else 0)
+    if name == "pn2_coarse_geometry":  # ints: b, n0, nlev, fps mode, bq mode, then (decoded by _lib) npoint[], nsample[]
+        b, n, L = a[:3]
+        byts = b * n * 12
+        for m, ns in zip(a[5:5 + L], a[5 + L:5 + 2 * L]):
+            byts += b * (m * 16 + m * ns * 4 + m * 4 + n * 24)
+            n = m
+        return "hbm", byts
     if name == "pn2_gather_point":
         b, n, m = a[:3]
         return "hbm", b * m * 4 + b * m * 12 * 2
@@ -666,6 +675,8 @@ def main():
     ap.add_argument("--wide", default="auto", help="A/B: off = one pn2_linear per coarse-level layer; N = pn2_*_mlp_wide from N rows on")
     ap.add_argument("--no-hoist", action="store_true", help="A/B: FP first layers computed in place (pn2_fp_mlp_fused) instead of hoisted")
     ap.add_argument("--binned-bq", action="store_true", help="A/B: ball query on a cloud binned once per level on a forked stream (default off)")
+    ap.add_argument("--no-coarse-geometry", action="store_true",
+                    help="A/B: levels 2-4 through the separate sampling / ball-query / three_nn launches instead of pn2_coarse_geometry")
     ap.add_argument("--train", action="store_true",
                     help="BASELINE configs[3] instead of the headline: data-parallel TRAINING steps (forward with batch-stat "
                          "BN + weighted CE + backward + one flat RCCL gradient all-reduce + Adam), 16 scenes per GPU")
@@ -736,6 +747,8 @@ def main():
     pn2.util.pointnet_util.USE_HOISTED_FP = not args.no_hoist
     pn2.util.pointnet_util.USE_HOISTED_SA = not args.no_hoist
     pn2.util.pointnet_util.USE_BINNED_BALL_QUERY = bool(args.binned_bq)
+    if args.no_coarse_geometry:
+        pn2.util.pointnet_util.USE_COARSE_GEOMETRY = False
     pn2._lib.lib.dup = tuple(args.dup)
     fused_fp = args.fp_front != "unfused"
     pn2.util.pointnet_util.USE_FUSED_FP = fused_fp
@@ -825,7 +838,7 @@ def main():
         total_points = world * B * N * args.steps
         ms_per_step = elapsed / args.steps * 1e3
         P_eff = 1 if args.eager else max(1, args.pipeline)
-        is_fps = lambda k: k["kernel"] in FPS_KERNELS  # noqa: E731
+        is_fps = lambda k: k["kernel"] in LATENCY_KERNELS  # noqa: E731
         dense = [k for k in kernels if not is_fps(k)]
         fps = [k for k in kernels if is_fps(k)]
         sum_all = sum(k["ms_per_step"] for k in kernels)
@@ -886,7 +899,11 @@ def main():
                              "flops_per_step": int(ref_flops), "effective": round(eff_tf, 2), "unit": "TFLOP/s",
                              "frac_of_peak_equivalent": round(eff_tf / MFMA_F32_PEAK_TF, 4)},
                          "kernel_time_sums_ms": {"all": round(sum_all, 4), "without_fps": round(sum_dense, 4),
-                                                 "fps": round(sum_all - sum_dense, 4)}},
+                                                 "fps": round(sum(k["ms_per_step"] for k in fps if k["kernel"] in FPS_KERNELS), 4),
+                                                 "coarse_geometry": round(sum(k["ms_per_step"] for k in fps
+                                                                              if k["kernel"] == "coarse_geometry"), 4),
+                                                 "note": "without_fps = the chip-filling kernels: everything but the samplers "
+                                                         "and pn2_coarse_geometry (latency-bound, a few workgroups per cloud)"}},
             "per_rank_points_per_s": [round(v, 1) for v in per_rank_pps],
             "kernels": kernels,
             "single_batch_latency_ms": None if latency_ms is None else round(latency_ms, 4),
@@ -894,14 +911,15 @@ def main():
         }
         res.update(rccl_info(world))
         if fps:
-            f0 = max(fps, key=lambda k: k["ms_per_step"])
+            f0 = max([k for k in fps if k["kernel"] in FPS_KERNELS], key=lambda k: k["ms_per_step"])
             fb, fn, fm = f0["args"][:3]
             res["latency_limiter"] = {
                 "kernel": f0["kernel"], "args": f0["args"], "avg_us": f0["avg_us"],
                 "bound": "latency: m-1 dependent rounds on one CU per scene (neither HBM nor MFMA)",
                 "ns_per_round": round(f0["avg_us"] * 1e3 / max(1, fm - 1), 1),
                 "distance_evals_per_s": round(fb * (fm - 1) * fn / (f0["avg_us"] * 1e-6), 1),
-                "fps_chain_ms": round(sum_all - sum_dense, 4),
+                "fps_chain_ms": round(sum(k["ms_per_step"] for k in fps if k["kernel"] in FPS_KERNELS), 4),
+                "geometry_chain_ms": round(sum_all - sum_dense, 4),  # samplers + pn2_coarse_geometry (levels 2-4 in one launch)
                 "share_of_single_batch_latency": None if latency_ms is None else round((sum_all - sum_dense) / latency_ms, 3),
                 "hbm_frac": f0["frac"],
                 "note": "a round is a dependent chain (LDS read -> distance -> max tree -> 6 DPP steps -> LDS atomic -> "
@@ -944,7 +962,7 @@ def main():
                 res["other_inputs"][nm] = {
                     "ms_per_step": round(thr, 4), "points_per_s": round(B * N / (thr * 1e-3), 1),
                     "single_batch_latency_ms": round(lat, 4),
-                    "fps_us": pick(FPS_KERNELS), "query_ball_point_us": pick(("query_ball_point", "query_ball_point_binned")),
+                    "fps_us": pick(FPS_KERNELS), "coarse_geometry_us": pick(("coarse_geometry",)), "query_ball_point_us": pick(("query_ball_point", "query_ball_point_binned")),
                     "three_nn_us": pick(("three_nn",)),
                     "gpu_ms_per_step_sum_of_kernels": round(sum(k["ms_per_step"] for k in ks), 4),
                     "slower_than_1.5x_S-scene": slow}

@@ -81,6 +81,23 @@ int pn2_fps_gather(int b, int n, int m, const float *inp, float *temp, int *out,
 int pn2_fps_nested(int b, int n, int m, const float *inp, float *temp, int *out, float *new_xyz,
                    const int *tie_in, int *tie_out, int arith_mode, void *stream);
 
+/* The coarse levels of the pyramid in ONE launch (extension; replaces 3 launches per level): for l = 0 .. nlev-1, with the
+ * source cloud of level l = the samples of level l-1 (level 0: xyz0 (b,n0,3)):
+ *   fps_idx[l] (b,npoint[l]) int32, new_xyz[l] (b,npoint[l],3)   = pn2_fps_nested   (util/pointnet_util.py:36-37)
+ *   bq_idx[l] (b,npoint[l],nsample[l]) int32, bq_cnt[l] (b,npoint[l]) or NULL = pn2_query_ball_point(radius[l], nsample[l],
+ *                                                                 source cloud, new_xyz[l])      (util/pointnet_util.py:39)
+ *   nn_dist[l], nn_idx[l] (b,n_l,3), n_l = points of the source cloud, or NULL = pn2_three_nn(source cloud, new_xyz[l])
+ *                                                                 (util/pointnet_util.py:300 of the FP level above it)
+ * bit for bit.  npoint / radius / nsample are HOST arrays of nlev entries, fps_idx ... nn_idx HOST arrays of nlev device
+ * pointers (nn_dist / nn_idx / bq_cnt may be NULL as a whole or per level).  tie_in (b) or NULL: tie record of the run that
+ * produced xyz0 (pn2_fps_nested); tie_out (b) or NULL: the record of the last level.  One workgroup per cloud walks down the
+ * levels.  PN2_EUNSUP: n0 > 1024, nlev > 4, npoint[l] > points of its source cloud, or a 3-NN table over more than 256
+ * samples -- use the separate entry points. */
+int pn2_coarse_geometry(int b, int n0, int nlev, const int *npoint, const float *radius, const int *nsample,
+                        const float *xyz0, const int *tie_in, int *const *fps_idx, float *const *new_xyz,
+                        int *const *bq_idx, int *const *bq_cnt, float *const *nn_dist, int *const *nn_idx,
+                        int *tie_out, int fps_arith_mode, int bq_arith_mode, void *stream);
+
 /* probsampleLauncher(b,n,m,inp_p,inp_r,temp,out)  tf_sampling.cu:212-216, tf_sampling.cpp:72.  inp_p (b,n)
  * non-negative weights, inp_r (b,m) uniforms in [0,1) -> out (b,m) int32: the index at which the running sum of
  * the weights reaches inp_r * total (the reference's exact fp32 summation order and branch-free binary search).

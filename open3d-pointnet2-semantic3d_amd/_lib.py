@@ -21,6 +21,8 @@ SIGNATURES = {
     "pn2_farthest_point_sample": [c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_int, c_void_p],
     "pn2_fps_gather": [c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p],
     "pn2_fps_nested": [c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p],
+    "pn2_coarse_geometry": [c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                            c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p],
     "pn2_prob_sample": [c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p],
     "pn2_fps_large": [c_int, c_int, c_int, c_void_p, c_void_p, ctypes.c_size_t, c_void_p, c_void_p, c_int, c_void_p],
     "pn2_gather_point": [c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p],
@@ -223,6 +225,8 @@ class _LibProxy:
             elif name in ("pn2_fp_mlp_fused_pre", "pn2_fp_mlp_fused_pre_schedule"):  # (b, n, m, c1, dist, idx, points1, z, nlayers, widths, ...)
                 wp = ctypes.cast(args[9], ctypes.POINTER(c_int))
                 ints += [wp[i] for i in range(args[8])]
+            elif name == "pn2_coarse_geometry":  # (b, n0, nlev, npoint[], radius[], nsample[], ...): decode the host arrays
+                ints += list(args[3]) + list(args[5])
             elif name == "pn2_mlp_chain":
                 wp = ctypes.cast(args[4], ctypes.POINTER(c_int))
                 ints += [wp[i] for i in range(args[3])]

@@ -60,6 +60,22 @@ struct Pn2BnGradEpilogue {
     int relu;
 };
 
+// Largest float T with  max(sqrtf(T), 1e-20f) < radius  (sqrtf correctly rounded, hence monotone): for every s >= 0,
+// (s <= T) <=> the reference's ball-query predicate tf_grouping.cu:28-31.  Returns -1 when nothing can match.  Host side.
+inline float pn2_ball_threshold(float radius) {
+    if (!(radius > 1e-20f)) return -1.0f;
+    auto pred = [radius](float s) { return sqrtf(s) < radius; };
+    float t = radius * radius;
+    if (!(t <= 3.402823466e38f)) t = 3.402823466e38f;
+    while (!pred(t)) t = nextafterf(t, -INFINITY);
+    for (;;) {
+        const float u = nextafterf(t, INFINITY);
+        if (!(u <= 3.402823466e38f) || !pred(u)) break;
+        t = u;
+    }
+    return t;
+}
+
 // Squared distance exactly as the reference expression
 //   (x2-x1)*(x2-x1) + (y2-y1)*(y2-y1) + (z2-z1)*(z2-z1)
 // (tf_sampling.cu:149-150, tf_grouping.cu:28-30) under the three contraction

@@ -21,22 +21,8 @@ namespace {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
-// Largest float T with  max(sqrtf(T), 1e-20f) < radius  (sqrtf correctly rounded,
-// hence monotone): for every s >= 0, (s <= T) <=> the reference predicate
-// tf_grouping.cu:28-31.  Returns -1 when nothing can match.
-float ball_threshold(float radius) {
-    if (!(radius > 1e-20f)) return -1.0f;
-    auto pred = [radius](float s) { return sqrtf(s) < radius; };
-    float t = radius * radius;
-    if (!(t <= 3.402823466e38f)) t = 3.402823466e38f;
-    while (!pred(t)) t = nextafterf(t, -INFINITY);
-    for (;;) {
-        const float u = nextafterf(t, INFINITY);
-        if (!(u <= 3.402823466e38f) || !pred(u)) break;
-        t = u;
-    }
-    return t;
-}
+// ball_threshold(radius): pn2_ball_threshold, pn2_common.h
+inline float ball_threshold(float radius) { return pn2_ball_threshold(radius); }
 
 constexpr int kBqThreads = 256;
 constexpr int kBqWaves = kBqThreads / 64;

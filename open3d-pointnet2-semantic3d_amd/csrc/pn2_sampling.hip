@@ -18,39 +18,16 @@
 // The kernel is latency-bound (m-1 dependent rounds), not HBM-bound: its HBM
 // traffic is b*n*12 + b*m*4 bytes in total.
 #include "pn2_fps_common.h"
+#include "pn2_fps_reg.h"
 
 namespace {
+
+using namespace pn2fpsreg;
 
 using pn2fps::kLazyCap;
 using pn2fps::wave_imax_from;
 using pn2fps::wave_umax_all;
 
-constexpr int kFpsSlotsMax = 16;  // waves per workgroup <= 16
-constexpr int kFpsRegHead = 48;   // fps_reg_kernel: bytes of LDS in front of the cloud copy (key slots + tie record)
-
-__device__ __forceinline__ unsigned fps_tiekey(int k) {
-    return (((unsigned)k & 511u) << 22) | ((unsigned)k >> 9);
-}
-__device__ __forceinline__ int fps_untiekey(unsigned key) {
-    return (int)(((key & 0x3FFFFFu) << 9) | (key >> 22));
-}
-
-// Fused-DPP wave64 reductions on 32-bit keys (one VALU op per step; the s_nop 1
-// are the 2 wait states a DPP read needs after a VALU write of the same VGPR).
-// All distances are >= +0, so their bit patterns order like signed/unsigned ints;
-// the sentinel -1.0f (threads without points) is a negative int.
-__device__ __forceinline__ int wave_imax(int v) {
-    asm volatile(
-        "s_nop 1\n"
-        "v_max_i32_dpp %0, %0, %0 row_shr:1 row_mask:0xf bank_mask:0xf\n s_nop 1\n"
-        "v_max_i32_dpp %0, %0, %0 row_shr:2 row_mask:0xf bank_mask:0xf\n s_nop 1\n"
-        "v_max_i32_dpp %0, %0, %0 row_shr:4 row_mask:0xf bank_mask:0xf\n s_nop 1\n"
-        "v_max_i32_dpp %0, %0, %0 row_shr:8 row_mask:0xf bank_mask:0xf\n s_nop 1\n"
-        "v_max_i32_dpp %0, %0, %0 row_bcast:15 row_mask:0xa bank_mask:0xf\n s_nop 1\n"
-        "v_max_i32_dpp %0, %0, %0 row_bcast:31 row_mask:0xc bank_mask:0xf\n s_nop 1\n"
-        : "+v"(v));
-    return __builtin_amdgcn_readlane(v, 63);
-}
 // max over lanes 0..15 (row 0), result from lane 15
 __device__ __forceinline__ int row0_imax(int v) {
     asm volatile(
@@ -110,204 +87,17 @@ __device__ __forceinline__ float wave_fmax_all(float v) {
     for (int o = 32; o >= 1; o >>= 1) v = fmaxf(v, __shfl_xor(v, o));
     return v;
 }
-__device__ __forceinline__ unsigned wave_umin_all(unsigned v) {
-#pragma unroll
-    for (int o = 32; o >= 1; o >>= 1) { const unsigned t = (unsigned)__shfl_xor((int)v, o); v = t < v ? t : v; }
-    return v;
-}
-
-// Exact 64-bit max of two (td bits : ~tiekey) pairs read as doubles.  The high word is an fp32 pattern in [0, bits(1e38f)]
-// (or bits(-1.0f) for "no point"), so the doubles are finite; pairs with td < 2^-126-ish map to fp64 DENORMALS (high word
-// < 0x00100000), which v_max_f64 orders correctly only because the kernel runs with fp64 denormals enabled -- the
-// default float mode of HIP kernels on gfx9 (FP64/FP16 denormals on, MODE.FP_DENORM = 0b11xx; only fp32 denormals are
-// affected by -fgpu-flush-denormals-to-zero).  tests/test_ops_gpu.py::test_fps_duplicates_and_degenerate and the
-// lattice tests (td == 0 everywhere) would fail if that ever changed.  (Inline asm: no canonicalisation inserted.)
-__device__ __forceinline__ double fps_dmax(double a, double b) {
-    double r;
-    asm("v_max_f64 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
-    return r;
-}
-
-// Nested sampling (pn2_fps_nested).  When `inp` is itself the (b,n,3) output of an FPS + gather of a larger cloud, its
-// rows are that run's picks in pick order, and FPS restricted to those rows retraces them: at step j the row j holds
-// the maximum td over the WHOLE parent cloud, hence over the subset, with bit-identical td values (same operands, same
-// expression) -- the pick is j itself unless another row TIES with it (then this level's tie-break by (j mod 512, j)
-// may differ from the parent's).  The parent run reports per cloud the first step at which its maximum was not unique
-// (pn2fps::TieTrack); a level asked for m <= that step is the identity: idx = 0..m-1, new_xyz = the first m rows.  The
-// answer is exact, not approximate: tests/test_ref_gpu.py holds it against the reference's kernel on tie-free and
-// tie-heavy clouds.  Returns true when the workgroup took the shortcut (uniform per workgroup).
-__device__ __forceinline__ bool fps_nested_shortcut(int n, int m, const float* __restrict__ xyz, int* __restrict__ out,
-                                                    float* __restrict__ nxyz, const int* __restrict__ tie_in,
-                                                    int* __restrict__ tie_out, int nthreads) {
-    if (tie_in == nullptr) return false;
-    const int T = __builtin_amdgcn_readfirstlane(tie_in[blockIdx.x]);
-    if (T < m || m > n) return false;
-    for (int jj = threadIdx.x; jj < m; jj += nthreads) out[jj] = jj;
-    if (nxyz) for (int e = threadIdx.x; e < m * 3; e += nthreads) nxyz[e] = xyz[e];
-    if (tie_out && threadIdx.x == 0) tie_out[blockIdx.x] = T;  // the prefix of a prefix: the same bound holds below
-    return true;
-}
-
-// NT threads, thread t owns points k = t + NT*i (i < PPT) in VGPRs for the whole kernel: coordinates and ONE 64-bit
-// register pair per point,
-//          (td bits : ~tiekey(k))        td = running min distance (>= +0: int order == float order),
-// read as a double.  For these bit patterns v_max_f64 is an exact 64-bit max, i.e. exactly the reference's order
-// (max td, then lowest k mod 512, then lowest k; tf_sampling.cu:153-170): the tie-break key rides through every
-// max, there is no "which of my points was it" search in the round and no constraint on the thread layout.
-// A round:
-//   1. distance update (fp32 sub/mul/fma: 2-cycle VALU pipe) + v_min_i32 on the high words, v_max_f64 tree;
-//   2. wave max of the high word by fused DPP; the lanes holding it (normally one) publish their pair with ONE
-//      LDS atomic max (ds_max_u64) -- the LDS unit merges lanes and waves;
-//   3. one barrier, one broadcast read of the winning pair, one broadcast read of the winner's xyz.
-// Three key slots rotate so the reset of a slot never races with its readers.  A single-wave block (NT == 64)
-// needs neither LDS atomics nor barriers: ballot + v_readlane.
-// TRACK: also write the run's tie record (pn2fps::tie_*) for the level below.
+// fps_reg_kernel: pn2fpsreg::fps_reg_body on cloud blockIdx.x, after the nested-sampling shortcut
 template <int NT, int PPT, int MODE, bool LDS_XYZ, bool TRACK>
 __global__ void __launch_bounds__(NT)
 fps_reg_kernel(int n, int m, const float* __restrict__ xyz_all, int* __restrict__ out_all,
                float* __restrict__ new_xyz_all, const int* __restrict__ tie_in, int* __restrict__ tie_out) {
-    static_assert(NT != 64 || LDS_XYZ, "single-wave path keeps the cloud in LDS");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    // layout: 4 x u64 key slots (3 used), 4 x i32 tie record (3 used) | float4 xyz[n] (if LDS_XYZ) | int picks[m] (if LDS_XYZ)
-    // The picks are kept in LDS and written to HBM once, coalesced, after the last round (together
-    // with their coordinates when the fused gather is requested): no global store sits on the
-    // round-to-round critical path of wave 0.
-    unsigned long long* slots = reinterpret_cast<unsigned long long*>(smem);
-    int* ttl = reinterpret_cast<int*>(smem + 4 * sizeof(unsigned long long));  // pn2fps::tie_* (TRACK only)
-    float4* sxyz = reinterpret_cast<float4*>(smem + kFpsRegHead);
-    int* spick = reinterpret_cast<int*>(sxyz + (LDS_XYZ ? n : 0));
-
-    const int tid = threadIdx.x;
     const float* __restrict__ xyz = xyz_all + (size_t)blockIdx.x * n * 3;
     int* __restrict__ out = out_all + (size_t)blockIdx.x * m;
-    // optional fused gather_point (tf_sampling.cu:178-191): the coordinates of every pick pass through
-    // this kernel anyway, so new_xyz[j] = xyz[out[j]] costs three extra stores per round
     float* __restrict__ nxyz = new_xyz_all ? new_xyz_all + (size_t)blockIdx.x * m * 3 : nullptr;
     if (fps_nested_shortcut(n, m, xyz, out, nxyz, tie_in, tie_out, NT)) return;
-    // TRACK: a second holder of the previous round's maximum is looked for at the top of the next round, when the winner's
-    // coordinates are at hand anyway
-    int pw_hi = -2;               // the previous winner's td bits (-2: none yet, never a point's high word)
-    unsigned pw_lo = 0u;
-
-    float px[PPT], py[PPT], pz[PPT];
-    double mk[PPT];
-#pragma unroll
-    for (int i = 0; i < PPT; ++i) {
-        const int k = tid + NT * i;
-        int hi;
-        if (k < n) {
-            px[i] = xyz[k * 3 + 0];
-            py[i] = xyz[k * 3 + 1];
-            pz[i] = xyz[k * 3 + 2];
-            hi = __float_as_int(1e38f);  // tf_sampling.cu:124-126
-            if constexpr (LDS_XYZ) sxyz[k] = make_float4(px[i], py[i], pz[i], 0.f);
-        } else {
-            px[i] = py[i] = pz[i] = 0.f;
-            hi = __float_as_int(-1.0f);  // never selected: a negative double, below every real pair
-        }
-        mk[i] = __hiloint2double(hi, (int)~fps_tiekey(k));
-    }
-    if (tid < 4) slots[tid] = 0ull;
-    if (TRACK && tid == 0) pn2fps::tie_init(ttl);
-    if (tid == 0) {  // first pick is index 0 (tf_sampling.cu:122-123)
-        if constexpr (LDS_XYZ) spick[0] = 0; else out[0] = 0;
-    }
-    __syncthreads();
-
-    int old = 0;
-    int slot = 1;  // j % 3
-    for (int j = 1; j < m; ++j) {
-        float x1, y1, z1;
-        if constexpr (LDS_XYZ) {
-            const float4 p = sxyz[old];
-            x1 = p.x; y1 = p.y; z1 = p.z;
-        } else {
-            x1 = xyz[old * 3 + 0]; y1 = xyz[old * 3 + 1]; z1 = xyz[old * 3 + 2];
-            if (nxyz && tid == 0) { nxyz[(j - 1) * 3 + 0] = x1; nxyz[(j - 1) * 3 + 1] = y1; nxyz[(j - 1) * 3 + 2] = z1; }
-        }
-        if constexpr (TRACK) {
-            // mk still holds the td the previous maximum was taken over: exactly ONE point of the cloud -- the winner, owned
-            // by lane (old % NT) -- may carry its value.  Branch-free count per wave: OR and XOR of the per-row ballots differ
-            // when one lane holds it twice, the population of the OR counts the lanes.
-            unsigned long long m_or = 0ull, m_xor = 0ull;
-#pragma unroll
-            for (int i = 0; i < PPT; ++i) {
-                const unsigned long long hb = __builtin_amdgcn_ballot_w64(__double2hiint(mk[i]) == pw_hi);
-                m_or |= hb; m_xor ^= hb;
-            }
-            const int expect = (((old & (NT - 1)) >> 6) == (tid >> 6)) ? 1 : 0;
-            if (__builtin_expect(m_or != m_xor || __popcll(m_or) != expect, 0)) {
-#pragma unroll
-                for (int i = 0; i < PPT; ++i) {
-                    if (__double2hiint(mk[i]) == pw_hi && (unsigned)__double2loint(mk[i]) != pw_lo)
-                        pn2fps::tie_note(ttl, j - 1, pw_hi == 0 || px[i] != x1 || py[i] != y1 || pz[i] != z1, pw_hi == 0);
-                }
-            }
-        }
-#pragma unroll
-        for (int i = 0; i < PPT; ++i) {
-            const float d = pn2_sqdist<MODE>(px[i] - x1, py[i] - y1, pz[i] - z1);
-            const int di = __float_as_int(d), oh = __double2hiint(mk[i]);  // d >= +0: int order == float order
-            mk[i] = __hiloint2double(di < oh ? di : oh, __double2loint(mk[i]));  // min(d, td) :151 on the high word
-        }
-        double tr[PPT];
-#pragma unroll
-        for (int i = 0; i < PPT; ++i) tr[i] = mk[i];
-#pragma unroll
-        for (int w = PPT; w > 1; w = (w + 1) / 2) {
-#pragma unroll
-            for (int g = 0; g < w / 2; ++g) tr[g] = fps_dmax(tr[g], tr[w - 1 - g]);
-        }
-        const int best = __double2hiint(tr[0]);
-        const int wmax = wave_imax(best);
-        if constexpr (NT == 64) {
-            // one wave: the winner is resolved with a ballot (equal td across lanes: lowest tie key = largest low
-            // word); no LDS atomic, no barrier in the round
-            const unsigned long long bal = __ballot(best == wmax);
-            const unsigned lo = (unsigned)__double2loint(tr[0]);
-            unsigned wl;
-            if (__popcll(bal) == 1) wl = (unsigned)__builtin_amdgcn_readlane((int)lo, __ffsll((long long)bal) - 1);
-            else wl = ~wave_umin_all(best == wmax ? ~lo : 0xFFFFFFFFu);
-            old = fps_untiekey(~wl);
-            if (tid == 0) spick[j] = old;
-            if constexpr (TRACK) { pw_hi = wmax; pw_lo = wl; }
-            continue;
-        }
-        if (best == wmax && wmax >= 0) {  // normally a single lane of the wave
-            // one ds_max_u64 per winning lane (normally exactly one per wave); written as asm so the
-            // compiler's uniform-address atomic optimiser does not wrap it in a per-lane scalar loop
-            const unsigned long long comp = (unsigned long long)__double_as_longlong(tr[0]);
-            const unsigned saddr = (unsigned)(size_t)(&slots[slot]);  // LDS byte address (low 32 bits of the generic pointer)
-            asm volatile("ds_max_u64 %0, %1\n s_waitcnt lgkmcnt(0)" : : "v"(saddr), "v"(comp) : "memory");
-        }
-        __syncthreads();
-        const unsigned long long win = slots[slot];
-        old = fps_untiekey(~(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)win));
-        if constexpr (TRACK) { pw_hi = (int)(unsigned)(win >> 32); pw_lo = (unsigned)win; }
-        const int nxt = slot == 2 ? 0 : slot + 1;          // (j+1) % 3
-        if (tid == 0) {
-            slots[nxt == 2 ? 0 : nxt + 1] = 0ull;          // (j+2) % 3: last read after barrier j-1, next used in round j+2
-            if constexpr (LDS_XYZ) spick[j] = old; else out[j] = old;
-        }
-        slot = nxt;
-    }
-    if constexpr (LDS_XYZ) {
-        __syncthreads();
-        for (int jj = tid; jj < m; jj += NT) {
-            const int k = spick[jj];
-            out[jj] = k;
-            if (nxyz) {
-                const float4 p = sxyz[k];
-                nxyz[jj * 3 + 0] = p.x; nxyz[jj * 3 + 1] = p.y; nxyz[jj * 3 + 2] = p.z;
-            }
-        }
-    } else if (nxyz && tid == 0) {  // coordinates of the last pick
-        nxyz[(m - 1) * 3 + 0] = xyz[old * 3 + 0]; nxyz[(m - 1) * 3 + 1] = xyz[old * 3 + 1]; nxyz[(m - 1) * 3 + 2] = xyz[old * 3 + 2];
-    }
-    if constexpr (TRACK) {  // (ties of the LAST pick are not looked at: a consumer asks for fewer picks than this level made)
-        __syncthreads();
-        if (tid == 0 && tie_out) tie_out[blockIdx.x] = pn2fps::tie_first(ttl);
-    }
+    fps_reg_body<NT, PPT, MODE, LDS_XYZ, TRACK>(n, m, xyz, out, nxyz, tie_out ? tie_out + blockIdx.x : nullptr, smem);
 }
 
 PN2_TUNABLE(int, g_fps_variant, 0)  // tuning hook (pn2_debug_set(0, v)), see dispatch_fps
@@ -976,6 +766,7 @@ extern "C" int pn2_debug_set_bn(int what, int value);
 extern "C" int pn2_debug_set_fused(int what, int value);
 extern "C" int pn2_debug_set_fps_large(int what, int value);
 extern "C" int pn2_debug_set_interp(int what, int value);
+extern "C" int pn2_debug_set_coarse(int what, int value);
 extern "C" int pn2_debug_set_fps_stats(long long* dev_ptr) { g_fps_stats = dev_ptr; return 0; }
 extern "C" int pn2_debug_set(int what, int value) {
     if (what == 0) { g_fps_variant = value; return 0; }
@@ -983,6 +774,7 @@ extern "C" int pn2_debug_set(int what, int value) {
     if (what == 10) return pn2_debug_set_bn(what, value);
     if (what == 11) return pn2_debug_set_fps_large(what, value);
     if (what == 12) return pn2_debug_set_interp(what, value);
+    if (what == 15) return pn2_debug_set_coarse(what, value);
     if (what == 6 || what == 7 || what == 13 || what == 14) return pn2_debug_set_fused(what, value);
     return pn2_debug_set_grouping(what, value);
 }

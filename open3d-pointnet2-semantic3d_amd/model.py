@@ -37,6 +37,17 @@ def load_hyperparams(path):
 
 
 
+def coarse_levels(l1_xyz, hyperparams):
+    """SA levels 2-4 (sampling, ball query) and the 3-NN tables of FP1-FP3 from the level-1 samples in ONE launch
+    (pu.coarse_geometry) -> [level 2, level 3, level 4] or None when the configuration does not fit that kernel."""
+    keys = ["l%d_" % i for i in (2, 3, 4)]
+    npoints = [int(hyperparams[k + "npoint"]) for k in keys]
+    if not pu.coarse_geometry_fits(l1_xyz.shape[1], npoints):
+        return None
+    return pu.coarse_geometry(l1_xyz, npoints, [hyperparams[k + "radius"] for k in keys],
+                              [int(hyperparams[k + "nsample"]) for k in keys])
+
+
 def compute_geometry(l0_xyz, hyperparams, plans=False):
     """The weight-independent half of the whole stack for one batch: FPS + gather + ball query of the four SA levels and
     three_nn of the four FP levels (coordinates only, HIP index kernels, no autograd).  A trainer runs it for batch k+1
@@ -47,13 +58,22 @@ def compute_geometry(l0_xyz, hyperparams, plans=False):
     where the gradient kernel cannot use one (feature width not a multiple of 4) or plans=False."""
     with torch.no_grad():
         xyzs, idxs = [l0_xyz.contiguous()], []
-        for li in range(4):
-            k = "l%d_" % (li + 1)
-            new_xyz, idx = pu.sa_geometry(xyzs[-1], hyperparams[k + "npoint"], hyperparams[k + "radius"],
-                                          hyperparams[k + "nsample"])
-            xyzs.append(new_xyz)
-            idxs.append(idx)
-        nn = [three_nn(xyzs[3 - fi], xyzs[4 - fi]) for fi in range(4)]
+        new_xyz, idx = pu.sa_geometry(xyzs[0], hyperparams["l1_npoint"], hyperparams["l1_radius"], hyperparams["l1_nsample"])
+        xyzs.append(new_xyz)
+        idxs.append(idx)
+        coarse = coarse_levels(new_xyz, hyperparams)  # levels 2-4 and the 3-NN tables of FP1-FP3 in one launch
+        if coarse is not None:
+            xyzs += [lv["new_xyz"] for lv in coarse]
+            idxs += [lv["idx"] for lv in coarse]
+            nn = [coarse[2 - fi]["nn"] for fi in range(3)] + [three_nn(xyzs[0], xyzs[1])]
+        else:
+            for li in range(1, 4):
+                k = "l%d_" % (li + 1)
+                new_xyz, idx = pu.sa_geometry(xyzs[-1], hyperparams[k + "npoint"], hyperparams[k + "radius"],
+                                              hyperparams[k + "nsample"])
+                xyzs.append(new_xyz)
+                idxs.append(idx)
+            nn = [three_nn(xyzs[3 - fi], xyzs[4 - fi]) for fi in range(4)]
         gplans, iplans = [None] * 4, [None] * 4
         if plans:
             for li in range(4):  # level li groups the features of level li: colour (3 wide) for li = 0, else the MLP output
@@ -102,14 +122,21 @@ def get_sa_fp_features(point_cloud, is_training, hyperparams, bn_decay=None, geo
         l0_points = None
     end_points["l0_xyz"] = l0_xyz
     xyzs, feats = [l0_xyz], [l0_points]
+    coarse = None  # geometry not computed ahead: levels 2-4 + the 3-NN tables of FP1-FP3 in one launch after SA1's sampling
     for li in range(4):
         k = "l%d_" % (li + 1)
+        if geometry is not None:
+            geo = (geometry["xyzs"][li + 1], geometry["idxs"][li], geometry.get("gplans", [None] * 4)[li])
+        elif li >= 1 and coarse is not None:
+            geo = (coarse[li - 1]["new_xyz"], coarse[li - 1]["idx"])
+        else:
+            geo = None
         new_xyz, new_points, _ = pointnet_sa_module(
             xyzs[-1], feats[-1], npoint=hyperparams[k + "npoint"], radius=hyperparams[k + "radius"],
             nsample=hyperparams[k + "nsample"], mlp=list(SA_MLPS[li]), mlp2=None, group_all=False,
-            is_training=is_training, bn_decay=bn_decay, scope="layer%d" % (li + 1),
-            geometry=None if geometry is None else (geometry["xyzs"][li + 1], geometry["idxs"][li],
-                                                    geometry.get("gplans", [None] * 4)[li]))
+            is_training=is_training, bn_decay=bn_decay, scope="layer%d" % (li + 1), geometry=geo)
+        if li == 0 and geometry is None:
+            coarse = coarse_levels(new_xyz, hyperparams)
         xyzs.append(new_xyz)
         feats.append(new_points)
 
@@ -123,7 +150,8 @@ def get_sa_fp_features(point_cloud, is_training, hyperparams, bn_decay=None, geo
         lvl = 3 - fi  # target level: 3,2,1,0
         up = pointnet_fp_module(xyzs[lvl], xyzs[lvl + 1], fp_in[lvl], up, list(FP_MLPS[fi]), is_training, bn_decay,
                                 scope="fa_layer%d" % (fi + 1),
-                                nn=None if geometry is None else tuple(geometry["nn"][fi]) + (geometry.get("iplans", [None] * 4)[fi],),
+                                nn=(tuple(geometry["nn"][fi]) + (geometry.get("iplans", [None] * 4)[fi],) if geometry is not None
+                                    else (tuple(coarse[2 - fi]["nn"]) + (None,) if (coarse is not None and fi < 3) else None)),
                                 defer_last_bn=head_width if (fi == 3 and is_training) else 0)
     end_points["xyzs"] = xyzs
     end_points["sa_features"] = feats  # [l0 .. l4] point features of the SA levels (extension: hooks of the trainer)

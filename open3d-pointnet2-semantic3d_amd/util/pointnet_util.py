@@ -286,6 +286,70 @@ def sa_geometry(xyz, npoint, radius, nsample):
     return new_xyz, idx
 
 
+# ---- the coarse levels in one launch (pn2_coarse_geometry) ----------------------------------------------------------------
+# Below the first SA level the clouds are tiny (semantic.json: 1024 -> 256 -> 64 -> 16 points): FPS (or its nested shortcut),
+# ball query and the FP side's three_nn of a level are three launches of 6-13 us for a few us of work, all on the critical
+# path of a batch.  They depend on coordinates only, so one workgroup per cloud walks down the levels in ONE launch; every
+# output is the bits of the separate ops.  False = the separate ops (A/B, tests).
+USE_COARSE_GEOMETRY = True
+COARSE_MAX_N, COARSE_MAX_LEVELS, COARSE_MAX_NN_M = 1024, 4, 256
+
+
+def coarse_geometry_fits(n0, npoints, want_nn=True):
+    """can pn2_coarse_geometry take levels of `npoints` samples under a source cloud of n0 points?"""
+    if not USE_COARSE_GEOMETRY or not (0 < n0 <= COARSE_MAX_N) or not (0 < len(npoints) <= COARSE_MAX_LEVELS):
+        return False
+    n = n0
+    for m in npoints:
+        if not (0 < m <= n) or (want_nn and not (3 <= m <= COARSE_MAX_NN_M)):
+            return False
+        n = m
+    return True
+
+
+def coarse_geometry(xyz0, npoints, radii, nsamples, want_nn=True, fps_arith_mode=None, bq_arith_mode=None):
+    """Levels l = 0 .. len(npoints)-1 under xyz0 (b,n0,3), the source cloud of level l being the samples of level l-1:
+    -> [{"new_xyz" (b,m,3), "fps_idx" (b,m), "idx" (b,m,nsample), "cnt" (b,m), "nn": (dist, idx) (b,n,3) or None}] --
+    farthest_point_sample + gather_point, query_ball_point and (want_nn) three_nn(source cloud, new_xyz) of every level,
+    bit for bit, in one launch (pn2_coarse_geometry).  xyz0 carrying the tie record of the FPS run that produced it
+    (tf_sampling.tag_fps_output) lets the clouds without ties skip the sampling, as farthest_point_sample does."""
+    from .. import config
+    from ..tf_ops.tf_sampling import fps_tie_record
+    require_cuda(xyz0)
+    if xyz0.dim() != 3 or xyz0.shape[2] != 3 or xyz0.dtype != torch.float32:
+        raise ValueError("coarse_geometry expects (batch_size,num_points,3) float32 xyz0")
+    nlev = len(npoints)
+    if not (len(radii) == len(nsamples) == nlev):
+        raise ValueError("coarse_geometry expects one radius and one nsample per level")
+    tie_in = fps_tie_record(xyz0, fps_arith_mode)
+    xyz0 = xyz0.detach().contiguous()
+    b, n0, _ = xyz0.shape
+    dev = xyz0.device
+    out, n = [], n0
+    for m, ns in zip(npoints, nsamples):
+        lv = {"new_xyz": torch.empty((b, m, 3), dtype=torch.float32, device=dev),
+              "fps_idx": torch.empty((b, m), dtype=torch.int32, device=dev),
+              "idx": torch.empty((b, m, ns), dtype=torch.int32, device=dev),
+              "cnt": torch.empty((b, m), dtype=torch.int32, device=dev),
+              "nn": (torch.empty((b, n, 3), dtype=torch.float32, device=dev),
+                     torch.empty((b, n, 3), dtype=torch.int32, device=dev)) if want_nn else None}
+        out.append(lv)
+        n = m
+    tie_out = torch.empty((b,), dtype=torch.int32, device=dev)
+    ia = lambda vals: (ctypes.c_int * nlev)(*[int(v) for v in vals])  # noqa: E731
+    pa = lambda ts: (ctypes.c_void_p * nlev)(*[None if t is None else t.data_ptr() for t in ts])  # noqa: E731
+    with torch.cuda.device(dev):
+        check(lib.pn2_coarse_geometry(b, n0, nlev, ia(npoints), (ctypes.c_float * nlev)(*[float(r) for r in radii]), ia(nsamples),
+                                      ptr(xyz0), ptr(tie_in), pa([lv["fps_idx"] for lv in out]), pa([lv["new_xyz"] for lv in out]),
+                                      pa([lv["idx"] for lv in out]), pa([lv["cnt"] for lv in out]),
+                                      pa([lv["nn"][0] if want_nn else None for lv in out]),
+                                      pa([lv["nn"][1] if want_nn else None for lv in out]), ptr(tie_out),
+                                      config.fps_mode(fps_arith_mode), config.bq_mode(bq_arith_mode), stream_ptr()),
+              "pn2_coarse_geometry")
+    tag_fps_output(out[-1]["new_xyz"], tie_out, fps_arith_mode)  # a further level may nest on the last one
+    return out
+
+
 def sa_features_inference(xyz, new_xyz, points, idx, mlp, bn=True, bn_decay=None):
     """The feature half of an SA layer (inference, max pooling): gather + MLP + max over K,
     fused when the widths allow it.  Must be called inside the layer's variable scope.

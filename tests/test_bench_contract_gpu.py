@@ -38,10 +38,13 @@ def test_bench_json_contract():
     assert r["regimes"]["latency"]["batches_in_flight"] == 1 and r["regimes"]["latency"]["ms_per_step"] >= r["ms_per_step"]
     assert r["roofline"]["regime"] == "throughput" and r["roofline"]["ms_per_step"] <= r["ms_per_step"]
     fps = ("farthest_point_sample", "fps_gather", "fps_nested")
-    assert r["roofline"]["kernel"] not in fps
+    assert r["roofline"]["kernel"] not in fps + ("coarse_geometry",)
+    assert sum(k["launches_per_step"] for k in r["kernels"]) <= 22  # library launches per forward (29 then)
     assert r["latency_limiter"]["kernel"] in fps and r["latency_limiter"]["ns_per_round"] > 0
     # the reference benchmark's own input and a duplicate-heavy cloud, same graphs, on the line
     for nm in ("S-randn", "S-dup25"):
         o = r["other_inputs"][nm]
         assert o["ms_per_step"] > 0 and o["single_batch_latency_ms"] >= o["ms_per_step"]
-        assert len(o["fps_us"]) == 4 and len(o["query_ball_point_us"]) == 4 and len(o["three_nn_us"]) == 4
+        # level 1 has its own sampler / ball query / three_nn launch, levels 2-4 share pn2_coarse_geometry
+        assert len(o["fps_us"]) == 1 and len(o["query_ball_point_us"]) == 1 and len(o["three_nn_us"]) == 1
+        assert len(o["coarse_geometry_us"]) == 1 and o["coarse_geometry_us"][0]["avg_us"] > 0
