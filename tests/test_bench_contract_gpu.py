@@ -39,7 +39,6 @@ def test_bench_json_contract():
     assert r["roofline"]["regime"] == "throughput" and r["roofline"]["ms_per_step"] <= r["ms_per_step"]
     fps = ("farthest_point_sample", "fps_gather", "fps_nested")
     assert r["roofline"]["kernel"] not in fps + ("coarse_geometry",)
-    assert sum(k["launches_per_step"] for k in r["kernels"]) <= 22  # library launches per forward (29 then)
     assert r["latency_limiter"]["kernel"] in fps and r["latency_limiter"]["ns_per_round"] > 0
     # the reference benchmark's own input and a duplicate-heavy cloud, same graphs, on the line
     for nm in ("S-randn", "S-dup25"):
