@@ -659,6 +659,10 @@ ball_query_grid_kernel(int n, int m, float radius, float thr, int nsample, const
     const BqgLds L = bqg_carve(smem_i, np);
     float* sx = L.sx; float* sy = L.sy; float* sz = L.sz;
     int* ccount = L.ccount; int* rowbuf = L.rowbuf;
+    // rowbuf[0..63]: first hit of every query of the workgroup; [64..128]: local numbers of its over-full queries and, in the
+    // last slot, their count (the launch already asks for all 160 KB: no static LDS beside it)
+    int* s_dense = rowbuf + kBqgWaves * kBqgQPW;
+    if (threadIdx.x == 0) s_dense[kBqgWaves * kBqgQPW] = 0;  // (bqg_build / the copy below end with a barrier)
     unsigned short* sidx = L.sidx; unsigned short* cstart = L.cstart; unsigned short* hits = L.hits;
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -738,11 +742,15 @@ ball_query_grid_kernel(int n, int m, float radius, float thr, int nsample, const
             }
         }
         // queries with more than kBqgCap hits (dense balls), the whole wave per query: the hits of the 27 cells set
-        // bits of an 8192-bit map (the histogram memory is free by now), which is then read out in index order
-        const unsigned long long dense = __ballot(qv && !sparse && l16 == 0);
-        for (int g2 = 0; g2 < 4; ++g2) {
-            if (!((dense >> (16 * g2)) & 1ull)) continue;  // wave-uniform
-            const int q2 = qbase + g2;
+        // bits of an 8192-bit map (the histogram memory is free by now), which is then read out in index order.
+        // They are SHARED OUT over the workgroup's waves through an LDS list (r04): a unit-normal cloud at r = 0.5 has ~6 of
+        // them among a workgroup's 64 queries, unevenly spread, and a wave that owns three of them made the other 15 wait.
+        // (Their rows are full -- more than kBqgCap >= nsample hits -- so the owning group needs nothing back.)
+        if (qv && !sparse && l16 == 0) s_dense[atomicAdd(&s_dense[kBqgWaves * kBqgQPW], 1)] = wave * kBqgQPW + grp;
+        __syncthreads();
+        const int ndense = s_dense[kBqgWaves * kBqgQPW];
+        for (int di = wave; di < ndense; di += kBqgWaves) {  // wave-uniform
+            const int q2 = bxq * (kBqgWaves * kBqgQPW) + s_dense[di];
             const float ax = xyz2[q2 * 3 + 0], ay = xyz2[q2 * 3 + 1], az = xyz2[q2 * 3 + 2];
             const int dx = bqg_cell1(ax, G.lo[0], G.inv_h[0], G.dim[0]);
             const int dy = bqg_cell1(ay, G.lo[1], G.inv_h[1], G.dim[1]);
@@ -776,8 +784,6 @@ ball_query_grid_kernel(int n, int m, float radius, float thr, int nsample, const
                 if (lane >= o) inc += t;
             }
             int pos = inc - mine;
-            const int total = __builtin_amdgcn_readlane(inc, 63);  // every hit of the ball (the list pass may have been skipped)
-            if (grp == g2) nh = total;
             int* __restrict__ o2 = idx_all + ((size_t)bi * m + q2) * nsample;
 #pragma unroll
             for (int w = 0; w < 4; ++w) {
@@ -785,9 +791,7 @@ ball_query_grid_kernel(int n, int m, float radius, float thr, int nsample, const
                 while (bits != 0u && pos < nsample) {
                     const int bit = __ffs(bits) - 1;
                     bits &= bits - 1u;
-                    const int id = (lane * 4 + w) * 32 + bit;
-                    o2[pos] = id;
-                    if (pos == 0) rowbuf[wave * 4 + g2] = id;
+                    o2[pos] = (lane * 4 + w) * 32 + bit;
                     ++pos;
                 }
             }
