@@ -436,6 +436,7 @@ def group_pool(new_points, grouped_xyz, pooling):
     require_cuda(new_points)
     if new_points.dtype != torch.float32:
         raise TypeError("pooling expects float32 features")
+    tf_util.assert_not_deferred(new_points, "a pooling")
     return _GroupPool.apply(new_points, grouped_xyz if mode == 2 else None, mode)
 
 

@@ -17,6 +17,8 @@ import contextlib
 import math
 from collections import OrderedDict
 
+import weakref
+
 import torch
 import torch.nn.functional as F
 
@@ -655,11 +657,15 @@ def _train_dense(inputs, w2d, b):
 # again in the backward: only when the tensor arriving as dz IS the linked GEMM's output (a second consumer makes autograd
 # hand over a sum in a new tensor) is the shortcut taken.
 USE_DGRAD_BN_STATS = True
-_bn_links = {}
+# Registry of the producer records, keyed by the storage address of the producer's output.  WEAK values: the record is owned by
+# the producer's autograd context (ctx.link), so it lives exactly as long as that node of the tape -- a forward pass whose tape
+# is dropped (or never built) leaves nothing behind, and an address reused by a later tensor finds no stale record.
+_bn_links = weakref.WeakValueDictionary()
 
 
 class _BnLink:
-    __slots__ = ("shape", "y", "gamma", "beta", "mean", "invstd", "relu", "ws", "dz_ptr", "dz_keep", "sc", "sh", "consumed")
+    __slots__ = ("shape", "y", "gamma", "beta", "mean", "invstd", "relu", "ws", "dz_ptr", "dz_keep", "sc", "sh", "consumed",
+                 "__weakref__")
 
 
 # ---- deferred normalisation: layer i publishes (scale, shift) and hands its PRE-normalisation output y to layer i+1 -------
@@ -670,8 +676,20 @@ USE_BN_ON_LOAD = True
 
 
 def can_defer_bn(rows, c, c_next):
-    """may a layer of width c over `rows` rows hand its un-normalised output to a following layer of width c_next?"""
-    return bool(USE_BN_ON_LOAD and USE_DGRAD_BN_STATS and rows > 2048 and c % 4 == 0 and c_next % 32 == 0)
+    """may a layer of width c over `rows` rows hand its un-normalised output to a following layer of width c_next?
+    (Only while a tape is being recorded: the record that tells the next layer what it is reading belongs to the tape.)"""
+    return bool(USE_BN_ON_LOAD and USE_DGRAD_BN_STATS and torch.is_grad_enabled() and rows > 2048 and c % 4 == 0
+                and c_next % 32 == 0)
+
+
+def assert_not_deferred(x, what):
+    """raise if x is the UN-normalised output of a layer that deferred its batch norm (conv2d(..., defer_bn=True)): only the
+    next dense layer of the stack may read such a tensor -- anything else would silently compute on un-normalised values"""
+    if x is None or not _bn_links:
+        return
+    lk = _bn_links.get(x.data_ptr())
+    if lk is not None and lk.sc is not None and not lk.consumed and lk.shape == (x.numel() // x.shape[-1], x.shape[-1]):
+        raise RuntimeError("a deferred batch-norm output (conv2d(..., defer_bn=True)) reached %s" % what)
 
 
 def _deferred_producer(x2d):
@@ -740,8 +758,6 @@ def _bn_register_producer(z, y, gamma, beta, save_mean, save_invstd, relu, poole
     sc / sh: the layer deferred its normalisation, z IS y"""
     if not USE_DGRAD_BN_STATS or pooled:
         return None
-    if len(_bn_links) > 256:
-        _bn_links.clear()
     lk = _BnLink()
     lk.shape, lk.y, lk.gamma, lk.beta, lk.mean, lk.invstd, lk.relu = tuple(z.shape), y, gamma, beta, save_mean, save_invstd, bool(relu)
     lk.ws = lk.dz_ptr = lk.dz_keep = None
@@ -806,6 +822,8 @@ class _TrainDenseBnRelu(torch.autograd.Function):
         ctx.xf = (prev.sc, prev.sh, bool(prev.relu)) if xf else None
         ctx.relu, ctx.pool = bool(relu), int(pool)
         ctx.prev = prev if (prev is not None and w.shape[1] > 16) else None
+        defer = defer and any(ctx.needs_input_grad)  # no tape node, nobody to keep the record: normalise here (the callers
+        #                                              also drop the request when no tape is being recorded at all)
         if defer and not pooled:
             save_mean, save_invstd, sc, sh = _bn_train_forward_deferred(y, b, gamma, beta, running_mean, running_var, decay, ws)
             ctx.save_for_backward(x2d, w, y, gamma, beta, save_mean, save_invstd)
@@ -892,6 +910,7 @@ class _TrainHoistedBnRelu(torch.autograd.Function):
                                             stream_ptr()), "pn2_fp_hoist_rows")
         pooled = pool > 1
         ctx.relu, ctx.pool, ctx.kind, ctx.dims = bool(relu), int(pool), kind, (bsz, nsrc, rows_b, c)
+        defer = defer and any(ctx.needs_input_grad)  # as _TrainDenseBnRelu
         if defer and not pooled:
             save_mean, save_invstd, sc, sh = _bn_train_forward_deferred(y, b, gamma, beta, running_mean, running_var, decay)
             ctx.save_for_backward(src2d, w, y, gamma, beta, save_mean, save_invstd, a, plan)
@@ -943,7 +962,7 @@ def conv2d_hoisted_first(kind, src, geo, plan, cin, num_output_channels, scope, 
         pool = int(pool) if pool and pool > 1 else 0
         z = _TrainHoistedBnRelu.apply(src.contiguous(), w.reshape(cin, cout), b, gamma, beta, mean, var, decay, True, pool, kind,
                                       geo[0].contiguous(), geo[1].contiguous(), geo[2].contiguous(), plan,
-                                      bool(defer_bn) and not pool)
+                                      bool(defer_bn) and not pool and torch.is_grad_enabled())
     if kind == "sa":
         m, ns = geo[2].shape[1], geo[2].shape[2]
         return z.reshape(src.shape[0], m, ns // pool if pool else ns, cout)
@@ -979,7 +998,7 @@ def _train_layer(inputs, w2d, b, bnv, bn_decay, relu, pool=0, defer=False):
     beta, gamma, mean, var = bnv
     decay = 0.9 if bn_decay is None else float(bn_decay)  # tf_util.py:571
     z = _TrainDenseBnRelu.apply(inputs.reshape(-1, cin).contiguous(), w2d.contiguous(), b, gamma, beta, mean, var,
-                                decay, relu, pool, bool(defer) and not pool and relu)
+                                decay, relu, pool, bool(defer) and not pool and relu and torch.is_grad_enabled())
     return z.reshape(lead + [cout])
 
 
@@ -1069,4 +1088,5 @@ def dropout(inputs, is_training, scope, keep_prob=0.5, noise_shape=None):
     import zlib
     key = _full_name(scope)
     state = st.dropout_state(key, zlib.crc32(key.encode()))
+    assert_not_deferred(inputs, "dropout")
     return _Dropout.apply(inputs, keep_prob, state)

@@ -630,6 +630,31 @@ def test_deferred_batch_norm_output_must_reach_a_dense_layer(pn2, cuda):
     h = tfu.conv2d(x, 32, [1, 1], padding="VALID", stride=[1, 1], bn=True, is_training=True, scope="a", bn_decay=0.5, defer_bn=True)
     with pytest.raises(RuntimeError):
         tfu.conv2d(h, 32, [1, 1], padding="VALID", stride=[1, 1], bn=False, activation_fn=None, is_training=True, scope="b")
+    # consumers that are not dense layers refuse it IN FORWARD (a forward-only pass has no backward to catch it)
+    with pytest.raises(RuntimeError):
+        tfu.dropout(h, True, "dp", keep_prob=0.5)
+    with pytest.raises(RuntimeError):
+        pn2.util.pointnet_util.group_pool(h.reshape(2, 64, 32, 32), None, "max")
+    # the records belong to the tape: they die with it (no process-global leftovers keyed by recycled addresses) ...
+    assert len(tfu._bn_links) >= 1
+    del h
+    import gc
+    gc.collect()  # (the tracebacks pytest.raises caught above still hold views of h in a reference cycle)
+    assert len(tfu._bn_links) == 0
+    # ... and a training-mode forward that records no tape (BN recalibration under no_grad, frozen inputs) does not defer at
+    # all: its output IS normalised, and equals the normalised activation of the recorded pass
+    with torch.no_grad():
+        hn = tfu.conv2d(x, 32, [1, 1], padding="VALID", stride=[1, 1], bn=True, is_training=True, scope="a", bn_decay=0.5, defer_bn=True)
+        assert len(tfu._bn_links) == 0
+        tfu.dropout(hn, True, "dp", keep_prob=0.5)   # accepted: normalised values
+    hg = tfu.conv2d(x, 32, [1, 1], padding="VALID", stride=[1, 1], bn=True, is_training=True, scope="a", bn_decay=0.5)
+    assert float((hn - hg).abs().max()) <= 1e-5 * float(hg.abs().max())
+    xf = x.detach()  # nothing requires a gradient through the layer's INPUT, but its weights do: a tape node exists, deferral is fine
+    hf = tfu.conv2d(xf, 32, [1, 1], padding="VALID", stride=[1, 1], bn=True, is_training=True, scope="a", bn_decay=0.5, defer_bn=True)
+    lk = tfu._bn_links.get(hf.data_ptr())
+    assert lk is not None and lk.sc is not None and hf.requires_grad
+    del lk
+    del hf
     tfu.reset_bn_links()
 
 
