@@ -64,6 +64,22 @@ def test_argument_validation_needs_no_gpu(pn2):
     assert L.pn2_scene_sample(1, 0, 8, nul, nul, nul, nul, nul, nul, 5.0, 5.0, nul, nul, nul, nul, nul, nul, nul) == -1
     assert L.pn2_voxel_downsample(10, nul, nul, nul, 0.0, nul, nul, nul, nul, nul, nul, 0, nul) == -1   # voxel_size > 0
     assert L.pn2_voxel_downsample(10, nul, nul, nul, 0.05, nul, nul, nul, nul, nul, nul, 0, nul) == -2
+    # pn2_coarse_geometry: host arrays of per-level sizes and of device pointers
+    import ctypes
+    one_i = lambda v: (ctypes.c_int * 1)(v)        # noqa: E731
+    one_f = lambda v: (ctypes.c_float * 1)(v)      # noqa: E731
+    one_p = lambda v: (ctypes.c_void_p * 1)(v)     # noqa: E731
+    fake = ctypes.c_void_p(4096)                   # never dereferenced: every call below is refused before a launch
+    assert L.pn2_coarse_geometry(1, 64, 1, nul, nul, nul, nul, nul, nul, nul, nul, nul, nul, nul, nul, 2, 1, nul) == -2
+    args = lambda b, n0, m, nn: (b, n0, 1, one_i(m), one_f(0.5), one_i(8), fake, nul, one_p(4096), one_p(4096), one_p(4096), nul,   # noqa: E731
+                                 one_p(4096) if nn else nul, one_p(4096) if nn else nul, nul, 2, 1, nul)
+    assert L.pn2_coarse_geometry(*args(0, 64, 16, False)) == -1       # b > 0
+    assert L.pn2_coarse_geometry(*args(1, 2048, 16, False)) == -4     # PN2_EUNSUP: source cloud above 1024 points
+    assert L.pn2_coarse_geometry(*args(1, 64, 65, False)) == -4       # more samples than points
+    assert L.pn2_coarse_geometry(*args(1, 1024, 512, True)) == -4     # 3-NN table over more than 256 samples
+    assert L.pn2_coarse_geometry(*args(1, 64, 2, True)) == -1         # 3-NN needs >= 3 known points
+    a = list(args(1, 64, 16, False)); a[-3] = 7
+    assert L.pn2_coarse_geometry(*a) == -1                            # unknown arithmetic mode
 
 
 def test_ops_refuse_cpu_tensors_loudly(pn2):
