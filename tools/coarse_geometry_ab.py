@@ -6,7 +6,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import numpy as np, torch
 import pn2_amd as pn2
-from conftest import s_scene, s_randn
+from conftest import s_grid, s_scene, s_randn
 dev = torch.device("cuda:0")
 pu, S = pn2.util.pointnet_util, pn2.tf_ops.tf_sampling
 lib = pn2._lib.lib
@@ -28,10 +28,10 @@ def graph_time(fn, iters=50):
     return float(np.median(ts))
 
 
-for name, gen in (("S-scene", s_scene), ("S-randn", s_randn)):
+for name, gen in (("S-scene", s_scene), ("S-randn", s_randn), ("16-lattice (every level through the sampler)", lambda s, b, n: s_grid(s, b, n, 16))):
     x = torch.from_numpy(gen(0, 16, 8192)).to(dev)
     _, l1 = S.farthest_point_sample_and_gather(1024, x)
-    radii = [1.0, 2.0, 4.0]
+    radii = [1.0, 2.0, 4.0] if name.startswith("S-") else [0.12, 0.24, 0.48]
 
     def separate():
         cur = l1
