@@ -29,7 +29,10 @@ namespace {
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
-constexpr int kWideDepth = 4;  // groups of 8 k in flight per wave
+#ifndef PN2_WIDE_DEPTH
+#define PN2_WIDE_DEPTH 4
+#endif
+constexpr int kWideDepth = PN2_WIDE_DEPTH;  // groups of 8 k in flight per wave
 
 struct WideParams {
     int rows, cin, x_stride, nlayers, pool, relu_last;
