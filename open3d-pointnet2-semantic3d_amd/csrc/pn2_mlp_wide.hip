@@ -29,10 +29,7 @@ namespace {
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
-#ifndef PN2_WIDE_DEPTH
-#define PN2_WIDE_DEPTH 4
-#endif
-constexpr int kWideDepth = PN2_WIDE_DEPTH;  // groups of 8 k in flight per wave
+constexpr int kWideDepth = 4;  // groups of 8 k in flight per wave (2 / 6 / 8 measured the same or slower, EXPERIMENTS.md)
 
 struct WideParams {
     int rows, cin, x_stride, nlayers, pool, relu_last;
