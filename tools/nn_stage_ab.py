@@ -4,7 +4,7 @@ import ctypes, sys, os, numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 PKG = os.path.join(ROOT, "open3d-pointnet2-semantic3d_amd")
-STAGES = [1, 2, 3, 9]
+STAGES = [1, 2, 3, 4, 9]
 if "--build" in sys.argv:
     import importlib.util
     spec = importlib.util.spec_from_file_location("b", os.path.join(PKG, "build.py")); b = importlib.util.module_from_spec(spec); spec.loader.exec_module(b)
