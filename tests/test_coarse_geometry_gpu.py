@@ -100,6 +100,44 @@ def test_coarse_geometry_without_a_tie_record_samples_every_level(pn2, cuda):
         assert (got[-1]["cnt"] <= nsamples[-1]).all()
 
 
+def test_coarse_geometry_fuzz_against_the_separate_ops(pn2, cuda):
+    """40 random pyramids (1-4 levels, ragged sizes down to 3 points, radii from empty to all-inclusive balls, nsample 1..80,
+    clouds drawn from four distributions incl. heavy duplication and coarse lattices, tagged or untagged source clouds)."""
+    import torch
+    pu, S = pn2.util.pointnet_util, pn2.tf_ops.tf_sampling
+    rs = np.random.RandomState(2024)
+    for it in range(40):
+        b = int(rs.choice([1, 2, 3, 7, 16, 33]))
+        n0 = int(rs.randint(8, 1025))
+        nlev = int(rs.randint(1, 5))
+        npoints, n = [], n0
+        for _ in range(nlev):
+            m = int(rs.randint(3, min(n, 256) + 1))
+            npoints.append(m)
+            n = m
+        kind = rs.choice(["scene", "randn", "dup", "grid"])
+        nbig = n0 if rs.rand() < 0.4 else int(n0 * rs.uniform(1.5, 4.0))  # source = an FPS output of a bigger cloud (tagged) or raw
+        if kind == "scene":
+            x = s_scene(it, b, nbig)
+        elif kind == "randn":
+            x = s_randn(it, b, nbig)
+        elif kind == "dup":
+            x = s_dup(it, b, max(nbig, 8), 0.5)
+        else:
+            x = s_grid(it, b, nbig, int(rs.choice([2, 4, 32])))
+        xt = T(x, cuda)
+        if nbig > n0:
+            _, src = S.farthest_point_sample_and_gather(n0, xt)
+        else:
+            src = xt
+        ext = float(np.abs(x).max()) + 1e-3
+        radii = [float(ext * rs.choice([1e-4, 0.05, 0.2, 0.6, 3.0])) for _ in range(nlev)]
+        nsamples = [int(rs.choice([1, 4, 16, 32, 64, 80])) for _ in range(nlev)]
+        want = _separate(pn2, src, npoints, radii, nsamples)
+        got = pu.coarse_geometry(src, npoints, radii, nsamples)
+        _assert_same(got, want, "fuzz %d (%s b=%d n0=%d levels=%s)" % (it, kind, b, n0, npoints))
+
+
 def test_coarse_geometry_device_side_branch_per_cloud(pn2, oracle, cuda):
     """The shortcut is decided per cloud on the device: forged records make a cloud answer the identity where it is wrong
     (tie-heavy lattice) and force the sampler where the identity would have been right -- the ball query and the 3-NN table
