@@ -71,6 +71,12 @@ def build(force=False, verbose=False, extra_flags=(), out=None):
     cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", tmp] + objs
     subprocess.check_call(cmd)
     os.replace(tmp, target)  # atomic: a concurrent importer sees the old or the new library, never a partial one
+    if tag:  # an experimental variant: its objects are of no further use (and would travel to the GPU box with the tree)
+        for obj in objs:
+            try:
+                os.remove(obj)
+            except OSError:
+                pass
     return target
 
 
