@@ -684,6 +684,14 @@ def main():
                     help="run only the two north-star kernel measurements and print them (the command the rocprofv3 / PMC passes "
                          "of tools/gpu_round4.sh profile: profiles/r04_pmc_north_star.json)")
     ap.add_argument("--no-other-inputs", action="store_true", help="skip the S-randn / S-dup25 legs of the line")
+    ap.add_argument("--sampler-ahead", type=int, default=0, metavar="SLOTS",
+                    help="throughput regime on runtime.SamplerAheadPipeline with SLOTS batch slots: two graphs per batch (SA1's "
+                         "sampling | everything else) on sampler / dense streams; 0 = one graph per batch on --pipeline streams")
+    ap.add_argument("--sampler-streams", type=int, default=2)
+    ap.add_argument("--dense-streams", type=int, default=2)
+    ap.add_argument("--cu-split", type=int, default=0, metavar="NS",
+                    help="with --sampler-ahead: confine the sampler streams to NS compute units and the dense streams to the "
+                         "other 256-NS (hipExtStreamCreateWithCUMask)")
     args = ap.parse_args()
 
     if args.gpus < 1:
@@ -763,23 +771,32 @@ def main():
         return out
 
     step = eager_step = lambda: eager_on(pc)  # noqa: E731
+    pipe = None
     if not args.eager:
         # one hipGraph per forward: replay removes the ~40 Python-side launches from the step.
         # --pipeline P: P independent batches in flight (P graphs with their own buffers, replayed
         # round-robin on P streams), so one batch's latency-bound FPS (16 CUs) overlaps the MFMA
         # layers of the previous batch.  Every step is still one full forward over one batch.
-        P = max(1, args.pipeline)
+        P = max(1, args.sampler_ahead if args.sampler_ahead else args.pipeline)
         fwd = lambda x: pn2.model.get_sa_fp_features(x, False, hp)[0]  # noqa: E731
         batches = [pc] + [torch.from_numpy(s_scene(2000 + 10 * rank + i, B, N)).to(dev) for i in range(1, P)]
-        caps = [pn2.runtime.CapturedForward(fwd, b_) for b_ in batches]
-        streams = [torch.cuda.Stream() for _ in range(P)]
-        counter = [0]
+        if args.sampler_ahead:
+            pipe = pn2.runtime.SamplerAheadPipeline(
+                lambda x: pn2.model.sa1_samples(x, hp), lambda x, s: pn2.model.get_sa_fp_features(x, False, hp, sa1=s)[0],
+                batches, sampler_streams=args.sampler_streams, dense_streams=args.dense_streams,
+                cu_split=(args.cu_split, 256) if args.cu_split else None)
+            caps = [pn2.runtime.CapturedForward(fwd, batches[0])]  # the latency regime: one graph, one batch in flight
+            step = pipe.step
+        else:
+            caps = [pn2.runtime.CapturedForward(fwd, b_) for b_ in batches]
+            streams = [torch.cuda.Stream() for _ in range(P)]
+            counter = [0]
 
-        def step():
-            i = counter[0] % P
-            counter[0] += 1
-            with torch.cuda.stream(streams[i]):
-                return caps[i].replay()
+            def step():
+                i = counter[0] % P
+                counter[0] += 1
+                with torch.cuda.stream(streams[i]):
+                    return caps[i].replay()
     for _ in range(args.warmup):
         step()
     torch.cuda.synchronize()
@@ -837,7 +854,7 @@ def main():
     if rank == 0:
         total_points = world * B * N * args.steps
         ms_per_step = elapsed / args.steps * 1e3
-        P_eff = 1 if args.eager else max(1, args.pipeline)
+        P_eff = 1 if args.eager else max(1, args.sampler_ahead if args.sampler_ahead else args.pipeline)
         is_fps = lambda k: k["kernel"] in LATENCY_KERNELS  # noqa: E731
         dense = [k for k in kernels if not is_fps(k)]
         fps = [k for k in kernels if is_fps(k)]
@@ -866,7 +883,12 @@ def main():
                        "arith_mode": {"fps": int(pn2.config.fps_mode()), "ball_query": int(pn2.config.bq_mode()),
                                       "pinned_to": "oracle/_ref fast_noslp build of the reference's own kernels (contraction on)"},
                        "launch": "eager python launches" if args.eager else "one hipGraph replay per step",
-                       "streams_per_batch": 1,
+                       "streams_per_batch": 1 if not args.sampler_ahead else 2,
+                       "execution": ("runtime.SamplerAheadPipeline: %d batch slots, two graphs per batch (SA1 sampling | the rest) on "
+                                     "%d sampler + %d dense streams%s" % (args.sampler_ahead, args.sampler_streams, args.dense_streams,
+                                                                          ", CU split %d | %d" % (args.cu_split, 256 - args.cu_split)
+                                                                          if args.cu_split else ""))
+                       if args.sampler_ahead else "one graph per batch, one stream per batch in flight",
                        "batches_in_flight": P_eff,
                        "fp_front": "fused" if fused_fp else "materialised"},
             "regimes": {
@@ -934,6 +956,9 @@ def main():
                 arrs = [torch.from_numpy(gen(3000 + 10 * rank + i, B, N)).to(dev) for i in range(P_eff)]
                 for c_, a_ in zip(caps, arrs):
                     c_.static_inputs[0].copy_(a_)
+                if pipe is not None:
+                    for d_, a_ in zip(pipe.inputs, arrs):
+                        d_.copy_(a_)
                 for _ in range(args.warmup):
                     step()
                 torch.cuda.synchronize()
@@ -968,6 +993,9 @@ def main():
                     "slower_than_1.5x_S-scene": slow}
             for c_, a_ in zip(caps, batches):  # back to S-scene for whatever follows
                 c_.static_inputs[0].copy_(a_)
+            if pipe is not None:
+                for d_, a_ in zip(pipe.inputs, batches):
+                    d_.copy_(a_)
         if not args.no_north_star:
             try:
                 res["north_star"] = north_star_kernels(pn2, dev)

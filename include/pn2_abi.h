@@ -448,6 +448,10 @@ int pn2_dropout(long long n, const float *x, float keep_prob, const long long *s
 int pn2_dropout_grad(long long n, const float *dy, const unsigned char *mask, float keep_prob, float *dx,
                      void *stream);
 
+/* Backward of bias + ReLU on a layer WITHOUT batch norm (util/tf_util.py:186-204 with bn=False, tf.nn.relu's ReluGrad):
+ * dx[i] = z[i] > 0 ? dz[i] : 0 over n elements, z = the layer's OUTPUT; dx may alias dz. */
+int pn2_relu_grad(long long n, const float *z, const float *dz, float *dx, void *stream);
+
 /* tf.train.AdamOptimizer.apply_gradients  train.py:381-388, one launch over flat fp32 buffers of n elements:
  * m <- b1 m + (1-b1) g;  v <- b2 v + (1-b2) g^2;  p <- p - lr_t * m / (sqrt(v) + eps), g = grads * grad_scale.
  * hyper: DEVICE float[5] = {lr_t, beta1, beta2, epsilon, grad_scale}, lr_t = lr*sqrt(1-beta2^t)/(1-beta1^t). */

@@ -97,6 +97,7 @@ SIGNATURES = {
                                  c_void_p],
     "pn2_dropout": [ctypes.c_longlong, c_void_p, c_float, c_void_p, c_void_p, c_void_p, c_void_p],
     "pn2_dropout_grad": [ctypes.c_longlong, c_void_p, c_void_p, c_float, c_void_p, c_void_p],
+    "pn2_relu_grad": [ctypes.c_longlong, c_void_p, c_void_p, c_void_p, c_void_p],
     "pn2_adam_step": [ctypes.c_longlong, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p],
     "pn2_scene_extract_z_box": [c_int, c_void_p, c_int, c_void_p, ctypes.c_double, ctypes.c_double, ctypes.c_double, c_int,
                                 c_void_p, c_void_p, c_void_p],

@@ -95,7 +95,7 @@ coarse_geometry_kernel(CgParams p) {
             float* nx = L.new_xyz + (size_t)c * m * 3;
             const int T = tab->tie;
             const float* nw;
-            if (T >= m) {  // the first m rows; workgroup 0 of the cloud writes them out
+            if (T >= m && m < n) {  // the first m rows; workgroup 0 of the cloud writes them out (m == n: see fps_nested_shortcut_b)
                 if (r == 0) {
                     for (int jj = tid; jj < m; jj += kCgThreads) out[jj] = jj;
                     for (int e = tid; e < m * 3; e += kCgThreads) nx[e] = src[e];

@@ -64,7 +64,9 @@ __device__ __forceinline__ bool fps_nested_shortcut_b(int n, int m, const float*
                                                       int* __restrict__ tie_out_b, int nthreads) {
     if (tie_in_b == nullptr) return false;
     const int T = __builtin_amdgcn_readfirstlane(*tie_in_b);
-    if (T < m || m > n) return false;
+    // m == n is refused as well: the sampler does not look at ties of its LAST pick (a consumer normally asks for fewer
+    // picks than the level above made), and a level that takes every row needs that step too.
+    if (T < m || m >= n) return false;
     for (int jj = threadIdx.x; jj < m; jj += nthreads) out[jj] = jj;
     if (nxyz) for (int e = threadIdx.x; e < m * 3; e += nthreads) nxyz[e] = xyz[e];
     if (tie_out_b && threadIdx.x == 0) *tie_out_b = T;  // the prefix of a prefix: the same bound holds below
@@ -152,16 +154,17 @@ __device__ __forceinline__ void fps_reg_body(int n, int m, const float* __restri
         }
         if constexpr (TRACK) {
             // mk still holds the td the previous maximum was taken over: exactly ONE point of the cloud -- the winner, owned
-            // by lane (old % NT) -- may carry its value.  Branch-free count per wave: OR and XOR of the per-row ballots differ
-            // when one lane holds it twice, the population of the OR counts the lanes.
-            unsigned long long m_or = 0ull, m_xor = 0ull;
+            // by lane (old % NT) -- may carry its value.  Branch-free count per wave: `dup` collects the lanes that hold it
+            // in MORE than one of their rows (any count >= 2: an OR/XOR parity would miss three), the population of the OR
+            // counts the lanes.
+            unsigned long long m_or = 0ull, dup = 0ull;
 #pragma unroll
             for (int i = 0; i < PPT; ++i) {
                 const unsigned long long hb = __builtin_amdgcn_ballot_w64(__double2hiint(mk[i]) == pw_hi);
-                m_or |= hb; m_xor ^= hb;
+                dup |= m_or & hb; m_or |= hb;
             }
             const int expect = (((old & (NT - 1)) >> 6) == (tid >> 6)) ? 1 : 0;
-            if (__builtin_expect(m_or != m_xor || __popcll(m_or) != expect, 0)) {
+            if (__builtin_expect(dup != 0ull || __popcll(m_or) != expect, 0)) {
 #pragma unroll
                 for (int i = 0; i < PPT; ++i) {
                     if (__double2hiint(mk[i]) == pw_hi && (unsigned)__double2loint(mk[i]) != pw_lo)

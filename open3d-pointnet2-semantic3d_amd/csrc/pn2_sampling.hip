@@ -822,6 +822,12 @@ extern "C" int pn2_fps_nested(int b, int n, int m, const float* inp, float* temp
                               const int* tie_in, int* tie_out, int arith_mode, void* stream) {
     const int rc = fps_entry(b, n, m, inp, temp, out, new_xyz, arith_mode, stream, tie_in, tie_out);
     if (rc == 1000000) return pn2_gather_point(b, n, m, inp, out, new_xyz, stream);
+    if (rc == PN2_OK && tie_out && n == 1 && m > 1) {
+        // a one-point cloud repeats its point from step 1 on: the maximum is 0 there (a strict step by definition) but there is
+        // no SECOND holder for the kernels' tie branches to see
+        hipError_t e = hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(tie_out), 1, (size_t)b, static_cast<hipStream_t>(stream));
+        if (e != hipSuccess) return (int)e;
+    }
     return rc;
 }
 

@@ -120,6 +120,24 @@ dropout_grad_kernel(long long n, const float* __restrict__ dy, const unsigned ch
     }
 }
 
+// Gradient of the ReLU of an un-normalised layer (tf_util.py:186-204 with bn=False: conv -> bias_add -> relu): TF's ReluGrad
+// passes the upstream gradient where the OUTPUT is positive.
+template <int VEC>
+__global__ void __launch_bounds__(256)
+relu_grad_kernel(long long n, const float* __restrict__ z, const float* __restrict__ dz, float* __restrict__ dx) {
+    const long long nv = n / VEC;
+    for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < nv; e += (long long)gridDim.x * 256) {
+        if constexpr (VEC == 4) {
+            const float4 a = reinterpret_cast<const float4*>(z)[e];
+            const float4 g = reinterpret_cast<const float4*>(dz)[e];
+            reinterpret_cast<float4*>(dx)[e] = make_float4(a.x > 0.f ? g.x : 0.f, a.y > 0.f ? g.y : 0.f,
+                                                           a.z > 0.f ? g.z : 0.f, a.w > 0.f ? g.w : 0.f);
+        } else {
+            dx[e] = z[e] > 0.f ? dz[e] : 0.f;
+        }
+    }
+}
+
 // tf.train.AdamOptimizer (python/training/adam.py): m <- b1 m + (1-b1) g; v <- b2 v + (1-b2) g^2;
 // p <- p - lr_t * m / (sqrt(v) + eps) with lr_t = lr * sqrt(1 - b2^t) / (1 - b1^t) supplied by the host in hyper[0].
 __global__ void __launch_bounds__(256)
@@ -227,6 +245,19 @@ extern "C" int pn2_dropout_grad(long long n, const float* dy, const unsigned cha
         dropout_grad_kernel<4><<<grid_1d(n / 4), 256, 0, static_cast<hipStream_t>(stream)>>>(n, dy, mask, keep_prob, dx);
     else
         dropout_grad_kernel<1><<<grid_1d(n), 256, 0, static_cast<hipStream_t>(stream)>>>(n, dy, mask, keep_prob, dx);
+    PN2_RETURN_IF_LAUNCH_FAILED();
+    return PN2_OK;
+}
+
+// dx = dz where z > 0, else 0 (n elements; dx may alias dz): backward of the bias + ReLU epilogue of pn2_linear on the training
+// path of layers WITHOUT batch norm (util/tf_util.py _TrainDenseRelu; reference tf_util.py:186-204 with bn=False).
+extern "C" int pn2_relu_grad(long long n, const float* z, const float* dz, float* dx, void* stream) {
+    if (n <= 0) return PN2_EINVAL;
+    if (!z || !dz || !dx) return PN2_ENULL;
+    if (n % 4 == 0 && (((uintptr_t)z | (uintptr_t)dz | (uintptr_t)dx) % 16) == 0)
+        relu_grad_kernel<4><<<grid_1d(n / 4), 256, 0, static_cast<hipStream_t>(stream)>>>(n, z, dz, dx);
+    else
+        relu_grad_kernel<1><<<grid_1d(n), 256, 0, static_cast<hipStream_t>(stream)>>>(n, z, dz, dx);
     PN2_RETURN_IF_LAUNCH_FAILED();
     return PN2_OK;
 }

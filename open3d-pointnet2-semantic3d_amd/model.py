@@ -101,10 +101,22 @@ def clone_geometry(geo, l0_xyz):
             "gplans": [cl(t) for t in geo.get("gplans", [None] * 4)], "iplans": [cl(t) for t in geo.get("iplans", [None] * 4)]}
 
 
+def sa1_samples(point_cloud, hyperparams):
+    """The first dependent chain of a batch, alone: farthest point sampling + gather of SA level 1 (pointnet_util.py:36-37 as
+    model.py:36-47 calls it) -> (l0_xyz (B,N,3) contiguous, new_xyz (B, l1_npoint, 3) carrying the run's tie record).
+    get_sa_fp_features(..., sa1=) takes it from there; runtime.SamplerAheadPipeline runs the two halves of a batch on
+    different streams."""
+    from .tf_ops.tf_sampling import farthest_point_sample_and_gather
+    with torch.no_grad():
+        l0_xyz = point_cloud[:, :, 0:3].contiguous()
+        return l0_xyz, farthest_point_sample_and_gather(int(hyperparams["l1_npoint"]), l0_xyz)[1]
+
+
 def get_sa_fp_features(point_cloud, is_training, hyperparams, bn_decay=None, geometry=None,
-                       head_width=0, cut_sa_fp=False):
+                       head_width=0, cut_sa_fp=False, sa1=None):
     """point_cloud (B,N,3 or 6) -> l0_points (B,N,128) and end_points.
     geometry (extension): compute_geometry(l0_xyz) of this very batch, computed ahead.
+    sa1 (extension, inference): sa1_samples(point_cloud) of this very batch, computed ahead (everything else is done here).
     head_width (extension, training; get_model passes 128): the result goes to ONE batch-normalised layer of that width and
     nowhere else, so the last FP layer may hand over its un-normalised output (pointnet_fp_module defer_last_bn).
     cut_sa_fp (extension, training): the FP modules read DETACHED copies of the SA outputs (end_points["sa_features_cut"],
@@ -115,10 +127,10 @@ def get_sa_fp_features(point_cloud, is_training, hyperparams, bn_decay=None, geo
         tf_util.reset_bn_links()  # producer records of the previous forward pass (tf_util._TrainDenseBnRelu)
     if hyperparams["use_color"]:
         feature_size = 3 * int(hyperparams["use_color"])
-        l0_xyz = point_cloud[:, :, 0:3].contiguous()
+        l0_xyz = sa1[0] if sa1 is not None else point_cloud[:, :, 0:3].contiguous()
         l0_points = point_cloud[:, :, 3:3 + feature_size].contiguous()
     else:
-        l0_xyz = point_cloud.contiguous()
+        l0_xyz = sa1[0] if sa1 is not None else point_cloud.contiguous()
         l0_points = None
     end_points["l0_xyz"] = l0_xyz
     xyzs, feats = [l0_xyz], [l0_points]
@@ -129,6 +141,8 @@ def get_sa_fp_features(point_cloud, is_training, hyperparams, bn_decay=None, geo
             geo = (geometry["xyzs"][li + 1], geometry["idxs"][li], geometry.get("gplans", [None] * 4)[li])
         elif li >= 1 and coarse is not None:
             geo = (coarse[li - 1]["new_xyz"], coarse[li - 1]["idx"])
+        elif li == 0 and sa1 is not None and not is_training:
+            geo = (sa1[1], None)
         else:
             geo = None
         new_xyz, new_points, _ = pointnet_sa_module(

@@ -72,13 +72,18 @@ def ball_query_bin(radius, xyz1, out=None):
     b, n, _ = xyz1.shape
     if not (BIN_MIN_N <= n <= BIN_MAX_N):
         return None
+    src = (xyz1.data_ptr(), xyz1._version)  # the caller's tensor (a non-contiguous one is copied below)
     xyz1 = xyz1.detach().contiguous()
     bins = out if out is not None else ball_query_bin_alloc(xyz1)  # `out`: allocated by the caller (on ITS stream)
     with torch.cuda.device(xyz1.device):
         check(lib.pn2_ball_query_bin(b, n, float(radius), ptr(xyz1), ptr(bins), bins.numel(), stream_ptr()), "pn2_ball_query_bin")
     # what the bins describe: the C entry point takes an opaque pointer and cannot check it -- bins of a smaller
     # cloud would be read out of bounds, bins of a smaller radius would silently miss neighbours
-    bins._pn2_bins_of = (float(radius), b, n)
+    # ... and bins of ANOTHER cloud of the same shape (a reused `out=` workspace after the input batch changed) would return wrong
+    # neighbours: the tag also names the storage and the version of the cloud it was built from.  Writes through
+    # raw pointers -- this library's own kernels, a graph replay into a static buffer -- do not bump a tensor's version: whoever
+    # overwrites xyz1 that way must bin again.
+    bins._pn2_bins_of = (float(radius), b, n) + src
     return bins
 
 
@@ -90,14 +95,17 @@ def query_ball_point_binned(radius, nsample, xyz1, xyz2, bins, arith_mode=None):
     if bins is None or nsample > BIN_MAX_NSAMPLE or m < BIN_MIN_M:
         return query_ball_point(radius, nsample, xyz1, xyz2, arith_mode=arith_mode)
     require_cuda(xyz1, xyz2)
+    src = (xyz1.data_ptr(), xyz1._version)
     xyz1 = xyz1.detach().contiguous()
     xyz2 = xyz2.detach().contiguous()
     made = getattr(bins, "_pn2_bins_of", None)
     if made is None:
         raise ValueError("bins must come from ball_query_bin(radius, xyz1)")
-    if made != (float(radius), b, n):
+    if made[:3] != (float(radius), b, n):
         raise ValueError("bins were built for radius %g on a (%d, %d, 3) cloud: they do not describe this query (radius %g, "
                          "cloud (%d, %d, 3))" % (made[0], made[1], made[2], radius, b, n))
+    if made[3:] != src:
+        raise ValueError("bins were built from another cloud (or xyz1 was modified in place since): bin again")
     if bins.dtype != torch.uint8 or bins.data_ptr() % 256 != 0 or bins.numel() < b * int(lib.pn2_ball_query_bin_bytes(n)):
         raise ValueError("bins: expected a 256-byte aligned uint8 tensor of b * pn2_ball_query_bin_bytes(n) bytes")
     idx = torch.empty((b, m, nsample), dtype=torch.int32, device=xyz1.device)

@@ -37,6 +37,19 @@ def tag_fps_output(new_xyz, tie, arith_mode=None):
     return new_xyz
 
 
+def drop_fps_tag(t):
+    """forget what is known about `t` (a tie record, ball-query bins built from it): for code that overwrites a tensor through
+    its raw pointer -- this library's kernels writing into a caller's buffer (tf_util.multi_copy_) -- which no version counter
+    sees.  (A graph replay that rewrites new_xyz rewrites its tie record in the same launch: that tag stays true.)"""
+    for attr in (_TIE_ATTR,):
+        if hasattr(t, attr):
+            try:
+                delattr(t, attr)
+            except AttributeError:
+                pass
+    return t
+
+
 def fps_tie_record(inp, arith_mode=None):
     """the tie record of the run that produced `inp`, or None (untagged, modified in place since, other batch / device /
     arithmetic mode: the distances of the two levels are only bit-identical under the same contraction)"""

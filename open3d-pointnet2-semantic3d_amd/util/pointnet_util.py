@@ -444,7 +444,7 @@ def pointnet_sa_module(xyz, points, npoint, radius, nsample, mlp, mlp2, group_al
                        bn=True, pooling="max", knn=False, use_xyz=True, use_nchw=False, geometry=None):
     """PointNet Set Abstraction module -> new_xyz (B,npoint,3), new_points (B,npoint,mlp[-1] or mlp2[-1]), idx.
     geometry = (new_xyz, idx[, plan]) (extension, training path): precomputed FPS / ball-query result of this level
-    (+ the scatter plan of the grouping's gradient)."""
+    (+ the scatter plan of the grouping's gradient); (new_xyz, None) (inference): only the samples are given."""
     require_cuda(xyz, points)
     # use_nchw: accepted and ignored.  In the reference it only transposes the grouped tensor to NCHW around the conv
     # stack and back (pointnet_util.py:143-146,165-166: a cuDNN layout hint, "faster than NHWC"); values, shapes and variable
@@ -453,7 +453,13 @@ def pointnet_sa_module(xyz, points, npoint, radius, nsample, mlp, mlp2, group_al
         if not is_training and not group_all and not knn and use_xyz and pooling == "max":
             # ---- inference fast path: HIP index ops + fused / MFMA MLP -------------
             xyz = xyz.contiguous()
-            new_xyz, idx = geometry[:2] if geometry is not None else sa_geometry(xyz, npoint, radius, nsample)
+            if geometry is not None and geometry[1] is None:
+                # the samples of this level were drawn ahead (runtime.SamplerAheadPipeline: the FPS of a batch runs on a sampler
+                # stream while earlier batches are in their dense layers); the ball query is still this module's
+                new_xyz = geometry[0]
+                idx, _ = query_ball_point(radius, nsample, xyz, new_xyz)
+            else:
+                new_xyz, idx = geometry[:2] if geometry is not None else sa_geometry(xyz, npoint, radius, nsample)
             new_points = sa_features_inference(xyz, new_xyz, points, idx, mlp, bn, bn_decay)
             new_points = new_points.unsqueeze(2)
         else:
@@ -481,7 +487,7 @@ def pointnet_sa_module(xyz, points, npoint, radius, nsample, mlp, mlp2, group_al
                 new_xyz, new_points, idx, grouped_xyz = sample_and_group(npoint, radius, nsample, xyz, points, knn,
                                                                          use_xyz, geometry=geometry)
             # training: the max over K rides in the last layer's batch-norm kernels (tf_util._TrainDenseBnRelu)
-            fuse_pool = bool(is_training) and pooling == "max" and len(mlp) > 0 and nsample <= 1024
+            fuse_pool = bool(is_training) and bn and pooling == "max" and len(mlp) > 0 and nsample <= 1024
             for i, cout in enumerate(mlp):
                 if i < first:
                     continue

@@ -269,6 +269,9 @@ def multi_copy_(dsts, srcs):
     for d, s in zip(dsts, srcs):
         if d.numel() * d.element_size() != s.numel() * s.element_size() or not d.is_contiguous() or not s.is_contiguous():
             raise ValueError("multi_copy_: contiguous tensors of equal byte size expected")
+    from ..tf_ops.tf_sampling import drop_fps_tag
+    for d in dsts:
+        drop_fps_tag(d)  # a write through the raw pointer: no version counter moves, so the tie-record tag must not survive it
     for i0 in range(0, n, 48):
         dd, ss = dsts[i0:i0 + 48], srcs[i0:i0 + 48]
         k = len(dd)
@@ -639,13 +642,47 @@ class _TrainMatmul(torch.autograd.Function):
         return dx, dw, db
 
 
-def _train_dense(inputs, w2d, b):
+class _TrainDenseRelu(torch.autograd.Function):
+    """z = relu(x2d @ w + b): the training path of a layer WITHOUT batch norm (reference tf_util.py:186-204 with bn=False:
+    conv -> bias_add -> relu).  Forward: pn2_linear with its bias + ReLU epilogue; backward: pn2_relu_grad (TF's ReluGrad: the
+    upstream gradient where the OUTPUT is positive), then the data / weight / bias gradients of _TrainMatmul."""
+
+    @staticmethod
+    def forward(ctx, x2d, w, b):
+        cin, cout = w.shape
+        if cout % 32 != 0:  # pn2_linear's output tiles are 32 wide: zero-padded weight / bias columns, sliced back
+            pad = 32 - cout % 32
+            z = hip_linear(x2d, F.pad(w, (0, pad)).contiguous(), None if b is None else F.pad(b, (0, pad)).contiguous(),
+                           relu=True)[:, :cout].contiguous()
+        else:
+            z = hip_linear(x2d, w.contiguous(), None if b is None else b.contiguous(), relu=True)
+        ctx.save_for_backward(x2d, w, z)
+        ctx.has_bias = b is not None
+        return z
+
+    @staticmethod
+    def backward(ctx, dz):
+        x2d, w, z = ctx.saved_tensors
+        dz = dz.contiguous()
+        dy = torch.empty_like(dz)
+        with torch.cuda.device(dz.device):
+            check(lib.pn2_relu_grad(dz.numel(), ptr(z), ptr(dz), ptr(dy), stream_ptr()), "pn2_relu_grad")
+        dx = hip_linear_dgrad(dy, w) if ctx.needs_input_grad[0] else None
+        dw = _hip_wgrad(x2d, dy, w) if ctx.needs_input_grad[1] else None
+        db = None
+        if ctx.has_bias and ctx.needs_input_grad[2]:
+            db = _hip_wgrad(_ones_column(dy.shape[0], dy.device), dy, dy.new_empty((1, dy.shape[1]))).reshape(-1)
+        return dx, dw, db
+
+
+def _train_dense(inputs, w2d, b, relu=False):
     """un-normalised dense layer of the training path (the class head): GEMM, data and weight gradients on the HIP library"""
     cin, cout = w2d.shape
     require_cuda(inputs)
     if inputs.dtype != torch.float32:
         raise TypeError("the training path is float32")
-    y = _TrainMatmul.apply(inputs.reshape(-1, cin).contiguous(), w2d.contiguous(), b)
+    fn = _TrainDenseRelu if relu else _TrainMatmul
+    y = fn.apply(inputs.reshape(-1, cin).contiguous(), w2d.contiguous(), b)
     return y.reshape(list(inputs.shape[:-1]) + [cout])
 
 
@@ -972,9 +1009,9 @@ def conv2d_hoisted_first(kind, src, geo, plan, cin, num_output_channels, scope, 
 def _train_layer(inputs, w2d, b, bnv, bn_decay, relu, pool=0, defer=False):
     """One dense layer of the training path, entirely on the HIP library: inputs (..., cin) -> (..., cout); pool > 1 also
     takes the max over groups of `pool` consecutive entries of the second-to-last axis (..., W, cin) -> (..., W/pool, cout).
-    With batch norm: _TrainDenseBnRelu; without (the class head, activation None): _TrainMatmul.  There is no torch
-    fallback: configurations the SA/FP stack and its head never use (ReLU / pooling without batch norm, widths beyond 1024
-    or not a multiple of 4 above 256) raise.  (tests/torch_layers.py holds the plain-torch reference of this function.)"""
+    With batch norm: _TrainDenseBnRelu; without: _TrainMatmul (activation None: the class head) or _TrainDenseRelu (bn=False
+    layers of the layer API, tf_util.py:186-204).  There is no torch fallback: batch-norm widths beyond 1024 or not a multiple of
+    4 above 256 raise.  (tests/torch_layers.py holds the plain-torch reference of this function.)"""
     cin, cout = w2d.shape
     pool = int(pool) if pool and pool > 1 else 0
     lead = list(inputs.shape[:-1])
@@ -986,13 +1023,11 @@ def _train_layer(inputs, w2d, b, bnv, bn_decay, relu, pool=0, defer=False):
     if inputs.dtype != torch.float32:
         raise TypeError("the training path is float32")
     if bnv is None:
-        if relu or pool:
-            raise NotImplementedError("is_training=True with bn=False and a ReLU / pooling: the training kernels of this package "
-                                      "fuse the activation into the batch-norm kernels (pn2_bn_relu_*); there is no HIP "
-                                      "bias + ReLU training kernel and no torch fallback (INTEGRATION.md, limitations)")
+        if pool:  # the fused max over K lives in the batch-norm kernels; a layer without batch norm is pooled by its caller
+            raise ValueError("pool > 1 needs bn=True on the training path (pointnet_sa_module pools bn=False stacks with group_pool)")
         if _deferred_producer(inputs.reshape(-1, cin)) is not None:
             raise RuntimeError("a deferred batch-norm output reached a layer without batch norm")
-        return _train_dense(inputs, w2d, b)
+        return _train_dense(inputs, w2d, b, relu=relu)
     if not (cout <= 1024 and (cout % 4 == 0 or cout <= 256)):
         raise NotImplementedError("batch-norm layer width %d: the HIP kernels take <= 1024 channels, a multiple of 4 above 256" % cout)
     beta, gamma, mean, var = bnv

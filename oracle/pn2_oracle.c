@@ -194,6 +194,9 @@ int oracle_fps_first_tie(int b, int n, int m, const float *inp, int *tie, int mo
                 if (best == 0.0f) zero = 1;
                 if (other || best == 0.0f) { if (j < strict) strict = j; }
                 else if (j < benign) benign = j;
+            } else if (best == 0.0f) { /* n == 1: the only point is picked again -- the maximum is 0, a strict step */
+                zero = 1;
+                if (j < strict) strict = j;
             }
         }
         tie[i] = (zero && benign < strict) ? benign : strict;

@@ -42,6 +42,27 @@ def _separate(pn2, xyz0, npoints, radii, nsamples, want_nn=True):
     return out
 
 
+_BUILD_OF = {(2, 1): "fast_noslp", (0, 0): "off"}   # (fps mode, ball-query mode) -> the oracle/_ref build that produces it
+
+
+def _assert_equals_reference_kernels(got, xyz0, npoints, radii, nsamples, build, what):
+    """every level against the REFERENCE's own kernels (oracle/_ref: tf_sampling.cu / tf_grouping.cu built for gfx950), directly:
+    farthestpointsamplingKernel + gatherpointKernel + query_ball_point_gpu on the level's source cloud"""
+    from oracle import ref
+    if not ref.available(build):
+        pytest.skip("oracle/_ref not built")
+    cur = xyz0.cpu().numpy()
+    for l, (g, m, r, ns) in enumerate(zip(got, npoints, radii, nsamples)):
+        f = ref.farthest_point_sample(m, cur, build)
+        nx = ref.gather_point(cur, f, build)
+        ri, rc = ref.query_ball_point(r, ns, cur, nx, build)
+        assert np.array_equal(g["fps_idx"].cpu().numpy(), f), "%s level %d: picks != reference kernel" % (what, l)
+        assert np.array_equal(g["new_xyz"].cpu().numpy(), nx), "%s level %d: new_xyz != reference kernel" % (what, l)
+        assert np.array_equal(g["cnt"].cpu().numpy(), rc), "%s level %d: pts_cnt != reference kernel" % (what, l)
+        assert np.array_equal(g["idx"].cpu().numpy(), ri), "%s level %d: ball query != reference kernel" % (what, l)
+        cur = nx
+
+
 def _assert_same(got, want, what):
     import torch
     for l, (g, w) in enumerate(zip(got, want)):
@@ -73,6 +94,9 @@ def test_coarse_geometry_equals_the_separate_ops(pn2, cuda, gen):
             want = _separate(pn2, l1, [256, 64, 16], radii, [32, 32, 32])
             got = pu.coarse_geometry(l1, [256, 64, 16], radii, [32, 32, 32])
             _assert_same(got, want, "%s modes %d/%d" % (gen, fps_mode, bq_mode))
+            if (fps_mode, bq_mode) in _BUILD_OF:  # not only transitively -- the reference's kernels, level by level
+                _assert_equals_reference_kernels(got, l1, [256, 64, 16], radii, [32, 32, 32], _BUILD_OF[(fps_mode, bq_mode)],
+                                                 "%s modes %d/%d" % (gen, fps_mode, bq_mode))
             took = (rec >= 256).cpu().numpy()
             if gen in ("scene", "randn", "dup25"):
                 assert took.all()

@@ -901,17 +901,119 @@ def test_sa_module_api_branches_vs_oracle(pn2, oracle, cuda, case):
     close(new_points.cpu().numpy(), r_pts)
 
 
-def test_sa_module_training_without_batch_norm_is_refused_loudly(pn2, cuda):
-    """the reference accepts pointnet_sa_module(..., bn=False, is_training=True); this package has no HIP
-    bias + ReLU training kernel for it and no torch fallback -- it must say so, not compute something else."""
+def _record_train_layers(tfu):
+    """patch tf_util._train_layer so that every layer's output is kept (call order) -> (list, restore())"""
+    orig, seen = tfu._train_layer, []
+
+    def rec(inputs, w2d, b, bnv, bn_decay, relu, pool=0, defer=False):
+        z = orig(inputs, w2d, b, bnv, bn_decay, relu, pool, defer)
+        seen.append(z.detach())
+        return z
+    tfu._train_layer = rec
+    return seen, lambda: setattr(tfu, "_train_layer", orig)
+
+
+def _rel(a, b):
+    return float((a.double() - b.double()).norm()) / max(float(b.double().norm()), 1e-30)
+
+
+@pytest.mark.parametrize("mlp,mlp2,C", [([32], None, 8), ([32, 32, 64], None, 16), ([64, 48], [40, 24], 5)])
+def test_sa_module_trains_without_batch_norm(pn2, cuda, mlp, mlp2, C):
+    """the reference accepts pointnet_sa_module(..., bn=False, is_training=True) (pointnet_util.py:150-166 on
+    tf_util.py:186-204: conv -> bias_add -> relu, no batch norm).  Forward within 1e-5 and every gradient (weights, biases, input
+    features) within 1e-4 of a float64 evaluation on the HIP path's own activation pattern (ReLU masks from the HIP outputs, max
+    pool winners = the neighbours whose float64 value is closest to the pooled HIP value)."""
+    import torch
     tfu, pu = pn2.util.tf_util, pn2.util.pointnet_util
-    rs = np.random.RandomState(0)
-    xyz = T(rs.random_sample((2, 256, 3)).astype(np.float32), cuda)
-    pts = T(rs.randn(2, 256, 8).astype(np.float32), cuda).requires_grad_(True)
-    tfu.set_default_store(tfu.VariableStore(device=cuda, seed=5))
-    with pytest.raises(NotImplementedError, match="bn=False"):
-        pu.pointnet_sa_module(xyz, pts, npoint=32, radius=0.3, nsample=16, mlp=[32], mlp2=None, group_all=False,
-                              is_training=True, bn_decay=None, scope="nb", bn=False)
+    rs = np.random.RandomState(len(mlp) + C)
+    B, N, M, K = 2, 512, 64, 16
+    xyz = T(rs.random_sample((B, N, 3)).astype(np.float32), cuda)
+    pts = T(rs.randn(B, N, C).astype(np.float32), cuda).requires_grad_(True)
+    store = tfu.set_default_store(tfu.VariableStore(device=cuda, seed=5))
+    seen, restore = _record_train_layers(tfu)
+    try:
+        new_xyz, out, idx = pu.pointnet_sa_module(xyz, pts, npoint=M, radius=0.3, nsample=K, mlp=mlp, mlp2=mlp2, group_all=False,
+                                                  is_training=True, bn_decay=None, scope="nb", bn=False)
+    finally:
+        restore()
+    assert not any("bn/" in k for k in store.params)
+    cot = T(rs.randn(*out.shape).astype(np.float32), cuda)
+    (out * cot).sum().backward()
+    names = ["conv%d" % i for i in range(len(mlp))] + ["conv_post_%d" % i for i in range(len(mlp2 or []))]
+    assert len(seen) == len(names)
+    # float64 on the same pattern
+    ii = idx.long()
+    bidx = torch.arange(B, device=cuda).view(B, 1, 1)
+    p64 = pts.detach().double().requires_grad_(True)
+    x64 = xyz.double()
+    h = torch.cat([x64[bidx, ii] - new_xyz.double().unsqueeze(2), p64[bidx, ii]], dim=-1)   # (B,M,K,3+C), xyz first
+    W64, b64 = {}, {}
+    for li, nm in enumerate(names):
+        w = store.params["nb/%s/weights" % nm].detach().double().reshape(-1, seen[li].shape[-1]).requires_grad_(True)
+        bb = store.params["nb/%s/biases" % nm].detach().double().requires_grad_(True)
+        W64[nm], b64[nm] = w, bb
+        if li == len(mlp):   # max over K between mlp and mlp2: the winner is named by the pooled HIP value
+            zt = seen[li - 1].double()                       # (B,M,K,c) un-pooled HIP output of the last mlp layer
+            pooled_hip = zt.max(dim=2, keepdim=True).values
+            pick = (zt - pooled_hip).abs().argmin(dim=2, keepdim=True)
+            h = torch.gather(h, 2, pick)
+        y = h @ w + bb
+        h = y * (seen[li].double().reshape(y.shape) > 0)
+    if mlp2 is None:
+        zt = seen[-1].double()
+        pick = (zt - zt.max(dim=2, keepdim=True).values).abs().argmin(dim=2, keepdim=True)
+        h = torch.gather(h, 2, pick)
+    ref = h.squeeze(2)
+    close(out.detach().cpu().numpy(), ref.detach().cpu().numpy())
+    (ref * cot.double()).sum().backward()
+    errs = {"points": _rel(pts.grad, p64.grad)}
+    for nm in names:
+        errs[nm + "/w"] = _rel(store.params["nb/%s/weights" % nm].grad.reshape(W64[nm].shape), W64[nm].grad)
+        errs[nm + "/b"] = _rel(store.params["nb/%s/biases" % nm].grad, b64[nm].grad)
+    assert max(errs.values()) < 1e-4, errs
+
+
+def test_fp_module_trains_without_batch_norm(pn2, cuda):
+    """pointnet_fp_module(..., bn=False, is_training=True) (pointnet_util.py:312-325 on tf_util.py:186-204): forward 1e-5,
+    gradients of weights, biases, points1 and points2 within 1e-4 of float64 on the HIP path's ReLU pattern."""
+    import torch
+    tfu, pu = pn2.util.tf_util, pn2.util.pointnet_util
+    rs = np.random.RandomState(11)
+    B, n1, n2, c1, c2, mlp = 2, 600, 96, 6, 24, [48, 32]
+    xyz1 = T(rs.random_sample((B, n1, 3)).astype(np.float32), cuda)
+    xyz2 = T(rs.random_sample((B, n2, 3)).astype(np.float32), cuda)
+    p1 = T(rs.randn(B, n1, c1).astype(np.float32), cuda).requires_grad_(True)
+    p2 = T(rs.randn(B, n2, c2).astype(np.float32), cuda).requires_grad_(True)
+    store = tfu.set_default_store(tfu.VariableStore(device=cuda, seed=6))
+    seen, restore = _record_train_layers(tfu)
+    try:
+        out = pu.pointnet_fp_module(xyz1, xyz2, p1, p2, mlp, True, None, scope="nbfp", bn=False)
+    finally:
+        restore()
+    assert not any("bn/" in k for k in store.params) and len(seen) == len(mlp)
+    cot = T(rs.randn(*out.shape).astype(np.float32), cuda)
+    (out * cot).sum().backward()
+    dist, idx = pn2.three_nn(xyz1, xyz2)
+    d = torch.clamp(dist.double(), min=1e-10)            # pointnet_util.py:300-303
+    wgt = (1.0 / d) / (1.0 / d).sum(dim=2, keepdim=True)
+    q1, q2 = p1.detach().double().requires_grad_(True), p2.detach().double().requires_grad_(True)
+    bidx = torch.arange(B, device=cuda).view(B, 1, 1)
+    interp = (q2[bidx, idx.long()] * wgt.unsqueeze(-1)).sum(dim=2)
+    h = torch.cat([interp, q1], dim=2)                    # interpolated FIRST (:306-311)
+    W64, b64 = [], []
+    for li in range(len(mlp)):
+        w = store.params["nbfp/conv_%d/weights" % li].detach().double().reshape(-1, mlp[li]).requires_grad_(True)
+        bb = store.params["nbfp/conv_%d/biases" % li].detach().double().requires_grad_(True)
+        W64.append(w); b64.append(bb)
+        y = h @ w + bb
+        h = y * (seen[li].double().reshape(y.shape) > 0)
+    close(out.detach().cpu().numpy(), h.detach().cpu().numpy())
+    (h * cot.double()).sum().backward()
+    errs = {"points1": _rel(p1.grad, q1.grad), "points2": _rel(p2.grad, q2.grad)}
+    for li in range(len(mlp)):
+        errs["w%d" % li] = _rel(store.params["nbfp/conv_%d/weights" % li].grad.reshape(W64[li].shape), W64[li].grad)
+        errs["b%d" % li] = _rel(store.params["nbfp/conv_%d/biases" % li].grad, b64[li].grad)
+    assert max(errs.values()) < 1e-4, errs
 
 
 def test_group_pool_kernels_all_modes_and_use_nchw(pn2, cuda):

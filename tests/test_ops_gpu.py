@@ -716,17 +716,21 @@ def test_query_ball_point_binned_equals_unbinned(pn2, oracle, cuda, case, mode):
     q = xyz[:, :m].copy()
     set_mode(mode)
     oi, oc = oracle.query_ball_point(r, K, xyz, q, mode)
-    bins = g.ball_query_bin(r, T(xyz, cuda))
+    xt = T(xyz, cuda)
+    bins = g.ball_query_bin(r, xt)
     assert bins is not None
-    bi, bc = g.query_ball_point_binned(r, K, T(xyz, cuda), T(q, cuda), bins)
+    bi, bc = g.query_ball_point_binned(r, K, xt, T(q, cuda), bins)
     assert np.array_equal(bi.cpu().numpy(), oi) and np.array_equal(bc.cpu().numpy(), oc)
     # bins that do not describe the query are refused (the C entry point takes an opaque pointer)
     with pytest.raises(ValueError, match="do not describe"):
-        g.query_ball_point_binned(r * 0.5, K, T(xyz, cuda), T(q, cuda), bins)
+        g.query_ball_point_binned(r * 0.5, K, xt, T(q, cuda), bins)
     with pytest.raises(ValueError, match="do not describe"):
         g.query_ball_point_binned(r, K, T(xyz[:1], cuda), T(q[:1], cuda), bins)
+    # ... and so are bins of ANOTHER cloud of the same shape, or of a cloud modified in place since
+    with pytest.raises(ValueError, match="another cloud"):
+        g.query_ball_point_binned(r, K, T(xyz, cuda), T(q, cuda), bins)
     q2 = xyz[:, -m:].copy()  # the bins depend on (radius, xyz1) only
-    b2, c2 = g.query_ball_point_binned(r, K, T(xyz, cuda), T(q2, cuda), bins)
+    b2, c2 = g.query_ball_point_binned(r, K, xt, T(q2, cuda), bins)
     o2, oc2 = oracle.query_ball_point(r, K, xyz, q2, mode)
     assert np.array_equal(b2.cpu().numpy(), o2) and np.array_equal(c2.cpu().numpy(), oc2)
     # the layer-level chain (bins built on a forked stream beside the FPS) equals the plain chain
@@ -740,6 +744,9 @@ def test_query_ball_point_binned_equals_unbinned(pn2, oracle, cuda, case, mode):
     import torch
     assert torch.equal(nx1, nx0) and torch.equal(idx1, idx0)
     assert g.ball_query_bin(r, T(xyz[:, :1000].copy(), cuda)) is None  # below the grid kernel's range: caller scans
+    xt.add_(0.0)  # an in-place update (same values): the tag no longer vouches for the cloud
+    with pytest.raises(ValueError, match="another cloud"):
+        g.query_ball_point_binned(r, K, xt, T(q, cuda), bins)
 
 
 def test_query_ball_point_kernels_fuzz(pn2, oracle, cuda):

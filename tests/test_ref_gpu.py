@@ -330,6 +330,82 @@ def test_nested_fps_edge_shapes(pn2, oracle, cuda):
         S.USE_NESTED_FPS = True
 
 
+def test_fps_tie_record_sees_three_holders_in_one_lane(pn2, oracle, cuda):
+    """the one-pick kernels keep PPT points per lane (k, k+NT, k+2NT, ...); a maximum held by THREE rows of one lane
+    (the winner among them) slipped through an OR/XOR parity count.  Three points at distance 1 from the first pick on indices
+    congruent mod NT, every layout with PPT >= 3 (<64,4>, <512,4>, the coarse kernel's <256,4>): the record must say step 1."""
+    import torch
+    from pn2_amd import _lib
+    lib, ptr = _lib.lib, _lib.ptr
+    S, pu = pn2.tf_ops.tf_sampling, pn2.util.pointnet_util
+    for n, nt, a in [(200, 64, 5), (1536, 512, 77), (2048, 512, 511), (1000, 256, 130)]:
+        rs = np.random.RandomState(n)
+        x = (rs.random_sample((3, n, 3)).astype(np.float32) - 0.5) * 0.2
+        x[:, 0] = 0.0
+        for ci in range(3):
+            x[ci, a], x[ci, a + nt], x[ci, a + 2 * nt] = (1, 0, 0), (0, 1, 0), (0, 0, 1)
+        x[2, a + nt] = (0.5, 0, 0)   # cloud 2: only two holders (the case the old count did see)
+        want = oracle.fps_first_tie(8, x, 2)
+        assert want.tolist() == [1, 1, 1]
+        xt = T(x, cuda)
+        out = torch.empty((3, 8), dtype=torch.int32, device=cuda)
+        tie = torch.empty((3,), dtype=torch.int32, device=cuda)
+        _lib.check(lib.pn2_fps_nested(3, n, 8, ptr(xt), None, ptr(out), None, None, ptr(tie), 2, _lib.stream_ptr()), "pn2_fps_nested")
+        assert np.array_equal(out.cpu().numpy(), oracle.farthest_point_sample(8, x, 2)), n
+        assert tie.cpu().tolist() == [1, 1, 1], (n, nt, tie.cpu().tolist())
+        if n <= pu.COARSE_MAX_N:  # the in-kernel sampler of pn2_coarse_geometry (<256,4>): an untagged source cloud is sampled
+            lv = pu.coarse_geometry(xt, [8], [0.5], [4])
+            assert np.array_equal(lv[0]["fps_idx"].cpu().numpy(), oracle.farthest_point_sample(8, x, 2))
+            assert S.fps_tie_record(lv[0]["new_xyz"]).cpu().tolist() == [1, 1, 1], n
+
+
+def test_nested_fps_refuses_the_shortcut_when_every_row_is_asked_for(pn2, oracle, cuda):
+    """the samplers do not look at ties of their LAST pick, so a level that asks for m == n rows of a tagged parent
+    must sample.  Parent [A, B, C, A'] (A' == A) picked completely: its last pick meets td == 0 everywhere and repeats index 0;
+    the child over those rows must repeat it too ([0, 1, 2, 0], not 0..3).  A one-point parent repeats its point from step 1 on
+    (no second holder of the maximum 0 for the tie branches to see: the record is set by the entry point)."""
+    S = pn2.tf_ops.tf_sampling
+    x = np.zeros((2, 4, 3), np.float32)
+    x[:, 1], x[:, 2], x[:, 3] = (4, 0, 0), (0, 3, 0), (0, 0, 0)   # row 3 duplicates row 0
+    for x0, levels in ((x, (4, 4, 4)), (np.ones((3, 1, 3), np.float32), (3, 2, 2)), (x, (4, 3, 3))):
+        cur, cur_ref = T(x0, cuda), x0
+        for m in levels:
+            idx, new_xyz = S.farthest_point_sample_and_gather(m, cur)
+            want = oracle.farthest_point_sample(m, cur_ref, 2)
+            assert np.array_equal(idx.cpu().numpy(), want), (m, idx.cpu().numpy(), want)
+            cur_ref = oracle.gather_point(cur_ref, want)
+            assert np.array_equal(new_xyz.cpu().numpy(), cur_ref)
+            cur = new_xyz
+
+
+def test_nested_fps_tag_and_buffers_rewritten_through_raw_pointers(pn2, oracle, cuda):
+    """tensors rewritten WITHOUT a version bump.  (1) a graph replay that rewrites new_xyz rewrites its tie
+    record in the same launch: the tag, consumed eagerly afterwards, describes the new contents (a lattice cloud full of ties
+    replayed into the static buffers of a graph captured on a tie-free cloud must NOT take the shortcut).  (2) the library's own
+    raw-pointer copy into a tagged tensor (tf_util.multi_copy_) drops the tag."""
+    import torch
+    S, tfu = pn2.tf_ops.tf_sampling, pn2.util.tf_util
+    b, n, m1, m2 = 4, 2048, 512, 128
+    scene, lattice = s_scene(77, b, n), s_grid(78, b, n, 8)
+    cap = pn2.runtime.CapturedForward(lambda x: S.farthest_point_sample_and_gather(m1, x)[1], T(scene, cuda))
+    for cloud in (lattice, scene, lattice):
+        (new_xyz,) = (cap(T(cloud, cuda)),)
+        torch.cuda.synchronize()
+        assert S.fps_tie_record(new_xyz) is not None            # still tagged: same tensor object, same version ...
+        idx2, _ = S.farthest_point_sample_and_gather(m2, new_xyz)  # ... and the record it points to was rewritten by the replay
+        r1 = oracle.gather_point(cloud, oracle.farthest_point_sample(m1, cloud, 2))
+        assert np.array_equal(new_xyz.cpu().numpy(), r1)
+        assert np.array_equal(idx2.cpu().numpy(), oracle.farthest_point_sample(m2, r1, 2))
+    # (2)
+    _, a = S.farthest_point_sample_and_gather(m1, T(scene, cuda))
+    assert S.fps_tie_record(a) is not None
+    other = T(oracle.gather_point(lattice, oracle.farthest_point_sample(m1, lattice, 2)), cuda)
+    tfu.multi_copy_([a], [other])
+    assert S.fps_tie_record(a) is None
+    idx3, _ = S.farthest_point_sample_and_gather(m2, a)
+    assert np.array_equal(idx3.cpu().numpy(), oracle.farthest_point_sample(m2, other.cpu().numpy(), 2))
+
+
 def test_nested_fps_tag_is_dropped_when_it_no_longer_describes_the_tensor(pn2, cuda):
     S = pn2.tf_ops.tf_sampling
     x = T(s_scene(0, 2, 2048), cuda)
