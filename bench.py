@@ -20,8 +20,11 @@ itself and exits with that job's status.  Either way the line is only printed by
 WITHOUT the GPU workload: the N > 1 plumbing checked on a CPU-only box.
 
 Prints ONE JSON line (rank 0).  `value` / `ms_per_step` are the THROUGHPUT regime: `config.batches_in_flight`
-(default 4) independent B=16 batches in flight, each its own hipGraph on its own stream -- a step is still one
-full batch through the whole stack.  The LATENCY regime (one batch in flight, what the reference's benchmark.py
+(default 6) independent B=16 batches in flight on `config.streams` (4) streams -- runtime.StaggeredPipeline: a batch is
+two hipGraphs (SA1's sampling | everything else) on its ONE stream, two of the four streams keep one sampled batch
+ahead of their dense work so that a region that starts with empty queues does not run its batches in lockstep
+(`--stagger off`: one graph per batch on `--pipeline` streams, the r01-r04 execution).  A step is still one full batch
+through the whole stack, submitted and completed inside the timed region.  The LATENCY regime (one batch in flight, what the reference's benchmark.py
 times) is reported next to it under `regimes`.  Besides the contract keys the line carries
   regimes       {"throughput": {...}, "latency": {...}}: ms per step and points/s of both regimes, each timed
                 over the same K steps with barrier + synchronize on both sides; "throughput_steady_state": the throughput
@@ -684,14 +687,10 @@ def main():
                     help="run only the two north-star kernel measurements and print them (the command the rocprofv3 / PMC passes "
                          "of tools/gpu_round4.sh profile: profiles/r04_pmc_north_star.json)")
     ap.add_argument("--no-other-inputs", action="store_true", help="skip the S-randn / S-dup25 legs of the line")
-    ap.add_argument("--sampler-ahead", type=int, default=0, metavar="SLOTS",
-                    help="throughput regime on runtime.SamplerAheadPipeline with SLOTS batch slots: two graphs per batch (SA1's "
-                         "sampling | everything else) on sampler / dense streams; 0 = one graph per batch on --pipeline streams")
-    ap.add_argument("--sampler-streams", type=int, default=2)
-    ap.add_argument("--dense-streams", type=int, default=2)
-    ap.add_argument("--cu-split", type=int, default=0, metavar="NS",
-                    help="with --sampler-ahead: confine the sampler streams to NS compute units and the dense streams to the "
-                         "other 256-NS (hipExtStreamCreateWithCUMask)")
+    ap.add_argument("--stagger", default="0,0,1,1", metavar="B0,B1,..|off",
+                    help="throughput regime on runtime.StaggeredPipeline: one stream per entry, the stream keeps that many sampled "
+                         "batches ahead of its dense work (two graphs per batch on ONE stream; breaks the lockstep of a region that "
+                         "starts with empty queues); off = one graph per batch on --pipeline streams (the r01-r04 execution)")
     args = ap.parse_args()
 
     if args.gpus < 1:
@@ -772,23 +771,25 @@ def main():
 
     step = eager_step = lambda: eager_on(pc)  # noqa: E731
     pipe = None
+    flush = lambda: None  # noqa: E731
     if not args.eager:
         # one hipGraph per forward: replay removes the ~40 Python-side launches from the step.
         # --pipeline P: P independent batches in flight (P graphs with their own buffers, replayed
         # round-robin on P streams), so one batch's latency-bound FPS (16 CUs) overlaps the MFMA
         # layers of the previous batch.  Every step is still one full forward over one batch.
-        P = max(1, args.sampler_ahead if args.sampler_ahead else args.pipeline)
         fwd = lambda x: pn2.model.get_sa_fp_features(x, False, hp)[0]  # noqa: E731
-        batches = [pc] + [torch.from_numpy(s_scene(2000 + 10 * rank + i, B, N)).to(dev) for i in range(1, P)]
-        if args.sampler_ahead:
-            pipe = pn2.runtime.SamplerAheadPipeline(
-                lambda x: pn2.model.sa1_samples(x, hp), lambda x, s: pn2.model.get_sa_fp_features(x, False, hp, sa1=s)[0],
-                batches, sampler_streams=args.sampler_streams, dense_streams=args.dense_streams,
-                cu_split=(args.cu_split, 256) if args.cu_split else None)
-            caps = [pn2.runtime.CapturedForward(fwd, batches[0])]  # the latency regime: one graph, one batch in flight
-            step = pipe.step
+        mk = lambda n: (pc if n == 0 else torch.from_numpy(s_scene(2000 + 10 * rank + n, B, N)).to(dev))  # noqa: E731
+        if args.stagger != "off":
+            backlog = [int(v) for v in args.stagger.split(",")]
+            pipe = pn2.runtime.StaggeredPipeline(lambda x: pn2.model.sa1_samples(x, hp),
+                                                 lambda x, s: pn2.model.get_sa_fp_features(x, False, hp, sa1=s)[0], mk, backlog)
+            caps = [pn2.runtime.CapturedForward(fwd, pc)]  # the latency regime: one graph, one batch in flight
+            step = lambda: (lambda r: None if r is None else r[1])(pipe.step())  # noqa: E731
+            flush = lambda: (lambda d: d[-1][1] if d else None)(pipe.flush())  # noqa: E731
+            thr_inputs, n_streams, n_flight = pipe.inputs(), pipe.P, pipe.batches_in_flight
         else:
-            caps = [pn2.runtime.CapturedForward(fwd, b_) for b_ in batches]
+            P = max(1, args.pipeline)
+            caps = [pn2.runtime.CapturedForward(fwd, mk(n)) for n in range(P)]
             streams = [torch.cuda.Stream() for _ in range(P)]
             counter = [0]
 
@@ -797,15 +798,21 @@ def main():
                 counter[0] += 1
                 with torch.cuda.stream(streams[i]):
                     return caps[i].replay()
+            thr_inputs, n_streams, n_flight = [c_.static_inputs[0] for c_ in caps], P, P
     for _ in range(args.warmup):
         step()
+    flush()
     torch.cuda.synchronize()
     if dist_on:
         dist.barrier()
         torch.cuda.synchronize()
     t0 = time.perf_counter()
+    out = None
     for _ in range(args.steps):
-        out = step()
+        r_ = step()
+        out = out if r_ is None else r_
+    r_ = flush()           # (a staggered pipeline holds dense halves back: all of them are submitted before the synchronize)
+    out = out if r_ is None else r_
     torch.cuda.synchronize()
     if dist_on:
         dist.barrier()
@@ -839,6 +846,7 @@ def main():
         t2 = time.perf_counter()
         for _ in range(10 * args.steps):
             step()
+        flush()
         torch.cuda.synchronize()
         steady_ms = (time.perf_counter() - t2) / (10 * args.steps) * 1e3
 
@@ -854,7 +862,7 @@ def main():
     if rank == 0:
         total_points = world * B * N * args.steps
         ms_per_step = elapsed / args.steps * 1e3
-        P_eff = 1 if args.eager else max(1, args.sampler_ahead if args.sampler_ahead else args.pipeline)
+        P_eff = 1 if args.eager else n_flight
         is_fps = lambda k: k["kernel"] in LATENCY_KERNELS  # noqa: E731
         dense = [k for k in kernels if not is_fps(k)]
         fps = [k for k in kernels if is_fps(k)]
@@ -883,12 +891,12 @@ def main():
                        "arith_mode": {"fps": int(pn2.config.fps_mode()), "ball_query": int(pn2.config.bq_mode()),
                                       "pinned_to": "oracle/_ref fast_noslp build of the reference's own kernels (contraction on)"},
                        "launch": "eager python launches" if args.eager else "one hipGraph replay per step",
-                       "streams_per_batch": 1 if not args.sampler_ahead else 2,
-                       "execution": ("runtime.SamplerAheadPipeline: %d batch slots, two graphs per batch (SA1 sampling | the rest) on "
-                                     "%d sampler + %d dense streams%s" % (args.sampler_ahead, args.sampler_streams, args.dense_streams,
-                                                                          ", CU split %d | %d" % (args.cu_split, 256 - args.cu_split)
-                                                                          if args.cu_split else ""))
-                       if args.sampler_ahead else "one graph per batch, one stream per batch in flight",
+                       "streams_per_batch": 1,
+                       "execution": ("runtime.StaggeredPipeline: %d streams, two graphs per batch (SA1 sampling | the rest) on the "
+                                     "batch's one stream, sampled batches kept ahead per stream %s" % (n_streams, args.stagger)
+                                     if (args.stagger != "off" and not args.eager) else
+                                     "one graph per batch, one stream per batch in flight"),
+                       "streams": n_streams,
                        "batches_in_flight": P_eff,
                        "fp_front": "fused" if fused_fp else "materialised"},
             "regimes": {
@@ -954,17 +962,17 @@ def main():
             base = {(k["kernel"], tuple(k["args"])): k["avg_us"] for k in kernels}
             for nm, gen in (("S-randn", s_randn), ("S-dup25", s_dup25)):
                 arrs = [torch.from_numpy(gen(3000 + 10 * rank + i, B, N)).to(dev) for i in range(P_eff)]
-                for c_, a_ in zip(caps, arrs):
-                    c_.static_inputs[0].copy_(a_)
-                if pipe is not None:
-                    for d_, a_ in zip(pipe.inputs, arrs):
-                        d_.copy_(a_)
+                caps[0].static_inputs[0].copy_(arrs[0])
+                for d_, a_ in zip(thr_inputs, arrs):
+                    d_.copy_(a_)
                 for _ in range(args.warmup):
                     step()
+                flush()
                 torch.cuda.synchronize()
                 t0 = time.perf_counter()
                 for _ in range(args.steps):
                     step()
+                flush()
                 torch.cuda.synchronize()
                 thr = (time.perf_counter() - t0) / args.steps * 1e3
                 t0 = time.perf_counter()
@@ -991,11 +999,9 @@ def main():
                     "three_nn_us": pick(("three_nn",)),
                     "gpu_ms_per_step_sum_of_kernels": round(sum(k["ms_per_step"] for k in ks), 4),
                     "slower_than_1.5x_S-scene": slow}
-            for c_, a_ in zip(caps, batches):  # back to S-scene for whatever follows
-                c_.static_inputs[0].copy_(a_)
-            if pipe is not None:
-                for d_, a_ in zip(pipe.inputs, batches):
-                    d_.copy_(a_)
+            caps[0].static_inputs[0].copy_(pc)  # back to S-scene for whatever follows
+            for n_, d_ in enumerate(thr_inputs):
+                d_.copy_(mk(n_))
         if not args.no_north_star:
             try:
                 res["north_star"] = north_star_kernels(pn2, dev)

@@ -39,94 +39,94 @@ class CapturedForward:
         return self.static_outputs
 
 
-def masked_stream(device, cu_bits):
-    """A HIP stream whose kernels run only on the compute units whose bit is set in `cu_bits` (an int; on MI300-class parts
-    bit i lands on XCD i % 8, so a run of 8k low bits is k CUs of every XCD) -> torch.cuda.ExternalStream.
-    hipExtStreamCreateWithCUMask through ctypes; the stream lives until the process ends."""
-    import ctypes
-    hip = ctypes.CDLL("libamdhip64.so")
-    nwords = max(1, (int(cu_bits).bit_length() + 31) // 32)
-    words = (ctypes.c_uint32 * nwords)(*[(int(cu_bits) >> (32 * i)) & 0xFFFFFFFF for i in range(nwords)])
-    st = ctypes.c_void_p()
-    with torch.cuda.device(device):
-        rc = hip.hipExtStreamCreateWithCUMask(ctypes.byref(st), ctypes.c_uint32(nwords), words)
-    if rc != 0:
-        raise RuntimeError("hipExtStreamCreateWithCUMask failed: %d" % rc)
-    return torch.cuda.ExternalStream(st.value, device=device)
-
-
-class SamplerAheadPipeline:
+class StaggeredPipeline:
     """Throughput execution of a stack whose every batch starts with a long dependent chain on a few CUs (farthest point
     sampling: 16 workgroups for ~0.34 ms at semantic.json's shapes) followed by chip-filling dense work.
 
-    A batch is TWO captured graphs: `sampler_fn(x) -> s` (the chain) and `dense_fn(x, s) -> y` (everything else).  Sampler
-    graphs are replayed on sampler streams, dense graphs on dense streams, with one event between the halves of a batch and
-    one guarding the reuse of a slot's buffers.  The sampler streams therefore run AHEAD of the dense streams by up to
-    `slots` batches: the chain of batch k+1.. sits beside the dense layers of batch k from the first step of a timed region
-    on, instead of all in-flight batches entering their chains together (one graph per batch on P streams starts every
-    region in lockstep: P chains side by side on an idle chip, then P dense halves contending -- 0.43 ms per step over the
-    first 20 steps against 0.38 in the steady state, r04).  Every step is still one full batch: both graphs of step k are
-    launched by step(k) and nothing of a later step is computed before it was submitted.
+    P batch streams; every batch is TWO captured graphs -- sampler_fn(x) -> s (the chain) and dense_fn(x, s) -> y (everything
+    else) -- launched on the batch's ONE stream (no events, no cross-stream dependencies; two graphs per batch on one stream cost
+    what one graph costs, measured), but not in the same phase on every stream: stream i keeps backlog[i] sampled batches ahead of
+    its dense work,
+        backlog 0:  F D F D F D ...                      backlog 1:  F F D F D F D ... D
+    so that the streams of a region that starts with empty queues do not all sit in their sampler chains together and then all
+    contend in their dense halves.  One graph per batch on 4 streams does exactly that for the first ~20 steps (0.423 ms per step
+    at K = 20 against 0.384 in its steady state); backlogs (0, 0, 1, 1) give 0.408-0.412 at K = 20 and the same steady state
+    (profiles/r05_scheduling_study.txt).  step() submits the sampler half of the next batch and the dense half of the batch
+    `backlog` steps older on that stream; flush() submits the dense halves still held back -- call it before synchronising:
+    every step's work is then submitted, and completed, inside the timed region, and nothing of a step is computed before the
+    step was submitted."""
 
-    cu_split = (n_sampler_cus, n_total_cus) additionally confines the sampler streams to the first n_sampler_cus compute-unit
-    bits and the dense streams to the rest (hipExtStreamCreateWithCUMask); None = ordinary streams."""
-
-    def __init__(self, sampler_fn, dense_fn, batches, sampler_streams=2, dense_streams=2, warmup=2, cu_split=None):
-        dev = batches[0].device
-        self.slots = len(batches)
-        self.inputs = [b.clone() for b in batches]
-        if cu_split is None:
-            mk_s = mk_d = lambda: torch.cuda.Stream(device=dev)  # noqa: E731
-        else:
-            ns, ntot = cu_split
-            mk_s = lambda: masked_stream(dev, (1 << ns) - 1)  # noqa: E731
-            mk_d = lambda: masked_stream(dev, ((1 << ntot) - 1) ^ ((1 << ns) - 1))  # noqa: E731
-        self.s_streams = [mk_s() for _ in range(max(1, sampler_streams))]
-        self.d_streams = [mk_d() for _ in range(max(1, dense_streams))]
-        self.s_graphs, self.d_graphs, self.samples, self.outputs = [], [], [], []
-        side = torch.cuda.Stream(device=dev)
-        for x in self.inputs:
-            side.wait_stream(torch.cuda.current_stream())
-            with torch.cuda.stream(side), torch.no_grad():
-                for _ in range(warmup):
-                    dense_fn(x, sampler_fn(x))
-            torch.cuda.current_stream().wait_stream(side)
-            torch.cuda.synchronize()
-            gs = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(gs, capture_error_mode="thread_local"), torch.no_grad():
-                s = sampler_fn(x)
-            gd = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(gd, capture_error_mode="thread_local"), torch.no_grad():
-                y = dense_fn(x, s)
-            self.s_graphs.append(gs)
-            self.d_graphs.append(gd)
-            self.samples.append(s)
-            self.outputs.append(y)
-        self.sampled = [torch.cuda.Event() for _ in range(self.slots)]
-        self.consumed = [torch.cuda.Event() for _ in range(self.slots)]
-        self.used = [False] * self.slots
+    def __init__(self, sampler_fn, dense_fn, make_batch, backlog=(0, 0, 1, 1), warmup=2):
+        """make_batch(n) -> the example input of slot n (sum(backlog) + len(backlog) slots, cloned into static buffers)"""
+        self.backlog = [int(b) for b in backlog]
+        if not self.backlog or min(self.backlog) < 0:
+            raise ValueError("backlog: one non-negative entry per stream")
+        self.P = len(self.backlog)
+        self.streams = [torch.cuda.Stream() for _ in range(self.P)]
+        self.slots = []   # per stream: [static input, sampler graph, dense graph, static output, samples]
+        side = torch.cuda.Stream()
+        n = 0
+        for i in range(self.P):
+            row = []
+            for _ in range(self.backlog[i] + 1):
+                x = make_batch(n).clone()
+                n += 1
+                side.wait_stream(torch.cuda.current_stream())
+                with torch.cuda.stream(side), torch.no_grad():
+                    for _ in range(warmup):  # creates variables, folded weights, sets kernel attributes
+                        dense_fn(x, sampler_fn(x))
+                torch.cuda.current_stream().wait_stream(side)
+                torch.cuda.synchronize()
+                gs = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(gs, capture_error_mode="thread_local"), torch.no_grad():
+                    s = sampler_fn(x)
+                gd = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(gd, capture_error_mode="thread_local"), torch.no_grad():
+                    y = dense_fn(x, s)
+                row.append((x, gs, gd, y, s))
+            self.slots.append(row)
+        self.next_slot = [0] * self.P
+        self.pending = [[] for _ in range(self.P)]
         self.count = 0
 
+    @property
+    def batches_in_flight(self):
+        return sum(self.backlog) + self.P
+
     def step(self, x=None):
-        """submit the next batch (slot = step number mod slots; x = its input, or None: the batch resident in the slot's static
-        input) -> its static output tensor (valid once the dense stream has finished it: torch.cuda.synchronize() or
-        self.consumed[slot].synchronize(); overwritten `slots` steps later)"""
-        k = self.count % self.slots
+        """submit the next batch (x = its input, or None: the batch resident in the slot's static buffer).  -> (slot, output)
+        of the dense half this call submitted -- the batch `backlog` steps older on this stream -- or None when it only
+        sampled.  An output is valid once its stream has run it (stream.synchronize / torch.cuda.synchronize) and is
+        overwritten when its slot comes round again (backlog + 1 steps of that stream later)."""
+        i = self.count % self.P
         self.count += 1
-        ss = self.s_streams[k % len(self.s_streams)]
-        ds = self.d_streams[k % len(self.d_streams)]
-        if self.used[k]:
-            ss.wait_event(self.consumed[k])  # the dense half of the slot's previous batch still reads the input and the samples
+        k = self.next_slot[i]
+        self.next_slot[i] = (k + 1) % len(self.slots[i])
+        st = self.streams[i]
         if x is not None:
-            ss.wait_stream(torch.cuda.current_stream(x.device))  # x was produced on the caller's stream
-        with torch.cuda.stream(ss):
-            if x is not None:
-                self.inputs[k].copy_(x, non_blocking=True)
-            self.s_graphs[k].replay()
-            self.sampled[k].record(ss)
-        ds.wait_event(self.sampled[k])
-        with torch.cuda.stream(ds):
-            self.d_graphs[k].replay()
-            self.consumed[k].record(ds)
-        self.used[k] = True
-        return self.outputs[k]
+            st.wait_stream(torch.cuda.current_stream(x.device))  # x was produced on the caller's stream
+        with torch.cuda.stream(st):
+            if x is not None:  # (the slot's previous batch is done with the buffer: its dense half precedes us on this stream)
+                self.slots[i][k][0].copy_(x, non_blocking=True)
+            self.slots[i][k][1].replay()
+            self.pending[i].append(k)
+            if len(self.pending[i]) > self.backlog[i]:
+                j = self.pending[i].pop(0)
+                self.slots[i][j][2].replay()
+                return (i, j), self.slots[i][j][3]
+        return None
+
+    def flush(self):
+        """submit the dense halves that are still held back -> [((stream, slot), output)] in submission order"""
+        done = []
+        for i in range(self.P):
+            with torch.cuda.stream(self.streams[i]):
+                while self.pending[i]:
+                    j = self.pending[i].pop(0)
+                    self.slots[i][j][2].replay()
+                    done.append(((i, j), self.slots[i][j][3]))
+        return done
+
+    def inputs(self):
+        """the static input buffers, slot order (= make_batch order)"""
+        return [sl[0] for row in self.slots for sl in row]

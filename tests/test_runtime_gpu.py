@@ -1,5 +1,6 @@
-"""runtime.SamplerAheadPipeline: two graphs per batch (SA1's sampling | the rest) on sampler / dense streams give the bits of the
-eager forward for every submitted batch, also when the sampler streams run slots ahead and slots are reused."""
+"""runtime.StaggeredPipeline: two graphs per batch (SA1's sampling | the rest) on the batch's one stream, some streams keeping
+sampled batches ahead of their dense work -- every submitted batch gets the bits of the eager forward, whatever the backlogs, with
+slots reused and inputs handed in per step; model.sa1_samples + get_sa_fp_features(sa1=) equal the module sampling for itself."""
 import numpy as np
 import pytest
 
@@ -21,43 +22,66 @@ def _cloud(seed, b, n, dev):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("slots,ns,nd", [(1, 1, 1), (3, 2, 1), (4, 2, 2)])
-def test_sampler_ahead_pipeline_equals_the_eager_forward(pn2, cuda, slots, ns, nd):
+@pytest.mark.parametrize("backlog", [(0,), (0, 0, 1, 1), (2, 0, 1), (1, 1)])
+def test_staggered_pipeline_equals_the_eager_forward(pn2, cuda, backlog):
     import torch
     tfu = pn2.util.tf_util
     B, N = 2, 2048
     hp = _small_hp(pn2, B, N)
     tfu.set_default_store(tfu.VariableStore(device=cuda, seed=3))
-    batches = [_cloud(100 + i, B, N, cuda) for i in range(slots)]
+    nslots = sum(backlog) + len(backlog)
+    resident = [_cloud(100 + i, B, N, cuda) for i in range(nslots)]
     with torch.no_grad():
-        pn2.model.get_sa_fp_features(batches[0], False, hp)  # creates the variables
-    pipe = pn2.runtime.SamplerAheadPipeline(lambda x: pn2.model.sa1_samples(x, hp),
-                                            lambda x, s: pn2.model.get_sa_fp_features(x, False, hp, sa1=s)[0],
-                                            batches, sampler_streams=ns, dense_streams=nd)
-    # resident batches
-    for k in range(slots):
-        y = pipe.step()
-        torch.cuda.synchronize()
+        pn2.model.get_sa_fp_features(resident[0], False, hp)  # creates the variables
+    pipe = pn2.runtime.StaggeredPipeline(lambda x: pn2.model.sa1_samples(x, hp),
+                                         lambda x, s: pn2.model.get_sa_fp_features(x, False, hp, sa1=s)[0],
+                                         lambda n: resident[n], backlog)
+    assert pipe.batches_in_flight == nslots and len(pipe.inputs()) == nslots
+
+    def eager(x):
         with torch.no_grad():
-            ref = pn2.model.get_sa_fp_features(batches[k], False, hp)[0]
-        assert torch.equal(y, ref), "slot %d" % k
-    # fresh inputs, submitted back to back (the sampler streams run ahead, every slot is reused), outputs collected per step
-    fresh = [_cloud(200 + i, B, N, cuda) for i in range(3 * slots + 1)]
-    outs, pending = [None] * len(fresh), {}
-    for i, x in enumerate(fresh):
-        k = pipe.count % slots
-        if k in pending:  # read a slot's output before the slot is submitted again
-            j, yy = pending.pop(k)
-            pipe.consumed[k].synchronize()
-            outs[j] = yy.clone()
-        pending[k] = (i, pipe.step(x))
+            return pn2.model.get_sa_fp_features(x, False, hp)[0]
+
+    # the resident batches: one round over every stream's slots, then the held-back dense halves
+    got = {}
+    for _ in range(len(backlog) * (max(backlog) + 1)):
+        r = pipe.step()
+        if r is not None:
+            torch.cuda.synchronize()
+            got[r[0]] = r[1].clone()
+    for key, y in pipe.flush():
+        torch.cuda.synchronize()
+        got[key] = y.clone()
+    flat = {}
+    n = 0
+    for i, b in enumerate(backlog):
+        for j in range(b + 1):
+            flat[(i, j)] = resident[n]
+            n += 1
+    assert got, "no dense half was submitted"
+    for key, y in got.items():
+        assert torch.equal(y, eager(flat[key])), "resident slot %s" % (key,)
+    # fresh inputs, submitted back to back: every output is read when its dense half is submitted + its stream has run it
+    fresh = [_cloud(200 + i, B, N, cuda) for i in range(3 * nslots + 1)]
+    owner = {}      # (stream, slot) -> index of the fresh batch sitting in it
+    outs = [None] * len(fresh)
+
+    def collect(key, y):
+        pipe.streams[key[0]].synchronize()
+        outs[owner[key]] = y.clone()
+
+    for t, x in enumerate(fresh):
+        i = pipe.count % pipe.P
+        owner[(i, pipe.next_slot[i])] = t   # (that slot's previous batch was completed: its dense half was submitted before)
+        r = pipe.step(x)
+        if r is not None:
+            collect(*r)
+    for key, y in pipe.flush():
+        collect(key, y)
     torch.cuda.synchronize()
-    for j, yy in pending.values():
-        outs[j] = yy.clone()
-    with torch.no_grad():
-        for i, x in enumerate(fresh):
-            ref = pn2.model.get_sa_fp_features(x, False, hp)[0]
-            assert torch.equal(outs[i], ref), "fresh batch %d" % i
+    for t, x in enumerate(fresh):
+        assert outs[t] is not None, "fresh batch %d was never completed" % t
+        assert torch.equal(outs[t], eager(x)), "fresh batch %d" % t
 
 
 @pytest.mark.gpu

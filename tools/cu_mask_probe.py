@@ -12,7 +12,9 @@ import torch
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-import pn2_amd as pn2  # noqa: E402
+import pn2_amd as pn2  # noqa: E402,F401
+sys.path.insert(0, os.path.join(ROOT, "tools", "experiments"))
+from r05_sampler_ahead import masked_stream  # noqa: E402
 
 lib = ctypes.CDLL(os.path.join(ROOT, "tools", "probe", "libcu_probe.so"))
 lib.cu_probe_launch.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_longlong, ctypes.c_void_p]
@@ -47,15 +49,15 @@ launch(out, G, plain); torch.cuda.synchronize()
 allc = describe("plain stream, eager", out)
 
 for nbits, label in ((16, "low 16 bits"), (32, "low 32 bits"), (8, "low 8 bits")):
-    ms = pn2.runtime.masked_stream(dev, (1 << nbits) - 1)
+    ms = masked_stream(dev, (1 << nbits) - 1)
     out.zero_(); torch.cuda.synchronize()
     launch(out, G, ms); torch.cuda.synchronize()
     s = describe("masked stream (%s), eager" % label, out)
     if nbits == 16:
         print("   CUs selected by the low 16 bits:", s)
 
-low16 = pn2.runtime.masked_stream(dev, (1 << 16) - 1)
-high240 = pn2.runtime.masked_stream(dev, ((1 << 256) - 1) ^ ((1 << 16) - 1))
+low16 = masked_stream(dev, (1 << 16) - 1)
+high240 = masked_stream(dev, ((1 << 256) - 1) ^ ((1 << 16) - 1))
 out.zero_(); torch.cuda.synchronize()
 launch(out, G, high240); torch.cuda.synchronize()
 s240 = describe("masked stream (bits 16..255), eager", out)
