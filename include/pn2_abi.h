@@ -81,6 +81,15 @@ int pn2_fps_gather(int b, int n, int m, const float *inp, float *temp, int *out,
 int pn2_fps_nested(int b, int n, int m, const float *inp, float *temp, int *out, float *new_xyz,
                    const int *tie_in, int *tie_out, int arith_mode, void *stream);
 
+/* In-place reads of a batch that keeps xyz and rgb side by side (model.py:26-29 slices point_cloud (b,n,6) into l0_xyz /
+ * l0_points; the reference's TF graph materialises both slices): the *_ld entry points take the ROW STRIDE in floats of such a
+ * column block (ld >= 3 resp. >= c; the pointer is the block's first element, rows are ld floats apart, cloud i starts at
+ * i * n * ld) and read it where it lies -- same bits as the dense entry point on a copy.  Shapes a strided kernel does not
+ * exist for return PN2_EUNSUP (the caller then makes the copy).
+ * pn2_fps_nested_ld: pn2_fps_nested for n <= 16384 (the register-resident kernels need no temp). */
+int pn2_fps_nested_ld(int b, int n, int m, const float *inp, int ld, int *out, float *new_xyz,
+                      const int *tie_in, int *tie_out, int arith_mode, void *stream);
+
 /* The coarse levels of the pyramid in ONE launch (extension; replaces 3 launches per level): for l = 0 .. nlev-1, with the
  * source cloud of level l = the samples of level l-1 (level 0: xyz0 (b,n0,3)):
  *   fps_idx[l] (b,npoint[l]) int32, new_xyz[l] (b,npoint[l],3)   = pn2_fps_nested   (util/pointnet_util.py:36-37)
@@ -134,6 +143,10 @@ int pn2_gather_point_grad(int b, int n, int m, const float *out_g, const int *id
 int pn2_query_ball_point(int b, int n, int m, float radius, int nsample,
                          const float *xyz1, const float *xyz2, int *idx,
                          int *pts_cnt, int arith_mode, void *stream);
+/* pn2_query_ball_point with the cloud's rows ld1 floats apart (see pn2_fps_nested_ld); only the shapes the LDS-grid kernel
+ * takes (4096 <= n <= 8192, m >= 256, nsample <= 64), else PN2_EUNSUP. */
+int pn2_query_ball_point_ld(int b, int n, int m, float radius, int nsample, const float *xyz1, int ld1,
+                            const float *xyz2, int *idx, int *pts_cnt, int arith_mode, void *stream);
 /* The same operator on an explicitly chosen kernel -- 0 by shape (= pn2_query_ball_point), 1 wave-per-queries scan,
  * 2 lane-per-query scan, 3 LDS grid; a kernel whose preconditions do not hold falls through to the next.  Every kernel
  * returns the same bits; this door lets the parity tests hold each of them to the oracle.  Stateless. */
@@ -182,6 +195,9 @@ int pn2_group_point_grad_ws(int b, int n, int c, int m, int nsample, const float
  * ties -> lowest index. */
 int pn2_three_nn(int b, int n, int m, const float *xyz1, const float *xyz2,
                  float *dist, int *idx, void *stream);
+/* pn2_three_nn with the QUERY rows ld1 floats apart (see pn2_fps_nested_ld) */
+int pn2_three_nn_ld(int b, int n, int m, const float *xyz1, int ld1, const float *xyz2,
+                    float *dist, int *idx, void *stream);
 
 /* threeinterpolate_cpu(b,m,c,n,points,idx,weight,out)  tf_interpolate.cpp:307-330 */
 int pn2_three_interpolate(int b, int m, int c, int n, const float *points,
@@ -312,6 +328,12 @@ int pn2_sa_mlp_max_fused(int b, int n, int m, int nsample, int c, const float *x
                          const float *new_xyz, const float *points, const int *idx,
                          int nlayers, const int *widths, const float *const *w,
                          const float *const *bias, float *out, void *stream);
+/* pn2_sa_mlp_max_fused with the rows of xyz / points ld_xyz / ld_points floats apart (see pn2_fps_nested_ld); a strided
+ * `points` needs the un-vectorised feature path (c % 8 != 0), else PN2_EUNSUP. */
+int pn2_sa_mlp_max_fused_ld(int b, int n, int m, int nsample, int c, const float *xyz, int ld_xyz,
+                            const float *new_xyz, const float *points, int ld_points, const int *idx,
+                            int nlayers, const int *widths, const float *const *w,
+                            const float *const *bias, float *out, void *stream);
 
 /* bf16 variant of pn2_sa_mlp_max_fused (BASELINE configs[4]: large-scene inference, nsample 64): points is
  * (b,n,c) bfloat16, weights/biases are fp32 and are rounded to bf16 (RNE) by the kernel, products exact,
@@ -505,6 +527,10 @@ int pn2_voxel_downsample(int n, const double *points, const double *colors, cons
 int pn2_fp_mlp_fused_pre(int b, int n, int m, int c1, const float *dist, const int *idx, const float *points1,
                          const float *z, int nlayers, const int *widths, const float *const *w,
                          const float *const *bias, float *y, void *stream);
+/* pn2_fp_mlp_fused_pre with the skip-link rows ld_points1 floats apart (see pn2_fps_nested_ld) */
+int pn2_fp_mlp_fused_pre_ld(int b, int n, int m, int c1, const float *dist, const int *idx, const float *points1,
+                            int ld_points1, const float *z, int nlayers, const int *widths, const float *const *w,
+                            const float *const *bias, float *y, void *stream);
 
 /* pn2_fp_mlp_fused_pre with the kernel SCHEDULE named by the caller (stateless door for parity tests / A-B timing):
  * 0 = lockstep kernel (8 waves: gather, MFMA layers, store), 1 = software-pipelined kernel (one wave per SIMD builds the next

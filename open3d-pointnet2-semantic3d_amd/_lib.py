@@ -21,6 +21,7 @@ SIGNATURES = {
     "pn2_farthest_point_sample": [c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_int, c_void_p],
     "pn2_fps_gather": [c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p],
     "pn2_fps_nested": [c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p],
+    "pn2_fps_nested_ld": [c_int, c_int, c_int, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p],
     "pn2_coarse_geometry": [c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                             c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p],
     "pn2_prob_sample": [c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p],
@@ -28,6 +29,7 @@ SIGNATURES = {
     "pn2_gather_point": [c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p],
     "pn2_gather_point_grad": [c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p],
     "pn2_query_ball_point": [c_int, c_int, c_int, c_float, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p],
+    "pn2_query_ball_point_ld": [c_int, c_int, c_int, c_float, c_int, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_int, c_void_p],
     "pn2_query_ball_point_kernel": [c_int, c_int, c_int, c_float, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int,
                                     c_void_p],
     "pn2_query_ball_point_multi": [c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
@@ -36,6 +38,7 @@ SIGNATURES = {
     "pn2_group_point": [c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p],
     "pn2_group_point_grad": [c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p],
     "pn2_three_nn": [c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p],
+    "pn2_three_nn_ld": [c_int, c_int, c_int, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p],
     "pn2_three_interpolate": [c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p],
     "pn2_three_interpolate_grad": [c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p],
     "pn2_group_point_grad_ws": [c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, ctypes.c_size_t,
@@ -50,6 +53,8 @@ SIGNATURES = {
                              c_int, c_void_p, c_void_p, c_void_p, ctypes.c_size_t, c_void_p, c_void_p, c_void_p, c_void_p],
     "pn2_sa_mlp_max_fused": [c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p,
                              c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p],
+    "pn2_sa_mlp_max_fused_ld": [c_int, c_int, c_int, c_int, c_int, c_void_p, c_int, c_void_p, c_void_p, c_int, c_void_p,
+                                c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p],
     "pn2_sa_mlp_max_fused_bf16": [c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p,
                                   c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p],
     "pn2_sa_mlp_rows_fused": [c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p,
@@ -105,6 +110,8 @@ SIGNATURES = {
                          ctypes.c_double, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p],
     "pn2_fp_mlp_fused_pre": [c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p,
                              c_void_p, c_void_p, c_void_p],
+    "pn2_fp_mlp_fused_pre_ld": [c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_int, c_void_p, c_void_p,
+                                c_void_p, c_void_p, c_void_p],
     "pn2_fp_mlp_fused_pre_schedule": [c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p,
                                       c_void_p, c_void_p, c_void_p, c_int, c_void_p],
     "pn2_sa_mlp_fused_pre": [c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p,
@@ -211,6 +218,14 @@ class _LibProxy:
             rc = fn(*args)
             e.record()
             ints = [a for a in args if isinstance(a, (int, float))]
+            if name in _LD_TRACE:  # an in-place (row-strided) call is the dense entry point's kernel: same trace key, strides dropped
+                base, drop, nl_at, w_at = _LD_TRACE[name]
+                ints = [v for i, v in enumerate(ints) if i not in drop]
+                if w_at is not None:
+                    wp = ctypes.cast(args[w_at], ctypes.POINTER(c_int))
+                    ints += [wp[i] for i in range(args[nl_at])]
+                self.trace.append((base, tuple(ints), s, e))
+                return rc
             if name in ("pn2_sa_mlp_max_fused", "pn2_sa_mlp_rows_fused", "pn2_sa_mlp_max_fused_bf16"):  # decode the host-side widths[] array for flop accounting
                 wp = ctypes.cast(args[10], ctypes.POINTER(c_int))
                 ints += [wp[i] for i in range(args[9])]
@@ -248,6 +263,14 @@ class _LibProxy:
         return call
 
 
+# *_ld entry point -> (dense entry point, positions of the stride arguments among the numeric arguments, index of nlayers /
+# widths[] in the argument list or None)
+_LD_TRACE = {"pn2_fps_nested_ld": ("pn2_fps_nested", (3,), None, None),
+             "pn2_query_ball_point_ld": ("pn2_query_ball_point", (5,), None, None),
+             "pn2_three_nn_ld": ("pn2_three_nn", (3,), None, None),
+             "pn2_sa_mlp_max_fused_ld": ("pn2_sa_mlp_max_fused", (5, 6), 11, 12),
+             "pn2_fp_mlp_fused_pre_ld": ("pn2_fp_mlp_fused_pre", (4,), 9, 10)}
+
 lib = _LibProxy(_raw)
 
 
@@ -263,6 +286,18 @@ def check(code, what):
 def ptr(t):
     """device pointer of a tensor (None -> NULL)."""
     return None if t is None else c_void_p(t.data_ptr())
+
+
+def rows_in_place(t):
+    """(tensor, ld) for a (b, n, c) float32 tensor the *_ld entry points can read where it lies: rows `ld` floats apart, clouds
+    n * ld floats apart -- a dense tensor (ld = c) or a column block of a wider dense one (point_cloud[:, :, 0:3] of a (b,n,6)
+    batch: ld = 6).  Anything else is copied."""
+    t = t.detach()
+    if t.dim() == 3 and t.stride(2) == 1 and t.stride(1) >= t.shape[2] and t.stride(0) == t.shape[1] * t.stride(1) \
+            and t.data_ptr() % 4 == 0:
+        return t, int(t.stride(1))
+    t = t.contiguous()
+    return t, int(t.shape[2])
 
 
 def stream_ptr():

@@ -61,22 +61,22 @@ __device__ __forceinline__ double fps_dmax(double a, double b) {
 // (tie_in_b / tie_out_b: THIS cloud's slots of the tie records, or null)
 __device__ __forceinline__ bool fps_nested_shortcut_b(int n, int m, const float* __restrict__ xyz, int* __restrict__ out,
                                                       float* __restrict__ nxyz, const int* __restrict__ tie_in_b,
-                                                      int* __restrict__ tie_out_b, int nthreads) {
+                                                      int* __restrict__ tie_out_b, int nthreads, int ld = 3) {
     if (tie_in_b == nullptr) return false;
     const int T = __builtin_amdgcn_readfirstlane(*tie_in_b);
     // m == n is refused as well: the sampler does not look at ties of its LAST pick (a consumer normally asks for fewer
     // picks than the level above made), and a level that takes every row needs that step too.
     if (T < m || m >= n) return false;
     for (int jj = threadIdx.x; jj < m; jj += nthreads) out[jj] = jj;
-    if (nxyz) for (int e = threadIdx.x; e < m * 3; e += nthreads) nxyz[e] = xyz[e];
+    if (nxyz) for (int e = threadIdx.x; e < m * 3; e += nthreads) nxyz[e] = xyz[(e / 3) * ld + e % 3];
     if (tie_out_b && threadIdx.x == 0) *tie_out_b = T;  // the prefix of a prefix: the same bound holds below
     return true;
 }
 __device__ __forceinline__ bool fps_nested_shortcut(int n, int m, const float* __restrict__ xyz, int* __restrict__ out,
                                                     float* __restrict__ nxyz, const int* __restrict__ tie_in,
-                                                    int* __restrict__ tie_out, int nthreads) {
+                                                    int* __restrict__ tie_out, int nthreads, int ld = 3) {
     return fps_nested_shortcut_b(n, m, xyz, out, nxyz, tie_in ? tie_in + blockIdx.x : nullptr,
-                                 tie_out ? tie_out + blockIdx.x : nullptr, nthreads);
+                                 tie_out ? tie_out + blockIdx.x : nullptr, nthreads, ld);
 }
 
 // NT threads, thread t owns points k = t + NT*i (i < PPT) in VGPRs for the whole kernel: coordinates and ONE 64-bit
@@ -95,9 +95,11 @@ __device__ __forceinline__ bool fps_nested_shortcut(int n, int m, const float* _
 // TRACK: also write the run's tie record (pn2fps::tie_*) for the level below.
 // fps_reg_body: ONE cloud (xyz (n,3), out (m), nxyz (m,3) or null, tie_out_b = the cloud's slot of the tie record or null)
 // by the calling workgroup of NT threads; smem = kFpsRegHead + (LDS_XYZ ? 16 n + 4 m : 0) bytes, 16-byte aligned.
+// ld = row stride of xyz in floats (3 = dense; 6 = the xyz columns of a (n,6) xyz+rgb cloud read in place).
 template <int NT, int PPT, int MODE, bool LDS_XYZ, bool TRACK>
 __device__ __forceinline__ void fps_reg_body(int n, int m, const float* __restrict__ xyz, int* __restrict__ out,
-                                             float* __restrict__ nxyz, int* __restrict__ tie_out_b, unsigned char* smem) {
+                                             float* __restrict__ nxyz, int* __restrict__ tie_out_b, unsigned char* smem,
+                                             int ld = 3) {
     static_assert(NT != 64 || LDS_XYZ, "single-wave path keeps the cloud in LDS");
     // layout: 4 x u64 key slots (3 used), 4 x i32 tie record (3 used) | float4 xyz[n] (if LDS_XYZ) | int picks[m] (if LDS_XYZ)
     // The picks are kept in LDS and written to HBM once, coalesced, after the last round (together
@@ -123,9 +125,9 @@ __device__ __forceinline__ void fps_reg_body(int n, int m, const float* __restri
         const int k = tid + NT * i;
         int hi;
         if (k < n) {
-            px[i] = xyz[k * 3 + 0];
-            py[i] = xyz[k * 3 + 1];
-            pz[i] = xyz[k * 3 + 2];
+            px[i] = xyz[k * ld + 0];
+            py[i] = xyz[k * ld + 1];
+            pz[i] = xyz[k * ld + 2];
             hi = __float_as_int(1e38f);  // tf_sampling.cu:124-126
             if constexpr (LDS_XYZ) sxyz[k] = make_float4(px[i], py[i], pz[i], 0.f);
         } else {
@@ -149,7 +151,7 @@ __device__ __forceinline__ void fps_reg_body(int n, int m, const float* __restri
             const float4 p = sxyz[old];
             x1 = p.x; y1 = p.y; z1 = p.z;
         } else {
-            x1 = xyz[old * 3 + 0]; y1 = xyz[old * 3 + 1]; z1 = xyz[old * 3 + 2];
+            x1 = xyz[old * ld + 0]; y1 = xyz[old * ld + 1]; z1 = xyz[old * ld + 2];
             if (nxyz && tid == 0) { nxyz[(j - 1) * 3 + 0] = x1; nxyz[(j - 1) * 3 + 1] = y1; nxyz[(j - 1) * 3 + 2] = z1; }
         }
         if constexpr (TRACK) {
@@ -230,7 +232,7 @@ __device__ __forceinline__ void fps_reg_body(int n, int m, const float* __restri
             }
         }
     } else if (nxyz && tid == 0) {  // coordinates of the last pick
-        nxyz[(m - 1) * 3 + 0] = xyz[old * 3 + 0]; nxyz[(m - 1) * 3 + 1] = xyz[old * 3 + 1]; nxyz[(m - 1) * 3 + 2] = xyz[old * 3 + 2];
+        nxyz[(m - 1) * 3 + 0] = xyz[old * ld + 0]; nxyz[(m - 1) * 3 + 1] = xyz[old * ld + 1]; nxyz[(m - 1) * 3 + 2] = xyz[old * ld + 2];
     }
     if constexpr (TRACK) {  // (ties of the LAST pick are not looked at: a consumer asks for fewer picks than this level made)
         __syncthreads();

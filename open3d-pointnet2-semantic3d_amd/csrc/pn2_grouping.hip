@@ -519,7 +519,7 @@ __host__ __device__ inline size_t bqg_ws_stride(int n) {
 
 // bounding box -> grid -> LDS histogram (the atomic returns the rank inside the cell) -> prefix sum -> scatter.
 // All kBqgThreads threads of the workgroup; ends with a barrier.
-__device__ __forceinline__ void bqg_build(const BqgLds& L, int n, float radius, const float* __restrict__ xyz1) {
+__device__ __forceinline__ void bqg_build(const BqgLds& L, int n, float radius, const float* __restrict__ xyz1, int ld = 3) {
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -531,7 +531,7 @@ __device__ __forceinline__ void bqg_build(const BqgLds& L, int n, float radius, 
     for (int j = 0; j < kBqgPPT; ++j) {
         const int k = tid + kBqgThreads * j;
         const int kc = k < n ? k : n - 1;
-        px[j] = xyz1[kc * 3 + 0]; py[j] = xyz1[kc * 3 + 1]; pz[j] = xyz1[kc * 3 + 2];
+        px[j] = xyz1[kc * ld + 0]; py[j] = xyz1[kc * ld + 1]; pz[j] = xyz1[kc * ld + 2];
         mn[0] = fminf(mn[0], px[j]); mx[0] = fmaxf(mx[0], px[j]);
         mn[1] = fminf(mn[1], py[j]); mx[1] = fmaxf(mx[1], py[j]);
         mn[2] = fminf(mn[2], pz[j]); mx[2] = fmaxf(mx[2], pz[j]);
@@ -653,7 +653,7 @@ template <int MODE, bool PRE>
 __global__ void __launch_bounds__(kBqgThreads)
 ball_query_grid_kernel(int n, int m, float radius, float thr, int nsample, const float* __restrict__ xyz1_all,
                        const float* __restrict__ xyz2_all, int* __restrict__ idx_all, int* __restrict__ cnt_all,
-                       unsigned char* __restrict__ ws_all, size_t ws_stride) {
+                       unsigned char* __restrict__ ws_all, size_t ws_stride, int ld1) {
     extern __shared__ int smem_i[];
     const int np = (n + 63) & ~63;
     const BqgLds L = bqg_carve(smem_i, np);
@@ -685,7 +685,7 @@ ball_query_grid_kernel(int n, int m, float radius, float thr, int nsample, const
         bqg_copy<true>(L, np, ws_all + (size_t)bi * ws_stride);
         __syncthreads();
     } else {
-        bqg_build(L, n, radius, xyz1_all + (size_t)bi * n * 3);
+        bqg_build(L, n, radius, xyz1_all + (size_t)bi * n * ld1, ld1);  // (ld1: row stride of the cloud in floats, 3 = dense)
     }
     const BqgGrid G = *L.grid;
     // ---- queries: a wave answers 4 at a time, one per 16-lane group ------------------------------------------
@@ -808,7 +808,7 @@ ball_query_grid_kernel(int n, int m, float radius, float thr, int nsample, const
 
 template <int MODE>
 int launch_ball_query_grid(int b, int n, int m, float radius, float thr, int nsample, const float* xyz1,
-                           const float* xyz2, int* idx, int* cnt, hipStream_t st, unsigned char* bins = nullptr) {
+                           const float* xyz2, int* idx, int* cnt, hipStream_t st, unsigned char* bins = nullptr, int ld1 = 3) {
     const int np = (n + 63) & ~63;
     const size_t lds = bqg_lds_bytes(np);
     static bool attr_set = false;
@@ -822,8 +822,8 @@ int launch_ball_query_grid(int b, int n, int m, float radius, float thr, int nsa
         attr_set = true;
     }
     dim3 grid((m + kBqgWaves * kBqgQPW - 1) / (kBqgWaves * kBqgQPW), b);
-    if (bins) ball_query_grid_kernel<MODE, true><<<grid, kBqgThreads, lds, st>>>(n, m, radius, thr, nsample, xyz1, xyz2, idx, cnt, bins, bqg_ws_stride(n));
-    else ball_query_grid_kernel<MODE, false><<<grid, kBqgThreads, lds, st>>>(n, m, radius, thr, nsample, xyz1, xyz2, idx, cnt, nullptr, 0);
+    if (bins) ball_query_grid_kernel<MODE, true><<<grid, kBqgThreads, lds, st>>>(n, m, radius, thr, nsample, xyz1, xyz2, idx, cnt, bins, bqg_ws_stride(n), ld1);
+    else ball_query_grid_kernel<MODE, false><<<grid, kBqgThreads, lds, st>>>(n, m, radius, thr, nsample, xyz1, xyz2, idx, cnt, nullptr, 0, ld1);
     PN2_RETURN_IF_LAUNCH_FAILED();
     return PN2_OK;
 }
@@ -1025,6 +1025,26 @@ extern "C" int pn2_query_ball_point(int b, int n, int m, float radius, int nsamp
                                     const float* xyz1, const float* xyz2, int* idx, int* pts_cnt,
                                     int arith_mode, void* stream) {
     return query_ball_point_impl(b, n, m, radius, nsample, xyz1, xyz2, idx, pts_cnt, arith_mode, 0, stream);
+}
+
+// pn2_query_ball_point on a cloud whose rows are ld1 floats apart (the xyz columns of a (b,n,6) xyz+rgb batch read in place;
+// model.py:26-29).  Only the shapes the LDS-grid kernel takes (it reads the cloud once, into LDS); anything else: PN2_EUNSUP
+// and the caller queries a dense copy.  Bit-identical to pn2_query_ball_point on that copy.
+extern "C" int pn2_query_ball_point_ld(int b, int n, int m, float radius, int nsample, const float* xyz1, int ld1,
+                                       const float* xyz2, int* idx, int* pts_cnt, int arith_mode, void* stream) {
+    if (b <= 0 || n <= 0 || m <= 0 || nsample <= 0 || ld1 < 3) return PN2_EINVAL;
+    if (!(radius > 0.0f)) return PN2_EINVAL;
+    if (!xyz1 || !xyz2 || !idx || !pts_cnt) return PN2_ENULL;
+    if ((long long)n * ld1 > 0x7fffffffLL || (long long)m * 3 > 0x7fffffffLL || b > 65535) return PN2_ERANGE;
+    if (!(g_bq_variant == 0 && n <= kBqgMaxN && n >= 4096 && m >= 256 && nsample <= 64 && radius < 1e18f)) return PN2_EUNSUP;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    const float thr = ball_threshold(radius);
+    switch (arith_mode) {
+        case PN2_ARITH_STRICT: return launch_ball_query_grid<PN2_ARITH_STRICT>(b, n, m, radius, thr, nsample, xyz1, xyz2, idx, pts_cnt, st, nullptr, ld1);
+        case PN2_ARITH_FMA: return launch_ball_query_grid<PN2_ARITH_FMA>(b, n, m, radius, thr, nsample, xyz1, xyz2, idx, pts_cnt, st, nullptr, ld1);
+        case PN2_ARITH_FMA_ALT: return launch_ball_query_grid<PN2_ARITH_FMA_ALT>(b, n, m, radius, thr, nsample, xyz1, xyz2, idx, pts_cnt, st, nullptr, ld1);
+        default: return PN2_EINVAL;
+    }
 }
 
 // Bin a batch of clouds once for a radius (see BqgLds): workspace = b * pn2_ball_query_bin_bytes(n) bytes, 256-byte aligned.

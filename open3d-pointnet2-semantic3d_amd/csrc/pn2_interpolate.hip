@@ -23,15 +23,15 @@ PN2_TUNABLE(int, g_nn_blocks, 2048)  // target workgroups per launch (sweep: 163
 // query groups grp, grp + stride, ... (pn2nn::three_nn_wave); grid.y = batch.
 template <int kNnChunks>
 __global__ void __launch_bounds__(kNnThreads)
-three_nn_kernel(int n, int m, const float* __restrict__ xyz1_all,
+three_nn_kernel(int n, int m, const float* __restrict__ xyz1_all, int ld1,
                 const float* __restrict__ xyz2_all, float* __restrict__ dist_all,
                 int* __restrict__ idx_all) {
     __shared__ __attribute__((aligned(16))) unsigned char slds[kNnWaves * kNnWaveLdsBytes];
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int bi = blockIdx.y;
-    three_nn_wave<kNnChunks>(n, m, xyz1_all + (size_t)bi * n * 3, xyz2_all + (size_t)bi * m * 3, dist_all + (size_t)bi * n * 3,
+    three_nn_wave<kNnChunks>(n, m, xyz1_all + (size_t)bi * n * ld1, xyz2_all + (size_t)bi * m * 3, dist_all + (size_t)bi * n * 3,
                              idx_all + (size_t)bi * n * 3, blockIdx.x * kNnWaves + wave, gridDim.x * kNnWaves,
-                             nn_wave_lds(slds, wave));
+                             nn_wave_lds(slds, wave), ld1);
 }
 
 // out[row, :] = (p1*w1 + p2*w2) + p3*w3, unfused fp32 (tf_interpolate.cpp:322-324).
@@ -444,22 +444,29 @@ inline int grid_x_for(unsigned long long total, int block, int batches) {
 extern "C" int pn2_debug_set_interp(int what, int value) { if (what == 12) { g_nn_blocks = value; return 0; } return -1; }
 #endif
 
-extern "C" int pn2_three_nn(int b, int n, int m, const float* xyz1, const float* xyz2, float* dist,
-                            int* idx, void* stream) {
-    if (b <= 0 || n <= 0 || m < 3) return PN2_EINVAL;
+// pn2_three_nn with query rows ld1 floats apart (ld1 >= 3: the xyz columns of a (b,n,6) xyz+rgb batch read in place,
+// model.py:26-29); bit-identical to pn2_three_nn on a dense copy.
+extern "C" int pn2_three_nn_ld(int b, int n, int m, const float* xyz1, int ld1, const float* xyz2, float* dist,
+                               int* idx, void* stream) {
+    if (b <= 0 || n <= 0 || m < 3 || ld1 < 3) return PN2_EINVAL;
     if (!xyz1 || !xyz2 || !dist || !idx) return PN2_ENULL;
-    if ((long long)n * 3 > 0x7fffffffLL || (long long)m * 3 > 0x7fffffffLL || b > 65535) return PN2_ERANGE;
+    if ((long long)n * ld1 > 0x7fffffffLL || (long long)m * 3 > 0x7fffffffLL || b > 65535) return PN2_ERANGE;
     // persistent waves: ~4 workgroups per CU over the whole batch, every wave takes the same number of query groups
     const int blocks_all = (n + kNnWaves * kNnQ - 1) / (kNnWaves * kNnQ);
     int per = (b * blocks_all + g_nn_blocks - 1) / g_nn_blocks;        // groups per wave
     if (per < 1) per = 1;
     dim3 grid((blocks_all + per - 1) / per, b);
     hipStream_t st = static_cast<hipStream_t>(stream);
-    if (m <= 64) three_nn_kernel<1><<<grid, kNnThreads, 0, st>>>(n, m, xyz1, xyz2, dist, idx);
-    else if (m <= 256) three_nn_kernel<4><<<grid, kNnThreads, 0, st>>>(n, m, xyz1, xyz2, dist, idx);
-    else three_nn_kernel<16><<<grid, kNnThreads, 0, st>>>(n, m, xyz1, xyz2, dist, idx);
+    if (m <= 64) three_nn_kernel<1><<<grid, kNnThreads, 0, st>>>(n, m, xyz1, ld1, xyz2, dist, idx);
+    else if (m <= 256) three_nn_kernel<4><<<grid, kNnThreads, 0, st>>>(n, m, xyz1, ld1, xyz2, dist, idx);
+    else three_nn_kernel<16><<<grid, kNnThreads, 0, st>>>(n, m, xyz1, ld1, xyz2, dist, idx);
     PN2_RETURN_IF_LAUNCH_FAILED();
     return PN2_OK;
+}
+
+extern "C" int pn2_three_nn(int b, int n, int m, const float* xyz1, const float* xyz2, float* dist,
+                            int* idx, void* stream) {
+    return pn2_three_nn_ld(b, n, m, xyz1, 3, xyz2, dist, idx, stream);
 }
 
 extern "C" int pn2_three_interpolate(int b, int m, int c, int n, const float* points, const int* idx,

@@ -43,6 +43,9 @@ struct SaFusedParams {
     const float* dist;     // INTERP mode: three_nn distances (rows, 3); idx is then (rows, 3)
     const float* points1;  // INTERP mode: skip-link features (rows, c1) or nullptr
     int c1;
+    // row strides in floats, 0 = dense (3 / c / c1): the xyz and rgb columns of a (b,n,6) batch read in place (model.py:26-29).
+    // ldp applies to the un-vectorised feature path only (c % 8 != 0); launch_chain fills the zeros in.
+    int ldx, ldp, ld1;
     const float* W[3];
     const float* bias[3];
     float* out;
@@ -437,9 +440,9 @@ sa_fused_kernel(SaFusedParams p) {
             const float cxv = p.new_xyz[(size_t)grp * 3 + 0];
             const float cyv = p.new_xyz[(size_t)grp * 3 + 1];
             const float czv = p.new_xyz[(size_t)grp * 3 + 2];
-            const float rx = p.xyz[prow * 3 + 0] - cxv;  // grouped_xyz -= tile(new_xyz) :44-46
-            const float ry = p.xyz[prow * 3 + 1] - cyv;
-            const float rz = p.xyz[prow * 3 + 2] - czv;
+            const float rx = p.xyz[prow * p.ldx + 0] - cxv;  // grouped_xyz -= tile(new_xyz) :44-46
+            const float ry = p.xyz[prow * p.ldx + 1] - cyv;
+            const float rz = p.xyz[prow * p.ldx + 2] - czv;
             mfma_step<NT1, LAST1>(a1, w1l + 0 * 2 * W1, half ? ry : rx);
             mfma_step<NT1, LAST1>(a1, w1l + 1 * 2 * W1, half ? 0.f : rz);
         }
@@ -457,7 +460,7 @@ sa_fused_kernel(SaFusedParams p) {
                 const f32x4* __restrict__ z2 = reinterpret_cast<const f32x4*>(p.points + (kb + ir[1]) * W1) + half;
                 const f32x4* __restrict__ z3 = reinterpret_cast<const f32x4*>(p.points + (kb + ir[2]) * W1) + half;
                 if (c1 > 0) {  // skip-link channels: the only MFMA work left in layer 1
-                    const float* __restrict__ fp = p.points1 + prow * c1;
+                    const float* __restrict__ fp = p.points1 + prow * p.ld1;
                     const int ns = (c1 + 1) >> 1;
                     for (int sp = 0; sp < ns; ++sp) {
                         const int ch = 2 * sp + half;
@@ -505,7 +508,7 @@ sa_fused_kernel(SaFusedParams p) {
                 c1v = n1; c2v = n2; c3v = n3;
             }
             if (c1 > 0) {
-                const float* __restrict__ fp = p.points1 + prow * c1;
+                const float* __restrict__ fp = p.points1 + prow * p.ld1;
                 const int ns = (c1 + 1) >> 1;
                 for (int sp = 0; sp < ns; ++sp) {
                     const int ch = 2 * sp + half;
@@ -551,7 +554,7 @@ sa_fused_kernel(SaFusedParams p) {
                 cur = nxt;
             }
         } else {
-            const float* __restrict__ fp = p.points + prow * c;
+            const float* __restrict__ fp = p.points + prow * p.ldp;
             const int ns = (c + 1) >> 1;
             for (int sp = 0; sp < ns; ++sp) {
                 const int ch = 2 * sp + half;
@@ -693,7 +696,7 @@ fp_chain_pipe_kernel(SaFusedParams p) {
 #pragma unroll
         for (int sp = 0; sp < NS; ++sp) {
             const int ch = 2 * sp + half;
-            fsk[sp] = ch < c1 ? p.points1[frow * c1 + ch] : 0.f;
+            fsk[sp] = ch < c1 ? p.points1[frow * p.ld1 + ch] : 0.f;
         }
     };
     auto front_weights = [&]() {  // inverse-distance weights exactly as fp_interp_concat_kernel (IEEE divisions)
@@ -904,6 +907,9 @@ template <int L, int NT1, int NT2, int NT3, bool VEC8, bool DENSE, bool POOL, bo
 int launch_chain(const SaFusedParams& p_in, hipStream_t st) {
     SaFusedParams p = p_in;
     p.prio = g_chain_prio;
+    if (!p.ldx) p.ldx = 3;
+    if (!p.ldp) p.ldp = p.c;
+    if (!p.ld1) p.ld1 = p.c1;
 #ifdef PN2_TUNING_HOOKS
     p.stats = g_chain_stats;
 #endif
@@ -1025,13 +1031,24 @@ extern "C" int pn2_debug_set_fused(int what, int value) {
 static int sa_fused_impl(int b, int n, int m, int nsample, int c, const float* xyz,
                          const float* new_xyz, const float* points, const int* idx,
                          int nlayers, const int* widths, const float* const* w,
-                         const float* const* bias, float* out, bool pool, void* stream);
+                         const float* const* bias, float* out, bool pool, void* stream, int ld_xyz, int ld_points);
 
 extern "C" int pn2_sa_mlp_max_fused(int b, int n, int m, int nsample, int c, const float* xyz,
                                     const float* new_xyz, const float* points, const int* idx,
                                     int nlayers, const int* widths, const float* const* w,
                                     const float* const* bias, float* out, void* stream) {
-    return sa_fused_impl(b, n, m, nsample, c, xyz, new_xyz, points, idx, nlayers, widths, w, bias, out, true, stream);
+    return sa_fused_impl(b, n, m, nsample, c, xyz, new_xyz, points, idx, nlayers, widths, w, bias, out, true, stream, 3, c);
+}
+
+// pn2_sa_mlp_max_fused with the rows of xyz / points ld_xyz / ld_points floats apart (>= 3 / >= c): the xyz and rgb columns
+// of a (b,n,6) batch gathered in place (model.py:26-29 slices them out of the input tensor; here no copy is made).
+// ld_points != c needs the un-vectorised feature path (c % 8 != 0): PN2_EUNSUP otherwise.  Same bits as the dense call.
+extern "C" int pn2_sa_mlp_max_fused_ld(int b, int n, int m, int nsample, int c, const float* xyz, int ld_xyz,
+                                       const float* new_xyz, const float* points, int ld_points, const int* idx,
+                                       int nlayers, const int* widths, const float* const* w,
+                                       const float* const* bias, float* out, void* stream) {
+    return sa_fused_impl(b, n, m, nsample, c, xyz, new_xyz, points, idx, nlayers, widths, w, bias, out, true, stream, ld_xyz,
+                         c > 0 ? ld_points : 0);
 }
 
 // Same gather + MLP chain WITHOUT the max over the neighbours: out is (b, m, nsample, widths[last])
@@ -1041,13 +1058,13 @@ extern "C" int pn2_sa_mlp_rows_fused(int b, int n, int m, int nsample, int c, co
                                      const float* new_xyz, const float* points, const int* idx,
                                      int nlayers, const int* widths, const float* const* w,
                                      const float* const* bias, float* out, void* stream) {
-    return sa_fused_impl(b, n, m, nsample, c, xyz, new_xyz, points, idx, nlayers, widths, w, bias, out, false, stream);
+    return sa_fused_impl(b, n, m, nsample, c, xyz, new_xyz, points, idx, nlayers, widths, w, bias, out, false, stream, 3, c);
 }
 
 static int sa_fused_impl(int b, int n, int m, int nsample, int c, const float* xyz,
                          const float* new_xyz, const float* points, const int* idx,
                          int nlayers, const int* widths, const float* const* w,
-                         const float* const* bias, float* out, bool pool, void* stream) {
+                         const float* const* bias, float* out, bool pool, void* stream, int ld_xyz, int ld_points) {
     if (b <= 0 || n <= 0 || m <= 0 || nsample <= 0 || c < 0 || nlayers <= 0) return PN2_EINVAL;
     if (!xyz || !new_xyz || !idx || !widths || !w || !bias || !out || (c > 0 && !points)) return PN2_ENULL;
     if (nlayers > 3) return PN2_EUNSUP;
@@ -1072,6 +1089,9 @@ static int sa_fused_impl(int b, int n, int m, int nsample, int c, const float* x
         nt[l] = widths[l] / 32;
     }
     const bool vec8 = c > 0 && (c % 8 == 0) && ((uintptr_t)points % 16 == 0);
+    if (ld_xyz < 3 || (c > 0 && ld_points < c)) return PN2_EINVAL;
+    if (vec8 && ld_points != c) return PN2_EUNSUP;  // the 16-byte feature gathers read dense rows
+    p.ldx = ld_xyz; p.ldp = ld_points;
     hipStream_t st = static_cast<hipStream_t>(stream);
     if (kshift > 5) {  // tiles of one centre merge through atomicMax: start from +0
         hipError_t e = hipMemsetAsync(out, 0, sizeof(float) * (size_t)b * m * widths[nlayers - 1], st);
@@ -1196,12 +1216,20 @@ extern "C" int pn2_fp_mlp_fused(int b, int n, int m, int c1, int c2, const float
 // rounding only (1e-7 of the activation scale; tests/test_layers_gpu.py holds both to the fp64 oracle at 1e-5).
 static int fp_mlp_fused_pre_impl(int b, int n, int m, int c1, const float* dist, const int* idx, const float* points1,
                                  const float* z, int nlayers, const int* widths, const float* const* w,
-                                 const float* const* bias, float* y, int schedule, void* stream);
+                                 const float* const* bias, float* y, int schedule, void* stream, int ld_points1 = 0);
 
 extern "C" int pn2_fp_mlp_fused_pre(int b, int n, int m, int c1, const float* dist, const int* idx, const float* points1,
                                     const float* z, int nlayers, const int* widths, const float* const* w,
                                     const float* const* bias, float* y, void* stream) {
     return fp_mlp_fused_pre_impl(b, n, m, c1, dist, idx, points1, z, nlayers, widths, w, bias, y, -1, stream);
+}
+
+// pn2_fp_mlp_fused_pre with the skip-link rows ld_points1 floats apart (>= c1): the rgb columns of a (b,n,6) batch read in
+// place (model.py:26-29, 121-129).  Same bits as the dense call.
+extern "C" int pn2_fp_mlp_fused_pre_ld(int b, int n, int m, int c1, const float* dist, const int* idx, const float* points1,
+                                       int ld_points1, const float* z, int nlayers, const int* widths, const float* const* w,
+                                       const float* const* bias, float* y, void* stream) {
+    return fp_mlp_fused_pre_impl(b, n, m, c1, dist, idx, points1, z, nlayers, widths, w, bias, y, -1, stream, ld_points1);
 }
 
 // The same call with the kernel SCHEDULE named by the caller (stateless door for the parity tests and A/B timing):
@@ -1218,7 +1246,8 @@ extern "C" int pn2_fp_mlp_fused_pre_schedule(int b, int n, int m, int c1, const 
 
 static int fp_mlp_fused_pre_impl(int b, int n, int m, int c1, const float* dist, const int* idx, const float* points1,
                                  const float* z, int nlayers, const int* widths, const float* const* w,
-                                 const float* const* bias, float* y, int schedule, void* stream) {
+                                 const float* const* bias, float* y, int schedule, void* stream, int ld_points1) {
+    if (ld_points1 != 0 && ld_points1 < c1) return PN2_EINVAL;
     if (b <= 0 || n <= 0 || m <= 0 || c1 < 0 || nlayers <= 0) return PN2_EINVAL;
     if (!dist || !idx || !z || !widths || !w || !bias || !y || (c1 > 0 && (!points1 || !w[0]))) return PN2_ENULL;
     if ((long long)b * n > 0x7fffffffLL - 32) return PN2_ERANGE;
@@ -1226,7 +1255,7 @@ static int fp_mlp_fused_pre_impl(int b, int n, int m, int c1, const float* dist,
     SaFusedParams p{};
     p.schedule = schedule;
     p.n = n; p.m = m; p.c = widths[0]; p.c1 = c1; p.rows = b * n; p.groups = (b * n + 31) / 32;
-    p.points = z; p.points1 = points1; p.dist = dist; p.idx = idx; p.out = y;
+    p.points = z; p.points1 = points1; p.dist = dist; p.idx = idx; p.out = y; p.ld1 = ld_points1;
     int nt[3] = {0, 0, 0};
     for (int l = 0; l < nlayers; ++l) {
         if (widths[l] <= 0 || widths[l] % 32 != 0 || widths[l] > 128) return PN2_EUNSUP;

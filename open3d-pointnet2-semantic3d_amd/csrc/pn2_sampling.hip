@@ -90,14 +90,14 @@ __device__ __forceinline__ float wave_fmax_all(float v) {
 // fps_reg_kernel: pn2fpsreg::fps_reg_body on cloud blockIdx.x, after the nested-sampling shortcut
 template <int NT, int PPT, int MODE, bool LDS_XYZ, bool TRACK>
 __global__ void __launch_bounds__(NT)
-fps_reg_kernel(int n, int m, const float* __restrict__ xyz_all, int* __restrict__ out_all,
+fps_reg_kernel(int n, int m, const float* __restrict__ xyz_all, int ld, int* __restrict__ out_all,
                float* __restrict__ new_xyz_all, const int* __restrict__ tie_in, int* __restrict__ tie_out) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    const float* __restrict__ xyz = xyz_all + (size_t)blockIdx.x * n * 3;
+    const float* __restrict__ xyz = xyz_all + (size_t)blockIdx.x * n * ld;
     int* __restrict__ out = out_all + (size_t)blockIdx.x * m;
     float* __restrict__ nxyz = new_xyz_all ? new_xyz_all + (size_t)blockIdx.x * m * 3 : nullptr;
-    if (fps_nested_shortcut(n, m, xyz, out, nxyz, tie_in, tie_out, NT)) return;
-    fps_reg_body<NT, PPT, MODE, LDS_XYZ, TRACK>(n, m, xyz, out, nxyz, tie_out ? tie_out + blockIdx.x : nullptr, smem);
+    if (fps_nested_shortcut(n, m, xyz, out, nxyz, tie_in, tie_out, NT, ld)) return;
+    fps_reg_body<NT, PPT, MODE, LDS_XYZ, TRACK>(n, m, xyz, out, nxyz, tie_out ? tie_out + blockIdx.x : nullptr, smem, ld);
 }
 
 PN2_TUNABLE(int, g_fps_variant, 0)  // tuning hook (pn2_debug_set(0, v)), see dispatch_fps
@@ -166,7 +166,7 @@ inline size_t fps_lazy_bytes(int n, int m) {
 // waves -- worker wi (wave-uniform, -1 for a wave that owns no rows) holds bucket q = i * NWK + wi in register row i -- with
 // the exact box of the lane's own row (lane l: row l / (64 / PPT)).  Leaves hist / perm dead (the caller may alias them).
 template <int NT, int LPT, int PPT, int NWK>
-__device__ __forceinline__ void fps_lazy_setup(int n, int wi, const float* __restrict__ xyz, float4* sxyz, int* hist, float* bbw, int* wsum,
+__device__ __forceinline__ void fps_lazy_setup(int n, int wi, const float* __restrict__ xyz, int ld, float4* sxyz, int* hist, float* bbw, int* wsum,
                                                float (&px)[PPT], float (&py)[PPT], float (&pz)[PPT], double (&mk)[PPT],
                                                float& bx0, float& by0, float& bz0, float& bx1, float& by1, float& bz1) {
     constexpr int NW = NT / 64;
@@ -182,7 +182,7 @@ __device__ __forceinline__ void fps_lazy_setup(int n, int wi, const float* __res
         const int k = tid + NT * i;
         lx[i] = ly[i] = lz[i] = 0.f;
         if (k < n) {
-            lx[i] = xyz[k * 3 + 0]; ly[i] = xyz[k * 3 + 1]; lz[i] = xyz[k * 3 + 2];
+            lx[i] = xyz[k * ld + 0]; ly[i] = xyz[k * ld + 1]; lz[i] = xyz[k * ld + 2];
             sxyz[k] = make_float4(lx[i], ly[i], lz[i], 0.f);
             lo[0] = fminf(lo[0], lx[i]); hi[0] = fmaxf(hi[0], lx[i]);
             lo[1] = fminf(lo[1], ly[i]); hi[1] = fmaxf(hi[1], ly[i]);
@@ -289,7 +289,7 @@ __device__ __forceinline__ void fps_lazy_setup(int n, int wi, const float* __res
 
 template <int NT, int PPT, int MODE, bool TRACK>
 __global__ void __launch_bounds__(NT)
-fps_lazy_kernel(int n, int m, const float* __restrict__ xyz_all, int* __restrict__ out_all,
+fps_lazy_kernel(int n, int m, const float* __restrict__ xyz_all, int ld, int* __restrict__ out_all,
                 float* __restrict__ new_xyz_all, long long* __restrict__ stats, const int* __restrict__ tie_in,
                 int* __restrict__ tie_out) {
     constexpr int NW = NT / 64;
@@ -307,10 +307,10 @@ fps_lazy_kernel(int n, int m, const float* __restrict__ xyz_all, int* __restrict
     int* spick = hist;
 
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const float* __restrict__ xyz = xyz_all + (size_t)blockIdx.x * n * 3;
+    const float* __restrict__ xyz = xyz_all + (size_t)blockIdx.x * n * ld;
     int* __restrict__ out = out_all + (size_t)blockIdx.x * m;
     float* __restrict__ nxyz = new_xyz_all ? new_xyz_all + (size_t)blockIdx.x * m * 3 : nullptr;
-    if (fps_nested_shortcut(n, m, xyz, out, nxyz, tie_in, tie_out, NT)) return;
+    if (fps_nested_shortcut(n, m, xyz, out, nxyz, tie_in, tie_out, NT, ld)) return;
     constexpr bool track = TRACK;
     int* ttl = ctrl + 8;                          // pn2fps::tie_* record {strict, benign, zero}, written by wave 0
     int* wtie = reinterpret_cast<int*>(bbw);      // per-wave tie class of the one-pick fallback (bbw is dead after the set-up)
@@ -319,7 +319,7 @@ fps_lazy_kernel(int n, int m, const float* __restrict__ xyz_all, int* __restrict
     double mk[PPT];
     float bx0, by0, bz0, bx1, by1, bz1;
     constexpr int PP = 64 / PPT;
-    fps_lazy_setup<NT, PPT, PPT, NW>(n, wave, xyz, sxyz, hist, bbw, wsum, px, py, pz, mk, bx0, by0, bz0, bx1, by1, bz1);
+    fps_lazy_setup<NT, PPT, PPT, NW>(n, wave, xyz, ld, sxyz, hist, bbw, wsum, px, py, pz, mk, bx0, by0, bz0, bx1, by1, bz1);
     if (tid == 0) {
         spick[0] = 0;  // first pick is index 0 (tf_sampling.cu:122-123)
         pend[0] = sxyz[0];
@@ -496,7 +496,7 @@ fps_lazy_kernel(int n, int m, const float* __restrict__ xyz_all, int* __restrict
 }
 
 template <int NT, int PPT, int MODE>
-int launch_fps_lazy(int b, int n, int m, const float* inp, int* out, float* nxyz, const int* tie_in, int* tie_out, hipStream_t st) {
+int launch_fps_lazy(int b, int n, int m, const float* inp, int ld, int* out, float* nxyz, const int* tie_in, int* tie_out, hipStream_t st) {
     const size_t bytes = fps_lazy_bytes(n, m);
     auto kern = tie_out ? fps_lazy_kernel<NT, PPT, MODE, true> : fps_lazy_kernel<NT, PPT, MODE, false>;
     static bool attr_set[2] = {false, false};  // per instantiation; benign race (idempotent call)
@@ -505,7 +505,7 @@ int launch_fps_lazy(int b, int n, int m, const float* inp, int* out, float* nxyz
         if (e != hipSuccess) return (int)e;
         attr_set[tie_out != nullptr] = true;
     }
-    kern<<<b, NT, bytes, st>>>(n, m, inp, out, nxyz, g_fps_stats, tie_in, tie_out);
+    kern<<<b, NT, bytes, st>>>(n, m, inp, ld, out, nxyz, g_fps_stats, tie_in, tie_out);
     PN2_RETURN_IF_LAUNCH_FAILED();
     return PN2_OK;
 }
@@ -553,7 +553,7 @@ fps_stream_kernel(int b, int n, int m, const float* __restrict__ xyz_all,
 }
 
 template <int NT, int PPT, int MODE>
-int launch_fps_reg(int b, int n, int m, const float* inp, int* out, float* nxyz, const int* tie_in, int* tie_out, hipStream_t st) {
+int launch_fps_reg(int b, int n, int m, const float* inp, int ld, int* out, float* nxyz, const int* tie_in, int* tie_out, hipStream_t st) {
     const size_t slots_bytes = kFpsRegHead;
     const size_t xyz_bytes = (size_t)n * sizeof(float4);
     // 160 KiB LDS per CU; keep the cloud (and the pick list) in LDS when they fit (n <= 8192 -> 128 KiB + 4m)
@@ -567,10 +567,10 @@ int launch_fps_reg(int b, int n, int m, const float* inp, int* out, float* nxyz,
             if (e != hipSuccess) return (int)e;
             attr_bytes[tie_out != nullptr] = 160 * 1024;
         }
-        kern<<<b, NT, slots_bytes + xyz_bytes + pick_bytes, st>>>(n, m, inp, out, nxyz, tie_in, tie_out);
+        kern<<<b, NT, slots_bytes + xyz_bytes + pick_bytes, st>>>(n, m, inp, ld, out, nxyz, tie_in, tie_out);
     } else if constexpr (NT != 64) {
         auto kern = tie_out ? fps_reg_kernel<NT, PPT, MODE, false, true> : fps_reg_kernel<NT, PPT, MODE, false, false>;
-        kern<<<b, NT, slots_bytes, st>>>(n, m, inp, out, nxyz, tie_in, tie_out);
+        kern<<<b, NT, slots_bytes, st>>>(n, m, inp, ld, out, nxyz, tie_in, tie_out);
     } else {
         return PN2_ERANGE;  // unreachable: a single-wave cloud (n <= 256) always fits LDS unless m is absurd
     }
@@ -579,7 +579,7 @@ int launch_fps_reg(int b, int n, int m, const float* inp, int* out, float* nxyz,
 }
 
 template <int MODE>
-int dispatch_fps(int b, int n, int m, const float* inp, float* temp, int* out, float* nxyz, const int* tie_in, int* tie_out,
+int dispatch_fps(int b, int n, int m, const float* inp, int ld, float* temp, int* out, float* nxyz, const int* tie_in, int* tie_out,
                  hipStream_t st) {
     // Any (threads, points per thread) layout is exact (every point carries its own tie-break key); the choice is
     // latency only.  A round's sync skeleton costs ~40 ns for one wave (no barrier, no LDS atomic), ~130 ns for 4
@@ -591,29 +591,30 @@ int dispatch_fps(int b, int n, int m, const float* inp, float* temp, int* out, f
     // round of the one-pick kernels below costs (93 vs 84 us at n = 1024), so those keep the small levels.
     // g_fps_variant (tuning builds): 2 = one-pick kernels everywhere, 3 = lazy kernel from n > 512.
     if (g_fps_variant != 2 && n > (g_fps_variant == 3 ? 512 : 2048) && n <= 8192 && fps_lazy_bytes(n, m) <= 160 * 1024) {
-        if (n <= 1024) return launch_fps_lazy<256, 4, MODE>(b, n, m, inp, out, nxyz, tie_in, tie_out, st);
-        if (n <= 2048) return launch_fps_lazy<512, 4, MODE>(b, n, m, inp, out, nxyz, tie_in, tie_out, st);
-        if (n <= 4096) return launch_fps_lazy<1024, 4, MODE>(b, n, m, inp, out, nxyz, tie_in, tie_out, st);
-        return launch_fps_lazy<1024, 8, MODE>(b, n, m, inp, out, nxyz, tie_in, tie_out, st);
+        if (n <= 1024) return launch_fps_lazy<256, 4, MODE>(b, n, m, inp, ld, out, nxyz, tie_in, tie_out, st);
+        if (n <= 2048) return launch_fps_lazy<512, 4, MODE>(b, n, m, inp, ld, out, nxyz, tie_in, tie_out, st);
+        if (n <= 4096) return launch_fps_lazy<1024, 4, MODE>(b, n, m, inp, ld, out, nxyz, tie_in, tie_out, st);
+        return launch_fps_lazy<1024, 8, MODE>(b, n, m, inp, ld, out, nxyz, tie_in, tie_out, st);
     }
     if (g_fps_variant == 1) {  // A/B hook: one point per thread up to 1024 threads (the round-1 layout)
-        if (n <= 64) return launch_fps_reg<64, 1, MODE>(b, n, m, inp, out, nxyz, tie_in, tie_out, st);
-        if (n <= 128) return launch_fps_reg<128, 1, MODE>(b, n, m, inp, out, nxyz, tie_in, tie_out, st);
-        if (n <= 256) return launch_fps_reg<256, 1, MODE>(b, n, m, inp, out, nxyz, tie_in, tie_out, st);
-        if (n <= 512) return launch_fps_reg<512, 1, MODE>(b, n, m, inp, out, nxyz, tie_in, tie_out, st);
-        if (n <= 1024) return launch_fps_reg<1024, 1, MODE>(b, n, m, inp, out, nxyz, tie_in, tie_out, st);
+        if (n <= 64) return launch_fps_reg<64, 1, MODE>(b, n, m, inp, ld, out, nxyz, tie_in, tie_out, st);
+        if (n <= 128) return launch_fps_reg<128, 1, MODE>(b, n, m, inp, ld, out, nxyz, tie_in, tie_out, st);
+        if (n <= 256) return launch_fps_reg<256, 1, MODE>(b, n, m, inp, ld, out, nxyz, tie_in, tie_out, st);
+        if (n <= 512) return launch_fps_reg<512, 1, MODE>(b, n, m, inp, ld, out, nxyz, tie_in, tie_out, st);
+        if (n <= 1024) return launch_fps_reg<1024, 1, MODE>(b, n, m, inp, ld, out, nxyz, tie_in, tie_out, st);
     } else {
-        if (n <= 64) return launch_fps_reg<64, 1, MODE>(b, n, m, inp, out, nxyz, tie_in, tie_out, st);
-        if (n <= 128) return launch_fps_reg<64, 2, MODE>(b, n, m, inp, out, nxyz, tie_in, tie_out, st);
-        if (n <= 256) return launch_fps_reg<64, 4, MODE>(b, n, m, inp, out, nxyz, tie_in, tie_out, st);
-        if (n <= 512) return launch_fps_reg<256, 2, MODE>(b, n, m, inp, out, nxyz, tie_in, tie_out, st);
-        if (n <= 1024) return launch_fps_reg<512, 2, MODE>(b, n, m, inp, out, nxyz, tie_in, tie_out, st);
-        if (n <= 2048) return launch_fps_reg<512, 4, MODE>(b, n, m, inp, out, nxyz, tie_in, tie_out, st);
+        if (n <= 64) return launch_fps_reg<64, 1, MODE>(b, n, m, inp, ld, out, nxyz, tie_in, tie_out, st);
+        if (n <= 128) return launch_fps_reg<64, 2, MODE>(b, n, m, inp, ld, out, nxyz, tie_in, tie_out, st);
+        if (n <= 256) return launch_fps_reg<64, 4, MODE>(b, n, m, inp, ld, out, nxyz, tie_in, tie_out, st);
+        if (n <= 512) return launch_fps_reg<256, 2, MODE>(b, n, m, inp, ld, out, nxyz, tie_in, tie_out, st);
+        if (n <= 1024) return launch_fps_reg<512, 2, MODE>(b, n, m, inp, ld, out, nxyz, tie_in, tie_out, st);
+        if (n <= 2048) return launch_fps_reg<512, 4, MODE>(b, n, m, inp, ld, out, nxyz, tie_in, tie_out, st);
     }
-    if (n <= 2048) return launch_fps_reg<1024, 2, MODE>(b, n, m, inp, out, nxyz, tie_in, tie_out, st);
-    if (n <= 4096) return launch_fps_reg<1024, 4, MODE>(b, n, m, inp, out, nxyz, tie_in, tie_out, st);
-    if (n <= 8192) return launch_fps_reg<1024, 8, MODE>(b, n, m, inp, out, nxyz, tie_in, tie_out, st);
-    if (n <= 16384) return launch_fps_reg<1024, 16, MODE>(b, n, m, inp, out, nxyz, tie_in, tie_out, st);
+    if (n <= 2048) return launch_fps_reg<1024, 2, MODE>(b, n, m, inp, ld, out, nxyz, tie_in, tie_out, st);
+    if (n <= 4096) return launch_fps_reg<1024, 4, MODE>(b, n, m, inp, ld, out, nxyz, tie_in, tie_out, st);
+    if (n <= 8192) return launch_fps_reg<1024, 8, MODE>(b, n, m, inp, ld, out, nxyz, tie_in, tie_out, st);
+    if (n <= 16384) return launch_fps_reg<1024, 16, MODE>(b, n, m, inp, ld, out, nxyz, tie_in, tie_out, st);
+    if (ld != 3) return PN2_EUNSUP;  // the streaming kernel reads dense rows
     if (!temp) return PN2_ENULL;
     const int grid = b < 32 ? b : 32;
     if (tie_out) {  // the streaming kernel keeps no tie record: "tied at step 0" = the next level always samples for real
@@ -781,15 +782,15 @@ extern "C" int pn2_debug_set(int what, int value) {
 #endif  // PN2_TUNING_HOOKS
 
 static int fps_entry(int b, int n, int m, const float* inp, float* temp, int* out, float* nxyz,
-                     int arith_mode, void* stream, const int* tie_in = nullptr, int* tie_out = nullptr) {
-    if (b <= 0 || n <= 0 || m <= 0) return PN2_EINVAL;
+                     int arith_mode, void* stream, const int* tie_in = nullptr, int* tie_out = nullptr, int ld = 3) {
+    if (b <= 0 || n <= 0 || m <= 0 || ld < 3) return PN2_EINVAL;
     if (!inp || !out) return PN2_ENULL;
-    if ((long long)n * 3 > 0x7fffffffLL) return PN2_ERANGE;
+    if ((long long)n * ld > 0x7fffffffLL) return PN2_ERANGE;
     hipStream_t st = static_cast<hipStream_t>(stream);
     switch (arith_mode) {
-        case PN2_ARITH_STRICT: return dispatch_fps<PN2_ARITH_STRICT>(b, n, m, inp, temp, out, nxyz, tie_in, tie_out, st);
-        case PN2_ARITH_FMA: return dispatch_fps<PN2_ARITH_FMA>(b, n, m, inp, temp, out, nxyz, tie_in, tie_out, st);
-        case PN2_ARITH_FMA_ALT: return dispatch_fps<PN2_ARITH_FMA_ALT>(b, n, m, inp, temp, out, nxyz, tie_in, tie_out, st);
+        case PN2_ARITH_STRICT: return dispatch_fps<PN2_ARITH_STRICT>(b, n, m, inp, ld, temp, out, nxyz, tie_in, tie_out, st);
+        case PN2_ARITH_FMA: return dispatch_fps<PN2_ARITH_FMA>(b, n, m, inp, ld, temp, out, nxyz, tie_in, tie_out, st);
+        case PN2_ARITH_FMA_ALT: return dispatch_fps<PN2_ARITH_FMA_ALT>(b, n, m, inp, ld, temp, out, nxyz, tie_in, tie_out, st);
         default: return PN2_EINVAL;
     }
 }
@@ -825,6 +826,19 @@ extern "C" int pn2_fps_nested(int b, int n, int m, const float* inp, float* temp
     if (rc == PN2_OK && tie_out && n == 1 && m > 1) {
         // a one-point cloud repeats its point from step 1 on: the maximum is 0 there (a strict step by definition) but there is
         // no SECOND holder for the kernels' tie branches to see
+        hipError_t e = hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(tie_out), 1, (size_t)b, static_cast<hipStream_t>(stream));
+        if (e != hipSuccess) return (int)e;
+    }
+    return rc;
+}
+
+// pn2_fps_nested on a cloud whose rows are `ld` floats apart (ld >= 3; the xyz columns of a (b,n,6) xyz+rgb batch read in
+// place: model.py:26-29 slices them out of the input tensor).  n <= 16384 (the register-resident kernels); beyond: PN2_EUNSUP.
+extern "C" int pn2_fps_nested_ld(int b, int n, int m, const float* inp, int ld, int* out, float* new_xyz,
+                                 const int* tie_in, int* tie_out, int arith_mode, void* stream) {
+    if (n > 16384) return PN2_EUNSUP;
+    const int rc = fps_entry(b, n, m, inp, nullptr, out, new_xyz, arith_mode, stream, tie_in, tie_out, ld);
+    if (rc == PN2_OK && tie_out && n == 1 && m > 1) {
         hipError_t e = hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(tie_out), 1, (size_t)b, static_cast<hipStream_t>(stream));
         if (e != hipSuccess) return (int)e;
     }

@@ -113,7 +113,7 @@ __device__ __forceinline__ NnWaveLds nn_wave_lds(unsigned char* base, int w) {
 template <int kNnChunks>
 __device__ __forceinline__ void three_nn_wave(int n, int m, const float* __restrict__ xyz1, const float* __restrict__ xyz2,
                                               float* __restrict__ dist_all, int* __restrict__ idx_all, int grp, int gstride,
-                                              const NnWaveLds& S) {
+                                              const NnWaveLds& S, int ld1 = 3) {  // ld1: row stride of the queries in floats
     const int lane = threadIdx.x & 63;
     // PERSISTENT waves (r03): a wave keeps the candidates in registers (m <= 64 * kNnChunks: the common case) and walks
     // query groups grp, grp + stride, ...; the next group's coordinates are fetched (one coalesced load, 24 lanes) while
@@ -150,7 +150,7 @@ __device__ __forceinline__ void three_nn_wave(int n, int m, const float* __restr
         const int l = lane < 3 * kNnQ ? lane : 3 * kNnQ - 1;
         int jq = g * kNnQ + l / 3;
         jq = jq < n ? jq : n - 1;
-        return xyz1[jq * 3 + l % 3];
+        return xyz1[jq * ld1 + l % 3];
     };
     float qnext = load_queries(grp);
     if (nblk == 1) load_block(0);
@@ -347,7 +347,7 @@ __device__ __forceinline__ void three_nn_wave(int n, int m, const float* __restr
                 }
             } else if (part == 0) {  // overflow: full float64 scan in ascending index order
                 const int jq = q0 + g;
-                const double dqx = xyz1[jq * 3 + 0], dqy = xyz1[jq * 3 + 1], dqz = xyz1[jq * 3 + 2];
+                const double dqx = xyz1[jq * ld1 + 0], dqy = xyz1[jq * ld1 + 1], dqz = xyz1[jq * ld1 + 2];
                 double b1 = INFINITY, b2 = INFINITY, b3 = INFINITY;
                 int i1 = 0, i2 = 0, i3 = 0;
                 for (int kk = 0; kk < m; ++kk) {

@@ -108,7 +108,9 @@ def sa1_samples(point_cloud, hyperparams):
     different streams."""
     from .tf_ops.tf_sampling import farthest_point_sample_and_gather
     with torch.no_grad():
-        l0_xyz = point_cloud[:, :, 0:3].contiguous()
+        l0_xyz = point_cloud[:, :, 0:3]  # a view: pn2_fps_nested_ld reads the xyz columns of the batch in place
+        if not (point_cloud.dtype == torch.float32 and point_cloud.is_contiguous()):
+            l0_xyz = l0_xyz.contiguous()
         return l0_xyz, farthest_point_sample_and_gather(int(hyperparams["l1_npoint"]), l0_xyz)[1]
 
 
@@ -125,10 +127,15 @@ def get_sa_fp_features(point_cloud, is_training, hyperparams, bn_decay=None, geo
     end_points = {}
     if is_training:
         tf_util.reset_bn_links()  # producer records of the previous forward pass (tf_util._TrainDenseBnRelu)
+    # model.py:26-29 slices the batch into coordinates and colours.  Inference: the slices stay VIEWS of point_cloud -- the
+    # sampler, SA1's ball query and fused MLP, FP4's three_nn and chain read their column block where it lies (the *_ld entry
+    # points), no copy kernel runs.  Training: dense copies (the training kernels read dense rows).
+    in_place = not is_training and point_cloud.dtype == torch.float32 and point_cloud.is_contiguous() and geometry is None
+    dense = (lambda t: t) if in_place else (lambda t: t.contiguous())
     if hyperparams["use_color"]:
         feature_size = 3 * int(hyperparams["use_color"])
-        l0_xyz = sa1[0] if sa1 is not None else point_cloud[:, :, 0:3].contiguous()
-        l0_points = point_cloud[:, :, 3:3 + feature_size].contiguous()
+        l0_xyz = sa1[0] if sa1 is not None else dense(point_cloud[:, :, 0:3])
+        l0_points = dense(point_cloud[:, :, 3:3 + feature_size])
     else:
         l0_xyz = sa1[0] if sa1 is not None else point_cloud.contiguous()
         l0_points = None

@@ -8,7 +8,7 @@ knn_point / select_top_k (tf_grouping.py:31-43,64-89) are not on the model's pat
 import torch
 
 from .. import config
-from .._lib import check, lib, ptr, require_cuda, stream_ptr
+from .._lib import PN2_EUNSUP, check, lib, ptr, require_cuda, rows_in_place, stream_ptr
 
 
 def query_ball_point(radius, nsample, xyz1, xyz2, kernel=0, arith_mode=None):
@@ -29,13 +29,21 @@ def query_ball_point(radius, nsample, xyz1, xyz2, kernel=0, arith_mode=None):
             raise TypeError("QueryBallPoint expects float32 %s" % nm)
     if xyz1.shape[0] != xyz2.shape[0]:
         raise ValueError("QueryBallPoint expects xyz1 and xyz2 with the same batch size")
-    xyz1 = xyz1.detach().contiguous()
+    xyz1, ld1 = rows_in_place(xyz1)  # a column block of a wider batch (point_cloud[:, :, 0:3]) is read where it lies
     xyz2 = xyz2.detach().contiguous()
     b, n, _ = xyz1.shape
     m = xyz2.shape[1]
     idx = torch.empty((b, m, nsample), dtype=torch.int32, device=xyz1.device)
     cnt = torch.empty((b, m), dtype=torch.int32, device=xyz1.device)
     with torch.cuda.device(xyz1.device):
+        if ld1 != 3:
+            rc = PN2_EUNSUP if kernel else lib.pn2_query_ball_point_ld(
+                b, n, m, float(radius), int(nsample), ptr(xyz1), ld1, ptr(xyz2), ptr(idx), ptr(cnt),
+                config.bq_mode(arith_mode), stream_ptr())
+            if rc != PN2_EUNSUP:
+                check(rc, "pn2_query_ball_point_ld")
+                return idx, cnt
+            xyz1 = xyz1.contiguous()  # no strided kernel for this shape: query a dense copy
         if kernel:
             check(lib.pn2_query_ball_point_kernel(b, n, m, float(radius), int(nsample), ptr(xyz1), ptr(xyz2), ptr(idx),
                                                   ptr(cnt), config.bq_mode(arith_mode), int(kernel), stream_ptr()),

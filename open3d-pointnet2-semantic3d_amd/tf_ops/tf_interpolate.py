@@ -9,7 +9,7 @@ import ctypes
 
 import torch
 
-from .._lib import check, lib, ptr, require_cuda, stream_ptr
+from .._lib import check, lib, ptr, require_cuda, rows_in_place, stream_ptr
 
 
 def three_nn(xyz1, xyz2):
@@ -23,14 +23,17 @@ def three_nn(xyz1, xyz2):
             raise TypeError("ThreeNN expects float32 %s" % nm)
     if xyz2.shape[1] < 3:
         raise ValueError("ThreeNN needs at least 3 known points")
-    xyz1 = xyz1.detach().contiguous()
+    xyz1, ld1 = rows_in_place(xyz1)  # queries that are a column block of a wider batch (point_cloud[:, :, 0:3]): read in place
     xyz2 = xyz2.detach().contiguous()
     b, n, _ = xyz1.shape
     m = xyz2.shape[1]
     dist = torch.empty((b, n, 3), dtype=torch.float32, device=xyz1.device)
     idx = torch.empty((b, n, 3), dtype=torch.int32, device=xyz1.device)
     with torch.cuda.device(xyz1.device):
-        check(lib.pn2_three_nn(b, n, m, ptr(xyz1), ptr(xyz2), ptr(dist), ptr(idx), stream_ptr()), "pn2_three_nn")
+        if ld1 == 3:
+            check(lib.pn2_three_nn(b, n, m, ptr(xyz1), ptr(xyz2), ptr(dist), ptr(idx), stream_ptr()), "pn2_three_nn")
+        else:
+            check(lib.pn2_three_nn_ld(b, n, m, ptr(xyz1), ld1, ptr(xyz2), ptr(dist), ptr(idx), stream_ptr()), "pn2_three_nn_ld")
     return dist, idx
 
 

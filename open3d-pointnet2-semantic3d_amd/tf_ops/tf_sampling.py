@@ -8,7 +8,7 @@ C ABI of libpn2_hip.so instead of tf.load_op_library.
 import torch
 
 from .. import config
-from .._lib import check, lib, ptr, require_cuda, stream_ptr
+from .._lib import check, lib, ptr, require_cuda, rows_in_place, stream_ptr
 
 
 def _chk_xyz(t, name, op):
@@ -101,8 +101,22 @@ def farthest_point_sample_with_ties(npoint, inp, arith_mode=None, want_xyz=False
     require_cuda(inp)
     _chk_xyz(inp, "inp", "FarthestPointSample")
     tie_in = fps_tie_record(inp, arith_mode)
-    inp = inp.detach().contiguous()
     b, n, _ = inp.shape
+    if n <= FPS_REG_MAX:
+        # the register-resident kernels read the cloud once: a column block of a wider batch (point_cloud[:, :, 0:3]) in place
+        inp, ld = rows_in_place(inp)
+        out = torch.empty((b, npoint), dtype=torch.int32, device=inp.device)
+        new_xyz = torch.empty((b, npoint, 3), dtype=torch.float32, device=inp.device) if want_xyz else None
+        tie = torch.empty((b,), dtype=torch.int32, device=inp.device) if USE_NESTED_FPS else None
+        with torch.cuda.device(inp.device):
+            if ld == 3:
+                check(lib.pn2_fps_nested(b, n, int(npoint), ptr(inp), None, ptr(out), ptr(new_xyz), ptr(tie_in), ptr(tie),
+                                         config.fps_mode(arith_mode), stream_ptr()), "pn2_fps_nested")
+            else:
+                check(lib.pn2_fps_nested_ld(b, n, int(npoint), ptr(inp), ld, ptr(out), ptr(new_xyz), ptr(tie_in), ptr(tie),
+                                            config.fps_mode(arith_mode), stream_ptr()), "pn2_fps_nested_ld")
+        return out, tie, new_xyz
+    inp = inp.detach().contiguous()
     if USE_BUCKET_FPS and FPS_REG_MAX < n <= FPS_BUCKET_MAX:
         out, new_xyz = _fps_large(npoint, inp, want_xyz, arith_mode)
         return out, None, new_xyz

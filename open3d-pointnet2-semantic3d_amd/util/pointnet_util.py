@@ -16,7 +16,7 @@ import ctypes
 import torch
 
 from . import tf_util
-from .._lib import PN2_EUNSUP, check, lib, ptr, require_cuda, stream_ptr
+from .._lib import PN2_EUNSUP, check, lib, ptr, require_cuda, rows_in_place, stream_ptr
 from ..tf_ops import tf_grouping
 from ..tf_ops.tf_grouping import query_ball_point_multi, group_point, knn_point, query_ball_point
 from ..tf_ops.tf_interpolate import three_interpolate, three_nn
@@ -106,6 +106,7 @@ def _sa_fused_inference(xyz, new_xyz, points, idx, mlp, bn, conv_scope_fmt, pool
         # feature part of the first layer hoisted by linearity: zf = points @ W1[3:] on the n source points (8x fewer rows
         # than the m*K grouped neighbours at every level of semantic.json), its rows gathered into the accumulators
         w1x, w1f = tf_util.split_first_layer(ws[0], 3, c, "sa_pre")   # rows [0,3) = xyz, [3, 3+c) = features
+        xyz, points = xyz.contiguous(), points.contiguous()
         zf = tf_util.hoist_gemm(points.reshape(b * n, c), w1f)
         wl = [w1x] + ws[1:]
         wptrs = (ctypes.c_void_p * L)(*[t.data_ptr() for t in wl])
@@ -119,10 +120,22 @@ def _sa_fused_inference(xyz, new_xyz, points, idx, mlp, bn, conv_scope_fmt, pool
             return out
     wptrs = (ctypes.c_void_p * L)(*[t.data_ptr() for t in ws])
     bptrs = (ctypes.c_void_p * L)(*[t.data_ptr() for t in bs])
-    pts = None if points is None else points.contiguous()
+    xyz_v, ldx = rows_in_place(xyz)
+    pts, ldp = (None, 0) if points is None else rows_in_place(points)
+    if pool and not bf16 and (ldx != 3 or (points is not None and ldp != c)):
+        # column blocks of a wider batch (model.get_sa_fp_features: the xyz / rgb halves of point_cloud (b,n,6)) gathered in place
+        with torch.cuda.device(xyz.device):
+            rc = lib.pn2_sa_mlp_max_fused_ld(b, n, m, nsample, c, ptr(xyz_v), ldx, ptr(new_xyz), ptr(pts), ldp, ptr(idx), L,
+                                             ctypes.cast(widths, ctypes.c_void_p), ctypes.cast(wptrs, ctypes.c_void_p),
+                                             ctypes.cast(bptrs, ctypes.c_void_p), ptr(out), stream_ptr())
+        if rc != PN2_EUNSUP:
+            check(rc, "pn2_sa_mlp_max_fused_ld")
+            return out
+    xyz_v = xyz_v.contiguous()
+    pts = None if pts is None else pts.contiguous()
     fn = lib.pn2_sa_mlp_max_fused_bf16 if bf16 else (lib.pn2_sa_mlp_max_fused if pool else lib.pn2_sa_mlp_rows_fused)
     with torch.cuda.device(xyz.device):
-        rc = fn(b, n, m, nsample, c, ptr(xyz), ptr(new_xyz), ptr(pts), ptr(idx), L,
+        rc = fn(b, n, m, nsample, c, ptr(xyz_v), ptr(new_xyz), ptr(pts), ptr(idx), L,
                                       ctypes.cast(widths, ctypes.c_void_p), ctypes.cast(wptrs, ctypes.c_void_p),
                                       ctypes.cast(bptrs, ctypes.c_void_p), ptr(out), stream_ptr())
     if rc == PN2_EUNSUP:
@@ -266,9 +279,10 @@ def sa_geometry(xyz, npoint, radius, nsample):
     Large levels (4096..8192 points): the cloud is sorted into the ball query's grid ONCE (tf_grouping.ball_query_bin) on a
     forked stream BESIDE the FPS -- both read the same input cloud, the FPS is a 16-CU latency chain -- and the query
     workgroups copy the bins instead of each re-binning the cloud (a parallel branch when the caller is capturing a graph)."""
-    xyz = xyz.contiguous()
     n = xyz.shape[1]
     bins = None
+    if USE_BINNED_BALL_QUERY:
+        xyz = xyz.contiguous()
     if (USE_BINNED_BALL_QUERY and tf_grouping.BIN_MIN_N <= n <= tf_grouping.BIN_MAX_N and npoint >= tf_grouping.BIN_MIN_M
             and nsample <= tf_grouping.BIN_MAX_NSAMPLE):
         cur = torch.cuda.current_stream(xyz.device)
@@ -358,6 +372,9 @@ def sa_features_inference(xyz, new_xyz, points, idx, mlp, bn=True, bn_decay=None
     new_points = None
     if USE_FUSED_SA:
         new_points = _sa_fused_inference(xyz, new_xyz, points, idx, mlp, bn, "conv%d")
+    if new_points is None:  # every other kernel reads dense rows (the fused kernel above takes column blocks in place)
+        xyz = xyz.contiguous()
+        points = None if points is None else points.contiguous()
     if new_points is None and points is not None and points.dtype == torch.bfloat16:
         points = points.float()  # configuration outside the bf16 kernel: run the fp32 kernels on the exact values
         if USE_FUSED_SA:
@@ -452,7 +469,8 @@ def pointnet_sa_module(xyz, points, npoint, radius, nsample, mlp, mlp2, group_al
     with tf_util.variable_scope(scope):
         if not is_training and not group_all and not knn and use_xyz and pooling == "max":
             # ---- inference fast path: HIP index ops + fused / MFMA MLP -------------
-            xyz = xyz.contiguous()
+            # (xyz / points may be column blocks of a wider batch -- point_cloud[:, :, 0:3] / [:, :, 3:6]: the sampler, the
+            # ball query and the fused MLP kernel read them where they lie, nothing is copied)
             if geometry is not None and geometry[1] is None:
                 # the samples of this level were drawn ahead (runtime.SamplerAheadPipeline: the FPS of a batch runs on a sampler
                 # stream while earlier batches are in their dense layers); the ball query is still this module's
@@ -609,6 +627,8 @@ def dense_mlp_inference(x2d, cin, mlp, scope_fmt, bn=True, fp_front=None):
                                              [folded[k][1] for k in range(take)])
             if y is not None:
                 h, i = y, take
+        if h is None and points1 is not None:
+            points1 = points1.contiguous()  # (only the hoisted chain above reads a column block in place)
         if (h is None and USE_FUSED_FP and USE_MLP_CHAIN and rows >= 65536 and points2.shape[2] % 8 == 0
                 and mlp[0] <= 128 and mlp[0] % 32 == 0):
             for take in (2, 1):

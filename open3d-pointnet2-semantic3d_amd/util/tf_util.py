@@ -22,7 +22,7 @@ import weakref
 import torch
 import torch.nn.functional as F
 
-from .._lib import check, lib, ptr, require_cuda, stream_ptr
+from .._lib import check, lib, ptr, require_cuda, rows_in_place, stream_ptr
 
 BN_EPSILON = 1e-3  # tf.contrib.layers.batch_norm default (tf_util.py:571-581)
 
@@ -490,7 +490,10 @@ def hip_fp_mlp_fused_pre(dist, idx, points1, points2, ws, bs, schedule=None):
         return None
     w1a, w1b = split_first_layer(ws[0], c2, c1, "fp_pre")
     z = hoist_gemm(points2.reshape(b * m, c2), w1a)  # (b*m, w1): the hoisted product
-    p1 = None if points1 is None else points1.contiguous()
+    # the skip link may be a column block of a wider batch (model.get_sa_fp_features: the rgb half of point_cloud): read in place
+    p1, ld1 = (None, 0) if points1 is None else rows_in_place(points1)
+    if schedule is not None and p1 is not None:
+        p1, ld1 = p1.contiguous(), c1
     widths = (ctypes.c_int * L)(*[w.shape[1] for w in ws])
     wlist = [w1b] + list(ws[1:])
     wptrs = (ctypes.c_void_p * L)(*[(w.data_ptr() if w is not None else None) for w in wlist])
@@ -500,7 +503,9 @@ def hip_fp_mlp_fused_pre(dist, idx, points1, points2, ws, bs, schedule=None):
         common = (b, n, m, c1, ptr(dist.contiguous()), ptr(idx.contiguous()), ptr(p1), ptr(z), L,
                   ctypes.cast(widths, ctypes.c_void_p), ctypes.cast(wptrs, ctypes.c_void_p),
                   ctypes.cast(bptrs, ctypes.c_void_p), ptr(y))
-        if schedule is None:
+        if schedule is None and p1 is not None and ld1 != c1:
+            rc = lib.pn2_fp_mlp_fused_pre_ld(*common[:7], ld1, *common[7:], stream_ptr())
+        elif schedule is None:
             rc = lib.pn2_fp_mlp_fused_pre(*common, stream_ptr())
         else:
             rc = lib.pn2_fp_mlp_fused_pre_schedule(*common, int(schedule), stream_ptr())
