@@ -96,7 +96,7 @@ def test_inference_forward_launches_no_copy_kernel(pn2, cuda):
     from torch.profiler import ProfilerActivity, profile
     tfu = pn2.util.tf_util
     hp = dict(pn2.model.SEMANTIC_HYPERPARAMS)
-    B, N = 4, 8192
+    B, N = 8, 8192   # (FP4 takes the hoisted three-layer chain from 65536 rows on; below, its wide-kernel path reads dense rows)
     hp.update(batch_size=B, num_point=N)
     pc = _batch(5, B, N, cuda)
     tfu.set_default_store(tfu.VariableStore(device=cuda, seed=2))
