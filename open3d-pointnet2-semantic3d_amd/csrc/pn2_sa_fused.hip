@@ -53,6 +53,8 @@ struct SaFusedParams {
     int schedule;  // FP chain: 0 = lockstep kernel, 1 = software-pipelined kernel, -1 = the default (pipelined where it applies)
 #ifdef PN2_TUNING_HOOKS
     long long* stats;  // tuning builds: cycle stamps of the first workgroups (tools/chain_stage_ab.py)
+    long long* trace;  // tuning builds: per-wave (start, end) in 100 MHz ticks of the last 16 launches of every graph (tools/insitu_chain.py)
+    int tag;           //   which graph (0..7) this launch belongs to: read from g_chain_tag when the launch is captured
 #endif
 };
 
@@ -894,6 +896,14 @@ fp_chain_pipe_kernel(SaFusedParams p) {
         p.stats[256 + 2048 + blockIdx.x * NW + wave] = (long long)__builtin_amdgcn_s_memrealtime();  // 100 MHz, chip-wide: end
         p.stats[256 + 3072 + blockIdx.x * NW + wave] = t_real0;
     }
+    if (p.trace && lane == 0) {  // in-situ spans WITHOUT a profiler: ring of the wave's last 16 launches under this graph's tag
+        const int wv = blockIdx.x * NW + wave;
+        unsigned long long* cnt = reinterpret_cast<unsigned long long*>(p.trace) + (size_t)p.tag * 1024 + wv;
+        const unsigned long long cidx = atomicAdd(cnt, 1ull);  // the wave's own word: uncontended
+        long long* r = p.trace + 8 * 1024 + (((size_t)p.tag * 1024 + wv) * 16 + (cidx & 15ull)) * 2;
+        r[0] = t_real0;
+        r[1] = (long long)__builtin_amdgcn_s_memrealtime();
+    }
 #endif
 }
 
@@ -902,6 +912,8 @@ PN2_TUNABLE(long long*, g_chain_stats, nullptr)  // tuning hook: device buffer o
 PN2_TUNABLE(int, g_chain_nw, 0)      // tuning hook (pn2_debug_set(7, v)): 16 = 16-wave workgroups for the single-layer kernels
 PN2_TUNABLE(int, g_chain_pipe, 1)    // tuning hook (pn2_debug_set(14, v)): 0 = the lockstep schedule for the FP4 chain (A/B)
 PN2_TUNABLE(int, g_chain_grid, 256)  // tuning hook (pn2_debug_set(6, v)): persistent workgroups of the 1-per-CU configuration
+PN2_TUNABLE(long long*, g_chain_trace, nullptr)  // tuning hook: (8 x 1024) counters + (8 x 1024 x 16 x 2) stamps, see SaFusedParams::trace
+PN2_TUNABLE(int, g_chain_tag, 0)     // tuning hook (pn2_debug_set(16, v)): graph tag of the launches captured from now on
 
 template <int L, int NT1, int NT2, int NT3, bool VEC8, bool DENSE, bool POOL, bool INTERP = false, bool PREZ = false>
 int launch_chain(const SaFusedParams& p_in, hipStream_t st) {
@@ -912,6 +924,8 @@ int launch_chain(const SaFusedParams& p_in, hipStream_t st) {
     if (!p.ld1) p.ld1 = p.c1;
 #ifdef PN2_TUNING_HOOKS
     p.stats = g_chain_stats;
+    p.trace = g_chain_trace;
+    p.tag = g_chain_tag & 7;
 #endif
     constexpr int W1 = NT1 * 32, W2 = NT2 * 32, W3 = NT3 * 32;
     const int steps1 = l1_steps(PREZ ? 0 : p.c, VEC8, DENSE, INTERP ? p.c1 : 0);
@@ -1019,11 +1033,13 @@ int launch_chain(const SaFusedParams& p_in, hipStream_t st) {
 
 #ifdef PN2_TUNING_HOOKS
 extern "C" int pn2_debug_set_chain_stats(long long* dev_ptr) { g_chain_stats = dev_ptr; return 0; }
+extern "C" int pn2_debug_set_chain_trace(long long* dev_ptr) { g_chain_trace = dev_ptr; return 0; }
 extern "C" int pn2_debug_set_fused(int what, int value) {
     if (what == 6) { g_chain_grid = value; return 0; }
     if (what == 7) { g_chain_nw = value; return 0; }
     if (what == 13) { g_chain_prio = value; return 0; }
     if (what == 14) { g_chain_pipe = value; return 0; }
+    if (what == 16) { g_chain_tag = value; return 0; }
     return PN2_EINVAL;
 }
 #endif  // PN2_TUNING_HOOKS

@@ -776,7 +776,7 @@ extern "C" int pn2_debug_set(int what, int value) {
     if (what == 11) return pn2_debug_set_fps_large(what, value);
     if (what == 12) return pn2_debug_set_interp(what, value);
     if (what == 15) return pn2_debug_set_coarse(what, value);
-    if (what == 6 || what == 7 || what == 13 || what == 14) return pn2_debug_set_fused(what, value);
+    if (what == 6 || what == 7 || what == 13 || what == 14 || what == 16) return pn2_debug_set_fused(what, value);
     return pn2_debug_set_grouping(what, value);
 }
 #endif  // PN2_TUNING_HOOKS
