@@ -99,3 +99,27 @@ def test_samples_given_ahead_equal_the_module_sampling_itself(pn2, cuda):
     assert torch.equal(a, b)
     for u, v in zip(ea["xyzs"], eb["xyzs"]):
         assert torch.equal(u, v)
+
+
+@pytest.mark.gpu
+def test_concurrent_streams_run_side_by_side(pn2, cuda):
+    """runtime.concurrent_streams(n): n distinct streams on which n spin kernels take about as long as one (the hardware-queue
+    mapping of the first streams of a process can serialise two of them: profiles/r05_scheduling_study.txt #8)"""
+    import time
+    import torch
+    streams = pn2.runtime.concurrent_streams(4)
+    assert len(streams) == 4 and len({s.cuda_stream for s in streams}) == 4
+
+    def wall(ss, cycles=2000000):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for s in ss:
+            with torch.cuda.stream(s):
+                torch.cuda._sleep(cycles)
+        torch.cuda.synchronize()
+        return time.perf_counter() - t0
+
+    wall(streams[:1])
+    one = min(wall(streams[:1]) for _ in range(3))
+    four = min(wall(streams) for _ in range(3))
+    assert four < 1.6 * one, (one, four)
