@@ -664,7 +664,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--eager", action="store_true", help="launch from Python instead of replaying a hipGraph")
     ap.add_argument("--one-stream", action="store_true", help="(default since r01q; kept for old scripts)")
-    ap.add_argument("--pipeline", type=int, default=4, help="independent batches in flight (graphs replayed round-robin)")
+    ap.add_argument("--pipeline", type=int, default=None,
+                    help="one graph per batch on this many streams (the r01-r04 execution; implies --stagger off)")
     ap.add_argument("--no-north-star", action="store_true")
     ap.add_argument("--no-other-configs", action="store_true", help="skip the configs[2] / [3]@1gpu / [4] sub-results")
     ap.add_argument("--debug-set", action="append", default=[], metavar="WHAT=VALUE",
@@ -687,11 +688,15 @@ def main():
                     help="run only the two north-star kernel measurements and print them (the command the rocprofv3 / PMC passes "
                          "of tools/gpu_round4.sh profile: profiles/r04_pmc_north_star.json)")
     ap.add_argument("--no-other-inputs", action="store_true", help="skip the S-randn / S-dup25 legs of the line")
-    ap.add_argument("--stagger", default="0,0,1,1", metavar="B0,B1,..|off",
+    ap.add_argument("--stagger", default=None, metavar="B0,B1,..|off",
                     help="throughput regime on runtime.StaggeredPipeline: one stream per entry, the stream keeps that many sampled "
                          "batches ahead of its dense work (two graphs per batch on ONE stream; breaks the lockstep of a region that "
                          "starts with empty queues); off = one graph per batch on --pipeline streams (the r01-r04 execution)")
     args = ap.parse_args()
+    if args.stagger is None:  # the default throughput execution, unless a script asks for the old one by naming --pipeline
+        args.stagger = "off" if args.pipeline is not None else "0,0,1,1"
+    if args.pipeline is None:
+        args.pipeline = 4
 
     if args.gpus < 1:
         raise SystemExit("--gpus must be >= 1")
