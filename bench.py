@@ -777,6 +777,7 @@ def main():
     step = eager_step = lambda: eager_on(pc)  # noqa: E731
     pipe = None
     flush = lambda: None  # noqa: E731
+    thr_inputs, n_streams, n_flight = [], 1, 1
     if not args.eager:
         # one hipGraph per forward: replay removes the ~40 Python-side launches from the step.
         # --pipeline P: P independent batches in flight (P graphs with their own buffers, replayed
