@@ -103,9 +103,8 @@ def clone_geometry(geo, l0_xyz):
 
 def sa1_samples(point_cloud, hyperparams):
     """The first dependent chain of a batch, alone: farthest point sampling + gather of SA level 1 (pointnet_util.py:36-37 as
-    model.py:36-47 calls it) -> (l0_xyz (B,N,3) contiguous, new_xyz (B, l1_npoint, 3) carrying the run's tie record).
-    get_sa_fp_features(..., sa1=) takes it from there; runtime.SamplerAheadPipeline runs the two halves of a batch on
-    different streams."""
+    model.py:36-47 calls it) -> (l0_xyz (B,N,3): a VIEW of the batch when it can be read in place, new_xyz (B, l1_npoint, 3) carrying the run's tie record).
+    get_sa_fp_features(..., sa1=) takes it from there; runtime.StaggeredPipeline captures the two halves of a batch as two graphs."""
     from .tf_ops.tf_sampling import farthest_point_sample_and_gather
     with torch.no_grad():
         l0_xyz = point_cloud[:, :, 0:3]  # a view: pn2_fps_nested_ld reads the xyz columns of the batch in place

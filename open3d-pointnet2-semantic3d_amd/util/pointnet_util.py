@@ -472,8 +472,8 @@ def pointnet_sa_module(xyz, points, npoint, radius, nsample, mlp, mlp2, group_al
             # (xyz / points may be column blocks of a wider batch -- point_cloud[:, :, 0:3] / [:, :, 3:6]: the sampler, the
             # ball query and the fused MLP kernel read them where they lie, nothing is copied)
             if geometry is not None and geometry[1] is None:
-                # the samples of this level were drawn ahead (runtime.SamplerAheadPipeline: the FPS of a batch runs on a sampler
-                # stream while earlier batches are in their dense layers); the ball query is still this module's
+                # the samples of this level were drawn ahead (runtime.StaggeredPipeline: the sampling of a batch is a graph of
+                # its own, submitted ahead of the batch's dense half); the ball query is still this module's
                 new_xyz = geometry[0]
                 idx, _ = query_ball_point(radius, nsample, xyz, new_xyz)
             else:

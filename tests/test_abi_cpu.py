@@ -80,6 +80,45 @@ def test_argument_validation_needs_no_gpu(pn2):
     assert L.pn2_coarse_geometry(*args(1, 64, 2, True)) == -1         # 3-NN needs >= 3 known points
     a = list(args(1, 64, 16, False)); a[-3] = 7
     assert L.pn2_coarse_geometry(*a) == -1                            # unknown arithmetic mode
+    # r05: the *_ld entry points (row stride in floats) and pn2_relu_grad: refused before any launch
+    assert L.pn2_fps_nested_ld(1, 64, 8, fake, 2, fake, nul, nul, nul, 2, nul) == -1             # ld >= 3
+    assert L.pn2_fps_nested_ld(1, 64, 8, nul, 6, fake, nul, nul, nul, 2, nul) == -2              # inp
+    assert L.pn2_fps_nested_ld(1, 20000, 8, fake, 6, fake, nul, nul, nul, 2, nul) == -4          # streaming kernel: dense rows only
+    assert L.pn2_fps_nested_ld(1, 64, 8, fake, 6, fake, nul, nul, nul, 9, nul) == -1             # arithmetic mode
+    assert L.pn2_query_ball_point_ld(1, 8192, 1024, 0.5, 32, fake, 2, fake, fake, fake, 1, nul) == -1
+    assert L.pn2_query_ball_point_ld(1, 8192, 1024, -1.0, 32, fake, 6, fake, fake, fake, 1, nul) == -1
+    assert L.pn2_query_ball_point_ld(1, 8192, 1024, 0.5, 32, fake, 6, nul, fake, fake, 1, nul) == -2
+    assert L.pn2_query_ball_point_ld(1, 1000, 100, 0.5, 32, fake, 6, fake, fake, fake, 1, nul) == -4   # outside the LDS-grid kernel
+    assert L.pn2_three_nn_ld(1, 64, 2, fake, 6, fake, fake, fake, nul) == -1                     # >= 3 known points
+    assert L.pn2_three_nn_ld(1, 64, 16, fake, 1, fake, fake, fake, nul) == -1                    # ld >= 3
+    assert L.pn2_three_nn_ld(1, 64, 16, fake, 6, nul, fake, fake, nul) == -2
+    w1 = one_i(32)
+    assert L.pn2_sa_mlp_max_fused_ld(1, 64, 8, 32, 3, fake, 2, fake, fake, 6, fake, 1, w1, one_p(4096), one_p(4096), fake, nul) == -1
+    assert L.pn2_sa_mlp_max_fused_ld(1, 64, 8, 32, 3, fake, 6, fake, fake, 2, fake, 1, w1, one_p(4096), one_p(4096), fake, nul) == -1
+    assert L.pn2_sa_mlp_max_fused_ld(1, 64, 8, 32, 8, fake, 6, fake, fake, 16, fake, 1, w1, one_p(4096), one_p(4096), fake, nul) == -4  # 16-byte gathers: dense rows
+    assert L.pn2_fp_mlp_fused_pre_ld(1, 64, 16, 3, fake, fake, fake, 2, fake, 2, w1, one_p(4096), one_p(4096), fake, nul) == -1    # ld < c1
+    assert L.pn2_relu_grad(0, fake, fake, fake, nul) == -1
+    assert L.pn2_relu_grad(16, nul, fake, fake, nul) == -2
+
+
+def test_rows_in_place_recognises_column_blocks():
+    """_lib.rows_in_place: a dense (b,n,c) tensor or a column block of a wider dense one is read where it lies (row stride in
+    floats); anything else is copied.  Host logic only."""
+    import torch
+    from pn2_amd._lib import rows_in_place
+    pc = torch.arange(2 * 5 * 6, dtype=torch.float32).reshape(2, 5, 6)
+    t, ld = rows_in_place(pc[:, :, 0:3])
+    assert ld == 6 and t.data_ptr() == pc.data_ptr() and not t.is_contiguous()
+    t, ld = rows_in_place(pc[:, :, 3:6])
+    assert ld == 6 and t.data_ptr() == pc.data_ptr() + 12
+    t, ld = rows_in_place(pc)
+    assert ld == 6 and t.data_ptr() == pc.data_ptr()
+    t, ld = rows_in_place(pc[:, ::2, 0:3])          # every second row: clouds are no longer n * ld apart
+    assert ld == 3 and t.is_contiguous() and torch.equal(t, pc[:, ::2, 0:3])
+    t, ld = rows_in_place(pc.transpose(1, 2))        # not row-major at all
+    assert ld == 5 and t.is_contiguous()
+    t, ld = rows_in_place(pc[:1, :, 0:3])            # a single cloud
+    assert torch.equal(t, pc[:1, :, 0:3]) and ld in (3, 6)
 
 
 def test_ops_refuse_cpu_tensors_loudly(pn2):
