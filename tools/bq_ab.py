@@ -4,7 +4,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from tools.fps_ab import scene, timeit  # noqa
 
 def main():
-    L = ctypes.CDLL(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "open3d-pointnet2-semantic3d_amd", "libpn2_hip.so"))
+    L = ctypes.CDLL(os.environ.get("PN2_HIP_LIBRARY") or os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "open3d-pointnet2-semantic3d_amd", "libpn2_hip.so"))
     dev = torch.device("cuda:0")
     st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
     P = lambda t: ctypes.c_void_p(t.data_ptr())

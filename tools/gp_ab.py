@@ -3,7 +3,7 @@ import ctypes, sys, os, numpy as np, torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 from tools.fps_ab import timeit
-L = ctypes.CDLL(os.path.join(ROOT, "open3d-pointnet2-semantic3d_amd", "libpn2_hip.so"))
+L = ctypes.CDLL(os.environ.get("PN2_HIP_LIBRARY") or os.path.join(ROOT, "open3d-pointnet2-semantic3d_amd", "libpn2_hip.so"))
 dev = torch.device("cuda:0"); st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
 P = lambda t: ctypes.c_void_p(t.data_ptr())
 b, n, m, k, c = 16, 8192, 1024, 32, 128

@@ -4,7 +4,7 @@
 import ctypes, os
 import torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-lib = ctypes.CDLL(os.path.join(ROOT, "open3d-pointnet2-semantic3d_amd", "libpn2_hip.so"))
+lib = ctypes.CDLL(os.environ.get("PN2_HIP_LIBRARY") or os.path.join(ROOT, "open3d-pointnet2-semantic3d_amd", "libpn2_hip.so"))
 P = ctypes.c_void_p
 
 SHAPES = [(524288, 9, 32), (524288, 32, 32), (524288, 32, 64), (131072, 67, 64), (131072, 64, 64), (131072, 64, 128),
