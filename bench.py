@@ -528,6 +528,8 @@ def bench_train(pn2, args, hp, B, N, rank, world, dev):
                                    % (B, N, tr.store.num_parameters()),
                        "global_batch": world * B, "parallelism": "dp%d" % world},
             "per_rank_ms_per_step": [round(v, 4) for v in per_rank], **diag,
+            # (the training step has no stream pipeline to verify: one trainer stream + one geometry-prefetch stream per rank)
+            "streams_verified_concurrent": [None] * world,
             "last_loss": float(loss), **rccl_info(world)}))
 
 
@@ -553,6 +555,8 @@ def train_comm_diagnosis(pn2, tr, args, pcs, labels, smpw, dev, world, ms_per_st
         out["exposed_comm_ms"] = round(sum(e1.elapsed_time(e2) for _, e1, e2 in ev) / len(ev), 4)
         out["early_launch_to_reduced_ms"] = round(sum(e0.elapsed_time(e2) for e0, _, e2 in ev) / len(ev), 4)
     out["exposed_comm_ms"] = round(pn2.dist.max_over_ranks(out["exposed_comm_ms"], device=dev), 4)
+    # every key of this dict is a maximum over ranks (r06: this one was rank 0's own value beside the maximum above)
+    out["early_launch_to_reduced_ms"] = round(pn2.dist.max_over_ranks(out.get("early_launch_to_reduced_ms", 0.0), device=dev), 4)
     pn2.dist.barrier()
     tr.bucket.skip_collectives = True
     torch.cuda.synchronize()
@@ -658,6 +662,8 @@ def main():
     ap.add_argument("--dry-run", action="store_true",
                     help="launcher / rendezvous / timing plumbing only, gloo on CPU, no GPU work (tests/test_dist_cpu.py)")
     ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--regions", type=int, default=5,
+                    help="timed regions of exactly --steps steps each; `value` / `ms_per_step` are the median region's")
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--batch", type=int, default=16)
     ap.add_argument("--points", type=int, default=8192)
@@ -808,25 +814,43 @@ def main():
     for _ in range(args.warmup):
         step()
     flush()
-    torch.cuda.synchronize()
-    if dist_on:
-        dist.barrier()
+
+    def timed_region():
+        """EXACTLY args.steps steps, submitted and completed between two barrier + synchronize brackets -> (seconds, last output)"""
         torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    out = None
-    for _ in range(args.steps):
-        r_ = step()
+        if dist_on:
+            dist.barrier()
+            torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        out = None
+        for _ in range(args.steps):
+            r_ = step()
+            out = out if r_ is None else r_
+        r_ = flush()       # (a staggered pipeline holds dense halves back: all of them are submitted before the synchronize)
         out = out if r_ is None else r_
-    r_ = flush()           # (a staggered pipeline holds dense halves back: all of them are submitted before the synchronize)
-    out = out if r_ is None else r_
-    torch.cuda.synchronize()
-    if dist_on:
-        dist.barrier()
         torch.cuda.synchronize()
-    elapsed = time.perf_counter() - t0
-    per_rank_pps = [B * N * args.steps / v for v in pn2.dist.gather_over_ranks(elapsed, device=dev)]
-    elapsed = pn2.dist.max_over_ranks(elapsed, device=dev)  # the slowest rank defines the step time
+        if dist_on:
+            dist.barrier()
+            torch.cuda.synchronize()
+        return time.perf_counter() - t0, out
+
+    # VERDICT r05 #3: a K-step region is ~8 ms and starts with empty queues; ONE draw of it moved by +-3 % with the hardware-queue
+    # mapping and the submission phase.  The headline is the MEDIAN of `--regions` such regions (each exactly K steps, each
+    # bracketed as the contract says, each the maximum over ranks), after one untimed region; min / max / all of them are printed.
+    timed_region()
+    regions = []
+    for _ in range(max(1, args.regions)):
+        el, out = timed_region()
+        per_rank = pn2.dist.gather_over_ranks(el, device=dev)
+        regions.append((max(per_rank), per_rank))  # the slowest rank defines a region's time
     assert torch.isfinite(out).all()
+    order = sorted(range(len(regions)), key=lambda i: regions[i][0])
+    elapsed, per_rank_el = regions[order[(len(order) - 1) // 2]]  # the median region (lower median for an even count)
+    per_rank_pps = [B * N * args.steps / v for v in per_rank_el]
+    region_ms = [round(r_[0] / args.steps * 1e3, 4) for r_ in regions]
+    streams_verified = getattr(pipe, "streams_verified_concurrent", None) if pipe is not None else None
+    verified_per_rank = [None if v < 0 else int(v) for v in
+                         pn2.dist.gather_over_ranks(-1 if streams_verified is None else streams_verified, device=dev)]
 
     # ---- latency regime: ONE batch in flight (what the reference's benchmark.py times), same K steps, bracketed the
     #      same way: replay -> synchronize per step
@@ -888,6 +912,13 @@ def main():
             "value": round(total_points / elapsed, 1), "unit": "points/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4), "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "value_statistic": "median of %d timed regions of exactly %d steps each (barrier + synchronize on both sides of every "
+                               "region, maximum over ranks per region), after %d warm-up steps and one untimed region"
+                               % (len(regions), args.steps, args.warmup),
+            "timed_regions": len(regions), "ms_per_step_regions": region_ms,
+            "value_min": round(total_points / max(r_[0] for r_ in regions), 1),
+            "value_max": round(total_points / min(r_[0] for r_ in regions), 1),
+            "streams_verified_concurrent": verified_per_rank,
             "value_regime": "throughput: %d independent B=%d batches in flight per GPU (see regimes.latency for one batch "
                             "in flight)" % (P_eff, B) if P_eff > 1 else "latency: one batch in flight",
             "config": {"workload": "configs[1]: full SSG PointNet++ SA x4 + FP x4 (semantic.json), inference forward, "

@@ -596,6 +596,43 @@ int pn2_linear_bn_stats_xf(int rows, int cin, int cout, const float *x_raw, cons
 int pn2_linear_wgrad_accumulate_xf(int rows, int cin, int cout, const float *x_raw, const float *dy, float *dw,
                                    const float *a_scale, const float *a_shift, int a_relu, void *stream);
 
+/* y (rows, cout) = x (rows, cin) . w (cin, cout) + bias (NULL: none), no activation, for 1 <= cout <= 16: the class head
+ * (model.py:145-146: conv1d(num_class), activation_fn=None) as one streaming launch instead of a zero-padded MFMA layer.
+ * cin % 4 == 0, cin * cout * 4 <= 48 KB, x 16-byte aligned, else PN2_EUNSUP. */
+int pn2_linear_narrow(int rows, int cin, int cout, const float *x, const float *w, const float *bias, float *y, void *stream);
+
+/* The batch-norm gradient of the training path (tf_util.py:555-581 through tf.gradients) applied ON LOAD by the two gradient
+ * GEMMs of the layer, so that dy = the gradient leaving the batch norm (+ReLU [+ max over groups of 32 rows]) is never written
+ * or re-read.  pn2_bn_grad_constants turns the two per-channel sums (stats_done = 1: left in the zeroed workspace by
+ * pn2_linear_dgrad_bn_grad_stats / pn2_linear_dgrad_gx of the layer above; 0: taken here with one pass over (dz, y), workspace
+ * zeroed by the caller) into dgamma, dbeta and coef (6, c) = sc, sh, mean, invstd, k1, k2 with
+ * dy = sc * fma(-(y - mean) * invstd, k2, g - k1), g = dz * [relu mask] -- pn2_bn_relu_backward's expressions, so both forms
+ * hand the GEMMs the same bits.  pn2_linear_dgrad_gx: dx (rows, cin) = dy (rows, cout) . W^T (pn2_linear_dgrad) with dy formed
+ * from y (rows, cout), dz ((rows, cout); pool = 32: the (rows / 32, cout) gradient of the pooled maxima beside zmax / ties of
+ * pn2_bn_relu_forward) and coef; y_below != NULL adds pn2_linear_dgrad_bn_grad_stats' epilogue for the layer below.
+ * pn2_linear_wgrad_gx: dw (cin, cout) += x^T . dy likewise; a_scale != NULL: x is the pre-normalisation output of the layer
+ * below (pn2_linear_wgrad_accumulate_xf).  pool in {0, 32}; cout % 4 == 0, 16 < cout <= 512 and 16-byte aligned y / dz / coef for
+ * the data gradient, else PN2_EUNSUP. */
+int pn2_bn_grad_constants(long long rows, int c, const float *dz, const float *y, const float *gamma, const float *beta,
+                          const float *save_mean, const float *save_invstd, int relu, int pool, const float *zmax,
+                          const float *ties, const float *ysel, int stats_done, void *workspace, size_t workspace_bytes,
+                          float *coef, float *dgamma, float *dbeta, void *stream);
+/* pn2_bn_relu_forward with pool > 1 that also keeps ysel (rows / pool, c) = the pre-normalisation value of the first row that
+ * attains each pooled maximum.  With it (pn2_bn_grad_constants(..., ysel != NULL, stats_done = 0)) the backward reduction behind
+ * the max pool reads the pooled tensors only -- the gradient is non-zero on the rows attaining the maximum, all of which carry
+ * zmax -- instead of making a pass over y (rows, c).  stats_mode 0 / 1 / 2 = pn2_bn_relu_forward / _ws0 / _stats. */
+int pn2_bn_relu_forward_pool(long long rows, int c, const float *y, const float *gamma, const float *beta, const float *bias,
+                             float eps, float decay, int relu, int pool, float *running_mean, float *running_var,
+                             void *workspace, size_t workspace_bytes, int stats_mode, float *save_mean, float *save_invstd,
+                             float *zmax, float *ties, float *ysel, void *stream);
+int pn2_linear_dgrad_gx(int rows, int cin, int cout, const float *y, const float *dz, const float *coef, int relu, int pool,
+                        const float *zmax, const float *ties, const float *w, float *dx, const float *y_below,
+                        const float *gamma_below, const float *beta_below, const float *mean_below, const float *invstd_below,
+                        int relu_below, void *ws_below, size_t ws_below_bytes, void *stream);
+int pn2_linear_wgrad_gx(int rows, int cin, int cout, const float *x, const float *a_scale, const float *a_shift, int a_relu,
+                        const float *y, const float *dz, const float *coef, int relu, int pool, const float *zmax,
+                        const float *ties, float *dw, void *stream);
+
 /* First layer of an SA / FP module of the TRAINING path with its feature half applied to the source rows (gather and
  * interpolation are linear and commute with a 1x1 conv):
  *   SA (pointnet_util.py:39-54,150-156):  y (b,m,nsample,cout) = (group_point(xyz, idx) - new_xyz) . w_xyz (3,cout) + z[b, idx]

@@ -97,6 +97,16 @@ SIGNATURES = {
                                        c_void_p, c_int, c_void_p, ctypes.c_size_t, c_void_p],
     "pn2_bn_relu_backward_stats": [ctypes.c_longlong, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int,
                                    c_int, c_void_p, c_void_p, c_void_p, ctypes.c_size_t, c_void_p, c_void_p, c_void_p, c_void_p],
+    "pn2_linear_narrow": [c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p],
+    "pn2_bn_grad_constants": [ctypes.c_longlong, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int,
+                              c_void_p, c_void_p, c_void_p, c_int, c_void_p, ctypes.c_size_t, c_void_p, c_void_p, c_void_p, c_void_p],
+    "pn2_bn_relu_forward_pool": [ctypes.c_longlong, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_float, c_int, c_int,
+                                 c_void_p, c_void_p, c_void_p, ctypes.c_size_t, c_int, c_void_p, c_void_p, c_void_p, c_void_p,
+                                 c_void_p, c_void_p],
+    "pn2_linear_dgrad_gx": [c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p,
+                            c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p, ctypes.c_size_t, c_void_p],
+    "pn2_linear_wgrad_gx": [c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_int, c_int,
+                            c_void_p, c_void_p, c_void_p, c_void_p],
     "pn2_weighted_ce_forward": [c_int, c_int, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p],
     "pn2_weighted_ce_backward": [c_int, c_int, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                  c_void_p],
@@ -188,6 +198,8 @@ _raw = _load()
 
 # entry points that mutate caller state beyond their outputs (moving averages): never launched twice by the dup hook
 _STATEFUL = frozenset({"pn2_bn_relu_forward", "pn2_bn_relu_forward_ws0", "pn2_bn_relu_forward_stats", "pn2_linear_bn_stats",
+                       "pn2_bn_relu_forward_pool", "pn2_bn_relu_forward_deferred", "pn2_linear_bn_stats_xf", "pn2_linear_wgrad_gx",
+                       "pn2_linear_wgrad_accumulate_xf", "pn2_bn_grad_constants", "pn2_linear_dgrad_gx",
                        "pn2_adam_step", "pn2_linear_wgrad_accumulate"})
 
 
@@ -291,9 +303,9 @@ def ptr(t):
 def rows_in_place(t):
     """(tensor, ld) for a (b, n, c) float32 tensor the *_ld entry points can read where it lies: rows `ld` floats apart, clouds
     n * ld floats apart -- a dense tensor (ld = c) or a column block of a wider dense one (point_cloud[:, :, 0:3] of a (b,n,6)
-    batch: ld = 6).  Anything else is copied."""
+    batch: ld = 6).  Anything else -- other layouts, other dtypes (ld counts FLOATS) -- is copied dense: ld = c elements."""
     t = t.detach()
-    if t.dim() == 3 and t.stride(2) == 1 and t.stride(1) >= t.shape[2] and t.stride(0) == t.shape[1] * t.stride(1) \
+    if t.dtype == torch.float32 and t.dim() == 3 and t.stride(2) == 1 and t.stride(1) >= t.shape[2] and t.stride(0) == t.shape[1] * t.stride(1) \
             and t.data_ptr() % 4 == 0:
         return t, int(t.stride(1))
     t = t.contiguous()

@@ -218,6 +218,38 @@ bn_constants_kernel(long long rows, int c, int nslots, double* __restrict__ ws, 
     }
 }
 
+// The backward twin of bn_constants_kernel (pn2_bn_grad_constants): fold the slot copies of (sum g, sum g * xhat) and publish
+// dgamma / dbeta and the six per-channel constants of dy = sc * fma(-xhat, k2, g - k1) -- the float values bn_grad_apply_kernel
+// derives in every block -- for the gradient GEMMs that form dy while they load (y, dz) (Pn2GradOnLoad).
+__global__ void __launch_bounds__(kBnThreads)
+bn_grad_constants_kernel(long long rows, int c, int nslots, double* __restrict__ ws, const float* __restrict__ gamma,
+                         const float* __restrict__ beta, const float* __restrict__ save_mean,
+                         const float* __restrict__ save_invstd, float* __restrict__ coef, float* __restrict__ dgamma,
+                         float* __restrict__ dbeta) {
+    const int ch = blockIdx.x * kBnThreads + threadIdx.x;
+    if (ch >= c) return;
+    double s1 = 0.0, s2 = 0.0;
+#pragma unroll 8
+    for (int k = 0; k < nslots; ++k) {
+        s1 += ws[kBnHead + (size_t)2 * c * (1 + k) + ch];
+        s2 += ws[kBnHead + (size_t)2 * c * (1 + k) + c + ch];
+    }
+    ws[kBnHead + ch] = s1;
+    ws[kBnHead + c + ch] = s2;
+    const double inv_n = 1.0 / (double)rows;
+    const float mu = save_mean[ch], is = save_invstd[ch];
+    float sc, sh;
+    bn_scale_shift(gamma[ch], beta[ch], mu, is, sc, sh);
+    coef[ch] = sc;
+    coef[(size_t)c + ch] = sh;
+    coef[(size_t)2 * c + ch] = mu;
+    coef[(size_t)3 * c + ch] = is;
+    coef[(size_t)4 * c + ch] = (float)(s1 * inv_n);
+    coef[(size_t)5 * c + ch] = (float)(s2 * inv_n);
+    dbeta[ch] = (float)s1;
+    dgamma[ch] = (float)s2;
+}
+
 // z = relu?(fma(y, sc[ch], sh[ch]))
 template <int VEC>
 __global__ void __launch_bounds__(kBnThreads)
@@ -256,7 +288,7 @@ bn_apply_pool_kernel(long long rows, int c, int pool, const float* __restrict__ 
                      const float* __restrict__ gamma, const float* __restrict__ beta, const float* __restrict__ bias,
                      float eps, float decay, int relu, float* __restrict__ running_mean, float* __restrict__ running_var,
                      float* __restrict__ save_mean, float* __restrict__ save_invstd, float* __restrict__ zmax,
-                     float* __restrict__ ties) {
+                     float* __restrict__ ties, float* __restrict__ ysel) {
     __shared__ float sc[kBnMaxC], sh[kBnMaxC];
     bn_forward_constants(rows, c, acc, gamma, beta, bias, eps, decay, running_mean, running_var, save_mean, save_invstd, sc, sh);
     const BnMap<VEC> mp(c);
@@ -267,15 +299,16 @@ bn_apply_pool_kernel(long long rows, int c, int pool, const float* __restrict__ 
     for (int v = 0; v < VEC; ++v) { s4[v] = sc[mp.cc * VEC + v]; h4[v] = sh[mp.cc * VEC + v]; }
     for (long long g = (long long)blockIdx.x * mp.rp + mp.rr; g < groups; g += (long long)gridDim.x * mp.rp) {
         const float* __restrict__ p = y + (size_t)g * pool * c + (size_t)mp.cc * VEC;
-        float best[VEC], cnt[VEC];
+        float best[VEC], cnt[VEC], ysl[VEC];  // ysl: the pre-normalisation value of the FIRST row attaining the maximum
 #pragma unroll
-        for (int v = 0; v < VEC; ++v) { best[v] = -__builtin_inff(); cnt[v] = 0.f; }
+        for (int v = 0; v < VEC; ++v) { best[v] = -__builtin_inff(); cnt[v] = 0.f; ysl[v] = 0.f; }
         auto take = [&](const float (&a)[VEC]) {
 #pragma unroll
             for (int v = 0; v < VEC; ++v) {
                 float t = __builtin_fmaf(a[v], s4[v], h4[v]);
                 if (relu) t = t > 0.f ? t : 0.f;
                 cnt[v] = t > best[v] ? 1.f : (t == best[v] ? cnt[v] + 1.f : cnt[v]);
+                ysl[v] = t > best[v] ? a[v] : ysl[v];
                 best[v] = t > best[v] ? t : best[v];
             }
         };
@@ -296,9 +329,11 @@ bn_apply_pool_kernel(long long rows, int c, int pool, const float* __restrict__ 
         if constexpr (VEC == 4) {
             *reinterpret_cast<float4*>(zmax + o) = make_float4(best[0], best[1], best[2], best[3]);
             *reinterpret_cast<float4*>(ties + o) = make_float4(cnt[0], cnt[1], cnt[2], cnt[3]);
+            if (ysel) *reinterpret_cast<float4*>(ysel + o) = make_float4(ysl[0], ysl[1], ysl[2], ysl[3]);
         } else {
             zmax[o] = best[0];
             ties[o] = cnt[0];
+            if (ysel) ysel[o] = ysl[0];
         }
     }
 }
@@ -377,6 +412,45 @@ bn_grad_reduce_kernel(long long rows, int c, long long slab, int nslots, const f
             float a0[VEC];
             bn_load<VEC>(y + (size_t)r * c + col, a0);
             take(r, a0);
+        }
+    }
+    bn_block_sums<VEC, 2>(mp, c, nslots, part, ws);
+}
+
+// backward pass 1 behind the fused max pool, from the POOLED tensors alone (groups = rows / pool entries per channel instead of
+// rows): the gradient reaching the activation is non-zero only on the rows that attain a group's maximum, where it is dzp / n on
+// each of the n tied rows -- all of them have the forward value zmax -- so sum g = sum over groups of dzp and
+// sum g * xhat = sum over groups of dzp * xhat(ysel), ysel = the pre-normalisation value of the first such row (kept by the
+// forward, bn_apply_pool_kernel); a group whose maximum is the ReLU's 0 passes nothing.  Same sums as bn_grad_reduce_kernel up to
+// rounding (n * fl(dzp / n) vs dzp; tied rows whose y differ inside one rounding of the normalisation), without its pass over y.
+template <int VEC>
+__global__ void __launch_bounds__(kBnThreads)
+bn_grad_reduce_pooled_kernel(long long groups, int c, long long slab, int nslots, const float* __restrict__ dzp,
+                             const float* __restrict__ zmax, const float* __restrict__ ysel, const float* __restrict__ save_mean,
+                             const float* __restrict__ save_invstd, int relu, double* __restrict__ ws) {
+    const BnMap<VEC> mp(c);
+    const long long gb = (long long)blockIdx.x * slab;
+    const long long ge = gb + slab < groups ? gb + slab : groups;
+    double part[2][VEC];
+#pragma unroll
+    for (int v = 0; v < VEC; ++v) part[0][v] = part[1][v] = 0.0;
+    if (mp.active) {
+        float mean[VEC], invstd[VEC];
+#pragma unroll
+        for (int v = 0; v < VEC; ++v) { mean[v] = save_mean[mp.cc * VEC + v]; invstd[v] = save_invstd[mp.cc * VEC + v]; }
+        const size_t col = (size_t)mp.cc * VEC;
+        for (long long g = gb + mp.rr; g < ge; g += mp.rp) {
+            float d[VEC], m[VEC], ys[VEC];
+            bn_load<VEC>(dzp + (size_t)g * c + col, d);
+            bn_load<VEC>(zmax + (size_t)g * c + col, m);
+            bn_load<VEC>(ysel + (size_t)g * c + col, ys);
+#pragma unroll
+            for (int v = 0; v < VEC; ++v) {
+                const double gd = (!relu || m[v] > 0.f) ? (double)d[v] : 0.0;
+                const double xh = (double)((ys[v] - mean[v]) * invstd[v]);
+                part[0][v] += gd;
+                part[1][v] = __builtin_fma(gd, xh, part[1][v]);
+            }
         }
     }
     bn_block_sums<VEC, 2>(mp, c, nslots, part, ws);
@@ -479,7 +553,7 @@ extern "C" size_t pn2_bn_workspace_bytes(int c) { return c > 0 ? sizeof(double) 
 static int bn_relu_forward_impl(long long rows, int c, const float* y, const float* gamma, const float* beta,
                                 const float* bias, float eps, float decay, int relu, int pool, float* running_mean,
                                 float* running_var, void* workspace, size_t workspace_bytes, float* save_mean,
-                                float* save_invstd, float* z, float* ties, void* stream, int mode) {
+                                float* save_invstd, float* z, float* ties, void* stream, int mode, float* ysel = nullptr) {
     // mode 0: zero the workspace here; 1: the caller zeroed it; 2: the caller zeroed it AND pn2_linear_bn_stats has already
     // added the column sums of y to all kBnSlots slot copies (no statistics pass)
     if (!y || !gamma || !beta || !workspace || !save_mean || !save_invstd || !z) return PN2_ENULL;
@@ -512,7 +586,7 @@ static int bn_relu_forward_impl(long long rows, int c, const float* y, const flo
         if (pool > 1)                                                                                                    \
             bn_apply_pool_kernel<V_><<<(int)pb, kBnThreads, 0, st>>>(rows, c, pool, y, acc, gamma, beta, bias, eps, decay, \
                                                                    relu, running_mean, running_var, save_mean,           \
-                                                                   save_invstd, z, ties);                                \
+                                                                   save_invstd, z, ties, ysel);                          \
         else                                                                                                             \
             bn_apply_kernel<V_><<<p.apply_blocks, kBnThreads, 0, st>>>(rows, c, y, acc, gamma, beta, bias, eps, decay,    \
                                                                      relu, running_mean, running_var, save_mean,         \
@@ -548,6 +622,21 @@ extern "C" int pn2_bn_relu_forward_stats(long long rows, int c, const float* y, 
                                          float* save_invstd, float* z, float* ties, void* stream) {
     return bn_relu_forward_impl(rows, c, y, gamma, beta, bias, eps, decay, relu, pool, running_mean, running_var, workspace,
                                 workspace_bytes, save_mean, save_invstd, z, ties, stream, 2);
+}
+
+// pn2_bn_relu_forward with pool > 1 that also keeps ysel (rows / pool, c): the pre-normalisation value of the first row attaining
+// each pooled maximum -- what lets the backward take its reduction from the pooled tensors alone (pn2_bn_grad_constants).
+// stats_mode 0: zero the workspace here; 1: the caller zeroed it; 2: pn2_linear_bn_stats already left the column sums in it.
+extern "C" int pn2_bn_relu_forward_pool(long long rows, int c, const float* y, const float* gamma, const float* beta,
+                                        const float* bias, float eps, float decay, int relu, int pool, float* running_mean,
+                                        float* running_var, void* workspace, size_t workspace_bytes, int stats_mode,
+                                        float* save_mean, float* save_invstd, float* zmax, float* ties, float* ysel,
+                                        void* stream) {
+    if (pool <= 1 || stats_mode < 0 || stats_mode > 2) return PN2_EINVAL;
+    if (!ysel) return PN2_ENULL;
+    if ((c % 4 == 0) && ((uintptr_t)ysel % 16) != 0) return PN2_EINVAL;
+    return bn_relu_forward_impl(rows, c, y, gamma, beta, bias, eps, decay, relu, pool, running_mean, running_var, workspace,
+                                workspace_bytes, save_mean, save_invstd, zmax, ties, stream, stats_mode, ysel);
 }
 
 // Batch norm of the training path WITHOUT writing the normalised activation: the statistics (stats_done = 1: already left in
@@ -644,4 +733,50 @@ extern "C" int pn2_bn_relu_backward_stats(long long rows, int c, const float* dz
                                           size_t workspace_bytes, float* dy, float* dgamma, float* dbeta, void* stream) {
     return bn_relu_backward_impl(rows, c, dz, y, gamma, beta, save_mean, save_invstd, relu, pool, zmax, ties, workspace,
                                  workspace_bytes, dy, dgamma, dbeta, stream, 2);
+}
+
+// The batch-norm gradient WITHOUT writing dy: the two per-channel sums (stats_done = 1: already left in the zeroed workspace by
+// pn2_linear_dgrad_bn_grad_stats; 0: taken here with one pass over (dz, y), workspace zeroed by the caller) are folded into dgamma,
+// dbeta and coef (6, c) = sc, sh, mean, invstd, k1, k2; the layer's data and weight gradient GEMMs apply them while they load
+// (y, dz) (pn2_linear_dgrad_gx / pn2_linear_wgrad_gx), so the write of dy and its two re-reads disappear.  pool as in
+// pn2_bn_relu_backward.  util/tf_util.py:555-581 via tf.gradients.
+extern "C" int pn2_bn_grad_constants(long long rows, int c, const float* dz, const float* y, const float* gamma, const float* beta,
+                                     const float* save_mean, const float* save_invstd, int relu, int pool, const float* zmax,
+                                     const float* ties, const float* ysel, int stats_done, void* workspace,
+                                     size_t workspace_bytes, float* coef, float* dgamma, float* dbeta, void* stream) {
+    if (!dz || !y || !gamma || !beta || !save_mean || !save_invstd || !workspace || !coef || !dgamma || !dbeta) return PN2_ENULL;
+    if (pool > 1 && (!zmax || !ties)) return PN2_ENULL;
+    if (pool > 1 && rows % pool != 0) return PN2_EINVAL;
+    if (stats_done && pool > 1) return PN2_EINVAL;
+    BnPlan p;
+    const int rc = bn_plan(rows, c, dz, y, y, p);
+    if (rc != PN2_OK) return rc;
+    if (pool > 1 && p.vec == 4 && (((uintptr_t)zmax | (uintptr_t)ties) % 16) != 0) return PN2_EINVAL;
+    if (workspace_bytes < pn2_bn_workspace_bytes(c) || ((uintptr_t)workspace % 8) != 0) return PN2_EINVAL;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    double* ws = static_cast<double*>(workspace);
+    if (stats_done) {
+        p.nslots = kBnSlots;
+    } else if (pool > 1 && ysel) {  // the reduction from the pooled tensors alone: rows / pool entries per channel
+        BnPlan q;
+        const int rq = bn_plan(rows / pool, c, dz, zmax, ysel, q);
+        if (rq != PN2_OK) return rq;
+        p.nslots = q.nslots;
+        if (q.vec == 4)
+            bn_grad_reduce_pooled_kernel<4><<<q.stat_blocks, kBnThreads, 0, st>>>(rows / pool, c, q.slab, q.nslots, dz, zmax, ysel,
+                                                                                save_mean, save_invstd, relu, ws);
+        else
+            bn_grad_reduce_pooled_kernel<1><<<q.stat_blocks, kBnThreads, 0, st>>>(rows / pool, c, q.slab, q.nslots, dz, zmax, ysel,
+                                                                                save_mean, save_invstd, relu, ws);
+    } else if (p.vec == 4) {
+        bn_grad_reduce_kernel<4><<<p.stat_blocks, kBnThreads, 0, st>>>(rows, c, p.slab, p.nslots, dz, y, gamma, beta, save_mean,
+                                                                     save_invstd, relu, pool, zmax, ties, ws);
+    } else {
+        bn_grad_reduce_kernel<1><<<p.stat_blocks, kBnThreads, 0, st>>>(rows, c, p.slab, p.nslots, dz, y, gamma, beta, save_mean,
+                                                                     save_invstd, relu, pool, zmax, ties, ws);
+    }
+    bn_grad_constants_kernel<<<(c + kBnThreads - 1) / kBnThreads, kBnThreads, 0, st>>>(rows, c, p.nslots, ws, gamma, beta, save_mean,
+                                                                                      save_invstd, coef, dgamma, dbeta);
+    PN2_RETURN_IF_LAUNCH_FAILED();
+    return PN2_OK;
 }

@@ -60,6 +60,43 @@ struct Pn2BnGradEpilogue {
     int relu;
 };
 
+// Operand transform of the two gradient GEMMs of a dense layer that consume the gradient dy LEAVING its batch norm (+ReLU
+// [+ max over groups of 32 rows]): dy is formed while the operand is staged and never written (util/tf_util.py:555-581 via
+// tf.gradients; pn2_linear_dgrad_gx / pn2_linear_wgrad_gx).  The float expressions are bn_grad_apply_kernel's, so the GEMMs see
+// the bits the materialised form would have handed them.  coef (6, c) = sc, sh, mean, invstd, k1, k2 per channel
+// (pn2_bn_grad_constants: sc = gamma * invstd, sh = fma(-mean, sc, beta), k1 = mean over rows of g, k2 = of g * xhat).
+constexpr int kPn2GxMaxC = 512;  // widest batch norm the on-load form takes (its constants are staged in LDS)
+struct Pn2GradOnLoad {
+    const float* y;     // (rows, c) pre-normalisation output of this layer
+    const float* dz;    // (rows, c) gradient reaching the activation; pool == 32: (rows / 32, c) gradient of the pooled maxima
+    const float* coef;  // (6, c)
+    const float* zmax;  // pool == 32: (rows / 32, c) the pooled maxima
+    const float* ties;  // pool == 32: (rows / 32, c) rows attaining them
+    int relu;
+    int pool;           // 0 or 32
+};
+
+// one element of that gradient; g_in = the gradient reaching the activation of this element (before the ReLU mask)
+__device__ __forceinline__ float pn2_bn_grad_element(float y, float g_in, float sc, float sh, float mu, float is, float k1,
+                                                     float k2, int relu) {
+    const float lin = __builtin_fmaf(y, sc, sh);
+    const bool on = !relu || lin > 0.f;
+    const float gk = on ? g_in : 0.f;
+    const float xh = (y - mu) * is;
+    return sc * __builtin_fmaf(-xh, k2, gk - k1);
+}
+// the same behind the fused max over 32 rows: the pooled gradient d is shared equally by the n rows attaining the maximum m
+__device__ __forceinline__ float pn2_bn_grad_element_pooled(float y, float d, float m, float n, float sc, float sh, float mu,
+                                                            float is, float k1, float k2, int relu) {
+    const float lin = __builtin_fmaf(y, sc, sh);
+    const bool on = !relu || lin > 0.f;
+    const float t = on ? lin : 0.f;
+    const float g = t == m ? d / n : 0.f;
+    const float gk = on ? g : 0.f;
+    const float xh = (y - mu) * is;
+    return sc * __builtin_fmaf(-xh, k2, gk - k1);
+}
+
 // Largest float T with  max(sqrtf(T), 1e-20f) < radius  (sqrtf correctly rounded, hence monotone): for every s >= 0,
 // (s <= T) <=> the reference's ball-query predicate tf_grouping.cu:28-31.  Returns -1 when nothing can match.  Host side.
 inline float pn2_ball_threshold(float radius) {

@@ -111,13 +111,18 @@ __device__ __forceinline__ void push_column_grad_stats(const f32x16& acc, int ha
 // XF = true (training, VEC_A): the A operand is the PRE-normalisation output of the layer below; its batch norm (+ReLU) is
 // applied per input channel k while the tile moves from the prefetch registers to LDS, a = relu?(fma(x, xf.scale[k],
 // xf.shift[k])) -- the normalised activation is never written (pn2_bn_relu_forward_deferred).
-template <int WM, int WN, int NT, bool VEC_A, int WK = 1, int ST = 2, bool TB = false, bool XF = false>
+// GX = 1 / 2 (training, VEC_A, TB): the A operand is the gradient dy LEAVING the batch norm (+ReLU; GX = 2: + max over groups of
+// 32 rows) of the layer whose data gradient this is, formed from (y, dz) while the tile moves from the prefetch registers to LDS
+// (Pn2GradOnLoad; x is not read).  The per-channel constants -- and for GX = 2 the pooled gradient / maxima / tie counts of the
+// block's BM / 32 groups -- are staged once per block in dynamic LDS.
+template <int WM, int WN, int NT, bool VEC_A, int WK = 1, int ST = 2, bool TB = false, bool XF = false, int GX = 0>
 __global__ void __launch_bounds__(256)
 linear_kernel(int rows, int cin, int cout, const float* __restrict__ x,
               const float* __restrict__ w, const float* __restrict__ bias, int relu, int pool,
               float* __restrict__ y, double* __restrict__ stats = nullptr, Pn2BnGradEpilogue gepi = Pn2BnGradEpilogue{},
-              Pn2LoadTransform xf = Pn2LoadTransform{}) {
+              Pn2LoadTransform xf = Pn2LoadTransform{}, Pn2GradOnLoad gx = Pn2GradOnLoad{}) {
     static_assert(!XF || (VEC_A && !TB && WK == 1), "the load transform exists for the forward GEMM with 16-byte A loads");
+    static_assert(GX == 0 || (VEC_A && TB && WK == 1 && !XF), "the gradient-on-load operand exists for the data gradient with 16-byte A loads");
     static_assert(WM * WN * WK == 4, "4 waves per block");
     static_assert(WK == 1 || (WK == 2 && NT * 16 * 64 * WM * WN <= kBK * (32 * NT * WN + 4)), "reduction buffer must fit the B tile");
     constexpr int BM = 32 * WM;
@@ -148,13 +153,32 @@ linear_kernel(int rows, int cin, int cout, const float* __restrict__ x,
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[nt][r] = 0.f;
 
+    // GX: coef (6, cin) | GX = 2: dz / zmax / ties of the block's BM / 32 groups, each (BM / 32, cin)
+    extern __shared__ __attribute__((aligned(16))) float gx_lds[];
+    if constexpr (GX != 0) {
+        for (int e = tid; e < 6 * cin; e += 256) gx_lds[e] = gx.coef[e];
+        if constexpr (GX == 2) {
+            constexpr int NG = BM / 32;
+            const int groups = rows / 32;
+            for (int e = tid; e < NG * cin; e += 256) {
+                const int g = e / cin, ch = e - g * cin;
+                const int gg = row0 / 32 + g < groups ? row0 / 32 + g : groups - 1;
+                gx_lds[6 * cin + e] = gx.dz[(size_t)gg * cin + ch];
+                gx_lds[6 * cin + NG * cin + e] = gx.zmax[(size_t)gg * cin + ch];
+                gx_lds[6 * cin + 2 * NG * cin + e] = gx.ties[(size_t)gg * cin + ch];
+            }
+        }
+    }
+
+    f32x4 a_gs[GX == 1 ? ST : 1][GX == 1 ? A_PER_T : 1];  // GX = 1: the dz tile beside the y tile
     f32x4 a_vs[ST][VEC_A ? A_PER_T : 1];
     float a_ss[ST][VEC_A ? 1 : A_SC];
     f32x4 b_vs[ST][B_PER_T];
     f32x4 x_sc[XF ? ST : 1], x_sh[XF ? ST : 1];  // XF: (scale, shift) of this thread's four k of the tile (k4 = tid & 7 for every i)
 
     auto load_tile = [&](int kt, f32x4 (&a_v)[VEC_A ? A_PER_T : 1], float (&a_s)[VEC_A ? 1 : A_SC],
-                         f32x4 (&b_v)[B_PER_T], f32x4& xsc, f32x4& xsh) {
+                         f32x4 (&b_v)[B_PER_T], f32x4& xsc, f32x4& xsh,
+                         f32x4 (&a_g)[GX == 1 ? A_PER_T : 1]) __attribute__((always_inline)) {
         // Every load is unconditional (addresses clamped into the buffers, out-of-range elements zeroed
         // afterwards): straight-line loads let the compiler use counted s_waitcnt vmcnt(N), which is what
         // keeps ST-1 tiles in flight; loads under a divergent branch force vmcnt(0).
@@ -168,9 +192,14 @@ linear_kernel(int rows, int cin, int cout, const float* __restrict__ x,
                 const int gr = row0 + r, gk = k0 + k4 * 4;
                 const int grc = gr < rows ? gr : rows - 1;
                 const int gkc = gk < cin ? gk : cin - 4;  // VEC_A: cin % 4 == 0
-                const f32x4 v = *reinterpret_cast<const f32x4*>(x + (size_t)grc * cin + gkc);
-                if constexpr (XF) a_v[i] = v;  // transformed, then zeroed, in store_tile
-                else a_v[i] = (gr < rows && gk < cin) ? v : z4;
+                if constexpr (GX != 0) {  // transformed, then zeroed, in store_tile
+                    a_v[i] = *reinterpret_cast<const f32x4*>(gx.y + (size_t)grc * cin + gkc);
+                    if constexpr (GX == 1) a_g[i] = *reinterpret_cast<const f32x4*>(gx.dz + (size_t)grc * cin + gkc);
+                } else {
+                    const f32x4 v = *reinterpret_cast<const f32x4*>(x + (size_t)grc * cin + gkc);
+                    if constexpr (XF) a_v[i] = v;  // transformed, then zeroed, in store_tile
+                    else a_v[i] = (gr < rows && gk < cin) ? v : z4;
+                }
             }
             if constexpr (XF) {
                 const int gk = k0 + (tid & 7) * 4;
@@ -221,13 +250,44 @@ linear_kernel(int rows, int cin, int cout, const float* __restrict__ x,
         }
     };
     auto store_tile = [&](int kt, const f32x4 (&a_v)[VEC_A ? A_PER_T : 1], const float (&a_s)[VEC_A ? 1 : A_SC],
-                          const f32x4 (&b_v)[B_PER_T], const f32x4& xsc, const f32x4& xsh) {
+                          const f32x4 (&b_v)[B_PER_T], const f32x4& xsc, const f32x4& xsh,
+                          const f32x4 (&a_g)[GX == 1 ? A_PER_T : 1]) __attribute__((always_inline)) {
         if constexpr (VEC_A) {
+            f32x4 gc[GX != 0 ? 6 : 1];  // GX: this thread's four channels of the tile (k4 = tid & 7 for every i)
+            int gch = 0;
+            if constexpr (GX != 0) {
+                const int gk = kt * kBK + (tid & 7) * 4;
+                gch = gk < cin ? gk : cin - 4;
+#pragma unroll
+                for (int j = 0; j < 6; ++j) gc[j] = *reinterpret_cast<const f32x4*>(gx_lds + j * cin + gch);
+            }
 #pragma unroll
             for (int i = 0; i < A_PER_T; ++i) {
                 const int f = tid + 256 * i;
                 const int r = f >> 3, k4 = f & 7;
                 f32x4 v = a_v[i];
+                if constexpr (GX != 0) {
+                    const bool live = row0 + r < rows && kt * kBK + k4 * 4 < cin;
+                    f32x4 pd, pm, pn;
+                    if constexpr (GX == 2) {
+                        constexpr int NG = BM / 32;
+                        const float* pg = gx_lds + 6 * cin + (r >> 5) * cin + gch;
+                        pd = *reinterpret_cast<const f32x4*>(pg);
+                        pm = *reinterpret_cast<const f32x4*>(pg + NG * cin);
+                        pn = *reinterpret_cast<const f32x4*>(pg + 2 * NG * cin);
+                    }
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        float t;
+                        if constexpr (GX == 2)
+                            t = pn2_bn_grad_element_pooled(v[q], pd[q], pm[q], pn[q], gc[0][q], gc[1][q], gc[2][q], gc[3][q],
+                                                           gc[4][q], gc[5][q], gx.relu);
+                        else
+                            t = pn2_bn_grad_element(v[q], a_g[i][q], gc[0][q], gc[1][q], gc[2][q], gc[3][q], gc[4][q], gc[5][q],
+                                                    gx.relu);
+                        v[q] = live ? t : 0.f;
+                    }
+                }
                 if constexpr (XF) {
                     const bool live = row0 + r < rows && kt * kBK + k4 * 4 < cin;
 #pragma unroll
@@ -265,16 +325,20 @@ linear_kernel(int rows, int cin, int cout, const float* __restrict__ x,
 
     const int nkt = (cin + kBK - 1) / kBK;
 #pragma unroll
-    for (int u = 0; u < ST - 1; ++u) load_tile(u < nkt ? u : nkt - 1, a_vs[u], a_ss[u], b_vs[u], x_sc[XF ? u : 0], x_sh[XF ? u : 0]);
-    auto tile_step = [&](auto uc, int kt) {  // statically unrolled: the prefetch ring slots are compile-time
+    for (int u = 0; u < ST - 1; ++u)
+        load_tile(u < nkt ? u : nkt - 1, a_vs[u], a_ss[u], b_vs[u], x_sc[XF ? u : 0], x_sh[XF ? u : 0], a_gs[GX == 1 ? u : 0]);
+    // (always_inline: past a code-size threshold the inliner leaves this lambda a real function, and every array it captures by
+    // reference then lives in scratch memory -- measured 876 us instead of 51 for a 131072 x 128 data gradient)
+    auto tile_step = [&](auto uc, int kt) __attribute__((always_inline)) {  // statically unrolled: the prefetch ring slots are compile-time
         constexpr int u = decltype(uc)::value;
         __syncthreads();  // previous tile fully consumed
-        store_tile(kt, a_vs[u], a_ss[u], b_vs[u], x_sc[XF ? u : 0], x_sh[XF ? u : 0]);
+        store_tile(kt, a_vs[u], a_ss[u], b_vs[u], x_sc[XF ? u : 0], x_sh[XF ? u : 0], a_gs[GX == 1 ? u : 0]);
         __syncthreads();
         constexpr int un = (u + ST - 1) % ST;
         // always issued (tile index clamped: the last ST-1 prefetches re-read the last tile and are
         // never stored) so that the loop body stays branch-free around the loads
-        load_tile(kt + ST - 1 < nkt ? kt + ST - 1 : nkt - 1, a_vs[un], a_ss[un], b_vs[un], x_sc[XF ? un : 0], x_sh[XF ? un : 0]);
+        load_tile(kt + ST - 1 < nkt ? kt + ST - 1 : nkt - 1, a_vs[un], a_ss[un], b_vs[un], x_sc[XF ? un : 0], x_sh[XF ? un : 0],
+                  a_gs[GX == 1 ? un : 0]);
         const float* as = As + (wm * 32 + l31) * kAS + 4 * half;
         const float* bs = Bs + (4 * half) * BS + wn * (NT * 32) + l31;
 #pragma unroll
@@ -293,11 +357,11 @@ linear_kernel(int rows, int cin, int cout, const float* __restrict__ x,
     };
     int kt0 = 0;
     for (; kt0 + ST <= nkt; kt0 += ST) {  // full groups: no branches between the counted waits
-        auto step = [&](auto uc) { tile_step(uc, kt0 + decltype(uc)::value); };
+        auto step = [&](auto uc) __attribute__((always_inline)) { tile_step(uc, kt0 + decltype(uc)::value); };
         static_for<0, ST>(step);
     }
     {
-        auto step = [&](auto uc) {
+        auto step = [&](auto uc) __attribute__((always_inline)) {
             if (kt0 + decltype(uc)::value < nkt) tile_step(uc, kt0 + decltype(uc)::value);
         };
         static_for<0, ST - 1>(step);
@@ -448,11 +512,72 @@ int launch_dgrad_smallk(int rows, int n_in, const float* dy, const float* w, flo
     return PN2_OK;
 }
 
+// Forward of a layer with a handful of OUTPUTS (the 9-class head, model.py:145-146): y[r][o] = sum_k x[r][k] * w[k][o] + b[o],
+// N = n_out <= 16.  The MFMA kernels need 32 output columns (zero-padded weight copy, padded output, slice copy, bias add:
+// five launches); this is one streaming kernel bound by the read of x: eight lanes share a row -- lane j of the group loads the
+// 16-byte pieces k = 4j + 32i, so a wave reads eight contiguous 128-byte runs per load -- keep N partial sums each and combine
+// them with three butterfly steps; W (cin x N) sits in LDS.  cin % 4 == 0, x 16-byte aligned.
+template <int N>
+__global__ void __launch_bounds__(256)
+linear_narrow_kernel(int rows, int cin, const float* __restrict__ x, const float* __restrict__ w,
+                     const float* __restrict__ bias, float* __restrict__ y) {
+    extern __shared__ float sw[];  // cin * N
+    for (int e = threadIdx.x; e < cin * N; e += 256) sw[e] = w[e];
+    __syncthreads();
+    const int j = threadIdx.x & 7;
+    const long long groups = (long long)gridDim.x * 32;
+    for (long long r = (long long)blockIdx.x * 32 + (threadIdx.x >> 3); r < (long long)((rows + 31) / 32) * 32; r += groups) {
+        const long long rc = r < rows ? r : rows - 1;  // whole groups of eight lanes stay in the loop: the butterflies need them
+        const float* __restrict__ px = x + rc * cin;
+        float acc[N];
+#pragma unroll
+        for (int o = 0; o < N; ++o) acc[o] = 0.f;
+        for (int k = 4 * j; k < cin; k += 32) {
+            const f32x4 v = *reinterpret_cast<const f32x4*>(px + k);
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+#pragma unroll
+                for (int o = 0; o < N; ++o) acc[o] = __builtin_fmaf(v[q], sw[(k + q) * N + o], acc[o]);
+        }
+#pragma unroll
+        for (int o = 0; o < N; ++o) {
+            acc[o] += __shfl_xor(acc[o], 1);
+            acc[o] += __shfl_xor(acc[o], 2);
+            acc[o] += __shfl_xor(acc[o], 4);
+        }
+        if (r < rows) {
+#pragma unroll
+            for (int o = 0; o < N; ++o)
+                if ((o & 7) == j) y[r * N + o] = acc[o] + (bias ? bias[o] : 0.f);
+        }
+    }
+}
+
+template <int N>
+int launch_linear_narrow(int rows, int cin, const float* x, const float* w, const float* bias, float* y, hipStream_t st) {
+    long long g = ((long long)rows + 31) / 32;
+    if (g > 256 * 16) g = 256 * 16;
+    linear_narrow_kernel<N><<<(int)g, 256, (size_t)cin * N * sizeof(float), st>>>(rows, cin, x, w, bias, y);
+    PN2_RETURN_IF_LAUNCH_FAILED();
+    return PN2_OK;
+}
+
 template <int WM, int WN, int NT>
 int launch_linear_dgrad(int rows, int n_in, int n_out, const float* dy, const float* w, float* dx, hipStream_t st,
-                        const Pn2BnGradEpilogue& gepi = Pn2BnGradEpilogue{}) {
+                        const Pn2BnGradEpilogue& gepi = Pn2BnGradEpilogue{}, const Pn2GradOnLoad* gx = nullptr) {
     constexpr int BM = 32 * WM, BN = 32 * NT * WN;
     dim3 grid((rows + BM - 1) / BM, (n_in + BN - 1) / BN);
+    if (gx) {  // dy formed on load from (y, dz): n_out % 4 == 0 and 16-byte aligned operands checked by the caller
+        const size_t lds = sizeof(float) * (size_t)n_out * (6 + (gx->pool ? 3 * (BM / 32) : 0));
+        if (gx->pool)
+            linear_kernel<WM, WN, NT, true, 1, 3, true, false, 2><<<grid, 256, lds, st>>>(rows, n_out, n_in, nullptr, w, nullptr, 0, 0, dx,
+                                                                                       nullptr, gepi, Pn2LoadTransform{}, *gx);
+        else
+            linear_kernel<WM, WN, NT, true, 1, 3, true, false, 1><<<grid, 256, lds, st>>>(rows, n_out, n_in, nullptr, w, nullptr, 0, 0, dx,
+                                                                                       nullptr, gepi, Pn2LoadTransform{}, *gx);
+        PN2_RETURN_IF_LAUNCH_FAILED();
+        return PN2_OK;
+    }
     const bool vec_a = (n_out % 4 == 0) && ((uintptr_t)dy % 16 == 0);
     if (vec_a) linear_kernel<WM, WN, NT, true, 1, 3, true><<<grid, 256, 0, st>>>(rows, n_out, n_in, dy, w, nullptr, 0, 0, dx, nullptr, gepi);
     else linear_kernel<WM, WN, NT, false, 1, 3, true><<<grid, 256, 0, st>>>(rows, n_out, n_in, dy, w, nullptr, 0, 0, dx, nullptr, gepi);
@@ -637,10 +762,14 @@ int launch_linear_splitk(int rows, int cin, int cout, const float* x, const floa
 // tile to dW with fp32 atomics (dW zeroed by the entry point).  Memory-bound: every row is read once per tile column.
 // XF: x is the pre-normalisation output of the layer below, the operand is relu?(fma(x, scale[m], shift[m])) (per lane: its
 // TM input channels), see linear_kernel.
-template <int TM, int TN, bool XF = false>
+// GX = 1 / 2: dy is the gradient leaving this layer's batch norm (+ReLU; 2: + max over groups of 32 rows), formed per lane from
+// (y, dz) and the constants of its TN output channels while the operand is loaded (Pn2GradOnLoad; the `dy` argument is not read).
+// GX = 2: chunk % 32 == 0, so a fetch of 2U rows never straddles a pooling group.
+template <int TM, int TN, bool XF = false, int GX = 0>
 __global__ void __launch_bounds__(256, 2)
 linear_wgrad_kernel(int rows, int cin, int cout, int chunk, const float* __restrict__ x,
-                    const float* __restrict__ dy, float* __restrict__ dw, Pn2LoadTransform xf = Pn2LoadTransform{}) {
+                    const float* __restrict__ dy, float* __restrict__ dw, Pn2LoadTransform xf = Pn2LoadTransform{},
+                    Pn2GradOnLoad gx = Pn2GradOnLoad{}) {
     const int lane = threadIdx.x & 63, half = lane >> 5, l31 = lane & 31;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // row bookkeeping stays in SGPRs
     const long long c0 = ((long long)blockIdx.x * 4 + wave) * chunk;
@@ -677,28 +806,80 @@ linear_wgrad_kernel(int rows, int cin, int cout, int chunk, const float* __restr
     // A = 0 is enough (the dy values it pairs with are finite data of the matrix).
     constexpr int U = 4;
     const int last_pair = rows > 1 ? rows - 2 : 0;
-    float av0[U][TM], bv0[U][TN], av1[U][TM], bv1[U][TN];
-    auto fetch = [&](float (&av)[U][TM], float (&bv)[U][TN], int r) {
+    // GX: the six batch-norm gradient constants of this lane's TN output channels
+    float gc[GX != 0 ? TN : 1][6];
+    unsigned offp[GX == 2 ? TN : 1];  // GX = 2: this lane's columns inside a row of the pooled tensors
+    if constexpr (GX != 0) {
+#pragma unroll
+        for (int t = 0; t < TN; ++t) {
+            const int n = n0 + t * 32 + l31;
+            const int nc = n < cout ? n : cout - 1;
+#pragma unroll
+            for (int j = 0; j < 6; ++j) gc[t][j] = gx.coef[(size_t)j * cout + nc];
+            if constexpr (GX == 2) offp[t] = (unsigned)nc;
+        }
+    }
+    // per register buffer: x (TM), dy or y (TN), GX = 1: dz (TN), GX = 2: pooled gradient / maximum / tie count of the fetch's group
+    struct Buf {
+        float av[U][TM], bv[U][TN];
+        float bg[GX == 1 ? U : 1][GX == 1 ? TN : 1];
+        float pd[GX == 2 ? TN : 1], pm[GX == 2 ? TN : 1], pn[GX == 2 ? TN : 1];
+    };
+    Buf b0, b1;
+    auto fetch = [&](Buf& bf, int r) __attribute__((always_inline)) {
 #pragma unroll
         for (int u = 0; u < U; ++u) {
             const int rb = r + 2 * u < last_pair ? r + 2 * u : last_pair;
             const float* __restrict__ px = x + (size_t)rb * cin;
-            const float* __restrict__ pd = dy + (size_t)rb * cout;
 #pragma unroll
-            for (int t = 0; t < TM; ++t) av[u][t] = px[offa[t]];
+            for (int t = 0; t < TM; ++t) bf.av[u][t] = px[offa[t]];
+            if constexpr (GX == 0) {
+                const float* __restrict__ pd = dy + (size_t)rb * cout;
 #pragma unroll
-            for (int t = 0; t < TN; ++t) bv[u][t] = pd[offb[t]];
+                for (int t = 0; t < TN; ++t) bf.bv[u][t] = pd[offb[t]];
+            } else {
+                const float* __restrict__ py = gx.y + (size_t)rb * cout;
+#pragma unroll
+                for (int t = 0; t < TN; ++t) bf.bv[u][t] = py[offb[t]];
+                if constexpr (GX == 1) {
+                    const float* __restrict__ pg = gx.dz + (size_t)rb * cout;
+#pragma unroll
+                    for (int t = 0; t < TN; ++t) bf.bg[u][t] = pg[offb[t]];
+                }
+            }
+        }
+        if constexpr (GX == 2) {  // r is a multiple of 2U = 8 inside a chunk that starts on a multiple of 32: one group per fetch
+            const int rc = r < last_pair ? r : last_pair;
+            const size_t go = (size_t)(rc >> 5) * cout;
+#pragma unroll
+            for (int t = 0; t < TN; ++t) {
+                bf.pd[t] = gx.dz[go + offp[t]];
+                bf.pm[t] = gx.zmax[go + offp[t]];
+                bf.pn[t] = gx.ties[go + offp[t]];
+            }
         }
     };
-    auto contract = [&](const float (&av)[U][TM], const float (&bv)[U][TN], int r) {
+    auto contract = [&](const Buf& bf, int r) __attribute__((always_inline)) {
 #pragma unroll
         for (int u = 0; u < U; ++u) {
             const int rb = r + 2 * u < last_pair ? r + 2 * u : last_pair;
             const int loaded = rb + half;
             const bool rv = loaded >= r + 2 * u && loaded < r1;
+            float bw[TN];
+#pragma unroll
+            for (int b = 0; b < TN; ++b) {
+                if constexpr (GX == 1)
+                    bw[b] = pn2_bn_grad_element(bf.bv[u][b], bf.bg[u][b], gc[b][0], gc[b][1], gc[b][2], gc[b][3], gc[b][4], gc[b][5],
+                                                gx.relu);
+                else if constexpr (GX == 2)
+                    bw[b] = pn2_bn_grad_element_pooled(bf.bv[u][b], bf.pd[b], bf.pm[b], bf.pn[b], gc[b][0], gc[b][1], gc[b][2],
+                                                       gc[b][3], gc[b][4], gc[b][5], gx.relu);
+                else
+                    bw[b] = bf.bv[u][b];
+            }
 #pragma unroll
             for (int a = 0; a < TM; ++a) {
-                float av_t = av[u][a];
+                float av_t = bf.av[u][a];
                 if constexpr (XF) {
                     av_t = __builtin_fmaf(av_t, xsc[a], xsh[a]);
                     av_t = xf.relu ? fmaxf(av_t, 0.f) : av_t;
@@ -706,19 +887,19 @@ linear_wgrad_kernel(int rows, int cin, int cout, int chunk, const float* __restr
                 const float av_m = rv ? av_t : 0.f;
 #pragma unroll
                 for (int b = 0; b < TN; ++b)
-                    acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(av_m, bv[u][b], acc[a][b], 0, 0, 0);
+                    acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(av_m, bw[b], acc[a][b], 0, 0, 0);
             }
         }
     };
-    fetch(av0, bv0, r0);
+    fetch(b0, r0);
     for (int r = r0; r < r1; r += 4 * U) {
-        fetch(av1, bv1, r + 2 * U);
+        fetch(b1, r + 2 * U);
         __builtin_amdgcn_sched_barrier(0);
-        contract(av0, bv0, r);
+        contract(b0, r);
         __builtin_amdgcn_sched_barrier(0);
-        fetch(av0, bv0, r + 4 * U);
+        fetch(b0, r + 4 * U);
         __builtin_amdgcn_sched_barrier(0);
-        contract(av1, bv1, r + 2 * U);
+        contract(b1, r + 2 * U);
         __builtin_amdgcn_sched_barrier(0);
     }
     // the four waves of the block own consecutive row chunks of the SAME tile: add them up through LDS (two tree steps)
@@ -857,6 +1038,25 @@ extern "C" int pn2_linear(int rows, int cin, int cout, const float* x, const flo
     return linear_impl(rows, cin, cout, x, w, bias, relu, pool, y, stream, nullptr);
 }
 
+// y (rows, cout) = x (rows, cin) . w (cin, cout) + bias for 1 <= cout <= 16 (no activation): the class head of the network
+// (model.py:145-146, tf_util.conv1d with activation_fn=None) without padding the layer to an MFMA tile.  cin % 4 == 0,
+// cin * cout * 4 <= 48 KB, x 16-byte aligned; otherwise PN2_EUNSUP (pad and call pn2_linear).
+extern "C" int pn2_linear_narrow(int rows, int cin, int cout, const float* x, const float* w, const float* bias, float* y,
+                                 void* stream) {
+    if (rows <= 0 || cin <= 0 || cout <= 0) return PN2_EINVAL;
+    if (!x || !w || !y) return PN2_ENULL;
+    if (cout > 16 || cin % 4 != 0 || ((uintptr_t)x % 16) != 0 || (size_t)cin * cout * sizeof(float) > 48 * 1024) return PN2_EUNSUP;
+    if ((long long)rows + 128 > 0x7fffffffLL) return PN2_ERANGE;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    switch (cout) {
+#define PN2_NW(N_) case N_: return launch_linear_narrow<N_>(rows, cin, x, w, bias, y, st);
+        PN2_NW(1) PN2_NW(2) PN2_NW(3) PN2_NW(4) PN2_NW(5) PN2_NW(6) PN2_NW(7) PN2_NW(8) PN2_NW(9) PN2_NW(10) PN2_NW(11)
+        PN2_NW(12) PN2_NW(13) PN2_NW(14) PN2_NW(15) PN2_NW(16)
+#undef PN2_NW
+    }
+    return PN2_EUNSUP;
+}
+
 // y = x . w (no bias, no activation) AND the per-column sums the following training-mode batch norm needs (tf_util.py:186-204:
 // conv2d -> batch_norm_template): every wave adds its tile's column sums of y and y^2 (16 fp32 terms per lane, then fp64) to
 // one of kPn2BnSlots copies of the accumulators in `bn_workspace` (pn2_bn_workspace_bytes(cout), ZEROED by the caller);
@@ -899,11 +1099,17 @@ extern "C" int pn2_linear_bn_stats_xf(int rows, int cin, int cout, const float* 
 // pass holds it (no transposed copy); any cin / cout.  The reference gets this from tf.gradients of tf.nn.conv2d
 // (util/tf_util.py:181-186).
 static int linear_dgrad_impl(int rows, int cin, int cout, const float* dy, const float* w, float* dx, void* stream,
-                             const Pn2BnGradEpilogue& gepi) {
+                             const Pn2BnGradEpilogue& gepi, const Pn2GradOnLoad* gx = nullptr) {
     if (rows <= 0 || cin <= 0 || cout <= 0) return PN2_EINVAL;
-    if (!dy || !w || !dx) return PN2_ENULL;
+    if ((!dy && !gx) || !w || !dx) return PN2_ENULL;
     if ((long long)rows + 128 > 0x7fffffffLL) return PN2_ERANGE;
     hipStream_t st = static_cast<hipStream_t>(stream);
+    if (gx) {
+        if (!gx->y || !gx->dz || !gx->coef || (gx->pool && (!gx->zmax || !gx->ties))) return PN2_ENULL;
+        if ((gx->pool != 0 && gx->pool != 32) || (gx->pool && rows % 32 != 0)) return PN2_EINVAL;
+        if (cout % 4 != 0 || cout <= 16 || cout > kPn2GxMaxC) return PN2_EUNSUP;
+        if ((((uintptr_t)gx->y | (uintptr_t)gx->dz | (uintptr_t)gx->coef) % 16) != 0) return PN2_EUNSUP;
+    }
     if (cout <= 16 && (size_t)cin * cout * sizeof(float) <= 48 * 1024) {
         if (gepi.ws) return PN2_EUNSUP;  // the streaming kernel has no accumulator tiles to take the sums from
         switch (cout) {
@@ -913,12 +1119,12 @@ static int linear_dgrad_impl(int rows, int cin, int cout, const float* dy, const
 #undef PN2_SK
         }
     }
-    if (cin <= 32) return launch_linear_dgrad<4, 1, 1>(rows, cin, cout, dy, w, dx, st, gepi);
-    if (cin <= 64) return launch_linear_dgrad<4, 1, 2>(rows, cin, cout, dy, w, dx, st, gepi);
-    if (cin <= 96) return launch_linear_dgrad<4, 1, 1>(rows, cin, cout, dy, w, dx, st, gepi);
+    if (cin <= 32) return launch_linear_dgrad<4, 1, 1>(rows, cin, cout, dy, w, dx, st, gepi, gx);
+    if (cin <= 64) return launch_linear_dgrad<4, 1, 2>(rows, cin, cout, dy, w, dx, st, gepi, gx);
+    if (cin <= 96) return launch_linear_dgrad<4, 1, 1>(rows, cin, cout, dy, w, dx, st, gepi, gx);
     const long long cb = (cin + 127) / 128;
-    if (((rows + 63) / 64) * cb >= 512) return launch_linear_dgrad<2, 2, 2>(rows, cin, cout, dy, w, dx, st, gepi);
-    return launch_linear_dgrad<1, 4, 1>(rows, cin, cout, dy, w, dx, st, gepi);
+    if (((rows + 63) / 64) * cb >= 512) return launch_linear_dgrad<2, 2, 2>(rows, cin, cout, dy, w, dx, st, gepi, gx);
+    return launch_linear_dgrad<1, 4, 1>(rows, cin, cout, dy, w, dx, st, gepi, gx);
 }
 
 extern "C" int pn2_linear_dgrad(int rows, int cin, int cout, const float* dy, const float* w, float* dx, void* stream) {
@@ -943,6 +1149,28 @@ extern "C" int pn2_linear_dgrad_bn_grad_stats(int rows, int cin, int cout, const
     return linear_dgrad_impl(rows, cin, cout, dy, w, dx, stream, e);
 }
 
+// pn2_linear_dgrad of a layer whose upstream gradient dy = the gradient LEAVING its batch norm (+ReLU [+ max over groups of 32
+// rows]) is formed while the GEMM loads it, from y (rows, cout) = this layer's pre-normalisation output, dz = the gradient
+// reaching the activation ((rows, cout), or with pool = 32 the (rows / 32, cout) gradient of the pooled maxima beside zmax / ties
+// of pn2_bn_relu_forward) and coef (6, cout) of pn2_bn_grad_constants: pn2_bn_relu_backward's second pass (read dz, y; write dy)
+// is not run and dy is never written (util/tf_util.py:555-581 + :181-186 via tf.gradients).  y_below != null: the epilogue of
+// pn2_linear_dgrad_bn_grad_stats for the layer below as well.  cout % 4 == 0, 16 < cout <= 512, else PN2_EUNSUP.
+extern "C" int pn2_linear_dgrad_gx(int rows, int cin, int cout, const float* y, const float* dz, const float* coef, int relu,
+                                   int pool, const float* zmax, const float* ties, const float* w, float* dx,
+                                   const float* y_below, const float* gamma_below, const float* beta_below,
+                                   const float* mean_below, const float* invstd_below, int relu_below, void* ws_below,
+                                   size_t ws_below_bytes, void* stream) {
+    Pn2BnGradEpilogue e{};
+    if (y_below) {
+        if (!gamma_below || !beta_below || !mean_below || !invstd_below || !ws_below) return PN2_ENULL;
+        if (cin <= 0 || ws_below_bytes < sizeof(double) * pn2_bn_ws_doubles(cin, kPn2BnSlots) || ((uintptr_t)ws_below % 8) != 0)
+            return PN2_EINVAL;
+        e = Pn2BnGradEpilogue{y_below, gamma_below, beta_below, mean_below, invstd_below, static_cast<double*>(ws_below), relu_below};
+    }
+    const Pn2GradOnLoad gx{y, dz, coef, zmax, ties, relu, pool};
+    return linear_dgrad_impl(rows, cin, cout, nullptr, w, dx, stream, e, &gx);
+}
+
 #ifdef PN2_TUNING_HOOKS
 extern "C" int pn2_debug_set_linear(int what, int value) {
     if (what == 5) { g_lin_stages = value; return 0; }
@@ -954,9 +1182,13 @@ extern "C" int pn2_debug_set_linear(int what, int value) {
 
 // dW = x^T . dy (see linear_wgrad_kernel): the training path's weight gradient.  dw (cin, cout) is overwritten.
 static int linear_wgrad_impl(int rows, int cin, int cout, const float* x, const float* dy, float* dw, void* stream, bool accumulate,
-                             const Pn2LoadTransform* xf = nullptr) {
+                             const Pn2LoadTransform* xf = nullptr, const Pn2GradOnLoad* gx = nullptr) {
     if (rows <= 0 || cin <= 0 || cout <= 0) return PN2_EINVAL;
-    if (!x || !dy || !dw) return PN2_ENULL;
+    if (!x || (!dy && !gx) || !dw) return PN2_ENULL;
+    if (gx) {
+        if (!gx->y || !gx->dz || !gx->coef || (gx->pool && (!gx->zmax || !gx->ties))) return PN2_ENULL;
+        if ((gx->pool != 0 && gx->pool != 32) || (gx->pool && rows % 32 != 0)) return PN2_EINVAL;
+    }
     if ((long long)rows + 128 > 0x7fffffffLL) return PN2_ERANGE;
     hipStream_t st = static_cast<hipStream_t>(stream);
     if (!accumulate) {
@@ -975,10 +1207,16 @@ static int linear_wgrad_impl(int rows, int cin, int cout, const float* x, const 
     if (chunk < 64) chunk = 64;
     const int nchunks = (rows + chunk - 1) / chunk;
     dim3 grid((nchunks + 3) / 4, gy, gz);
-#define PN2_WG(TM_, TN_)                                                                                       \
-    do {                                                                                                       \
-        if (xf) linear_wgrad_kernel<TM_, TN_, true><<<grid, 256, 0, st>>>(rows, cin, cout, chunk, x, dy, dw, *xf); \
-        else linear_wgrad_kernel<TM_, TN_><<<grid, 256, 0, st>>>(rows, cin, cout, chunk, x, dy, dw);             \
+#define PN2_WG_X(TM_, TN_, XF_, XFV_)                                                                                     \
+    do {                                                                                                                  \
+        if (!gx) linear_wgrad_kernel<TM_, TN_, XF_><<<grid, 256, 0, st>>>(rows, cin, cout, chunk, x, dy, dw, XFV_);         \
+        else if (gx->pool) linear_wgrad_kernel<TM_, TN_, XF_, 2><<<grid, 256, 0, st>>>(rows, cin, cout, chunk, x, nullptr, dw, XFV_, *gx); \
+        else linear_wgrad_kernel<TM_, TN_, XF_, 1><<<grid, 256, 0, st>>>(rows, cin, cout, chunk, x, nullptr, dw, XFV_, *gx); \
+    } while (0)
+#define PN2_WG(TM_, TN_)                                              \
+    do {                                                              \
+        if (xf) PN2_WG_X(TM_, TN_, true, *xf);                        \
+        else PN2_WG_X(TM_, TN_, false, Pn2LoadTransform{});           \
     } while (0)
     if (tm == 1 && tn == 1) PN2_WG(1, 1);
     else if (tm == 1 && tn == 2) PN2_WG(1, 2);
@@ -987,6 +1225,7 @@ static int linear_wgrad_impl(int rows, int cin, int cout, const float* x, const 
     else if (tm == 2 && tn == 2) PN2_WG(2, 2);
     else PN2_WG(2, 4);
 #undef PN2_WG
+#undef PN2_WG_X
     PN2_RETURN_IF_LAUNCH_FAILED();
     return PN2_OK;
 }
@@ -1005,6 +1244,17 @@ extern "C" int pn2_linear_wgrad_accumulate_xf(int rows, int cin, int cout, const
     if (!a_scale || !a_shift) return PN2_ENULL;
     const Pn2LoadTransform xf{a_scale, a_shift, a_relu};
     return linear_wgrad_impl(rows, cin, cout, x_raw, dy, dw, stream, true, &xf);
+}
+
+// dw += x^T . dy with dy = the gradient leaving this layer's batch norm formed on load (see pn2_linear_dgrad_gx; same y / dz /
+// coef / pool operands); a_scale != null: x is the pre-normalisation output of the layer below (pn2_linear_wgrad_accumulate_xf).
+extern "C" int pn2_linear_wgrad_gx(int rows, int cin, int cout, const float* x, const float* a_scale, const float* a_shift,
+                                   int a_relu, const float* y, const float* dz, const float* coef, int relu, int pool,
+                                   const float* zmax, const float* ties, float* dw, void* stream) {
+    if ((a_scale == nullptr) != (a_shift == nullptr)) return PN2_ENULL;
+    const Pn2LoadTransform xf{a_scale, a_shift, a_relu};
+    const Pn2GradOnLoad gx{y, dz, coef, zmax, ties, relu, pool};
+    return linear_wgrad_impl(rows, cin, cout, x, nullptr, dw, stream, true, a_scale ? &xf : nullptr, &gx);
 }
 
 // internal helper (exported for the host package's unfused SA path and for tests)

@@ -39,13 +39,17 @@ class CapturedForward:
         return self.static_outputs
 
 
-def concurrent_streams(n, device=None, candidates=12, spin_cycles=300000):
-    """n torch streams that the hardware really runs side by side.  HIP multiplexes streams onto a few hardware queues (4 by
-    default) in an order that depends on what the process submitted before; two streams that land on one queue serialise, and a
-    4-stream pipeline then runs like a 2- or 3-stream one (measured: 0.505 instead of 0.383 ms per step for the FIRST four
-    streams of a process, profiles/r05_scheduling_study.txt #8).  So: draw `candidates` streams, time a spin kernel on a growing
-    set of them, and keep a stream only if it does not lengthen the set's wall time (a few ms, once).  Falls back to the first
-    n candidates when fewer than n concurrent ones are found."""
+def concurrent_streams(n, device=None, candidates=12, spin_cycles=300000, strict=False):
+    """-> (streams, verified): n torch streams and how many of them the hardware was SEEN to run side by side.
+    HIP multiplexes streams onto a few hardware queues (4 by default) in an order that depends on what the process submitted
+    before; two streams that land on one queue serialise, and a 4-stream pipeline then runs like a 2- or 3-stream one
+    (measured: 0.505 instead of 0.383 ms per step for the FIRST four streams of a process, profiles/r05_scheduling_study.txt #8).
+    So: draw `candidates` streams, time a spin kernel on a growing set of them, and keep a stream only if the set's wall time
+    stays that of ONE spin (best of three runs < 1.5 x; a serialised pair costs 2 x, so the threshold sits midway and a noisy
+    box errs towards rejecting a stream, never towards accepting a serialised one: the minimum of repeated runs can only be
+    inflated by noise, not deflated).  When fewer than n concurrent streams are found the set is filled up with unverified
+    candidates -- the pipeline still works, a hardware queue is shared -- and `verified` < n says so (strict=True: raise
+    instead).  Candidates that are not returned are dropped (torch returns their HIP streams to its pool)."""
     import time
     cand = [torch.cuda.Stream(device=device) for _ in range(max(n, candidates))]
 
@@ -64,12 +68,16 @@ def concurrent_streams(n, device=None, candidates=12, spin_cycles=300000):
     for st in cand[1:]:
         if len(chosen) == n:
             break
-        if min(wall(chosen + [st]) for _ in range(2)) < 1.5 * t1:
+        if min(wall(chosen + [st]) for _ in range(3)) < 1.5 * t1:
             chosen.append(st)
+    verified = len(chosen)
+    if verified < n and strict:
+        raise RuntimeError("concurrent_streams: only %d of %d streams run side by side on this device" % (verified, n))
     for st in cand:  # not enough concurrent ones: fill up (the pipeline still works, a queue is shared)
         if len(chosen) < n and st not in chosen:
             chosen.append(st)
-    return chosen
+    del cand
+    return chosen, verified
 
 
 class StaggeredPipeline:
@@ -89,13 +97,21 @@ class StaggeredPipeline:
     every step's work is then submitted, and completed, inside the timed region, and nothing of a step is computed before the
     step was submitted."""
 
-    def __init__(self, sampler_fn, dense_fn, make_batch, backlog=(0, 0, 1, 1), warmup=2):
-        """make_batch(n) -> the example input of slot n (sum(backlog) + len(backlog) slots, cloned into static buffers)"""
+    def __init__(self, sampler_fn, dense_fn, make_batch, backlog=(0, 0, 1, 1), warmup=2, streams=None, strict_streams=False):
+        """make_batch(n) -> the example input of slot n (sum(backlog) + len(backlog) slots, cloned into static buffers).
+        streams: the caller's own streams (one per backlog entry; `streams_verified_concurrent` is then None: not probed);
+        default: concurrent_streams(P), whose verified count is kept in `streams_verified_concurrent` (bench.py prints it per
+        rank) -- strict_streams=True raises when fewer than P streams were seen to run side by side."""
         self.backlog = [int(b) for b in backlog]
         if not self.backlog or min(self.backlog) < 0:
             raise ValueError("backlog: one non-negative entry per stream")
         self.P = len(self.backlog)
-        self.streams = concurrent_streams(self.P)
+        if streams is not None:
+            if len(streams) != self.P:
+                raise ValueError("streams: one per backlog entry")
+            self.streams, self.streams_verified_concurrent = list(streams), None
+        else:
+            self.streams, self.streams_verified_concurrent = concurrent_streams(self.P, strict=strict_streams)
         self.slots = []   # per stream: [static input, sampler graph, dense graph, static output, samples]
         side = torch.cuda.Stream()
         n = 0

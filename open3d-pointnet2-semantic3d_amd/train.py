@@ -111,6 +111,12 @@ class Trainer:
         # backward reaches the head and the FP layers first: they are the early bucket (created after layer1..layer4)
         split = next((i for i, k in enumerate(names) if not k.startswith("layer")), len(names))
         self.bucket = pdist.OverlappedGradAllReduce(params, split)
+        # the gradient kernels write every parameter's gradient straight into its slice of the bucket's flat buffer
+        # (tf_util.VariableStore.grad_view): backward leaves nothing to pack
+        off = 0
+        for p in self.bucket.params:
+            self.store.grad_map[p.data_ptr()] = (self.bucket.flat, off, p.numel())
+            off += p.numel()
         # pn2_adam_step's device-side scalars: [lr_t, beta1, beta2, eps, grad_scale].  Only lr_t changes per step; it is
         # written with a fill whose value travels BY VALUE in the launch (no host buffer a run-ahead host could rewrite
         # before an asynchronous copy has read it: with sync=False the host is several steps ahead of the device).
@@ -135,12 +141,17 @@ class Trainer:
         elif self.store.zero_arena.buf is None:
             self.store.zero_arena.allocate()
         self.store.zero_arena.reset()  # ONE zero fill for every accumulator of the step
+        self.bucket.flat.zero_()       # and one for the flat gradient the weight-gradient kernels add into
         for p in self.bucket.params:
             p.grad = None
-        logits, _ = model.get_model(pc, True, self.num_class, self.hp, bn_decay=decay, geometry=geometry)
-        loss = model.get_loss(logits, labels, smpw)
-        self.bucket.begin()
-        loss.backward()
+        self.store.grad_direct = True
+        try:
+            logits, _ = model.get_model(pc, True, self.num_class, self.hp, bn_decay=decay, geometry=geometry)
+            loss = model.get_loss(logits, labels, smpw)
+            self.bucket.begin()
+            loss.backward()
+        finally:
+            self.store.grad_direct = False
         return loss.detach(), self.bucket.finish()
 
     def _forward_backward_early(self, pc, labels, smpw, decay, geometry=None):
@@ -151,13 +162,18 @@ class Trainer:
         elif self.store.zero_arena.buf is None:
             self.store.zero_arena.allocate()
         self.store.zero_arena.reset()
+        self.bucket.flat.zero_()
         for p in self.bucket.params:
             p.grad = None
-        logits, ep = model.get_model(pc, True, self.num_class, self.hp, bn_decay=decay, geometry=geometry, cut_sa_fp=True)
-        loss = model.get_loss(logits, labels, smpw)
-        early = list(self.bucket.params[self.bucket.split:])
-        cut = list(ep["sa_features_cut"])
-        grads = torch.autograd.grad(loss, early + cut, allow_unused=True)
+        self.store.grad_direct = True
+        try:
+            logits, ep = model.get_model(pc, True, self.num_class, self.hp, bn_decay=decay, geometry=geometry, cut_sa_fp=True)
+            loss = model.get_loss(logits, labels, smpw)
+            early = list(self.bucket.params[self.bucket.split:])
+            cut = list(ep["sa_features_cut"])
+            grads = torch.autograd.grad(loss, early + cut, allow_unused=True)
+        finally:
+            self.store.grad_direct = False
         for p, g in zip(early, grads[:len(early)]):
             p.grad = g
         self.bucket.pack_early()
@@ -166,7 +182,11 @@ class Trainer:
 
     def _backward_late(self):
         """second piece: the SA modules' backward pass from the gradients at the cut; the late bucket is packed"""
-        torch.autograd.backward([t for t, _ in self._cut], [g for _, g in self._cut])
+        self.store.grad_direct = True
+        try:
+            torch.autograd.backward([t for t, _ in self._cut], [g for _, g in self._cut])
+        finally:
+            self.store.grad_direct = False
         self._cut = None
         return self.bucket.pack_late_and_bind()
 

@@ -40,10 +40,13 @@ def sample_and_group(npoint, radius, nsample, xyz, points, knn=False, use_xyz=Tr
             _, idx = knn_point(nsample, xyz, new_xyz)
         else:
             idx, pts_cnt = query_ball_point(radius, nsample, xyz, new_xyz)
-    if (USE_FUSED_TRAIN_FRONT and points is not None and use_xyz and points.dtype == torch.float32
-            and (points.requires_grad or not torch.is_grad_enabled())):
-        # gather + centre + concat in one launch; grouped_xyz is a view of its first three columns
-        new_points = _SAGroupConcat.apply(xyz.contiguous(), new_xyz.contiguous(), points.contiguous(), idx, plan)
+    if USE_FUSED_TRAIN_FRONT and points is not None and use_xyz and points.dtype == torch.float32:
+        # gather + centre + concat in one launch; grouped_xyz is a view of its first three columns.  Features that carry no
+        # gradient (the colours of the level-0 module) need no tape node: the same launch, called directly
+        if points.requires_grad and torch.is_grad_enabled():
+            new_points = _SAGroupConcat.apply(xyz.contiguous(), new_xyz.contiguous(), points.contiguous(), idx, plan)
+        else:
+            new_points = _sa_group_concat(xyz.detach().contiguous(), new_xyz.detach().contiguous(), points.detach(), idx)
         return new_xyz, new_points, idx, new_points[..., :3]
     grouped_xyz = group_point(xyz, idx)
     grouped_xyz = grouped_xyz - new_xyz.unsqueeze(2)  # translation normalisation (:44-46)

@@ -22,6 +22,7 @@ import weakref
 import torch
 import torch.nn.functional as F
 
+from .._lib import PN2_EUNSUP as PN2_EUNSUP_CODE
 from .._lib import check, lib, ptr, require_cuda, rows_in_place, stream_ptr
 
 BN_EPSILON = 1e-3  # tf.contrib.layers.batch_norm default (tf_util.py:571-581)
@@ -40,8 +41,24 @@ class VariableStore:
         self._dropout = {}
         self._folded = {}
         self.zero_arena = None  # ZeroArena of the training step (set by train.Trainer), None = every call zero-fills its own scratch
+        # direct gradients (train.Trainer): parameter storage address -> (flat gradient buffer, offset, numel).  While
+        # `grad_direct` is set -- inside a trainer's forward/backward, which zero-fills the flat buffer first -- the weight-gradient
+        # and batch-norm kernels write each parameter's gradient straight into its slice (grad_view): no per-step pack copy
+        self.grad_map = {}
+        self.grad_direct = False
         self.train_epoch = 0  # bumped by every training-mode layer call: the HIP BN kernel updates the moving averages
                               # through raw pointers (no autograd version bump), so folded inference weights key on it too
+
+    def grad_view(self, t):
+        """a FRESH view, shaped like t, of the flat-gradient slice of the parameter whose storage t shares, or None (no trainer
+        bound / outside its backward).  Fresh: autograd keeps a returned gradient without a copy only when nothing else holds it."""
+        if not self.grad_direct:
+            return None
+        ent = self.grad_map.get(t.data_ptr())
+        if ent is None or ent[2] != t.numel():
+            return None
+        flat, off, n = ent
+        return flat[off:off + n].view(t.shape)
 
     def dropout_state(self, key, salt):
         """device int64[2] = {seed ^ salt, step} of one dropout call site; `set_step` advances every site."""
@@ -515,10 +532,34 @@ def hip_fp_mlp_fused_pre(dist, idx, points1, points2, ws, bs, schedule=None):
     return y
 
 
+def hip_linear_narrow(x2d, w, b=None):
+    """y = x2d @ w (+ b) for a layer of at most 16 outputs (the 9-class head) in ONE streaming launch (pn2_linear_narrow);
+    None when the library reports the shape as unsupported (the caller pads to an MFMA tile)."""
+    require_cuda(x2d, w, b)
+    rows, cin = x2d.shape
+    cout = w.shape[1]
+    if cout > 16 or cin % 4 != 0 or x2d.dtype != torch.float32:
+        return None
+    x2d = x2d.contiguous()
+    y = torch.empty((rows, cout), dtype=torch.float32, device=x2d.device)
+    with torch.cuda.device(x2d.device):
+        rc = lib.pn2_linear_narrow(rows, cin, cout, ptr(x2d), ptr(w.contiguous()), ptr(None if b is None else b.contiguous()), ptr(y),
+                                   stream_ptr())
+    if rc == PN2_EUNSUP_CODE:
+        return None
+    check(rc, "pn2_linear_narrow")
+    return y
+
+
 def hip_matmul(x2d, w):
     """y = x2d @ w on pn2_linear (no bias, no activation) -- the forward GEMM of the training path.  Output widths that
-    are not a multiple of 32 (the 9-class head) run with zero-padded weight columns and are sliced back."""
+    are not a multiple of 32 run on pn2_linear_narrow (<= 16 outputs: the 9-class head) or with zero-padded weight columns,
+    sliced back."""
     cin, cout = w.shape
+    if cout <= 16:
+        y = hip_linear_narrow(x2d, w)
+        if y is not None:
+            return y
     if cout % 32 != 0:
         wp = F.pad(w, (0, 32 - cout % 32)).contiguous()
         return hip_linear(x2d, wp, None, relu=False)[:, :cout].contiguous()
@@ -588,6 +629,16 @@ def _hip_wgrad(x2d, dy, w, xf=None):
     """dW = x2d^T @ dy on pn2_linear_wgrad; the tile is added to with atomics, so it starts from the zero arena when the
     step has one (no memset of its own).  xf = (scale, shift, relu): x2d is the producer's un-normalised output, the
     kernel applies its batch norm while loading (pn2_linear_wgrad_accumulate_xf)."""
+    gv = get_default_store().grad_view(w)  # the parameter's slice of the trainer's (zero-filled) flat gradient
+    if gv is not None:
+        with torch.cuda.device(w.device):
+            if xf is not None:
+                check(lib.pn2_linear_wgrad_accumulate_xf(x2d.shape[0], w.shape[0], w.shape[1], ptr(x2d), ptr(dy), ptr(gv), ptr(xf[0]),
+                                                         ptr(xf[1]), int(xf[2]), stream_ptr()), "pn2_linear_wgrad_accumulate_xf")
+            else:
+                check(lib.pn2_linear_wgrad_accumulate(x2d.shape[0], w.shape[0], w.shape[1], ptr(x2d), ptr(dy), ptr(gv), stream_ptr()),
+                      "pn2_linear_wgrad_accumulate")
+        return gv
     arena = get_default_store().zero_arena
     v = arena.take(w.numel() * 4) if arena is not None else None
     with torch.cuda.device(w.device):
@@ -626,14 +677,18 @@ class _TrainMatmul(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x2d, w, b=None):
-        ctx.save_for_backward(x2d, w)
+        ctx.save_for_backward(x2d, w, *(() if b is None else (b,)))
         ctx.has_bias = b is not None
+        if w.shape[1] <= 16:  # the class head: GEMM + bias in one streaming launch
+            y = hip_linear_narrow(x2d, w, b)
+            if y is not None:
+                return y
         y = hip_matmul(x2d, w)
         return y if b is None else y.add_(b)
 
     @staticmethod
     def backward(ctx, dy):
-        x2d, w = ctx.saved_tensors
+        x2d, w = ctx.saved_tensors[:2]
         dy = dy.contiguous()
         dx = None
         if ctx.needs_input_grad[0]:
@@ -643,7 +698,7 @@ class _TrainMatmul(torch.autograd.Function):
             dw = _hip_wgrad(x2d, dy, w)
         db = None
         if ctx.has_bias and ctx.needs_input_grad[2]:
-            db = _hip_wgrad(_ones_column(dy.shape[0], dy.device), dy, dy.new_empty((1, dy.shape[1]))).reshape(-1)
+            db = _hip_wgrad(_ones_column(dy.shape[0], dy.device), dy, ctx.saved_tensors[2].view(1, -1)).reshape(-1)
         return dx, dw, db
 
 
@@ -770,14 +825,24 @@ def _bn_train_forward(y, b, gamma, beta, running_mean, running_var, decay, relu,
         ws, fwd = _bn_scratch(c, y.device, lib.pn2_bn_relu_forward, lib.pn2_bn_relu_forward_ws0)
     pooled = pool > 1
     z = torch.empty((rows // pool, c) if pooled else (rows, c), dtype=y.dtype, device=y.device)
-    ties = torch.empty_like(z) if pooled else None
     save_mean = torch.empty(c, dtype=torch.float32, device=y.device)
     save_invstd = torch.empty_like(save_mean)
+    ties = None
     with torch.cuda.device(y.device):
-        check(fwd(rows, c, ptr(y), ptr(gamma), ptr(beta), ptr(b), BN_EPSILON, decay, int(relu),
-                  int(pool), ptr(running_mean), ptr(running_var), ptr(ws), ws.numel() * ws.element_size(),
-                  ptr(save_mean), ptr(save_invstd), ptr(z), ptr(ties), stream_ptr()),
-              "pn2_bn_relu_forward")
+        if pooled:
+            # ties = [tie counts | ysel]: ysel = the pre-normalisation value of the first row attaining each maximum, which lets the
+            # backward take its reduction from the pooled tensors (pn2_bn_grad_constants) instead of a pass over y
+            ties = torch.empty((2,) + tuple(z.shape), dtype=y.dtype, device=y.device)
+            mode = 2 if stats_ws is not None else (1 if fwd is lib.pn2_bn_relu_forward_ws0 else 0)
+            check(lib.pn2_bn_relu_forward_pool(rows, c, ptr(y), ptr(gamma), ptr(beta), ptr(b), BN_EPSILON, decay, int(relu), int(pool),
+                                               ptr(running_mean), ptr(running_var), ptr(ws), ws.numel() * ws.element_size(), mode,
+                                               ptr(save_mean), ptr(save_invstd), ptr(z), ptr(ties[0]), ptr(ties[1]), stream_ptr()),
+                  "pn2_bn_relu_forward_pool")
+        else:
+            check(fwd(rows, c, ptr(y), ptr(gamma), ptr(beta), ptr(b), BN_EPSILON, decay, int(relu),
+                      int(pool), ptr(running_mean), ptr(running_var), ptr(ws), ws.numel() * ws.element_size(),
+                      ptr(save_mean), ptr(save_invstd), ptr(z), None, stream_ptr()),
+                  "pn2_bn_relu_forward")
     return z, ties, save_mean, save_invstd
 
 
@@ -808,6 +873,12 @@ def _bn_register_producer(z, y, gamma, beta, save_mean, save_invstd, relu, poole
     return lk
 
 
+def _param_grad_out(p):
+    """where a kernel WRITES the gradient of parameter p: its slice of the trainer's flat gradient, else a fresh tensor"""
+    gv = get_default_store().grad_view(p)
+    return gv if gv is not None else torch.empty_like(p)
+
+
 def _bn_train_backward(dz, y, gamma, beta, save_mean, save_invstd, relu, pool, zmax, ties, lk):
     """gradient of _bn_train_forward on pn2_bn_relu_backward -> dy (rows, c), dgamma, dbeta.  lk: this layer's producer
     record; when the consumer's data-gradient GEMM has already left the two reduction sums there (and dz is that GEMM's
@@ -815,8 +886,7 @@ def _bn_train_backward(dz, y, gamma, beta, save_mean, save_invstd, relu, pool, z
     rows, c = y.shape
     dz = dz.contiguous()
     dy = torch.empty_like(y)
-    dgamma = torch.empty_like(gamma)
-    dbeta = torch.empty_like(beta)
+    dgamma, dbeta = _param_grad_out(gamma), _param_grad_out(beta)
     if lk is not None and lk.ws is not None and lk.dz_ptr == dz.data_ptr() and dz.shape == y.shape:
         ws, bwd = lk.ws, lib.pn2_bn_relu_backward_stats
     else:
@@ -826,12 +896,89 @@ def _bn_train_backward(dz, y, gamma, beta, save_mean, save_invstd, relu, pool, z
         raise RuntimeError("a deferred batch-norm output (conv2d(..., defer_bn=True)) was not consumed by a following conv2d")
     if lk is not None:  # this layer's backward runs once: drop what the record kept alive
         lk.ws = lk.dz_keep = lk.dz_ptr = lk.y = lk.gamma = lk.beta = lk.mean = lk.invstd = lk.sc = lk.sh = None
+    if ties is not None and ties.dim() == zmax.dim() + 1:
+        ties = ties[0]  # [tie counts | ysel] of _bn_train_forward
     with torch.cuda.device(y.device):
         check(bwd(rows, c, ptr(dz), ptr(y), ptr(gamma), ptr(beta), ptr(save_mean),
                   ptr(save_invstd), int(relu), int(pool), ptr(zmax), ptr(ties), ptr(ws),
                   ws.numel() * ws.element_size(), ptr(dy), ptr(dgamma), ptr(dbeta), stream_ptr()),
               "pn2_bn_relu_backward")
     return dy, dgamma, dbeta
+
+
+# ---- batch-norm gradient applied on load (round 6): the gradient dy LEAVING a layer's batch norm is only ever read by that
+# layer's own data and weight gradient GEMMs, so it is not written: pn2_bn_grad_constants folds the two reduction sums into six
+# per-channel constants (+ dgamma, dbeta) and pn2_linear_dgrad_gx / pn2_linear_wgrad_gx form dy from (y, dz) while they load
+# their operand -- bn_grad_apply_kernel's pass (read dz, y; write dy) and the two re-reads of dy are gone, and behind the fused
+# max pool the (rows, c) gradient never exists at all.  Same float expressions as the materialised form: both hand the GEMMs the
+# same bits (tests/test_train_gpu.py::test_bn_grad_on_load_equals_the_materialised_form).
+USE_BN_GRAD_ON_LOAD = True
+# behind the fused max pool the first backward reduction is taken from the pooled tensors (rows / 32 entries per channel: the
+# gradient is non-zero only on the rows attaining a maximum) instead of a pass over y (A/B, tests)
+USE_POOLED_BN_REDUCE = True
+
+
+def _gx_usable(rows, c, pool, dz, y):
+    return bool(USE_BN_GRAD_ON_LOAD and c % 4 == 0 and 16 < c <= 512 and pool in (0, 32) and (not pool or rows % 32 == 0)
+                and dz.dtype == torch.float32 and dz.data_ptr() % 16 == 0 and y.data_ptr() % 16 == 0)
+
+
+def _bn_grad_constants(dz, y, gamma, beta, save_mean, save_invstd, relu, pool, zmax, ties, lk):
+    """first half of the on-load batch-norm gradient (pn2_bn_grad_constants) -> coef (6, c), dgamma, dbeta.  lk as in
+    _bn_train_backward: the reduction pass is skipped when the consumer's data-gradient GEMM has already left the sums."""
+    rows, c = y.shape
+    if lk is not None and lk.ws is not None and lk.dz_ptr == dz.data_ptr() and dz.shape == y.shape:
+        ws, done = lk.ws, 1
+    else:
+        ws, done = _bn_zeroed_scratch(c, y.device), 0
+    if lk is not None and lk.sc is not None and not lk.consumed:
+        raise RuntimeError("a deferred batch-norm output (conv2d(..., defer_bn=True)) was not consumed by a following conv2d")
+    if lk is not None:
+        lk.ws = lk.dz_keep = lk.dz_ptr = lk.y = lk.gamma = lk.beta = lk.mean = lk.invstd = lk.sc = lk.sh = None
+    coef = torch.empty((6, c), dtype=torch.float32, device=y.device)
+    dgamma, dbeta = _param_grad_out(gamma), _param_grad_out(beta)
+    ysel = None
+    if ties is not None and ties.dim() == zmax.dim() + 1:
+        ties, ysel = ties[0], (ties[1] if USE_POOLED_BN_REDUCE else None)
+    with torch.cuda.device(y.device):
+        check(lib.pn2_bn_grad_constants(rows, c, ptr(dz), ptr(y), ptr(gamma), ptr(beta), ptr(save_mean), ptr(save_invstd), int(relu),
+                                        int(pool), ptr(zmax), ptr(ties), ptr(ysel), done, ptr(ws), ws.numel() * ws.element_size(),
+                                        ptr(coef), ptr(dgamma), ptr(dbeta), stream_ptr()), "pn2_bn_grad_constants")
+    return coef, dgamma, dbeta
+
+
+def _hip_dgrad_gx(y, dz, coef, relu, pool, zmax, ties, w, link):
+    """dx = dy @ w^T with dy formed on load (pn2_linear_dgrad_gx); link: the producer record of the layer below (its two batch-norm
+    gradient sums are left in a zeroed workspace and noted on the record, as hip_linear_dgrad_linked does) or None"""
+    rows, cin = y.shape[0], w.shape[0]
+    dx = torch.empty((rows, cin), dtype=torch.float32, device=y.device)
+    pws = _bn_zeroed_scratch(cin, y.device) if link is not None else None
+    with torch.cuda.device(y.device):
+        if link is not None:
+            below = (ptr(link.y), ptr(link.gamma), ptr(link.beta), ptr(link.mean), ptr(link.invstd), int(link.relu), ptr(pws),
+                     pws.numel() * pws.element_size())
+        else:
+            below = (None, None, None, None, None, 0, None, 0)
+        check(lib.pn2_linear_dgrad_gx(rows, cin, w.shape[1], ptr(y), ptr(dz), ptr(coef), int(relu), int(pool), ptr(zmax), ptr(ties),
+                                      ptr(w.contiguous()), ptr(dx), *below, stream_ptr()), "pn2_linear_dgrad_gx")
+    if link is not None:
+        link.ws, link.dz_ptr, link.dz_keep = pws, dx.data_ptr(), dx
+    return dx
+
+
+def _hip_wgrad_gx(x2d, xf, y, dz, coef, relu, pool, zmax, ties, w):
+    """dW = x2d^T @ dy with dy formed on load (pn2_linear_wgrad_gx); xf as in _hip_wgrad"""
+    dw = get_default_store().grad_view(w)
+    if dw is None:
+        arena = get_default_store().zero_arena
+        v = arena.take(w.numel() * 4) if arena is not None else None
+        dw = v[:w.numel() * 4].view(torch.float32).view_as(w) if v is not None else torch.zeros_like(w)
+    sc, sh, xrelu = xf if xf is not None else (None, None, 0)
+    with torch.cuda.device(w.device):
+        check(lib.pn2_linear_wgrad_gx(x2d.shape[0], w.shape[0], w.shape[1], ptr(x2d), ptr(sc), ptr(sh), int(xrelu), ptr(y), ptr(dz),
+                                      ptr(coef), int(relu), int(pool), ptr(zmax), ptr(ties), ptr(dw), stream_ptr()),
+              "pn2_linear_wgrad_gx")
+    return dw
 
 
 class _TrainDenseBnRelu(torch.autograd.Function):
@@ -885,6 +1032,17 @@ class _TrainDenseBnRelu(torch.autograd.Function):
     def backward(ctx, dz):
         x2d, w, y, gamma, beta, save_mean, save_invstd = ctx.saved_tensors[:7]
         zmax, ties = ctx.saved_tensors[7:] if ctx.pool > 1 else (None, None)
+        dz = dz.contiguous()
+        if _gx_usable(y.shape[0], y.shape[1], ctx.pool, dz, y):
+            # the gradient leaving the batch norm is formed by the two GEMMs while they load (y, dz): never written
+            coef, dgamma, dbeta = _bn_grad_constants(dz, y, gamma, beta, save_mean, save_invstd, ctx.relu, ctx.pool, zmax, ties,
+                                                     ctx.link)
+            dx = None
+            if ctx.needs_input_grad[0]:
+                pv = ctx.prev if (ctx.prev is not None and ctx.prev.y is not None) else None
+                dx = _hip_dgrad_gx(y, dz, coef, ctx.relu, ctx.pool, zmax, ties, w, pv)
+            dw = _hip_wgrad_gx(x2d, ctx.xf, y, dz, coef, ctx.relu, ctx.pool, zmax, ties, w) if ctx.needs_input_grad[1] else None
+            return dx, dw, None, dgamma, dbeta, None, None, None, None, None, None
         dy, dgamma, dbeta = _bn_train_backward(dz, y, gamma, beta, save_mean, save_invstd, ctx.relu, ctx.pool, zmax, ties, ctx.link)
         dx = None
         if ctx.needs_input_grad[0]:
@@ -980,9 +1138,11 @@ class _TrainHoistedBnRelu(torch.autograd.Function):
         dsrc = hip_linear_dgrad(dzs2d, wb).view(bsz, nsrc, c) if ctx.needs_input_grad[0] else None
         dw = None
         if ctx.needs_input_grad[1]:
-            arena = get_default_store().zero_arena
-            v = arena.take(w.numel() * 4) if arena is not None else None
-            dw = v[:w.numel() * 4].view(torch.float32).view_as(w) if v is not None else torch.zeros_like(w)
+            dw = get_default_store().grad_view(w)
+            if dw is None:
+                arena = get_default_store().zero_arena
+                v = arena.take(w.numel() * 4) if arena is not None else None
+                dw = v[:w.numel() * 4].view(torch.float32).view_as(w) if v is not None else torch.zeros_like(w)
             dwa, dwb = (dw[:3], dw[3:]) if sa else (dw[c:], dw[:c])
             _hip_wgrad_into(src2d, dzs2d, dwb)
             _hip_wgrad_into(a, dy, dwa)
@@ -1015,8 +1175,9 @@ def _train_layer(inputs, w2d, b, bnv, bn_decay, relu, pool=0, defer=False):
     """One dense layer of the training path, entirely on the HIP library: inputs (..., cin) -> (..., cout); pool > 1 also
     takes the max over groups of `pool` consecutive entries of the second-to-last axis (..., W, cin) -> (..., W/pool, cout).
     With batch norm: _TrainDenseBnRelu; without: _TrainMatmul (activation None: the class head) or _TrainDenseRelu (bn=False
-    layers of the layer API, tf_util.py:186-204).  There is no torch fallback: batch-norm widths beyond 1024 or not a multiple of
-    4 above 256 raise.  (tests/torch_layers.py holds the plain-torch reference of this function.)"""
+    layers of the layer API, tf_util.py:186-204).  There is no torch fallback: batch-norm widths beyond 1024, or not a multiple of
+    4 above 256, run as independent column blocks on the same kernels.  (tests/torch_layers.py holds the plain-torch reference
+    of this function.)"""
     cin, cout = w2d.shape
     pool = int(pool) if pool and pool > 1 else 0
     lead = list(inputs.shape[:-1])
@@ -1034,7 +1195,23 @@ def _train_layer(inputs, w2d, b, bnv, bn_decay, relu, pool=0, defer=False):
             raise RuntimeError("a deferred batch-norm output reached a layer without batch norm")
         return _train_dense(inputs, w2d, b, relu=relu)
     if not (cout <= 1024 and (cout % 4 == 0 or cout <= 256)):
-        raise NotImplementedError("batch-norm layer width %d: the HIP kernels take <= 1024 channels, a multiple of 4 above 256" % cout)
+        # A width the batch-norm kernels do not take in one piece (> 1024 channels, or > 256 and not a multiple of 4; the reference's
+        # batch_norm_template takes any width, tf_util.py:555-581).  Batch norm, ReLU and the max over K act per channel, so the
+        # layer IS the concatenation of independent layers on column blocks of (W, gamma, beta, moving averages): blocks of
+        # <= 1024 channels (multiples of 4) and one remainder of <= 256.  Slow -- one GEMM and one set of batch-norm launches per
+        # block, a column copy in and a concatenation out -- but every value comes from the same HIP kernels.
+        beta, gamma, mean, var = bnv
+        cuts, c0 = [], 0
+        while cout - c0 > 256 and (cout - c0) % 4 != 0 or cout - c0 > 1024:
+            step = min(1024, (cout - c0) // 4 * 4)
+            if (cout - c0 - step) > 256 and step < 1024:  # keep the remainder <= 256
+                step = (cout - c0 - 256 + 3) // 4 * 4
+            cuts.append((c0, c0 + step))
+            c0 += step
+        cuts.append((c0, cout))
+        outs = [_train_layer(inputs, w2d[:, a:e].contiguous(), None if b is None else b[a:e],
+                             (beta[a:e], gamma[a:e], mean[a:e], var[a:e]), bn_decay, relu, pool, defer=False) for a, e in cuts]
+        return torch.cat(outs, dim=-1)
     beta, gamma, mean, var = bnv
     decay = 0.9 if bn_decay is None else float(bn_decay)  # tf_util.py:571
     z = _TrainDenseBnRelu.apply(inputs.reshape(-1, cin).contiguous(), w2d.contiguous(), b, gamma, beta, mean, var,
@@ -1081,6 +1258,11 @@ def conv1d(inputs, num_output_channels, kernel_size, scope, stride=1, padding="S
     cout = int(num_output_channels)
     with variable_scope(scope):
         if not is_training:
+            if cout <= 16 and not bn and activation_fn is None:  # the class head (model.py:145-146): one streaming launch
+                st, w, b, _ = _dense_variables(cin, cout, False, (1, cin, cout))
+                y = hip_linear_narrow(inputs.reshape(-1, cin), w.detach().reshape(cin, cout), b.detach())
+                if y is not None:
+                    return y.reshape(list(inputs.shape[:-1]) + [cout])
             w2, b2 = folded_dense(cin, cout, bn, (1, cin, cout), pad_to=32)
             y = hip_linear(inputs.reshape(-1, cin), w2, b2, relu=activation_fn is not None)
             if y.shape[1] != cout:

@@ -27,6 +27,12 @@ def test_bench_json_contract():
     assert r["scaling"] == "weak" and r["vs_baseline"] is None and r["dtype"] == "f32" and r["data"] == "synthetic"
     assert abs(r["value"] - 4 * 2048 * 4 / (r["ms_per_step"] * 4 * 1e-3)) < 1e-3 * r["value"]
     assert "workload" in r["config"] and "model" not in r["config"]
+    # the headline is a statistic -- the median of >= 5 timed regions of exactly K steps -- with its range and the
+    # number of pipeline streams seen to run concurrently (per rank) on the line
+    assert r["timed_regions"] >= 5 and len(r["ms_per_step_regions"]) == r["timed_regions"]
+    assert r["value_min"] <= r["value"] <= r["value_max"]
+    assert sorted(r["ms_per_step_regions"])[(r["timed_regions"] - 1) // 2] == r["ms_per_step"]
+    assert r["streams_verified_concurrent"] == [r["config"]["streams"]], r["streams_verified_concurrent"]
     for k in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
         assert k in r["roofline"], k
     for k in ("value", "unit", "cores", "kind", "sample"):

@@ -330,6 +330,62 @@ def test_nested_fps_edge_shapes(pn2, oracle, cuda):
         S.USE_NESTED_FPS = True
 
 
+def test_fps_more_samples_than_points_equals_the_reference_kernel(pn2, oracle, ref, cuda):
+    """VERDICT r05 missing #3: npoint > n.  The reference accepts it (tf_sampling.cpp:116-156 checks only npoint > 0) and its
+    kernel keeps picking once every point is taken -- all running minima are 0, the strict `>` scan and the left-biased tree
+    (tf_sampling.cu:131-175) then answer index 0 -- e.g. [0 5 4 6 7 2 1 3 0 0 0 0] for 12 of 8.  Every sampler entry point of
+    this package == the reference's own kernel (oracle/_ref) == the C restatement: the one-pick register kernels (n = 1, 8, 64),
+    the multi-wave layouts (300, 1536), the lazy kernel (8192-point clouds), a lattice full of ties, the row-strided twin, the
+    nested chain on such a level's output, and the large-scene sampler."""
+    import torch
+    from pn2_amd import _lib
+    S = pn2.tf_ops.tf_sampling
+    lib, ptr = _lib.lib, _lib.ptr
+    cases = [(2, 1, 3, "scene"), (3, 8, 12, "scene"), (2, 64, 100, "grid"), (2, 300, 333, "scene"), (2, 1536, 1600, "randn"),
+             (1, 8192, 8200, "scene"), (2, 27, 64, "lattice")]
+    for b, n, m, kind in cases:
+        if kind == "lattice":  # 3 x 3 x 3 lattice: every step after the first is tied
+            g = np.stack(np.meshgrid(*[np.arange(3)] * 3, indexing="ij"), -1).reshape(-1, 3).astype(np.float32)
+            x = np.stack([g, g[::-1].copy()])
+        else:
+            x = _gen(kind, 11 * n + m, b, n)
+        build = "fast_noslp"
+        want = ref.farthest_point_sample(m, x, build)
+        assert np.array_equal(want, oracle.farthest_point_sample(m, x, FPS_MODE[build])), (n, m)
+        if kind != "lattice" and n > 1:
+            assert (want[:, n:] == 0).all() and sorted(want[0, :n].tolist()) == list(range(n))  # a permutation, then index 0
+        xt = T(x, cuda)
+        set_mode(FPS_MODE[build])
+        got = pn2.farthest_point_sample(m, xt).cpu().numpy()
+        assert np.array_equal(got, want), (n, m, got[0, -8:], want[0, -8:])
+        # fps + gather in one launch, its coordinates, and the chain below it (the tie record of an exhausted cloud must not
+        # let the next level take the shortcut: rows n.. are copies of row 0)
+        idx, new_xyz = S.farthest_point_sample_and_gather(m, xt)
+        assert np.array_equal(idx.cpu().numpy(), want)
+        nx_ref = oracle.gather_point(x, want)
+        assert np.array_equal(new_xyz.cpu().numpy(), nx_ref)
+        m2 = max(1, m // 2)
+        idx2, _ = S.farthest_point_sample_and_gather(m2, new_xyz)
+        assert np.array_equal(idx2.cpu().numpy(), ref.farthest_point_sample(m2, nx_ref, build)), (n, m, m2)
+        # the xyz columns of a wider batch read in place (pn2_fps_nested_ld)
+        wide = torch.zeros((b, n, 6), dtype=torch.float32, device=cuda)
+        wide[:, :, :3] = xt
+        wide[:, :, 3:] = 7.0
+        assert np.array_equal(pn2.farthest_point_sample(m, wide[:, :, 0:3]).cpu().numpy(), want)
+        # the raw entry point without the nested machinery
+        out = torch.full((b, m), -1, dtype=torch.int32, device=cuda)
+        temp = torch.empty((b, n), dtype=torch.float32, device=cuda)
+        _lib.check(lib.pn2_farthest_point_sample(b, n, m, ptr(xt), ptr(temp), ptr(out), FPS_MODE[build], _lib.stream_ptr()),
+                   "pn2_farthest_point_sample")
+        assert np.array_equal(out.cpu().numpy(), want)
+    # the large-scene sampler (pn2_fps_large, configs[4]'s kernel) on a cloud just above the register kernels' limit
+    n, m = 16500, 16600
+    x = s_scene(9, 1, n)
+    want = ref.farthest_point_sample(m, x, "fast_noslp")
+    got = pn2.farthest_point_sample(m, T(x, cuda)).cpu().numpy()
+    assert np.array_equal(got, want), np.argwhere(got != want)[:4]
+
+
 def test_fps_tie_record_sees_three_holders_in_one_lane(pn2, oracle, cuda):
     """the one-pick kernels keep PPT points per lane (k, k+NT, k+2NT, ...); a maximum held by THREE rows of one lane
     (the winner among them) slipped through an OR/XOR parity count.  Three points at distance 1 from the first pick on indices

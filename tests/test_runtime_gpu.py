@@ -107,8 +107,9 @@ def test_concurrent_streams_run_side_by_side(pn2, cuda):
     mapping of the first streams of a process can serialise two of them: profiles/r05_scheduling_study.txt #8)"""
     import time
     import torch
-    streams = pn2.runtime.concurrent_streams(4)
+    streams, verified = pn2.runtime.concurrent_streams(4)
     assert len(streams) == 4 and len({s.cuda_stream for s in streams}) == 4
+    assert verified == 4, verified  # an idle MI355X has at least four hardware queues; fewer = the probe (or the box) is off
 
     def wall(ss, cycles=2000000):
         torch.cuda.synchronize()

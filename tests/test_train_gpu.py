@@ -320,8 +320,36 @@ def test_every_gemm_of_a_real_step_is_as_accurate_as_the_library(pn2, cuda):
                      float(((dy @ w.t()).double() - ref).norm() / ref.norm())))
         return dx
 
+    orig_dgx, orig_nw = tfu._hip_dgrad_gx, tfu.hip_linear_narrow
+
+    def nw(x, w, b=None):  # the 9-class head: GEMM + bias in one streaming launch (pn2_linear_narrow)
+        y = orig_nw(x, w, b)
+        ref = x.double() @ w.double() + (0.0 if b is None else b.double())
+        yt = x @ w if b is None else x @ w + b
+        seen.append(("fwd", tuple(x.shape), w.shape[1], float((y.double() - ref).norm() / ref.norm()),
+                     float((yt.double() - ref).norm() / ref.norm())))
+        return y
+
+    def dgx(y, dz, coef, relu, pool, zmax, ties, w, link):  # the data gradient that forms dy = the batch-norm gradient while loading (y, dz)
+        dx = orig_dgx(y, dz, coef, relu, pool, zmax, ties, w, link)
+        sc, sh, mu, is_, k1, k2 = coef
+        lin = y.double() * sc.double() + sh.double()  # the kernel's fmaf(y, sc, sh): one rounding of the exact value
+        on = (lin > 0) if relu else torch.ones_like(lin, dtype=torch.bool)
+        if pool:
+            t = torch.where(on, lin, torch.zeros_like(lin)).float().view(-1, pool, y.shape[1])
+            g = torch.where(t == zmax.view(-1, 1, y.shape[1]), (dz / ties).view(-1, 1, y.shape[1]), torch.zeros_like(t)).view_as(y)
+        else:
+            g = dz
+        gk = torch.where(on, g, torch.zeros_like(g))
+        dy = sc * (-((y - mu) * is_) * k2 + (gk - k1))
+        ref = dy.double() @ w.double().t()
+        seen.append(("dgrad_gx", tuple(dy.shape), w.shape[0], float((dx.double() - ref).norm() / ref.norm()),
+                     float(((dy @ w.t()).double() - ref).norm() / ref.norm())))
+        return dx
+
     tfu.hip_matmul, tfu.hip_linear_dgrad, tfu.hip_matmul_bn_stats, tfu.hip_linear_dgrad_linked = mm, dg, mm, dg
     tfu.hip_matmul_bn_stats_xf = mmx
+    tfu._hip_dgrad_gx, tfu.hip_linear_narrow = dgx, nw
     try:
         tfu.set_default_store(tfu.VariableStore(device=cuda, seed=5))
         logits, _ = pn2.model.get_model(pc, True, 9, hp, bn_decay=0.5)
@@ -329,9 +357,12 @@ def test_every_gemm_of_a_real_step_is_as_accurate_as_the_library(pn2, cuda):
     finally:
         tfu.hip_matmul, tfu.hip_linear_dgrad, tfu.hip_matmul_bn_stats, tfu.hip_linear_dgrad_linked = orig_mm, orig_dg, orig_mms, orig_dgl
         tfu.hip_matmul_bn_stats_xf = orig_mmx
-    assert sum(1 for s_ in seen if s_[0] == "fwd") == 23 and sum(1 for s_ in seen if s_[0] == "dgrad") == 22
+        tfu._hip_dgrad_gx, tfu.hip_linear_narrow = orig_dgx, orig_nw
+    assert sum(1 for s_ in seen if s_[0] == "fwd") == 23 and sum(1 for s_ in seen if s_[0].startswith("dgrad")) == 22
+    assert sum(1 for s_ in seen if s_[0] == "dgrad_gx") >= 14  # every batch-normalised layer below another dense layer
     for kind, shape, n, e_pn2, e_torch in seen:
-        assert e_pn2 <= 1e-6 and e_pn2 <= 2.0 * e_torch + 1e-8, (kind, shape, n, e_pn2, e_torch)
+        # dgrad_gx: the operand itself is formed in fp32 by the kernel (fma) and by the yardstick (separate ops): + 2e-7
+        assert e_pn2 <= 1e-6 and e_pn2 <= 2.0 * e_torch + (2e-7 if kind == "dgrad_gx" else 1e-8), (kind, shape, n, e_pn2, e_torch)
 
 
 def _batch(cuda, seed=0, b=8, n=2048):
@@ -443,7 +474,7 @@ def _ddp_worker(rank, world, port, capture, q):
     split_graphs = tr._graph is not None and tr._graph_adam is not None
     res = dict(losses=losses, p=tr.flat_p.cpu().numpy(), split=split_graphs, world=tr.bucket.world(),
                scale=float(tr.hyper[4]), late=tr._graph_late is not None)
-    if capture:  # bench.py --train's diagnosis legs on this very job (they perturb the replicas: after the snapshot above)
+    if capture and not os.environ.get("PN2_TWO_RANK_NO_DIAG"):  # bench.py --train's diagnosis legs on this very job (they perturb the replicas: after the snapshot above)
         import argparse
         import bench
         res["diag"] = bench.train_comm_diagnosis(pn2, tr, argparse.Namespace(steps=4), [batches[0][0], batches[1][0]],
@@ -460,14 +491,14 @@ def test_two_rank_captured_step_keeps_replicas_identical(pn2, cuda):
     world = 2: two processes, different data, different initial seeds.  After warm-up + several replays the parameters are
     bit-identical on both ranks (same summed gradient, same 1/world scale, same Adam launch), and they follow the EAGER
     two-rank trajectory (two-bucket all-reduce launched from inside backward)."""
-    # One retry: the comparison is between two separately spawned two-process jobs whose fp32 atomics order differently from run
-    # to run (losses within 3 %, parameters within 5 %); r05 saw one unexplained failure in about ten full-suite runs that did
-    # not reproduce in isolation (5 / 5).  A systematic error (missing / doubled all-reduce, wrong 1 / world) fails both attempts.
-    try:
-        _two_rank_once(pn2, cuda)
-    except AssertionError as ex:
-        print("two-rank comparison failed once, retrying: %r" % (ex,))
-        _two_rank_once(pn2, cuda)
+    # No retry (VERDICT r05 weak #1).  r05 wrapped this in one and recorded neither the assertion nor the values.  r06 ran the
+    # world-2 job 30 x captured + 10 x eager on the GPU box (tools/two_rank_repeat.py, profiles/r06_two_rank_repeat.txt): replicas
+    # bit-identical 40 / 40; between separately spawned jobs the parameters differ by <= 1.5 % and the losses by <= 0.8 % (bounds
+    # here: 5 % / 3 %).  What CAN flip under load is a comparison of timings: bench.train_comm_diagnosis reported
+    # `early_launch_to_reduced_ms` of rank 0 beside `exposed_comm_ms` = the maximum over ranks, and the test asserted the first >=
+    # the second -- with two processes sharing one GPU through gloo, rank 1's wait can exceed rank 0's.  Both are maxima over
+    # ranks now (>= holds by construction: e0 precedes e1 on every rank's stream) and every assertion names itself.
+    _two_rank_once(pn2, cuda)
 
 
 def _two_rank_once(pn2, cuda):
@@ -488,21 +519,27 @@ def _two_rank_once(pn2, cuda):
             pytest.skip("gloo cannot reduce CUDA tensors on this box: %s" % (got,))
         res[capture] = got
     cap, eag = res[True], res[False]
-    assert cap[0]["split"] and cap[1]["split"] and cap[0]["world"] == 2 and cap[0]["scale"] == 0.5
-    assert cap[0]["late"] and cap[1]["late"]  # three segments: the early all-reduce overlapped the SA backward graph
-    assert np.array_equal(cap[0]["p"], cap[1]["p"])  # replicas stay bit-identical through the captured steps
-    assert np.array_equal(eag[0]["p"], eag[1]["p"])
-    np.testing.assert_allclose(cap[0]["losses"][:2], eag[0]["losses"][:2], rtol=1e-4)  # the eager warm-up is the same code
-    np.testing.assert_allclose(cap[0]["losses"], eag[0]["losses"], rtol=3e-2)
+    assert cap[0]["split"] and cap[1]["split"] and cap[0]["world"] == 2 and cap[0]["scale"] == 0.5, "capture layout / 1/world scale"
+    assert cap[0]["late"] and cap[1]["late"], "three segments: the early all-reduce overlaps the SA backward graph"
+    ndiff = int((cap[0]["p"] != cap[1]["p"]).sum())
+    assert ndiff == 0, "captured replicas differ in %d parameters (max %g): a collective / replay ordering error" % (
+        ndiff, float(np.abs(cap[0]["p"] - cap[1]["p"]).max()))
+    assert np.array_equal(eag[0]["p"], eag[1]["p"]), "eager replicas differ"
+    np.testing.assert_allclose(cap[0]["losses"][:2], eag[0]["losses"][:2], rtol=1e-4,
+                               err_msg="the eager warm-up steps of both jobs are the same code")
+    np.testing.assert_allclose(cap[0]["losses"], eag[0]["losses"], rtol=3e-2, err_msg="captured vs eager loss trajectory")
     rel = float(np.linalg.norm(cap[0]["p"] - eag[0]["p"]) / np.linalg.norm(eag[0]["p"]))
-    assert rel <= 5e-2, rel  # a missing or doubled all-reduce / a wrong 1/world would be O(0.1 .. 1)
-    assert cap[0]["losses"] != cap[1]["losses"]  # the ranks did train on different scenes
+    assert rel <= 5e-2, "captured vs eager parameters after 7 steps: rel %g (a missing or doubled all-reduce would be O(0.1 .. 1); " \
+                        "measured 0.015 over 300 job pairs)" % rel
+    assert cap[0]["losses"] != cap[1]["losses"], "the ranks did train on different scenes"
     # the keys bench.py --train --gpus N prints to decompose a multi-rank step, measured on this job
     d = cap[0]["diag"]
-    assert d["allreduce_early_ms"] > 0 and d["allreduce_late_ms"] > 0 and d["early_bytes"] + d["late_bytes"] == 967945 * 4
-    assert d["exposed_comm_ms"] > 0 and d["early_launch_to_reduced_ms"] >= d["exposed_comm_ms"]
-    assert d["ms_per_step_no_comm"] > 0 and abs(d["scaling_efficiency"] - d["ms_per_step_no_comm"] / 1000.0) < 1e-3  # vs the 1000 ms passed in
-    assert d == cap[1]["diag"] or d["exposed_comm_ms"] == cap[1]["diag"]["exposed_comm_ms"]  # maxima over ranks: rank-independent
+    assert d["allreduce_early_ms"] > 0 and d["allreduce_late_ms"] > 0 and d["early_bytes"] + d["late_bytes"] == 967945 * 4, d
+    assert d["exposed_comm_ms"] > 0 and d["early_launch_to_reduced_ms"] >= d["exposed_comm_ms"], \
+        "timings (maxima over ranks): launch of the early bucket -> both reduced must cover end of SA backward -> both reduced: %r" % (d,)
+    assert d["ms_per_step_no_comm"] > 0 and abs(d["scaling_efficiency"] - d["ms_per_step_no_comm"] / 1000.0) < 1e-3, d  # vs the 1000 ms passed in
+    for k in ("exposed_comm_ms", "early_launch_to_reduced_ms", "ms_per_step_no_comm", "allreduce_early_ms", "allreduce_late_ms"):
+        assert d[k] == cap[1]["diag"][k], "%s is a maximum over ranks: rank-independent (%r vs %r)" % (k, d[k], cap[1]["diag"][k])
 
 
 def test_split_capture_with_a_process_group(pn2, cuda):
@@ -581,6 +618,58 @@ def test_trainer_setup_leaves_moving_averages_untouched_and_params_flat(pn2, cud
     # norm never do) the early bucket is packed from inside backward
     assert tr.bucket.early_launched_in_backward and tr.bucket._expected_early < len(tr.bucket.params) - tr.bucket.split
     assert np.isfinite(l0) and np.isfinite(l1)
+
+
+@pytest.mark.parametrize("rows,cin,cout,bias", [(131072, 128, 9, True), (777, 128, 9, False), (100, 64, 16, True), (33, 132, 1, True),
+                                                (4096, 256, 13, False)])
+def test_linear_narrow_vs_fp64(pn2, cuda, rows, cin, cout, bias):
+    """pn2_linear_narrow: the class head (model.py:145-146, conv1d(num_class) without activation) as one streaming launch,
+    y = x @ w + b for <= 16 outputs, against float64; ragged row counts, every lane group of the butterfly."""
+    tfu = pn2.util.tf_util
+    rs = np.random.RandomState(rows % 991 + cout)
+    x = rs.randn(rows, cin).astype(np.float32)
+    w = (rs.randn(cin, cout) / np.sqrt(cin)).astype(np.float32)
+    b = rs.randn(cout).astype(np.float32) if bias else None
+    y = tfu.hip_linear_narrow(T(x, cuda), T(w, cuda), None if b is None else T(b, cuda))
+    assert y is not None and y.shape == (rows, cout)
+    ref = x.astype(np.float64) @ w.astype(np.float64) + (0.0 if b is None else b.astype(np.float64))
+    close(y.cpu().numpy(), ref)
+    assert tfu.hip_linear_narrow(T(x, cuda), T(np.zeros((cin, 17), np.float32), cuda)) is None  # wider: the MFMA path's
+
+
+def test_backward_writes_gradients_straight_into_the_flat_buffer(pn2, cuda):
+    """Round 6: inside a trainer's backward the weight-gradient and batch-norm kernels write every parameter's gradient into its
+    slice of the bucket's flat buffer (VariableStore.grad_view) -- no pack copy -- and outside a trainer the same layers
+    return ordinary tensors.  The flat gradient equals the one the packing path builds (USE direct off)."""
+    import torch
+    hp = dict(pn2.model.SEMANTIC_HYPERPARAMS)
+    hp.update(l1_npoint=128, l2_npoint=64, l3_npoint=32, l4_npoint=16)
+    pc, labels, smpw = _batch(cuda, 5, 4, 1024)
+    flats = {}
+    for direct in (True, False):
+        tr = pn2.train.Trainer(hp, 9, store=pn2.util.tf_util.VariableStore(device=cuda, seed=4), capture=False)
+        tr._lazy_init(pc)
+        if not direct:
+            tr.store.grad_map.clear()
+        copies = []
+        orig = torch._foreach_copy_
+        torch._foreach_copy_ = lambda d, s_: (copies.append(len(d)), orig(d, s_))[1]
+        try:
+            loss, flat = tr._forward_backward(pc, labels, smpw, 0.5)
+        finally:
+            torch._foreach_copy_ = orig
+        flats[direct] = flat.clone()
+        withgrad = [p for p in tr.bucket.params if p.grad is not None]
+        assert len(withgrad) == len(tr.bucket.params)  # finish() binds every p.grad to its view
+        if direct:
+            assert copies == [], copies  # nothing left to pack
+        else:
+            assert sum(copies) > 50
+        assert not tr.store.grad_direct
+    a, b = flats[True], flats[False]
+    # two runs of the same fp32 step already differ by the order of their atomics, amplified through 23 batch norms (DESIGN section 5)
+    assert float((a - b).norm()) <= 5e-2 * float(b.norm()), (float((a - b).norm()), float(b.norm()))
+    assert float(b.abs().max()) > 0
 
 
 def test_eval_after_training_passes_uses_fresh_statistics(pn2, cuda):
