@@ -516,6 +516,16 @@ def bench_train(pn2, args, hp, B, N, rank, world, dev):
     per_rank = pn2.dist.gather_over_ranks(local / args.steps * 1e3, device=dev)
     # ---- diagnosis legs, AFTER the measured region (they perturb the replicas): where a step's time goes when N > 1
     diag = train_comm_diagnosis(pn2, tr, args, pcs, labels, smpw, dev, world, elapsed / args.steps * 1e3)
+    # what the concurrent geometry chain of the NEXT batch costs the step: the captured step replayed back to back on the inputs
+    # resident in its static buffers, nothing on the side stream (single rank; after the measured region: the weights move on)
+    if world == 1 and tr._graph is not None and tr._graph_adam is None:
+        with torch.cuda.stream(tr._stream):
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            for _ in range(args.steps):
+                tr._graph.replay()
+            torch.cuda.synchronize()
+        diag["graph_replay_alone_ms"] = round((time.perf_counter() - t1) / args.steps * 1e3, 4)
     if rank == 0:
         print(json.dumps({
             "metric": "training points/sec through SA+FP stack + head (B=16/GPU, N=%d)" % N,

@@ -618,7 +618,7 @@ int pn2_bn_grad_constants(long long rows, int c, const float *dz, const float *y
                           const float *ties, const float *ysel, int stats_done, void *workspace, size_t workspace_bytes,
                           float *coef, float *dgamma, float *dbeta, void *stream);
 /* pn2_bn_relu_forward with pool > 1 that also keeps ysel (rows / pool, c) = the pre-normalisation value of the first row that
- * attains each pooled maximum.  With it (pn2_bn_grad_constants(..., ysel != NULL, stats_done = 0)) the backward reduction behind
+ * attains each pooled maximum (stats_mode 3: sums there and folded, see pn2_linear_bn_stats_fin).  With it (pn2_bn_grad_constants(..., ysel != NULL, stats_done = 0)) the backward reduction behind
  * the max pool reads the pooled tensors only -- the gradient is non-zero on the rows attaining the maximum, all of which carry
  * zmax -- instead of making a pass over y (rows, c).  stats_mode 0 / 1 / 2 = pn2_bn_relu_forward / _ws0 / _stats. */
 int pn2_bn_relu_forward_pool(long long rows, int c, const float *y, const float *gamma, const float *beta, const float *bias,
@@ -632,6 +632,39 @@ int pn2_linear_dgrad_gx(int rows, int cin, int cout, const float *y, const float
 int pn2_linear_wgrad_gx(int rows, int cin, int cout, const float *x, const float *a_scale, const float *a_shift, int a_relu,
                         const float *y, const float *dz, const float *coef, int relu, int pool, const float *zmax,
                         const float *ties, float *dw, void *stream);
+
+/* "The last workgroup finishes" (round 6): every producer of batch-norm sums used to be followed by a one-block launch that folds
+ * the slot copies of the sums and derives per-channel constants (45 launches of ~5 us per training step, all on the critical
+ * path).  The producers below take a two-level ticket per workgroup instead, and the workgroup that draws the last one does that
+ * work inside the producing launch.
+ *   pn2_linear_bn_stats_fin: pn2_linear_bn_stats (a_scale == NULL) / pn2_linear_bn_stats_xf + finish 1: fold (then
+ *     pn2_bn_relu_forward_mode / pn2_bn_relu_forward_pool with stats_mode 3), or 2: fold + what pn2_bn_relu_forward_deferred
+ *     publishes (save_mean, save_invstd, moving averages, scale / shift; scale == shift == NULL: not wanted).
+ *   pn2_linear_dgrad_fin: pn2_linear_dgrad (dy given, y == NULL) / pn2_linear_dgrad_gx (dy == NULL) + the epilogue of
+ *     pn2_linear_dgrad_bn_grad_stats for the layer below (y_below != NULL) + finish_below 0: none, 1: fold (then
+ *     pn2_bn_relu_backward_mode with stats_mode 3), 3: fold + what pn2_bn_grad_constants publishes for the layer below.
+ *   pn2_bn_relu_forward_mode / pn2_bn_relu_backward_mode: pn2_bn_relu_forward (pool = 0) / pn2_bn_relu_backward with the state
+ *     of the workspace explicit: 0 zero it here, 1 caller zeroed it, 2 sums already there, 3 sums there and folded.
+ * (pn2_bn_relu_forward_deferred with stats_done = 0, pn2_bn_relu_forward / _backward in modes 0 / 1 and pn2_bn_grad_constants
+ * with stats_done = 0 finish inside their own reduction kernel; no signature changes.)  Reference: tf_util.py:186-204,555-581. */
+int pn2_linear_bn_stats_fin(int rows, int cin, int cout, const float *x, const float *w, float *y, void *bn_workspace,
+                            size_t workspace_bytes, const float *a_scale, const float *a_shift, int a_relu, int finish,
+                            const float *gamma, const float *beta, const float *bias, float eps, float decay,
+                            float *running_mean, float *running_var, float *save_mean, float *save_invstd, float *scale,
+                            float *shift, void *stream);
+int pn2_linear_dgrad_fin(int rows, int cin, int cout, const float *dy, const float *y, const float *dz, const float *coef,
+                         int relu, int pool, const float *zmax, const float *ties, const float *w, float *dx,
+                         const float *y_below, const float *gamma_below, const float *beta_below, const float *mean_below,
+                         const float *invstd_below, int relu_below, void *ws_below, size_t ws_below_bytes, int finish_below,
+                         float *coef_below, float *dgamma_below, float *dbeta_below, void *stream);
+int pn2_bn_relu_forward_mode(long long rows, int c, const float *y, const float *gamma, const float *beta, const float *bias,
+                             float eps, float decay, int relu, float *running_mean, float *running_var, void *workspace,
+                             size_t workspace_bytes, int stats_mode, float *save_mean, float *save_invstd, float *z,
+                             void *stream);
+int pn2_bn_relu_backward_mode(long long rows, int c, const float *dz, const float *y, const float *gamma, const float *beta,
+                              const float *save_mean, const float *save_invstd, int relu, int pool, const float *zmax,
+                              const float *ties, void *workspace, size_t workspace_bytes, int stats_mode, float *dy,
+                              float *dgamma, float *dbeta, void *stream);
 
 /* First layer of an SA / FP module of the TRAINING path with its feature half applied to the source rows (gather and
  * interpolation are linear and commute with a 1x1 conv):

@@ -97,6 +97,17 @@ SIGNATURES = {
                                        c_void_p, c_int, c_void_p, ctypes.c_size_t, c_void_p],
     "pn2_bn_relu_backward_stats": [ctypes.c_longlong, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int,
                                    c_int, c_void_p, c_void_p, c_void_p, ctypes.c_size_t, c_void_p, c_void_p, c_void_p, c_void_p],
+    "pn2_linear_bn_stats_fin": [c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, ctypes.c_size_t, c_void_p, c_void_p,
+                                c_int, c_int, c_void_p, c_void_p, c_void_p, c_float, c_float, c_void_p, c_void_p, c_void_p,
+                                c_void_p, c_void_p, c_void_p, c_void_p],
+    "pn2_linear_dgrad_fin": [c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p,
+                             c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p,
+                             ctypes.c_size_t, c_int, c_void_p, c_void_p, c_void_p, c_void_p],
+    "pn2_bn_relu_forward_mode": [ctypes.c_longlong, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_float, c_int,
+                                 c_void_p, c_void_p, c_void_p, ctypes.c_size_t, c_int, c_void_p, c_void_p, c_void_p, c_void_p],
+    "pn2_bn_relu_backward_mode": [ctypes.c_longlong, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int,
+                                  c_int, c_void_p, c_void_p, c_void_p, ctypes.c_size_t, c_int, c_void_p, c_void_p, c_void_p,
+                                  c_void_p],
     "pn2_linear_narrow": [c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p],
     "pn2_bn_grad_constants": [ctypes.c_longlong, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int,
                               c_void_p, c_void_p, c_void_p, c_int, c_void_p, ctypes.c_size_t, c_void_p, c_void_p, c_void_p, c_void_p],
@@ -199,7 +210,8 @@ _raw = _load()
 # entry points that mutate caller state beyond their outputs (moving averages): never launched twice by the dup hook
 _STATEFUL = frozenset({"pn2_bn_relu_forward", "pn2_bn_relu_forward_ws0", "pn2_bn_relu_forward_stats", "pn2_linear_bn_stats",
                        "pn2_bn_relu_forward_pool", "pn2_bn_relu_forward_deferred", "pn2_linear_bn_stats_xf", "pn2_linear_wgrad_gx",
-                       "pn2_linear_wgrad_accumulate_xf", "pn2_bn_grad_constants", "pn2_linear_dgrad_gx",
+                       "pn2_linear_wgrad_accumulate_xf", "pn2_bn_grad_constants", "pn2_linear_dgrad_gx", "pn2_linear_dgrad_fin",
+                       "pn2_linear_bn_stats_fin", "pn2_bn_relu_forward_mode", "pn2_linear_dgrad_bn_grad_stats",
                        "pn2_adam_step", "pn2_linear_wgrad_accumulate"})
 
 

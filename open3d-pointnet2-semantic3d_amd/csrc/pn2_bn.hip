@@ -55,7 +55,7 @@ __device__ __forceinline__ void bn_load(const float* __restrict__ p, float (&v)[
 // ws[kBnHead .. kBnHead+NS*c), the sums every consumer reads)
 template <int VEC, int NS>
 __device__ __forceinline__ void bn_block_sums(const BnMap<VEC>& mp, int c, int nslots, double (&part)[NS][VEC],
-                                              double* __restrict__ ws) {
+                                              double* __restrict__ ws, const Pn2BnFinish& fin) {
     __shared__ double red[kBnThreads * NS * VEC];
     if (mp.active) {
 #pragma unroll
@@ -86,6 +86,7 @@ __device__ __forceinline__ void bn_block_sums(const BnMap<VEC>& mp, int c, int n
             for (int v = 0; v < VEC; ++v)
                 atomicAdd(&slot[(size_t)s * c + mp.cc * VEC + v], red[((s * VEC + v) * mp.rp) * mp.cv + mp.cc]);
     }
+    pn2_bn_finish(fin, gridDim.x, blockIdx.x);  // the last workgroup folds the copies (and derives the constants)
 }
 
 // final[col] = sum over the slot copies.  A launch of its own rather than a "last block folds" epilogue: that variant
@@ -106,7 +107,8 @@ bn_fold_kernel(int cols, int nslots, double* __restrict__ ws) {
 // acc[0][ch] = sum_r y[r][ch], acc[1][ch] = sum_r y[r][ch]^2 over the block's slab of rows
 template <int VEC>
 __global__ void __launch_bounds__(kBnThreads)
-bn_stats_kernel(long long rows, int c, long long slab, int nslots, const float* __restrict__ y, double* __restrict__ ws) {
+bn_stats_kernel(long long rows, int c, long long slab, int nslots, const float* __restrict__ y, double* __restrict__ ws,
+                Pn2BnFinish fin) {
     const BnMap<VEC> mp(c);
     const long long rb = (long long)blockIdx.x * slab;
     const long long re = rb + slab < rows ? rb + slab : rows;
@@ -141,7 +143,7 @@ bn_stats_kernel(long long rows, int c, long long slab, int nslots, const float* 
             }
         }
     }
-    bn_block_sums<VEC, 2>(mp, c, nslots, part, ws);
+    bn_block_sums<VEC, 2>(mp, c, nslots, part, ws, fin);
 }
 
 // bn_scale_shift (the per-channel constants of the normalisation): pn2_common.h
@@ -364,7 +366,8 @@ __global__ void __launch_bounds__(kBnThreads)
 bn_grad_reduce_kernel(long long rows, int c, long long slab, int nslots, const float* __restrict__ dz, const float* __restrict__ y,
                       const float* __restrict__ gamma, const float* __restrict__ beta,
                       const float* __restrict__ save_mean, const float* __restrict__ save_invstd, int relu, int pool,
-                      const float* __restrict__ zmax, const float* __restrict__ ties, double* __restrict__ ws) {
+                      const float* __restrict__ zmax, const float* __restrict__ ties, double* __restrict__ ws,
+                      Pn2BnFinish fin) {
     const BnMap<VEC> mp(c);
     const long long rb = (long long)blockIdx.x * slab;
     const long long re = rb + slab < rows ? rb + slab : rows;
@@ -414,7 +417,7 @@ bn_grad_reduce_kernel(long long rows, int c, long long slab, int nslots, const f
             take(r, a0);
         }
     }
-    bn_block_sums<VEC, 2>(mp, c, nslots, part, ws);
+    bn_block_sums<VEC, 2>(mp, c, nslots, part, ws, fin);
 }
 
 // backward pass 1 behind the fused max pool, from the POOLED tensors alone (groups = rows / pool entries per channel instead of
@@ -427,7 +430,7 @@ template <int VEC>
 __global__ void __launch_bounds__(kBnThreads)
 bn_grad_reduce_pooled_kernel(long long groups, int c, long long slab, int nslots, const float* __restrict__ dzp,
                              const float* __restrict__ zmax, const float* __restrict__ ysel, const float* __restrict__ save_mean,
-                             const float* __restrict__ save_invstd, int relu, double* __restrict__ ws) {
+                             const float* __restrict__ save_invstd, int relu, double* __restrict__ ws, Pn2BnFinish fin) {
     const BnMap<VEC> mp(c);
     const long long gb = (long long)blockIdx.x * slab;
     const long long ge = gb + slab < groups ? gb + slab : groups;
@@ -453,7 +456,7 @@ bn_grad_reduce_pooled_kernel(long long groups, int c, long long slab, int nslots
             }
         }
     }
-    bn_block_sums<VEC, 2>(mp, c, nslots, part, ws);
+    bn_block_sums<VEC, 2>(mp, c, nslots, part, ws, fin);
 }
 
 // backward pass 2: dy = sc * (g - mean(g) - xhat * mean(g * xhat)); block 0 publishes dgamma = sum g*xhat, dbeta = sum g
@@ -539,6 +542,12 @@ int bn_plan(long long rows, int c, const void* a, const void* b, const void* o, 
     return PN2_OK;
 }
 
+Pn2BnFinish bn_finish_fold(long long rows, int c, int nslots, double* ws) {
+    Pn2BnFinish f{};
+    f.kind = 1; f.c = c; f.nslots = nslots; f.rows = rows; f.ws = ws;
+    return f;
+}
+
 }  // namespace
 
 #ifdef PN2_TUNING_HOOKS
@@ -555,7 +564,8 @@ static int bn_relu_forward_impl(long long rows, int c, const float* y, const flo
                                 float* running_var, void* workspace, size_t workspace_bytes, float* save_mean,
                                 float* save_invstd, float* z, float* ties, void* stream, int mode, float* ysel = nullptr) {
     // mode 0: zero the workspace here; 1: the caller zeroed it; 2: the caller zeroed it AND pn2_linear_bn_stats has already
-    // added the column sums of y to all kBnSlots slot copies (no statistics pass)
+    // added the column sums of y to all kBnSlots slot copies (no statistics pass); 3: ... and the GEMM's last workgroup has folded
+    // them too (pn2_linear_bn_stats_fin): only the normalisation is left
     if (!y || !gamma || !beta || !workspace || !save_mean || !save_invstd || !z) return PN2_ENULL;
     if ((running_mean == nullptr) != (running_var == nullptr)) return PN2_ENULL;
     if (pool > 1 && !ties) return PN2_ENULL;
@@ -571,8 +581,9 @@ static int bn_relu_forward_impl(long long rows, int c, const float* y, const flo
         hipError_t e = hipMemsetAsync(ws, 0, sizeof(double) * bn_ws_doubles(c, p.nslots), st);
         if (e != hipSuccess) return (int)e;
     }
-    if (mode == 2) p.nslots = kBnSlots;
+    if (mode >= 2) p.nslots = kBnSlots;
     const int fold_blocks = (2 * c + kBnThreads - 1) / kBnThreads;
+    const Pn2BnFinish fin = bn_finish_fold(rows, c, p.nslots, ws);  // the statistics kernel's last workgroup folds the copies
     long long pb = 1;  // pooled apply: one group per (thread row slot), grid-stride beyond 8 blocks per CU
     if (pool > 1) {
         const int rp = kBnThreads / (c / p.vec);
@@ -581,8 +592,8 @@ static int bn_relu_forward_impl(long long rows, int c, const float* y, const flo
     }
 #define PN2_BN_FWD(V_)                                                                                                   \
     do {                                                                                                                 \
-        if (mode != 2) bn_stats_kernel<V_><<<p.stat_blocks, kBnThreads, 0, st>>>(rows, c, p.slab, p.nslots, y, ws);       \
-        bn_fold_kernel<<<fold_blocks, kBnThreads, 0, st>>>(2 * c, p.nslots, ws);                                          \
+        if (mode < 2) bn_stats_kernel<V_><<<p.stat_blocks, kBnThreads, 0, st>>>(rows, c, p.slab, p.nslots, y, ws, fin);   \
+        if (mode == 2) bn_fold_kernel<<<fold_blocks, kBnThreads, 0, st>>>(2 * c, p.nslots, ws);                           \
         if (pool > 1)                                                                                                    \
             bn_apply_pool_kernel<V_><<<(int)pb, kBnThreads, 0, st>>>(rows, c, pool, y, acc, gamma, beta, bias, eps, decay, \
                                                                    relu, running_mean, running_var, save_mean,           \
@@ -626,13 +637,14 @@ extern "C" int pn2_bn_relu_forward_stats(long long rows, int c, const float* y, 
 
 // pn2_bn_relu_forward with pool > 1 that also keeps ysel (rows / pool, c): the pre-normalisation value of the first row attaining
 // each pooled maximum -- what lets the backward take its reduction from the pooled tensors alone (pn2_bn_grad_constants).
-// stats_mode 0: zero the workspace here; 1: the caller zeroed it; 2: pn2_linear_bn_stats already left the column sums in it.
+// stats_mode 0: zero the workspace here; 1: the caller zeroed it; 2: pn2_linear_bn_stats already left the column sums in it;
+// 3: pn2_linear_bn_stats_fin left them there AND folded.
 extern "C" int pn2_bn_relu_forward_pool(long long rows, int c, const float* y, const float* gamma, const float* beta,
                                         const float* bias, float eps, float decay, int relu, int pool, float* running_mean,
                                         float* running_var, void* workspace, size_t workspace_bytes, int stats_mode,
                                         float* save_mean, float* save_invstd, float* zmax, float* ties, float* ysel,
                                         void* stream) {
-    if (pool <= 1 || stats_mode < 0 || stats_mode > 2) return PN2_EINVAL;
+    if (pool <= 1 || stats_mode < 0 || stats_mode > 3) return PN2_EINVAL;
     if (!ysel) return PN2_ENULL;
     if ((c % 4 == 0) && ((uintptr_t)ysel % 16) != 0) return PN2_EINVAL;
     return bn_relu_forward_impl(rows, c, y, gamma, beta, bias, eps, decay, relu, pool, running_mean, running_var, workspace,
@@ -659,14 +671,18 @@ extern "C" int pn2_bn_relu_forward_deferred(long long rows, int c, const float* 
     double* ws = static_cast<double*>(workspace);
     if (stats_done) {
         p.nslots = kBnSlots;
-    } else if (p.vec == 4) {
-        bn_stats_kernel<4><<<p.stat_blocks, kBnThreads, 0, st>>>(rows, c, p.slab, p.nslots, y, ws);
-    } else {
-        bn_stats_kernel<1><<<p.stat_blocks, kBnThreads, 0, st>>>(rows, c, p.slab, p.nslots, y, ws);
+        bn_constants_kernel<<<(c + kBnThreads - 1) / kBnThreads, kBnThreads, 0, st>>>(rows, c, p.nslots, ws, gamma, beta, bias, eps,
+                                                                                     decay, running_mean, running_var, save_mean,
+                                                                                     save_invstd, scale, shift);
+    } else {  // one launch: the statistics kernel's last workgroup folds the copies and publishes the constants
+        Pn2BnFinish f{};
+        f.kind = 2; f.c = c; f.nslots = p.nslots; f.rows = rows; f.ws = ws;
+        f.gamma = gamma; f.beta = beta; f.bias = bias; f.eps = eps; f.decay = decay;
+        f.running_mean = running_mean; f.running_var = running_var; f.save_mean = save_mean; f.save_invstd = save_invstd;
+        f.scale = scale; f.shift = shift;
+        if (p.vec == 4) bn_stats_kernel<4><<<p.stat_blocks, kBnThreads, 0, st>>>(rows, c, p.slab, p.nslots, y, ws, f);
+        else bn_stats_kernel<1><<<p.stat_blocks, kBnThreads, 0, st>>>(rows, c, p.slab, p.nslots, y, ws, f);
     }
-    bn_constants_kernel<<<(c + kBnThreads - 1) / kBnThreads, kBnThreads, 0, st>>>(rows, c, p.nslots, ws, gamma, beta, bias, eps,
-                                                                                 decay, running_mean, running_var, save_mean,
-                                                                                 save_invstd, scale, shift);
     PN2_RETURN_IF_LAUNCH_FAILED();
     return PN2_OK;
 }
@@ -676,11 +692,12 @@ static int bn_relu_backward_impl(long long rows, int c, const float* dz, const f
                                  int pool, const float* zmax, const float* ties, void* workspace,
                                  size_t workspace_bytes, float* dy, float* dgamma, float* dbeta, void* stream, int mode) {
     // mode 0: zero the workspace here; 1: the caller zeroed it; 2: the caller zeroed it AND pn2_linear_dgrad_bn_grad_stats has
-    // already added (sum g, sum g * xhat) to all kBnSlots slot copies while it produced dz (no reduction pass; pool <= 1)
+    // already added (sum g, sum g * xhat) to all kBnSlots slot copies while it produced dz (no reduction pass; pool <= 1);
+    // 3: ... and that GEMM's last workgroup has folded them (pn2_linear_dgrad_fin, finish kind 1)
     if (!dz || !y || !gamma || !beta || !save_mean || !save_invstd || !workspace || !dy || !dgamma || !dbeta) return PN2_ENULL;
     if (pool > 1 && (!zmax || !ties)) return PN2_ENULL;
     if (pool > 1 && (rows % pool != 0 || dy == dz)) return PN2_EINVAL;
-    if (mode == 2 && pool > 1) return PN2_EINVAL;
+    if (mode >= 2 && pool > 1) return PN2_EINVAL;
     BnPlan p;
     int rc = bn_plan(rows, c, dz, y, dy, p);
     if (rc != PN2_OK) return rc;
@@ -693,14 +710,15 @@ static int bn_relu_backward_impl(long long rows, int c, const float* dz, const f
         hipError_t e = hipMemsetAsync(ws, 0, sizeof(double) * bn_ws_doubles(c, p.nslots), st);
         if (e != hipSuccess) return (int)e;
     }
-    if (mode == 2) p.nslots = kBnSlots;
+    if (mode >= 2) p.nslots = kBnSlots;
     const int fold_blocks = (2 * c + kBnThreads - 1) / kBnThreads;
+    const Pn2BnFinish fin = bn_finish_fold(rows, c, p.nslots, ws);  // the reduction's last workgroup folds the copies
 #define PN2_BN_BWD(V_)                                                                                                  \
     do {                                                                                                                \
-        if (mode != 2)                                                                                                  \
+        if (mode < 2)                                                                                                   \
             bn_grad_reduce_kernel<V_><<<p.stat_blocks, kBnThreads, 0, st>>>(rows, c, p.slab, p.nslots, dz, y, gamma, beta, \
-                                                                          save_mean, save_invstd, relu, pool, zmax, ties, ws); \
-        bn_fold_kernel<<<fold_blocks, kBnThreads, 0, st>>>(2 * c, p.nslots, ws);                                         \
+                                                                          save_mean, save_invstd, relu, pool, zmax, ties, ws, fin); \
+        if (mode == 2) bn_fold_kernel<<<fold_blocks, kBnThreads, 0, st>>>(2 * c, p.nslots, ws);                          \
         bn_grad_apply_kernel<V_><<<p.apply_blocks, kBnThreads, 0, st>>>(rows, c, dz, y, acc, gamma, beta, save_mean,     \
                                                                       save_invstd, relu, pool, zmax, ties, dy, dgamma,  \
                                                                       dbeta);                                           \
@@ -757,26 +775,57 @@ extern "C" int pn2_bn_grad_constants(long long rows, int c, const float* dz, con
     double* ws = static_cast<double*>(workspace);
     if (stats_done) {
         p.nslots = kBnSlots;
-    } else if (pool > 1 && ysel) {  // the reduction from the pooled tensors alone: rows / pool entries per channel
+        bn_grad_constants_kernel<<<(c + kBnThreads - 1) / kBnThreads, kBnThreads, 0, st>>>(rows, c, p.nslots, ws, gamma, beta,
+                                                                                          save_mean, save_invstd, coef, dgamma, dbeta);
+        PN2_RETURN_IF_LAUNCH_FAILED();
+        return PN2_OK;
+    }
+    // one launch: the reduction's last workgroup folds the copies and publishes the constants
+    Pn2BnFinish f{};
+    f.kind = 3; f.c = c; f.rows = rows; f.ws = ws;
+    f.gamma = gamma; f.beta = beta; f.mean_in = save_mean; f.invstd_in = save_invstd;
+    f.coef = coef; f.dgamma = dgamma; f.dbeta = dbeta;
+    if (pool > 1 && ysel) {  // the reduction from the pooled tensors alone: rows / pool entries per channel
         BnPlan q;
         const int rq = bn_plan(rows / pool, c, dz, zmax, ysel, q);
         if (rq != PN2_OK) return rq;
-        p.nslots = q.nslots;
+        f.nslots = q.nslots;
         if (q.vec == 4)
             bn_grad_reduce_pooled_kernel<4><<<q.stat_blocks, kBnThreads, 0, st>>>(rows / pool, c, q.slab, q.nslots, dz, zmax, ysel,
-                                                                                save_mean, save_invstd, relu, ws);
+                                                                                save_mean, save_invstd, relu, ws, f);
         else
             bn_grad_reduce_pooled_kernel<1><<<q.stat_blocks, kBnThreads, 0, st>>>(rows / pool, c, q.slab, q.nslots, dz, zmax, ysel,
-                                                                                save_mean, save_invstd, relu, ws);
-    } else if (p.vec == 4) {
-        bn_grad_reduce_kernel<4><<<p.stat_blocks, kBnThreads, 0, st>>>(rows, c, p.slab, p.nslots, dz, y, gamma, beta, save_mean,
-                                                                     save_invstd, relu, pool, zmax, ties, ws);
+                                                                                save_mean, save_invstd, relu, ws, f);
     } else {
-        bn_grad_reduce_kernel<1><<<p.stat_blocks, kBnThreads, 0, st>>>(rows, c, p.slab, p.nslots, dz, y, gamma, beta, save_mean,
-                                                                     save_invstd, relu, pool, zmax, ties, ws);
+        f.nslots = p.nslots;
+        if (p.vec == 4)
+            bn_grad_reduce_kernel<4><<<p.stat_blocks, kBnThreads, 0, st>>>(rows, c, p.slab, p.nslots, dz, y, gamma, beta, save_mean,
+                                                                         save_invstd, relu, pool, zmax, ties, ws, f);
+        else
+            bn_grad_reduce_kernel<1><<<p.stat_blocks, kBnThreads, 0, st>>>(rows, c, p.slab, p.nslots, dz, y, gamma, beta, save_mean,
+                                                                         save_invstd, relu, pool, zmax, ties, ws, f);
     }
-    bn_grad_constants_kernel<<<(c + kBnThreads - 1) / kBnThreads, kBnThreads, 0, st>>>(rows, c, p.nslots, ws, gamma, beta, save_mean,
-                                                                                      save_invstd, coef, dgamma, dbeta);
     PN2_RETURN_IF_LAUNCH_FAILED();
     return PN2_OK;
+}
+
+// pn2_bn_relu_forward / pn2_bn_relu_backward with the state of the workspace given explicitly (the numbered modes of the two
+// implementations above; 3 = the sums are there AND folded, left by pn2_linear_bn_stats_fin / pn2_linear_dgrad_fin with finish
+// kind 1): the one-block fold launch between a GEMM and the normalisation pass is gone.
+extern "C" int pn2_bn_relu_forward_mode(long long rows, int c, const float* y, const float* gamma, const float* beta,
+                                        const float* bias, float eps, float decay, int relu, float* running_mean,
+                                        float* running_var, void* workspace, size_t workspace_bytes, int stats_mode,
+                                        float* save_mean, float* save_invstd, float* z, void* stream) {
+    if (stats_mode < 0 || stats_mode > 3) return PN2_EINVAL;
+    return bn_relu_forward_impl(rows, c, y, gamma, beta, bias, eps, decay, relu, 0, running_mean, running_var, workspace,
+                                workspace_bytes, save_mean, save_invstd, z, nullptr, stream, stats_mode);
+}
+extern "C" int pn2_bn_relu_backward_mode(long long rows, int c, const float* dz, const float* y, const float* gamma,
+                                         const float* beta, const float* save_mean, const float* save_invstd, int relu,
+                                         int pool, const float* zmax, const float* ties, void* workspace,
+                                         size_t workspace_bytes, int stats_mode, float* dy, float* dgamma, float* dbeta,
+                                         void* stream) {
+    if (stats_mode < 0 || stats_mode > 3) return PN2_EINVAL;
+    return bn_relu_backward_impl(rows, c, dz, y, gamma, beta, save_mean, save_invstd, relu, pool, zmax, ties, workspace,
+                                 workspace_bytes, dy, dgamma, dbeta, stream, stats_mode);
 }

@@ -25,9 +25,11 @@
     } while (0)
 
 // Training-mode batch-norm workspace (pn2_bn.hip; pn2_linear_bn_stats in pn2_linear.hip writes into it), in doubles:
-//   reserved[kPn2BnHead] | final[2][c] | slot[nslots][2][c], nslots <= kPn2BnSlots chosen per call
-constexpr int kPn2BnHead = 8;    // doubles reserved in front (alignment of the sums to 64 bytes)
+//   head[kPn2BnHead] | final[2][c] | slot[nslots][2][c], nslots <= kPn2BnSlots chosen per call
+// head (zeroed with the rest of the workspace) holds the ticket counters of pn2_bn_finish: 64 first-level + 1 second-level.
+constexpr int kPn2BnHead = 48;   // doubles in front: 384 bytes, keeps the sums 64-byte aligned
 constexpr int kPn2BnSlots = 64;  // most copies of the per-channel accumulators the producers spread their atomics over
+constexpr int kPn2BnTickets = 64;
 __host__ __device__ inline size_t pn2_bn_ws_doubles(int c, int nslots) { return kPn2BnHead + (size_t)(1 + nslots) * 2 * (size_t)c; }
 
 // per-channel constants of the normalisation, identical float expressions in the forward and the backward kernels so
@@ -36,6 +38,124 @@ __host__ __device__ inline size_t pn2_bn_ws_doubles(int c, int nslots) { return 
 __device__ __forceinline__ void bn_scale_shift(float gamma, float beta, float mean, float invstd, float& sc, float& sh) {
     sc = gamma * invstd;
     sh = __builtin_fmaf(-mean, sc, beta);
+}
+
+// ---- "the last workgroup finishes": what follows a batch-norm reduction, inside the kernel that produced the sums ------------
+// Every producer of per-channel sums (the GEMM epilogues of pn2_linear.hip, the reduction kernels of pn2_bn.hip) used to be
+// followed by a one-block launch that folds the slot copies and derives per-channel constants: 45 launches of ~5 us per training
+// step, each on the critical path.  Instead every workgroup takes a ticket once its atomics have been performed, and the one
+// that draws the last ticket does that work.  Same-address atomics retire one after another (~0.1 us each), so the ticket is
+// two-level: workgroup L counts on counter L % 64, the last arrival of each counter counts on the second level.
+//   * a workgroup's sums are device-scope atomics (performed at the coherence point, not in its XCD's L2); `s_waitcnt vmcnt(0)`
+//     in every wave + the workgroup barrier make them complete before the ticket is drawn;
+//   * the finishing workgroup reads the slot copies with device-scope (sc1) loads, which bypass its XCD's non-coherent L2;
+//   * what it writes (folded sums, constants) is read by LATER kernels only.
+// kind: 0 nothing, 1 fold only, 2 fold + forward constants (bn_constants_kernel), 3 fold + gradient constants
+// (bn_grad_constants_kernel).
+struct Pn2BnFinish {
+    int kind;
+    int c, nslots;
+    long long rows;
+    double* ws;
+    const float* gamma;
+    const float* beta;
+    const float* bias;          // kind 2 (may be null)
+    const float* mean_in;       // kind 3: saved moments of the forward
+    const float* invstd_in;
+    float eps, decay;           // kind 2
+    float* running_mean;        // kind 2 (may be null, both or none)
+    float* running_var;
+    float* save_mean;           // kind 2
+    float* save_invstd;
+    float* scale;               // kind 2 (may be null: the consumer derives them from the folded sums)
+    float* shift;
+    float* coef;                // kind 3: (6, c)
+    float* dgamma;
+    float* dbeta;
+};
+
+__device__ __forceinline__ double pn2_load_device_scope(const double* p) {
+    return __longlong_as_double((long long)__hip_atomic_load(reinterpret_cast<const unsigned long long*>(p), __ATOMIC_RELAXED,
+                                                             __HIP_MEMORY_SCOPE_AGENT));
+}
+
+// Call from EVERY thread of EVERY workgroup of the producing kernel, after the workgroup's last atomic on f.ws (uniform control
+// flow: contains workgroup barriers).  nwg = workgroups of the launch, wg = this workgroup's linear index.
+__device__ __forceinline__ void pn2_bn_finish(const Pn2BnFinish& f, unsigned nwg, unsigned wg) {
+    if (f.kind == 0) return;
+    __shared__ int s_last;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's atomics have been performed
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        unsigned* tick = reinterpret_cast<unsigned*>(f.ws);
+        const unsigned g = wg % (unsigned)kPn2BnTickets;
+        const unsigned ng = nwg < (unsigned)kPn2BnTickets ? nwg : (unsigned)kPn2BnTickets;  // first-level counters in use
+        const unsigned expect = nwg / kPn2BnTickets + (g < nwg % kPn2BnTickets ? 1u : 0u);  // workgroups counting on counter g
+        int last = 0;
+        if (__hip_atomic_fetch_add(tick + g, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == expect - 1u)
+            last = __hip_atomic_fetch_add(tick + kPn2BnTickets, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == ng - 1u;
+        s_last = last;
+    }
+    __syncthreads();
+    if (!s_last) return;
+    const int c = f.c;
+    // fold: one thread per COLUMN of the 2c sums, 16 copies in flight per thread (a device-scope load is a ~1 us round trip: the
+    // chain of batches is this tail's duration), added in slot order like bn_fold_kernel; the two sums of a channel then meet in LDS
+    for (int col = threadIdx.x; col < 2 * c; col += blockDim.x) {
+        double t = 0.0;
+        const double* sl = f.ws + kPn2BnHead + (size_t)2 * c + col;
+        int k = 0;
+        for (; k + 16 <= f.nslots; k += 16) {
+            double v[16];
+#pragma unroll
+            for (int u = 0; u < 16; ++u) v[u] = pn2_load_device_scope(sl + (size_t)2 * c * (k + u));
+#pragma unroll
+            for (int u = 0; u < 16; ++u) t += v[u];
+        }
+        for (; k < f.nslots; ++k) t += pn2_load_device_scope(sl + (size_t)2 * c * k);
+        f.ws[kPn2BnHead + col] = t;
+    }
+    if (f.kind == 1) return;
+    __threadfence_block();  // the folded sums were stored by other threads of THIS workgroup: visible after the barrier
+    __syncthreads();
+    for (int ch = threadIdx.x; ch < c; ch += blockDim.x) {
+        const double s1 = __hip_atomic_load(f.ws + kPn2BnHead + ch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        const double s2 = __hip_atomic_load(f.ws + kPn2BnHead + c + ch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        const double inv_n = 1.0 / (double)f.rows;
+        if (f.kind == 2) {  // bn_constants_kernel
+            const double mean_d = s1 * inv_n;
+            double var_d = s2 * inv_n - mean_d * mean_d;
+            var_d = var_d > 0.0 ? var_d : 0.0;
+            const float mean = (float)mean_d;
+            const float invstd = (float)(1.0 / __builtin_sqrt(var_d + (double)f.eps));
+            if (f.scale) {
+                float sc, sh;
+                bn_scale_shift(f.gamma[ch], f.beta[ch], mean, invstd, sc, sh);
+                f.scale[ch] = sc;
+                f.shift[ch] = sh;
+            }
+            f.save_mean[ch] = mean;
+            f.save_invstd[ch] = invstd;
+            if (f.running_mean) {
+                const double m_out = mean_d + (f.bias ? (double)f.bias[ch] : 0.0);
+                const double var_unb = f.rows > 1 ? var_d * ((double)f.rows / (double)(f.rows - 1)) : var_d;
+                f.running_mean[ch] = (float)((double)f.decay * f.running_mean[ch] + (1.0 - (double)f.decay) * m_out);
+                f.running_var[ch] = (float)((double)f.decay * f.running_var[ch] + (1.0 - (double)f.decay) * var_unb);
+            }
+        } else if (f.kind == 3) {  // bn_grad_constants_kernel
+            const float mu = f.mean_in[ch], is = f.invstd_in[ch];
+            float sc, sh;
+            bn_scale_shift(f.gamma[ch], f.beta[ch], mu, is, sc, sh);
+            f.coef[ch] = sc;
+            f.coef[(size_t)c + ch] = sh;
+            f.coef[(size_t)2 * c + ch] = mu;
+            f.coef[(size_t)3 * c + ch] = is;
+            f.coef[(size_t)4 * c + ch] = (float)(s1 * inv_n);
+            f.coef[(size_t)5 * c + ch] = (float)(s2 * inv_n);
+            f.dbeta[ch] = (float)s1;
+            f.dgamma[ch] = (float)s2;
+        }
+    }
 }
 
 // Operand transform of the training GEMMs that read the PRE-normalisation output of the layer below: the batch norm (+ReLU)

@@ -120,7 +120,7 @@ __global__ void __launch_bounds__(256)
 linear_kernel(int rows, int cin, int cout, const float* __restrict__ x,
               const float* __restrict__ w, const float* __restrict__ bias, int relu, int pool,
               float* __restrict__ y, double* __restrict__ stats = nullptr, Pn2BnGradEpilogue gepi = Pn2BnGradEpilogue{},
-              Pn2LoadTransform xf = Pn2LoadTransform{}, Pn2GradOnLoad gx = Pn2GradOnLoad{}) {
+              Pn2LoadTransform xf = Pn2LoadTransform{}, Pn2GradOnLoad gx = Pn2GradOnLoad{}, Pn2BnFinish fin = Pn2BnFinish{}) {
     static_assert(!XF || (VEC_A && !TB && WK == 1), "the load transform exists for the forward GEMM with 16-byte A loads");
     static_assert(GX == 0 || (VEC_A && TB && WK == 1 && !XF), "the gradient-on-load operand exists for the data gradient with 16-byte A loads");
     static_assert(WM * WN * WK == 4, "4 waves per block");
@@ -377,16 +377,18 @@ linear_kernel(int rows, int cin, int cout, const float* __restrict__ x,
                 for (int r = 0; r < 16; ++r) red[(nt * 16 + r) * 64 + lane] = acc[nt][r];
         }
         __syncthreads();
-        if (wk == 1) return;
+        if (wk == 0) {
 #pragma unroll
-        for (int nt = 0; nt < NT; ++nt)
+            for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) acc[nt][r] += red[(nt * 16 + r) * 64 + lane];
+                for (int r = 0; r < 16; ++r) acc[nt][r] += red[(nt * 16 + r) * 64 + lane];
+        }
     }
 
     // ---- epilogue ------------------------------------------------------------
     // D[i][j]: j = l31, i = (r&3) + 8*(r>>2) + 4*half
     const int wrow0 = row0 + wm * 32;
+    if (wk == 0) {  // (WK = 2: the second k-half has handed its tile over and only takes part in the finishing barrier below)
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) {
         const int col = col0 + wn * (NT * 32) + nt * 32 + l31;
@@ -435,22 +437,28 @@ linear_kernel(int rows, int cin, int cout, const float* __restrict__ x,
             }
         }
     }
+    }
+    // the last workgroup folds the batch-norm sums this launch has left (and derives the constants): pn2_common.h
+    pn2_bn_finish(fin, gridDim.x * gridDim.y, blockIdx.x + gridDim.x * blockIdx.y);
 }
 
 template <int WM, int WN, int NT, int WK = 1, int ST = 2>
 int launch_linear(int rows, int cin, int cout, const float* x, const float* w, const float* bias,
-                  int relu, int pool, float* y, hipStream_t st, double* stats = nullptr) {
+                  int relu, int pool, float* y, hipStream_t st, double* stats = nullptr, const Pn2BnFinish* fin = nullptr) {
     constexpr int BM = 32 * WM, BN = 32 * NT * WN;
     dim3 grid((rows + BM - 1) / BM, cout / BN);
     const bool vec_a = (cin % 4 == 0) && ((uintptr_t)x % 16 == 0);
+    const Pn2BnFinish f = fin ? *fin : Pn2BnFinish{};
+#define PN2_LK_ARGS rows, cin, cout, x, w, bias, relu, pool, y, stats, Pn2BnGradEpilogue{}, Pn2LoadTransform{}, Pn2GradOnLoad{}, f
     if constexpr (WM == 4 && NT == 4) {
         // the 128x128 tile exists with 16-byte A loads only (the scalar-load variant spills its accumulators)
-        if (!vec_a) return launch_linear<2, 2, 2, 1, ST>(rows, cin, cout, x, w, bias, relu, pool, y, st, stats);
-        linear_kernel<WM, WN, NT, true, WK, ST><<<grid, 256, 0, st>>>(rows, cin, cout, x, w, bias, relu, pool, y, stats);
+        if (!vec_a) return launch_linear<2, 2, 2, 1, ST>(rows, cin, cout, x, w, bias, relu, pool, y, st, stats, fin);
+        linear_kernel<WM, WN, NT, true, WK, ST><<<grid, 256, 0, st>>>(PN2_LK_ARGS);
     } else {
-        if (vec_a) linear_kernel<WM, WN, NT, true, WK, ST><<<grid, 256, 0, st>>>(rows, cin, cout, x, w, bias, relu, pool, y, stats);
-        else linear_kernel<WM, WN, NT, false, WK, ST><<<grid, 256, 0, st>>>(rows, cin, cout, x, w, bias, relu, pool, y, stats);
+        if (vec_a) linear_kernel<WM, WN, NT, true, WK, ST><<<grid, 256, 0, st>>>(PN2_LK_ARGS);
+        else linear_kernel<WM, WN, NT, false, WK, ST><<<grid, 256, 0, st>>>(PN2_LK_ARGS);
     }
+#undef PN2_LK_ARGS
     PN2_RETURN_IF_LAUNCH_FAILED();
     return PN2_OK;
 }
@@ -458,11 +466,12 @@ int launch_linear(int rows, int cin, int cout, const float* x, const float* w, c
 // pn2_linear_bn_stats_xf: the forward GEMM + statistics epilogue with the load transform (ST = 3, 16-byte A loads)
 template <int WM, int WN, int NT>
 int launch_linear_xf(int rows, int cin, int cout, const float* x, const float* w, float* y, hipStream_t st, double* stats,
-                     const Pn2LoadTransform& xf) {
+                     const Pn2LoadTransform& xf, const Pn2BnFinish* fin = nullptr) {
     constexpr int BM = 32 * WM, BN = 32 * NT * WN;
     dim3 grid((rows + BM - 1) / BM, cout / BN);
     linear_kernel<WM, WN, NT, true, 1, 3, false, true><<<grid, 256, 0, st>>>(rows, cin, cout, x, w, nullptr, 0, 0, y, stats,
-                                                                            Pn2BnGradEpilogue{}, xf);
+                                                                            Pn2BnGradEpilogue{}, xf, Pn2GradOnLoad{},
+                                                                            fin ? *fin : Pn2BnFinish{});
     PN2_RETURN_IF_LAUNCH_FAILED();
     return PN2_OK;
 }
@@ -502,9 +511,48 @@ dgrad_smallk_kernel(int rows, int n_in, const float* __restrict__ dy, const floa
     }
 }
 
+// The same when the number of 4-input groups divides the block size (n_in = 128: 32 groups): a thread then keeps the SAME four
+// inputs for every row it visits, so their 4 x K weights live in registers and the loop is 9 broadcast loads of dy, 36 fma and one
+// 16-byte store per row -- bound by the write of dx (131072 x 128 <- 9: 38 -> ~17 us; the LDS form issues 36 ds_read per store).
+template <int K>
+__global__ void __launch_bounds__(256)
+dgrad_smallk_fixed_kernel(int rows, int n_in, const float* __restrict__ dy, const float* __restrict__ w, float* __restrict__ dx) {
+    const int groups = n_in >> 2;                   // n_in % 4 == 0, 256 % groups == 0
+    const int g = (int)threadIdx.x % groups;
+    const int rpb = 256 / groups;                   // rows per block and pass
+    float wr[4][K];
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+#pragma unroll
+        for (int o = 0; o < K; ++o) wr[q][o] = w[(size_t)(4 * g + q) * K + o];
+    for (long long r = (long long)blockIdx.x * rpb + (int)threadIdx.x / groups; r < rows; r += (long long)gridDim.x * rpb) {
+        float d[K];
+#pragma unroll
+        for (int o = 0; o < K; ++o) d[o] = dy[r * K + o];
+        f32x4 a = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            float t = 0.f;
+#pragma unroll
+            for (int o = 0; o < K; ++o) t = __builtin_fmaf(d[o], wr[q][o], t);
+            a[q] = t;
+        }
+        *reinterpret_cast<f32x4*>(dx + r * n_in + 4 * g) = a;
+    }
+}
+
 template <int K>
 int launch_dgrad_smallk(int rows, int n_in, const float* dy, const float* w, float* dx, hipStream_t st) {
-    const long long total = (long long)rows * ((n_in + 3) / 4);
+    const int groups = (n_in + 3) / 4;
+    if ((n_in & 3) == 0 && groups <= 256 && 256 % groups == 0 && ((uintptr_t)dx % 16) == 0) {
+        const int rpb = 256 / groups;
+        long long g = ((long long)rows + rpb - 1) / rpb;
+        if (g > 256 * 16) g = 256 * 16;
+        dgrad_smallk_fixed_kernel<K><<<(int)g, 256, 0, st>>>(rows, n_in, dy, w, dx);
+        PN2_RETURN_IF_LAUNCH_FAILED();
+        return PN2_OK;
+    }
+    const long long total = (long long)rows * groups;
     long long g = (total + 255) / 256;
     if (g > 256 * 32) g = 256 * 32;
     dgrad_smallk_kernel<K><<<(int)g, 256, (size_t)n_in * K * sizeof(float), st>>>(rows, n_in, dy, w, dx);
@@ -564,23 +612,29 @@ int launch_linear_narrow(int rows, int cin, const float* x, const float* w, cons
 
 template <int WM, int WN, int NT>
 int launch_linear_dgrad(int rows, int n_in, int n_out, const float* dy, const float* w, float* dx, hipStream_t st,
-                        const Pn2BnGradEpilogue& gepi = Pn2BnGradEpilogue{}, const Pn2GradOnLoad* gx = nullptr) {
+                        const Pn2BnGradEpilogue& gepi = Pn2BnGradEpilogue{}, const Pn2GradOnLoad* gx = nullptr,
+                        const Pn2BnFinish* fin = nullptr) {
     constexpr int BM = 32 * WM, BN = 32 * NT * WN;
     dim3 grid((rows + BM - 1) / BM, (n_in + BN - 1) / BN);
+    const Pn2BnFinish f = fin ? *fin : Pn2BnFinish{};
     if (gx) {  // dy formed on load from (y, dz): n_out % 4 == 0 and 16-byte aligned operands checked by the caller
         const size_t lds = sizeof(float) * (size_t)n_out * (6 + (gx->pool ? 3 * (BM / 32) : 0));
         if (gx->pool)
             linear_kernel<WM, WN, NT, true, 1, 3, true, false, 2><<<grid, 256, lds, st>>>(rows, n_out, n_in, nullptr, w, nullptr, 0, 0, dx,
-                                                                                       nullptr, gepi, Pn2LoadTransform{}, *gx);
+                                                                                       nullptr, gepi, Pn2LoadTransform{}, *gx, f);
         else
             linear_kernel<WM, WN, NT, true, 1, 3, true, false, 1><<<grid, 256, lds, st>>>(rows, n_out, n_in, nullptr, w, nullptr, 0, 0, dx,
-                                                                                       nullptr, gepi, Pn2LoadTransform{}, *gx);
+                                                                                       nullptr, gepi, Pn2LoadTransform{}, *gx, f);
         PN2_RETURN_IF_LAUNCH_FAILED();
         return PN2_OK;
     }
     const bool vec_a = (n_out % 4 == 0) && ((uintptr_t)dy % 16 == 0);
-    if (vec_a) linear_kernel<WM, WN, NT, true, 1, 3, true><<<grid, 256, 0, st>>>(rows, n_out, n_in, dy, w, nullptr, 0, 0, dx, nullptr, gepi);
-    else linear_kernel<WM, WN, NT, false, 1, 3, true><<<grid, 256, 0, st>>>(rows, n_out, n_in, dy, w, nullptr, 0, 0, dx, nullptr, gepi);
+    if (vec_a)
+        linear_kernel<WM, WN, NT, true, 1, 3, true><<<grid, 256, 0, st>>>(rows, n_out, n_in, dy, w, nullptr, 0, 0, dx, nullptr, gepi,
+                                                                         Pn2LoadTransform{}, Pn2GradOnLoad{}, f);
+    else
+        linear_kernel<WM, WN, NT, false, 1, 3, true><<<grid, 256, 0, st>>>(rows, n_out, n_in, dy, w, nullptr, 0, 0, dx, nullptr, gepi,
+                                                                          Pn2LoadTransform{}, Pn2GradOnLoad{}, f);
     PN2_RETURN_IF_LAUNCH_FAILED();
     return PN2_OK;
 }
@@ -601,7 +655,7 @@ template <int TM, int TN, bool VEC_A, int G>
 __global__ void __launch_bounds__(256)
 linear_splitk_kernel(int rows, int cin, int cout, const float* __restrict__ x, const float* __restrict__ w,
                      const float* __restrict__ bias, int relu, int pool, float* __restrict__ y,
-                     double* __restrict__ stats = nullptr) {
+                     double* __restrict__ stats = nullptr, Pn2BnFinish fin = Pn2BnFinish{}) {
     // G = groups of 8 k in flight per wave (a group's MFMAs take ~0.1 us, an L2 round trip ~0.7 us)
     __shared__ float red[3 * TM * TN * 16 * 64];
     const int lane = threadIdx.x & 63, half = lane >> 5, l31 = lane & 31;
@@ -702,7 +756,7 @@ linear_splitk_kernel(int rows, int cin, int cout, const float* __restrict__ x, c
                 for (int r = 0; r < 16; ++r) dst[((a * TN + b) * 16 + r) * 64 + lane] = acc[a][b][r];
     }
     __syncthreads();
-    if (wave > 0) return;
+    if (wave == 0) {  // (waves 1..3 have handed their tiles over and only take part in the finishing barrier below)
 #pragma unroll
     for (int wv = 0; wv < 3; ++wv) {
         const float* src = red + (size_t)wv * (TM * TN * 16 * 64);
@@ -741,15 +795,18 @@ linear_splitk_kernel(int rows, int cin, int cout, const float* __restrict__ x, c
             }
         }
     }
+    }
+    pn2_bn_finish(fin, gridDim.x * gridDim.y, blockIdx.x + gridDim.x * blockIdx.y);
 }
 
 template <int TM, int TN, int G = 2>
 int launch_linear_splitk(int rows, int cin, int cout, const float* x, const float* w, const float* bias, int relu,
-                         int pool, float* y, hipStream_t st, double* stats = nullptr) {
+                         int pool, float* y, hipStream_t st, double* stats = nullptr, const Pn2BnFinish* fin = nullptr) {
     dim3 grid((rows + 32 * TM - 1) / (32 * TM), cout / (32 * TN));
     const bool vec_a = (cin % 4 == 0) && ((uintptr_t)x % 16 == 0);
-    if (vec_a) linear_splitk_kernel<TM, TN, true, G><<<grid, 256, 0, st>>>(rows, cin, cout, x, w, bias, relu, pool, y, stats);
-    else linear_splitk_kernel<TM, TN, false, G><<<grid, 256, 0, st>>>(rows, cin, cout, x, w, bias, relu, pool, y, stats);
+    const Pn2BnFinish f = fin ? *fin : Pn2BnFinish{};
+    if (vec_a) linear_splitk_kernel<TM, TN, true, G><<<grid, 256, 0, st>>>(rows, cin, cout, x, w, bias, relu, pool, y, stats, f);
+    else linear_splitk_kernel<TM, TN, false, G><<<grid, 256, 0, st>>>(rows, cin, cout, x, w, bias, relu, pool, y, stats, f);
     PN2_RETURN_IF_LAUNCH_FAILED();
     return PN2_OK;
 }
@@ -975,7 +1032,8 @@ PN2_TUNABLE(int, g_lin_stages, 3)  // tuning hook (pn2_debug_set(5, v)): registe
 PN2_TUNABLE(int, g_wgrad_waves, 0) // tuning hook (pn2_debug_set(9, v)): waves in flight targeted by pn2_linear_wgrad (0 = auto)
 
 static int linear_impl(int rows, int cin, int cout, const float* x, const float* w,
-                       const float* bias, int relu, int pool, float* y, void* stream, double* stats) {
+                       const float* bias, int relu, int pool, float* y, void* stream, double* stats,
+                       const Pn2BnFinish* fin = nullptr) {
     if (rows <= 0 || cin <= 0 || cout <= 0) return PN2_EINVAL;
     if (!x || !w || !y) return PN2_ENULL;
     if (cout % 32 != 0 || ((uintptr_t)w % 16) != 0) return PN2_EUNSUP;
@@ -991,21 +1049,21 @@ static int linear_impl(int rows, int cin, int cout, const float* x, const float*
         }
     }
 #define PN2_LIN(WM_, WN_, NT_, WK_)                                                                          \
-    (st_depth >= 4 ? launch_linear<WM_, WN_, NT_, WK_, 4>(rows, cin, cout, x, w, bias, relu, pool, y, st, stats)      \
-     : st_depth == 3 ? launch_linear<WM_, WN_, NT_, WK_, 3>(rows, cin, cout, x, w, bias, relu, pool, y, st, stats)    \
-                     : launch_linear<WM_, WN_, NT_, WK_, 2>(rows, cin, cout, x, w, bias, relu, pool, y, st, stats))
+    (st_depth >= 4 ? launch_linear<WM_, WN_, NT_, WK_, 4>(rows, cin, cout, x, w, bias, relu, pool, y, st, stats, fin)      \
+     : st_depth == 3 ? launch_linear<WM_, WN_, NT_, WK_, 3>(rows, cin, cout, x, w, bias, relu, pool, y, st, stats, fin)    \
+                     : launch_linear<WM_, WN_, NT_, WK_, 2>(rows, cin, cout, x, w, bias, relu, pool, y, st, stats, fin))
     const int st_depth = g_lin_stages;
     if (g_lin_cfg >= 5 && (pool <= 1 || pool == 32)) {  // tuning hook: split-K direct-feed tiles
-        if (g_lin_cfg == 5) return launch_linear_splitk<1, 1, 2>(rows, cin, cout, x, w, bias, relu, pool, y, st, stats);
-        if (g_lin_cfg == 6) return launch_linear_splitk<1, 1, 4>(rows, cin, cout, x, w, bias, relu, pool, y, st, stats);
-        if (g_lin_cfg == 7) return launch_linear_splitk<1, 1, 8>(rows, cin, cout, x, w, bias, relu, pool, y, st, stats);
-        if (g_lin_cfg == 8 && cout % 64 == 0) return launch_linear_splitk<1, 2, 4>(rows, cin, cout, x, w, bias, relu, pool, y, st, stats);
+        if (g_lin_cfg == 5) return launch_linear_splitk<1, 1, 2>(rows, cin, cout, x, w, bias, relu, pool, y, st, stats, fin);
+        if (g_lin_cfg == 6) return launch_linear_splitk<1, 1, 4>(rows, cin, cout, x, w, bias, relu, pool, y, st, stats, fin);
+        if (g_lin_cfg == 7) return launch_linear_splitk<1, 1, 8>(rows, cin, cout, x, w, bias, relu, pool, y, st, stats, fin);
+        if (g_lin_cfg == 8 && cout % 64 == 0) return launch_linear_splitk<1, 2, 4>(rows, cin, cout, x, w, bias, relu, pool, y, st, stats, fin);
     }
     // few rows (FP1: 1024): one 32x32 tile per workgroup with the contraction split over its 4 waves fills the chip
     // where the LDS-tiled kernel leaves 3/4 of the CUs idle: 1024x768->256 15.3 -> 9.7 us, 1024x256->256 7.6 -> 6.0 us;
     // from 4096 rows on the LDS-tiled kernel wins (operand re-reads from L2) -- profiles/r02_linear_splitk.txt
     if (g_lin_cfg == 0 && rows <= 2048 && (pool <= 1 || pool == 32))
-        return launch_linear_splitk<1, 1, 2>(rows, cin, cout, x, w, bias, relu, pool, y, st, stats);
+        return launch_linear_splitk<1, 1, 2>(rows, cin, cout, x, w, bias, relu, pool, y, st, stats, fin);
     if (cout % 128 == 0 && g_lin_cfg != 0 && g_lin_cfg < 5) {  // tuning hook: force a tile configuration
         if (g_lin_cfg == 1) return PN2_LIN(4, 1, 4, 1);
         if (g_lin_cfg == 2) return PN2_LIN(2, 2, 2, 1);
@@ -1073,9 +1131,9 @@ extern "C" int pn2_linear_bn_stats(int rows, int cin, int cout, const float* x, 
 // relu?(fma(x_raw, a_scale[k], a_shift[k])) formed while the tile is staged (a_scale / a_shift (cin) from
 // pn2_bn_relu_forward_deferred).  cin % 4 == 0, x_raw / a_scale / a_shift 16-byte aligned, rows > 2048 (the few-row split-K
 // tiles have no staging step); otherwise PN2_EUNSUP.
-extern "C" int pn2_linear_bn_stats_xf(int rows, int cin, int cout, const float* x_raw, const float* w, float* y,
-                                      void* bn_workspace, size_t workspace_bytes, const float* a_scale, const float* a_shift,
-                                      int a_relu, void* stream) {
+static int linear_bn_stats_xf_impl(int rows, int cin, int cout, const float* x_raw, const float* w, float* y,
+                                   void* bn_workspace, size_t workspace_bytes, const float* a_scale, const float* a_shift,
+                                   int a_relu, void* stream, const Pn2BnFinish* fin) {
     if (rows <= 0 || cin <= 0 || cout <= 0) return PN2_EINVAL;
     if (!x_raw || !w || !y || !bn_workspace || !a_scale || !a_shift) return PN2_ENULL;
     if (workspace_bytes < sizeof(double) * pn2_bn_ws_doubles(cout, kPn2BnSlots) || ((uintptr_t)bn_workspace % 8) != 0) return PN2_EINVAL;
@@ -1088,18 +1146,53 @@ extern "C" int pn2_linear_bn_stats_xf(int rows, int cin, int cout, const float* 
     if (cout % 128 == 0) {  // the tile choice of linear_impl, without its 128 x 128 tile (with the transform's registers its
                             // accumulators spill: 630 us instead of ~45 at 32768 x 128 -> 256)
         const long long cb = cout / 128;
-        if (((rows + 63) / 64) * cb >= 512) return launch_linear_xf<2, 2, 2>(rows, cin, cout, x_raw, w, y, st, stats, xf);
-        return launch_linear_xf<1, 4, 1>(rows, cin, cout, x_raw, w, y, st, stats, xf);
+        if (((rows + 63) / 64) * cb >= 512) return launch_linear_xf<2, 2, 2>(rows, cin, cout, x_raw, w, y, st, stats, xf, fin);
+        return launch_linear_xf<1, 4, 1>(rows, cin, cout, x_raw, w, y, st, stats, xf, fin);
     }
-    if (cout % 64 == 0) return launch_linear_xf<4, 1, 2>(rows, cin, cout, x_raw, w, y, st, stats, xf);
-    return launch_linear_xf<4, 1, 1>(rows, cin, cout, x_raw, w, y, st, stats, xf);
+    if (cout % 64 == 0) return launch_linear_xf<4, 1, 2>(rows, cin, cout, x_raw, w, y, st, stats, xf, fin);
+    return launch_linear_xf<4, 1, 1>(rows, cin, cout, x_raw, w, y, st, stats, xf, fin);
+}
+
+extern "C" int pn2_linear_bn_stats_xf(int rows, int cin, int cout, const float* x_raw, const float* w, float* y,
+                                      void* bn_workspace, size_t workspace_bytes, const float* a_scale, const float* a_shift,
+                                      int a_relu, void* stream) {
+    return linear_bn_stats_xf_impl(rows, cin, cout, x_raw, w, y, bn_workspace, workspace_bytes, a_scale, a_shift, a_relu, stream,
+                                   nullptr);
+}
+
+// pn2_linear_bn_stats (a_scale == NULL) / pn2_linear_bn_stats_xf whose LAST WORKGROUP also does what used to be the next launch
+// (pn2_common.h pn2_bn_finish): finish = 1 folds the slot copies of the column sums (then pn2_bn_relu_forward_mode /
+// pn2_bn_relu_forward_pool with stats_mode 3 normalise); finish = 2 also derives what pn2_bn_relu_forward_deferred publishes --
+// save_mean / save_invstd, the moving averages, per-channel (scale, shift) -- so a layer that hands its un-normalised output on
+// is ONE launch.  tf_util.py:186-204 + :555-581.
+extern "C" int pn2_linear_bn_stats_fin(int rows, int cin, int cout, const float* x, const float* w, float* y, void* bn_workspace,
+                                       size_t workspace_bytes, const float* a_scale, const float* a_shift, int a_relu,
+                                       int finish, const float* gamma, const float* beta, const float* bias, float eps,
+                                       float decay, float* running_mean, float* running_var, float* save_mean,
+                                       float* save_invstd, float* scale, float* shift, void* stream) {
+    if (!bn_workspace) return PN2_ENULL;
+    if (finish != 1 && finish != 2) return PN2_EINVAL;
+    if (cout <= 0 || workspace_bytes < sizeof(double) * pn2_bn_ws_doubles(cout, kPn2BnSlots) || ((uintptr_t)bn_workspace % 8) != 0)
+        return PN2_EINVAL;
+    if ((a_scale == nullptr) != (a_shift == nullptr)) return PN2_ENULL;
+    Pn2BnFinish f{};
+    f.kind = finish; f.c = cout; f.nslots = kPn2BnSlots; f.rows = rows; f.ws = static_cast<double*>(bn_workspace);
+    if (finish == 2) {
+        if (!gamma || !beta || !save_mean || !save_invstd || (scale == nullptr) != (shift == nullptr)) return PN2_ENULL;
+        if ((running_mean == nullptr) != (running_var == nullptr)) return PN2_ENULL;
+        f.gamma = gamma; f.beta = beta; f.bias = bias; f.eps = eps; f.decay = decay; f.running_mean = running_mean;
+        f.running_var = running_var; f.save_mean = save_mean; f.save_invstd = save_invstd; f.scale = scale; f.shift = shift;
+    }
+    if (a_scale)
+        return linear_bn_stats_xf_impl(rows, cin, cout, x, w, y, bn_workspace, workspace_bytes, a_scale, a_shift, a_relu, stream, &f);
+    return linear_impl(rows, cin, cout, x, w, nullptr, 0, 0, y, stream, static_cast<double*>(bn_workspace), &f);
 }
 
 // Data gradient of a dense layer (training): dx (rows, cin) = dy (rows, cout) . W^T, W (cin, cout) row-major as the forward
 // pass holds it (no transposed copy); any cin / cout.  The reference gets this from tf.gradients of tf.nn.conv2d
 // (util/tf_util.py:181-186).
 static int linear_dgrad_impl(int rows, int cin, int cout, const float* dy, const float* w, float* dx, void* stream,
-                             const Pn2BnGradEpilogue& gepi, const Pn2GradOnLoad* gx = nullptr) {
+                             const Pn2BnGradEpilogue& gepi, const Pn2GradOnLoad* gx = nullptr, const Pn2BnFinish* fin = nullptr) {
     if (rows <= 0 || cin <= 0 || cout <= 0) return PN2_EINVAL;
     if ((!dy && !gx) || !w || !dx) return PN2_ENULL;
     if ((long long)rows + 128 > 0x7fffffffLL) return PN2_ERANGE;
@@ -1119,12 +1212,12 @@ static int linear_dgrad_impl(int rows, int cin, int cout, const float* dy, const
 #undef PN2_SK
         }
     }
-    if (cin <= 32) return launch_linear_dgrad<4, 1, 1>(rows, cin, cout, dy, w, dx, st, gepi, gx);
-    if (cin <= 64) return launch_linear_dgrad<4, 1, 2>(rows, cin, cout, dy, w, dx, st, gepi, gx);
-    if (cin <= 96) return launch_linear_dgrad<4, 1, 1>(rows, cin, cout, dy, w, dx, st, gepi, gx);
+    if (cin <= 32) return launch_linear_dgrad<4, 1, 1>(rows, cin, cout, dy, w, dx, st, gepi, gx, fin);
+    if (cin <= 64) return launch_linear_dgrad<4, 1, 2>(rows, cin, cout, dy, w, dx, st, gepi, gx, fin);
+    if (cin <= 96) return launch_linear_dgrad<4, 1, 1>(rows, cin, cout, dy, w, dx, st, gepi, gx, fin);
     const long long cb = (cin + 127) / 128;
-    if (((rows + 63) / 64) * cb >= 512) return launch_linear_dgrad<2, 2, 2>(rows, cin, cout, dy, w, dx, st, gepi, gx);
-    return launch_linear_dgrad<1, 4, 1>(rows, cin, cout, dy, w, dx, st, gepi, gx);
+    if (((rows + 63) / 64) * cb >= 512) return launch_linear_dgrad<2, 2, 2>(rows, cin, cout, dy, w, dx, st, gepi, gx, fin);
+    return launch_linear_dgrad<1, 4, 1>(rows, cin, cout, dy, w, dx, st, gepi, gx, fin);
 }
 
 extern "C" int pn2_linear_dgrad(int rows, int cin, int cout, const float* dy, const float* w, float* dx, void* stream) {
@@ -1169,6 +1262,44 @@ extern "C" int pn2_linear_dgrad_gx(int rows, int cin, int cout, const float* y, 
     }
     const Pn2GradOnLoad gx{y, dz, coef, zmax, ties, relu, pool};
     return linear_dgrad_impl(rows, cin, cout, nullptr, w, dx, stream, e, &gx);
+}
+
+// The data gradient in all its training forms as ONE entry point whose last workgroup also finishes the batch-norm reduction of
+// the layer BELOW (pn2_common.h pn2_bn_finish):
+//   upstream gradient: dy (rows, cout) given (y == NULL) as in pn2_linear_dgrad, or formed on load from (y, dz, coef, relu, pool,
+//     zmax, ties) as in pn2_linear_dgrad_gx (dy == NULL);
+//   y_below != NULL: pn2_linear_dgrad_bn_grad_stats' epilogue for the layer below, and finish_below = 1: its slot copies folded
+//     (pn2_bn_relu_backward_mode with stats_mode 3 follows), 3: folded AND turned into coef_below (6, cin), dgamma_below,
+//     dbeta_below (what pn2_bn_grad_constants publishes), 0: left as they are.
+// A layer inside a stack then costs two launches in the backward pass (this + its weight gradient) instead of four.
+extern "C" int pn2_linear_dgrad_fin(int rows, int cin, int cout, const float* dy, const float* y, const float* dz,
+                                    const float* coef, int relu, int pool, const float* zmax, const float* ties, const float* w,
+                                    float* dx, const float* y_below, const float* gamma_below, const float* beta_below,
+                                    const float* mean_below, const float* invstd_below, int relu_below, void* ws_below,
+                                    size_t ws_below_bytes, int finish_below, float* coef_below, float* dgamma_below,
+                                    float* dbeta_below, void* stream) {
+    if ((dy == nullptr) == (y == nullptr)) return PN2_EINVAL;  // exactly one form of the upstream gradient
+    Pn2BnGradEpilogue e{};
+    Pn2BnFinish f{};
+    if (y_below) {
+        if (!gamma_below || !beta_below || !mean_below || !invstd_below || !ws_below) return PN2_ENULL;
+        if (cin <= 0 || ws_below_bytes < sizeof(double) * pn2_bn_ws_doubles(cin, kPn2BnSlots) || ((uintptr_t)ws_below % 8) != 0)
+            return PN2_EINVAL;
+        e = Pn2BnGradEpilogue{y_below, gamma_below, beta_below, mean_below, invstd_below, static_cast<double*>(ws_below), relu_below};
+        if (finish_below != 0 && finish_below != 1 && finish_below != 3) return PN2_EINVAL;
+        if (finish_below == 3 && (!coef_below || !dgamma_below || !dbeta_below)) return PN2_ENULL;
+        f.kind = finish_below; f.c = cin; f.nslots = kPn2BnSlots; f.rows = rows; f.ws = static_cast<double*>(ws_below);
+        f.gamma = gamma_below; f.beta = beta_below; f.mean_in = mean_below; f.invstd_in = invstd_below;
+        f.coef = coef_below; f.dgamma = dgamma_below; f.dbeta = dbeta_below;
+    } else if (finish_below != 0) {
+        return PN2_EINVAL;
+    }
+    if (y) {
+        const Pn2GradOnLoad gx{y, dz, coef, zmax, ties, relu, pool};
+        return linear_dgrad_impl(rows, cin, cout, nullptr, w, dx, stream, e, &gx, f.kind ? &f : nullptr);
+    }
+    if (f.kind && cout <= 16) return PN2_EUNSUP;  // the streaming kernel of the class head has no epilogue
+    return linear_dgrad_impl(rows, cin, cout, dy, w, dx, stream, e, nullptr, f.kind ? &f : nullptr);
 }
 
 #ifdef PN2_TUNING_HOOKS

@@ -615,6 +615,33 @@ def _bn_scratch(c, device, fn, fn_ws0):
 
 
 USE_GEMM_BN_STATS = True  # batch statistics from the forward GEMM's epilogue (set False: separate pass over y; tests / A-B)
+# The one-block launches that used to follow every producer of batch-norm sums (fold the slot copies; derive scale / shift resp. the
+# gradient constants) are done by the producer's LAST WORKGROUP (csrc/pn2_common.h pn2_bn_finish): a layer inside a stack is one
+# launch forward (GEMM + statistics + constants) and two backward (data gradient + finish of the layer below; weight gradient).
+# False: the separate launches (A/B, tests).
+USE_BN_FINISH_IN_PRODUCER = True
+
+
+def hip_matmul_bn_stats_fin(x2d, w, ws, xf, finish, gamma=None, beta=None, b=None, decay=0.0, running_mean=None, running_var=None):
+    """hip_matmul_bn_stats (xf None) / hip_matmul_bn_stats_xf (xf = (scale, shift, relu)) whose last workgroup also folds the
+    statistics (finish 1) or folds them and publishes the deferred batch norm's constants (finish 2, pn2_linear_bn_stats_fin).
+    -> y, (save_mean, save_invstd, scale, shift) or None"""
+    require_cuda(x2d, w)
+    rows, cin = x2d.shape
+    cout = w.shape[1]
+    y = torch.empty((rows, cout), dtype=torch.float32, device=x2d.device)
+    consts = None
+    if finish == 2:
+        save_mean = torch.empty(cout, dtype=torch.float32, device=x2d.device)
+        consts = (save_mean, torch.empty_like(save_mean), torch.empty_like(save_mean), torch.empty_like(save_mean))
+    sc, sh, xrelu = xf if xf is not None else (None, None, 0)
+    cs = consts if consts is not None else (None, None, None, None)
+    with torch.cuda.device(x2d.device):
+        check(lib.pn2_linear_bn_stats_fin(rows, cin, cout, ptr(x2d.contiguous()), ptr(w.contiguous()), ptr(y), ptr(ws),
+                                          ws.numel() * ws.element_size(), ptr(sc), ptr(sh), int(xrelu), int(finish), ptr(gamma),
+                                          ptr(beta), ptr(b), BN_EPSILON, float(decay), ptr(running_mean), ptr(running_var),
+                                          ptr(cs[0]), ptr(cs[1]), ptr(cs[2]), ptr(cs[3]), stream_ptr()), "pn2_linear_bn_stats_fin")
+    return y, consts
 
 
 def _bn_zeroed_scratch(c, device):
@@ -762,7 +789,7 @@ _bn_links = weakref.WeakValueDictionary()
 
 class _BnLink:
     __slots__ = ("shape", "y", "gamma", "beta", "mean", "invstd", "relu", "ws", "dz_ptr", "dz_keep", "sc", "sh", "consumed",
-                 "__weakref__")
+                 "gx", "folded", "coef", "dgamma", "dbeta", "__weakref__")
 
 
 # ---- deferred normalisation: layer i publishes (scale, shift) and hands its PRE-normalisation output y to layer i+1 -------
@@ -803,6 +830,8 @@ def hip_linear_dgrad_linked(dy, w, link):
     """hip_linear_dgrad whose result is the gradient reaching the batch norm of the layer recorded in `link`: the GEMM also
     leaves that batch norm's two gradient sums in a zeroed workspace (pn2_linear_dgrad_bn_grad_stats) and notes both on the
     record for the producer's backward."""
+    if USE_BN_FINISH_IN_PRODUCER and w.shape[1] > 16:
+        return _hip_dgrad_fin(dy.contiguous(), None, w, link)
     rows, cin = dy.shape[0], w.shape[0]
     pws = _bn_zeroed_scratch(cin, dy.device)
     dx = torch.empty((rows, cin), dtype=torch.float32, device=dy.device)
@@ -815,7 +844,7 @@ def hip_linear_dgrad_linked(dy, w, link):
     return dx
 
 
-def _bn_train_forward(y, b, gamma, beta, running_mean, running_var, decay, relu, pool, stats_ws=None):
+def _bn_train_forward(y, b, gamma, beta, running_mean, running_var, decay, relu, pool, stats_ws=None, folded=False):
     """batch norm (+ReLU, + max over groups of `pool` rows) of a layer output y (rows, c) on pn2_bn_relu_forward; stats_ws: the
     workspace pn2_linear_bn_stats has already left the column sums in.  -> z, ties, save_mean, save_invstd"""
     rows, c = y.shape
@@ -833,11 +862,15 @@ def _bn_train_forward(y, b, gamma, beta, running_mean, running_var, decay, relu,
             # ties = [tie counts | ysel]: ysel = the pre-normalisation value of the first row attaining each maximum, which lets the
             # backward take its reduction from the pooled tensors (pn2_bn_grad_constants) instead of a pass over y
             ties = torch.empty((2,) + tuple(z.shape), dtype=y.dtype, device=y.device)
-            mode = 2 if stats_ws is not None else (1 if fwd is lib.pn2_bn_relu_forward_ws0 else 0)
+            mode = (3 if folded else 2) if stats_ws is not None else (1 if fwd is lib.pn2_bn_relu_forward_ws0 else 0)
             check(lib.pn2_bn_relu_forward_pool(rows, c, ptr(y), ptr(gamma), ptr(beta), ptr(b), BN_EPSILON, decay, int(relu), int(pool),
                                                ptr(running_mean), ptr(running_var), ptr(ws), ws.numel() * ws.element_size(), mode,
                                                ptr(save_mean), ptr(save_invstd), ptr(z), ptr(ties[0]), ptr(ties[1]), stream_ptr()),
                   "pn2_bn_relu_forward_pool")
+        elif folded and stats_ws is not None:  # the GEMM's last workgroup has folded the sums: only the normalisation pass is left
+            check(lib.pn2_bn_relu_forward_mode(rows, c, ptr(y), ptr(gamma), ptr(beta), ptr(b), BN_EPSILON, decay, int(relu),
+                                               ptr(running_mean), ptr(running_var), ptr(ws), ws.numel() * ws.element_size(), 3,
+                                               ptr(save_mean), ptr(save_invstd), ptr(z), stream_ptr()), "pn2_bn_relu_forward_mode")
         else:
             check(fwd(rows, c, ptr(y), ptr(gamma), ptr(beta), ptr(b), BN_EPSILON, decay, int(relu),
                       int(pool), ptr(running_mean), ptr(running_var), ptr(ws), ws.numel() * ws.element_size(),
@@ -860,7 +893,7 @@ def _bn_train_forward_deferred(y, b, gamma, beta, running_mean, running_var, dec
     return save_mean, save_invstd, sc, sh
 
 
-def _bn_register_producer(z, y, gamma, beta, save_mean, save_invstd, relu, pooled, sc=None, sh=None):
+def _bn_register_producer(z, y, gamma, beta, save_mean, save_invstd, relu, pooled, sc=None, sh=None, gx=False):
     """record an un-pooled dense+BN layer as the possible producer of the next layer's input (see _BnLink) -> link or None;
     sc / sh: the layer deferred its normalisation, z IS y"""
     if not USE_DGRAD_BN_STATS or pooled:
@@ -869,6 +902,9 @@ def _bn_register_producer(z, y, gamma, beta, save_mean, save_invstd, relu, poole
     lk.shape, lk.y, lk.gamma, lk.beta, lk.mean, lk.invstd, lk.relu = tuple(z.shape), y, gamma, beta, save_mean, save_invstd, bool(relu)
     lk.ws = lk.dz_ptr = lk.dz_keep = None
     lk.sc, lk.sh, lk.consumed = sc, sh, False
+    # gx: this layer's backward forms its batch-norm gradient on load -- the consumer's data-gradient GEMM may then publish the
+    # gradient constants itself (finish kind 3); folded / coef / dgamma / dbeta: what that GEMM's last workgroup has left
+    lk.gx, lk.folded, lk.coef, lk.dgamma, lk.dbeta = bool(gx), False, None, None, None
     _bn_links[z.data_ptr()] = lk
     return lk
 
@@ -887,8 +923,9 @@ def _bn_train_backward(dz, y, gamma, beta, save_mean, save_invstd, relu, pool, z
     dz = dz.contiguous()
     dy = torch.empty_like(y)
     dgamma, dbeta = _param_grad_out(gamma), _param_grad_out(beta)
+    mode3 = False
     if lk is not None and lk.ws is not None and lk.dz_ptr == dz.data_ptr() and dz.shape == y.shape:
-        ws, bwd = lk.ws, lib.pn2_bn_relu_backward_stats
+        ws, bwd, mode3 = lk.ws, lib.pn2_bn_relu_backward_stats, bool(lk.folded)
     else:
         ws, bwd = _bn_scratch(c, y.device, lib.pn2_bn_relu_backward, lib.pn2_bn_relu_backward_ws0)
     if lk is not None and lk.sc is not None and not lk.consumed:
@@ -896,13 +933,19 @@ def _bn_train_backward(dz, y, gamma, beta, save_mean, save_invstd, relu, pool, z
         raise RuntimeError("a deferred batch-norm output (conv2d(..., defer_bn=True)) was not consumed by a following conv2d")
     if lk is not None:  # this layer's backward runs once: drop what the record kept alive
         lk.ws = lk.dz_keep = lk.dz_ptr = lk.y = lk.gamma = lk.beta = lk.mean = lk.invstd = lk.sc = lk.sh = None
+        lk.coef = lk.dgamma = lk.dbeta = None
     if ties is not None and ties.dim() == zmax.dim() + 1:
         ties = ties[0]  # [tie counts | ysel] of _bn_train_forward
     with torch.cuda.device(y.device):
-        check(bwd(rows, c, ptr(dz), ptr(y), ptr(gamma), ptr(beta), ptr(save_mean),
-                  ptr(save_invstd), int(relu), int(pool), ptr(zmax), ptr(ties), ptr(ws),
-                  ws.numel() * ws.element_size(), ptr(dy), ptr(dgamma), ptr(dbeta), stream_ptr()),
-              "pn2_bn_relu_backward")
+        if mode3:  # the consumer's data-gradient GEMM has left the sums AND folded them (pn2_linear_dgrad_fin)
+            check(lib.pn2_bn_relu_backward_mode(rows, c, ptr(dz), ptr(y), ptr(gamma), ptr(beta), ptr(save_mean), ptr(save_invstd),
+                                                int(relu), int(pool), ptr(zmax), ptr(ties), ptr(ws), ws.numel() * ws.element_size(),
+                                                3, ptr(dy), ptr(dgamma), ptr(dbeta), stream_ptr()), "pn2_bn_relu_backward_mode")
+        else:
+            check(bwd(rows, c, ptr(dz), ptr(y), ptr(gamma), ptr(beta), ptr(save_mean),
+                      ptr(save_invstd), int(relu), int(pool), ptr(zmax), ptr(ties), ptr(ws),
+                      ws.numel() * ws.element_size(), ptr(dy), ptr(dgamma), ptr(dbeta), stream_ptr()),
+                  "pn2_bn_relu_backward")
     return dy, dgamma, dbeta
 
 
@@ -927,14 +970,20 @@ def _bn_grad_constants(dz, y, gamma, beta, save_mean, save_invstd, relu, pool, z
     """first half of the on-load batch-norm gradient (pn2_bn_grad_constants) -> coef (6, c), dgamma, dbeta.  lk as in
     _bn_train_backward: the reduction pass is skipped when the consumer's data-gradient GEMM has already left the sums."""
     rows, c = y.shape
+    ready = None
     if lk is not None and lk.ws is not None and lk.dz_ptr == dz.data_ptr() and dz.shape == y.shape:
         ws, done = lk.ws, 1
+        if lk.coef is not None:  # the consumer's data-gradient GEMM has published them already (finish kind 3)
+            ready = (lk.coef, lk.dgamma, lk.dbeta)
     else:
         ws, done = _bn_zeroed_scratch(c, y.device), 0
     if lk is not None and lk.sc is not None and not lk.consumed:
         raise RuntimeError("a deferred batch-norm output (conv2d(..., defer_bn=True)) was not consumed by a following conv2d")
     if lk is not None:
         lk.ws = lk.dz_keep = lk.dz_ptr = lk.y = lk.gamma = lk.beta = lk.mean = lk.invstd = lk.sc = lk.sh = None
+        lk.coef = lk.dgamma = lk.dbeta = None
+    if ready is not None:
+        return ready
     coef = torch.empty((6, c), dtype=torch.float32, device=y.device)
     dgamma, dbeta = _param_grad_out(gamma), _param_grad_out(beta)
     ysel = None
@@ -947,9 +996,44 @@ def _bn_grad_constants(dz, y, gamma, beta, save_mean, save_invstd, relu, pool, z
     return coef, dgamma, dbeta
 
 
+def _hip_dgrad_fin(dy, gx, w, link):
+    """The data gradient dx = dy @ w^T of a dense layer with everything the training path hangs on it (pn2_linear_dgrad_fin):
+    dy given, or gx = (y, dz, coef, relu, pool, zmax, ties): formed on load; link: the producer record of the layer below -- its
+    two batch-norm gradient sums come from the accumulator tiles, and the GEMM's last workgroup folds them (link.gx False: the
+    materialised backward follows) or publishes that layer's gradient constants, dgamma and dbeta (link.gx True)."""
+    ref = dy if dy is not None else gx[0]
+    rows, cin = ref.shape[0], w.shape[0]
+    dx = torch.empty((rows, cin), dtype=torch.float32, device=ref.device)
+    below, fin_out = (None, None, None, None, None, 0, None, 0), (0, None, None, None)
+    pws = None
+    if link is not None:
+        pws = _bn_zeroed_scratch(cin, ref.device)
+        below = (ptr(link.y), ptr(link.gamma), ptr(link.beta), ptr(link.mean), ptr(link.invstd), int(link.relu), ptr(pws),
+                 pws.numel() * pws.element_size())
+        if link.gx and _gx_usable(rows, cin, 0, dx, link.y):
+            link.coef = torch.empty((6, cin), dtype=torch.float32, device=ref.device)
+            link.dgamma, link.dbeta = _param_grad_out(link.gamma), _param_grad_out(link.beta)
+            fin_out = (3, ptr(link.coef), ptr(link.dgamma), ptr(link.dbeta))
+        else:
+            fin_out = (1, None, None, None)
+    if gx is not None:
+        y, dz, coef, relu, pool, zmax, ties = gx
+        up = (None, ptr(y), ptr(dz), ptr(coef), int(relu), int(pool), ptr(zmax), ptr(ties))
+    else:
+        up = (ptr(dy), None, None, None, 0, 0, None, None)
+    with torch.cuda.device(ref.device):
+        check(lib.pn2_linear_dgrad_fin(rows, cin, w.shape[1], *up, ptr(w.contiguous()), ptr(dx), *below, *fin_out, stream_ptr()),
+              "pn2_linear_dgrad_fin")
+    if link is not None:
+        link.ws, link.dz_ptr, link.dz_keep, link.folded = pws, dx.data_ptr(), dx, True
+    return dx
+
+
 def _hip_dgrad_gx(y, dz, coef, relu, pool, zmax, ties, w, link):
     """dx = dy @ w^T with dy formed on load (pn2_linear_dgrad_gx); link: the producer record of the layer below (its two batch-norm
     gradient sums are left in a zeroed workspace and noted on the record, as hip_linear_dgrad_linked does) or None"""
+    if USE_BN_FINISH_IN_PRODUCER:
+        return _hip_dgrad_fin(None, (y, dz, coef, relu, pool, zmax, ties), w, link)
     rows, cin = y.shape[0], w.shape[0]
     dx = torch.empty((rows, cin), dtype=torch.float32, device=y.device)
     pws = _bn_zeroed_scratch(cin, y.device) if link is not None else None
@@ -996,36 +1080,50 @@ class _TrainDenseBnRelu(torch.autograd.Function):
         prev = _bn_links.get(x2d.data_ptr()) if USE_DGRAD_BN_STATS else None
         prev = prev if (prev is not None and prev.y is not None and prev.shape == tuple(x2d.shape)) else None
         xf = prev is not None and prev.sc is not None  # x2d is the producer's UN-normalised output
-        if xf:
-            if c % 32 != 0:
-                raise RuntimeError("a deferred batch-norm output reached a layer that cannot apply it")
+        defer = defer and not pooled and any(ctx.needs_input_grad)  # no tape node, nobody to keep the record: normalise here
+        #                                    (the callers also drop the request when no tape is being recorded at all)
+        if xf and c % 32 != 0:
+            raise RuntimeError("a deferred batch-norm output reached a layer that cannot apply it")
+        consts, folded = None, False
+        if (xf or (USE_GEMM_BN_STATS and c % 32 == 0)) and USE_BN_FINISH_IN_PRODUCER:
+            # ONE launch: GEMM (batch norm of the layer below applied on load when it was deferred) + column sums of y + -- in the
+            # launch's last workgroup -- their fold and, for a layer that defers its own batch norm, its constants
+            ws = _bn_zeroed_scratch(c, x2d.device)
+            y, consts = hip_matmul_bn_stats_fin(x2d, w, ws, (prev.sc, prev.sh, prev.relu) if xf else None, 2 if defer else 1,
+                                                gamma, beta, b, decay, running_mean, running_var)
+            folded = True
+        elif xf:
             ws = _bn_zeroed_scratch(c, x2d.device)
             y = hip_matmul_bn_stats_xf(x2d, w, ws, prev.sc, prev.sh, prev.relu)
-            prev.consumed = True
         elif USE_GEMM_BN_STATS and c % 32 == 0:
             # the GEMM's epilogue leaves the column sums of y in the batch-norm workspace: no statistics pass over y
             ws = _bn_zeroed_scratch(c, x2d.device)
             y = hip_matmul_bn_stats(x2d, w, ws)
         else:
             ws, y = None, hip_matmul(x2d, w)
+        if xf:
+            prev.consumed = True
         ctx.xf = (prev.sc, prev.sh, bool(prev.relu)) if xf else None
         ctx.relu, ctx.pool = bool(relu), int(pool)
         ctx.prev = prev if (prev is not None and w.shape[1] > 16) else None
-        defer = defer and any(ctx.needs_input_grad)  # no tape node, nobody to keep the record: normalise here (the callers
-        #                                              also drop the request when no tape is being recorded at all)
-        if defer and not pooled:
-            save_mean, save_invstd, sc, sh = _bn_train_forward_deferred(y, b, gamma, beta, running_mean, running_var, decay, ws)
+        gx = bool(USE_BN_GRAD_ON_LOAD and c % 4 == 0 and 16 < c <= 512 and not pooled)  # what backward will do (see _gx_usable)
+        if defer:
+            if consts is not None:
+                save_mean, save_invstd, sc, sh = consts
+            else:
+                save_mean, save_invstd, sc, sh = _bn_train_forward_deferred(y, b, gamma, beta, running_mean, running_var, decay, ws)
             ctx.save_for_backward(x2d, w, y, gamma, beta, save_mean, save_invstd)
-            ctx.link = _bn_register_producer(y, y, gamma, beta, save_mean, save_invstd, relu, False, sc, sh)
+            ctx.link = _bn_register_producer(y, y, gamma, beta, save_mean, save_invstd, relu, False, sc, sh, gx=gx)
             if ctx.link is None:
                 raise RuntimeError("deferred batch norm needs the producer links (USE_DGRAD_BN_STATS)")
             return y  # un-normalised: only the next dense layer of the stack may consume it
-        z, ties, save_mean, save_invstd = _bn_train_forward(y, b, gamma, beta, running_mean, running_var, decay, relu, pool, ws)
+        z, ties, save_mean, save_invstd = _bn_train_forward(y, b, gamma, beta, running_mean, running_var, decay, relu, pool, ws,
+                                                            folded=folded)
         if pooled:
             ctx.save_for_backward(x2d, w, y, gamma, beta, save_mean, save_invstd, z, ties)
         else:
             ctx.save_for_backward(x2d, w, y, gamma, beta, save_mean, save_invstd)
-        ctx.link = _bn_register_producer(z, y, gamma, beta, save_mean, save_invstd, relu, pooled)
+        ctx.link = _bn_register_producer(z, y, gamma, beta, save_mean, save_invstd, relu, pooled, gx=gx)
         return z
 
     @staticmethod

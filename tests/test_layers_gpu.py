@@ -590,6 +590,7 @@ def test_training_stack_with_batch_norm_applied_on_load_equals_the_materialised_
     for on in (True, False):
         tfu.USE_BN_ON_LOAD = on
         tfu.USE_BN_GRAD_ON_LOAD = False  # this test pins the forward transform + its weight gradient; the gradient side has its own
+        tfu.USE_BN_FINISH_IN_PRODUCER = False  # ... and the separate-launch form of the entry points it counts
         store = tfu.set_default_store(tfu.VariableStore(device=cuda, seed=11))
         calls = []
         pn2._lib.lib.trace = calls
@@ -605,6 +606,7 @@ def test_training_stack_with_batch_norm_applied_on_load_equals_the_materialised_
             pn2._lib.lib.trace = None
             tfu.USE_BN_ON_LOAD = True
             tfu.USE_BN_GRAD_ON_LOAD = True
+            tfu.USE_BN_FINISH_IN_PRODUCER = True
         names = [c_[0] for c_ in calls]
         assert names.count("pn2_bn_relu_forward_deferred") == (len(mlp) - 1 if on else 0), names
         assert names.count("pn2_linear_bn_stats_xf") == (len(mlp) - 1 if on else 0)
@@ -671,13 +673,102 @@ def test_bn_grad_on_load_equals_the_materialised_form(pn2, cuda, kind, mlp, c, p
     hoisted = 1 if plan_on else 0
     pooled_other = 1 if (kind == "sa" and ns != 32) else 0
     want = len(mlp) - hoisted - pooled_other
-    assert counts[True]["pn2_bn_grad_constants"] == want and counts[True]["pn2_linear_wgrad_gx"] == want, counts
-    assert counts[True]["pn2_linear_dgrad_gx"] >= want - 1, counts
+    # (a layer whose dz is the data gradient of the layer above gets its constants from that GEMM's last workgroup: only the top
+    # layer of the stack still calls pn2_bn_grad_constants; the data gradients run through pn2_linear_dgrad_fin)
+    assert counts[True]["pn2_linear_wgrad_gx"] == want and counts[True]["pn2_bn_grad_constants"] <= min(want, 1), counts
     assert not any(counts[False].values()), counts
     assert len(outs[True]) == len(outs[False]) and len(outs[True]) >= 6
     for a, r in zip(outs[True], outs[False]):
         sc = max(float(r.abs().max()), 1e-3)
         assert float((a - r).abs().max()) <= 1e-5 * sc, (a.shape, float((a - r).abs().max()), sc)
+
+
+@pytest.mark.parametrize("kind,mlp,c,plan_on,ns", [("sa", [32, 32, 64], 3, False, 32), ("sa", [64, 64, 128], 64, True, 32),
+                                                   ("sa", [256, 256, 512], 256, True, 32), ("fp", [256, 128], 64, False, 0),
+                                                   ("fp", [128, 128, 128], 128, True, 0)])
+def test_bn_finish_in_the_producer_equals_the_separate_launches(pn2, cuda, kind, mlp, c, plan_on, ns):
+    """Round 6: the one-block launches that followed every producer of batch-norm sums (fold the slot copies, derive scale / shift
+    resp. the gradient constants) are done by the producer's last workgroup (two-level ticket, pn2_common.h pn2_bn_finish):
+    module output, moving averages, source gradient and every parameter gradient against the separate launches
+    (tf_util.USE_BN_FINISH_IN_PRODUCER = False), and the launches are really gone.  tf_util.py:186-204,555-581."""
+    import torch
+    tfu, pu = pn2.util.tf_util, pn2.util.pointnet_util
+    rs = np.random.RandomState(len(mlp) + c)
+    b, n = 3, 1024
+    xyz = T(s_scene(c + 1, b, n), cuda)
+    if kind == "sa":
+        m = 128
+        src0 = T(rs.randn(b, n, c).astype(np.float32), cuda)
+        new_xyz, idx = pu.sa_geometry(xyz, m, 0.8, ns)
+        geo = (new_xyz, idx, pu.scatter_plan(idx, n)) if plan_on else (new_xyz, idx)
+        oshape = (b, m, mlp[-1])
+    else:
+        m = 128
+        xyz2 = xyz[:, :m].contiguous()
+        src0 = T(rs.randn(b, m, 96).astype(np.float32), cuda)
+        p1 = T(rs.rand(b, n, 3 if plan_on else c).astype(np.float32), cuda)
+        dist, idx = pn2.three_nn(xyz, xyz2)
+        nn = (dist, idx, pu.scatter_plan(idx, m, dist, weight_kind=2)) if plan_on else (dist, idx)
+        oshape = (b, n, mlp[-1])
+    probe = torch.sin(torch.arange(int(np.prod(oshape)), device=cuda).float() * 0.13).reshape(oshape)
+    outs, names = {}, {}
+    for on in (True, False):
+        tfu.USE_BN_FINISH_IN_PRODUCER = on
+        store = tfu.set_default_store(tfu.VariableStore(device=cuda, seed=11))
+        calls = []
+        pn2._lib.lib.trace = calls
+        try:
+            tfu.reset_bn_links()
+            src = src0.clone().requires_grad_(True)
+            if kind == "sa":
+                _, out, _ = pu.pointnet_sa_module(xyz, src, m, 0.8, ns, mlp, None, False, True, 0.5, "mod", geometry=geo)
+            else:
+                out = pu.pointnet_fp_module(xyz, xyz2, p1, src, mlp, True, 0.5, "mod", nn=nn)
+            (out * probe).sum().backward()
+        finally:
+            pn2._lib.lib.trace = None
+            tfu.USE_BN_FINISH_IN_PRODUCER = True
+        names[on] = [c_[0] for c_ in calls]
+        outs[on] = [out.detach(), src.grad] + [p_.grad for _, p_ in sorted(store.params.items()) if p_.grad is not None] + \
+                   [v.clone() for _, v in sorted(store.buffers.items())]
+    assert "pn2_linear_bn_stats_fin" in names[True] and "pn2_linear_dgrad_fin" in names[True]
+    assert "pn2_linear_bn_stats_fin" not in names[False] and "pn2_linear_dgrad_fin" not in names[False]
+    assert "pn2_linear_bn_stats_xf" not in names[True] and "pn2_linear_bn_stats" not in names[True]
+    assert len(names[True]) < len(names[False])
+    assert len(outs[True]) == len(outs[False]) and len(outs[True]) >= 6
+    for a, r in zip(outs[True], outs[False]):
+        sc = max(float(r.abs().max()), 1e-3)
+        assert float((a - r).abs().max()) <= 1e-5 * sc, (a.shape, float((a - r).abs().max()), sc)
+
+
+@pytest.mark.parametrize("rows,cin,cout", [(524288, 32, 32), (131072, 128, 128), (1024, 768, 256), (40000, 64, 512), (33, 32, 32)])
+def test_bn_finish_ticket_under_many_workgroups(pn2, cuda, rows, cin, cout):
+    """The ticket of pn2_bn_finish under load: the forward GEMM + statistics + constants as ONE launch (finish 2), twelve times in a
+    row on grids of 1 .. 4096 workgroups, against float64 moments of the same y -- a finishing workgroup that ran before another
+    workgroup's sums had landed, or read a stale copy, would miss whole tiles of rows -- and the counters must read exactly
+    `workgroups` afterwards."""
+    import torch
+    tfu = pn2.util.tf_util
+    rs = np.random.RandomState(rows % 991 + cout)
+    x = T(rs.randn(rows, cin).astype(np.float32), cuda)
+    w = T((rs.randn(cin, cout) / np.sqrt(cin)).astype(np.float32), cuda)
+    w[0, 1] = 3.0
+    gamma = T((1.0 + 0.1 * rs.randn(cout)).astype(np.float32), cuda)
+    beta = T((0.1 * rs.randn(cout)).astype(np.float32), cuda)
+    nbytes = pn2._lib.lib.pn2_bn_workspace_bytes(cout)
+    for it in range(12):
+        ws = torch.zeros(nbytes // 8, dtype=torch.float64, device=cuda)
+        rm, rv = torch.zeros(cout, device=cuda), torch.ones(cout, device=cuda)
+        y, (save_mean, save_invstd, sc, sh) = tfu.hip_matmul_bn_stats_fin(x, w, ws, None, 2, gamma, beta, None, 0.5, rm, rv)
+        yd = y.double()
+        mean, var = yd.mean(0), yd.var(0, unbiased=False)
+        assert float((save_mean.double() - mean).abs().max()) <= 1e-5 * max(1.0, float(mean.abs().max())), it
+        invstd = 1.0 / torch.sqrt(var + 1e-3)
+        assert float(((save_invstd.double() - invstd) / invstd).abs().max()) <= 1e-5, it
+        assert float((sc.double() - gamma.double() * invstd).abs().max()) <= 1e-5 * float(invstd.max()), it
+        assert float((rm.double() - 0.5 * mean).abs().max()) <= 1e-5 * max(1.0, float(mean.abs().max())), it
+        tick = ws[:48].view(torch.int32)[:65].cpu().numpy()  # 64 first-level counters + the second level
+        assert tick[:64].sum() > 0 and tick[64] == min(64, int(tick[:64].sum())), tick
 
 
 def test_deferred_batch_norm_output_must_reach_a_dense_layer(pn2, cuda):
@@ -1649,6 +1740,7 @@ def test_bn_grad_sums_from_the_next_layers_dgrad(pn2, cuda, widths, pool, rows_s
     probe = torch.cos(torch.arange(int(np.prod(oshape)), device=cuda).float() * 0.37).reshape(oshape)
     calls = []
     real, real_gx = pn2._lib.lib.pn2_bn_relu_backward_stats, pn2._lib.lib.pn2_bn_grad_constants
+    real_fin = pn2._lib.lib.pn2_linear_dgrad_fin
     outs = {}
     for use in (True, False):
         tfu.USE_DGRAD_BN_STATS = use
@@ -1656,8 +1748,11 @@ def test_bn_grad_sums_from_the_next_layers_dgrad(pn2, cuda, widths, pool, rows_s
         try:
             if use:
                 pn2._lib.lib.pn2_bn_relu_backward_stats = lambda *a: (calls.append(a[1]), real(*a))[1]
-                # the on-load form of the batch-norm gradient (round 6) takes the sums the same way: stats_done = a[12]
-                pn2._lib.lib.pn2_bn_grad_constants = lambda *a: (calls.append(a[1]) if a[12] else None, real_gx(*a))[1]
+                # the on-load form of the batch-norm gradient (round 6) takes the sums the same way: stats_done = a[13]
+                pn2._lib.lib.pn2_bn_grad_constants = lambda *a: (calls.append(a[1]) if a[13] else None, real_gx(*a))[1]
+                # ... and with the finish inside the producer the data-gradient GEMM of the layer above leaves sums, fold and
+                # constants in one launch: y_below = a[13], width of the layer below = a[1]
+                pn2._lib.lib.pn2_linear_dgrad_fin = lambda *a: (calls.append(a[1]) if a[13] is not None else None, real_fin(*a))[1]
             xx = x0.clone().requires_grad_(True)
             params, h = [], xx
             for i, wd in enumerate(widths):
@@ -1675,6 +1770,7 @@ def test_bn_grad_sums_from_the_next_layers_dgrad(pn2, cuda, widths, pool, rows_s
             tfu.USE_DGRAD_BN_STATS = True
             pn2._lib.lib.pn2_bn_relu_backward_stats = real
             pn2._lib.lib.pn2_bn_grad_constants = real_gx
+            pn2._lib.lib.pn2_linear_dgrad_fin = real_fin
     assert calls == list(widths[:-1][::-1]), calls   # every layer but the last got its sums from the layer above
     for a, r in zip(outs[True], outs[False]):
         s = max(float(r.abs().max()), 1e-3)

@@ -274,7 +274,7 @@ def test_deferred_batch_norm_constants_and_load_transform_vs_float64(pn2, cuda, 
         ref = zref @ w.astype(np.float64)
         assert np.abs(y2.cpu().numpy() - ref).max() <= 2e-5 * max(1.0, np.abs(ref).max())
         sums = ws2.cpu().numpy()
-        head = 8
+        head = sums.size - 65 * 2 * cout  # doubles in front of final[2][cout] | slot[64][2][cout] (ticket counters live there)
         got = sums[head + 2 * cout:].reshape(-1, 2, cout).sum(0)      # slot copies [nslots][2][cout]
         np.testing.assert_allclose(got[0], ref.sum(0), rtol=1e-4, atol=1e-2 * np.sqrt(rows))
         np.testing.assert_allclose(got[1], (ref ** 2).sum(0), rtol=1e-4)
@@ -320,7 +320,7 @@ def test_every_gemm_of_a_real_step_is_as_accurate_as_the_library(pn2, cuda):
                      float(((dy @ w.t()).double() - ref).norm() / ref.norm())))
         return dx
 
-    orig_dgx, orig_nw = tfu._hip_dgrad_gx, tfu.hip_linear_narrow
+    orig_nw, orig_fin, orig_dfin = tfu.hip_linear_narrow, tfu.hip_matmul_bn_stats_fin, tfu._hip_dgrad_fin
 
     def nw(x, w, b=None):  # the 9-class head: GEMM + bias in one streaming launch (pn2_linear_narrow)
         y = orig_nw(x, w, b)
@@ -330,26 +330,42 @@ def test_every_gemm_of_a_real_step_is_as_accurate_as_the_library(pn2, cuda):
                      float((yt.double() - ref).norm() / ref.norm())))
         return y
 
-    def dgx(y, dz, coef, relu, pool, zmax, ties, w, link):  # the data gradient that forms dy = the batch-norm gradient while loading (y, dz)
-        dx = orig_dgx(y, dz, coef, relu, pool, zmax, ties, w, link)
+    def mmfin(x_raw, w, ws, xf, finish, *a, **k):  # GEMM (+ load transform) + statistics + the last workgroup's fold / constants
+        y, consts = orig_fin(x_raw, w, ws, xf, finish, *a, **k)
+        x = x_raw
+        if xf is not None:
+            x = torch.addcmul(xf[1], x_raw, xf[0])   # one fma per element, as the kernel forms it
+            x = torch.relu(x) if xf[2] else x
+        ref = x.double() @ w.double()
+        seen.append(("fwd", tuple(x.shape), w.shape[1], float((y.double() - ref).norm() / ref.norm()),
+                     float(((x @ w).double() - ref).norm() / ref.norm())))
+        return y, consts
+
+    def dy_on_load(y, dz, coef, relu, pool, zmax, ties):  # the batch-norm gradient the data-gradient GEMM forms while loading (y, dz)
         sc, sh, mu, is_, k1, k2 = coef
         lin = y.double() * sc.double() + sh.double()  # the kernel's fmaf(y, sc, sh): one rounding of the exact value
         on = (lin > 0) if relu else torch.ones_like(lin, dtype=torch.bool)
         if pool:
+            ties = ties[0] if ties.dim() == zmax.dim() + 1 else ties  # [tie counts | ysel] of the pooled forward
             t = torch.where(on, lin, torch.zeros_like(lin)).float().view(-1, pool, y.shape[1])
             g = torch.where(t == zmax.view(-1, 1, y.shape[1]), (dz / ties).view(-1, 1, y.shape[1]), torch.zeros_like(t)).view_as(y)
         else:
             g = dz
         gk = torch.where(on, g, torch.zeros_like(g))
-        dy = sc * (-((y - mu) * is_) * k2 + (gk - k1))
+        return sc * (-((y - mu) * is_) * k2 + (gk - k1))
+
+    def dfin(dy, gx, w, link):  # the data gradient in one entry point: dy given or formed on load, + the finish of the layer below
+        dx = orig_dfin(dy, gx, w, link)
+        kind = "dgrad" if gx is None else "dgrad_gx"
+        dy = dy if gx is None else dy_on_load(*gx)
         ref = dy.double() @ w.double().t()
-        seen.append(("dgrad_gx", tuple(dy.shape), w.shape[0], float((dx.double() - ref).norm() / ref.norm()),
+        seen.append((kind, tuple(dy.shape), w.shape[0], float((dx.double() - ref).norm() / ref.norm()),
                      float(((dy @ w.t()).double() - ref).norm() / ref.norm())))
         return dx
 
     tfu.hip_matmul, tfu.hip_linear_dgrad, tfu.hip_matmul_bn_stats, tfu.hip_linear_dgrad_linked = mm, dg, mm, dg
     tfu.hip_matmul_bn_stats_xf = mmx
-    tfu._hip_dgrad_gx, tfu.hip_linear_narrow = dgx, nw
+    tfu.hip_linear_narrow, tfu.hip_matmul_bn_stats_fin, tfu._hip_dgrad_fin = nw, mmfin, dfin
     try:
         tfu.set_default_store(tfu.VariableStore(device=cuda, seed=5))
         logits, _ = pn2.model.get_model(pc, True, 9, hp, bn_decay=0.5)
@@ -357,7 +373,7 @@ def test_every_gemm_of_a_real_step_is_as_accurate_as_the_library(pn2, cuda):
     finally:
         tfu.hip_matmul, tfu.hip_linear_dgrad, tfu.hip_matmul_bn_stats, tfu.hip_linear_dgrad_linked = orig_mm, orig_dg, orig_mms, orig_dgl
         tfu.hip_matmul_bn_stats_xf = orig_mmx
-        tfu._hip_dgrad_gx, tfu.hip_linear_narrow = orig_dgx, orig_nw
+        tfu.hip_linear_narrow, tfu.hip_matmul_bn_stats_fin, tfu._hip_dgrad_fin = orig_nw, orig_fin, orig_dfin
     assert sum(1 for s_ in seen if s_[0] == "fwd") == 23 and sum(1 for s_ in seen if s_[0].startswith("dgrad")) == 22
     assert sum(1 for s_ in seen if s_[0] == "dgrad_gx") >= 14  # every batch-normalised layer below another dense layer
     for kind, shape, n, e_pn2, e_torch in seen:
