@@ -233,6 +233,12 @@ int pn2_three_interpolate_grad_ws(int b, int n, int c, int m, const float *grad_
  * is read in place), c % 4 == 0, c <= 1024, out (b,nsrc,c) 16-byte aligned, overwritten (no zero fill needed).  The order
  * of a list (= the fp32 summation order) is fixed by the build. */
 size_t pn2_scatter_plan_bytes(int b, int nent, int nsrc);
+/* pn2_scatter_plan_build for up to 8 plans of one batch in ONE memset + three launches (a training step builds seven beside the
+ * previous step's dense work): plan i = the pn2_scatter_plan_bytes(b, nent[i], nsrc[i]) bytes at buffer + offset[i] (offsets
+ * ascending, 16-byte aligned, non-overlapping, inside buffer_bytes), each a plan pn2_scatter_plan_apply takes. */
+int pn2_scatter_plan_build_multi(int nplans, int b, const int *nent, const int *div, const int *nsrc, const int *const *idx,
+                                 const float *const *weight, const int *weight_kind, void *buffer, const size_t *offset,
+                                 size_t buffer_bytes, void *stream);
 int pn2_scatter_plan_build(int b, int nent, int div, int nsrc, const int *idx, const float *weight, int weight_kind,
                            void *plan, size_t plan_bytes, void *stream);
 int pn2_scatter_plan_apply(int b, int nent, int div, int c, int nsrc, const float *rows_in, int in_stride,
@@ -242,6 +248,11 @@ int pn2_scatter_plan_apply(int b, int nent, int div, int c, int nsrc, const floa
  * are host arrays read at call time; regions must not overlap.  Training-step plumbing: a batch's geometry tensors (mixed
  * int32 / float32 / byte buffers) into the static buffers the captured step reads. */
 int pn2_multi_copy(int n, const void *const *srcs, void *const *dsts, const unsigned long long *bytes, void *stream);
+/* pn2_multi_copy + nfill (<= 4) scalar stores of 4 or 8 bytes in the same launch: *fill_dsts[i] = low fill_bytes[i] bytes of
+ * fill_vals[i] (host arrays; the values travel in the launch arguments).  A captured training step's per-step scalars (Adam's
+ * bias-corrected rate, the dropout step) ride with its input copy. */
+int pn2_multi_copy_fill(int n, const void *const *srcs, void *const *dsts, const unsigned long long *bytes, int nfill,
+                        void *const *fill_dsts, const unsigned long long *fill_vals, const int *fill_bytes, void *stream);
 
 /* ---- fused layer kernels (new: no reference kernel; they replace the TF
  *      sub-graphs of util/pointnet_util.py:44-54,150-170 and :300-325) ------- */
@@ -665,6 +676,17 @@ int pn2_bn_relu_backward_mode(long long rows, int c, const float *dz, const floa
                               const float *save_mean, const float *save_invstd, int relu, int pool, const float *zmax,
                               const float *ties, void *workspace, size_t workspace_bytes, int stats_mode, float *dy,
                               float *dgamma, float *dbeta, void *stream);
+
+/* First layer of an SA module whose points carry few channels (c <= 5: xyz + rgb of the level-0 module), training path, in ONE
+ * launch: y (b,m,nsample,cout) = [group_point(xyz, idx) - new_xyz | group_point(points, idx)] . w (3 + c, cout)
+ * (pointnet_util.py:39-54 + tf_util.py:181-186) written once, its batch statistics taken on the way out into the ZEROED
+ * workspace and folded by the launch's last workgroup (finish 1) or folded and turned into the deferred batch norm's constants
+ * (finish 2, see pn2_linear_bn_stats_fin).  xg (b,m,nsample,3+c), optional: the grouped input for the weight gradient. */
+int pn2_sa_first_layer_bn(int b, int n, int m, int nsample, int c, int cout, const float *xyz, const float *new_xyz,
+                          const float *points, const int *idx, const float *w, float *y, float *xg, void *workspace,
+                          size_t workspace_bytes, int finish, const float *gamma, const float *beta, const float *bias, float eps,
+                          float decay, float *running_mean, float *running_var, float *save_mean, float *save_invstd,
+                          float *scale, float *shift, void *stream);
 
 /* First layer of an SA / FP module of the TRAINING path with its feature half applied to the source rows (gather and
  * interpolation are linear and commute with a 1x1 conv):

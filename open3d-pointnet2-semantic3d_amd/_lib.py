@@ -78,7 +78,10 @@ SIGNATURES = {
     "pn2_fp_mlp_wide": [c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p,
                         c_void_p, c_void_p, c_void_p],
     "pn2_multi_copy": [c_int, c_void_p, c_void_p, c_void_p, c_void_p],
+    "pn2_multi_copy_fill": [c_int, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p],
     "pn2_scatter_plan_build": [c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_int, c_void_p, ctypes.c_size_t, c_void_p],
+    "pn2_scatter_plan_build_multi": [c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                                     ctypes.c_size_t, c_void_p],
     "pn2_scatter_plan_apply": [c_int, c_int, c_int, c_int, c_int, c_void_p, c_int, c_void_p, ctypes.c_size_t, c_void_p, c_void_p],
     "pn2_linear_bn_stats": [c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, ctypes.c_size_t, c_void_p],
     "pn2_bn_relu_forward_stats": [ctypes.c_longlong, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_float, c_int, c_int,
@@ -108,6 +111,9 @@ SIGNATURES = {
     "pn2_bn_relu_backward_mode": [ctypes.c_longlong, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int,
                                   c_int, c_void_p, c_void_p, c_void_p, ctypes.c_size_t, c_int, c_void_p, c_void_p, c_void_p,
                                   c_void_p],
+    "pn2_sa_first_layer_bn": [c_int, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                              c_void_p, c_void_p, ctypes.c_size_t, c_int, c_void_p, c_void_p, c_void_p, c_float, c_float,
+                              c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p],
     "pn2_linear_narrow": [c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p],
     "pn2_bn_grad_constants": [ctypes.c_longlong, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int,
                               c_void_p, c_void_p, c_void_p, c_int, c_void_p, ctypes.c_size_t, c_void_p, c_void_p, c_void_p, c_void_p],
@@ -211,7 +217,7 @@ _raw = _load()
 _STATEFUL = frozenset({"pn2_bn_relu_forward", "pn2_bn_relu_forward_ws0", "pn2_bn_relu_forward_stats", "pn2_linear_bn_stats",
                        "pn2_bn_relu_forward_pool", "pn2_bn_relu_forward_deferred", "pn2_linear_bn_stats_xf", "pn2_linear_wgrad_gx",
                        "pn2_linear_wgrad_accumulate_xf", "pn2_bn_grad_constants", "pn2_linear_dgrad_gx", "pn2_linear_dgrad_fin",
-                       "pn2_linear_bn_stats_fin", "pn2_bn_relu_forward_mode", "pn2_linear_dgrad_bn_grad_stats",
+                       "pn2_linear_bn_stats_fin", "pn2_bn_relu_forward_mode", "pn2_sa_first_layer_bn", "pn2_linear_dgrad_bn_grad_stats",
                        "pn2_adam_step", "pn2_linear_wgrad_accumulate"})
 
 

@@ -146,6 +146,81 @@ bn_stats_kernel(long long rows, int c, long long slab, int nslots, const float* 
     bn_block_sums<VEC, 2>(mp, c, nslots, part, ws, fin);
 }
 
+// The first layer of an SA module whose points carry FEW channels (the level-0 module: xyz + rgb, util/pointnet_util.py:39-54 then
+// tf_util.py:181-186) computed where its input is gathered: row r = (cloud, centre j, neighbour k),
+//     in = [xyz[idx[r]] - new_xyz[j] | points[idx[r], 0:c]]   (CIN = 3 + c <= 8 values),   y[r, :] = in @ W (CIN, cout),
+// one thread per (row, 4 output channels) -- W's CIN rows of its four columns in registers, an fma chain in k order -- with the
+// batch statistics of y taken on the way out (the mapping and the block reduction of bn_stats_kernel) and the grouped input xg
+// (rows, CIN) kept for the weight gradient.  An MFMA tile would pad K = 6 to 32 behind scalar operand loads (measured 50 us for
+// 524288 x 6 -> 32); this is bound by the write of y (67 MB).  cout % 4 == 0, cout <= 1024.
+template <int CIN>
+__global__ void __launch_bounds__(kBnThreads)
+sa_first_layer_stats_kernel(long long rows, int n, int m, int nsample, int cout, long long slab, int nslots,
+                            const float* __restrict__ xyz, const float* __restrict__ new_xyz, const float* __restrict__ points,
+                            const int* __restrict__ idx, const float* __restrict__ w, float* __restrict__ y,
+                            float* __restrict__ xg, double* __restrict__ ws, Pn2BnFinish fin) {
+    constexpr int C = CIN - 3;
+    const BnMap<4> mp(cout);
+    const long long rb = (long long)blockIdx.x * slab;
+    const long long re = rb + slab < rows ? rb + slab : rows;
+    double part[2][4];
+#pragma unroll
+    for (int v = 0; v < 4; ++v) part[0][v] = part[1][v] = 0.0;
+    if (mp.active) {
+        float4 wr[CIN];
+#pragma unroll
+        for (int k = 0; k < CIN; ++k) wr[k] = *reinterpret_cast<const float4*>(w + (size_t)k * cout + (size_t)mp.cc * 4);
+        const long long per_cloud = (long long)m * nsample;
+        constexpr int U = 4;  // rows in flight per thread: idx -> gather is a dependent chain of two round trips
+        for (long long r0 = rb + mp.rr; r0 < re; r0 += (long long)U * mp.rp) {
+            int ii[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const long long r = r0 + (long long)u * mp.rp;
+                ii[u] = idx[r < re ? r : re - 1];
+            }
+            float in[U][CIN];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const long long r = r0 + (long long)u * mp.rp;
+                const long long rc = r < re ? r : re - 1;
+                const unsigned bi = (unsigned)rc / (unsigned)per_cloud;  // rows < 2^31 (checked by the entry point)
+                const unsigned grp = (unsigned)rc / (unsigned)nsample;   // = bi * m + j
+                const size_t src = (size_t)bi * n + (size_t)ii[u];
+#pragma unroll
+                for (int a = 0; a < 3; ++a) in[u][a] = xyz[src * 3 + a] - new_xyz[(size_t)grp * 3 + a];
+#pragma unroll
+                for (int a = 0; a < C; ++a) in[u][3 + a] = points[src * C + a];
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const long long r = r0 + (long long)u * mp.rp;
+                if (r >= re) break;
+                float o[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int k = 0; k < CIN; ++k) {
+                    o[0] = __builtin_fmaf(in[u][k], wr[k].x, o[0]);
+                    o[1] = __builtin_fmaf(in[u][k], wr[k].y, o[1]);
+                    o[2] = __builtin_fmaf(in[u][k], wr[k].z, o[2]);
+                    o[3] = __builtin_fmaf(in[u][k], wr[k].w, o[3]);
+                }
+                *reinterpret_cast<float4*>(y + (size_t)r * cout + (size_t)mp.cc * 4) = make_float4(o[0], o[1], o[2], o[3]);
+                if (xg && mp.cc == 0) {
+#pragma unroll
+                    for (int k = 0; k < CIN; ++k) xg[(size_t)r * CIN + k] = in[u][k];
+                }
+#pragma unroll
+                for (int v = 0; v < 4; ++v) {
+                    const double d = (double)o[v];
+                    part[0][v] += d;
+                    part[1][v] = __builtin_fma(d, d, part[1][v]);
+                }
+            }
+        }
+    }
+    bn_block_sums<4, 2>(mp, cout, nslots, part, ws, fin);
+}
+
 // bn_scale_shift (the per-channel constants of the normalisation): pn2_common.h
 
 // Per-channel (scale, shift) of the forward into LDS.  Every block derives (mean, invstd) of all channels from the fp64
@@ -828,4 +903,49 @@ extern "C" int pn2_bn_relu_backward_mode(long long rows, int c, const float* dz,
     if (stats_mode < 0 || stats_mode > 3) return PN2_EINVAL;
     return bn_relu_backward_impl(rows, c, dz, y, gamma, beta, save_mean, save_invstd, relu, pool, zmax, ties, workspace,
                                  workspace_bytes, dy, dgamma, dbeta, stream, stats_mode);
+}
+
+// First layer of an SA module with few point channels (c <= 5: the level-0 module's colours), training path, in ONE launch:
+// gather + centre + concat (pn2_sa_group_concat) + the (3 + c) -> cout product (tf_util.py:181-186) + the batch statistics of y
+// (workspace ZEROED by the caller) + their fold by the launch's last workgroup (finish 1; pn2_bn_relu_forward_mode /
+// pn2_bn_relu_forward_pool with stats_mode 3 normalise) or fold + the constants pn2_bn_relu_forward_deferred publishes
+// (finish 2).  y (b, m, nsample, cout) un-normalised; xg (b, m, nsample, 3 + c), optional: the grouped input, operand of the
+// weight gradient.  cout % 4 == 0, cout <= 1024, 16-byte aligned w / y.
+extern "C" int pn2_sa_first_layer_bn(int b, int n, int m, int nsample, int c, int cout, const float* xyz, const float* new_xyz,
+                                     const float* points, const int* idx, const float* w, float* y, float* xg,
+                                     void* workspace, size_t workspace_bytes, int finish, const float* gamma, const float* beta,
+                                     const float* bias, float eps, float decay, float* running_mean, float* running_var,
+                                     float* save_mean, float* save_invstd, float* scale, float* shift, void* stream) {
+    if (b <= 0 || n <= 0 || m <= 0 || nsample <= 0 || c < 0 || cout <= 0) return PN2_EINVAL;
+    if (!xyz || !new_xyz || !idx || !w || !y || !workspace || (c > 0 && !points)) return PN2_ENULL;
+    if (finish != 1 && finish != 2) return PN2_EINVAL;
+    if (c > 5 || cout % 4 != 0 || cout > 1024 || (((uintptr_t)w | (uintptr_t)y) % 16) != 0) return PN2_EUNSUP;
+    const long long rows = (long long)b * m * nsample;
+    if (rows + 128 > 0x7fffffffLL) return PN2_ERANGE;
+    BnPlan p;
+    const int rc = bn_plan(rows, cout, y, y, y, p);
+    if (rc != PN2_OK) return rc;
+    if (p.vec != 4) return PN2_EUNSUP;
+    if (workspace_bytes < pn2_bn_workspace_bytes(cout) || ((uintptr_t)workspace % 8) != 0) return PN2_EINVAL;
+    double* ws = static_cast<double*>(workspace);
+    Pn2BnFinish f{};
+    f.kind = finish; f.c = cout; f.nslots = p.nslots; f.rows = rows; f.ws = ws;
+    if (finish == 2) {
+        if (!gamma || !beta || !save_mean || !save_invstd || (scale == nullptr) != (shift == nullptr)) return PN2_ENULL;
+        if ((running_mean == nullptr) != (running_var == nullptr)) return PN2_ENULL;
+        f.gamma = gamma; f.beta = beta; f.bias = bias; f.eps = eps; f.decay = decay; f.running_mean = running_mean;
+        f.running_var = running_var; f.save_mean = save_mean; f.save_invstd = save_invstd; f.scale = scale; f.shift = shift;
+    }
+    hipStream_t st = static_cast<hipStream_t>(stream);
+#define PN2_SAF(CIN_)                                                                                                          \
+    case CIN_:                                                                                                                 \
+        sa_first_layer_stats_kernel<CIN_><<<p.stat_blocks, kBnThreads, 0, st>>>(rows, n, m, nsample, cout, p.slab, p.nslots, xyz, \
+                                                                               new_xyz, points, idx, w, y, xg, ws, f);          \
+        break;
+    switch (3 + c) {
+        PN2_SAF(3) PN2_SAF(4) PN2_SAF(5) PN2_SAF(6) PN2_SAF(7) PN2_SAF(8)
+    }
+#undef PN2_SAF
+    PN2_RETURN_IF_LAUNCH_FAILED();
+    return PN2_OK;
 }

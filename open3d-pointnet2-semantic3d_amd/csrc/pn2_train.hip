@@ -164,15 +164,27 @@ inline int grid_1d(long long n) {
 // buffers -- going into the static buffers a captured training step reads: torch._foreach_copy_ falls back to one memcpy
 // per tensor for mixed dtypes, ~25 launches on the step's critical path)
 constexpr int kMultiCopyMax = 48;
+constexpr int kMultiFillMax = 4;
 struct MultiCopyArgs {
     const unsigned char* src[kMultiCopyMax];
     unsigned char* dst[kMultiCopyMax];
     unsigned long long bytes[kMultiCopyMax];
+    // a few 4- or 8-byte scalars written by the same launch (their values travel in the launch arguments): the per-step scalars of
+    // a captured training step -- Adam's lr_t, the dropout step -- which were one fill launch each between two graph replays
+    void* fill_dst[kMultiFillMax];
+    unsigned long long fill_val[kMultiFillMax];
+    int fill_bytes[kMultiFillMax];
+    int nfill;
 };
 
 __global__ void __launch_bounds__(256)
 multi_copy_kernel(MultiCopyArgs a) {
     const int t = blockIdx.y;
+    if (t == 0 && blockIdx.x == 0 && (int)threadIdx.x < a.nfill) {
+        const int f = threadIdx.x;
+        if (a.fill_bytes[f] == 8) *static_cast<unsigned long long*>(a.fill_dst[f]) = a.fill_val[f];
+        else *static_cast<unsigned*>(a.fill_dst[f]) = (unsigned)a.fill_val[f];
+    }
     const unsigned char* __restrict__ s = a.src[t];
     unsigned char* __restrict__ d = a.dst[t];
     const unsigned long long nb = a.bytes[t];
@@ -276,11 +288,20 @@ extern "C" int pn2_adam_step(long long n, float* params, const float* grads, flo
 // n (<= 48) independent device-to-device copies in one launch: dst[i][0 .. bytes[i]) = src[i][0 .. bytes[i]).  srcs / dsts /
 // bytes are HOST arrays (read at call time); the regions must not overlap.  Plumbing of the training step (geometry
 // tensors of a batch into the static buffers of the captured graph).
-extern "C" int pn2_multi_copy(int n, const void* const* srcs, void* const* dsts, const unsigned long long* bytes, void* stream) {
-    if (n <= 0) return PN2_EINVAL;
-    if (n > kMultiCopyMax) return PN2_ERANGE;
-    if (!srcs || !dsts || !bytes) return PN2_ENULL;
+static int multi_copy_impl(int n, const void* const* srcs, void* const* dsts, const unsigned long long* bytes, int nfill,
+                           void* const* fill_dsts, const unsigned long long* fill_vals, const int* fill_bytes, void* stream) {
+    if (n <= 0 || nfill < 0) return PN2_EINVAL;
+    if (n > kMultiCopyMax || nfill > kMultiFillMax) return PN2_ERANGE;
+    if (!srcs || !dsts || !bytes || (nfill > 0 && (!fill_dsts || !fill_vals || !fill_bytes))) return PN2_ENULL;
     MultiCopyArgs a = {};
+    a.nfill = nfill;
+    for (int i = 0; i < nfill; ++i) {
+        if (!fill_dsts[i]) return PN2_ENULL;
+        if ((fill_bytes[i] != 4 && fill_bytes[i] != 8) || ((uintptr_t)fill_dsts[i] % (uintptr_t)fill_bytes[i]) != 0) return PN2_EINVAL;
+        a.fill_dst[i] = fill_dsts[i];
+        a.fill_val[i] = fill_vals[i];
+        a.fill_bytes[i] = fill_bytes[i];
+    }
     unsigned long long mx = 0;
     for (int i = 0; i < n; ++i) {
         if (!srcs[i] || !dsts[i]) return PN2_ENULL;
@@ -295,4 +316,18 @@ extern "C" int pn2_multi_copy(int n, const void* const* srcs, void* const* dsts,
     multi_copy_kernel<<<dim3((unsigned)gx, (unsigned)n), 256, 0, static_cast<hipStream_t>(stream)>>>(a);
     PN2_RETURN_IF_LAUNCH_FAILED();
     return PN2_OK;
+}
+
+extern "C" int pn2_multi_copy(int n, const void* const* srcs, void* const* dsts, const unsigned long long* bytes, void* stream) {
+    return multi_copy_impl(n, srcs, dsts, bytes, 0, nullptr, nullptr, nullptr, stream);
+}
+
+// pn2_multi_copy that also writes nfill (<= 4) scalars of 4 or 8 bytes: *fill_dsts[i] = the low fill_bytes[i] bytes of
+// fill_vals[i] (HOST arrays, the values travel in the launch arguments -- no host buffer a run-ahead host could rewrite before
+// an asynchronous copy has read it).  The training step's Adam rate and dropout step ride with its input copy: ONE launch
+// between two replays of the captured step (train.py:381-388 is the reference's per-step feed of those scalars).
+extern "C" int pn2_multi_copy_fill(int n, const void* const* srcs, void* const* dsts, const unsigned long long* bytes, int nfill,
+                                   void* const* fill_dsts, const unsigned long long* fill_vals, const int* fill_bytes,
+                                   void* stream) {
+    return multi_copy_impl(n, srcs, dsts, bytes, nfill, fill_dsts, fill_vals, fill_bytes, stream);
 }

@@ -76,14 +76,17 @@ def compute_geometry(l0_xyz, hyperparams, plans=False):
             nn = [three_nn(xyzs[3 - fi], xyzs[4 - fi]) for fi in range(4)]
         gplans, iplans = [None] * 4, [None] * 4
         if plans:
+            specs = [None] * 8  # all of them in one memset + three launches (pu.scatter_plans)
             for li in range(4):  # level li groups the features of level li: colour (3 wide) for li = 0, else the MLP output
                 width = 3 * int(hyperparams["use_color"]) if li == 0 else SA_MLPS[li - 1][-1]
                 if width > 0 and width % 4 == 0:
-                    gplans[li] = pu.scatter_plan(idxs[li], xyzs[li].shape[1])
+                    specs[li] = (idxs[li], xyzs[li].shape[1], None, None)
             for fi in range(4):
                 width = SA_MLPS[3][-1] if fi == 0 else FP_MLPS[fi - 1][-1]
                 if width % 4 == 0:
-                    iplans[fi] = pu.scatter_plan(nn[fi][1], xyzs[4 - fi].shape[1], nn[fi][0], weight_kind=2)
+                    specs[4 + fi] = (nn[fi][1], xyzs[4 - fi].shape[1], nn[fi][0], 2)
+            built = pu.scatter_plans(specs)
+            gplans, iplans = built[:4], built[4:]
     return {"xyzs": xyzs, "idxs": idxs, "nn": nn, "gplans": gplans, "iplans": iplans}
 
 

@@ -282,18 +282,23 @@ class Trainer:
                 geo = self._geometry_for(pc, self._stream)  # eager (or eagerly prefetched: prefetch_geometry)
                 if recapture:
                     self._capture(pc, labels, smpw, decay, geo, split)
-                self._lr_slot.fill_(lr_t)
-                self.store.set_step(self.step_count)
-                # every per-step device-to-device copy (inputs, and this batch's geometry when it is not in place yet) in ONE
-                # launch: they sit between two graphs on the critical path
+                # every per-step device-to-device copy (inputs, and this batch's geometry when it is not in place yet) AND the
+                # step's scalars (Adam's lr_t, the dropout step: their values travel in the launch arguments) in ONE launch: they
+                # sit between two graphs on the critical path
                 pairs = [(d, s_) for d, s_ in zip(self._static[:3], (pc, labels, smpw))
                          if d.data_ptr() != s_.data_ptr() and s_.is_contiguous() and s_.dtype == d.dtype]
                 for d, s_ in zip(self._static[:3], (pc, labels, smpw)):
                     if d.data_ptr() != s_.data_ptr() and not (s_.is_contiguous() and s_.dtype == d.dtype):
                         d.copy_(s_, non_blocking=True)
                 pairs += list(zip(model.geometry_tensors(self._static_geo), model.geometry_tensors(geo)))
-                if pairs:
-                    tf_util.multi_copy_([d for d, _ in pairs], [s_ for _, s_ in pairs])
+                fills = [(self._lr_slot, lr_t)] + self.store.step_fills(self.step_count)
+                if pairs and len(fills) <= 4:
+                    tf_util.multi_copy_([d for d, _ in pairs], [s_ for _, s_ in pairs], fills=fills)
+                else:
+                    self._lr_slot.fill_(lr_t)
+                    self.store.set_step(self.step_count)
+                    if pairs:
+                        tf_util.multi_copy_([d for d, _ in pairs], [s_ for _, s_ in pairs])
                 taken = torch.cuda.Event()
                 taken.record(self._stream)
                 self._prefetch(next_pc, taken)

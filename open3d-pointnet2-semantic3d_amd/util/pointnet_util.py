@@ -176,6 +176,42 @@ def scatter_plan(idx, nsrc, weight=None, weight_kind=None):
     return plan
 
 
+def scatter_plans(specs):
+    """several scatter plans of one batch in ONE memset + three launches (pn2_scatter_plan_build_multi) instead of four launches
+    each: specs = [(idx (b, rows, k) int32, nsrc, weight or None, weight_kind or None), ...] as scatter_plan takes them (None
+    entries pass through) -> list of plans, slices of one buffer.  The geometry stream of a training step builds its seven
+    plans this way (model.compute_geometry)."""
+    live = [(i, sp) for i, sp in enumerate(specs) if sp is not None]
+    out = [None] * len(specs)
+    for lo in range(0, len(live), 8):
+        chunk = live[lo:lo + 8]
+        b = chunk[0][1][0].shape[0]
+        dev = chunk[0][1][0].device
+        nent, div, nsrc, kinds, idxs, ws, offs, total = [], [], [], [], [], [], [], 0
+        for _, (idx, ns, weight, weight_kind) in chunk:
+            if idx.shape[0] != b:
+                raise ValueError("scatter_plans: one batch size")
+            ne = idx.shape[1] * idx.shape[2]
+            nent.append(ne)
+            div.append(idx.shape[2] if weight is not None else 1)
+            nsrc.append(int(ns))
+            kinds.append((1 if weight_kind is None else weight_kind) if weight is not None else 0)
+            idxs.append(idx.contiguous())
+            ws.append(None if weight is None else weight.contiguous())
+            offs.append(total)
+            total += (lib.pn2_scatter_plan_bytes(b, ne, int(ns)) + 15) // 16 * 16
+        buf = torch.empty(total, dtype=torch.uint8, device=dev)
+        k = len(chunk)
+        ia = lambda v: (ctypes.c_int * k)(*v)  # noqa: E731
+        pa = lambda ts: (ctypes.c_void_p * k)(*[None if t is None else t.data_ptr() for t in ts])  # noqa: E731
+        with torch.cuda.device(dev):
+            check(lib.pn2_scatter_plan_build_multi(k, b, ia(nent), ia(div), ia(nsrc), pa(idxs), pa(ws), ia(kinds), ptr(buf),
+                                                   (ctypes.c_size_t * k)(*offs), total, stream_ptr()), "pn2_scatter_plan_build_multi")
+        for j, (i, _) in enumerate(chunk):
+            out[i] = buf[offs[j]:offs[j] + lib.pn2_scatter_plan_bytes(b, nent[j], nsrc[j])]
+    return out
+
+
 def _scatter_plan_apply(plan, rows_in, col0, c, nent, div, nsrc):
     """columns [col0, col0+c) of rows_in (b, ..., width) (read in place) scattered through `plan` -> (b, nsrc, c)"""
     b, width = rows_in.shape[0], rows_in.shape[-1]
@@ -495,7 +531,19 @@ def pointnet_sa_module(xyz, points, npoint, radius, nsample, mlp, mlp2, group_al
             # (tf_util.USE_BN_ON_LOAD): the next layer applies the batch norm + ReLU while loading it
             defer = lambda i, rows: (bool(is_training) and bn and i + 1 < len(mlp)  # noqa: E731
                                      and tf_util.can_defer_bn(rows, mlp[i], mlp[i + 1]))
-            if hoist:
+            small_first = (bool(is_training) and tf_util.USE_SA_FIRST_LAYER_FUSED and tf_util.USE_BN_FINISH_IN_PRODUCER
+                           and not hoist and not group_all and not knn and use_xyz and bn and pooling == "max"
+                           and points is not None and points.dtype == torch.float32 and points.shape[2] <= 5
+                           and not points.requires_grad and len(mlp) > 0 and mlp[0] % 4 == 0 and mlp[0] <= 1024
+                           and nsample <= 1024)
+            if small_first:
+                # few point channels (the level-0 module: xyz + rgb): front end + first conv + its statistics in ONE launch
+                new_xyz, idx = geometry[:2] if geometry is not None else sa_geometry(xyz, npoint, radius, nsample)
+                grouped_xyz = None
+                new_points = tf_util.conv2d_sa_first_small(xyz, new_xyz, points, idx, mlp[0], "conv0", bn_decay,
+                                                           pool=nsample if len(mlp) == 1 else 0, defer_bn=defer(0, idx.numel()))
+                first = 1
+            elif hoist:
                 new_xyz, idx, grouped_xyz = geometry[0], geometry[1], None
                 new_points = tf_util.conv2d_hoisted_first("sa", points, (xyz, new_xyz, idx), geometry[2], 3 + points.shape[2],
                                                           mlp[0], "conv0", bn_decay, pool=nsample if len(mlp) == 1 else 0,

@@ -68,6 +68,10 @@ class VariableStore:
             self._dropout[key] = t
         return t
 
+    def step_fills(self, step):
+        """[(tensor, value)] that set_step would write: for a launch that stores them itself (tf_util.multi_copy_(fills=))"""
+        return [(t[1:2], int(step)) for t in self._dropout.values()]
+
     def set_step(self, step):
         # a fill KERNEL on the current stream.  (`t[1] = int(step)` is a host-to-device copy of a pageable scalar: it blocks
         # the host until everything queued before it has run -- measured 4.2 ms per training step, tools/train_host_probe.py)
@@ -276,10 +280,13 @@ def hip_mlp_chain(x2d, ws, bs, pool=0):
     return y
 
 
-def multi_copy_(dsts, srcs):
+def multi_copy_(dsts, srcs, fills=()):
     """dsts[i].copy_(srcs[i]) for lists of contiguous device tensors of any dtypes in ONE launch (pn2_multi_copy);
-    torch._foreach_copy_ issues one memcpy per tensor when the dtypes are mixed."""
+    torch._foreach_copy_ issues one memcpy per tensor when the dtypes are mixed.  fills = [(one-element float32 / int64 tensor,
+    python value), ...] (<= 4): scalars stored by the same launch, their values travelling in the launch arguments
+    (pn2_multi_copy_fill) -- a training step's lr_t and dropout step ride with its input copy."""
     import ctypes
+    import struct
     n = len(dsts)
     if n != len(srcs):
         raise ValueError("multi_copy_: list lengths differ")
@@ -289,6 +296,9 @@ def multi_copy_(dsts, srcs):
     from ..tf_ops.tf_sampling import drop_fps_tag
     for d in dsts:
         drop_fps_tag(d)  # a write through the raw pointer: no version counter moves, so the tie-record tag must not survive it
+    fills = list(fills)
+    if len(fills) > 4:
+        raise ValueError("multi_copy_: at most 4 scalar fills")
     for i0 in range(0, n, 48):
         dd, ss = dsts[i0:i0 + 48], srcs[i0:i0 + 48]
         k = len(dd)
@@ -296,8 +306,28 @@ def multi_copy_(dsts, srcs):
         dp = (ctypes.c_void_p * k)(*[t.data_ptr() for t in dd])
         nb = (ctypes.c_ulonglong * k)(*[t.numel() * t.element_size() for t in dd])
         with torch.cuda.device(dd[0].device):
-            check(lib.pn2_multi_copy(k, ctypes.cast(sp, ctypes.c_void_p), ctypes.cast(dp, ctypes.c_void_p),
-                                     ctypes.cast(nb, ctypes.c_void_p), stream_ptr()), "pn2_multi_copy")
+            if fills and i0 == 0:
+                nf = len(fills)
+                vals, sizes = [], []
+                for t, v in fills:
+                    if t.numel() != 1 or t.dtype not in (torch.float32, torch.int64):
+                        raise ValueError("multi_copy_: a fill target is one float32 or int64 element")
+                    if t.dtype == torch.float32:
+                        vals.append(struct.unpack("<I", struct.pack("<f", float(v)))[0])
+                        sizes.append(4)
+                    else:
+                        vals.append(int(v) & 0xFFFFFFFFFFFFFFFF)
+                        sizes.append(8)
+                fp = (ctypes.c_void_p * nf)(*[t.data_ptr() for t, _ in fills])
+                fv = (ctypes.c_ulonglong * nf)(*vals)
+                fb = (ctypes.c_int * nf)(*sizes)
+                check(lib.pn2_multi_copy_fill(k, ctypes.cast(sp, ctypes.c_void_p), ctypes.cast(dp, ctypes.c_void_p),
+                                              ctypes.cast(nb, ctypes.c_void_p), nf, ctypes.cast(fp, ctypes.c_void_p),
+                                              ctypes.cast(fv, ctypes.c_void_p), ctypes.cast(fb, ctypes.c_void_p), stream_ptr()),
+                      "pn2_multi_copy_fill")
+            else:
+                check(lib.pn2_multi_copy(k, ctypes.cast(sp, ctypes.c_void_p), ctypes.cast(dp, ctypes.c_void_p),
+                                         ctypes.cast(nb, ctypes.c_void_p), stream_ptr()), "pn2_multi_copy")
 
 
 def _layer_arrays(ws, bs):
@@ -1073,11 +1103,11 @@ class _TrainDenseBnRelu(torch.autograd.Function):
     -> dX = dY @ w^T, dW on pn2_linear_wgrad.  Replaces nine elementwise / reduction kernels per layer."""
 
     @staticmethod
-    def forward(ctx, x2d, w, b, gamma, beta, running_mean, running_var, decay, relu, pool, defer):
+    def forward(ctx, x2d, w, b, gamma, beta, running_mean, running_var, decay, relu, pool, defer, front=None):
         c = w.shape[1]
         pooled = pool > 1
         # producer of this layer's input (if it was an un-pooled dense+BN layer of this forward pass)
-        prev = _bn_links.get(x2d.data_ptr()) if USE_DGRAD_BN_STATS else None
+        prev = _bn_links.get(x2d.data_ptr()) if (USE_DGRAD_BN_STATS and x2d is not None) else None
         prev = prev if (prev is not None and prev.y is not None and prev.shape == tuple(x2d.shape)) else None
         xf = prev is not None and prev.sc is not None  # x2d is the producer's UN-normalised output
         defer = defer and not pooled and any(ctx.needs_input_grad)  # no tape node, nobody to keep the record: normalise here
@@ -1085,7 +1115,28 @@ class _TrainDenseBnRelu(torch.autograd.Function):
         if xf and c % 32 != 0:
             raise RuntimeError("a deferred batch-norm output reached a layer that cannot apply it")
         consts, folded = None, False
-        if (xf or (USE_GEMM_BN_STATS and c % 32 == 0)) and USE_BN_FINISH_IN_PRODUCER:
+        if front is not None:
+            # the first layer of an SA module with few point channels: gather + centre + concat + product + statistics + their
+            # fold / constants in ONE launch (pn2_sa_first_layer_bn); x2d = the grouped input it leaves for the weight gradient
+            xyz, new_xyz, points, idx = front
+            bsz, n = xyz.shape[0], xyz.shape[1]
+            m, ns = idx.shape[1], idx.shape[2]
+            cpts = points.shape[2]
+            ws = _bn_zeroed_scratch(c, xyz.device)
+            y = torch.empty((bsz * m * ns, c), dtype=torch.float32, device=xyz.device)
+            x2d = torch.empty((bsz * m * ns, 3 + cpts), dtype=torch.float32, device=xyz.device)
+            if defer:
+                save_mean = torch.empty(c, dtype=torch.float32, device=xyz.device)
+                consts = (save_mean, torch.empty_like(save_mean), torch.empty_like(save_mean), torch.empty_like(save_mean))
+            cs = consts if consts is not None else (None, None, None, None)
+            with torch.cuda.device(xyz.device):
+                check(lib.pn2_sa_first_layer_bn(bsz, n, m, ns, cpts, c, ptr(xyz), ptr(new_xyz), ptr(points), ptr(idx), ptr(w.contiguous()),
+                                                ptr(y), ptr(x2d), ptr(ws), ws.numel() * ws.element_size(), 2 if defer else 1,
+                                                ptr(gamma), ptr(beta), ptr(b), BN_EPSILON, float(decay), ptr(running_mean),
+                                                ptr(running_var), ptr(cs[0]), ptr(cs[1]), ptr(cs[2]), ptr(cs[3]), stream_ptr()),
+                      "pn2_sa_first_layer_bn")
+            folded = True
+        elif (xf or (USE_GEMM_BN_STATS and c % 32 == 0)) and USE_BN_FINISH_IN_PRODUCER:
             # ONE launch: GEMM (batch norm of the layer below applied on load when it was deferred) + column sums of y + -- in the
             # launch's last workgroup -- their fold and, for a layer that defers its own batch norm, its constants
             ws = _bn_zeroed_scratch(c, x2d.device)
@@ -1140,7 +1191,7 @@ class _TrainDenseBnRelu(torch.autograd.Function):
                 pv = ctx.prev if (ctx.prev is not None and ctx.prev.y is not None) else None
                 dx = _hip_dgrad_gx(y, dz, coef, ctx.relu, ctx.pool, zmax, ties, w, pv)
             dw = _hip_wgrad_gx(x2d, ctx.xf, y, dz, coef, ctx.relu, ctx.pool, zmax, ties, w) if ctx.needs_input_grad[1] else None
-            return dx, dw, None, dgamma, dbeta, None, None, None, None, None, None
+            return dx, dw, None, dgamma, dbeta, None, None, None, None, None, None, None
         dy, dgamma, dbeta = _bn_train_backward(dz, y, gamma, beta, save_mean, save_invstd, ctx.relu, ctx.pool, zmax, ties, ctx.link)
         dx = None
         if ctx.needs_input_grad[0]:
@@ -1151,7 +1202,30 @@ class _TrainDenseBnRelu(torch.autograd.Function):
             dw = _hip_wgrad(x2d, dy, w, ctx.xf)
         # a constant in front of batch norm has no effect on the output: its gradient is exactly zero -- None, which the
         # trainer's gradient buffer treats as (and keeps at) zero without a fill per layer
-        return dx, dw, None, dgamma, dbeta, None, None, None, None, None, None
+        return dx, dw, None, dgamma, dbeta, None, None, None, None, None, None, None
+
+
+USE_SA_FIRST_LAYER_FUSED = True  # SA module, few point channels: front end + first conv + statistics in one launch (A/B, tests)
+
+
+def conv2d_sa_first_small(xyz, new_xyz, points, idx, num_output_channels, scope, bn_decay=None, pool=0, defer_bn=False):
+    """conv2d(sample_and_group's [grouped_xyz - new_xyz | grouped points], ..., bn=True, is_training=True, relu) -- the FIRST layer
+    of an SA module whose points carry at most 5 channels and no gradient (the level-0 module's colours) -- without building the
+    grouped tensor first: _TrainDenseBnRelu(front=...) on pn2_sa_first_layer_bn.  Same variables as tf_util.conv2d under `scope`.
+    -> (b, m, nsample or 1, cout)"""
+    cout = int(num_output_channels)
+    cin = 3 + points.shape[2]
+    with variable_scope(scope):
+        st, w, b, bnv = _dense_variables(cin, cout, True, (1, 1, cin, cout))
+        st.train_epoch += 1
+        beta, gamma, mean, var = bnv
+        decay = 0.9 if bn_decay is None else float(bn_decay)
+        pool = int(pool) if pool and pool > 1 else 0
+        front = (xyz.detach().contiguous(), new_xyz.detach().contiguous(), points.detach().contiguous(), idx.contiguous())
+        z = _TrainDenseBnRelu.apply(None, w.reshape(cin, cout), b, gamma, beta, mean, var, decay, True, pool,
+                                    bool(defer_bn) and not pool and torch.is_grad_enabled(), front)
+    m, ns = idx.shape[1], idx.shape[2]
+    return z.reshape(xyz.shape[0], m, ns // pool if pool else ns, cout)
 
 
 USE_HOISTED_TRAIN = True  # first layer of SA2-SA4 / FP4 with its feature half applied to the source rows (A/B, tests)

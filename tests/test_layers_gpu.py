@@ -741,6 +741,45 @@ def test_bn_finish_in_the_producer_equals_the_separate_launches(pn2, cuda, kind,
         assert float((a - r).abs().max()) <= 1e-5 * sc, (a.shape, float((a - r).abs().max()), sc)
 
 
+@pytest.mark.parametrize("c,mlp,ns,with_geo", [(3, [32, 32, 64], 32, True), (3, [64], 32, False), (5, [48, 96], 16, True),
+                                               (1, [128, 128], 32, True)])
+def test_sa_first_layer_in_one_launch_equals_the_separate_ops(pn2, cuda, c, mlp, ns, with_geo):
+    """Round 6: the first layer of an SA module with few point channels (the level-0 module: xyz + rgb) -- gather, centre, concat,
+    the (3 + c) -> w product, its batch statistics and their fold / constants -- as ONE launch (pn2_sa_first_layer_bn) against
+    pn2_sa_group_concat + the MFMA layer: module output, moving averages, every parameter gradient.
+    pointnet_util.py:39-54,150-156, tf_util.py:181-204."""
+    import torch
+    tfu, pu = pn2.util.tf_util, pn2.util.pointnet_util
+    rs = np.random.RandomState(c + len(mlp))
+    b, n, m = 3, 1024, 128
+    xyz = T(s_scene(c + 1, b, n), cuda)
+    pts = T(rs.rand(b, n, c).astype(np.float32), cuda)
+    geo = pu.sa_geometry(xyz, m, 0.8, ns) if with_geo else None
+    probe = torch.sin(torch.arange(b * m * mlp[-1], device=cuda).float() * 0.13).reshape(b, m, mlp[-1])
+    outs, names = {}, {}
+    for on in (True, False):
+        tfu.USE_SA_FIRST_LAYER_FUSED = on
+        store = tfu.set_default_store(tfu.VariableStore(device=cuda, seed=11))
+        calls = []
+        pn2._lib.lib.trace = calls
+        try:
+            tfu.reset_bn_links()
+            new_xyz, out, idx = pu.pointnet_sa_module(xyz, pts, m, 0.8, ns, mlp, None, False, True, 0.5, "mod", geometry=geo)
+            (out * probe).sum().backward()
+        finally:
+            pn2._lib.lib.trace = None
+            tfu.USE_SA_FIRST_LAYER_FUSED = True
+        names[on] = [c_[0] for c_ in calls]
+        outs[on] = [out.detach(), new_xyz, idx.float()] + [p_.grad for _, p_ in sorted(store.params.items()) if p_.grad is not None] + \
+                   [v.clone() for _, v in sorted(store.buffers.items())]
+    assert names[True].count("pn2_sa_first_layer_bn") == 1 and "pn2_sa_group_concat" not in names[True]
+    assert "pn2_sa_first_layer_bn" not in names[False] and "pn2_sa_group_concat" in names[False]
+    assert len(outs[True]) == len(outs[False]) and len(outs[True]) >= 7
+    for a, r in zip(outs[True], outs[False]):
+        sc = max(float(r.abs().max()), 1e-3)
+        assert float((a - r).abs().max()) <= 2e-5 * sc, (a.shape, float((a - r).abs().max()), sc)
+
+
 @pytest.mark.parametrize("rows,cin,cout", [(524288, 32, 32), (131072, 128, 128), (1024, 768, 256), (40000, 64, 512), (33, 32, 32)])
 def test_bn_finish_ticket_under_many_workgroups(pn2, cuda, rows, cin, cout):
     """The ticket of pn2_bn_finish under load: the forward GEMM + statistics + constants as ONE launch (finish 2), twelve times in a
