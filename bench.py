@@ -424,12 +424,12 @@ def other_configs(pn2, dev, hp, steps):
         pcs = [pc, pc.clone()]  # two resident batches, alternated (the trainer prefetches the next batch's geometry)
         w3 = tr.warmup_eager + 2
         for i in range(w3):  # eager steps, then the capture, then one replay: all outside the timing
-            tr.train_step(pcs[i % 2], labels, smpw, next_pc=pcs[(i + 1) % 2])
+            tr.train_step(pcs[i % 2], labels, smpw, next_pc=pcs[(i + 1) % 2], next_labels=labels, next_smpw=smpw)
         torch.cuda.synchronize()
         n3 = max(2, min(steps, 10))
         t0 = time.perf_counter()
         for i in range(w3, w3 + n3):
-            loss = tr.train_step(pcs[i % 2], labels, smpw, next_pc=pcs[(i + 1) % 2], sync=False)
+            loss = tr.train_step(pcs[i % 2], labels, smpw, next_pc=pcs[(i + 1) % 2], next_labels=labels, next_smpw=smpw, sync=False)
         torch.cuda.synchronize()
         t = (time.perf_counter() - t0) / n3 * 1e3
         out["configs[3]@1gpu"] = {"workload": "training step (forward with batch-stat BN + weighted CE + backward + Adam), "
@@ -502,13 +502,13 @@ def bench_train(pn2, args, hp, B, N, rank, world, dev):
     tr = pn2.train.Trainer(hp, 9, store=pn2.util.tf_util.VariableStore(device=dev, seed=0), device=dev)
     pcs = [pc, pc.clone()]  # two resident batches, alternated: the trainer prefetches the geometry of the next one
     for i in range(max(tr.warmup_eager + 2, args.warmup)):  # includes the one-time hipGraph capture of the step (1 GPU)
-        tr.train_step(pcs[i % 2], labels, smpw, next_pc=pcs[(i + 1) % 2])
+        tr.train_step(pcs[i % 2], labels, smpw, next_pc=pcs[(i + 1) % 2], next_labels=labels, next_smpw=smpw)
     pn2.dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     i0 = max(tr.warmup_eager + 2, args.warmup)
     for i in range(i0, i0 + args.steps):  # no host synchronisation inside the timed region: the loss stays on the device
-        loss = tr.train_step(pcs[i % 2], labels, smpw, next_pc=pcs[(i + 1) % 2], sync=False)
+        loss = tr.train_step(pcs[i % 2], labels, smpw, next_pc=pcs[(i + 1) % 2], next_labels=labels, next_smpw=smpw, sync=False)
     torch.cuda.synchronize()
     local = time.perf_counter() - t0  # this rank's own clock, before the closing barrier
     pn2.dist.barrier()
@@ -558,7 +558,7 @@ def train_comm_diagnosis(pn2, tr, args, pcs, labels, smpw, dev, world, ms_per_st
     i0 = tr.step_count
     tr.comm_events = []
     for i in range(i0, i0 + k):
-        tr.train_step(pcs[i % 2], labels, smpw, next_pc=pcs[(i + 1) % 2], sync=False)
+        tr.train_step(pcs[i % 2], labels, smpw, next_pc=pcs[(i + 1) % 2], next_labels=labels, next_smpw=smpw, sync=False)
     torch.cuda.synchronize()
     ev, tr.comm_events = tr.comm_events, None
     if ev:
@@ -572,7 +572,7 @@ def train_comm_diagnosis(pn2, tr, args, pcs, labels, smpw, dev, world, ms_per_st
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for i in range(i0 + k, i0 + 2 * k):
-        tr.train_step(pcs[i % 2], labels, smpw, next_pc=pcs[(i + 1) % 2], sync=False)
+        tr.train_step(pcs[i % 2], labels, smpw, next_pc=pcs[(i + 1) % 2], next_labels=labels, next_smpw=smpw, sync=False)
     torch.cuda.synchronize()
     no_comm = pn2.dist.max_over_ranks((time.perf_counter() - t0) / k * 1e3, device=dev)
     tr.bucket.skip_collectives = False

@@ -72,6 +72,11 @@ class Trainer:
         # ONE all-reduce of the whole flat gradient.
         self.overlap_collective = bool(overlap_collective)
         self._graph_adam, self._graph_late = None, None
+        # staging (single-graph capture): the NEXT batch -- inputs, geometry, Adam's lr_t, the dropout step -- is put into staging
+        # buffers by the geometry stream while this step runs; a one-node copy graph moves it into the step's static buffers.  The
+        # trainer's stream then carries graphs only: an eager launch between two replays costs ~0.1 ms of idle queue (measured:
+        # the captured step replays back to back in 3.33 ms, with one eager copy in between 3.45), a graph after a graph nothing.
+        self._copy_graph, self._staging, self._staged_tag, self._copied_event = None, None, None, None
         # comm_events (bench.py --train): a list that receives, per captured multi-rank step, three HIP events on the
         # trainer's stream: early bucket launched | SA backward graph done | both buckets reduced
         self.comm_events = None
@@ -222,15 +227,31 @@ class Trainer:
         self._geo, self._geo_tag = None, None
         return geo
 
-    def _prefetch(self, next_pc, after_event):
+    def _prefetch(self, next_pc, after_event, next_labels=None, next_smpw=None):
         """launch the geometry of the NEXT batch on the side stream; it may start once `after_event` has passed (the
-        consumer of the previous prefetch has taken its copy)."""
+        consumer of the previous prefetch has taken its copy).  With the whole next batch announced (labels, weights) and a
+        captured step with staging buffers, the batch, its geometry and the next step's scalars are also put into the staging
+        buffers there: the next call then launches graphs only."""
+        self._staged_tag = None
         if next_pc is None:
             return
         g = self._geo_stream
         g.wait_event(after_event)
         with torch.cuda.stream(g):
             self._geo = model.compute_geometry(self._xyz_of(next_pc), self.hp, plans=True)
+            stg = self._staging
+            if (stg is not None and next_labels is not None and next_smpw is not None and self._copied_event is not None
+                    and all(a.shape == d.shape and a.dtype == d.dtype and a.is_contiguous()
+                            for a, d in zip((next_pc, next_labels, next_smpw), stg["inputs"]))):
+                g.wait_event(self._copied_event)  # the copy graph that read the staging buffers last has run
+                srcs = [next_pc, next_labels, next_smpw] + model.geometry_tensors(self._geo)
+                dsts = stg["inputs"] + stg["geo"]
+                if len(srcs) == len(dsts):
+                    nxt = self.step_count + 1  # the step this batch is for (0-based), its Adam time step is nxt + 1
+                    lr_t = adam_lr_t(self._learning_rate(nxt, next_pc.shape[0]), nxt + 1, self.BETA1, self.BETA2)
+                    fills = [(stg["lr"], lr_t)] + [(t, nxt) for t in stg["steps"]]
+                    tf_util.multi_copy_(dsts, srcs, fills=fills)
+                    self._staged_tag = (self._tag(next_pc), self._tag(next_labels), self._tag(next_smpw), nxt)
             self._geo_event = torch.cuda.Event()
             self._geo_event.record(g)
         self._geo_tag = (next_pc.data_ptr(), next_pc._version, tuple(next_pc.shape))
@@ -242,12 +263,14 @@ class Trainer:
         ev.record(torch.cuda.current_stream())
         self._prefetch(next_pc, ev)
 
-    def train_step(self, pc, labels, smpw, sync=True, next_pc=None):
+    def train_step(self, pc, labels, smpw, sync=True, next_pc=None, next_labels=None, next_smpw=None):
         """pc (B,N,6) float32, labels (B,N) int, smpw (B,N) float32 -> loss (python float; the device scalar when
         sync=False, to be read after the next synchronisation point).
         next_pc: the point cloud of the NEXT call (optional).  Its FPS / ball-query / three_nn chain -- weight-independent,
         latency-bound, 16 of 256 CUs -- then runs on a side stream beside this step's dense work instead of in front of
-        the next one (what the reference's mp.Pool data loader does for its CPU pre-processing)."""
+        the next one (what the reference's mp.Pool data loader does for its CPU pre-processing).  next_labels / next_smpw
+        (optional, with next_pc): the rest of the next batch; a captured step then finds the whole batch staged and launches
+        graphs only (see _prefetch)."""
         tf_util.set_default_store(self.store)
         if self.bucket is None:
             self._lazy_init(pc)
@@ -269,7 +292,7 @@ class Trainer:
             geo = self._geometry_for(pc, caller)
             taken = torch.cuda.Event()
             taken.record(caller)
-            self._prefetch(next_pc, taken)
+            self._prefetch(next_pc, taken)  # (an eager step has no staging buffers)
             loss = self._step_body(pc, labels, smpw, decay, geometry=geo)
         else:
             # Replays and the per-step writes they depend on run on the trainer's OWN stream.  Launching the graph into
@@ -279,6 +302,25 @@ class Trainer:
             self._stream.wait_stream(caller)
             with torch.cuda.stream(self._stream):
                 recapture = self._graph is None or self._graph_decay != decay or self._static[0].shape != pc.shape
+                staged = (not recapture and self._copy_graph is not None and self._staged_tag is not None and self._staged_tag ==
+                          (self._tag(pc), self._tag(labels), self._tag(smpw), self.step_count))
+                if staged:
+                    # the geometry stream has put this batch, its geometry and this step's scalars into the staging buffers:
+                    # copy graph -> step graph, no eager launch on this stream
+                    self._stream.wait_event(self._geo_event)
+                    self._geo, self._geo_tag, self._staged_tag = None, None, None
+                    self._copy_graph.replay()
+                    self._copied_event = torch.cuda.Event()
+                    self._copied_event.record(self._stream)
+                    self._prefetch(next_pc, self._copied_event, next_labels, next_smpw)
+                    self._graph.replay()
+                    loss = self._static[3]
+                    if sync:
+                        loss = float(loss)
+                    caller.wait_stream(self._stream)
+                    self.step_count += 1
+                    self.store.train_epoch += 1
+                    return float(loss) if sync else loss
                 geo = self._geometry_for(pc, self._stream)  # eager (or eagerly prefetched: prefetch_geometry)
                 if recapture:
                     self._capture(pc, labels, smpw, decay, geo, split)
@@ -301,7 +343,8 @@ class Trainer:
                         tf_util.multi_copy_([d for d, _ in pairs], [s_ for _, s_ in pairs])
                 taken = torch.cuda.Event()
                 taken.record(self._stream)
-                self._prefetch(next_pc, taken)
+                self._copied_event = taken  # (nothing reads the staging buffers in this form of the step)
+                self._prefetch(next_pc, taken, next_labels, next_smpw)
                 self._graph.replay()
                 if self._graph_late is not None:  # three segments: the early bucket travels while the SA backward replays
                     ev = self.comm_events  # bench: [(early launched, SA backward done, both buckets reduced)] per step
@@ -367,4 +410,17 @@ class Trainer:
                 self._adam(flat_g)
             self._graph_adam = ga
         self._graph, self._graph_decay, self._static, self._static_geo = g, decay, st + [loss], sg
+        # staging buffers + the one-node copy graph (single-graph capture only: a multi-rank step has collectives between its
+        # graphs anyway)
+        self._copy_graph, self._staging, self._staged_tag = None, None, None
+        if not split:
+            steps = [t[1:2] for t in self.store._dropout.values()]
+            dsts = st + model.geometry_tensors(sg) + [self._lr_slot] + steps
+            stg = {"inputs": [t.clone() for t in st], "geo": [t.clone() for t in model.geometry_tensors(sg)],
+                   "lr": self._lr_slot.clone(), "steps": [t.clone() for t in steps]}
+            srcs = stg["inputs"] + stg["geo"] + [stg["lr"]] + stg["steps"]
+            gc = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(gc, **mode):
+                tf_util.multi_copy_(dsts, srcs)
+            self._copy_graph, self._staging = gc, stg
         # the capture itself executed nothing: the replay that follows is this step

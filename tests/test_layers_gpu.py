@@ -1463,6 +1463,9 @@ def test_training_gradients_with_hip_wgrad_match_torch(pn2, cuda):
             tfu._train_layer = layer_fp64
         elif mode == "torch":
             tfu._train_layer = train_layer_torch  # library GEMMs + F.batch_norm: the plain fp32 reference
+        # (the reference stacks replace tf_util._train_layer: SA1's first layer must reach it as a layer of its own, not inside
+        # the one-launch front end of the HIP path)
+        tfu.USE_SA_FIRST_LAYER_FUSED = mode == "hip"
         try:
             store = tfu.set_default_store(tfu.VariableStore(device=cuda, seed=5))
             torch.manual_seed(123)  # same dropout mask in every run
@@ -1471,6 +1474,7 @@ def test_training_gradients_with_hip_wgrad_match_torch(pn2, cuda):
             return {k: v.grad.detach().double().clone() for k, v in store.params.items() if v.grad is not None}
         finally:
             tfu._train_layer = orig
+            tfu.USE_SA_FIRST_LAYER_FUSED = True
 
     hip, t32, ref = run("hip"), run("torch"), run("fp64")
     assert t32.keys() == ref.keys() and len(hip) > 40
@@ -1542,6 +1546,7 @@ def test_training_gradients_match_float64_on_the_same_activation_pattern(pn2, cu
         tfu._train_layer = layer
         keep = tfu.USE_BN_ON_LOAD
         tfu.USE_BN_ON_LOAD = False  # every layer hands over its normalised activation (what is recorded / replaced)
+        tfu.USE_SA_FIRST_LAYER_FUSED = False  # ... and SA1's first layer is a layer of its own (its one-launch form has its own test)
         try:
             store = tfu.set_default_store(tfu.VariableStore(device=cuda, seed=5))
             torch.manual_seed(123)  # same dropout mask in every run
@@ -1551,6 +1556,7 @@ def test_training_gradients_match_float64_on_the_same_activation_pattern(pn2, cu
         finally:
             tfu._train_layer = orig
             tfu.USE_BN_ON_LOAD = keep
+            tfu.USE_SA_FIRST_LAYER_FUSED = True
 
     hip, lh = run(layer_recording)
     ref, lr = run(layer_fp64_forced)

@@ -664,6 +664,40 @@ def test_geometry_prefetch_is_the_same_geometry(pn2, cuda):
         np.testing.assert_allclose(la, lb, rtol=3e-2)
 
 
+def test_staged_next_batch_steps_with_graphs_only(pn2, cuda):
+    """Round 6: with the WHOLE next batch announced (next_pc, next_labels, next_smpw) the geometry stream stages it -- inputs,
+    geometry, Adam's lr_t, the dropout step -- and the captured step is copy graph -> step graph: no eager launch on the
+    trainer's stream.  Same trajectory as a trainer that is not told anything; a batch that differs from the announced one (other
+    labels) falls back to the copying form instead of training on staged data; lr_t in device memory is the staged step's."""
+    import torch
+    hp = dict(pn2.model.SEMANTIC_HYPERPARAMS)
+    hp.update(l1_npoint=256, l2_npoint=64, l3_npoint=32, l4_npoint=16)
+    batches = [_batch(cuda, s) for s in range(3)]
+    tr = pn2.train.Trainer(hp, 9, store=pn2.util.tf_util.VariableStore(device=cuda, seed=3), capture=True, warmup_eager=2)
+    ref = pn2.train.Trainer(hp, 9, store=pn2.util.tf_util.VariableStore(device=cuda, seed=3), capture=True, warmup_eager=2)
+    la, lb, staged_steps = [], [], []
+    for i in range(9):
+        nb = batches[(i + 1) % 3]
+        announce = dict(next_pc=nb[0], next_labels=nb[1], next_smpw=nb[2])
+        if i == 5:  # announce labels that will NOT be the ones passed next time
+            announce["next_labels"] = nb[1].clone()
+        staged_steps.append(tr._staged_tag is not None)
+        la.append(tr.train_step(*batches[i % 3], **announce))
+        lb.append(ref.train_step(*batches[i % 3]))
+    # steps 0, 1 are eager, 2 captures (and so copies): from step 3 on the batch was staged by the step before -- but not step 6
+    assert staged_steps[4] and staged_steps[5] and staged_steps[7] and staged_steps[8], staged_steps
+    assert tr._copy_graph is not None and tr._staging is not None
+    np.testing.assert_allclose(la[:2], lb[:2], rtol=1e-4)
+    np.testing.assert_allclose(la, lb, rtol=3e-2)
+    dist = float((tr.flat_p - ref.flat_p).norm() / ref.flat_p.norm())
+    assert dist <= 5e-2, dist
+    torch.cuda.synchronize()
+    want = pn2.train.adam_lr_t(tr._learning_rate(8, 8), 9)   # the last executed step: index 8, Adam time step 9
+    np.testing.assert_allclose(tr.hyper.cpu().numpy()[0], want, rtol=1e-6)
+    for t in tr.store._dropout.values():
+        assert int(t[1]) == 8
+
+
 def test_trainer_setup_leaves_moving_averages_untouched_and_params_flat(pn2, cuda):
     import torch
     hp = dict(pn2.model.SEMANTIC_HYPERPARAMS)
