@@ -358,6 +358,42 @@ def north_star_kernels(pn2, dev):
     return out
 
 
+def both_regimes(pn2, sampler_fn, dense_fn, make_batch, units_per_step, steps, regions=3):
+    """a workload that starts with a sampler chain, timed like the headline -- `latency`: ONE batch in flight (one
+    graph: sampler + rest, replay + synchronise per step) and `throughput`: runtime.StaggeredPipeline (two graphs per batch on the
+    batch's one stream, 4 streams, backlogs 0,0,1,1), median of `regions` regions of `steps` steps after one untimed region.
+    sampler_fn(x) -> s, dense_fn(x, s) -> y, make_batch(n) -> input of slot n."""
+    cap = pn2.runtime.CapturedForward(lambda x: dense_fn(x, sampler_fn(x)), make_batch(0))
+    for _ in range(2):
+        cap.replay()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        cap.replay()
+        torch.cuda.synchronize()
+    lat = (time.perf_counter() - t0) / steps * 1e3
+    del cap
+    pipe = pn2.runtime.StaggeredPipeline(sampler_fn, dense_fn, make_batch, (0, 0, 1, 1))
+
+    def region():
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for _ in range(steps):
+            pipe.step()
+        pipe.flush()
+        torch.cuda.synchronize()
+        return (time.perf_counter() - t1) / steps * 1e3
+    region()
+    ts = sorted(region() for _ in range(regions))
+    thr = ts[(len(ts) - 1) // 2]
+    res = {"latency": {"batches_in_flight": 1, "ms_per_step": round(lat, 4), "points_per_s": round(units_per_step / (lat * 1e-3), 1)},
+           "throughput": {"batches_in_flight": pipe.batches_in_flight, "streams": pipe.P,
+                          "streams_verified_concurrent": pipe.streams_verified_concurrent, "ms_per_step": round(thr, 4),
+                          "ms_per_step_regions": [round(v, 4) for v in ts], "points_per_s": round(units_per_step / (thr * 1e-3), 1)}}
+    del pipe
+    return res
+
+
 def other_configs(pn2, dev, hp, steps):
     """configs[2], configs[4] and configs[3]@1GPU timed in the same run (graph replay where the path is captured)."""
     out = {}
@@ -378,6 +414,12 @@ def other_configs(pn2, dev, hp, steps):
                              "ms_per_step": round(t, 4), "points_per_s": round(B * N / (t * 1e-3), 1), "steps": steps,
                              "launch": "one hipGraph replay per step, one batch in flight"}
         del cap
+        # both regimes (sampler | the rest of the module on the sampled centres), as the headline config gets them
+        fps_gather = pn2.tf_ops.tf_sampling.farthest_point_sample_and_gather
+        out["configs[2]"]["regimes"] = both_regimes(
+            pn2, lambda x: fps_gather(M, x)[1],
+            lambda x, nx: pu.pointnet_sa_module_msg(x, pts, M, radii, ks, mlps, False, None, scope="msg", new_xyz=nx)[1],
+            lambda n: (xyz if n == 0 else torch.from_numpy(s_scene(5100 + n, B, N)[:, :, :3].copy()).to(dev)), B * N, steps)
         # configs[4]: large scenes, N=65536 -> npoint 4096, K=64, C=128 bf16 features, fused bf16 grouped MLP; B=1 (eager and
         # as a hipGraph replay) and B=16 ("B=1 (and 16 if memory allows)")
         N4, M4, K4, C4 = 65536, 4096, 64, 128
@@ -399,16 +441,28 @@ def other_configs(pn2, dev, hp, steps):
                 t_fps = time_call(lambda: pn2.tf_ops.tf_sampling.farthest_point_sample_and_gather(M4, xyz4), n4, warmup=1)
             cap4 = pn2.runtime.CapturedForward(sa4, xyz4)
             t_graph = time_call(cap4.replay, n4, warmup=1)
-            res4[B4] = (t_eager, t_graph, t_fps, n4)
+            reg4 = None
+            if B4 == 16:  # both regimes on the B = 16 form (sampler | ball query + fused bf16 MLP)
+
+                def dense4(x, nx):
+                    idx, _ = pn2.query_ball_point(0.5, K4, x, nx)
+                    with tfu.variable_scope("sa"):
+                        return pu.sa_features_inference(x, nx, pts4, idx, [128, 128])
+                with torch.no_grad():
+                    reg4 = both_regimes(pn2, lambda x: pn2.tf_ops.tf_sampling.farthest_point_sample_and_gather(M4, x)[1], dense4,
+                                        lambda n: (xyz4 if n == 0 else
+                                                   torch.from_numpy(s_scene(5200 + n, B4, N4)[:, :, :3].copy()).to(dev)),
+                                        B4 * N4, n4)
+            res4[B4] = (t_eager, t_graph, t_fps, n4, reg4)
             del cap4, xyz4, pts4
-        t_eager, t_graph, t_fps, n4 = res4[1]
+        t_eager, t_graph, t_fps, n4, _ = res4[1]
         out["configs[4]"] = {"workload": "large-scene SA layer: B=1, N=65536, npoint=4096, K=64, C=128 bf16 features, "
                                          "FPS (lazy multi-pick over Hilbert-sorted buckets) + ball query + fused bf16 grouped MLP [128,128] + max",
                              "ms_per_step": round(t_graph, 4), "points_per_s": round(N4 / (t_graph * 1e-3), 1), "steps": n4,
                              "fps_ms": round(t_fps, 4), "launch": "one hipGraph replay per step", "eager_ms_per_step": round(t_eager, 4),
                              "B16": {"ms_per_step": round(res4[16][1], 4), "points_per_s": round(16 * N4 / (res4[16][1] * 1e-3), 1),
                                      "fps_ms": round(res4[16][2], 4), "eager_ms_per_step": round(res4[16][0], 4),
-                                     "launch": "one hipGraph replay per step, 16 scenes per step"}}
+                                     "launch": "one hipGraph replay per step, 16 scenes per step", "regimes": res4[16][4]}}
     except Exception as ex:  # keep the headline line alive
         out["error"] = repr(ex)
     finally:

@@ -677,6 +677,19 @@ int pn2_bn_relu_backward_mode(long long rows, int c, const float *dz, const floa
                               const float *ties, void *workspace, size_t workspace_bytes, int stats_mode, float *dy,
                               float *dgamma, float *dbeta, void *stream);
 
+/* Data gradient AND weight gradient of a narrow dense + batch-norm layer in ONE launch (csrc/pn2_bwd_fused.hip): what
+ * pn2_linear_dgrad_fin and pn2_linear_wgrad_gx compute for the same arguments -- dx (rows, cin) = dy . W^T, dw (cin, cout) +=
+ * x^T . dy with dy = the gradient leaving the layer's batch norm formed on load from (y, dz, coef), the epilogue and finish for
+ * the layer below -- reading (y, dz) ONCE: for 32 / 64-channel layers over 10^5 .. 10^6 rows both GEMMs are HBM streams and the
+ * second read is a third of the traffic.  cin, cout in {32, 64}, rows % 32 == 0, 16-byte aligned operands, else PN2_EUNSUP.
+ * dw is added to.  tf_util.py:181-204,555-581 through tf.gradients. */
+int pn2_linear_bwd_fused(int rows, int cin, int cout, const float *x, const float *a_scale, const float *a_shift, int a_relu,
+                         const float *y, const float *dz, const float *coef, int relu, int pool, const float *zmax,
+                         const float *ties, const float *w, float *dx, float *dw, const float *y_below,
+                         const float *gamma_below, const float *beta_below, const float *mean_below, const float *invstd_below,
+                         int relu_below, void *ws_below, size_t ws_below_bytes, int finish_below, float *coef_below,
+                         float *dgamma_below, float *dbeta_below, void *stream);
+
 /* First layer of an SA module whose points carry few channels (c <= 5: xyz + rgb of the level-0 module), training path, in ONE
  * launch: y (b,m,nsample,cout) = [group_point(xyz, idx) - new_xyz | group_point(points, idx)] . w (3 + c, cout)
  * (pointnet_util.py:39-54 + tf_util.py:181-186) written once, its batch statistics taken on the way out into the ZEROED

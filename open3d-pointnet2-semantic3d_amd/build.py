@@ -16,7 +16,7 @@ LIB = os.path.join(HERE, "libpn2_hip.so")
 SOURCES = ["pn2_abi.hip", "pn2_sampling.hip", "pn2_grouping.hip", "pn2_interpolate.hip",
            "pn2_linear.hip", "pn2_sa_fused.hip", "pn2_sa_fused_bf16.hip", "pn2_label_interp.hip", "pn2_fps_bucket.hip",
            "pn2_bn.hip", "pn2_scene.hip", "pn2_train.hip", "pn2_mlp_wide.hip", "pn2_pool.hip", "pn2_hoist.hip",
-           "pn2_coarse_geometry.hip"]
+           "pn2_coarse_geometry.hip", "pn2_bwd_fused.hip"]
 # per-file additions.  pn2_sa_fused.hip: MFMA results in VGPRs where they fit (the fused chains feed every accumulator back into
 # the next layer's MFMA as an A / B operand, which must be an arch VGPR: with AGPR accumulators each of those 128 values per
 # tile costs a v_accvgpr_read, and non-MFMA instructions cost their full issue time on a SIMD whose matrix pipe is busy)

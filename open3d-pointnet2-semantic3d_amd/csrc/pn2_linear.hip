@@ -23,6 +23,7 @@
 #include <type_traits>
 
 #include "pn2_common.h"
+#include "pn2_mfma_stats.h"
 
 namespace {
 
@@ -34,71 +35,12 @@ __device__ __forceinline__ void static_for(F& f) {
     }
 }
 
-typedef float f32x4 __attribute__((ext_vector_type(4)));
-typedef float f32x16 __attribute__((ext_vector_type(16)));
-
 constexpr int kBK = 32;
 constexpr int kAS = kBK + 4;  // A tile row stride (floats): 144 B, keeps b128 accesses 16-B aligned
 
 __device__ __forceinline__ void atomic_max_nonneg(float* addr, float v) {
     // v >= 0 (post-ReLU): integer order == float order
     atomicMax(reinterpret_cast<int*>(addr), __float_as_int(v));
-}
-
-// Column sums of one 32x32 accumulator tile for the batch norm that follows (pn2_linear_bn_stats), in fp64 from the first
-// term on -- the same moments the two-pass path (bn_stats_kernel) forms, up to summation order: 48 fp64 operations per lane
-// and tile, ~23 us over all layers of a training step against the 280 us of statistics passes they replace.  One atomic
-// pair per column into slot copy `slot`.  Rows past `rows` hold exact zeros (their A operand was zeroed): they add nothing.
-__device__ __forceinline__ void push_column_stats(const f32x16& acc, int half, int col, int cout, unsigned slot,
-                                                  double* __restrict__ stats) {
-    double d1 = 0.0, d2 = 0.0;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-        const double d = (double)acc[r];
-        d1 += d;
-        d2 = __builtin_fma(d, d, d2);
-    }
-    d1 += __shfl_xor(d1, 32);
-    d2 += __shfl_xor(d2, 32);
-    if (half == 0 && col < cout) {
-        double* __restrict__ sl = stats + kPn2BnHead + (size_t)2 * cout * (1 + slot % (unsigned)kPn2BnSlots);
-        atomicAdd(sl + col, d1);
-        atomicAdd(sl + cout + col, d2);
-    }
-}
-
-// The same for the data gradient that reaches a batch norm (+ReLU): column sums of g = dz * [mask] and g * xhat over one
-// 32x32 tile of dz (see Pn2BnGradEpilogue); float expressions of bn_grad_reduce_kernel, fp64 accumulation.
-__device__ __forceinline__ void push_column_grad_stats(const f32x16& acc, int half, int wrow0, int rows, int col, int c,
-                                                       unsigned slot, const Pn2BnGradEpilogue& e) {
-    double d1 = 0.0, d2 = 0.0;
-    if (col < c) {
-        const float mean = e.mean[col], invstd = e.invstd[col];
-        float sc, sh;
-        bn_scale_shift(e.gamma[col], e.beta[col], mean, invstd, sc, sh);
-        float a[16];
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int row = wrow0 + (r & 3) + 8 * (r >> 2) + 4 * half;
-            a[r] = e.y[(size_t)(row < rows ? row : rows - 1) * c + col];
-        }
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int row = wrow0 + (r & 3) + 8 * (r >> 2) + 4 * half;
-            const bool on = row < rows && (!e.relu || __builtin_fmaf(a[r], sc, sh) > 0.f);
-            const double gd = on ? (double)acc[r] : 0.0;
-            const double xh = (double)((a[r] - mean) * invstd);
-            d1 += gd;
-            d2 = __builtin_fma(gd, xh, d2);
-        }
-    }
-    d1 += __shfl_xor(d1, 32);
-    d2 += __shfl_xor(d2, 32);
-    if (half == 0 && col < c) {
-        double* __restrict__ sl = e.ws + kPn2BnHead + (size_t)2 * c * (1 + slot % (unsigned)kPn2BnSlots);
-        atomicAdd(sl + col, d1);
-        atomicAdd(sl + c + col, d2);
-    }
 }
 
 // WK = 2 splits every k-tile between two waves of the same output tile (intra-workgroup split-K,
@@ -1143,6 +1085,11 @@ static int linear_bn_stats_xf_impl(int rows, int cin, int cout, const float* x_r
     hipStream_t st = static_cast<hipStream_t>(stream);
     double* stats = static_cast<double*>(bn_workspace);
     const Pn2LoadTransform xf{a_scale, a_shift, a_relu};
+#ifdef PN2_TUNING_HOOKS
+    if (cout % 128 == 0 && g_lin_cfg == 1) return launch_linear_xf<4, 1, 4>(rows, cin, cout, x_raw, w, y, st, stats, xf, fin);
+    if (cout % 128 == 0 && g_lin_cfg == 2) return launch_linear_xf<2, 2, 2>(rows, cin, cout, x_raw, w, y, st, stats, xf, fin);
+    if (cout % 128 == 0 && g_lin_cfg == 3) return launch_linear_xf<1, 4, 1>(rows, cin, cout, x_raw, w, y, st, stats, xf, fin);
+#endif
     if (cout % 128 == 0) {  // the tile choice of linear_impl, without its 128 x 128 tile (with the transform's registers its
                             // accumulators spill: 630 us instead of ~45 at 32768 x 128 -> 256)
         const long long cb = cout / 128;
@@ -1212,6 +1159,11 @@ static int linear_dgrad_impl(int rows, int cin, int cout, const float* dy, const
 #undef PN2_SK
         }
     }
+#ifdef PN2_TUNING_HOOKS
+    if (cin > 96 && g_lin_cfg == 1) return launch_linear_dgrad<4, 1, 4>(rows, cin, cout, dy, w, dx, st, gepi, gx, fin);
+    if (cin > 96 && g_lin_cfg == 2) return launch_linear_dgrad<2, 2, 2>(rows, cin, cout, dy, w, dx, st, gepi, gx, fin);
+    if (cin > 96 && g_lin_cfg == 3) return launch_linear_dgrad<1, 4, 1>(rows, cin, cout, dy, w, dx, st, gepi, gx, fin);
+#endif
     if (cin <= 32) return launch_linear_dgrad<4, 1, 1>(rows, cin, cout, dy, w, dx, st, gepi, gx, fin);
     if (cin <= 64) return launch_linear_dgrad<4, 1, 2>(rows, cin, cout, dy, w, dx, st, gepi, gx, fin);
     if (cin <= 96) return launch_linear_dgrad<4, 1, 1>(rows, cin, cout, dy, w, dx, st, gepi, gx, fin);

@@ -577,15 +577,20 @@ def pointnet_sa_module(xyz, points, npoint, radius, nsample, mlp, mlp2, group_al
 
 
 def pointnet_sa_module_msg(xyz, points, npoint, radius_list, nsample_list, mlp_list, is_training, bn_decay, scope,
-                           bn=True, use_xyz=True, use_nchw=False):
+                           bn=True, use_xyz=True, use_nchw=False, new_xyz=None):
     """Multi-scale grouping SA module (:219-282): one FPS, per scale ball query +
     group + MLP + max; NOTE the concat order here is [features, xyz] (:259), unlike
-    sample_and_group.  -> new_xyz, new_points (B,npoint,sum mlp[k][-1])."""
+    sample_and_group.  -> new_xyz, new_points (B,npoint,sum mlp[k][-1]).
+    new_xyz (extension): the npoint samples of this very cloud, drawn ahead (runtime.StaggeredPipeline runs a batch's sampling as
+    a graph of its own); everything else is done here."""
     require_cuda(xyz, points)
     with tf_util.variable_scope(scope):
         xyz = xyz.contiguous()
-        fps_idx, fps_tie, _ = farthest_point_sample_with_ties(npoint, xyz)  # (:36-37; the tie record rides on new_xyz, see
-        new_xyz = tag_fps_output(gather_point(xyz, fps_idx), fps_tie)         #  tf_sampling.USE_NESTED_FPS)
+        if new_xyz is None:
+            fps_idx, fps_tie, _ = farthest_point_sample_with_ties(npoint, xyz)  # (:36-37; the tie record rides on new_xyz, see
+            new_xyz = tag_fps_output(gather_point(xyz, fps_idx), fps_tie)         #  tf_sampling.USE_NESTED_FPS)
+        elif tuple(new_xyz.shape) != (xyz.shape[0], int(npoint), 3):
+            raise ValueError("new_xyz: (batch_size, npoint, 3) samples of xyz expected")
         outs = []
         # one scan of xyz for all radii (the reference re-scans once per radius, :245-250)
         queries = query_ball_point_multi(radius_list, nsample_list, xyz, new_xyz)

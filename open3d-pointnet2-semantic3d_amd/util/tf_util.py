@@ -1059,6 +1059,50 @@ def _hip_dgrad_fin(dy, gx, w, link):
     return dx
 
 
+USE_FUSED_BWD_NARROW = True  # 32 / 64-channel layers: data and weight gradient in one launch, (y, dz) read once (A/B, tests)
+
+
+def _hip_bwd_fused(x2d, xf, y, dz, coef, relu, pool, zmax, ties, w, link):
+    """dx AND dW of a narrow layer in ONE launch (pn2_linear_bwd_fused): what _hip_dgrad_fin + _hip_wgrad_gx return, or None when
+    the library reports the shape as unsupported (the caller then launches the two)."""
+    rows, cin, cout = y.shape[0], w.shape[0], w.shape[1]
+    if not (USE_FUSED_BWD_NARROW and USE_BN_FINISH_IN_PRODUCER and cin in (32, 64) and cout in (32, 64) and rows % 32 == 0
+            and x2d.is_contiguous() and x2d.shape[1] == cin):
+        return None
+    dx = torch.empty((rows, cin), dtype=torch.float32, device=y.device)
+    dw = get_default_store().grad_view(w)
+    if dw is None:
+        arena = get_default_store().zero_arena
+        v = arena.take(w.numel() * 4) if arena is not None else None
+        dw = v[:w.numel() * 4].view(torch.float32).view_as(w) if v is not None else torch.zeros_like(w)
+    below, fin_out, pws = (None, None, None, None, None, 0, None, 0), (0, None, None, None), None
+    gxb = False
+    if link is not None:
+        pws = _bn_zeroed_scratch(cin, y.device)
+        below = (ptr(link.y), ptr(link.gamma), ptr(link.beta), ptr(link.mean), ptr(link.invstd), int(link.relu), ptr(pws),
+                 pws.numel() * pws.element_size())
+        gxb = bool(link.gx and _gx_usable(rows, cin, 0, dx, link.y))
+        if gxb:
+            cb = torch.empty((6, cin), dtype=torch.float32, device=y.device)
+            dgb, dbb = _param_grad_out(link.gamma), _param_grad_out(link.beta)
+            fin_out = (3, ptr(cb), ptr(dgb), ptr(dbb))
+        else:
+            fin_out = (1, None, None, None)
+    sc, sh, xrelu = xf if xf is not None else (None, None, 0)
+    with torch.cuda.device(y.device):
+        rc = lib.pn2_linear_bwd_fused(rows, cin, cout, ptr(x2d), ptr(sc), ptr(sh), int(xrelu), ptr(y), ptr(dz), ptr(coef), int(relu),
+                                      int(pool), ptr(zmax), ptr(ties), ptr(w.contiguous()), ptr(dx), ptr(dw), *below, *fin_out,
+                                      stream_ptr())
+    if rc == PN2_EUNSUP_CODE:
+        return None
+    check(rc, "pn2_linear_bwd_fused")
+    if link is not None:
+        if gxb:
+            link.coef, link.dgamma, link.dbeta = cb, dgb, dbb
+        link.ws, link.dz_ptr, link.dz_keep, link.folded = pws, dx.data_ptr(), dx, True
+    return dx, dw
+
+
 def _hip_dgrad_gx(y, dz, coef, relu, pool, zmax, ties, w, link):
     """dx = dy @ w^T with dy formed on load (pn2_linear_dgrad_gx); link: the producer record of the layer below (its two batch-norm
     gradient sums are left in a zeroed workspace and noted on the record, as hip_linear_dgrad_linked does) or None"""
@@ -1187,8 +1231,12 @@ class _TrainDenseBnRelu(torch.autograd.Function):
             coef, dgamma, dbeta = _bn_grad_constants(dz, y, gamma, beta, save_mean, save_invstd, ctx.relu, ctx.pool, zmax, ties,
                                                      ctx.link)
             dx = None
+            pv = ctx.prev if (ctx.prev is not None and ctx.prev.y is not None) else None
+            if ctx.needs_input_grad[0] and ctx.needs_input_grad[1]:
+                both = _hip_bwd_fused(x2d, ctx.xf, y, dz, coef, ctx.relu, ctx.pool, zmax, ties, w, pv)  # narrow layers: one launch
+                if both is not None:
+                    return both[0], both[1], None, dgamma, dbeta, None, None, None, None, None, None, None
             if ctx.needs_input_grad[0]:
-                pv = ctx.prev if (ctx.prev is not None and ctx.prev.y is not None) else None
                 dx = _hip_dgrad_gx(y, dz, coef, ctx.relu, ctx.pool, zmax, ties, w, pv)
             dw = _hip_wgrad_gx(x2d, ctx.xf, y, dz, coef, ctx.relu, ctx.pool, zmax, ties, w) if ctx.needs_input_grad[1] else None
             return dx, dw, None, dgamma, dbeta, None, None, None, None, None, None, None

@@ -53,3 +53,27 @@ def test_bench_json_contract():
         # level 1 has its own sampler / ball query / three_nn launch, levels 2-4 share pn2_coarse_geometry
         assert len(o["fps_us"]) == 1 and len(o["query_ball_point_us"]) == 1 and len(o["three_nn_us"]) == 1
         assert len(o["coarse_geometry_us"]) == 1 and o["coarse_geometry_us"][0]["avg_us"] > 0
+
+
+@pytest.mark.gpu
+@pytest.mark.timeout(900)
+def test_bench_other_configs_carry_both_regimes():
+    """BASELINE configs[2] (MSG module) and configs[4] (large-scene layer, B = 16) are timed like the headline --
+    one batch in flight and the staggered throughput pipeline (sampler | rest) -- and configs[3]@1gpu is on the line."""
+    env = dict(os.environ)
+    env.pop("RANK", None); env.pop("WORLD_SIZE", None); env.pop("LOCAL_RANK", None)
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "4", "--warmup", "2",
+                          "--no-north-star", "--no-cpu-baseline", "--no-other-inputs"],
+                         cwd=ROOT, env=env, capture_output=True, text=True, timeout=850)
+    assert out.returncode == 0, out.stderr[-2000:]
+    r = json.loads([l for l in out.stdout.splitlines() if l.strip()][-1])
+    oc = r["other_configs"]
+    assert "error" not in oc, oc.get("error")
+    for key, node in (("configs[2]", oc["configs[2]"]), ("configs[4]", oc["configs[4]"]["B16"])):
+        reg = node["regimes"]
+        assert reg["latency"]["batches_in_flight"] == 1 and reg["latency"]["ms_per_step"] > 0, key
+        thr = reg["throughput"]
+        assert thr["batches_in_flight"] == 6 and thr["streams"] == 4 and thr["streams_verified_concurrent"] is not None, key
+        assert 0 < thr["ms_per_step"] <= reg["latency"]["ms_per_step"], (key, reg)   # several batches in flight never cost more per batch
+        assert thr["ms_per_step"] == sorted(thr["ms_per_step_regions"])[(len(thr["ms_per_step_regions"]) - 1) // 2]
+    assert oc["configs[3]@1gpu"]["ms_per_step"] > 0

@@ -667,7 +667,8 @@ def test_bn_grad_on_load_equals_the_materialised_form(pn2, cuda, kind, mlp, c, p
             pn2._lib.lib.trace = None
             tfu.USE_BN_GRAD_ON_LOAD = True
         names = [c_[0] for c_ in calls]
-        counts[on] = {k: names.count(k) for k in ("pn2_bn_grad_constants", "pn2_linear_dgrad_gx", "pn2_linear_wgrad_gx")}
+        counts[on] = {k: names.count(k) for k in ("pn2_bn_grad_constants", "pn2_linear_dgrad_gx", "pn2_linear_wgrad_gx",
+                                                  "pn2_linear_bwd_fused")}
         outs[on] = [out.detach(), src.grad] + [p_.grad for _, p_ in sorted(store.params.items()) if p_.grad is not None]
     # every layer but a source-row first layer (whose dy feeds the scatter plan) takes the on-load form; a 16-neighbour pool does not
     hoisted = 1 if plan_on else 0
@@ -675,7 +676,11 @@ def test_bn_grad_on_load_equals_the_materialised_form(pn2, cuda, kind, mlp, c, p
     want = len(mlp) - hoisted - pooled_other
     # (a layer whose dz is the data gradient of the layer above gets its constants from that GEMM's last workgroup: only the top
     # layer of the stack still calls pn2_bn_grad_constants; the data gradients run through pn2_linear_dgrad_fin)
-    assert counts[True]["pn2_linear_wgrad_gx"] == want and counts[True]["pn2_bn_grad_constants"] <= min(want, 1), counts
+    # (32 / 64-channel layers that need both gradients take them from ONE launch: pn2_linear_bwd_fused)
+    assert counts[True]["pn2_linear_wgrad_gx"] + counts[True]["pn2_linear_bwd_fused"] == want, counts
+    assert counts[True]["pn2_bn_grad_constants"] <= min(want, 1), counts
+    narrow = sum(1 for i in range(1, len(mlp)) if mlp[i - 1] in (32, 64) and mlp[i] in (32, 64) and not (i == len(mlp) - 1 and pooled_other))
+    assert counts[True]["pn2_linear_bwd_fused"] == narrow, (counts, narrow)
     assert not any(counts[False].values()), counts
     assert len(outs[True]) == len(outs[False]) and len(outs[True]) >= 6
     for a, r in zip(outs[True], outs[False]):
@@ -808,6 +813,73 @@ def test_bn_finish_ticket_under_many_workgroups(pn2, cuda, rows, cin, cout):
         assert float((rm.double() - 0.5 * mean).abs().max()) <= 1e-5 * max(1.0, float(mean.abs().max())), it
         tick = ws[:48].view(torch.int32)[:65].cpu().numpy()  # 64 first-level counters + the second level
         assert tick[:64].sum() > 0 and tick[64] == min(64, int(tick[:64].sum())), tick
+
+
+@pytest.mark.parametrize("rows,cin,cout,pool,xf_on,below", [(8192, 32, 32, 0, True, True), (8192, 32, 64, 32, True, True),
+                                                            (4096, 64, 64, 0, False, True), (2048, 64, 32, 32, True, False),
+                                                            (96, 32, 64, 0, False, False)])
+def test_fused_narrow_backward_equals_the_two_launches(pn2, cuda, rows, cin, cout, pool, xf_on, below):
+    """pn2_linear_bwd_fused (data + weight gradient of a 32 / 64-channel layer in one launch, (y, dz) read once) against
+    pn2_linear_dgrad_fin + pn2_linear_wgrad_gx on the same operands: dx bit for bit (same MFMA order per tile), dW, and the
+    batch-norm gradient constants it publishes for the layer below, to the order of the atomics; and against float64."""
+    import torch
+    lib, ptr, sp, check = pn2._lib.lib, pn2._lib.ptr, pn2._lib.stream_ptr, pn2._lib.check
+    rs = np.random.RandomState(rows + cin + cout)
+    x = T((rs.randn(rows, cin) * 0.7 + 0.2).astype(np.float32), cuda)           # the layer below's un-normalised output
+    y = T(rs.randn(rows, cout).astype(np.float32), cuda)
+    w = T((rs.randn(cin, cout) / np.sqrt(cin)).astype(np.float32), cuda)
+    coef = T(np.stack([1 + 0.1 * rs.randn(cout), 0.1 * rs.randn(cout), 0.1 * rs.randn(cout), 1 + 0.1 * rs.rand(cout),
+                       0.01 * rs.randn(cout), 0.01 * rs.randn(cout)]).astype(np.float32), cuda)
+    sc, sh = T((1 + 0.1 * rs.randn(cin)).astype(np.float32), cuda), T((0.1 * rs.randn(cin)).astype(np.float32), cuda)
+    if pool:
+        dz = T(rs.randn(rows // 32, cout).astype(np.float32), cuda)
+        lin = torch.relu(y * coef[0] + coef[1]).view(rows // 32, 32, cout)
+        zmax = lin.max(1).values.contiguous()
+        ties = (lin == zmax[:, None, :]).sum(1).float().contiguous()
+    else:
+        dz, zmax, ties = T(rs.randn(rows, cout).astype(np.float32), cuda), None, None
+    gb, bb = T((1 + 0.1 * rs.randn(cin)).astype(np.float32), cuda), T((0.1 * rs.randn(cin)).astype(np.float32), cuda)
+    mb, ib = T((0.2 + 0.1 * rs.randn(cin)).astype(np.float32), cuda), T((1.4 + 0.1 * rs.rand(cin)).astype(np.float32), cuda)
+    nb = lib.pn2_bn_workspace_bytes(cin)
+    res = {}
+    for fused in (True, False):
+        dx = torch.empty(rows, cin, device=cuda)
+        dw = torch.zeros(cin, cout, device=cuda)
+        ws = torch.zeros(nb // 8, dtype=torch.float64, device=cuda)
+        cb, dgb, dbb = torch.zeros(6, cin, device=cuda), torch.zeros(cin, device=cuda), torch.zeros(cin, device=cuda)
+        bl = (ptr(x), ptr(gb), ptr(bb), ptr(mb), ptr(ib), 1, ptr(ws), nb, 3, ptr(cb), ptr(dgb), ptr(dbb)) if below else \
+             (None, None, None, None, None, 0, None, 0, 0, None, None, None)
+        xfa = (ptr(sc), ptr(sh), 1) if xf_on else (None, None, 0)
+        if fused:
+            check(lib.pn2_linear_bwd_fused(rows, cin, cout, ptr(x), *xfa, ptr(y), ptr(dz), ptr(coef), 1, pool, ptr(zmax), ptr(ties),
+                                           ptr(w), ptr(dx), ptr(dw), *bl, sp()), "pn2_linear_bwd_fused")
+        else:
+            check(lib.pn2_linear_dgrad_fin(rows, cin, cout, None, ptr(y), ptr(dz), ptr(coef), 1, pool, ptr(zmax), ptr(ties), ptr(w),
+                                           ptr(dx), *bl, sp()), "pn2_linear_dgrad_fin")
+            check(lib.pn2_linear_wgrad_gx(rows, cin, cout, ptr(x), *xfa, ptr(y), ptr(dz), ptr(coef), 1, pool, ptr(zmax), ptr(ties),
+                                          ptr(dw), sp()), "pn2_linear_wgrad_gx")
+        res[fused] = (dx, dw, cb, dgb, dbb)
+    # float64 yardstick of dy / dx / dW
+    c6 = coef.double()
+    lin = y.double() * c6[0] + c6[1]
+    on = lin > 0
+    if pool:
+        t = torch.where(on, lin, torch.zeros_like(lin)).float().view(-1, 32, cout)
+        g = torch.where(t == zmax.view(-1, 1, cout), (dz / ties).view(-1, 1, cout), torch.zeros_like(t)).view(rows, cout).double()
+    else:
+        g = dz.double()
+    gk = torch.where(on, g, torch.zeros_like(g))
+    dy = c6[0] * (-((y.double() - c6[2]) * c6[3]) * c6[5] + (gk - c6[4]))
+    xa = torch.relu(x.double() * sc.double() + sh.double()) if xf_on else x.double()
+    for fused in (True, False):
+        dx, dw = res[fused][0].double(), res[fused][1].double()
+        assert float((dx - dy @ w.double().t()).norm() / (dy @ w.double().t()).norm()) <= 2e-6, fused
+        assert float((dw - xa.t() @ dy).norm() / (xa.t() @ dy).norm()) <= 2e-6, fused
+    assert float((res[True][0] - res[False][0]).abs().max()) <= 1e-6 * float(res[False][0].abs().max())
+    assert float((res[True][1] - res[False][1]).abs().max()) <= 1e-5 * float(res[False][1].abs().max())
+    if below:
+        for a, r in zip(res[True][2:], res[False][2:]):
+            assert float((a - r).abs().max()) <= 1e-5 * max(float(r.abs().max()), 1e-3)
 
 
 def test_deferred_batch_norm_output_must_reach_a_dense_layer(pn2, cuda):
@@ -1785,7 +1857,7 @@ def test_bn_grad_sums_from_the_next_layers_dgrad(pn2, cuda, widths, pool, rows_s
     probe = torch.cos(torch.arange(int(np.prod(oshape)), device=cuda).float() * 0.37).reshape(oshape)
     calls = []
     real, real_gx = pn2._lib.lib.pn2_bn_relu_backward_stats, pn2._lib.lib.pn2_bn_grad_constants
-    real_fin = pn2._lib.lib.pn2_linear_dgrad_fin
+    real_fin, real_both = pn2._lib.lib.pn2_linear_dgrad_fin, pn2._lib.lib.pn2_linear_bwd_fused
     outs = {}
     for use in (True, False):
         tfu.USE_DGRAD_BN_STATS = use
@@ -1798,6 +1870,8 @@ def test_bn_grad_sums_from_the_next_layers_dgrad(pn2, cuda, widths, pool, rows_s
                 # ... and with the finish inside the producer the data-gradient GEMM of the layer above leaves sums, fold and
                 # constants in one launch: y_below = a[13], width of the layer below = a[1]
                 pn2._lib.lib.pn2_linear_dgrad_fin = lambda *a: (calls.append(a[1]) if a[13] is not None else None, real_fin(*a))[1]
+                # ... narrow layers form data and weight gradient in one launch (pn2_linear_bwd_fused): y_below = a[17], cin = a[1]
+                pn2._lib.lib.pn2_linear_bwd_fused = lambda *a: (calls.append(a[1]) if a[17] is not None else None, real_both(*a))[1]
             xx = x0.clone().requires_grad_(True)
             params, h = [], xx
             for i, wd in enumerate(widths):
@@ -1816,6 +1890,7 @@ def test_bn_grad_sums_from_the_next_layers_dgrad(pn2, cuda, widths, pool, rows_s
             pn2._lib.lib.pn2_bn_relu_backward_stats = real
             pn2._lib.lib.pn2_bn_grad_constants = real_gx
             pn2._lib.lib.pn2_linear_dgrad_fin = real_fin
+            pn2._lib.lib.pn2_linear_bwd_fused = real_both
     assert calls == list(widths[:-1][::-1]), calls   # every layer but the last got its sums from the layer above
     for a, r in zip(outs[True], outs[False]):
         s = max(float(r.abs().max()), 1e-3)

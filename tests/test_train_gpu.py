@@ -413,9 +413,22 @@ def test_every_gemm_of_a_real_step_is_as_accurate_as_the_library(pn2, cuda):
                      float(((dy @ w.t()).double() - ref).norm() / ref.norm())))
         return dx
 
+    orig_both = tfu._hip_bwd_fused
+
+    def both(x2d, xf, y, dz, coef, relu, pool, zmax, ties, w, link):  # narrow layers: data + weight gradient in ONE launch
+        out = orig_both(x2d, xf, y, dz, coef, relu, pool, zmax, ties, w, link)
+        if out is None:
+            return None
+        dy = dy_on_load(y, dz, coef, relu, pool, zmax, ties)
+        ref = dy.double() @ w.double().t()
+        seen.append(("dgrad_gx", tuple(dy.shape), w.shape[0], float((out[0].double() - ref).norm() / ref.norm()),
+                     float(((dy @ w.t()).double() - ref).norm() / ref.norm())))
+        return out
+
     tfu.hip_matmul, tfu.hip_linear_dgrad, tfu.hip_matmul_bn_stats, tfu.hip_linear_dgrad_linked = mm, dg, mm, dg
     tfu.hip_matmul_bn_stats_xf = mmx
     tfu.hip_linear_narrow, tfu.hip_matmul_bn_stats_fin, tfu._hip_dgrad_fin = nw, mmfin, dfin
+    tfu._hip_bwd_fused = both
     try:
         tfu.set_default_store(tfu.VariableStore(device=cuda, seed=5))
         logits, _ = pn2.model.get_model(pc, True, 9, hp, bn_decay=0.5)
@@ -424,6 +437,7 @@ def test_every_gemm_of_a_real_step_is_as_accurate_as_the_library(pn2, cuda):
         tfu.hip_matmul, tfu.hip_linear_dgrad, tfu.hip_matmul_bn_stats, tfu.hip_linear_dgrad_linked = orig_mm, orig_dg, orig_mms, orig_dgl
         tfu.hip_matmul_bn_stats_xf = orig_mmx
         tfu.hip_linear_narrow, tfu.hip_matmul_bn_stats_fin, tfu._hip_dgrad_fin = orig_nw, orig_fin, orig_dfin
+        tfu._hip_bwd_fused = orig_both
     # 23 layers; the first one (SA1's 6 -> 32 on the gathered rows) is not a GEMM launch any more (pn2_sa_first_layer_bn, pinned by
     # test_sa_first_layer_in_one_launch_equals_the_separate_ops)
     assert sum(1 for s_ in seen if s_[0] == "fwd") == 22 and sum(1 for s_ in seen if s_[0].startswith("dgrad")) == 22

@@ -2,8 +2,8 @@
 OUT=gpurun_out/r06h; mkdir -p $OUT
 timeout 1500 python -m pytest tests/test_train_gpu.py tests/test_layers_gpu.py -x -q -m gpu > $OUT/pytest.log 2>&1; echo "pytest rc=$?"; tail -4 $OUT/pytest.log
 for i in 1 2; do
-timeout 600 python tools/train_flags_ab.py USE_SA_FIRST_LAYER_FUSED=1 -- --steps 40 --warmup 5 2>&1 | tail -1 | tee -a $OUT/ab.txt
-timeout 600 python tools/train_flags_ab.py USE_SA_FIRST_LAYER_FUSED=0 -- --steps 40 --warmup 5 2>&1 | tail -1 | tee -a $OUT/ab.txt
+timeout 600 python tools/train_flags_ab.py USE_FUSED_BWD_NARROW=1 -- --steps 40 --warmup 5 2>&1 | tail -1 | tee -a $OUT/ab.txt
+timeout 600 python tools/train_flags_ab.py USE_FUSED_BWD_NARROW=0 -- --steps 40 --warmup 5 2>&1 | tail -1 | tee -a $OUT/ab.txt
 done
 (cd /tmp && export TMPDIR=/tmp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OLDPWD/$OUT/prof_train -o train -- python $OLDPWD/bench.py --train --steps 95 --warmup 5 > $OLDPWD/$OUT/prof_train.log 2>&1); echo "rocprof train rc=$?"
 for f in $(find $OUT/prof_train -name "*kernel_stats.csv"); do cp $f $OUT/train_kernel_stats.csv; done
