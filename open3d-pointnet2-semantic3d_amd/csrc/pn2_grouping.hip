@@ -461,7 +461,9 @@ int launch_ball_query_multi(int b, const BqmParams& p, hipStream_t st) {
 // wide, so every point with sqrtf(d2) < radius lies in those cells; the hits (typically < 32 of ~100
 // candidates instead of a scan over all n points) are ordered by index with a rank pass, which reproduces
 // "first nsample in index order" (tf_grouping.cu:18-37).  A query with more than kBqgCap hits (dense clouds)
-// is re-done by an ordered early-exit scan over the cloud.  Results are bit-identical to the scan kernels.
+// is re-done over the same 27 cells: each lane marks its hits in a per-query LDS bitmap indexed by point number, and a
+// prefix count over the bitmap hands out the first nsample set bits in index order (no scan of the cloud).  Results are
+// bit-identical to the scan kernels.
 constexpr int kBqgThreads = 1024;
 constexpr int kBqgWaves = kBqgThreads / 64;
 constexpr int kBqgMaxN = 8192;

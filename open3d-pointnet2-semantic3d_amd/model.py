@@ -127,6 +127,9 @@ def get_sa_fp_features(point_cloud, is_training, hyperparams, bn_decay=None, geo
     requiring grad), so the backward pass can be run in two pieces -- loss -> head -> FP -> the cut, then the cut -> SA --
     with the gradient all-reduce of the first piece's parameters travelling during the second (train.Trainer)."""
     end_points = {}
+    if sa1 is not None and (is_training or geometry is not None):
+        # sa1[0] may be a strided view of the (b,n,6) batch: only the inference path reads rows where they lie
+        raise ValueError("sa1= is an inference-only hand-over: not with is_training=True or geometry=")
     if is_training:
         tf_util.reset_bn_links()  # producer records of the previous forward pass (tf_util._TrainDenseBnRelu)
     # model.py:26-29 slices the batch into coordinates and colours.  Inference: the slices stay VIEWS of point_cloud -- the

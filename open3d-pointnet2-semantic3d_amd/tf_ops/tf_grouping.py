@@ -57,6 +57,14 @@ def query_ball_point(radius, nsample, xyz1, xyz2, kernel=0, arith_mode=None):
 BIN_MAX_N, BIN_MIN_N, BIN_MIN_M, BIN_MAX_NSAMPLE = 8192, 4096, 256, 64  # the LDS-grid kernel's range (pn2_grouping.hip)
 
 
+def _version_of(t):
+    """the tensor's version counter, or None for tensors that keep none (created under torch.inference_mode())"""
+    try:
+        return t._version
+    except RuntimeError:
+        return None
+
+
 def ball_query_bin_alloc(xyz1):
     """workspace of ball_query_bin for xyz1 (b,n,3), or None when n is outside the grid kernel's range"""
     b, n, _ = xyz1.shape
@@ -80,7 +88,7 @@ def ball_query_bin(radius, xyz1, out=None):
     b, n, _ = xyz1.shape
     if not (BIN_MIN_N <= n <= BIN_MAX_N):
         return None
-    src = (xyz1.data_ptr(), xyz1._version)  # the caller's tensor (a non-contiguous one is copied below)
+    src = (xyz1.data_ptr(), _version_of(xyz1))  # the caller's tensor (a non-contiguous one is copied below)
     xyz1 = xyz1.detach().contiguous()
     bins = out if out is not None else ball_query_bin_alloc(xyz1)  # `out`: allocated by the caller (on ITS stream)
     with torch.cuda.device(xyz1.device):
@@ -103,7 +111,7 @@ def query_ball_point_binned(radius, nsample, xyz1, xyz2, bins, arith_mode=None):
     if bins is None or nsample > BIN_MAX_NSAMPLE or m < BIN_MIN_M:
         return query_ball_point(radius, nsample, xyz1, xyz2, arith_mode=arith_mode)
     require_cuda(xyz1, xyz2)
-    src = (xyz1.data_ptr(), xyz1._version)
+    src = (xyz1.data_ptr(), _version_of(xyz1))
     xyz1 = xyz1.detach().contiguous()
     xyz2 = xyz2.detach().contiguous()
     made = getattr(bins, "_pn2_bins_of", None)

@@ -38,9 +38,11 @@ def tag_fps_output(new_xyz, tie, arith_mode=None):
 
 
 def drop_fps_tag(t):
-    """forget what is known about `t` (a tie record, ball-query bins built from it): for code that overwrites a tensor through
+    """forget the FPS tie record attached to `t`: for code that overwrites a tensor through
     its raw pointer -- this library's kernels writing into a caller's buffer (tf_util.multi_copy_) -- which no version counter
-    sees.  (A graph replay that rewrites new_xyz rewrites its tie record in the same launch: that tag stays true.)"""
+    sees.  (A graph replay that rewrites new_xyz rewrites its tie record in the same launch: that tag stays true.)  Ball-query bins
+    carry their own provenance tag on the bins tensor (tf_grouping.ball_query_bin), keyed on the source's address and version:
+    a raw-pointer overwrite of the cloud does not invalidate it -- whoever overwrites a binned cloud that way bins again."""
     for attr in (_TIE_ATTR,):
         if hasattr(t, attr):
             try:

@@ -520,6 +520,9 @@ def pointnet_sa_module(xyz, points, npoint, radius, nsample, mlp, mlp2, group_al
             new_points = sa_features_inference(xyz, new_xyz, points, idx, mlp, bn, bn_decay)
             new_points = new_points.unsqueeze(2)
         else:
+            if geometry is not None and geometry[1] is None:
+                raise ValueError("geometry=(new_xyz, None) (samples drawn ahead, ball query here) is the inference fast path's "
+                                 "hand-over: pass the idx too for training / group_all / knn / non-max pooling")
             # training, features of >= 16 channels, geometry + scatter plan computed ahead: the feature half of the first
             # conv runs on the n SOURCE points instead of the m * nsample grouped rows (tf_util._TrainHoistedBnRelu)
             hoist = (bool(is_training) and tf_util.USE_HOISTED_TRAIN and not group_all and not knn and use_xyz and bn

@@ -124,3 +124,40 @@ def test_concurrent_streams_run_side_by_side(pn2, cuda):
     one = min(wall(streams[:1]) for _ in range(3))
     four = min(wall(streams) for _ in range(3))
     assert four < 1.6 * one, (one, four)
+
+
+@pytest.mark.gpu
+def test_timed_region_of_the_bench_launches_library_kernels_only(pn2, cuda):
+    """VERDICT r05 #7c: what bench.py times -- K x pipe.step() + flush() of the staggered pipeline it builds (bench.py main():
+    StaggeredPipeline(sa1_samples | get_sa_fp_features(sa1=)), backlog (0,0,1,1), resident inputs) -- launches this library's
+    kernels and nothing else: no at::native elementwise / cat / copy kernel, no memcpy or fill (torch profiler over the region)."""
+    import torch
+    from torch.profiler import ProfilerActivity, profile
+    tfu = pn2.util.tf_util
+    B, N = 4, 8192   # the full-size level shapes per cloud (the kernels dispatch on n, m, nsample), a smaller batch
+    hp = dict(pn2.model.SEMANTIC_HYPERPARAMS)
+    hp.update(batch_size=B, num_point=N)
+    tfu.set_default_store(tfu.VariableStore(device=cuda, seed=4))
+    resident = [_cloud(300 + i, B, N, cuda) for i in range(6)]
+    with torch.no_grad():
+        pn2.model.get_sa_fp_features(resident[0], False, hp)  # creates variables and folded weights (their own torch kernels)
+    pipe = pn2.runtime.StaggeredPipeline(lambda x: pn2.model.sa1_samples(x, hp),
+                                         lambda x, s: pn2.model.get_sa_fp_features(x, False, hp, sa1=s)[0],
+                                         lambda n: resident[n], (0, 0, 1, 1))
+    for _ in range(8):      # warm-up, as bench.py does before its regions
+        pipe.step()
+    pipe.flush()
+    torch.cuda.synchronize()
+    K = 12
+    with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA]) as prof:
+        for _ in range(K):
+            pipe.step()
+        pipe.flush()
+        torch.cuda.synchronize()
+    names = [e.name for e in prof.events() if e.device_type == torch.autograd.DeviceType.CUDA]
+    assert names, "the profiler saw no device activity"
+    ours = [nm for nm in names if "anonymous namespace" in nm or nm.startswith("pn2_") or "_kernel" in nm]
+    assert len(ours) >= K * 10, "the graph replays' kernels were not seen (%d device events)" % len(names)
+    bad = ("at::native", "elementwise", "Memcpy", "memcpy", "Memset", "memset", "fillBuffer", "copyBuffer", "CatArray")
+    foreign = [nm for nm in names if any(t in nm for t in bad)]
+    assert not foreign, "torch / copy kernels inside the timed region: %s" % sorted(set(foreign))
