@@ -94,7 +94,7 @@ def s_dup25(seed, b, n):
 
 FPS_KERNELS = ("farthest_point_sample", "fps_gather", "fps_nested")
 # one workgroup per cloud, latency-bound like the samplers (they hide behind the other batches when several are in flight)
-LATENCY_KERNELS = FPS_KERNELS + ("coarse_geometry",)
+LATENCY_KERNELS = FPS_KERNELS + ("coarse_geometry", "ball_query_bin")
 
 # HBM bytes per launch of the roofline kernel: PMC counters are a separate rocprofv3 pass (--pmc FETCH_SIZE / WRITE_SIZE cannot
 # share a run with the timed region), so the line cites the committed summary of that pass (tools/gpu_round4.sh,
@@ -326,8 +326,9 @@ def north_star_kernels(pn2, dev):
         "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4),
         "group_point_alone_GBs": round(gp_bytes / (t_gp * 1e-3) / 1e9, 1),
         "binned_once_variant": {
-            "note": "pn2_ball_query_bin once per cloud + pn2_query_ball_point_binned (same indices); off by default in the model "
-                    "(util/pointnet_util.py USE_BINNED_BALL_QUERY: the binning launch costs throughput when 4 batches are in flight)",
+            "note": "pn2_ball_query_bin once per cloud + pn2_query_ball_point_binned (same indices): what the pipelined "
+                    "(throughput) execution runs since r06 -- the binning rides in the sampler half of a batch (model.sa1_samples); "
+                    "the one-batch graph keeps the self-binning query",
             "bin_us": round(t_bin * 1e3, 1), "ball_query_us": round(t_bq * 1e3, 1),
             "frac_query_only": round(gbs(t_bq + t_gp) / HBM_PEAK_GBS, 4),
             "frac_including_bin": round(gbs(t_bin + t_bq + t_gp) / HBM_PEAK_GBS, 4)}}}
@@ -748,7 +749,7 @@ def main():
                          "pn2_fp_interp_concat; auto = fused (faster at every pipeline depth with one stream per batch)")
     ap.add_argument("--wide", default="auto", help="A/B: off = one pn2_linear per coarse-level layer; N = pn2_*_mlp_wide from N rows on")
     ap.add_argument("--no-hoist", action="store_true", help="A/B: FP first layers computed in place (pn2_fp_mlp_fused) instead of hoisted")
-    ap.add_argument("--binned-bq", action="store_true", help="A/B: ball query on a cloud binned once per level on a forked stream (default off)")
+    ap.add_argument("--no-binned-bq", action="store_true", help="A/B: the sampler half of a pipelined batch does NOT bin the cloud for SA1's ball query")
     ap.add_argument("--no-coarse-geometry", action="store_true",
                     help="A/B: levels 2-4 through the separate sampling / ball-query / three_nn launches instead of pn2_coarse_geometry")
     ap.add_argument("--train", action="store_true",
@@ -828,7 +829,7 @@ def main():
 
     pn2.util.pointnet_util.USE_HOISTED_FP = not args.no_hoist
     pn2.util.pointnet_util.USE_HOISTED_SA = not args.no_hoist
-    pn2.util.pointnet_util.USE_BINNED_BALL_QUERY = bool(args.binned_bq)
+
     if args.no_coarse_geometry:
         pn2.util.pointnet_util.USE_COARSE_GEOMETRY = False
     pn2._lib.lib.dup = tuple(args.dup)
@@ -857,11 +858,15 @@ def main():
         mk = lambda n: (pc if n == 0 else torch.from_numpy(s_scene(2000 + 10 * rank + n, B, N)).to(dev))  # noqa: E731
         if args.stagger != "off":
             backlog = [int(v) for v in args.stagger.split(",")]
-            pipe = pn2.runtime.StaggeredPipeline(lambda x: pn2.model.sa1_samples(x, hp),
+            pipe = pn2.runtime.StaggeredPipeline(lambda x: pn2.model.sa1_samples(x, hp, bins=not args.no_binned_bq),
                                                  lambda x, s: pn2.model.get_sa_fp_features(x, False, hp, sa1=s)[0], mk, backlog)
             caps = [pn2.runtime.CapturedForward(fwd, pc)]  # the latency regime: one graph, one batch in flight
             step = lambda: (lambda r: None if r is None else r[1])(pipe.step())  # noqa: E731
-            flush = lambda: (lambda d: d[-1][1] if d else None)(pipe.flush())  # noqa: E731
+
+            def eager_on(x):  # the instrumented passes launch what the pipeline's two graphs hold  # noqa: F811
+                with torch.no_grad():
+                    return pn2.model.get_sa_fp_features(x, False, hp, sa1=pn2.model.sa1_samples(x, hp, bins=not args.no_binned_bq))[0]
+            eager_step = lambda: eager_on(pc)  # noqa: E731
             thr_inputs, n_streams, n_flight = pipe.inputs(), pipe.P, pipe.batches_in_flight
         else:
             P = max(1, args.pipeline)

@@ -579,6 +579,10 @@ int pn2_sa_mlp_wide_pre(int b, int n, int m, int nsample, const float *xyz, cons
  * pn2_query_ball_point (tf_grouping.cu:3-43).  PN2_EUNSUP for shapes outside the grid kernel (n > 8192, nsample > 64). */
 size_t pn2_ball_query_bin_bytes(int n);
 int pn2_ball_query_bin(int b, int n, float radius, const float *xyz1, void *workspace, size_t workspace_bytes, void *stream);
+/* pn2_ball_query_bin with the cloud's rows ld1 floats apart (see pn2_fps_nested_ld): the bins of a dense copy, bit for bit.
+ * pn2_query_ball_point_binned never reads xyz1 (the bins hold the cell-sorted cloud): it takes the strided pointer as it is. */
+int pn2_ball_query_bin_ld(int b, int n, float radius, const float *xyz1, int ld1, void *workspace, size_t workspace_bytes,
+                          void *stream);
 int pn2_query_ball_point_binned(int b, int n, int m, float radius, int nsample, const float *xyz1, const float *xyz2,
                                 const void *bins, int *idx, int *pts_cnt, int arith_mode, void *stream);
 

@@ -151,6 +151,7 @@ SIGNATURES = {
     "pn2_sa_mlp_wide_pre": [c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p,
                             c_void_p, c_int, c_void_p, c_void_p],
     "pn2_ball_query_bin": [c_int, c_int, c_float, c_void_p, c_void_p, ctypes.c_size_t, c_void_p],
+    "pn2_ball_query_bin_ld": [c_int, c_int, c_float, c_void_p, c_int, c_void_p, ctypes.c_size_t, c_void_p],
     "pn2_query_ball_point_binned": [c_int, c_int, c_int, c_float, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int,
                                     c_void_p],
     "pn2_group_pool": [ctypes.c_longlong, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p],
@@ -301,6 +302,7 @@ class _LibProxy:
 _LD_TRACE = {"pn2_fps_nested_ld": ("pn2_fps_nested", (3,), None, None),
              "pn2_query_ball_point_ld": ("pn2_query_ball_point", (5,), None, None),
              "pn2_three_nn_ld": ("pn2_three_nn", (3,), None, None),
+             "pn2_ball_query_bin_ld": ("pn2_ball_query_bin", (3,), None, None),
              "pn2_sa_mlp_max_fused_ld": ("pn2_sa_mlp_max_fused", (5, 6), 11, 12),
              "pn2_fp_mlp_fused_pre_ld": ("pn2_fp_mlp_fused_pre", (4,), 9, 10)}
 

@@ -643,11 +643,11 @@ __device__ __forceinline__ void bqg_copy(const BqgLds& L, int np, unsigned char*
 }
 
 __global__ void __launch_bounds__(kBqgThreads)
-ball_query_bin_kernel(int n, float radius, const float* __restrict__ xyz1_all, unsigned char* __restrict__ ws_all, size_t stride) {
+ball_query_bin_kernel(int n, float radius, const float* __restrict__ xyz1_all, int ld1, unsigned char* __restrict__ ws_all, size_t stride) {
     extern __shared__ int smem_i[];
     const int np = (n + 63) & ~63;
     const BqgLds L = bqg_carve(smem_i, np);
-    bqg_build(L, n, radius, xyz1_all + (size_t)blockIdx.x * n * 3);
+    bqg_build(L, n, radius, xyz1_all + (size_t)blockIdx.x * n * ld1, ld1);
     bqg_copy<false>(L, np, ws_all + (size_t)blockIdx.x * stride);
 }
 
@@ -1053,13 +1053,15 @@ extern "C" int pn2_query_ball_point_ld(int b, int n, int m, float radius, int ns
 // PN2_EUNSUP when the shape is outside the LDS-grid kernel's range (the caller then uses pn2_query_ball_point).
 extern "C" size_t pn2_ball_query_bin_bytes(int n) { return (n >= 1 && n <= kBqgMaxN) ? bqg_ws_stride(n) : 0; }
 
-extern "C" int pn2_ball_query_bin(int b, int n, float radius, const float* xyz1, void* workspace, size_t workspace_bytes,
-                                  void* stream) {
-    if (b <= 0 || n <= 0) return PN2_EINVAL;
+// pn2_ball_query_bin with the cloud's rows ld1 floats apart (ld1 >= 3: the xyz columns of a (b,n,6) xyz+rgb batch read in place,
+// model.py:26-29); the bins are those of a dense copy, bit for bit.
+extern "C" int pn2_ball_query_bin_ld(int b, int n, float radius, const float* xyz1, int ld1, void* workspace, size_t workspace_bytes,
+                                     void* stream) {
+    if (b <= 0 || n <= 0 || ld1 < 3) return PN2_EINVAL;
     if (!(radius > 0.0f)) return PN2_EINVAL;
     if (!xyz1 || !workspace) return PN2_ENULL;
     if (n > kBqgMaxN || !(radius < 1e18f)) return PN2_EUNSUP;
-    if (b > 65535) return PN2_ERANGE;
+    if (b > 65535 || (long long)n * ld1 > 0x7fffffffLL) return PN2_ERANGE;
     const size_t stride = bqg_ws_stride(n);
     if (workspace_bytes < stride * (size_t)b || ((uintptr_t)workspace & 255) != 0) return PN2_EINVAL;
     static bool attr_set = false;
@@ -1069,9 +1071,14 @@ extern "C" int pn2_ball_query_bin(int b, int n, float radius, const float* xyz1,
         attr_set = true;
     }
     ball_query_bin_kernel<<<b, kBqgThreads, bqg_lds_bytes((n + 63) & ~63), static_cast<hipStream_t>(stream)>>>(
-        n, radius, xyz1, static_cast<unsigned char*>(workspace), stride);
+        n, radius, xyz1, ld1, static_cast<unsigned char*>(workspace), stride);
     PN2_RETURN_IF_LAUNCH_FAILED();
     return PN2_OK;
+}
+
+extern "C" int pn2_ball_query_bin(int b, int n, float radius, const float* xyz1, void* workspace, size_t workspace_bytes,
+                                  void* stream) {
+    return pn2_ball_query_bin_ld(b, n, radius, xyz1, 3, workspace, workspace_bytes, stream);
 }
 
 // query_ball_point on a cloud binned by pn2_ball_query_bin(b, n, radius, xyz1, ...) -- same radius, same xyz1: the query

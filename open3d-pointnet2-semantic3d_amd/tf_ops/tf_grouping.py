@@ -88,11 +88,13 @@ def ball_query_bin(radius, xyz1, out=None):
     b, n, _ = xyz1.shape
     if not (BIN_MIN_N <= n <= BIN_MAX_N):
         return None
-    src = (xyz1.data_ptr(), _version_of(xyz1))  # the caller's tensor (a non-contiguous one is copied below)
-    xyz1 = xyz1.detach().contiguous()
+    src = (xyz1.data_ptr(), _version_of(xyz1))  # the caller's tensor
+    # a column block of a wider batch (point_cloud[:, :, 0:3]) is read where it lies; other layouts are copied dense
+    xyz1, ld1 = rows_in_place(xyz1)
     bins = out if out is not None else ball_query_bin_alloc(xyz1)  # `out`: allocated by the caller (on ITS stream)
     with torch.cuda.device(xyz1.device):
-        check(lib.pn2_ball_query_bin(b, n, float(radius), ptr(xyz1), ptr(bins), bins.numel(), stream_ptr()), "pn2_ball_query_bin")
+        check(lib.pn2_ball_query_bin_ld(b, n, float(radius), ptr(xyz1), ld1, ptr(bins), bins.numel(), stream_ptr()),
+              "pn2_ball_query_bin_ld")
     # what the bins describe: the C entry point takes an opaque pointer and cannot check it -- bins of a smaller
     # cloud would be read out of bounds, bins of a smaller radius would silently miss neighbours
     # ... and bins of ANOTHER cloud of the same shape (a reused `out=` workspace after the input batch changed) would return wrong
@@ -112,7 +114,7 @@ def query_ball_point_binned(radius, nsample, xyz1, xyz2, bins, arith_mode=None):
         return query_ball_point(radius, nsample, xyz1, xyz2, arith_mode=arith_mode)
     require_cuda(xyz1, xyz2)
     src = (xyz1.data_ptr(), _version_of(xyz1))
-    xyz1 = xyz1.detach().contiguous()
+    xyz1 = xyz1.detach()   # (never read by the kernel: the bins hold the cell-sorted cloud; a strided view is fine)
     xyz2 = xyz2.detach().contiguous()
     made = getattr(bins, "_pn2_bins_of", None)
     if made is None:

@@ -295,47 +295,15 @@ USE_FUSED_SA = True
 
 USE_HOISTED_SA = True  # A/B: feature part of the first SA layer computed on the source points (linearity)
 USE_HOISTED_FP = True  # A/B: first FP layer's product with the interpolated channels computed on the known points (linearity)
-# Bin the cloud once per level on a side stream while the FPS of the level runs (tf_grouping.ball_query_bin).  OFF by default:
-# the binned query is 15.8 vs 18.4 us at the SA1 shape, but the forked stream inside every batch's graph costs the
-# throughput regime 0.49 -> 0.64 ms per step (4 batches in flight: twice the streams per hardware queue, as with the
-# two-stream geometry capture) and the single batch nothing (0.95 -> 0.98 ms).  The ops stay available.
-USE_BINNED_BALL_QUERY = False
-
-_bin_streams = {}
-
-
-def _bin_stream(device):
-    key = (device.type, device.index)
-    if key not in _bin_streams:
-        _bin_streams[key] = torch.cuda.Stream(device=device)
-    return _bin_streams[key]
-
-
 def sa_geometry(xyz, npoint, radius, nsample):
     """The feature-independent half of an SA layer: FPS -> gather -> ball query.
     -> new_xyz (B,npoint,3), idx (B,npoint,nsample).  Depends only on coordinates, so a model can
     run the geometry of all levels on a side stream (see model.get_sa_fp_features).
-    Large levels (4096..8192 points): the cloud is sorted into the ball query's grid ONCE (tf_grouping.ball_query_bin) on a
-    forked stream BESIDE the FPS -- both read the same input cloud, the FPS is a 16-CU latency chain -- and the query
-    workgroups copy the bins instead of each re-binning the cloud (a parallel branch when the caller is capturing a graph)."""
-    n = xyz.shape[1]
-    bins = None
-    if USE_BINNED_BALL_QUERY:
-        xyz = xyz.contiguous()
-    if (USE_BINNED_BALL_QUERY and tf_grouping.BIN_MIN_N <= n <= tf_grouping.BIN_MAX_N and npoint >= tf_grouping.BIN_MIN_M
-            and nsample <= tf_grouping.BIN_MAX_NSAMPLE):
-        cur = torch.cuda.current_stream(xyz.device)
-        side = _bin_stream(xyz.device)
-        bins = tf_grouping.ball_query_bin_alloc(xyz)  # allocated on the caller's stream, which joins the fork below
-        side.wait_stream(cur)
-        with torch.cuda.stream(side):
-            tf_grouping.ball_query_bin(radius, xyz, out=bins)
+    (The binned-once ball query -- tf_grouping.ball_query_bin + query_ball_point_binned -- pays when the binning sits in the
+    sampler half of a pipelined batch: model.sa1_samples; forked onto a second stream inside one batch's graph it cost the
+    throughput regime 0.49 -> 0.64 ms per step, r03, and was removed from this function in r06.)"""
     _, new_xyz = farthest_point_sample_and_gather(npoint, xyz)  # one launch: the FPS kernel emits the coordinates
-    if bins is not None:
-        torch.cuda.current_stream(xyz.device).wait_stream(_bin_stream(xyz.device))
-        idx, _ = tf_grouping.query_ball_point_binned(radius, nsample, xyz, new_xyz, bins)
-    else:
-        idx, _ = query_ball_point(radius, nsample, xyz, new_xyz)
+    idx, _ = query_ball_point(radius, nsample, xyz, new_xyz)
     return new_xyz, idx
 
 
@@ -514,7 +482,10 @@ def pointnet_sa_module(xyz, points, npoint, radius, nsample, mlp, mlp2, group_al
                 # the samples of this level were drawn ahead (runtime.StaggeredPipeline: the sampling of a batch is a graph of
                 # its own, submitted ahead of the batch's dense half); the ball query is still this module's
                 new_xyz = geometry[0]
-                idx, _ = query_ball_point(radius, nsample, xyz, new_xyz)
+                if len(geometry) > 2 and geometry[2] is not None:  # the cloud was binned beside the sampling (model.sa1_samples)
+                    idx, _ = tf_grouping.query_ball_point_binned(radius, nsample, xyz, new_xyz, geometry[2])
+                else:
+                    idx, _ = query_ball_point(radius, nsample, xyz, new_xyz)
             else:
                 new_xyz, idx = geometry[:2] if geometry is not None else sa_geometry(xyz, npoint, radius, nsample)
             new_points = sa_features_inference(xyz, new_xyz, points, idx, mlp, bn, bn_decay)

@@ -90,6 +90,9 @@ def test_argument_validation_needs_no_gpu(pn2):
     assert L.pn2_query_ball_point_ld(1, 8192, 1024, 0.5, 32, fake, 6, nul, fake, fake, 1, nul) == -2
     assert L.pn2_query_ball_point_ld(1, 1000, 100, 0.5, 32, fake, 6, fake, fake, fake, 1, nul) == -4   # outside the LDS-grid kernel
     assert L.pn2_three_nn_ld(1, 64, 2, fake, 6, fake, fake, fake, nul) == -1                     # >= 3 known points
+    assert L.pn2_ball_query_bin_ld(1, 8192, 0.5, fake, 2, fake, 1 << 20, nul) == -1              # r06: ld >= 3
+    assert L.pn2_ball_query_bin_ld(1, 8192, 0.5, nul, 6, fake, 1 << 20, nul) == -2
+    assert L.pn2_ball_query_bin_ld(1, 20000, 0.5, fake, 6, fake, 1 << 20, nul) == -4             # outside the LDS-grid kernel
     assert L.pn2_three_nn_ld(1, 64, 16, fake, 1, fake, fake, fake, nul) == -1                    # ld >= 3
     assert L.pn2_three_nn_ld(1, 64, 16, fake, 6, nul, fake, fake, nul) == -2
     w1 = one_i(32)

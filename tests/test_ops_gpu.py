@@ -733,16 +733,14 @@ def test_query_ball_point_binned_equals_unbinned(pn2, oracle, cuda, case, mode):
     b2, c2 = g.query_ball_point_binned(r, K, xt, T(q2, cuda), bins)
     o2, oc2 = oracle.query_ball_point(r, K, xyz, q2, mode)
     assert np.array_equal(b2.cpu().numpy(), o2) and np.array_equal(c2.cpu().numpy(), oc2)
-    # the layer-level chain (bins built on a forked stream beside the FPS) equals the plain chain
-    pu = pn2.util.pointnet_util
-    nx0, idx0 = pu.sa_geometry(T(xyz, cuda), m, r, K)
-    pu.USE_BINNED_BALL_QUERY = True
-    try:
-        nx1, idx1 = pu.sa_geometry(T(xyz, cuda), m, r, K)
-    finally:
-        pu.USE_BINNED_BALL_QUERY = False
+    # bins of a column block of a wider batch read in place (pn2_ball_query_bin_ld) are the bins of the dense copy, bit for bit,
+    # and the binned query takes the strided view as it is (model.sa1_samples hands point_cloud[:, :, 0:3] over)
     import torch
-    assert torch.equal(nx1, nx0) and torch.equal(idx1, idx0)
+    wide = torch.cat([xt, torch.rand_like(xt)], dim=2)      # (b, n, 6): xyz | colours
+    view = wide[:, :, 0:3]
+    bins_v = g.ball_query_bin(r, view)
+    bv, cv = g.query_ball_point_binned(r, K, view, T(q, cuda), bins_v)
+    assert torch.equal(bv, bi) and torch.equal(cv, bc)
     assert g.ball_query_bin(r, T(xyz[:, :1000].copy(), cuda)) is None  # below the grid kernel's range: caller scans
     xt.add_(0.0)  # an in-place update (same values): the tag no longer vouches for the cloud
     with pytest.raises(ValueError, match="another cloud"):

@@ -85,18 +85,22 @@ def test_staggered_pipeline_equals_the_eager_forward(pn2, cuda, backlog):
 
 
 @pytest.mark.gpu
-def test_samples_given_ahead_equal_the_module_sampling_itself(pn2, cuda):
+@pytest.mark.parametrize("B,N,binned", [(2, 1024, False), (2, 8192, True), (3, 4096, True)])
+def test_samples_given_ahead_equal_the_module_sampling_itself(pn2, cuda, B, N, binned):
+    """model.sa1_samples + get_sa_fp_features(sa1=): the sampling (and, for clouds the LDS-grid ball query takes, the binning of the
+    cloud: r06) done ahead, everything else afterwards == the forward that does it all itself, bit for bit"""
     import torch
     tfu = pn2.util.tf_util
-    B, N = 2, 1024
     hp = _small_hp(pn2, B, N)
     tfu.set_default_store(tfu.VariableStore(device=cuda, seed=4))
     x = _cloud(7, B, N, cuda)
     with torch.no_grad():
         a, ea = pn2.model.get_sa_fp_features(x, False, hp)
         s = pn2.model.sa1_samples(x, hp)
+        assert (s[2] is not None) == binned
         b, eb = pn2.model.get_sa_fp_features(x, False, hp, sa1=s)
-    assert torch.equal(a, b)
+        c, _ = pn2.model.get_sa_fp_features(x, False, hp, sa1=pn2.model.sa1_samples(x, hp, bins=False))
+    assert torch.equal(a, b) and torch.equal(a, c)
     for u, v in zip(ea["xyzs"], eb["xyzs"]):
         assert torch.equal(u, v)
 
@@ -134,7 +138,8 @@ def test_timed_region_of_the_bench_launches_library_kernels_only(pn2, cuda):
     import torch
     from torch.profiler import ProfilerActivity, profile
     tfu = pn2.util.tf_util
-    B, N = 4, 8192   # the full-size level shapes per cloud (the kernels dispatch on n, m, nsample), a smaller batch
+    B, N = 8, 8192   # the full-size level shapes per cloud, half the batch (FP4 takes its in-place three-layer chain from 65536 rows on;
+                     # below that its wide-kernel path reads dense rows: one copy, as test_in_place_gpu.py notes)
     hp = dict(pn2.model.SEMANTIC_HYPERPARAMS)
     hp.update(batch_size=B, num_point=N)
     tfu.set_default_store(tfu.VariableStore(device=cuda, seed=4))
