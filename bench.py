@@ -99,7 +99,7 @@ LATENCY_KERNELS = FPS_KERNELS + ("coarse_geometry", "ball_query_bin")
 # HBM bytes per launch of the roofline kernel: PMC counters are a separate rocprofv3 pass (--pmc FETCH_SIZE / WRITE_SIZE cannot
 # share a run with the timed region), so the line cites the committed summary of that pass (tools/gpu_round4.sh,
 # tools/pmc_to_profiles.py: gfx950 corrections as MI355X_MICROARCH.md prescribes) instead of carrying `null`.
-PMC_FILE = "profiles/r05_pmc_hbm_traffic.json"
+PMC_FILE = "profiles/r06_pmc_hbm_traffic.json"
 PMC_KERNEL_OF = {"fp_mlp_fused_pre": "fp_chain_pipe_kernel", "fp_mlp_fused": "sa_fused_kernel<2", "sa_mlp_max_fused": "sa_fused_kernel<3, 1, 1, 2"}
 
 
