@@ -63,439 +63,12 @@ import torch
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-HBM_PEAK_GBS = 8000.0      # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
-MFMA_F32_PEAK_TF = 157.3   # dense fp32 MFMA peak (v_mfma_f32_32x32x2_f32)
-
-
-def s_scene(seed, b, n):
-    rs = np.random.RandomState(seed)
-    xy = rs.uniform(-5, 5, (b, n, 2))
-    z = np.clip(np.abs(rs.normal(0, 1.5, (b, n, 1))), 0, 8)
-    rgb = rs.uniform(0, 1, (b, n, 3))
-    return np.concatenate([xy, z, rgb], axis=2).astype(np.float32)
-
-
-def s_randn(seed, b, n):
-    """S-randn: the reference benchmark's own input (benchmark.py:16-18: np.random.randn(batch, num_point, 6))"""
-    return np.random.RandomState(seed).randn(b, n, 6).astype(np.float32)
-
-
-def s_dup25(seed, b, n):
-    """S-dup25: S-scene with a quarter of its rows duplicates of other rows (xyz and colour), shuffled -- how the reference
-    fills a cloud shorter than num_points_per_sample (dataset/semantic_dataset.py:101-106: np.random.choice of its own rows)"""
-    rs = np.random.RandomState(seed + 7919)
-    x = s_scene(seed, b, n)
-    nd = n // 4
-    for i in range(b):
-        x[i, n - nd:] = x[i, rs.randint(0, n - nd, nd)]
-        x[i] = x[i][rs.permutation(n)]
-    return x
-
-
-FPS_KERNELS = ("farthest_point_sample", "fps_gather", "fps_nested")
-# one workgroup per cloud, latency-bound like the samplers (they hide behind the other batches when several are in flight)
-LATENCY_KERNELS = FPS_KERNELS + ("coarse_geometry", "ball_query_bin")
-
-# HBM bytes per launch of the roofline kernel: PMC counters are a separate rocprofv3 pass (--pmc FETCH_SIZE / WRITE_SIZE cannot
-# share a run with the timed region), so the line cites the committed summary of that pass (tools/gpu_round4.sh,
-# tools/pmc_to_profiles.py: gfx950 corrections as MI355X_MICROARCH.md prescribes) instead of carrying `null`.
-PMC_FILE = "profiles/r06_pmc_hbm_traffic.json"
-PMC_KERNEL_OF = {"fp_mlp_fused_pre": "fp_chain_pipe_kernel", "fp_mlp_fused": "sa_fused_kernel<2", "sa_mlp_max_fused": "sa_fused_kernel<3, 1, 1, 2"}
-
-
-def pmc_traffic(kernel):
-    """bytes per launch of `kernel` from the committed PMC summary, or None (file absent / kernel not in it)"""
-    try:
-        with open(os.path.join(ROOT, PMC_FILE)) as f:
-            ks = json.load(f)["kernels"]
-    except (OSError, ValueError, KeyError):
-        return None
-    key = PMC_KERNEL_OF.get(kernel, kernel)
-    hits = [v["traffic_bytes"] for k, v in ks.items() if key in k]
-    return max(hits) if hits else None
-
-
-# ---- algorithmic work per launch (SURVEY.md section 8d: compulsory traffic) -----------------
-def kernel_model(name, a):
-    """-> (bound, units) with units = algorithmic bytes (hbm) or flops (mfma) of ONE launch."""
-    if name in ("pn2_farthest_point_sample", "pn2_fps_gather", "pn2_fps_nested"):
-        b, n, m = a[0], a[1], a[2]
-        return "hbm", b * n * 12 + b * m * 4 + (b * m * 12 if name != "pn2_farthest_point_sample" else 0)
-    if name == "pn2_coarse_geometry":  # ints: b, n0, nlev, fps mode, bq mode, then (decoded by _lib) npoint[], nsample[]
-        b, n, L = a[:3]
-        byts = b * n * 12
-        for m, ns in zip(a[5:5 + L], a[5 + L:5 + 2 * L]):
-            byts += b * (m * 16 + m * ns * 4 + m * 4 + n * 24)
-            n = m
-        return "hbm", byts
-    if name == "pn2_gather_point":
-        b, n, m = a[:3]
-        return "hbm", b * m * 4 + b * m * 12 * 2
-    if name in ("pn2_query_ball_point", "pn2_query_ball_point_binned"):
-        b, n, m, _, ns = a[:5]
-        return "hbm", b * n * 12 + b * m * 12 + b * m * ns * 4 + b * m * 4
-    if name == "pn2_ball_query_bin":
-        b, n = a[:2]
-        return "hbm", b * n * 12 + b * n * 14
-    if name == "pn2_group_point":
-        b, n, c, m, ns = a[:5]
-        return "hbm", b * m * ns * 4 + b * n * c * 4 + b * m * ns * c * 4
-    if name == "pn2_sa_group_concat":
-        b, n, m, ns, c = a[:5]
-        return "hbm", b * m * ns * 4 + b * n * (3 + c) * 4 + b * m * 12 + b * m * ns * (3 + c) * 4
-    if name == "pn2_three_nn":
-        b, n, m = a[:3]
-        return "hbm", b * n * 12 + b * m * 12 + b * n * 24
-    if name == "pn2_three_interpolate":
-        b, m, c, n = a[:4]
-        return "hbm", b * m * c * 4 + b * n * 24 + b * n * c * 4
-    if name == "pn2_fp_interp_concat":
-        b, n, m, c1, c2 = a[:5]
-        return "hbm", b * m * c2 * 4 + b * n * 24 + b * n * c1 * 4 + b * n * (c1 + c2) * 4
-    if name == "pn2_linear":
-        rows, cin, cout = a[:3]
-        return "mfma", 2 * rows * cin * cout
-    if name == "pn2_mlp_chain":
-        rows, cin, L = a[0], a[1], a[2]
-        widths = a[4:4 + L]
-        fl = 0
-        for w in widths:
-            fl += 2 * rows * cin * w
-            cin = w
-        return "mfma", fl
-    if name == "pn2_mlp_wide":      # ints: rows, cin, x_stride, nlayers, relu_last, pool, widths...
-        rows, cin, L = a[0], a[1], a[3]
-        fl = 0
-        for w in a[6:6 + L]:
-            fl += 2 * rows * cin * w
-            cin = w
-        return "mfma", fl
-    if name == "pn2_sa_mlp_wide":   # ints: b, n, m, nsample, c, nlayers, pool, widths...
-        b, n, m, ns, c, L = a[:6]
-        cin, fl = 3 + c, 0
-        for w in a[7:7 + L]:
-            fl += 2 * b * m * ns * cin * w
-            cin = w
-        return "mfma", fl
-    if name == "pn2_fp_mlp_wide":   # ints: b, n, m, c1, c2, nlayers, widths...
-        b, n, m, c1, c2, L = a[:6]
-        cin, fl = c1 + c2, 0
-        for w in a[6:6 + L]:
-            fl += 2 * b * n * cin * w
-            cin = w
-        return "mfma", fl
-    if name == "pn2_fp_mlp_fused":
-        b, n, m, c1, c2, L = a[:6]
-        widths = a[6:6 + L]
-        cin, fl = c1 + c2, 0
-        for w in widths:
-            fl += 2 * b * n * cin * w
-            cin = w
-        return "mfma", fl
-    if name == "pn2_fp_mlp_wide_pre":  # ints: b, n, m, c1, nlayers, widths...   EXECUTED flops
-        b, n, m, c1, L = a[:5]
-        widths = a[5:5 + L]
-        fl, cin = 2 * b * n * c1 * widths[0], widths[0]
-        for w in widths[1:]:
-            fl += 2 * b * n * cin * w
-            cin = w
-        return "mfma", fl
-    if name == "pn2_sa_mlp_wide_pre":  # ints: b, n, m, nsample, nlayers, pool, widths...
-        b, n, m, ns, L = a[:5]
-        widths = a[6:6 + L]
-        fl, cin = 2 * b * m * ns * 3 * widths[0], widths[0]
-        for w in widths[1:]:
-            fl += 2 * b * m * ns * cin * w
-            cin = w
-        return "mfma", fl
-    if name == "pn2_sa_mlp_fused_pre":  # ints: b, n, m, nsample, nlayers, pool, widths...  EXECUTED flops (xyz rows + later layers)
-        b, n, m, ns, L = a[:5]
-        widths = a[6:6 + L]
-        fl = 2 * b * m * ns * 3 * widths[0]
-        cin = widths[0]
-        for w in widths[1:]:
-            fl += 2 * b * m * ns * cin * w
-            cin = w
-        return "mfma", fl
-    if name == "pn2_fp_mlp_fused_pre":  # ints: b, n, m, c1, nlayers, widths...  EXECUTED flops: skip channels + later layers
-        b, n, m, c1, L = a[:5]
-        widths = a[5:5 + L]
-        fl = 2 * b * n * c1 * widths[0]
-        cin = widths[0]
-        for w in widths[1:]:
-            fl += 2 * b * n * cin * w
-            cin = w
-        return "mfma", fl
-    if name in ("pn2_sa_mlp_max_fused", "pn2_sa_mlp_rows_fused"):
-        b, n, m, ns, c, L = a[:6]
-        widths = a[6:6 + L]
-        cin, fl = 3 + c, 0
-        for w in widths:
-            fl += 2 * b * m * ns * cin * w
-            cin = w
-        return "mfma", fl
-    return "hbm", 0
-
-
-def reference_flops(pn2, hp, B, N):
-    """MFMA flops of one step in the reference's own formulation (every 1x1 conv of every SA / FP module applied to the
-    grouped / concatenated tensor: SURVEY.md 8(d)'s 2*rows*cin*cout).  The product executes fewer: the first layer of a
-    module is applied to the SOURCE rows where linearity allows (DESIGN.md 4 'hoisting')."""
-    mdl = pn2.model
-    npts = [N] + [hp["l%d_npoint" % i] for i in (1, 2, 3, 4)]
-    width = [3 * int(hp["use_color"])] + [w[-1] for w in mdl.SA_MLPS]
-    fl = 0
-    for li in range(4):
-        rows, cin = B * npts[li + 1] * hp["l%d_nsample" % (li + 1)], 3 + width[li]
-        for w in mdl.SA_MLPS[li]:
-            fl, cin = fl + 2 * rows * cin * w, w
-    up = width[4]
-    for fi in range(4):
-        lvl = 3 - fi
-        rows, cin = B * npts[lvl], width[lvl] + up
-        for w in mdl.FP_MLPS[fi]:
-            fl, cin = fl + 2 * rows * cin * w, w
-        up = cin
-    return fl
-
-
-def summarize_trace(trace, steps):
-    """aggregate (name, args) -> avg ms per launch, launches per step, roofline numbers."""
-    agg = {}
-    for name, args, s, e in trace:
-        key = (name, args)
-        d = agg.setdefault(key, [0.0, 0])
-        d[0] += s.elapsed_time(e)
-        d[1] += 1
-    rows = []
-    for (name, args), (tot_ms, cnt) in agg.items():
-        bound, units = kernel_model(name, args)
-        avg_ms = tot_ms / cnt
-        if bound == "hbm":
-            ach = units / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
-            peak, unit = HBM_PEAK_GBS, "GB/s"
-        else:
-            ach = units / (avg_ms * 1e-3) / 1e12 if avg_ms > 0 else 0.0
-            peak, unit = MFMA_F32_PEAK_TF, "TFLOP/s"
-        rows.append({"kernel": name.replace("pn2_", ""), "args": list(args), "bound": bound,
-                     "avg_us": round(avg_ms * 1e3, 2), "launches_per_step": cnt / steps,
-                     "ms_per_step": round(tot_ms / steps, 4), "achieved": round(ach, 3), "peak": peak,
-                     "unit": unit, "frac": round(ach / peak, 5),
-                     "algorithmic_units": int(units)})
-    rows.sort(key=lambda r: -r["ms_per_step"])
-    return rows
-
-
-def time_call(fn, iters, warmup=3):
-    for _ in range(warmup):
-        fn()
-    torch.cuda.synchronize()
-    s = torch.cuda.Event(enable_timing=True)
-    e = torch.cuda.Event(enable_timing=True)
-    s.record()
-    for _ in range(iters):
-        fn()
-    e.record()
-    torch.cuda.synchronize()
-    return s.elapsed_time(e) / iters  # ms
-
-
-def north_star_kernels(pn2, dev):
-    """ball_query+group_point and fused grouped MLP at B=16,N=8192,M=1024,K=32,C=128."""
-    B, N, M, K, C = 16, 8192, 1024, 32, 128
-    pc = s_scene(0, B, N)
-    xyz = torch.from_numpy(pc[:, :, :3].copy()).to(dev)
-    feat = torch.from_numpy(np.random.RandomState(1).randn(B, N, C).astype(np.float32)).to(dev)
-    new_xyz = pn2.gather_point(xyz, pn2.farthest_point_sample(M, xyz))
-    idx, _ = pn2.query_ball_point(0.5, K, xyz, new_xyz)
-    g = pn2.tf_ops.tf_grouping
-    bins = g.ball_query_bin_alloc(xyz)
-    t_bin = time_call(lambda: g.ball_query_bin(0.5, xyz, out=bins), 20)
-    idx_b, _ = g.query_ball_point_binned(0.5, K, xyz, new_xyz, bins)
-    assert torch.equal(idx_b, idx)
-    t_bq_self = time_call(lambda: pn2.query_ball_point(0.5, K, xyz, new_xyz), 20)           # every workgroup bins the cloud itself
-    t_bq = time_call(lambda: g.query_ball_point_binned(0.5, K, xyz, new_xyz, bins), 20)     # variant: cloud binned once
-    t_gp = time_call(lambda: pn2.group_point(feat, idx), 20)
-    bq_bytes = B * N * 12 + B * M * 12 + B * M * K * 4 + B * M * 4
-    gp_bytes = B * M * K * 4 + B * N * C * 4 + B * M * K * C * 4
-    gbs = lambda t: (bq_bytes + gp_bytes) / (t * 1e-3) / 1e9  # noqa: E731
-    ach = gbs(t_bq_self + t_gp)                                # the default product path: pn2_query_ball_point + pn2_group_point
-    out = {"ball_query_group_point": {
-        "shape": "B16 N8192 M1024 K32 C128", "ball_query_us": round(t_bq_self * 1e3, 1),
-        "group_point_us": round(t_gp * 1e3, 1), "bytes": bq_bytes + gp_bytes, "bound": "hbm",
-        "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4),
-        "group_point_alone_GBs": round(gp_bytes / (t_gp * 1e-3) / 1e9, 1),
-        "binned_once_variant": {
-            "note": "pn2_ball_query_bin once per cloud + pn2_query_ball_point_binned (same indices): what the pipelined "
-                    "(throughput) execution runs since r06 -- the binning rides in the sampler half of a batch (model.sa1_samples); "
-                    "the one-batch graph keeps the self-binning query",
-            "bin_us": round(t_bin * 1e3, 1), "ball_query_us": round(t_bq * 1e3, 1),
-            "frac_query_only": round(gbs(t_bq + t_gp) / HBM_PEAK_GBS, 4),
-            "frac_including_bin": round(gbs(t_bin + t_bq + t_gp) / HBM_PEAK_GBS, 4)}}}
-    # SURVEY 8(d): the achievable copy bandwidth next to the 8 TB/s peak (device-to-device copy of the same 268 MB)
-    grouped = pn2.group_point(feat, idx)
-    dst = torch.empty_like(grouped)
-    t_cp = time_call(lambda: dst.copy_(grouped), 20)
-    cp = 2 * grouped.numel() * 4 / (t_cp * 1e-3) / 1e9
-    out["ball_query_group_point"]["d2d_copy_probe_GBs"] = round(cp, 1)
-    out["ball_query_group_point"]["frac_of_copy_probe"] = round(ach / cp, 4)
-    del grouped, dst
-    # fused grouped MLP: one 128 -> 128 layer (+3 xyz channels of the SA concat) + max over K
-    tfu, pu = pn2.util.tf_util, pn2.util.pointnet_util
-    keep = tfu.get_default_store()
-    tfu.set_default_store(tfu.VariableStore(device=dev, seed=2))
-    try:
-        with tfu.variable_scope("ns"):
-            fn = lambda: pu._sa_fused_inference(xyz, new_xyz, feat, idx, [128], True, "conv%d")  # noqa: E731
-            assert fn() is not None
-            t_mlp = time_call(fn, 10)
-    finally:
-        tfu.set_default_store(keep)
-    flops = 2 * B * M * K * (3 + C) * 128
-    ach = flops / (t_mlp * 1e-3) / 1e12
-    out["fused_grouped_mlp"] = {"shape": "B16 N8192 M1024 K32 Cin131 Cout128 + max", "us": round(t_mlp * 1e3, 1),
-                                "flops": flops, "bound": "mfma", "achieved": round(ach, 2), "peak": MFMA_F32_PEAK_TF,
-                                "unit": "TFLOP/s", "frac": round(ach / MFMA_F32_PEAK_TF, 4)}
-    return out
-
-
-def both_regimes(pn2, sampler_fn, dense_fn, make_batch, units_per_step, steps, regions=3):
-    """a workload that starts with a sampler chain, timed like the headline -- `latency`: ONE batch in flight (one
-    graph: sampler + rest, replay + synchronise per step) and `throughput`: runtime.StaggeredPipeline (two graphs per batch on the
-    batch's one stream, 4 streams, backlogs 0,0,1,1), median of `regions` regions of `steps` steps after one untimed region.
-    sampler_fn(x) -> s, dense_fn(x, s) -> y, make_batch(n) -> input of slot n."""
-    cap = pn2.runtime.CapturedForward(lambda x: dense_fn(x, sampler_fn(x)), make_batch(0))
-    for _ in range(2):
-        cap.replay()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(steps):
-        cap.replay()
-        torch.cuda.synchronize()
-    lat = (time.perf_counter() - t0) / steps * 1e3
-    del cap
-    pipe = pn2.runtime.StaggeredPipeline(sampler_fn, dense_fn, make_batch, (0, 0, 1, 1))
-
-    def region():
-        torch.cuda.synchronize()
-        t1 = time.perf_counter()
-        for _ in range(steps):
-            pipe.step()
-        pipe.flush()
-        torch.cuda.synchronize()
-        return (time.perf_counter() - t1) / steps * 1e3
-    region()
-    ts = sorted(region() for _ in range(regions))
-    thr = ts[(len(ts) - 1) // 2]
-    res = {"latency": {"batches_in_flight": 1, "ms_per_step": round(lat, 4), "points_per_s": round(units_per_step / (lat * 1e-3), 1)},
-           "throughput": {"batches_in_flight": pipe.batches_in_flight, "streams": pipe.P,
-                          "streams_verified_concurrent": pipe.streams_verified_concurrent, "ms_per_step": round(thr, 4),
-                          "ms_per_step_regions": [round(v, 4) for v in ts], "points_per_s": round(units_per_step / (thr * 1e-3), 1)}}
-    del pipe
-    return res
-
-
-def other_configs(pn2, dev, hp, steps):
-    """configs[2], configs[4] and configs[3]@1GPU timed in the same run (graph replay where the path is captured)."""
-    out = {}
-    tfu, pu = pn2.util.tf_util, pn2.util.pointnet_util
-    keep = tfu.get_default_store()
-    try:
-        # configs[2]: MSG set abstraction, 3 scales (radii / K / MLPs are builder-chosen: the reference ships none)
-        B, N, M = 16, 8192, 1024
-        radii, ks, mlps = [0.25, 0.5, 1.0], [16, 32, 64], [[32, 32, 64], [64, 64, 128], [64, 96, 128]]
-        pc = torch.from_numpy(s_scene(5000, B, N)).to(dev)
-        xyz, pts = pc[:, :, :3].contiguous(), pc[:, :, 3:].contiguous()
-        tfu.set_default_store(tfu.VariableStore(device=dev, seed=1))
-        cap = pn2.runtime.CapturedForward(
-            lambda x: pu.pointnet_sa_module_msg(x, pts, M, radii, ks, mlps, False, None, scope="msg")[1], xyz)
-        t = time_call(cap.replay, steps)
-        out["configs[2]"] = {"workload": "MSG SA module, 3 scales r=(0.25,0.5,1.0) K=(16,32,64) "
-                                         "MLPs ([32,32,64],[64,64,128],[64,96,128]) (builder-chosen), B=16, N=8192, npoint=1024, fp32",
-                             "ms_per_step": round(t, 4), "points_per_s": round(B * N / (t * 1e-3), 1), "steps": steps,
-                             "launch": "one hipGraph replay per step, one batch in flight"}
-        del cap
-        # both regimes (sampler | the rest of the module on the sampled centres), as the headline config gets them
-        fps_gather = pn2.tf_ops.tf_sampling.farthest_point_sample_and_gather
-        out["configs[2]"]["regimes"] = both_regimes(
-            pn2, lambda x: fps_gather(M, x)[1],
-            lambda x, nx: pu.pointnet_sa_module_msg(x, pts, M, radii, ks, mlps, False, None, scope="msg", new_xyz=nx)[1],
-            lambda n: (xyz if n == 0 else torch.from_numpy(s_scene(5100 + n, B, N)[:, :, :3].copy()).to(dev)), B * N, steps)
-        # configs[4]: large scenes, N=65536 -> npoint 4096, K=64, C=128 bf16 features, fused bf16 grouped MLP; B=1 (eager and
-        # as a hipGraph replay) and B=16 (SURVEY 8d: "B=1 (and 16 if memory allows)")
-        N4, M4, K4, C4 = 65536, 4096, 64, 128
-        tfu.set_default_store(tfu.VariableStore(device=dev, seed=2))
-        res4 = {}
-        for B4 in (1, 16):
-            xyz4 = torch.from_numpy(s_scene(5001, B4, N4)[:, :, :3].copy()).to(dev)
-            pts4 = torch.randn(B4, N4, C4, device=dev).to(torch.bfloat16)
-
-            def sa4(x):
-                _, nx = pn2.tf_ops.tf_sampling.farthest_point_sample_and_gather(M4, x)
-                idx, _ = pn2.query_ball_point(0.5, K4, x, nx)
-                with tfu.variable_scope("sa"):
-                    return pu.sa_features_inference(x, nx, pts4, idx, [128, 128])
-            with torch.no_grad():
-                sa4(xyz4)
-                n4 = max(2, min(steps, 5))
-                t_eager = time_call(lambda: sa4(xyz4), n4, warmup=1)
-                t_fps = time_call(lambda: pn2.tf_ops.tf_sampling.farthest_point_sample_and_gather(M4, xyz4), n4, warmup=1)
-            cap4 = pn2.runtime.CapturedForward(sa4, xyz4)
-            t_graph = time_call(cap4.replay, n4, warmup=1)
-            reg4 = None
-            if B4 == 16:  # both regimes on the B = 16 form (sampler | ball query + fused bf16 MLP)
-
-                def dense4(x, nx):
-                    idx, _ = pn2.query_ball_point(0.5, K4, x, nx)
-                    with tfu.variable_scope("sa"):
-                        return pu.sa_features_inference(x, nx, pts4, idx, [128, 128])
-                with torch.no_grad():
-                    reg4 = both_regimes(pn2, lambda x: pn2.tf_ops.tf_sampling.farthest_point_sample_and_gather(M4, x)[1], dense4,
-                                        lambda n: (xyz4 if n == 0 else
-                                                   torch.from_numpy(s_scene(5200 + n, B4, N4)[:, :, :3].copy()).to(dev)),
-                                        B4 * N4, n4)
-            res4[B4] = (t_eager, t_graph, t_fps, n4, reg4)
-            del cap4, xyz4, pts4
-        t_eager, t_graph, t_fps, n4, _ = res4[1]
-        out["configs[4]"] = {"workload": "large-scene SA layer: B=1, N=65536, npoint=4096, K=64, C=128 bf16 features, "
-                                         "FPS (lazy multi-pick over Hilbert-sorted buckets) + ball query + fused bf16 grouped MLP [128,128] + max",
-                             "ms_per_step": round(t_graph, 4), "points_per_s": round(N4 / (t_graph * 1e-3), 1), "steps": n4,
-                             "fps_ms": round(t_fps, 4), "launch": "one hipGraph replay per step", "eager_ms_per_step": round(t_eager, 4),
-                             "B16": {"ms_per_step": round(res4[16][1], 4), "points_per_s": round(16 * N4 / (res4[16][1] * 1e-3), 1),
-                                     "fps_ms": round(res4[16][2], 4), "eager_ms_per_step": round(res4[16][0], 4),
-                                     "launch": "one hipGraph replay per step, 16 scenes per step", "regimes": res4[16][4]}}
-    except Exception as ex:  # keep the headline line alive
-        out["error"] = repr(ex)
-    finally:
-        tfu.set_default_store(keep)
-    try:
-        # configs[3] on this one GPU: a full training step (forward with batch-stat BN, weighted CE, backward, Adam)
-        B, N = hp["batch_size"], hp["num_point"]
-        rs = np.random.RandomState(100)
-        pc = torch.from_numpy(np.concatenate([s_scene(3000, B, N)[:, :, :3], rs.random_sample((B, N, 3)).astype(np.float32)], 2)).to(dev)
-        labels = torch.from_numpy(rs.randint(0, 9, (B, N)).astype(np.int64)).to(dev)
-        smpw = torch.from_numpy((rs.random_sample((B, N)) + 0.5).astype(np.float32)).to(dev)
-        tr = pn2.train.Trainer(hp, 9, store=tfu.VariableStore(device=dev, seed=0), device=dev)
-        pcs = [pc, pc.clone()]  # two resident batches, alternated (the trainer prefetches the next batch's geometry)
-        w3 = tr.warmup_eager + 2
-        for i in range(w3):  # eager steps, then the capture, then one replay: all outside the timing
-            tr.train_step(pcs[i % 2], labels, smpw, next_pc=pcs[(i + 1) % 2], next_labels=labels, next_smpw=smpw)
-        torch.cuda.synchronize()
-        n3 = max(2, min(steps, 10))
-        t0 = time.perf_counter()
-        for i in range(w3, w3 + n3):
-            loss = tr.train_step(pcs[i % 2], labels, smpw, next_pc=pcs[(i + 1) % 2], next_labels=labels, next_smpw=smpw, sync=False)
-        torch.cuda.synchronize()
-        t = (time.perf_counter() - t0) / n3 * 1e3
-        out["configs[3]@1gpu"] = {"workload": "training step (forward with batch-stat BN + weighted CE + backward + Adam), "
-                                              "%d scenes x %d points, fp32; the multi-GPU line is `bench.py --train --gpus N`" % (B, N),
-                                  "ms_per_step": round(t, 4), "points_per_s": round(B * N / (t * 1e-3), 1), "steps": n3,
-                                  "last_loss": float(loss)}
-    except Exception as ex:
-        out["configs[3]@1gpu"] = {"error": repr(ex)}
-    finally:
-        tfu.set_default_store(keep)
-    return out
+from benchlib.accounting import (FPS_KERNELS, HBM_PEAK_GBS, LATENCY_KERNELS, MFMA_F32_PEAK_TF, PMC_FILE, kernel_model, pmc_traffic,  # noqa: E402,F401
+                                 reference_flops, summarize_trace, time_call)
+from benchlib.configs import both_regimes, north_star_kernels, other_configs  # noqa: E402,F401
+from benchlib.inputs import s_dup25, s_randn, s_scene  # noqa: E402,F401
+from benchlib.launch import dry_run, launch_ranks, rccl_info  # noqa: E402,F401
+from benchlib.training import bench_train, train_comm_diagnosis  # noqa: E402,F401
 
 
 def cpu_baseline(pn2, store, pc, hp):
@@ -546,179 +119,6 @@ def cpu_baseline(pn2, store, pc, hp):
             "sample": "%d forward passes of the same SA+FP stack over the full batch (%d scenes x %d points): "
                       "OpenMP C oracle for FPS/ball query/group/three_nn/interpolate + numpy(BLAS) fp32 dense layers"
                       % (passes, pc.shape[0], pc.shape[1])}
-
-
-def bench_train(pn2, args, hp, B, N, rank, world, dev):
-    """configs[3]: every rank trains on its own 16 scenes; the only collective is the flat gradient all-reduce."""
-    rs = np.random.RandomState(100 + rank)
-    pc = torch.from_numpy(np.concatenate([s_scene(3000 + rank, B, N), rs.random_sample((B, N, 3)).astype(np.float32)], 2)).to(dev)
-    labels = torch.from_numpy(rs.randint(0, 9, (B, N)).astype(np.int64)).to(dev)
-    smpw = torch.from_numpy((rs.random_sample((B, N)) + 0.5).astype(np.float32)).to(dev)
-    tr = pn2.train.Trainer(hp, 9, store=pn2.util.tf_util.VariableStore(device=dev, seed=0), device=dev)
-    pcs = [pc, pc.clone()]  # two resident batches, alternated: the trainer prefetches the geometry of the next one
-    for i in range(max(tr.warmup_eager + 2, args.warmup)):  # includes the one-time hipGraph capture of the step (1 GPU)
-        tr.train_step(pcs[i % 2], labels, smpw, next_pc=pcs[(i + 1) % 2], next_labels=labels, next_smpw=smpw)
-    pn2.dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    i0 = max(tr.warmup_eager + 2, args.warmup)
-    for i in range(i0, i0 + args.steps):  # no host synchronisation inside the timed region: the loss stays on the device
-        loss = tr.train_step(pcs[i % 2], labels, smpw, next_pc=pcs[(i + 1) % 2], next_labels=labels, next_smpw=smpw, sync=False)
-    torch.cuda.synchronize()
-    local = time.perf_counter() - t0  # this rank's own clock, before the closing barrier
-    pn2.dist.barrier()
-    elapsed = pn2.dist.max_over_ranks(time.perf_counter() - t0, device=dev)
-    per_rank = pn2.dist.gather_over_ranks(local / args.steps * 1e3, device=dev)
-    # ---- diagnosis legs, AFTER the measured region (they perturb the replicas): where a step's time goes when N > 1
-    diag = train_comm_diagnosis(pn2, tr, args, pcs, labels, smpw, dev, world, elapsed / args.steps * 1e3)
-    # what the concurrent geometry chain of the NEXT batch costs the step: the captured step replayed back to back on the inputs
-    # resident in its static buffers, nothing on the side stream (single rank; after the measured region: the weights move on)
-    if world == 1 and tr._graph is not None and tr._graph_adam is None:
-        with torch.cuda.stream(tr._stream):
-            torch.cuda.synchronize()
-            t1 = time.perf_counter()
-            for _ in range(args.steps):
-                tr._graph.replay()
-            torch.cuda.synchronize()
-        diag["graph_replay_alone_ms"] = round((time.perf_counter() - t1) / args.steps * 1e3, 4)
-    if rank == 0:
-        print(json.dumps({
-            "metric": "training points/sec through SA+FP stack + head (B=16/GPU, N=%d)" % N,
-            "value": round(world * B * N * args.steps / elapsed, 1), "unit": "points/s", "n_gpus": world,
-            "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 4),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "configs[3]: data-parallel training, %d scenes x %d points per GPU, semantic.json, "
-                                   "batch-stat BN, weighted CE, Adam, two-bucket gradient all-reduce (%d parameters), next batch's FPS/ball-query/three_nn "
-                                   "chain prefetched on a side stream"
-                                   % (B, N, tr.store.num_parameters()),
-                       "global_batch": world * B, "parallelism": "dp%d" % world},
-            "per_rank_ms_per_step": [round(v, 4) for v in per_rank], **diag,
-            # (the training step has no stream pipeline to verify: one trainer stream + one geometry-prefetch stream per rank)
-            "streams_verified_concurrent": [None] * world,
-            "last_loss": float(loss), **rccl_info(world)}))
-
-
-def train_comm_diagnosis(pn2, tr, args, pcs, labels, smpw, dev, world, ms_per_step):
-    """the keys that let a sub-linear N > 1 result be read from the record.
-      allreduce_early_ms / allreduce_late_ms   each bucket's all-reduce alone (nothing to hide behind): the wire
-      exposed_comm_ms                          in a real step: end of the SA backward graph -> both buckets reduced (HIP
-                                               events on the trainer's stream); what the step waits for the collectives
-      ms_per_step_no_comm, scaling_efficiency  the SAME job stepping with its collectives skipped (max over ranks), and
-                                               that over the measured step: 1.0 = the collectives cost nothing"""
-    k = max(4, min(args.steps, 10))
-    out = {"allreduce_early_ms": 0.0, "allreduce_late_ms": 0.0, "exposed_comm_ms": 0.0,
-           "ms_per_step_no_comm": round(ms_per_step, 4), "scaling_efficiency": 1.0}
-    if world == 1:
-        return out
-    i0 = tr.step_count
-    tr.comm_events = []
-    for i in range(i0, i0 + k):
-        tr.train_step(pcs[i % 2], labels, smpw, next_pc=pcs[(i + 1) % 2], next_labels=labels, next_smpw=smpw, sync=False)
-    torch.cuda.synchronize()
-    ev, tr.comm_events = tr.comm_events, None
-    if ev:
-        out["exposed_comm_ms"] = round(sum(e1.elapsed_time(e2) for _, e1, e2 in ev) / len(ev), 4)
-        out["early_launch_to_reduced_ms"] = round(sum(e0.elapsed_time(e2) for e0, _, e2 in ev) / len(ev), 4)
-    out["exposed_comm_ms"] = round(pn2.dist.max_over_ranks(out["exposed_comm_ms"], device=dev), 4)
-    # every key of this dict is a maximum over ranks (r06: this one was rank 0's own value beside the maximum above)
-    out["early_launch_to_reduced_ms"] = round(pn2.dist.max_over_ranks(out.get("early_launch_to_reduced_ms", 0.0), device=dev), 4)
-    pn2.dist.barrier()
-    tr.bucket.skip_collectives = True
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for i in range(i0 + k, i0 + 2 * k):
-        tr.train_step(pcs[i % 2], labels, smpw, next_pc=pcs[(i + 1) % 2], next_labels=labels, next_smpw=smpw, sync=False)
-    torch.cuda.synchronize()
-    no_comm = pn2.dist.max_over_ranks((time.perf_counter() - t0) / k * 1e3, device=dev)
-    tr.bucket.skip_collectives = False
-    out["ms_per_step_no_comm"] = round(no_comm, 4)
-    out["scaling_efficiency"] = round(no_comm / ms_per_step, 4)
-    tc = tr.bucket.time_collectives(iters=k)
-    out.update({kk: (round(pn2.dist.max_over_ranks(v, device=dev), 4) if kk.endswith("_ms") else v) for kk, v in tc.items()})
-    return out
-
-
-def _free_port():
-    import socket
-    with socket.socket() as so:
-        so.bind(("127.0.0.1", 0))
-        return so.getsockname()[1]
-
-
-def launch_ranks(args):
-    """`bench.py --gpus N` started bare (no RANK in the environment): become the launcher of N ranks on this node."""
-    import subprocess
-    if not args.dry_run:
-        have = torch.cuda.device_count() if torch.cuda.is_available() else 0
-        if have < args.gpus:
-            raise SystemExit("bench.py --gpus %d: this node has %d visible GPU(s); refusing to print a line for fewer "
-                             "ranks than requested" % (args.gpus, have))
-    env = dict(os.environ)
-    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC (RCCL across processes on this driver)
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
-           "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), os.path.abspath(__file__)] + sys.argv[1:]
-    raise SystemExit(subprocess.call(cmd, env=env))
-
-
-def rccl_info(world):
-    """what the collective layer really is: world size of the initialised group, backend, RCCL version."""
-    import torch.distributed as dist
-    info = {"rccl_ranks": dist.get_world_size() if dist.is_initialized() else 1,
-            "backend": dist.get_backend() if dist.is_initialized() else None}
-    try:
-        info["rccl_version"] = ".".join(str(v) for v in torch.cuda.nccl.version())
-    except Exception:
-        info["rccl_version"] = None
-    assert info["rccl_ranks"] == world, info
-    return info
-
-
-def dry_run(args, rank, world):
-    """The N > 1 plumbing without the GPU workload (gloo on CPU): rendezvous, barrier-bracketed timed region,
-    max over ranks, ONE line from rank 0."""
-    import torch.distributed as dist
-    import pn2_amd as pn2
-    pn2.dist.init_from_env(backend="gloo")
-    pn2.dist.barrier()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        time.sleep(0.001 * (1 + rank))  # rank-dependent "work": the slowest rank must define the step
-    local = time.perf_counter() - t0
-    pn2.dist.barrier()
-    elapsed = pn2.dist.max_over_ranks(time.perf_counter() - t0)
-    per_rank = pn2.dist.gather_over_ranks(local / args.steps * 1e3)
-    line = {"metric": "dry run (no GPU work): launcher / rendezvous / max-over-ranks only", "value": None,
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": round(elapsed / args.steps * 1e3, 4), "dry_run": True,
-            "per_rank_ms_per_step": [round(v, 4) for v in per_rank],
-            "per_rank_points_per_s": [round(args.batch * args.points / (v * 1e-3), 1) for v in per_rank]}
-    if args.train:
-        # the diagnosis keys of `--train --gpus N` on the same two-bucket exchange (gloo, CPU tensors of the real sizes:
-        # 967945 gradients, the head + FP layers in the early bucket)
-        params = [torch.nn.Parameter(torch.zeros(n_)) for n_ in (300000, 667945)]
-        bucket = pn2.dist.OverlappedGradAllReduce(params, 1)
-        tc = bucket.time_collectives(iters=3)
-        t1 = time.perf_counter()
-        work = bucket.reduce_early_async()
-        time.sleep(0.002)  # "the SA backward graph"
-        t2 = time.perf_counter()
-        bucket.reduce_late_and_wait(work)
-        exposed = (time.perf_counter() - t2) * 1e3
-        bucket.skip_collectives = True
-        assert bucket.reduce_early_async() is None and bucket.world() == 1
-        bucket.skip_collectives = False
-        no_comm = line["ms_per_step"]
-        line.update({k: (round(pn2.dist.max_over_ranks(v), 4) if k.endswith("_ms") else v) for k, v in tc.items()})
-        line.update({"exposed_comm_ms": round(pn2.dist.max_over_ranks(exposed), 4),
-                     "early_launch_to_reduced_ms": round((time.perf_counter() - t1) * 1e3, 4),
-                     "ms_per_step_no_comm": no_comm,
-                     "scaling_efficiency": round(no_comm / (no_comm + pn2.dist.max_over_ranks(exposed)), 4)})
-    if rank == 0:
-        line.update(rccl_info(world))
-        print(json.dumps(line))
-    pn2.dist.barrier()
-    if dist.is_initialized():
-        dist.destroy_process_group()
 
 
 def main():
