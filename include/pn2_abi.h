@@ -717,6 +717,21 @@ int pn2_sa_hoist_rows(int b, int n, int m, int nsample, int cout, const float *x
                       const float *z, const float *w_xyz, float *y, float *gxyz, void *stream);
 int pn2_fp_hoist_rows(int b, int n, int m, int c1, int cout, const float *dist, const int *idx, const float *points1,
                       const float *z, const float *w1, float *y, void *stream);
+/* The same two with the batch statistics of y (tf_util.py:186-204: conv2d -> batch_norm_template) taken on the way out: every
+ * workgroup adds its column sums of y and y^2 (fp64) to one of the slot copies of the ZEROED batch-norm workspace
+ * (pn2_bn_workspace_bytes(cout)), so no statistics pass reads y again; finish = 0: the copies are left there
+ * (pn2_bn_relu_forward_stats / _deferred with stats_done = 1 fold them), 1: the last workgroup folds them, 2: it also publishes what
+ * pn2_bn_relu_forward_deferred publishes (save_mean / save_invstd, the moving averages, scale / shift) -- the arguments of
+ * pn2_linear_bn_stats_fin.  r06: the hoisted first layers of SA2-SA4 / FP4 in training are one launch less each. */
+int pn2_sa_hoist_rows_bn(int b, int n, int m, int nsample, int cout, const float *xyz, const float *new_xyz, const int *idx,
+                         const float *z, const float *w_xyz, float *y, float *gxyz, void *bn_workspace, size_t workspace_bytes,
+                         int finish, const float *gamma, const float *beta, const float *bias, float eps, float decay,
+                         float *running_mean, float *running_var, float *save_mean, float *save_invstd, float *scale,
+                         float *shift, void *stream);
+int pn2_fp_hoist_rows_bn(int b, int n, int m, int c1, int cout, const float *dist, const int *idx, const float *points1,
+                         const float *z, const float *w1, float *y, void *bn_workspace, size_t workspace_bytes, int finish,
+                         const float *gamma, const float *beta, const float *bias, float eps, float decay, float *running_mean,
+                         float *running_var, float *save_mean, float *save_invstd, float *scale, float *shift, void *stream);
 
 #ifdef __cplusplus
 }

@@ -96,6 +96,10 @@ SIGNATURES = {
     "pn2_sa_hoist_rows": [c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                           c_void_p],
     "pn2_fp_hoist_rows": [c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p],
+    "pn2_sa_hoist_rows_bn": [c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                             c_void_p, ctypes.c_size_t, c_int, c_void_p, c_void_p, c_void_p, c_float, c_float, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p],
+    "pn2_fp_hoist_rows_bn": [c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                             c_void_p, ctypes.c_size_t, c_int, c_void_p, c_void_p, c_void_p, c_float, c_float, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p],
     "pn2_linear_dgrad_bn_grad_stats": [c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                        c_void_p, c_int, c_void_p, ctypes.c_size_t, c_void_p],
     "pn2_bn_relu_backward_stats": [ctypes.c_longlong, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int,
@@ -221,7 +225,7 @@ _raw = _load()
 _STATEFUL = frozenset({"pn2_bn_relu_forward", "pn2_bn_relu_forward_ws0", "pn2_bn_relu_forward_stats", "pn2_linear_bn_stats",
                        "pn2_bn_relu_forward_pool", "pn2_bn_relu_forward_deferred", "pn2_linear_bn_stats_xf", "pn2_linear_wgrad_gx",
                        "pn2_linear_wgrad_accumulate_xf", "pn2_bn_grad_constants", "pn2_linear_dgrad_gx", "pn2_linear_dgrad_fin",
-                       "pn2_linear_bn_stats_fin", "pn2_bn_relu_forward_mode", "pn2_sa_first_layer_bn", "pn2_linear_bwd_fused", "pn2_linear_dgrad_bn_grad_stats",
+                       "pn2_linear_bn_stats_fin", "pn2_bn_relu_forward_mode", "pn2_sa_first_layer_bn", "pn2_sa_hoist_rows_bn", "pn2_fp_hoist_rows_bn", "pn2_linear_bwd_fused", "pn2_linear_dgrad_bn_grad_stats",
                        "pn2_adam_step", "pn2_linear_wgrad_accumulate"})
 
 

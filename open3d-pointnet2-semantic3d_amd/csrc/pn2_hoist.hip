@@ -18,6 +18,9 @@ namespace {
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 constexpr int kHoistMaxCa = 8;
+#ifndef PN2_HOIST_STAT_WGS
+#define PN2_HOIST_STAT_WGS 512
+#endif
 
 struct HoistParams {
     int rows;      // output rows per batch element (SA: m * nsample, FP: n)
@@ -36,9 +39,15 @@ struct HoistParams {
     float* y;              // (b, rows, cout)
     float* gxyz;           // SA (b, rows, 3) centred coordinates (operand of the weight gradient), may be null
     int accumulate;        // FP with ca == 0: y already holds points1 @ W[c2:] (a GEMM of the caller), the blended rows are added
+    // STATS (pn2_*_hoist_rows_bn): the column sums of y and y^2 the batch norm behind this layer needs, taken on the way out
+    // (fp64 from the first term on, as bn_stats_kernel forms them) into slot copies of the ZEROED workspace; the workgroup that
+    // draws the last ticket folds them and derives the deferred batch norm's constants (pn2_common.h pn2_bn_finish)
+    double* stats_ws;
+    int nslots;
+    Pn2BnFinish fin;
 };
 
-template <bool SA, int CA>
+template <bool SA, int CA, bool STATS = false>
 __global__ void __launch_bounds__(256)
 hoist_rows_kernel(HoistParams p) {
     int bx = blockIdx.x, bi = blockIdx.y;
@@ -54,14 +63,18 @@ hoist_rows_kernel(HoistParams p) {
     const int cv = p.cout >> 2;                 // float4 columns
     const int rp = 256 / cv;                    // rows per pass of the block (cv <= 256)
     const int rr = (int)threadIdx.x / cv, cc = (int)threadIdx.x - rr * cv;
-    if (rr >= rp) return;
+    const bool active = rr < rp;
+    if (!STATS && !active) return;
+    double part[2][4];
+#pragma unroll
+    for (int v = 0; v < 4; ++v) part[0][v] = part[1][v] = 0.0;
     const f32x4* __restrict__ z = reinterpret_cast<const f32x4*>(p.z + (size_t)bi * p.nsrc * p.cout);
     f32x4* __restrict__ y = reinterpret_cast<f32x4*>(p.y + (size_t)bi * p.rows * p.cout);
     f32x4 wa[CA > 0 ? CA : 1];
 #pragma unroll
     for (int a = 0; a < CA; ++a) wa[a] = *reinterpret_cast<const f32x4*>(p.wa + (size_t)a * p.cout + cc * 4);
     constexpr int U = 4;  // rows in flight per thread
-    for (int r0 = bx * rp * U + rr; r0 < p.rows; r0 += gridDim.x * rp * U) {
+    for (int r0 = bx * rp * U + rr; active && r0 < p.rows; r0 += gridDim.x * rp * U) {
         f32x4 acc[U];
         float av[U][CA > 0 ? CA : 1];
         int rows_[U];
@@ -131,8 +144,49 @@ hoist_rows_kernel(HoistParams p) {
                 v[2] = __builtin_fmaf(av[u][a], wa[a][2], v[2]);
                 v[3] = __builtin_fmaf(av[u][a], wa[a][3], v[3]);
             }
-            if (rows_[u] < p.rows) y[(size_t)rows_[u] * cv + cc] = v;
+            if (rows_[u] < p.rows) {
+                y[(size_t)rows_[u] * cv + cc] = v;
+                if constexpr (STATS) {
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const double d = (double)v[q];
+                        part[0][q] += d;
+                        part[1][q] = __builtin_fma(d, d, part[1][q]);
+                    }
+                }
+            }
         }
+    }
+    if constexpr (STATS) {
+        // the rp row slots of the workgroup meet in LDS (tree; rp need not be a power of two), one atomic pair per column
+        __shared__ double red[256 * 2 * 4];
+        if (active) {
+#pragma unroll
+            for (int s_ = 0; s_ < 2; ++s_)
+#pragma unroll
+                for (int v = 0; v < 4; ++v) red[((s_ * 4 + v) * rp + rr) * cv + cc] = part[s_][v];
+        }
+        __syncthreads();
+        for (int sz = rp; sz > 1;) {
+            const int h = (sz + 1) >> 1;
+            if (active && rr + h < sz) {
+#pragma unroll
+                for (int s_ = 0; s_ < 2; ++s_)
+#pragma unroll
+                    for (int v = 0; v < 4; ++v) red[((s_ * 4 + v) * rp + rr) * cv + cc] += red[((s_ * 4 + v) * rp + rr + h) * cv + cc];
+            }
+            __syncthreads();
+            sz = h;
+        }
+        const unsigned lin = blockIdx.x + gridDim.x * blockIdx.y, nwg = gridDim.x * gridDim.y;
+        double* __restrict__ slot = p.stats_ws + kPn2BnHead + (size_t)2 * p.cout * (1 + lin % (unsigned)p.nslots);
+        if (active && rr == 0) {
+#pragma unroll
+            for (int s_ = 0; s_ < 2; ++s_)
+#pragma unroll
+                for (int v = 0; v < 4; ++v) atomicAdd(&slot[(size_t)s_ * p.cout + cc * 4 + v], red[((s_ * 4 + v) * rp) * cv + cc]);
+        }
+        pn2_bn_finish(p.fin, nwg, lin);
     }
 }
 
@@ -140,11 +194,15 @@ template <bool SA, int CA>
 int launch_hoist(int b, const HoistParams& p, hipStream_t st) {
     const int cv = p.cout / 4, rp = 256 / cv;
     long long blocks = ((long long)p.rows + rp * 4 - 1) / (rp * 4);
-    const long long cap = 2048 / (b < 1 ? 1 : b) < 8 ? 8 : 2048 / b;   // ~8 workgroups per CU over the batch
+    // ~8 workgroups per CU over the batch; with the statistics epilogue every workgroup ends in 2 * cout fp64 atomics and a ticket:
+    // PN2_HOIST_STAT_WGS of them (tools/hoist_stats_ab.py)
+    const int total = p.stats_ws ? PN2_HOIST_STAT_WGS : 2048;
+    const long long cap = total / (b < 1 ? 1 : b) < 8 ? 8 : total / b;
     if (blocks > cap) blocks = cap;
     if (blocks < 1) blocks = 1;
     if ((blocks * b) % 8 != 0 && blocks > 8) blocks -= blocks % 8;     // keeps the XCD remap active
-    hoist_rows_kernel<SA, CA><<<dim3((unsigned)blocks, b), 256, 0, st>>>(p);
+    if (p.stats_ws) hoist_rows_kernel<SA, CA, true><<<dim3((unsigned)blocks, b), 256, 0, st>>>(p);
+    else hoist_rows_kernel<SA, CA><<<dim3((unsigned)blocks, b), 256, 0, st>>>(p);
     PN2_RETURN_IF_LAUNCH_FAILED();
     return PN2_OK;
 }
@@ -154,8 +212,30 @@ int launch_hoist(int b, const HoistParams& p, hipStream_t st) {
 // SA: y (b, m, nsample, cout) = (group_point(xyz, idx) - new_xyz) @ w_xyz (3, cout) + z[b, idx] with z (b, n, cout) =
 // points @ W[3:] computed by the caller (pn2_linear); gxyz (b, m, nsample, 3) (optional) receives the centred coordinates
 // (x operand of w_xyz's gradient).  cout % 4 == 0, cout <= 1024.
-extern "C" int pn2_sa_hoist_rows(int b, int n, int m, int nsample, int cout, const float* xyz, const float* new_xyz,
-                                 const int* idx, const float* z, const float* w_xyz, float* y, float* gxyz, void* stream) {
+// the statistics arguments of the *_bn entry points -> (stats_ws, nslots, fin) of HoistParams; finish: 0 sums only (slot copies
+// left in the workspace), 1 folded, 2 folded + the deferred batch norm's constants (as pn2_linear_bn_stats_fin)
+static int hoist_stats_args(HoistParams& p, long long rows_total, int cout, void* bn_workspace, size_t workspace_bytes, int finish,
+                            const float* gamma, const float* beta, const float* bias, float eps, float decay, float* running_mean,
+                            float* running_var, float* save_mean, float* save_invstd, float* scale, float* shift) {
+    if (!bn_workspace) return PN2_ENULL;
+    if (finish < 0 || finish > 2) return PN2_EINVAL;
+    if (workspace_bytes < sizeof(double) * pn2_bn_ws_doubles(cout, kPn2BnSlots) || ((uintptr_t)bn_workspace % 8) != 0) return PN2_EINVAL;
+    p.stats_ws = static_cast<double*>(bn_workspace);
+    p.nslots = kPn2BnSlots;
+    Pn2BnFinish f{};
+    f.kind = finish; f.c = cout; f.nslots = kPn2BnSlots; f.rows = rows_total; f.ws = p.stats_ws;
+    if (finish == 2) {
+        if (!gamma || !beta || !save_mean || !save_invstd || (scale == nullptr) != (shift == nullptr)) return PN2_ENULL;
+        if ((running_mean == nullptr) != (running_var == nullptr)) return PN2_ENULL;
+        f.gamma = gamma; f.beta = beta; f.bias = bias; f.eps = eps; f.decay = decay; f.running_mean = running_mean;
+        f.running_var = running_var; f.save_mean = save_mean; f.save_invstd = save_invstd; f.scale = scale; f.shift = shift;
+    }
+    p.fin = f;
+    return PN2_OK;
+}
+
+static int sa_hoist_impl(int b, int n, int m, int nsample, int cout, const float* xyz, const float* new_xyz, const int* idx,
+                         const float* z, const float* w_xyz, float* y, float* gxyz, void* stream, const HoistParams* st_args) {
     if (b <= 0 || n <= 0 || m <= 0 || nsample <= 0 || cout <= 0) return PN2_EINVAL;
     if (!xyz || !new_xyz || !idx || !z || !w_xyz || !y) return PN2_ENULL;
     if (cout % 4 != 0 || cout > 1024) return PN2_EUNSUP;
@@ -164,7 +244,29 @@ extern "C" int pn2_sa_hoist_rows(int b, int n, int m, int nsample, int cout, con
     HoistParams p = {};
     p.rows = m * nsample; p.nsrc = n; p.cout = cout; p.ca = 3; p.nsample = nsample; p.m = m;
     p.idx = idx; p.z = z; p.xyz = xyz; p.new_xyz = new_xyz; p.wa = w_xyz; p.y = y; p.gxyz = gxyz;
+    if (st_args) { p.stats_ws = st_args->stats_ws; p.nslots = st_args->nslots; p.fin = st_args->fin; }
     return launch_hoist<true, 3>(b, p, static_cast<hipStream_t>(stream));
+}
+
+extern "C" int pn2_sa_hoist_rows(int b, int n, int m, int nsample, int cout, const float* xyz, const float* new_xyz,
+                                 const int* idx, const float* z, const float* w_xyz, float* y, float* gxyz, void* stream) {
+    return sa_hoist_impl(b, n, m, nsample, cout, xyz, new_xyz, idx, z, w_xyz, y, gxyz, stream, nullptr);
+}
+
+// pn2_sa_hoist_rows that also leaves the batch statistics of y (tf_util.py:186-204: conv2d -> batch_norm_template) in the ZEROED
+// batch-norm workspace (pn2_bn_workspace_bytes(cout)) -- no statistics pass over y -- and, finish = 1 / 2, folds them / publishes
+// what pn2_bn_relu_forward_deferred publishes, as pn2_linear_bn_stats_fin does for a GEMM.
+extern "C" int pn2_sa_hoist_rows_bn(int b, int n, int m, int nsample, int cout, const float* xyz, const float* new_xyz,
+                                    const int* idx, const float* z, const float* w_xyz, float* y, float* gxyz, void* bn_workspace,
+                                    size_t workspace_bytes, int finish, const float* gamma, const float* beta, const float* bias,
+                                    float eps, float decay, float* running_mean, float* running_var, float* save_mean,
+                                    float* save_invstd, float* scale, float* shift, void* stream) {
+    if (b <= 0 || m <= 0 || nsample <= 0 || cout <= 0) return PN2_EINVAL;
+    HoistParams sp = {};
+    const int rc = hoist_stats_args(sp, (long long)b * m * nsample, cout, bn_workspace, workspace_bytes, finish, gamma, beta, bias, eps,
+                                    decay, running_mean, running_var, save_mean, save_invstd, scale, shift);
+    if (rc != PN2_OK) return rc;
+    return sa_hoist_impl(b, n, m, nsample, cout, xyz, new_xyz, idx, z, w_xyz, y, gxyz, stream, &sp);
 }
 
 // FP: y (b, n, cout) = three_interpolate(z, idx, w(dist)) + points1 (b, n, c1) @ w1 (c1, cout) with z (b, m, cout) =
@@ -172,8 +274,8 @@ extern "C" int pn2_sa_hoist_rows(int b, int n, int m, int nsample, int cout, con
 // pn2_fp_interp_concat.  1 <= c1 <= 8: the product with points1 is formed here (the level-0 module: colours).
 // c1 == 0 with points1 == w1 == NULL: y += three_interpolate(...), y holding the caller's GEMM points1 @ W[c2:] (wider skip
 // links: that product is a real GEMM).
-extern "C" int pn2_fp_hoist_rows(int b, int n, int m, int c1, int cout, const float* dist, const int* idx,
-                                 const float* points1, const float* z, const float* w1, float* y, void* stream) {
+static int fp_hoist_impl(int b, int n, int m, int c1, int cout, const float* dist, const int* idx, const float* points1,
+                         const float* z, const float* w1, float* y, void* stream, const HoistParams* st_args) {
     if (b <= 0 || n <= 0 || m <= 0 || cout <= 0) return PN2_EINVAL;
     if (!dist || !idx || !z || !y) return PN2_ENULL;
     if (c1 > 0 && (!points1 || !w1)) return PN2_ENULL;
@@ -184,6 +286,7 @@ extern "C" int pn2_fp_hoist_rows(int b, int n, int m, int c1, int cout, const fl
     p.rows = n; p.nsrc = m; p.cout = cout; p.ca = c1;
     p.idx = idx; p.dist = dist; p.z = z; p.points1 = points1; p.wa = w1; p.y = y;
     p.accumulate = c1 == 0;
+    if (st_args) { p.stats_ws = st_args->stats_ws; p.nslots = st_args->nslots; p.fin = st_args->fin; }
     hipStream_t st = static_cast<hipStream_t>(stream);
     switch (c1) {
         case 0: return launch_hoist<false, 0>(b, p, st);
@@ -196,4 +299,23 @@ extern "C" int pn2_fp_hoist_rows(int b, int n, int m, int c1, int cout, const fl
         case 7: return launch_hoist<false, 7>(b, p, st);
         default: return launch_hoist<false, 8>(b, p, st);
     }
+}
+
+extern "C" int pn2_fp_hoist_rows(int b, int n, int m, int c1, int cout, const float* dist, const int* idx,
+                                 const float* points1, const float* z, const float* w1, float* y, void* stream) {
+    return fp_hoist_impl(b, n, m, c1, cout, dist, idx, points1, z, w1, y, stream, nullptr);
+}
+
+// pn2_fp_hoist_rows with the statistics epilogue of pn2_sa_hoist_rows_bn.
+extern "C" int pn2_fp_hoist_rows_bn(int b, int n, int m, int c1, int cout, const float* dist, const int* idx,
+                                    const float* points1, const float* z, const float* w1, float* y, void* bn_workspace,
+                                    size_t workspace_bytes, int finish, const float* gamma, const float* beta, const float* bias,
+                                    float eps, float decay, float* running_mean, float* running_var, float* save_mean,
+                                    float* save_invstd, float* scale, float* shift, void* stream) {
+    if (b <= 0 || n <= 0 || cout <= 0) return PN2_EINVAL;
+    HoistParams sp = {};
+    const int rc = hoist_stats_args(sp, (long long)b * n, cout, bn_workspace, workspace_bytes, finish, gamma, beta, bias, eps, decay,
+                                    running_mean, running_var, save_mean, save_invstd, scale, shift);
+    if (rc != PN2_OK) return rc;
+    return fp_hoist_impl(b, n, m, c1, cout, dist, idx, points1, z, w1, y, stream, &sp);
 }

@@ -1276,6 +1276,8 @@ def conv2d_sa_first_small(xyz, new_xyz, points, idx, num_output_channels, scope,
     return z.reshape(xyz.shape[0], m, ns // pool if pool else ns, cout)
 
 
+HOIST_BN_STATS_MIN_ROWS = 32768
+USE_HOIST_BN_STATS = True  # ... and its batch statistics (+ fold + constants) taken by the launch that writes it (A/B, tests)
 USE_HOISTED_TRAIN = True  # first layer of SA2-SA4 / FP4 with its feature half applied to the source rows (A/B, tests)
 # (FP1-FP3, whose skip link is a wide SA feature tensor that needs a GEMM of its own, keep the concatenated form: the hoisted
 # variant was built and measured slower -- 4.13 vs 4.05 ms per step, DESIGN.md section 9 -- and removed in round 4.)
@@ -1317,22 +1319,35 @@ class _TrainHoistedBnRelu(torch.autograd.Function):
             rows_b = n
         z = hip_matmul(src2d, wb)  # (b * nsrc, cout)
         y = torch.empty((bsz * rows_b, cout), dtype=torch.float32, device=src.device)
+        pooled = pool > 1
+        defer = defer and any(ctx.needs_input_grad)  # as _TrainDenseBnRelu
+        # the deferred batch norm's statistics (+ their fold and the constants) ride in the launch that writes y
+        # (from 32768 rows on: below, the epilogue's tail -- 2 * cout fp64 atomics per workgroup, the ticket, the fold of 64 slot copies
+        #  by one workgroup -- costs more than the statistics pass it replaces: 8192 x 256: 19 vs 15 us, tools/hoist_stats_ab.py)
+        fused_stats = bool(defer and not pooled and USE_HOIST_BN_STATS and USE_BN_FINISH_IN_PRODUCER and bsz * rows_b >= HOIST_BN_STATS_MIN_ROWS)
+        bn_args = ()
+        if fused_stats:
+            ws = _bn_zeroed_scratch(cout, src.device)
+            save_mean = torch.empty(cout, dtype=torch.float32, device=src.device)
+            save_invstd, sc, sh = torch.empty_like(save_mean), torch.empty_like(save_mean), torch.empty_like(save_mean)
+            bn_args = (ptr(ws), ws.numel() * ws.element_size(), 2, ptr(gamma), ptr(beta), ptr(b), BN_EPSILON, float(decay),
+                       ptr(running_mean), ptr(running_var), ptr(save_mean), ptr(save_invstd), ptr(sc), ptr(sh))
         with torch.cuda.device(src.device):
             if kind == "sa":
                 a = torch.empty((bsz * rows_b, 3), dtype=torch.float32, device=src.device)
-                check(lib.pn2_sa_hoist_rows(bsz, nsrc, m, ns, cout, ptr(xyz), ptr(new_xyz), ptr(idx), ptr(z), ptr(wa), ptr(y),
-                                            ptr(a), stream_ptr()), "pn2_sa_hoist_rows")
+                fn, nm = (lib.pn2_sa_hoist_rows_bn, "pn2_sa_hoist_rows_bn") if fused_stats else (lib.pn2_sa_hoist_rows, "pn2_sa_hoist_rows")
+                check(fn(bsz, nsrc, m, ns, cout, ptr(xyz), ptr(new_xyz), ptr(idx), ptr(z), ptr(wa), ptr(y), ptr(a), *bn_args,
+                         stream_ptr()), nm)
             else:
                 a = points1.reshape(-1, c1)
                 if c1 > 8:
                     raise ValueError("the hoisted FP front end takes at most 8 skip-link channels")
-                check(lib.pn2_fp_hoist_rows(bsz, n, nsrc, c1, cout, ptr(dist), ptr(idx), ptr(a), ptr(z), ptr(wa), ptr(y),
-                                            stream_ptr()), "pn2_fp_hoist_rows")
-        pooled = pool > 1
+                fn, nm = (lib.pn2_fp_hoist_rows_bn, "pn2_fp_hoist_rows_bn") if fused_stats else (lib.pn2_fp_hoist_rows, "pn2_fp_hoist_rows")
+                check(fn(bsz, n, nsrc, c1, cout, ptr(dist), ptr(idx), ptr(a), ptr(z), ptr(wa), ptr(y), *bn_args, stream_ptr()), nm)
         ctx.relu, ctx.pool, ctx.kind, ctx.dims = bool(relu), int(pool), kind, (bsz, nsrc, rows_b, c)
-        defer = defer and any(ctx.needs_input_grad)  # as _TrainDenseBnRelu
         if defer and not pooled:
-            save_mean, save_invstd, sc, sh = _bn_train_forward_deferred(y, b, gamma, beta, running_mean, running_var, decay)
+            if not fused_stats:
+                save_mean, save_invstd, sc, sh = _bn_train_forward_deferred(y, b, gamma, beta, running_mean, running_var, decay)
             ctx.save_for_backward(src2d, w, y, gamma, beta, save_mean, save_invstd, a, plan)
             ctx.link = _bn_register_producer(y, y, gamma, beta, save_mean, save_invstd, relu, False, sc, sh)
             if ctx.link is None:

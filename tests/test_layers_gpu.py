@@ -547,7 +547,8 @@ def test_training_first_layer_on_the_source_rows_equals_the_grouped_form(pn2, cu
             pn2._lib.lib.trace = None
             tfu.USE_HOISTED_TRAIN = True
         names = [c_[0] for c_ in calls]
-        assert (("pn2_sa_hoist_rows" if kind == "sa" else "pn2_fp_hoist_rows") in names) == hoist
+        hname = "pn2_sa_hoist_rows" if kind == "sa" else "pn2_fp_hoist_rows"   # (+ "_bn": the layer's statistics taken on the way out)
+        assert ((hname in names) or (hname + "_bn" in names)) == hoist
         assert (("pn2_sa_group_concat" if kind == "sa" else "pn2_fp_interp_concat") in names) == (not hoist)
         outs[hoist] = [out.detach(), src.grad] + [p_.grad for _, p_ in sorted(store.params.items()) if p_.grad is not None] + \
                       [v.clone() for _, v in sorted(store.buffers.items())]
@@ -780,6 +781,126 @@ def test_sa_first_layer_in_one_launch_equals_the_separate_ops(pn2, cuda, c, mlp,
     assert names[True].count("pn2_sa_first_layer_bn") == 1 and "pn2_sa_group_concat" not in names[True]
     assert "pn2_sa_first_layer_bn" not in names[False] and "pn2_sa_group_concat" in names[False]
     assert len(outs[True]) == len(outs[False]) and len(outs[True]) >= 7
+    for a, r in zip(outs[True], outs[False]):
+        sc = max(float(r.abs().max()), 1e-3)
+        assert float((a - r).abs().max()) <= 2e-5 * sc, (a.shape, float((a - r).abs().max()), sc)
+
+
+@pytest.mark.parametrize("kind,b,n,m,ns,c1,cout", [
+    ("sa", 16, 1024, 256, 32, 0, 64),     # SA2 of configs[1]: 131072 rows
+    ("sa", 3, 500, 37, 16, 0, 132),       # ragged: rows per cloud not a multiple of the row slots, cout / 4 = 33 columns
+    ("sa", 2, 256, 64, 8, 0, 1024),       # the widest row the kernel takes: one row slot per workgroup
+    ("fp", 16, 8192, 1024, 0, 3, 128),    # FP4 of configs[1]
+    ("fp", 2, 1000, 100, 0, 5, 36),
+])
+def test_hoist_rows_take_the_batch_statistics_on_the_way_out(pn2, cuda, kind, b, n, m, ns, c1, cout):
+    """Round 6: pn2_sa_hoist_rows_bn / pn2_fp_hoist_rows_bn -- the hoisted first layer of an SA / FP module (csrc/pn2_hoist.hip) that
+    also leaves the batch statistics of what it writes, folds them and publishes the deferred batch norm's constants (finish 2) --
+    against the plain entry point (y bit for bit) and float64 moments of that y (tf_util.py:186-204,555-581: batch_norm_template
+    with is_training=True; the moving averages as tf's fused batch norm keeps them).  Three times in a row: the ticket must elect
+    exactly one finishing workgroup each time."""
+    import torch
+    from ctypes import c_float
+    L, P = pn2._lib.lib, pn2._lib.ptr
+    rs = np.random.RandomState(b + n + cout)
+    st = pn2._lib.stream_ptr()
+    if kind == "sa":
+        xyz = T(s_scene(3, b, n), cuda)
+        new_xyz, idx = pn2.util.pointnet_util.sa_geometry(xyz, m, 0.9, ns)
+        z = T(rs.randn(b, n, cout).astype(np.float32), cuda)
+        wa = T(rs.randn(3, cout).astype(np.float32), cuda)
+        rows = b * m * ns
+        plain = lambda y, a: L.pn2_sa_hoist_rows(b, n, m, ns, cout, P(xyz), P(new_xyz), P(idx), P(z), P(wa), P(y), P(a), st)  # noqa: E731
+        fused = lambda y, a, *bn: L.pn2_sa_hoist_rows_bn(b, n, m, ns, cout, P(xyz), P(new_xyz), P(idx), P(z), P(wa), P(y), P(a), *bn, st)  # noqa: E731
+        gx = lambda: torch.empty(rows, 3, device=cuda)  # noqa: E731
+    else:
+        xyz = T(s_scene(4, b, n), cuda)
+        dist, idx = pn2.three_nn(xyz, xyz[:, :m].contiguous())
+        z = T(rs.randn(b, m, cout).astype(np.float32), cuda)
+        p1 = T(rs.rand(b, n, c1).astype(np.float32), cuda)
+        wa = T(rs.randn(c1, cout).astype(np.float32), cuda)
+        rows = b * n
+        plain = lambda y, a: L.pn2_fp_hoist_rows(b, n, m, c1, cout, P(dist), P(idx), P(p1), P(z), P(wa), P(y), st)  # noqa: E731
+        fused = lambda y, a, *bn: L.pn2_fp_hoist_rows_bn(b, n, m, c1, cout, P(dist), P(idx), P(p1), P(z), P(wa), P(y), *bn, st)  # noqa: E731
+        gx = lambda: None  # noqa: E731
+    y0, a0 = torch.empty(rows, cout, device=cuda), gx()
+    assert plain(y0, a0) == 0
+    gamma = T((1.0 + 0.1 * rs.randn(cout)).astype(np.float32), cuda)
+    beta, bias = T((0.1 * rs.randn(cout)).astype(np.float32), cuda), T((0.2 * rs.randn(cout)).astype(np.float32), cuda)
+    yd = y0.double()
+    mean, var = yd.mean(0), yd.var(0, unbiased=False)
+    invstd = 1.0 / torch.sqrt(var + 1e-3)
+    nbytes = L.pn2_bn_workspace_bytes(cout)
+    for it in range(3):
+        ws = torch.zeros(nbytes // 8, dtype=torch.float64, device=cuda)
+        rm, rv = torch.zeros(cout, device=cuda), torch.ones(cout, device=cuda)
+        sm, si, sc, sh = (torch.empty(cout, device=cuda) for _ in range(4))
+        y1, a1 = torch.empty(rows, cout, device=cuda), gx()
+        assert fused(y1, a1, P(ws), nbytes, 2, P(gamma), P(beta), P(bias), c_float(1e-3), c_float(0.5), P(rm), P(rv), P(sm), P(si),
+                     P(sc), P(sh)) == 0
+        assert torch.equal(y1, y0) and (a0 is None or torch.equal(a1, a0)), it
+        assert float((sm.double() - mean).abs().max()) <= 1e-5 * max(1.0, float(mean.abs().max())), it
+        assert float(((si.double() - invstd) / invstd).abs().max()) <= 1e-5, it
+        assert float((sc.double() - gamma.double() * invstd).abs().max()) <= 1e-5 * float((gamma.double() * invstd).abs().max()), it
+        assert float((sh.double() - (beta.double() - mean * gamma.double() * invstd)).abs().max()) <= 1e-4, it
+        var_unb = var * (rows / (rows - 1.0))
+        assert float((rm.double() - 0.5 * (mean + bias.double())).abs().max()) <= 1e-5 * max(1.0, float(mean.abs().max())), it
+        assert float((rv.double() - (0.5 + 0.5 * var_unb)).abs().max()) <= 1e-5 * max(1.0, float(var.max())), it
+    # refused before any launch
+    assert L.pn2_bn_workspace_bytes(cout) > 0
+    assert fused(y1, a1, None, nbytes, 2, P(gamma), P(beta), None, c_float(1e-3), c_float(0.5), None, None, P(sm), P(si), P(sc), P(sh)) == -2
+    assert fused(y1, a1, P(ws), 8, 2, P(gamma), P(beta), None, c_float(1e-3), c_float(0.5), None, None, P(sm), P(si), P(sc), P(sh)) == -1
+    assert fused(y1, a1, P(ws), nbytes, 7, P(gamma), P(beta), None, c_float(1e-3), c_float(0.5), None, None, P(sm), P(si), P(sc), P(sh)) == -1
+
+
+@pytest.mark.parametrize("kind", ["sa", "fp"])
+def test_hoisted_layer_with_fused_statistics_equals_the_two_launches(pn2, cuda, kind):
+    """... and at module level: tf_util.USE_HOIST_BN_STATS on / off -- output, moving averages, every gradient of an SA / FP module in
+    training mode agree to summation order; on = no statistics kernel behind the hoisted layer."""
+    import torch
+    tfu, pu = pn2.util.tf_util, pn2.util.pointnet_util
+    rs = np.random.RandomState(5)
+    b, n, c, mlp = 2, (1024 if kind == "sa" else 4096), 32, [64, 64, 128]   # (> 2048 rows: the layer defers its batch norm)
+    xyz = T(s_scene(9, b, n), cuda)
+    if kind == "sa":
+        m, ns = 128, 32
+        src0 = T(rs.randn(b, n, c).astype(np.float32), cuda)
+        new_xyz, idx = pu.sa_geometry(xyz, m, 0.8, ns)
+        plan = pu.scatter_plan(idx, n)
+        oshape = (b, m, mlp[-1])
+    else:
+        m = 128
+        xyz2 = xyz[:, :m].contiguous()
+        src0 = T(rs.randn(b, m, c).astype(np.float32), cuda)
+        p1_0 = T(rs.rand(b, n, 3).astype(np.float32), cuda)
+        dist, idx = pn2.three_nn(xyz, xyz2)
+        plan = pu.scatter_plan(idx, m, dist, weight_kind=2)
+        oshape = (b, n, mlp[-1])
+    probe = torch.sin(torch.arange(int(np.prod(oshape)), device=cuda).float() * 0.11).reshape(oshape)
+    outs, names = {}, {}
+    for on in (True, False):
+        tfu.USE_HOIST_BN_STATS, min_rows, tfu.HOIST_BN_STATS_MIN_ROWS = on, tfu.HOIST_BN_STATS_MIN_ROWS, 0
+        store = tfu.set_default_store(tfu.VariableStore(device=cuda, seed=9))
+        calls = []
+        pn2._lib.lib.trace = calls
+        try:
+            tfu.reset_bn_links()
+            src = src0.clone().requires_grad_(True)
+            if kind == "sa":
+                _, out, _ = pu.pointnet_sa_module(xyz, src, m, 0.8, ns, mlp, None, False, True, 0.5, "mod", geometry=(new_xyz, idx, plan))
+            else:
+                out = pu.pointnet_fp_module(xyz, xyz2, p1_0.clone(), src, mlp, True, 0.5, "mod", nn=(dist, idx, plan))
+            (out * probe).sum().backward()
+        finally:
+            pn2._lib.lib.trace = None
+            tfu.USE_HOIST_BN_STATS, tfu.HOIST_BN_STATS_MIN_ROWS = True, min_rows
+        names[on] = [c_[0] for c_ in calls]
+        outs[on] = [out.detach(), src.grad] + [p_.grad for _, p_ in sorted(store.params.items()) if p_.grad is not None] + \
+                   [v.clone() for _, v in sorted(store.buffers.items())]
+    hname = "pn2_sa_hoist_rows" if kind == "sa" else "pn2_fp_hoist_rows"
+    assert hname + "_bn" in names[True] and hname not in names[True]
+    assert hname in names[False] and hname + "_bn" not in names[False]
+    assert names[True].count("pn2_bn_relu_forward_deferred") == names[False].count("pn2_bn_relu_forward_deferred") - 1
     for a, r in zip(outs[True], outs[False]):
         sc = max(float(r.abs().max()), 1e-3)
         assert float((a - r).abs().max()) <= 2e-5 * sc, (a.shape, float((a - r).abs().max()), sc)
