@@ -30,6 +30,10 @@
 constexpr int kPn2BnHead = 48;   // doubles in front: 384 bytes, keeps the sums 64-byte aligned
 constexpr int kPn2BnSlots = 64;  // most copies of the per-channel accumulators the producers spread their atomics over
 constexpr int kPn2BnTickets = 64;
+#ifndef PN2_FOLD_DEPTH
+#define PN2_FOLD_DEPTH 64
+#endif
+constexpr int kPn2FoldDepth = PN2_FOLD_DEPTH;  // slot copies a folding thread keeps in flight (a device-scope load is a ~1 us round trip)
 __host__ __device__ inline size_t pn2_bn_ws_doubles(int c, int nslots) { return kPn2BnHead + (size_t)(1 + nslots) * 2 * (size_t)c; }
 
 // per-channel constants of the normalisation, identical float expressions in the forward and the backward kernels so
@@ -105,12 +109,12 @@ __device__ __forceinline__ void pn2_bn_finish(const Pn2BnFinish& f, unsigned nwg
         double t = 0.0;
         const double* sl = f.ws + kPn2BnHead + (size_t)2 * c + col;
         int k = 0;
-        for (; k + 16 <= f.nslots; k += 16) {
-            double v[16];
+        for (; k + kPn2FoldDepth <= f.nslots; k += kPn2FoldDepth) {
+            double v[kPn2FoldDepth];
 #pragma unroll
-            for (int u = 0; u < 16; ++u) v[u] = pn2_load_device_scope(sl + (size_t)2 * c * (k + u));
+            for (int u = 0; u < kPn2FoldDepth; ++u) v[u] = pn2_load_device_scope(sl + (size_t)2 * c * (k + u));
 #pragma unroll
-            for (int u = 0; u < 16; ++u) t += v[u];
+            for (int u = 0; u < kPn2FoldDepth; ++u) t += v[u];
         }
         for (; k < f.nslots; ++k) t += pn2_load_device_scope(sl + (size_t)2 * c * k);
         f.ws[kPn2BnHead + col] = t;
