@@ -624,6 +624,72 @@ ti_csr_fill_multi_kernel(PlanBatch pb) {
     }
 }
 
+// The three kernels above as ONE, for plans whose source counts fit LDS: a workgroup owns one (plan, cloud) pair -- counts with LDS
+// atomics, an exclusive scan over the <= kPlanLdsMaxSrc counters in LDS, then the fill with LDS cursors.  The global atomics of the
+// three-kernel form (1.1 M of them for the seven plans of a configs[1] training step, executed at the memory side: 43 + 62 us on
+// the geometry stream, and they slow the training step beside them by almost their whole duration) become LDS atomics; cnt / off
+// are written once, so the range needs no memset.  The order inside a source's list is as arbitrary as before.
+constexpr int kPlanLdsMaxSrc = 16384;
+constexpr int kPlanLdsThreads = 1024;
+__global__ void __launch_bounds__(kPlanLdsThreads)
+ti_csr_build_lds_kernel(PlanBatch pb) {
+    extern __shared__ int plan_lds[];
+    __shared__ int wsum[kPlanLdsThreads / 64];
+    const PlanDesc& p = pb.d[blockIdx.y];
+    const int bi = blockIdx.x, t = threadIdx.x, m = p.nsrc, n3 = p.nent;
+    int* __restrict__ cnt = plan_lds;       // [m] counters, then cursors
+    int* __restrict__ off = plan_lds + m;   // [m] list starts
+    const int* __restrict__ idx = p.idx + (size_t)bi * n3;
+    for (int i = t; i < m; i += kPlanLdsThreads) cnt[i] = 0;
+    __syncthreads();
+    for (int e = t; e < n3; e += kPlanLdsThreads) atomicAdd(&cnt[idx[e]], 1);
+    __syncthreads();
+    // exclusive scan: thread t owns the counters [t * per, (t + 1) * per)
+    const int per = (m + kPlanLdsThreads - 1) / kPlanLdsThreads;
+    const int lo = t * per < m ? t * per : m, hi = lo + per < m ? lo + per : m;
+    int sum = 0;
+    for (int i = lo; i < hi; ++i) sum += cnt[i];
+    int inc = sum;  // inclusive scan inside the wave, then over the 16 wave totals
+    const int lane = t & 63, wave = t >> 6;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) { const int v = __shfl_up(inc, o); if (lane >= o) inc += v; }
+    if (lane == 63) wsum[wave] = inc;
+    __syncthreads();
+    int base = 0;
+    for (int w_ = 0; w_ < wave; ++w_) base += wsum[w_];
+    int run = base + inc - sum;
+    int* __restrict__ gcnt = p.cnt + (size_t)bi * m;
+    int* __restrict__ goff = p.off + (size_t)bi * m;
+    for (int i = lo; i < hi; ++i) {
+        const int v = cnt[i];
+        off[i] = run;
+        goff[i] = run;
+        gcnt[i] = v;   // (the three-kernel form leaves the list lengths here too)
+        cnt[i] = 0;
+        run += v;
+    }
+    __syncthreads();
+    const float* __restrict__ w = p.kind ? p.w + (size_t)bi * n3 : nullptr;
+    int* __restrict__ eq = p.eq + (size_t)bi * n3;
+    float* __restrict__ ew = p.ew + (size_t)bi * n3;
+    for (int e = t; e < n3; e += kPlanLdsThreads) {
+        const int s_ = idx[e];
+        const int q = off[s_] + atomicAdd(&cnt[s_], 1);
+        eq[q] = e / p.div;
+        float wt = 1.f;
+        if (w && p.kind == 2) {  // three_nn's squared distances -> inverse-distance weights, as ti_csr_fill_kernel
+            const int r = e / 3, j = e - 3 * r;
+            const float r1 = 1.0f / fmaxf(w[r * 3 + 0], 1e-10f), r2 = 1.0f / fmaxf(w[r * 3 + 1], 1e-10f);
+            const float r3 = 1.0f / fmaxf(w[r * 3 + 2], 1e-10f);
+            const float norm = (r1 + r2) + r3;
+            wt = (j == 0 ? r1 : (j == 1 ? r2 : r3)) / norm;
+        } else if (w) {
+            wt = w[e];
+        }
+        ew[q] = wt;
+    }
+}
+
 // pn2_scatter_plan_build for nplans <= 8 plans of the same batch size at once: plan i is the pn2_scatter_plan_bytes(b, nent[i],
 // nsrc[i]) bytes at `buffer + offset[i]` (offsets ascending, 16-byte aligned, the whole range inside buffer_bytes) -- each of
 // them a plan pn2_scatter_plan_apply takes.  One memset of the range + three launches.
@@ -653,6 +719,21 @@ extern "C" int pn2_scatter_plan_build_multi(int nplans, int b, const int* nent, 
     }
     if (((uintptr_t)buffer % 16) != 0) return PN2_EINVAL;
     hipStream_t st = static_cast<hipStream_t>(stream);
+    int max_src = 0;
+    for (int i = 0; i < nplans; ++i) max_src = nsrc[i] > max_src ? nsrc[i] : max_src;
+    if (max_src <= kPlanLdsMaxSrc) {  // one launch, LDS atomics, no memset (cnt / off / eq / ew are all written)
+        const size_t lds = sizeof(int) * 2 * (size_t)max_src;
+        static bool attr_set = false;
+        if (!attr_set) {
+            hipError_t ea = hipFuncSetAttribute(reinterpret_cast<const void*>(ti_csr_build_lds_kernel),
+                                                hipFuncAttributeMaxDynamicSharedMemorySize, sizeof(int) * 2 * kPlanLdsMaxSrc);
+            if (ea != hipSuccess) return (int)ea;
+            attr_set = true;
+        }
+        ti_csr_build_lds_kernel<<<dim3(b, nplans), kPlanLdsThreads, lds, st>>>(pb);
+        PN2_RETURN_IF_LAUNCH_FAILED();
+        return PN2_OK;
+    }
     hipError_t e = hipMemsetAsync(static_cast<char*>(buffer) + offset[0], 0, end - offset[0], st);
     if (e != hipSuccess) return (int)e;
     dim3 ge(grid_x_for((unsigned long long)max_ent, 256, b * nplans), b, nplans);

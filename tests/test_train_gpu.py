@@ -134,15 +134,18 @@ def test_scatter_plan_three_interpolate_gradient(pn2, cuda, b, n, m, c2, c1):
         np.testing.assert_array_equal(grads[1][1], g[:, :, c2:])
 
 
-def test_scatter_plans_built_together_equal_the_single_builds(pn2, cuda):
+@pytest.mark.parametrize("big_src", [0, 8192, 20000])
+def test_scatter_plans_built_together_equal_the_single_builds(pn2, cuda, big_src):
     """pn2_scatter_plan_build_multi: the seven plans of a training batch (three grouping levels, four interpolation levels, different
-    sizes / kinds) in one memset + three launches; every plan gathers what its single build gathers (float64 yardstick: np.add.at)."""
+    sizes / kinds) at once -- r06: ONE launch with LDS counters / cursors while every plan's source count fits LDS (<= 16384; also
+    at 8192 sources, the level-0 plan of a model whose colours are 4 wide), one memset + three launches otherwise (a plan with 20000
+    sources forces that path for the whole batch); every plan gathers what its single build gathers (float64 yardstick: np.add.at)."""
     import torch
     pu = pn2.util.pointnet_util
     rs = np.random.RandomState(3)
     b = 4
-    shapes = [(1024, 256, 32, None), (256, 64, 32, None), (64, 16, 32, None), None, (16, 64, 3, 2), (64, 256, 3, 2), (256, 1024, 3, 2),
-              (1024, 2048, 3, 2)]   # (nsrc, rows, k, weight_kind)
+    shapes = [(1024, 256, 32, None), (256, 64, 32, None), (64, 16, 32, None), (big_src, 1024, 32, None) if big_src else None,
+              (16, 64, 3, 2), (64, 256, 3, 2), (256, 1024, 3, 2), (1024, 2048, 3, 2)]   # (nsrc, rows, k, weight_kind)
     specs, keep = [], []
     for sh in shapes:
         if sh is None:
@@ -155,7 +158,7 @@ def test_scatter_plans_built_together_equal_the_single_builds(pn2, cuda):
         specs.append((idx, nsrc, w, kind))
         keep.append((idx, nsrc, w, kind))
     plans = pu.scatter_plans(specs)
-    assert plans[3] is None and len(plans) == len(specs)
+    assert (plans[3] is None) == (big_src == 0) and len(plans) == len(specs)
     for sp, plan in zip(keep, plans):
         if sp is None:
             continue
