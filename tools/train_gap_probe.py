@@ -1,4 +1,5 @@
-"""Where the time between "the captured training step replayed alone" and "a training step" goes (round 6: 3.35 vs 3.77 ms).
+"""Where the time between "the captured training step replayed alone" and "a training step" goes (round 6: 3.35 vs 3.77 ms at first;
+3.22 vs 3.45 after the staged hand-over and the LDS scatter-plan build).
 
     gpurun -- 'python tools/train_gap_probe.py > gpurun_out/train_gap.txt'
 
@@ -70,7 +71,8 @@ xyz = tr._xyz_of(pc)
 
 
 def with_side(work, copy=False):
-    def prefetch(next_pc, after_event):
+    def prefetch(next_pc, after_event, next_labels=None, next_smpw=None):
+        tr._staged_tag = None
         if work is None:
             return
         side.wait_event(after_event)
