@@ -24,6 +24,7 @@
 
 #include "pn2_common.h"
 #include "pn2_mfma_stats.h"
+#include "pn2_fwd_narrow.h"
 
 namespace {
 
@@ -970,6 +971,7 @@ sa_group_concat_kernel(int n, int m, int nsample, int c, const float* __restrict
 }  // namespace
 
 PN2_TUNABLE(int, g_lin_cfg, 0)     // tuning hook (pn2_debug_set(8, v)): 0 = auto, 1..4 = force <4,1,4> / <2,2,2> / <1,4,1> / <1,2,1,split-K>
+PN2_TUNABLE(int, g_lin_narrow, 1)  // tuning hook (pn2_debug_set(17, v)): the streaming forward kernel of the narrow training layers (pn2_fwd_narrow.h)
 PN2_TUNABLE(int, g_lin_stages, 3)  // tuning hook (pn2_debug_set(5, v)): register prefetch depth of linear_kernel
 PN2_TUNABLE(int, g_wgrad_waves, 0) // tuning hook (pn2_debug_set(9, v)): waves in flight targeted by pn2_linear_wgrad (0 = auto)
 
@@ -995,6 +997,9 @@ static int linear_impl(int rows, int cin, int cout, const float* x, const float*
      : st_depth == 3 ? launch_linear<WM_, WN_, NT_, WK_, 3>(rows, cin, cout, x, w, bias, relu, pool, y, st, stats, fin)    \
                      : launch_linear<WM_, WN_, NT_, WK_, 2>(rows, cin, cout, x, w, bias, relu, pool, y, st, stats, fin))
     const int st_depth = g_lin_stages;
+    // training forward of a narrow layer over many rows (statistics epilogue, no bias / activation): the streaming kernel
+    if (g_lin_cfg == 0 && g_lin_narrow && stats && !bias && !relu && pool <= 1 && fwd_narrow_fits(rows, cin, cout, x, w))
+        return launch_fwd_narrow(rows, cin, cout, x, nullptr, w, y, stats, fin, st);
     if (g_lin_cfg >= 5 && (pool <= 1 || pool == 32)) {  // tuning hook: split-K direct-feed tiles
         if (g_lin_cfg == 5) return launch_linear_splitk<1, 1, 2>(rows, cin, cout, x, w, bias, relu, pool, y, st, stats, fin);
         if (g_lin_cfg == 6) return launch_linear_splitk<1, 1, 4>(rows, cin, cout, x, w, bias, relu, pool, y, st, stats, fin);
@@ -1085,6 +1090,8 @@ static int linear_bn_stats_xf_impl(int rows, int cin, int cout, const float* x_r
     hipStream_t st = static_cast<hipStream_t>(stream);
     double* stats = static_cast<double*>(bn_workspace);
     const Pn2LoadTransform xf{a_scale, a_shift, a_relu};
+    if (g_lin_cfg == 0 && g_lin_narrow && fwd_narrow_fits(rows, cin, cout, x_raw, w))
+        return launch_fwd_narrow(rows, cin, cout, x_raw, &xf, w, y, stats, fin, st);
 #ifdef PN2_TUNING_HOOKS
     if (cout % 128 == 0 && g_lin_cfg == 1) return launch_linear_xf<4, 1, 4>(rows, cin, cout, x_raw, w, y, st, stats, xf, fin);
     if (cout % 128 == 0 && g_lin_cfg == 2) return launch_linear_xf<2, 2, 2>(rows, cin, cout, x_raw, w, y, st, stats, xf, fin);
@@ -1259,6 +1266,7 @@ extern "C" int pn2_debug_set_linear(int what, int value) {
     if (what == 5) { g_lin_stages = value; return 0; }
     if (what == 8) { g_lin_cfg = value; return 0; }
     if (what == 9) { g_wgrad_waves = value; return 0; }
+    if (what == 17) { g_lin_narrow = value; return 0; }
     return PN2_EINVAL;
 }
 #endif  // PN2_TUNING_HOOKS

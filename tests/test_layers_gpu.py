@@ -906,6 +906,48 @@ def test_hoisted_layer_with_fused_statistics_equals_the_two_launches(pn2, cuda, 
         assert float((a - r).abs().max()) <= 2e-5 * sc, (a.shape, float((a - r).abs().max()), sc)
 
 
+@pytest.mark.parametrize("rows,cin,cout", [(65536, 32, 32), (524288, 32, 64), (131072, 64, 64), (131072, 64, 128), (65536, 32, 128),
+                                           (98304, 64, 32)])
+@pytest.mark.parametrize("xf", [False, True])
+def test_streaming_forward_of_the_narrow_layers_equals_the_tiled_kernel(pn2, cuda, rows, cin, cout, xf):
+    """Round 6: fwd_narrow_kernel (csrc/pn2_fwd_narrow.h: 32 / 64 input channels, 32 / 64 / 128 outputs, >= 65536 rows, rows % 32 == 0)
+    behind pn2_linear_bn_stats_fin, without / with the batch norm of the layer below applied on load.  y is the tiled linear_kernel's
+    bit for bit -- reached through the same entry point on rows + 1 rows, a shape the streaming kernel refuses -- and the published
+    moments / constants are those of float64 sums over that y; three times in a row (the ticket).  tf_util.py:181-204,555-581."""
+    import torch
+    tfu = pn2.util.tf_util
+    rs = np.random.RandomState(rows % 977 + cin + cout)
+    x1 = T(rs.randn(rows + 1, cin).astype(np.float32), cuda)
+    x = x1[:rows]
+    w = T((rs.randn(cin, cout) / np.sqrt(cin)).astype(np.float32), cuda)
+    gamma = T((1.0 + 0.1 * rs.randn(cout)).astype(np.float32), cuda)
+    beta = T((0.1 * rs.randn(cout)).astype(np.float32), cuda)
+    xft = (T((0.5 + rs.rand(cin)).astype(np.float32), cuda), T((0.2 * rs.randn(cin)).astype(np.float32), cuda), True) if xf else None
+    nbytes = pn2._lib.lib.pn2_bn_workspace_bytes(cout)
+    calls = []
+    pn2._lib.lib.trace = calls
+    try:
+        ws = torch.zeros(nbytes // 8, dtype=torch.float64, device=cuda)
+        y_tiled, _ = tfu.hip_matmul_bn_stats_fin(x1, w, ws, xft, 1)
+    finally:
+        pn2._lib.lib.trace = None
+    for it in range(3):
+        ws = torch.zeros(nbytes // 8, dtype=torch.float64, device=cuda)
+        rm, rv = torch.zeros(cout, device=cuda), torch.ones(cout, device=cuda)
+        y, (save_mean, save_invstd, sc, sh) = tfu.hip_matmul_bn_stats_fin(x, w, ws, xft, 2, gamma, beta, None, 0.5, rm, rv)
+        assert torch.equal(y, y_tiled[:rows]), it
+        yd = y.double()
+        mean, var = yd.mean(0), yd.var(0, unbiased=False)
+        invstd = 1.0 / torch.sqrt(var + 1e-3)
+        assert float((save_mean.double() - mean).abs().max()) <= 1e-6 * max(1.0, float(mean.abs().max())), it
+        assert float(((save_invstd.double() - invstd) / invstd).abs().max()) <= 1e-6, it
+        assert float((sc.double() - gamma.double() * invstd).abs().max()) <= 1e-6 * float((gamma.double() * invstd).abs().max()), it
+        assert float((rm.double() - 0.5 * mean).abs().max()) <= 1e-6 * max(1.0, float(mean.abs().max())), it
+        tick = ws[:48].view(torch.int32)[:65].cpu().numpy()  # 64 first-level counters + the second level: one ticket per workgroup
+        wg = min(rows // 128, 1024)
+        assert int(tick[:64].sum()) == wg and int(tick[64]) == min(wg, 64), (it, int(tick[:64].sum()), int(tick[64]))
+
+
 @pytest.mark.parametrize("rows,cin,cout", [(524288, 32, 32), (131072, 128, 128), (1024, 768, 256), (40000, 64, 512), (33, 32, 32)])
 def test_bn_finish_ticket_under_many_workgroups(pn2, cuda, rows, cin, cout):
     """The ticket of pn2_bn_finish under load: the forward GEMM + statistics + constants as ONE launch (finish 2), twelve times in a
