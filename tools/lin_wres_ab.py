@@ -2,6 +2,8 @@
 (tuning build: PN2_HIP_LIBRARY=.../libpn2_tune.so), at the many-row layers of configs[1]: plain forward (+ max over 32 rows), the
 training forward (batch norm of the layer below on load + statistics + finish), the data gradient (given dy / formed on load,
 epilogue for the layer below).  Graph-timed (20 launches per replay); outputs compared bit for bit.
+NEEDS tools/experiments/r06_linear_wres/ applied (dispatch.patch + the header into csrc/): in the tree as it is, hook 17 selects the
+streaming narrow-layer kernel (csrc/pn2_fwd_narrow.h, tools/fwd_narrow_ab.py) and this script would compare that one.
     python tools/dbg/build_both.py && gpurun -- 'PN2_HIP_LIBRARY=$PWD/open3d-pointnet2-semantic3d_amd/libpn2_tune.so python tools/lin_wres_ab.py'"""
 import ctypes, os, sys
 import torch
