@@ -766,14 +766,16 @@ int launch_linear_splitk(int rows, int cin, int cout, const float* x, const floa
 // GX = 1 / 2: dy is the gradient leaving this layer's batch norm (+ReLU; 2: + max over groups of 32 rows), formed per lane from
 // (y, dz) and the constants of its TN output channels while the operand is loaded (Pn2GradOnLoad; the `dy` argument is not read).
 // GX = 2: chunk % 32 == 0, so a fetch of 2U rows never straddles a pooling group.
-template <int TM, int TN, bool XF = false, int GX = 0>
-__global__ void __launch_bounds__(256, 2)
+// NWV = waves per workgroup: 4 (two workgroups per CU) or 8 (one workgroup per CU, TWO WAVES PER SIMD with the same number of
+// workgroups, hence the same number of closing atomics: one wave's operand transform and loads run under its partner's MFMAs).
+template <int TM, int TN, bool XF = false, int GX = 0, int NWV = 4>
+__global__ void __launch_bounds__(64 * NWV, NWV == 4 ? 2 : 1)
 linear_wgrad_kernel(int rows, int cin, int cout, int chunk, const float* __restrict__ x,
                     const float* __restrict__ dy, float* __restrict__ dw, Pn2LoadTransform xf = Pn2LoadTransform{},
                     Pn2GradOnLoad gx = Pn2GradOnLoad{}) {
     const int lane = threadIdx.x & 63, half = lane >> 5, l31 = lane & 31;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // row bookkeeping stays in SGPRs
-    const long long c0 = ((long long)blockIdx.x * 4 + wave) * chunk;
+    const long long c0 = ((long long)blockIdx.x * NWV + wave) * chunk;
     // a wave past the end contributes zeros (it still takes part in the block reduction)
     const int r0 = c0 < rows ? (int)c0 : rows;
     const int r1 = c0 + chunk < rows ? (int)(c0 + chunk) : rows;
@@ -903,9 +905,10 @@ linear_wgrad_kernel(int rows, int cin, int cout, int chunk, const float* __restr
         contract(b1, r + 2 * U);
         __builtin_amdgcn_sched_barrier(0);
     }
-    // the four waves of the block own consecutive row chunks of the SAME tile: add them up through LDS (two tree steps)
+    // the waves of the block own consecutive row chunks of the SAME tile: add them up through LDS (a tree: log2(NWV) steps)
     // so that only one wave per block issues the global atomics
-    __shared__ float red[2][TM * TN * 16 * 64];
+    extern __shared__ __attribute__((aligned(16))) float wgrad_red[];  // (NWV / 2) x TM * TN * 16 * 64 floats (128 KB at NWV = 8)
+    float (*red)[TM * TN * 16 * 64] = reinterpret_cast<float (*)[TM * TN * 16 * 64]>(wgrad_red);
     auto spill = [&](float* dst) {
 #pragma unroll
         for (int a = 0; a < TM; ++a)
@@ -922,14 +925,14 @@ linear_wgrad_kernel(int rows, int cin, int cout, int chunk, const float* __restr
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[a][b][r] += src[((a * TN + b) * 16 + r) * 64 + lane];
     };
-    if (wave >= 2) spill(red[wave - 2]);
-    __syncthreads();
-    if (wave < 2) absorb(red[wave]);
-    __syncthreads();
-    if (wave == 1) spill(red[0]);
-    __syncthreads();
+#pragma unroll
+    for (int h = NWV / 2; h >= 1; h >>= 1) {  // waves [h, 2h) hand their tiles to waves [0, h)
+        if (wave >= h && wave < 2 * h) spill(red[wave - h]);
+        __syncthreads();
+        if (wave < h) absorb(red[wave]);
+        __syncthreads();
+    }
     if (wave != 0) return;
-    absorb(red[0]);
     // D[i][j]: j = l31 (cout index), i = (r&3) + 8*(r>>2) + 4*half (cin index)
 #pragma unroll
     for (int a = 0; a < TM; ++a)
@@ -974,6 +977,7 @@ sa_group_concat_kernel(int n, int m, int nsample, int c, const float* __restrict
 PN2_TUNABLE(int, g_lin_cfg, 0)     // tuning hook (pn2_debug_set(8, v)): 0 = auto, 1..4 = force <4,1,4> / <2,2,2> / <1,4,1> / <1,2,1,split-K>
 PN2_TUNABLE(int, g_lin_narrow, 1)  // tuning hook (pn2_debug_set(17, v)): the streaming forward kernel of the narrow training layers (pn2_fwd_narrow.h)
 PN2_TUNABLE(int, g_lin_stages, 3)  // tuning hook (pn2_debug_set(5, v)): register prefetch depth of linear_kernel
+PN2_TUNABLE(int, g_wgrad_nwv8, 1)  // tuning hook (pn2_debug_set(18, v)): eight-wave workgroups for the 64 x 128 weight-gradient tile over >= 65536 rows
 PN2_TUNABLE(int, g_wgrad_waves, 0) // tuning hook (pn2_debug_set(9, v)): waves in flight targeted by pn2_linear_wgrad (0 = auto)
 
 static int linear_impl(int rows, int cin, int cout, const float* x, const float* w,
@@ -1270,6 +1274,7 @@ extern "C" int pn2_debug_set_linear(int what, int value) {
     if (what == 8) { g_lin_cfg = value; return 0; }
     if (what == 9) { g_wgrad_waves = value; return 0; }
     if (what == 17) { g_lin_narrow = value; return 0; }
+    if (what == 18) { g_wgrad_nwv8 = value; return 0; }
     return PN2_EINVAL;
 }
 #endif  // PN2_TUNING_HOOKS
@@ -1294,18 +1299,50 @@ static int linear_wgrad_impl(int rows, int cin, int cout, const float* x, const 
     // each block adds its four partial tiles in LDS and issues one set of atomics
     const int tm = cin > 32 ? 2 : 1, tn = cout > 64 ? 4 : (cout > 32 ? 2 : 1);
     const int gy = (cin + 32 * tm - 1) / (32 * tm), gz = (cout + 32 * tn - 1) / (32 * tn);
-    long long waves = (g_wgrad_waves > 0 ? g_wgrad_waves : 1024) / ((long long)gy * gz);
+    // the 64 x 128 tile over many rows: eight waves per workgroup (twice the waves, the same 256 workgroups and closing atomics)
+    const bool wide8 = g_wgrad_nwv8 && tm == 2 && tn == 4 && rows >= 65536;
+    long long waves = (g_wgrad_waves > 0 ? g_wgrad_waves : (wide8 ? 2048 : 1024)) / ((long long)gy * gz);
     if (waves < 16) waves = 16;
     int chunk = (int)((rows + waves - 1) / waves);
     chunk = (chunk + 7) & ~7;
     if (chunk < 64) chunk = 64;
     const int nchunks = (rows + chunk - 1) / chunk;
     dim3 grid((nchunks + 3) / 4, gy, gz);
+    if (wide8) {
+        const dim3 grid8((nchunks + 7) / 8, gy, gz);
+        constexpr size_t lds8 = sizeof(float) * 4 * 2 * 4 * 16 * 64;  // 128 KB: beyond the default dynamic limit
+#define PN2_WG8(XF_, GX_, XFV_, GXV_)                                                                                              \
+        do {                                                                                                                       \
+            static bool attr_set = false; /* per instantiation; benign race (idempotent call) */                                  \
+            if (!attr_set) {                                                                                                       \
+                hipError_t e8 = hipFuncSetAttribute(reinterpret_cast<const void*>(linear_wgrad_kernel<2, 4, XF_, GX_, 8>),         \
+                                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds8);                       \
+                if (e8 != hipSuccess) return (int)e8;                                                                              \
+                attr_set = true;                                                                                                   \
+            }                                                                                                                      \
+            linear_wgrad_kernel<2, 4, XF_, GX_, 8><<<grid8, 512, lds8, st>>>(rows, cin, cout, chunk, x, dy, dw, XFV_, GXV_);       \
+        } while (0)
+        const Pn2LoadTransform xv = xf ? *xf : Pn2LoadTransform{};
+        const Pn2GradOnLoad gv = gx ? *gx : Pn2GradOnLoad{};
+        if (xf) {
+            if (!gx) PN2_WG8(true, 0, xv, gv);
+            else if (gx->pool) PN2_WG8(true, 2, xv, gv);
+            else PN2_WG8(true, 1, xv, gv);
+        } else {
+            if (!gx) PN2_WG8(false, 0, xv, gv);
+            else if (gx->pool) PN2_WG8(false, 2, xv, gv);
+            else PN2_WG8(false, 1, xv, gv);
+        }
+#undef PN2_WG8
+        PN2_RETURN_IF_LAUNCH_FAILED();
+        return PN2_OK;
+    }
 #define PN2_WG_X(TM_, TN_, XF_, XFV_)                                                                                     \
     do {                                                                                                                  \
-        if (!gx) linear_wgrad_kernel<TM_, TN_, XF_><<<grid, 256, 0, st>>>(rows, cin, cout, chunk, x, dy, dw, XFV_);         \
-        else if (gx->pool) linear_wgrad_kernel<TM_, TN_, XF_, 2><<<grid, 256, 0, st>>>(rows, cin, cout, chunk, x, nullptr, dw, XFV_, *gx); \
-        else linear_wgrad_kernel<TM_, TN_, XF_, 1><<<grid, 256, 0, st>>>(rows, cin, cout, chunk, x, nullptr, dw, XFV_, *gx); \
+        constexpr size_t lds_ = sizeof(float) * 2 * TM_ * TN_ * 16 * 64;                                                   \
+        if (!gx) linear_wgrad_kernel<TM_, TN_, XF_><<<grid, 256, lds_, st>>>(rows, cin, cout, chunk, x, dy, dw, XFV_);      \
+        else if (gx->pool) linear_wgrad_kernel<TM_, TN_, XF_, 2><<<grid, 256, lds_, st>>>(rows, cin, cout, chunk, x, nullptr, dw, XFV_, *gx); \
+        else linear_wgrad_kernel<TM_, TN_, XF_, 1><<<grid, 256, lds_, st>>>(rows, cin, cout, chunk, x, nullptr, dw, XFV_, *gx); \
     } while (0)
 #define PN2_WG(TM_, TN_)                                              \
     do {                                                              \

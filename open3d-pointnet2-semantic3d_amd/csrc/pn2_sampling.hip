@@ -771,7 +771,7 @@ extern "C" int pn2_debug_set_coarse(int what, int value);
 extern "C" int pn2_debug_set_fps_stats(long long* dev_ptr) { g_fps_stats = dev_ptr; return 0; }
 extern "C" int pn2_debug_set(int what, int value) {
     if (what == 0) { g_fps_variant = value; return 0; }
-    if (what == 5 || what == 8 || what == 9 || what == 17) return pn2_debug_set_linear(what, value);
+    if (what == 5 || what == 8 || what == 9 || what == 17 || what == 18) return pn2_debug_set_linear(what, value);
     if (what == 10) return pn2_debug_set_bn(what, value);
     if (what == 11) return pn2_debug_set_fps_large(what, value);
     if (what == 12) return pn2_debug_set_interp(what, value);
