@@ -1690,9 +1690,11 @@ def test_large_scene_bf16_config4(pn2, oracle, cuda):
 
 # ------------------------------------------------------------------ training: weight gradient kernel ---------
 @pytest.mark.parametrize("rows,cin,cout", [(524288 // 8, 6, 32), (4096, 32, 64), (1000, 67, 64), (777, 259, 256), (64, 131, 128),
-                                           (5, 3, 9), (20000, 128, 512), (33, 768, 256)])
+                                           (5, 3, 9), (20000, 128, 512), (33, 768, 256),
+                                           (131072, 128, 128), (70001, 128, 128), (65560, 96, 256), (65536, 64, 128)])
 def test_linear_wgrad_vs_fp64(pn2, cuda, rows, cin, cout):
-    """pn2_linear_wgrad: dW = x^T . dy against float64 (fp32 products are exact; only the summation order differs)."""
+    """pn2_linear_wgrad: dW = x^T . dy against float64 (fp32 products are exact; only the summation order differs).  The last four
+    shapes take the eight-wave workgroups of the 64 x 128 tile (r06: >= 65536 rows), one of them with a ragged last chunk."""
     import ctypes
     import torch
     rs = np.random.RandomState(rows + cin)
@@ -1707,6 +1709,46 @@ def test_linear_wgrad_vs_fp64(pn2, cuda, rows, cin, cout):
     err = np.abs(dw.cpu().numpy() - ref)
     assert err.max() <= 1e-5 * np.sqrt(rows) * 8, err.max()  # random-walk growth of the fp32 rounding
     assert err.max() <= 2e-4 * np.abs(ref).max() + 1e-3
+
+
+@pytest.mark.parametrize("rows,pool,xf_on", [(131072, 0, True), (65568, 0, False), (98304, 32, True)])
+def test_eight_wave_weight_gradient_with_operands_formed_on_load(pn2, cuda, rows, pool, xf_on):
+    """Round 6: pn2_linear_wgrad_gx at 128 x 128 over >= 65536 rows (eight waves per workgroup, dy formed on load from (y, dz, coef),
+    x normalised on load) against float64 of the materialised operands: dW += a^T . dy with a = relu(fma(x, sc, sh)) and dy =
+    pn2_bn_grad_element(...) -- the float expressions of the kernels, summed in float64.  tf_util.py:181-204,555-581 via tf.gradients."""
+    import torch
+    L, P = pn2._lib.lib, pn2._lib.ptr
+    rs = np.random.RandomState(rows % 887 + pool)
+    c = 128
+    x = T(rs.randn(rows, c).astype(np.float32), cuda)
+    y = T(rs.randn(rows, c).astype(np.float32), cuda)
+    sc, sh = T((0.5 + rs.rand(c)).astype(np.float32), cuda), T((0.2 * rs.randn(c)).astype(np.float32), cuda)
+    coef = T(np.stack([0.5 + rs.rand(c), 0.2 * rs.randn(c), 0.1 * rs.randn(c), 0.5 + rs.rand(c), 0.01 * rs.randn(c),
+                       0.01 * rs.randn(c)]).astype(np.float32), cuda)
+    csc, csh, cmu, cis, k1, k2 = (coef[j] for j in range(6))
+    lin = (y.double() * csc.double() + csh.double()).float()   # the kernel's fmaf(y, sc, sh): one rounding of the exact value
+    on = lin > 0
+    if pool:
+        groups = rows // pool
+        dzp = T(rs.randn(groups, c).astype(np.float32), cuda)
+        t = torch.where(on, lin, torch.zeros_like(lin)).view(groups, pool, c)
+        zmax = t.max(1).values
+        ties = (t == zmax.view(groups, 1, c)).sum(1).float()
+        g = torch.where(t == zmax.view(groups, 1, c), (dzp / ties).view(groups, 1, c), torch.zeros_like(t)).view(rows, c)
+        dz_arg, zm_arg, ti_arg = dzp, zmax, ties
+    else:
+        dz = T(rs.randn(rows, c).astype(np.float32), cuda)
+        g, dz_arg, zm_arg, ti_arg = dz, dz, None, None
+    gk = torch.where(on, g, torch.zeros_like(g))
+    dy = csc * (-((y - cmu) * cis) * k2 + (gk - k1))
+    a = torch.relu((x.double() * sc.double() + sh.double()).float()) if xf_on else x
+    ref = a.double().t() @ dy.double()
+    dw = torch.zeros(c, c, device=cuda)
+    rc = L.pn2_linear_wgrad_gx(rows, c, c, P(x), P(sc) if xf_on else None, P(sh) if xf_on else None, 1, P(y), P(dz_arg), P(coef), 1, pool,
+                               P(zm_arg), P(ti_arg), P(dw), pn2._lib.stream_ptr())
+    assert rc == 0, rc
+    err = float((dw.double() - ref).abs().max())
+    assert err <= 2e-5 * float(ref.abs().max()) + 1e-5 * np.sqrt(rows), (err, float(ref.abs().max()))
 
 
 def test_training_gradients_with_hip_wgrad_match_torch(pn2, cuda):
