@@ -30,6 +30,10 @@
 constexpr int kPn2BnHead = 48;   // doubles in front: 384 bytes, keeps the sums 64-byte aligned
 constexpr int kPn2BnSlots = 64;  // most copies of the per-channel accumulators the producers spread their atomics over
 constexpr int kPn2BnTickets = 64;
+#ifndef PN2_STREAM_MIN_ROWS
+#define PN2_STREAM_MIN_ROWS 65536   // fewest rows the wave-per-tile streaming kernels of the training GEMMs take (pn2_fwd_narrow.h, pn2_dgrad_wide.h, the
+                                    // eight-wave weight gradient); measured: 32768 -> step 3.19 -> 3.21 ms, 16384 -> 3.24 (too few tiles per wave)
+#endif
 #ifndef PN2_FOLD_DEPTH
 #define PN2_FOLD_DEPTH 64
 #endif

@@ -155,7 +155,7 @@ dgrad_wide_kernel(int rows, const float* __restrict__ w, float* __restrict__ dx,
 // n_in = n_out = 128, rows % 32 == 0, >= 65536 rows, dy formed on load without pooling, 16-byte aligned operands
 inline bool dgrad_wide_fits(int rows, int n_in, int n_out, const Pn2GradOnLoad* gx, const void* w_) {
     if (!gx || gx->pool || n_in != 128 || n_out != 128) return false;
-    if (rows % 32 != 0 || rows < 65536) return false;
+    if (rows % 32 != 0 || rows < PN2_STREAM_MIN_ROWS) return false;
     return (((uintptr_t)gx->y | (uintptr_t)gx->dz | (uintptr_t)gx->coef | (uintptr_t)w_) % 16) == 0;
 }
 

@@ -313,7 +313,7 @@ int launch_fwd_wide_in(int rows, const float* x, const Pn2LoadTransform* xf, con
 inline bool fwd_narrow_fits(int rows, int cin, int cout, const void* x, const void* w_) {
     if (cin != 32 && cin != 64 && !(cin == 128 && cout == 128)) return false;
     if (cout != 32 && cout != 64 && cout != 128) return false;
-    if (rows % 32 != 0 || rows < 65536) return false;
+    if (rows % 32 != 0 || rows < PN2_STREAM_MIN_ROWS) return false;
     return (((uintptr_t)x | (uintptr_t)w_) % 16) == 0;
 }
 

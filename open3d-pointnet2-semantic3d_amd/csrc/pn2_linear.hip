@@ -1300,7 +1300,7 @@ static int linear_wgrad_impl(int rows, int cin, int cout, const float* x, const 
     const int tm = cin > 32 ? 2 : 1, tn = cout > 64 ? 4 : (cout > 32 ? 2 : 1);
     const int gy = (cin + 32 * tm - 1) / (32 * tm), gz = (cout + 32 * tn - 1) / (32 * tn);
     // the 64 x 128 tile over many rows: eight waves per workgroup (twice the waves, the same 256 workgroups and closing atomics)
-    const bool wide8 = g_wgrad_nwv8 && tm == 2 && tn == 4 && rows >= 65536;
+    const bool wide8 = g_wgrad_nwv8 && tm == 2 && tn == 4 && rows >= PN2_STREAM_MIN_ROWS;
     long long waves = (g_wgrad_waves > 0 ? g_wgrad_waves : (wide8 ? 2048 : 1024)) / ((long long)gy * gz);
     if (waves < 16) waves = 16;
     int chunk = (int)((rows + waves - 1) / waves);
