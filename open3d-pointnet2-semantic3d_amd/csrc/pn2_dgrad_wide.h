@@ -1,4 +1,4 @@
-// pn2_dgrad_wide.h -- the data gradient of a 128 -> 128 dense + batch-norm layer of the training path over >= 65536 rows, with the
+// pn2_dgrad_wide.h -- the data gradient of a 128 -> 128 (or 64 -> 128) dense + batch-norm layer of the training path over >= 65536 rows, with the
 // upstream gradient formed on load: dx (rows, 128) = dy . W^T, dy = the gradient LEAVING this layer's batch norm (+ReLU) formed
 // from (y, dz) and the six per-channel constants (Pn2GradOnLoad, GX = 1), plus the batch-norm gradient sums of the layer BELOW from
 // the dx tiles (Pn2BnGradEpilogue) and their finish -- what pn2_linear_dgrad_fin computes on linear_kernel<2, 2, 2, ..., TB, GX = 1>
@@ -19,10 +19,13 @@
 
 namespace {
 
+// CO = n_in / 32 (2, 4); GX = 1: dz (rows, 128); GX = 2: behind the max over groups of 32 rows -- a wave's tile IS one group, its
+// pooled gradient / maximum / tie count rows (gx.dz / zmax / ties, (rows / 32, 128)) travel with the slice
+template <int CO, int GX>
 __global__ void __launch_bounds__(512, 1)
 dgrad_wide_kernel(int rows, const float* __restrict__ w, float* __restrict__ dx, Pn2GradOnLoad gx, Pn2BnGradEpilogue gepi,
                   Pn2BnFinish fin) {
-    constexpr int K = 128, N = 128, CO = N / 32, KS = PN2_DGW_KS, NS = K / KS, NW = 8;
+    constexpr int K = 128, N = 32 * CO, KS = PN2_DGW_KS, NS = K / KS, NW = 8;
     constexpr int AS = KS + 4;
     constexpr int NF = 32 * (KS / 4) / 64;  // float4 of a slice per lane (8)
     extern __shared__ __attribute__((aligned(16))) float dgw_lds[];
@@ -45,7 +48,7 @@ dgrad_wide_kernel(int rows, const float* __restrict__ w, float* __restrict__ dx,
     const int ntiles = rows / 32;
     const int tstep = gridDim.x * NW;
     int tile = blockIdx.x * NW + wave;
-    f32x4 py[NF], pg[NF];  // ONE slice of (y, dz) ahead
+    f32x4 py[NF], pg[GX == 1 ? NF : 3];  // ONE slice of (y, dz) ahead (GX = 2: the group's three pooled rows instead of dz)
     auto fetch = [&](int t, int s_) __attribute__((always_inline)) {
         const int tc = t < ntiles ? t : ntiles - 1;
         const size_t base = (size_t)tc * 32 * K + s_ * KS + k4 * 4;
@@ -53,7 +56,13 @@ dgrad_wide_kernel(int rows, const float* __restrict__ w, float* __restrict__ dx,
         for (int i = 0; i < NF; ++i) {
             const size_t o = base + (size_t)((lane + 64 * i) / (KS / 4)) * K;
             py[i] = *reinterpret_cast<const f32x4*>(gx.y + o);
-            pg[i] = *reinterpret_cast<const f32x4*>(gx.dz + o);
+            if constexpr (GX == 1) pg[i] = *reinterpret_cast<const f32x4*>(gx.dz + o);
+        }
+        if constexpr (GX == 2) {
+            const size_t go = (size_t)tc * K + s_ * KS + k4 * 4;
+            pg[0] = *reinterpret_cast<const f32x4*>(gx.dz + go);
+            pg[1] = *reinterpret_cast<const f32x4*>(gx.zmax + go);
+            pg[2] = *reinterpret_cast<const f32x4*>(gx.ties + go);
         }
     };
     // the layer below: this lane's column of each 32-column block (running sums in fp64, as push_column_grad_stats forms them)
@@ -86,8 +95,13 @@ dgrad_wide_kernel(int rows, const float* __restrict__ w, float* __restrict__ dx,
                 const int r = (lane + 64 * i) / (KS / 4);
                 f32x4 v;
 #pragma unroll
-                for (int q = 0; q < 4; ++q)
-                    v[q] = pn2_bn_grad_element(py[i][q], pg[i][q], gc[0][q], gc[1][q], gc[2][q], gc[3][q], gc[4][q], gc[5][q], gx.relu);
+                for (int q = 0; q < 4; ++q) {
+                    if constexpr (GX == 1)
+                        v[q] = pn2_bn_grad_element(py[i][q], pg[i][q], gc[0][q], gc[1][q], gc[2][q], gc[3][q], gc[4][q], gc[5][q], gx.relu);
+                    else
+                        v[q] = pn2_bn_grad_element_pooled(py[i][q], pg[0][q], pg[1][q], pg[2][q], gc[0][q], gc[1][q], gc[2][q], gc[3][q],
+                                                          gc[4][q], gc[5][q], gx.relu);
+                }
                 *reinterpret_cast<f32x4*>(As + r * AS + k4 * 4) = v;
             }
             // the next slice: of this tile, or the first one of this wave's next tile (clamped past the end: never used)
@@ -152,29 +166,42 @@ dgrad_wide_kernel(int rows, const float* __restrict__ w, float* __restrict__ dx,
     pn2_bn_finish(fin, gridDim.x, blockIdx.x);
 }
 
-// n_in = n_out = 128, rows % 32 == 0, >= 65536 rows, dy formed on load without pooling, 16-byte aligned operands
+// n_out = 128, n_in in {64, 128}, rows % 32 == 0, enough rows, dy formed on load (plain or behind the max over 32 rows), 16-byte
+// aligned operands
 inline bool dgrad_wide_fits(int rows, int n_in, int n_out, const Pn2GradOnLoad* gx, const void* w_) {
-    if (!gx || gx->pool || n_in != 128 || n_out != 128) return false;
+    if (!gx || n_out != 128 || (n_in != 128 && n_in != 64)) return false;
+    if (gx->pool != 0 && gx->pool != 32) return false;
     if (rows % 32 != 0 || rows < PN2_STREAM_MIN_ROWS) return false;
-    return (((uintptr_t)gx->y | (uintptr_t)gx->dz | (uintptr_t)gx->coef | (uintptr_t)w_) % 16) == 0;
+    uintptr_t a = (uintptr_t)gx->y | (uintptr_t)gx->dz | (uintptr_t)gx->coef | (uintptr_t)w_;
+    if (gx->pool) a |= (uintptr_t)gx->zmax | (uintptr_t)gx->ties;
+    return (a % 16) == 0;
 }
 
-inline int launch_dgrad_wide(int rows, const float* w, float* dx, const Pn2GradOnLoad& gx, const Pn2BnGradEpilogue& gepi,
-                             const Pn2BnFinish* fin, hipStream_t st) {
+template <int CO, int GX>
+int launch_dgrad_wide_one(int rows, const float* w, float* dx, const Pn2GradOnLoad& gx, const Pn2BnGradEpilogue& gepi,
+                          const Pn2BnFinish* fin, hipStream_t st) {
     const int ntiles = rows / 32;
     int blocks = (ntiles + 7) / 8;
     if (blocks > 256) blocks = 256;  // one workgroup of eight waves per CU
-    constexpr size_t lds = sizeof(float) * ((size_t)16 * 4 * 256 + 6 * 128 + 8 * 32 * (PN2_DGW_KS + 4));
-    static bool attr_set = false;  // benign race (idempotent call)
+    constexpr size_t lds = sizeof(float) * ((size_t)16 * CO * 256 + 6 * 128 + 8 * 32 * (PN2_DGW_KS + 4));
+    static bool attr_set = false;  // per instantiation; benign race (idempotent call)
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(dgrad_wide_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                           (int)lds);
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(dgrad_wide_kernel<CO, GX>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return (int)e;
         attr_set = true;
     }
-    dgrad_wide_kernel<<<blocks, 512, lds, st>>>(rows, w, dx, gx, gepi, fin ? *fin : Pn2BnFinish{});
+    dgrad_wide_kernel<CO, GX><<<blocks, 512, lds, st>>>(rows, w, dx, gx, gepi, fin ? *fin : Pn2BnFinish{});
     PN2_RETURN_IF_LAUNCH_FAILED();
     return PN2_OK;
+}
+
+inline int launch_dgrad_wide(int rows, int n_in, const float* w, float* dx, const Pn2GradOnLoad& gx, const Pn2BnGradEpilogue& gepi,
+                             const Pn2BnFinish* fin, hipStream_t st) {
+    if (n_in == 128) return gx.pool ? launch_dgrad_wide_one<4, 2>(rows, w, dx, gx, gepi, fin, st)
+                                    : launch_dgrad_wide_one<4, 1>(rows, w, dx, gx, gepi, fin, st);
+    return gx.pool ? launch_dgrad_wide_one<2, 2>(rows, w, dx, gx, gepi, fin, st)
+                   : launch_dgrad_wide_one<2, 1>(rows, w, dx, gx, gepi, fin, st);
 }
 
 }  // namespace

@@ -1172,7 +1172,7 @@ static int linear_dgrad_impl(int rows, int cin, int cout, const float* dy, const
         }
     }
     // 128 -> 128 over many rows with dy formed on load: the streaming kernel with two waves per SIMD (pn2_dgrad_wide.h; same dx bits)
-    if (g_lin_cfg == 0 && g_lin_narrow && dgrad_wide_fits(rows, cin, cout, gx, w)) return launch_dgrad_wide(rows, w, dx, *gx, gepi, fin, st);
+    if (g_lin_cfg == 0 && g_lin_narrow && dgrad_wide_fits(rows, cin, cout, gx, w)) return launch_dgrad_wide(rows, cin, w, dx, *gx, gepi, fin, st);
 #ifdef PN2_TUNING_HOOKS
     if (cin > 96 && g_lin_cfg == 1) return launch_linear_dgrad<4, 1, 4>(rows, cin, cout, dy, w, dx, st, gepi, gx, fin);
     if (cin > 96 && g_lin_cfg == 2) return launch_linear_dgrad<2, 2, 2>(rows, cin, cout, dy, w, dx, st, gepi, gx, fin);

@@ -949,48 +949,60 @@ def test_streaming_forward_of_the_narrow_layers_equals_the_tiled_kernel(pn2, cud
         assert int(tick[:64].sum()) == wg and int(tick[64]) == min(wg, 64), (it, int(tick[:64].sum()), int(tick[64]))
 
 
-@pytest.mark.parametrize("rows,below,relu", [(131072, True, True), (65568, True, False), (98304, False, True)])
-def test_streaming_data_gradient_of_the_128_wide_layers_equals_the_tiled_kernel(pn2, cuda, rows, below, relu):
-    """Round 6: dgrad_wide_kernel (csrc/pn2_dgrad_wide.h: 128 -> 128, >= 65536 rows, the gradient leaving the batch norm formed on
-    load, eight waves per workgroup) behind pn2_linear_dgrad_fin.  dx is the tiled linear_kernel's bit for bit (same entry point on
-    rows + 1 rows, which the streaming kernel refuses); the constants it publishes for the layer below (finish 3: coef (6, c), dgamma,
-    dbeta) are those of float64 sums over that dx.  tf.gradients through conv2d -> batch_norm -> relu, tf_util.py:181-204,555-581."""
+@pytest.mark.parametrize("rows,n_in,pool,below,relu", [(131072, 128, 0, True, True), (65568, 128, 0, True, False), (98304, 128, 0, False, True),
+                                                       (131072, 64, 32, True, True), (65536, 128, 32, True, True), (65600, 64, 0, True, True)])
+def test_streaming_data_gradient_of_the_128_wide_layers_equals_the_tiled_kernel(pn2, cuda, rows, n_in, pool, below, relu):
+    """Round 6: dgrad_wide_kernel (csrc/pn2_dgrad_wide.h: 128 output channels of the layer, 64 / 128 inputs, >= 65536 rows, the gradient
+    leaving the batch norm formed on load -- plain or behind the max over 32 rows -- eight waves per workgroup) behind
+    pn2_linear_dgrad_fin.  dx is the tiled linear_kernel's bit for bit: the same entry point on the first 65504 rows (below the
+    streaming kernel's threshold; a row of dx depends on its own row / group only); the constants it publishes for the layer below
+    (finish 3: coef (6, c), dgamma, dbeta) are those of float64 sums over that dx.  tf.gradients through conv2d -> batch_norm -> relu
+    (-> max over K), tf_util.py:181-204,555-581, pointnet_util.py:167-170."""
     import torch
     L, P = pn2._lib.lib, pn2._lib.ptr
     st = pn2._lib.stream_ptr()
-    rs = np.random.RandomState(rows % 613)
+    rs = np.random.RandomState(rows % 613 + n_in + pool)
     c = 128
-    y1 = T(rs.randn(rows + 1, c).astype(np.float32), cuda)
-    dz1 = T(rs.randn(rows + 1, c).astype(np.float32), cuda)
-    yb1 = T(rs.randn(rows + 1, c).astype(np.float32), cuda)          # pre-normalisation output of the layer below
-    w = T((rs.randn(c, c) / np.sqrt(c)).astype(np.float32), cuda)
+    y1 = T(rs.randn(rows, c).astype(np.float32), cuda)
+    yb1 = T(rs.randn(rows, n_in).astype(np.float32), cuda)          # pre-normalisation output of the layer below
+    w = T((rs.randn(n_in, c) / np.sqrt(c)).astype(np.float32), cuda)
     coef = T(np.stack([0.5 + rs.rand(c), 0.2 * rs.randn(c), 0.1 * rs.randn(c), 0.5 + rs.rand(c), 0.01 * rs.randn(c),
                        0.01 * rs.randn(c)]).astype(np.float32), cuda)
-    gb, bb = T((1.0 + 0.1 * rs.randn(c)).astype(np.float32), cuda), T((0.1 * rs.randn(c)).astype(np.float32), cuda)
-    mb, ib = T((0.1 * rs.randn(c)).astype(np.float32), cuda), T((0.5 + rs.rand(c)).astype(np.float32), cuda)
-    nb = L.pn2_bn_workspace_bytes(c)
+    if pool:
+        lin = (y1.double() * coef[0].double() + coef[1].double()).float()     # the forward's fmaf(y, sc, sh)
+        t = torch.relu(lin).view(rows // pool, pool, c)
+        zmax = t.max(1).values.contiguous()
+        ties = (t == zmax.view(-1, 1, c)).sum(1).float().contiguous()
+        dz1 = T(rs.randn(rows // pool, c).astype(np.float32), cuda)
+    else:
+        zmax = ties = None
+        dz1 = T(rs.randn(rows, c).astype(np.float32), cuda)
+    gb, bb = T((1.0 + 0.1 * rs.randn(n_in)).astype(np.float32), cuda), T((0.1 * rs.randn(n_in)).astype(np.float32), cuda)
+    mb, ib = T((0.1 * rs.randn(n_in)).astype(np.float32), cuda), T((0.5 + rs.rand(n_in)).astype(np.float32), cuda)
+    nb = L.pn2_bn_workspace_bytes(n_in)
 
     def run(n, finish):
-        dx = torch.empty(n, c, device=cuda)
+        dx = torch.empty(n, n_in, device=cuda)
         ws = torch.zeros(nb // 8, dtype=torch.float64, device=cuda)
-        cb, dg, db = torch.empty(6, c, device=cuda), torch.empty(c, device=cuda), torch.empty(c, device=cuda)
-        bel = (P(yb1[:n]), P(gb), P(bb), P(mb), P(ib), int(relu), P(ws), nb, finish, P(cb), P(dg), P(db)) if below else \
+        cb, dg, db = torch.empty(6, n_in, device=cuda), torch.empty(n_in, device=cuda), torch.empty(n_in, device=cuda)
+        bel = (P(yb1), P(gb), P(bb), P(mb), P(ib), int(relu), P(ws), nb, finish, P(cb), P(dg), P(db)) if below else \
               (None, None, None, None, None, 0, None, 0, 0, None, None, None)
-        rc = L.pn2_linear_dgrad_fin(n, c, c, None, P(y1[:n]), P(dz1[:n]), P(coef), 1, 0, None, None, P(w), P(dx), *bel, st)
+        rc = L.pn2_linear_dgrad_fin(n, n_in, c, None, P(y1), P(dz1), P(coef), 1, pool, P(zmax), P(ties), P(w), P(dx), *bel, st)
         assert rc == 0, rc
         return dx, cb, dg, db
 
-    dx_tiled = run(rows + 1, 3 if below else 0)[0]
+    n_tiled = 65504
+    dx_tiled = run(n_tiled, 3 if below else 0)[0]
     for it in range(3):
         dx, cb, dg, db = run(rows, 3 if below else 0)
-        assert torch.equal(dx, dx_tiled[:rows]), it
+        assert torch.equal(dx[:n_tiled], dx_tiled), it
         if below:
-            ybd, dxd = yb1[:rows].double(), dx.double()
+            dxd = dx.double()
             sc = gb.double() * ib.double()
             sh = bb.double() - mb.double() * sc
-            on = (torch.addcmul(sh.float(), yb1[:rows], sc.float()) > 0) if relu else torch.ones_like(dx, dtype=torch.bool)
+            on = ((yb1.double() * sc + sh).float() > 0) if relu else torch.ones_like(dx, dtype=torch.bool)
             g = torch.where(on, dxd, torch.zeros_like(dxd))
-            xh = ((yb1[:rows] - mb) * ib).double()
+            xh = ((yb1 - mb) * ib).double()
             s1, s2 = g.sum(0), (g * xh).sum(0)
             tol = 1e-5 * float(g.abs().sum(0).max())
             assert float((db.double() - s1).abs().max()) <= tol and float((dg.double() - s2).abs().max()) <= tol, it
