@@ -63,12 +63,13 @@ def concurrent_streams(n, device=None, candidates=12, spin_cycles=300000, strict
         return time.perf_counter() - t0
 
     wall(cand[:1])  # first use of the spin kernel (module load)
-    t1 = min(wall(cand[:1]) for _ in range(3))
+    t1 = min(wall(cand[:1]) for _ in range(5))
     chosen = [cand[0]]
     for st in cand[1:]:
         if len(chosen) == n:
             break
-        if min(wall(chosen + [st]) for _ in range(3)) < 1.5 * t1:
+        # best of five (r06: best of three rejected a good stream once in three suite runs on a box still draining other work)
+        if min(wall(chosen + [st]) for _ in range(5)) < 1.5 * t1:
             chosen.append(st)
     verified = len(chosen)
     if verified < n and strict:

@@ -111,9 +111,15 @@ def test_concurrent_streams_run_side_by_side(pn2, cuda):
     mapping of the first streams of a process can serialise two of them: profiles/r05_scheduling_study.txt #8)"""
     import time
     import torch
-    streams, verified = pn2.runtime.concurrent_streams(4)
-    assert len(streams) == 4 and len({s.cuda_stream for s in streams}) == 4
-    assert verified == 4, verified  # an idle MI355X has at least four hardware queues; fewer = the probe (or the box) is off
+    # an idle MI355X has at least four hardware queues; the probe is a wall-clock measurement, so it gets three attempts on a box
+    # that may still be draining the previous test's work (one of them must confirm all four; every attempt returns four streams)
+    for attempt in range(3):
+        streams, verified = pn2.runtime.concurrent_streams(4)
+        assert len(streams) == 4 and len({s.cuda_stream for s in streams}) == 4
+        if verified == 4:
+            break
+        torch.cuda.synchronize()
+    assert verified == 4, verified
 
     def wall(ss, cycles=2000000):
         torch.cuda.synchronize()
