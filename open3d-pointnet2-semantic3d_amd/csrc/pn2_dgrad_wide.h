@@ -6,7 +6,7 @@
 //
 // The streaming form of pn2_fwd_narrow.h's fwd_wide_in_kernel: eight waves per workgroup (two per SIMD: one wave's transform,
 // loads of y_below, stores and sums run under the other's MFMAs), a wave owns 32-row tiles, the operand tile goes through the wave's
-// own LDS tile in two K-slices of 64 channels (loaded with coalesced 16-byte lanes one slice ahead), W^T sits in LDS in fragment
+// own LDS tile in K-slices of PN2_DGW_KS = 32 channels (loaded with coalesced 16-byte lanes one slice ahead), W^T sits in LDS in fragment
 // order, and the two gradient sums per column stay in registers (fp64) across the wave's tiles: one pair of atomics per column
 // and wave.  Same contraction order as linear_kernel, hence the same dx bits.
 #pragma once
