@@ -1280,6 +1280,10 @@ extern "C" int pn2_debug_set_linear(int what, int value) {
 #endif  // PN2_TUNING_HOOKS
 
 // dW = x^T . dy (see linear_wgrad_kernel): the training path's weight gradient.  dw (cin, cout) is overwritten.
+#ifndef PN2_WGRAD_MIN_CHUNK
+#define PN2_WGRAD_MIN_CHUNK 32   // fewest rows a wave of the weight-gradient kernel contracts (64 until r06: the few-row layers are
+                                // bound by their chain of dependent fetch rounds; 32: step 3.187 -> 3.161 ms, 16: the same)
+#endif
 static int linear_wgrad_impl(int rows, int cin, int cout, const float* x, const float* dy, float* dw, void* stream, bool accumulate,
                              const Pn2LoadTransform* xf = nullptr, const Pn2GradOnLoad* gx = nullptr) {
     if (rows <= 0 || cin <= 0 || cout <= 0) return PN2_EINVAL;
@@ -1305,7 +1309,7 @@ static int linear_wgrad_impl(int rows, int cin, int cout, const float* x, const 
     if (waves < 16) waves = 16;
     int chunk = (int)((rows + waves - 1) / waves);
     chunk = (chunk + 7) & ~7;
-    if (chunk < 64) chunk = 64;
+    if (chunk < PN2_WGRAD_MIN_CHUNK) chunk = PN2_WGRAD_MIN_CHUNK;
     const int nchunks = (rows + chunk - 1) / chunk;
     dim3 grid((nchunks + 3) / 4, gy, gz);
     if (wide8) {
